@@ -1,0 +1,176 @@
+/*
+ * include/hipbfv.h -- C ABI of libhipbfv.so, the MI355X-native BFV ciphertext-arithmetic backend.
+ *
+ * This is the drop-in boundary for the one hot path of the reference: everything that
+ * `seal_fhe::Evaluator` (seal_fhe/src/evaluator.rs:7-280) forwards to Microsoft SEAL's C API
+ * through bindgen.  Part 1 re-exports the SEAL C entry points that the `seal_fhe` crate binds for
+ * that path, with the same names, argument order, opaque `void*` handles and HRESULT return values,
+ * so that `seal_fhe/src/*.rs` can link against this library unchanged.
+ * Part 2 is the extension the reference API lacks: raw-array import/export for handles and the
+ * batched, device-pointer entry points used by the GPU batch executor.
+ *
+ * Conventions (seal_fhe/src/lib.rs:28-34, error.rs:65-91):
+ *   - every function returns a `long` HRESULT: S_OK = 0 on success;
+ *   - objects are opaque `void*` created through an out-parameter and destroyed by X_Destroy;
+ *   - `pool` arguments are accepted and ignored (the crate always passes NULL);
+ *   - in-place calls alias `destination` with an operand (evaluator_base.rs:107-113,184-196);
+ *   - all handle-level calls are synchronous and may be issued concurrently from several host
+ *     threads on one evaluator handle (sunscreen_runtime/src/run.rs:415-469).
+ * Ciphertext data layout: u64[size][K][N], K = data-level primes, N = poly degree
+ * (seal_fhe/src/plaintext_ciphertext.rs:303-314).  Key-switching key: u64[K][2][K+1][N], NTT form.
+ */
+#ifndef HIPBFV_H
+#define HIPBFV_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPBFV_S_OK 0L
+#define HIPBFV_E_POINTER ((long)0x80004003L)
+#define HIPBFV_E_INVALIDARG ((long)0x80070057L)
+#define HIPBFV_E_OUTOFMEMORY ((long)0x8007000EL)
+#define HIPBFV_E_UNEXPECTED ((long)0x8000FFFFL)
+#define HIPBFV_COR_E_IO ((long)0x80131620L)
+#define HIPBFV_COR_E_INVALIDOPERATION ((long)0x80131509L)
+
+/* ===================================================================================== */
+/* Part 1: SEAL C API subset bound by seal_fhe for the evaluator path                      */
+/* ===================================================================================== */
+
+/* ---- Modulus (seal_fhe/src/modulus.rs:225-262) ---- */
+long Modulus_Create1(uint64_t value, void **small_modulus);
+long Modulus_Create2(void *copy, void **small_modulus);
+long Modulus_Destroy(void *thisptr);
+long Modulus_Value(void *thisptr, uint64_t *result);
+
+/* ---- CoeffModulus helpers (seal_fhe/src/modulus.rs:149-205) ---- */
+long CoeffModulus_MaxBitCount(uint64_t poly_modulus_degree, int sec_level, int *bit_count);
+long CoeffModulus_BFVDefault(uint64_t poly_modulus_degree, int sec_level, uint64_t *length, void **coeffs);
+long CoeffModulus_Create1(uint64_t poly_modulus_degree, uint64_t length, int *bit_sizes, void **coeffs);
+/* PlainModulus::batching is CoeffModulus_Create1 with one entry (seal_fhe/src/modulus.rs:100-116) */
+
+/* ---- EncryptionParameters (seal_fhe/src/encryption_parameters.rs:100-330); scheme 1 = BFV ---- */
+long EncParams_Create1(uint8_t scheme, void **enc_params);
+long EncParams_Destroy(void *thisptr);
+long EncParams_SetPolyModulusDegree(void *thisptr, uint64_t degree);
+long EncParams_GetPolyModulusDegree(void *thisptr, uint64_t *degree);
+long EncParams_SetCoeffModulus(void *thisptr, uint64_t length, void **coeffs);
+long EncParams_GetCoeffModulus(void *thisptr, uint64_t *length, void **coeffs);
+long EncParams_SetPlainModulus1(void *thisptr, void *modulus);
+long EncParams_SetPlainModulus2(void *thisptr, uint64_t plain_modulus);
+long EncParams_GetPlainModulus(void *thisptr, void **plain_modulus);
+long EncParams_GetScheme(void *thisptr, uint8_t *scheme);
+
+/* ---- SEALContext (seal_fhe/src/context.rs:63-115); sec_level: 0 none, 128, 192, 256 ---- */
+long SEALContext_Create(void *encryption_params, bool expand_mod_chain, int sec_level, void **context);
+long SEALContext_Destroy(void *thisptr);
+
+/* ---- Plaintext (seal_fhe/src/plaintext_ciphertext.rs:36-300) ---- */
+long Plaintext_Create1(void *pool, void **plaintext);
+long Plaintext_Create5(void *copy, void **plaintext);
+long Plaintext_Destroy(void *thisptr);
+long Plaintext_CoeffCount(void *thisptr, uint64_t *coeff_count);
+long Plaintext_CoeffAt(void *thisptr, uint64_t index, uint64_t *coeff);
+long Plaintext_SetCoeffAt(void *thisptr, uint64_t index, uint64_t value);
+long Plaintext_Resize(void *thisptr, uint64_t coeff_count);
+long Plaintext_IsNTTForm(void *thisptr, bool *is_ntt_form);
+
+/* ---- Ciphertext (seal_fhe/src/plaintext_ciphertext.rs:326-504) ---- */
+long Ciphertext_Create1(void *pool, void **cipher);
+long Ciphertext_Create2(void *copy, void **cipher);
+long Ciphertext_Destroy(void *thisptr);
+long Ciphertext_Size(void *thisptr, uint64_t *size);
+long Ciphertext_CoeffModulusSize(void *thisptr, uint64_t *coeff_modulus_size);
+long Ciphertext_PolyModulusDegree(void *thisptr, uint64_t *poly_modulus_degree);
+long Ciphertext_GetDataAt1(void *thisptr, uint64_t index, uint64_t *data);
+long Ciphertext_GetDataAt2(void *thisptr, uint64_t poly_index, uint64_t coeff_index, uint64_t *data);
+long Ciphertext_IsNTTForm(void *thisptr, bool *is_ntt_form);
+
+/* ---- KSwitchKeys: RelinKeys and GaloisKeys (seal_fhe/src/key_generator.rs:467-729) ---- */
+long KSwitchKeys_Create1(void **kswitch_keys);
+long KSwitchKeys_Create2(void *copy, void **kswitch_keys);
+long KSwitchKeys_Destroy(void *thisptr);
+
+/* ---- Evaluator (seal_fhe/src/evaluator_base.rs:55-407, bfv_evaluator.rs:12-248) ---- */
+long Evaluator_Create(void *seal_context, void **evaluator);
+long Evaluator_Destroy(void *thisptr);
+long Evaluator_Negate(void *thisptr, void *encrypted, void *destination);
+long Evaluator_Add(void *thisptr, void *encrypted1, void *encrypted2, void *destination);
+long Evaluator_AddMany(void *thisptr, uint64_t count, void **encrypteds, void *destination);
+long Evaluator_Sub(void *thisptr, void *encrypted1, void *encrypted2, void *destination);
+long Evaluator_Multiply(void *thisptr, void *encrypted1, void *encrypted2, void *destination, void *pool);
+long Evaluator_MultiplyMany(void *thisptr, uint64_t count, void **encrypteds, void *relin_keys, void *destination, void *pool);
+long Evaluator_Square(void *thisptr, void *encrypted, void *destination, void *pool);
+long Evaluator_Relinearize(void *thisptr, void *encrypted, void *relin_keys, void *destination, void *pool);
+long Evaluator_Exponentiate(void *thisptr, void *encrypted, uint64_t exponent, void *relin_keys, void *destination, void *pool);
+long Evaluator_AddPlain(void *thisptr, void *encrypted, void *plain, void *destination);
+long Evaluator_SubPlain(void *thisptr, void *encrypted, void *plain, void *destination);
+long Evaluator_MultiplyPlain(void *thisptr, void *encrypted, void *plain, void *destination, void *pool);
+long Evaluator_RotateRows(void *thisptr, void *encrypted, int steps, void *galois_keys, void *destination, void *pool);
+long Evaluator_RotateColumns(void *thisptr, void *encrypted, void *galois_keys, void *destination, void *pool);
+
+/* ===================================================================================== */
+/* Part 2: hipbfv extensions                                                               */
+/* ===================================================================================== */
+
+/* Library / device */
+long hipbfv_version(uint32_t *major, uint32_t *minor);
+long hipbfv_last_error(char *buffer, uint64_t capacity);       /* thread-local message of the last failure */
+long hipbfv_set_device(int device);                            /* HIP device used by contexts created afterwards */
+/* SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT switch (seal_fhe `transparent-ciphertexts` feature): default on */
+long hipbfv_set_throw_on_transparent(bool enabled);
+
+/* Context shortcuts: build a context straight from raw parameters */
+long hipbfv_Context_Create(uint64_t poly_modulus_degree, const uint64_t *coeff_modulus, uint64_t coeff_count,
+                           uint64_t plain_modulus, void **context);
+long hipbfv_Context_Info(void *context, uint64_t *poly_modulus_degree, uint64_t *data_primes, uint64_t *key_primes,
+                         uint64_t *plain_modulus);
+long hipbfv_Context_GetPrime(void *context, uint64_t index, uint64_t *value); /* key-level prime `index` */
+
+/* Raw-array import/export for handles (host memory; stands in for X_Load/X_Save until the SEAL wire
+ * format lands -- SURVEY 8f row 2) */
+long hipbfv_Ciphertext_Assign(void *cipher, void *context, uint64_t size, const uint64_t *host_data);
+long hipbfv_Ciphertext_Export(void *cipher, uint64_t *host_data, uint64_t capacity_words);
+long hipbfv_Ciphertext_DevicePtr(void *cipher, uint64_t **device_ptr);
+long hipbfv_KSwitchKeys_AssignRelin(void *keys, void *context, const uint64_t *host_data);
+long hipbfv_KSwitchKeys_AssignGalois(void *keys, void *context, uint32_t galois_elt, const uint64_t *host_data);
+long hipbfv_KSwitchKeys_DevicePtr(void *keys, uint64_t index, uint64_t **device_ptr); /* index 0 = relin, (elt-1)/2 = galois */
+
+/* Batched entry points: device pointers, `count` independent ciphertexts u64[count][size][K][N],
+ * enqueued asynchronously on `stream` (a hipStream_t; NULL = default stream). */
+long hipbfv_batch_multiply(void *evaluator, const uint64_t *a, uint64_t size_a, const uint64_t *b, uint64_t size_b,
+                           uint64_t *out, uint64_t count, void *stream);
+long hipbfv_batch_relinearize(void *evaluator, const uint64_t *ct3, void *relin_keys, uint64_t *out2, uint64_t count,
+                              void *stream);
+long hipbfv_batch_multiply_relin(void *evaluator, const uint64_t *a, const uint64_t *b, void *relin_keys,
+                                 uint64_t *out2, uint64_t count, void *stream);
+long hipbfv_batch_apply_galois(void *evaluator, const uint64_t *ct2, uint32_t galois_elt, void *galois_keys,
+                               uint64_t *out2, uint64_t count, void *stream);
+long hipbfv_batch_rotate_rows(void *evaluator, const uint64_t *ct2, int steps, void *galois_keys, uint64_t *out2,
+                              uint64_t count, void *stream);
+long hipbfv_batch_rotate_columns(void *evaluator, const uint64_t *ct2, void *galois_keys, uint64_t *out2,
+                                 uint64_t count, void *stream);
+long hipbfv_batch_add(void *evaluator, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t size,
+                      uint64_t count, void *stream);
+long hipbfv_batch_sub(void *evaluator, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t size,
+                      uint64_t count, void *stream);
+long hipbfv_batch_negate(void *evaluator, const uint64_t *a, uint64_t *out, uint64_t size, uint64_t count, void *stream);
+/* plain: device u64[count][N] (plain_stride = N) or one shared plaintext (plain_stride = 0) */
+long hipbfv_batch_add_plain(void *evaluator, const uint64_t *ct, uint64_t size, const uint64_t *plain,
+                            uint64_t plain_stride, uint64_t *out, uint64_t count, void *stream);
+long hipbfv_batch_sub_plain(void *evaluator, const uint64_t *ct, uint64_t size, const uint64_t *plain,
+                            uint64_t plain_stride, uint64_t *out, uint64_t count, void *stream);
+long hipbfv_batch_multiply_plain(void *evaluator, const uint64_t *ct, uint64_t size, const uint64_t *plain,
+                                 uint64_t plain_stride, uint64_t *out, uint64_t count, void *stream);
+/* forward / inverse negacyclic NTT of u64[polys][N]; polynomial p uses key-level prime (p % nprimes) */
+long hipbfv_batch_ntt(void *evaluator, uint64_t *data, uint64_t polys, uint64_t nprimes, bool inverse, void *stream);
+long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPBFV_H */

@@ -1,0 +1,145 @@
+"""ctypes binding of include/hipbfv.h.
+
+There is deliberately no fallback: if libhipbfv.so is missing or fails to load, importing this
+module raises.  PyTorch (when present) is imported first so that both share one HIP runtime
+(torch bundles its own libamdhip64 with the same SONAME).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhipbfv.so")
+
+S_OK = 0
+E_POINTER = 0x80004003
+E_INVALIDARG = 0x80070057
+E_OUTOFMEMORY = 0x8007000E
+E_UNEXPECTED = 0x8000FFFF
+COR_E_IO = 0x80131620
+COR_E_INVALIDOPERATION = 0x80131509
+
+vp = C.c_void_p
+vpp = C.POINTER(C.c_void_p)
+u64 = C.c_uint64
+u64p = C.POINTER(C.c_uint64)
+
+# name -> argtypes; every function returns `long` (HRESULT)
+_SIGNATURES = {
+    "Modulus_Create1": [u64, vpp],
+    "Modulus_Create2": [vp, vpp],
+    "Modulus_Destroy": [vp],
+    "Modulus_Value": [vp, u64p],
+    "CoeffModulus_MaxBitCount": [u64, C.c_int, C.POINTER(C.c_int)],
+    "CoeffModulus_BFVDefault": [u64, C.c_int, u64p, vpp],
+    "CoeffModulus_Create1": [u64, u64, C.POINTER(C.c_int), vpp],
+    "EncParams_Create1": [C.c_uint8, vpp],
+    "EncParams_Destroy": [vp],
+    "EncParams_SetPolyModulusDegree": [vp, u64],
+    "EncParams_GetPolyModulusDegree": [vp, u64p],
+    "EncParams_SetCoeffModulus": [vp, u64, vpp],
+    "EncParams_GetCoeffModulus": [vp, u64p, vpp],
+    "EncParams_SetPlainModulus1": [vp, vp],
+    "EncParams_SetPlainModulus2": [vp, u64],
+    "EncParams_GetPlainModulus": [vp, vpp],
+    "EncParams_GetScheme": [vp, C.POINTER(C.c_uint8)],
+    "SEALContext_Create": [vp, C.c_bool, C.c_int, vpp],
+    "SEALContext_Destroy": [vp],
+    "Plaintext_Create1": [vp, vpp],
+    "Plaintext_Create5": [vp, vpp],
+    "Plaintext_Destroy": [vp],
+    "Plaintext_CoeffCount": [vp, u64p],
+    "Plaintext_CoeffAt": [vp, u64, u64p],
+    "Plaintext_SetCoeffAt": [vp, u64, u64],
+    "Plaintext_Resize": [vp, u64],
+    "Plaintext_IsNTTForm": [vp, C.POINTER(C.c_bool)],
+    "Ciphertext_Create1": [vp, vpp],
+    "Ciphertext_Create2": [vp, vpp],
+    "Ciphertext_Destroy": [vp],
+    "Ciphertext_Size": [vp, u64p],
+    "Ciphertext_CoeffModulusSize": [vp, u64p],
+    "Ciphertext_PolyModulusDegree": [vp, u64p],
+    "Ciphertext_GetDataAt1": [vp, u64, u64p],
+    "Ciphertext_GetDataAt2": [vp, u64, u64, u64p],
+    "Ciphertext_IsNTTForm": [vp, C.POINTER(C.c_bool)],
+    "KSwitchKeys_Create1": [vpp],
+    "KSwitchKeys_Create2": [vp, vpp],
+    "KSwitchKeys_Destroy": [vp],
+    "Evaluator_Create": [vp, vpp],
+    "Evaluator_Destroy": [vp],
+    "Evaluator_Negate": [vp, vp, vp],
+    "Evaluator_Add": [vp, vp, vp, vp],
+    "Evaluator_AddMany": [vp, u64, vpp, vp],
+    "Evaluator_Sub": [vp, vp, vp, vp],
+    "Evaluator_Multiply": [vp, vp, vp, vp, vp],
+    "Evaluator_MultiplyMany": [vp, u64, vpp, vp, vp, vp],
+    "Evaluator_Square": [vp, vp, vp, vp],
+    "Evaluator_Relinearize": [vp, vp, vp, vp, vp],
+    "Evaluator_Exponentiate": [vp, vp, u64, vp, vp, vp],
+    "Evaluator_AddPlain": [vp, vp, vp, vp],
+    "Evaluator_SubPlain": [vp, vp, vp, vp],
+    "Evaluator_MultiplyPlain": [vp, vp, vp, vp, vp],
+    "Evaluator_RotateRows": [vp, vp, C.c_int, vp, vp, vp],
+    "Evaluator_RotateColumns": [vp, vp, vp, vp, vp],
+    "hipbfv_version": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
+    "hipbfv_last_error": [C.c_char_p, u64],
+    "hipbfv_set_device": [C.c_int],
+    "hipbfv_set_throw_on_transparent": [C.c_bool],
+    "hipbfv_Context_Create": [u64, u64p, u64, u64, vpp],
+    "hipbfv_Context_Info": [vp, u64p, u64p, u64p, u64p],
+    "hipbfv_Context_GetPrime": [vp, u64, u64p],
+    "hipbfv_Ciphertext_Assign": [vp, vp, u64, u64p],
+    "hipbfv_Ciphertext_Export": [vp, u64p, u64],
+    "hipbfv_Ciphertext_DevicePtr": [vp, C.POINTER(u64p)],
+    "hipbfv_KSwitchKeys_AssignRelin": [vp, vp, u64p],
+    "hipbfv_KSwitchKeys_AssignGalois": [vp, vp, C.c_uint32, u64p],
+    "hipbfv_KSwitchKeys_DevicePtr": [vp, u64, C.POINTER(u64p)],
+    "hipbfv_batch_multiply": [vp, vp, u64, vp, u64, vp, u64, vp],
+    "hipbfv_batch_relinearize": [vp, vp, vp, vp, u64, vp],
+    "hipbfv_batch_multiply_relin": [vp, vp, vp, vp, vp, u64, vp],
+    "hipbfv_batch_apply_galois": [vp, vp, C.c_uint32, vp, vp, u64, vp],
+    "hipbfv_batch_rotate_rows": [vp, vp, C.c_int, vp, vp, u64, vp],
+    "hipbfv_batch_rotate_columns": [vp, vp, vp, vp, u64, vp],
+    "hipbfv_batch_add": [vp, vp, vp, vp, u64, u64, vp],
+    "hipbfv_batch_sub": [vp, vp, vp, vp, u64, u64, vp],
+    "hipbfv_batch_negate": [vp, vp, vp, u64, u64, vp],
+    "hipbfv_batch_add_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
+    "hipbfv_batch_sub_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
+    "hipbfv_batch_multiply_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
+    "hipbfv_batch_ntt": [vp, vp, u64, u64, C.c_bool, vp],
+    "hipbfv_set_chunk_ops": [vp, u64],
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libhipbfv.so (once).  Raises OSError if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C sunscreen_amd/csrc` -- there is no CPU fallback"
+        )
+    try:  # share torch's HIP runtime when torch is installed
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_long
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().hipbfv_last_error(buf, 512)
+    return buf.value.decode(errors="replace")

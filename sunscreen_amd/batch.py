@@ -1,0 +1,145 @@
+"""GPU batch executor: Evaluator operations over device-resident batches of ciphertexts.
+
+Replaces the reference's per-node dispatch (sunscreen_runtime/src/run.rs:160-341: one
+`evaluator.<op>()` FFI call and at least one allocation per graph node per ciphertext) with one
+sequence of kernel launches per operation over `count` independent ciphertexts.  Tensors are
+`torch.int64` CUDA tensors holding uint64 bit patterns, shape [count, size, K, N]; PyTorch is used
+only for device memory and streams -- all arithmetic happens in libhipbfv.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .seal import BFVEvaluator, Context, GaloisKeys, RelinearizationKeys, _check
+
+
+def to_device(a: np.ndarray, device: str = "cuda:0") -> torch.Tensor:
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+def _ptr(t: torch.Tensor):
+    assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class BatchEvaluator:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._ev = BFVEvaluator(ctx)
+        self._h = self._ev.get_handle()
+        self.n, self.K, self.KK = ctx.poly_modulus_degree, ctx.K, ctx.KK
+
+    def set_chunk_ops(self, chunk: int) -> None:
+        _check(_lib.load().hipbfv_set_chunk_ops(self._h, chunk))
+
+    def _shape_ok(self, t: torch.Tensor, size=None):
+        assert t.dim() == 4 and t.shape[2] == self.K and t.shape[3] == self.n, tuple(t.shape)
+        if size is not None:
+            assert t.shape[1] == size, tuple(t.shape)
+
+    def _new(self, count: int, size: int, like: torch.Tensor) -> torch.Tensor:
+        return torch.empty((count, size, self.K, self.n), dtype=torch.int64, device=like.device)
+
+    # ---- a1 / a2 ----
+    def multiply(self, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(a)
+        self._shape_ok(b)
+        count, sa, sb = a.shape[0], a.shape[1], b.shape[1]
+        assert b.shape[0] == count
+        out = out if out is not None else self._new(count, sa + sb - 1, a)
+        _check(_lib.load().hipbfv_batch_multiply(self._h, _ptr(a), sa, _ptr(b), sb, _ptr(out), count, _stream()))
+        return out
+
+    def relinearize(self, ct3: torch.Tensor, rk: RelinearizationKeys, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(ct3, 3)
+        out = out if out is not None else self._new(ct3.shape[0], 2, ct3)
+        _check(_lib.load().hipbfv_batch_relinearize(self._h, _ptr(ct3), rk.get_handle(), _ptr(out), ct3.shape[0], _stream()))
+        return out
+
+    def multiply_relin(self, a: torch.Tensor, b: torch.Tensor, rk: RelinearizationKeys, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(a, 2)
+        self._shape_ok(b, 2)
+        assert a.shape[0] == b.shape[0]
+        out = out if out is not None else self._new(a.shape[0], 2, a)
+        _check(_lib.load().hipbfv_batch_multiply_relin(self._h, _ptr(a), _ptr(b), rk.get_handle(), _ptr(out), a.shape[0], _stream()))
+        return out
+
+    # ---- a3 ----
+    def apply_galois(self, ct: torch.Tensor, galois_elt: int, gk: GaloisKeys, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(ct, 2)
+        out = out if out is not None else self._new(ct.shape[0], 2, ct)
+        _check(_lib.load().hipbfv_batch_apply_galois(self._h, _ptr(ct), galois_elt, gk.get_handle(), _ptr(out), ct.shape[0], _stream()))
+        return out
+
+    def rotate_rows(self, ct: torch.Tensor, steps: int, gk: GaloisKeys, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(ct, 2)
+        out = out if out is not None else self._new(ct.shape[0], 2, ct)
+        _check(_lib.load().hipbfv_batch_rotate_rows(self._h, _ptr(ct), steps, gk.get_handle(), _ptr(out), ct.shape[0], _stream()))
+        return out
+
+    def rotate_columns(self, ct: torch.Tensor, gk: GaloisKeys, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(ct, 2)
+        out = out if out is not None else self._new(ct.shape[0], 2, ct)
+        _check(_lib.load().hipbfv_batch_rotate_columns(self._h, _ptr(ct), gk.get_handle(), _ptr(out), ct.shape[0], _stream()))
+        return out
+
+    # ---- a5 ----
+    def add(self, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(a)
+        assert a.shape == b.shape
+        out = out if out is not None else torch.empty_like(a)
+        _check(_lib.load().hipbfv_batch_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.shape[1], a.shape[0], _stream()))
+        return out
+
+    def sub(self, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(a)
+        assert a.shape == b.shape
+        out = out if out is not None else torch.empty_like(a)
+        _check(_lib.load().hipbfv_batch_sub(self._h, _ptr(a), _ptr(b), _ptr(out), a.shape[1], a.shape[0], _stream()))
+        return out
+
+    def negate(self, a: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(a)
+        out = out if out is not None else torch.empty_like(a)
+        _check(_lib.load().hipbfv_batch_negate(self._h, _ptr(a), _ptr(out), a.shape[1], a.shape[0], _stream()))
+        return out
+
+    def _plain(self, fn, ct: torch.Tensor, plain: torch.Tensor, out):
+        self._shape_ok(ct)
+        assert plain.shape[-1] == self.n
+        stride = 0 if plain.dim() == 1 or plain.shape[0] == 1 else self.n
+        if stride:
+            assert plain.shape[0] == ct.shape[0]
+        out = out if out is not None else torch.empty_like(ct)
+        _check(fn(self._h, _ptr(ct), ct.shape[1], _ptr(plain), stride, _ptr(out), ct.shape[0], _stream()))
+        return out
+
+    def add_plain(self, ct, plain, out=None):
+        return self._plain(_lib.load().hipbfv_batch_add_plain, ct, plain, out)
+
+    def sub_plain(self, ct, plain, out=None):
+        return self._plain(_lib.load().hipbfv_batch_sub_plain, ct, plain, out)
+
+    # ---- a4 ----
+    def multiply_plain(self, ct, plain, out=None):
+        return self._plain(_lib.load().hipbfv_batch_multiply_plain, ct, plain, out)
+
+    # ---- a6: NTT entry points (BASELINE config 2) ----
+    def ntt(self, data: torch.Tensor, nprimes: int, inverse: bool = False) -> torch.Tensor:
+        """In-place negacyclic NTT of int64[polys, N]; polynomial p uses key-level prime p % nprimes."""
+        assert data.dim() == 2 and data.shape[1] == self.n
+        _check(_lib.load().hipbfv_batch_ntt(self._h, _ptr(data), data.shape[0], nprimes, inverse, _stream()))
+        return data

@@ -1,0 +1,1204 @@
+// sunscreen_amd/csrc/capi.cpp -- the C ABI declared in include/hipbfv.h.
+//
+// Part 1 implements the SEAL C entry points that seal_fhe binds for the evaluator path (names,
+// arity and HRESULT behaviour as used in seal_fhe/src/evaluator_base.rs:55-407,
+// bfv_evaluator.rs:12-248, plaintext_ciphertext.rs:36-504, context.rs:63-115, modulus.rs,
+// encryption_parameters.rs); Part 2 the batched device-pointer extension.
+#include "../../include/hipbfv.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "evaluator.hpp"
+
+using namespace hipbfv;
+
+namespace {
+
+thread_local std::string tls_error;
+int g_device = 0;
+bool g_throw_transparent = true;
+
+long fail(long hr, const char* msg) {
+  tls_error = msg ? msg : "";
+  return hr;
+}
+
+long from_status(int st) {
+  switch (st) {
+    case kOk: return HIPBFV_S_OK;
+    case kInvalidArg: return fail(HIPBFV_E_INVALIDARG, "invalid argument");
+    case kTransparent: return fail(HIPBFV_COR_E_INVALIDOPERATION, "result ciphertext is transparent");
+    case kNoKey: return fail(HIPBFV_E_INVALIDARG, "required key-switching key is not present");
+    case kOutOfMemory: return fail(HIPBFV_E_OUTOFMEMORY, "out of device memory");
+    case kUnsupported: return fail(HIPBFV_COR_E_INVALIDOPERATION, "unsupported parameters for the HIP path");
+    default: {
+      static thread_local char buf[160];
+      snprintf(buf, sizeof(buf), "HIP runtime error: %s", hipGetErrorString(hipGetLastError()));
+      return fail(HIPBFV_E_UNEXPECTED, buf);
+    }
+  }
+}
+
+enum Magic : uint32_t {
+  kMagicModulus = 0x4D4F4431,
+  kMagicParams = 0x50524D31,
+  kMagicContext = 0x43545831,
+  kMagicPlain = 0x504C4E31,
+  kMagicCipher = 0x43504831,
+  kMagicKeys = 0x4B535731,
+  kMagicEval = 0x45564C31,
+};
+
+struct Obj {
+  uint32_t magic;
+  explicit Obj(uint32_t m) : magic(m) {}
+  virtual ~Obj() { magic = 0; }
+};
+
+template <typename T>
+T* as(void* p, uint32_t magic) {
+  if (!p) return nullptr;
+  Obj* o = static_cast<Obj*>(p);
+  return o->magic == magic ? static_cast<T*>(o) : nullptr;
+}
+
+struct ModulusObj : Obj {
+  u64 value;
+  explicit ModulusObj(u64 v) : Obj(kMagicModulus), value(v) {}
+};
+
+struct ParamsObj : Obj {
+  uint8_t scheme = 1;
+  u64 n = 0;
+  std::vector<u64> coeff;
+  u64 plain = 0;
+  ParamsObj() : Obj(kMagicParams) {}
+};
+
+struct ContextObj : Obj {
+  std::shared_ptr<Context> ctx;
+  ContextObj() : Obj(kMagicContext) {}
+};
+
+struct PlainObj : Obj {
+  std::vector<u64> coeffs;
+  PlainObj() : Obj(kMagicPlain) {}
+};
+
+// Device buffers for ciphertexts are recycled: hipFree synchronises the whole device, which would
+// serialise concurrent evaluator threads (sunscreen_runtime/src/run.rs:415-469 calls from a rayon pool).
+class BufferCache {
+ public:
+  u64* get(size_t words) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto it = free_.find(words);
+      if (it != free_.end() && !it->second.empty()) {
+        u64* p = it->second.back();
+        it->second.pop_back();
+        return p;
+      }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, words * sizeof(u64)) != hipSuccess) {
+      drain();
+      if (hipMalloc(&p, words * sizeof(u64)) != hipSuccess) return nullptr;
+    }
+    return (u64*)p;
+  }
+  void put(u64* p, size_t words) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu_);
+    free_[words].push_back(p);
+  }
+  void drain() {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto& kv : free_)
+      for (u64* p : kv.second) (void)hipFree(p);
+    free_.clear();
+  }
+
+ private:
+  std::mutex mu_;
+  std::map<size_t, std::vector<u64*>> free_;
+};
+BufferCache g_buffers;
+
+struct CipherObj : Obj {
+  std::shared_ptr<Context> ctx;
+  u32 size = 0;
+  u64* dev = nullptr;
+  size_t words = 0;
+  std::vector<u64> host;  // lazily filled host mirror for GetDataAt
+  bool host_valid = false;
+  CipherObj() : Obj(kMagicCipher) {}
+  ~CipherObj() override { g_buffers.put(dev, words); }
+  void adopt(const std::shared_ptr<Context>& c, u32 sz, u64* buf, size_t w) {
+    if (dev && dev != buf) g_buffers.put(dev, words);
+    ctx = c;
+    size = sz;
+    dev = buf;
+    words = w;
+    host_valid = false;
+  }
+};
+
+struct KeysObj : Obj {
+  std::shared_ptr<Context> ctx;
+  std::map<u32, u64*> keys;  // index -> device key u64[K][2][K+1][N]
+  KeysObj() : Obj(kMagicKeys) {}
+  ~KeysObj() override {
+    for (auto& kv : keys) g_buffers.put(kv.second, ctx ? ctx->key_words() : 0);
+  }
+  const u64* find(u32 index) const {
+    auto it = keys.find(index);
+    return it == keys.end() ? nullptr : it->second;
+  }
+};
+
+struct EvalObj : Obj {
+  std::shared_ptr<Context> ctx;
+  std::unique_ptr<Evaluator> ev;
+  EvalObj() : Obj(kMagicEval) {}
+};
+
+// one non-blocking stream per host thread: concurrent handle-level calls do not serialise on the null stream
+hipStream_t thread_stream() {
+  thread_local hipStream_t s = nullptr;
+  if (!s) (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  return s;
+}
+
+long sync_stream(hipStream_t s) {
+  if (hipStreamSynchronize(s) != hipSuccess) return from_status(kHipError);
+  return HIPBFV_S_OK;
+}
+
+bool same_context(const CipherObj* a, const EvalObj* e) { return a->ctx && a->ctx.get() == e->ctx.get() && a->dev && a->size >= 2; }
+
+// transparent check of the finished result (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT); stream already holds the op
+long finish_result(EvalObj* e, CipherObj* dst, u32 size, u64* buf, size_t words, hipStream_t s, bool check_transparent) {
+  u32 flag = 1;
+  if (check_transparent && g_throw_transparent) {
+    u32* dflag = (u32*)g_buffers.get(1);
+    if (!dflag) {
+      g_buffers.put(buf, words);
+      return from_status(kOutOfMemory);
+    }
+    (void)hipMemsetAsync(dflag, 0, sizeof(u32), s);
+    int st = e->ev->nonzero_tail(buf, size, dflag, 1, s);
+    if (st == kOk && hipMemcpyAsync(&flag, dflag, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) st = kHipError;
+    long hr = st == kOk ? sync_stream(s) : from_status(st);
+    g_buffers.put((u64*)dflag, 1);
+    if (hr != HIPBFV_S_OK) {
+      g_buffers.put(buf, words);
+      return hr;
+    }
+  } else {
+    long hr = sync_stream(s);
+    if (hr != HIPBFV_S_OK) {
+      g_buffers.put(buf, words);
+      return hr;
+    }
+  }
+  if (!flag) {
+    g_buffers.put(buf, words);
+    return from_status(kTransparent);
+  }
+  dst->adopt(e->ctx, size, buf, words);
+  return HIPBFV_S_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ library
+long hipbfv_version(uint32_t* major, uint32_t* minor) {
+  if (!major || !minor) return HIPBFV_E_POINTER;
+  *major = 0;
+  *minor = 1;
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_last_error(char* buffer, uint64_t capacity) {
+  if (!buffer || capacity == 0) return HIPBFV_E_POINTER;
+  std::strncpy(buffer, tls_error.c_str(), capacity - 1);
+  buffer[capacity - 1] = 0;
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_set_device(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return fail(HIPBFV_E_INVALIDARG, "no such HIP device");
+  g_device = device;
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_set_throw_on_transparent(bool enabled) {
+  g_throw_transparent = enabled;
+  return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ Modulus
+long Modulus_Create1(uint64_t value, void** out) {
+  if (!out) return HIPBFV_E_POINTER;
+  if (value == 1 || (value >> 61)) return fail(HIPBFV_E_INVALIDARG, "modulus must be 0 or in [2, 2^61)");
+  *out = new ModulusObj(value);
+  return HIPBFV_S_OK;
+}
+
+long Modulus_Create2(void* copy, void** out) {
+  ModulusObj* m = as<ModulusObj>(copy, kMagicModulus);
+  if (!m || !out) return HIPBFV_E_POINTER;
+  *out = new ModulusObj(m->value);
+  return HIPBFV_S_OK;
+}
+
+long Modulus_Destroy(void* p) {
+  ModulusObj* m = as<ModulusObj>(p, kMagicModulus);
+  if (!m) return HIPBFV_E_POINTER;
+  delete m;
+  return HIPBFV_S_OK;
+}
+
+long Modulus_Value(void* p, uint64_t* result) {
+  ModulusObj* m = as<ModulusObj>(p, kMagicModulus);
+  if (!m || !result) return HIPBFV_E_POINTER;
+  *result = m->value;
+  return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ CoeffModulus
+long CoeffModulus_MaxBitCount(uint64_t n, int sec, int* bit_count) {
+  if (!bit_count) return HIPBFV_E_POINTER;
+  *bit_count = max_coeff_bit_count(n, sec);
+  return *bit_count ? HIPBFV_S_OK : fail(HIPBFV_E_INVALIDARG, "unsupported degree / security level");
+}
+
+long CoeffModulus_BFVDefault(uint64_t n, int sec, uint64_t* length, void** coeffs) {
+  if (!length) return HIPBFV_E_POINTER;
+  std::vector<u64> p = default_coeff_modulus(n, sec);
+  if (p.empty()) return fail(HIPBFV_E_INVALIDARG, "no default coefficient modulus for these parameters");
+  *length = p.size();
+  if (!coeffs) return HIPBFV_S_OK;  // SEAL convention: first call queries the length
+  for (size_t i = 0; i < p.size(); i++) coeffs[i] = new ModulusObj(p[i]);
+  return HIPBFV_S_OK;
+}
+
+long CoeffModulus_Create1(uint64_t n, uint64_t length, int* bit_sizes, void** coeffs) {
+  if (!bit_sizes || !coeffs) return HIPBFV_E_POINTER;
+  if (n < 2 || (n & (n - 1)) || length == 0 || length > 64) return fail(HIPBFV_E_INVALIDARG, "invalid degree or length");
+  // per distinct bit size: take the needed count from the descending prime list, hand out smallest first
+  std::vector<u64> result(length, 0);
+  std::vector<bool> done(length, false);
+  for (uint64_t i = 0; i < length; i++) {
+    if (done[i]) continue;
+    if (bit_sizes[i] < 2 || bit_sizes[i] > 60) return fail(HIPBFV_E_INVALIDARG, "bit sizes must be in [2, 60]");
+    size_t need = 0;
+    for (uint64_t j = i; j < length; j++) need += bit_sizes[j] == bit_sizes[i];
+    std::vector<u64> primes = find_primes(2 * n, bit_sizes[i], need);
+    if (primes.size() != need) return fail(HIPBFV_E_INVALIDARG, "failed to find enough qualifying primes");
+    for (uint64_t j = i; j < length; j++) {
+      if (bit_sizes[j] == bit_sizes[i]) {
+        result[j] = primes.back();
+        primes.pop_back();
+        done[j] = true;
+      }
+    }
+  }
+  for (uint64_t i = 0; i < length; i++) coeffs[i] = new ModulusObj(result[i]);
+  return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ EncryptionParameters
+long EncParams_Create1(uint8_t scheme, void** out) {
+  if (!out) return HIPBFV_E_POINTER;
+  if (scheme != 1) return fail(HIPBFV_E_INVALIDARG, "only the BFV scheme (1) is supported");
+  ParamsObj* p = new ParamsObj();
+  p->scheme = scheme;
+  *out = p;
+  return HIPBFV_S_OK;
+}
+
+long EncParams_Destroy(void* h) {
+  ParamsObj* p = as<ParamsObj>(h, kMagicParams);
+  if (!p) return HIPBFV_E_POINTER;
+  delete p;
+  return HIPBFV_S_OK;
+}
+
+long EncParams_SetPolyModulusDegree(void* h, uint64_t degree) {
+  ParamsObj* p = as<ParamsObj>(h, kMagicParams);
+  if (!p) return HIPBFV_E_POINTER;
+  p->n = degree;
+  return HIPBFV_S_OK;
+}
+
+long EncParams_GetPolyModulusDegree(void* h, uint64_t* degree) {
+  ParamsObj* p = as<ParamsObj>(h, kMagicParams);
+  if (!p || !degree) return HIPBFV_E_POINTER;
+  *degree = p->n;
+  return HIPBFV_S_OK;
+}
+
+long EncParams_SetCoeffModulus(void* h, uint64_t length, void** coeffs) {
+  ParamsObj* p = as<ParamsObj>(h, kMagicParams);
+  if (!p || !coeffs) return HIPBFV_E_POINTER;
+  std::vector<u64> v;
+  for (uint64_t i = 0; i < length; i++) {
+    ModulusObj* m = as<ModulusObj>(coeffs[i], kMagicModulus);
+    if (!m) return HIPBFV_E_POINTER;
+    v.push_back(m->value);
+  }
+  p->coeff = v;
+  return HIPBFV_S_OK;
+}
+
+long EncParams_GetCoeffModulus(void* h, uint64_t* length, void** coeffs) {
+  ParamsObj* p = as<ParamsObj>(h, kMagicParams);
+  if (!p || !length) return HIPBFV_E_POINTER;
+  *length = p->coeff.size();
+  if (!coeffs) return HIPBFV_S_OK;
+  for (size_t i = 0; i < p->coeff.size(); i++) coeffs[i] = new ModulusObj(p->coeff[i]);
+  return HIPBFV_S_OK;
+}
+
+long EncParams_SetPlainModulus1(void* h, void* modulus) {
+  ParamsObj* p = as<ParamsObj>(h, kMagicParams);
+  ModulusObj* m = as<ModulusObj>(modulus, kMagicModulus);
+  if (!p || !m) return HIPBFV_E_POINTER;
+  p->plain = m->value;
+  return HIPBFV_S_OK;
+}
+
+long EncParams_SetPlainModulus2(void* h, uint64_t plain) {
+  ParamsObj* p = as<ParamsObj>(h, kMagicParams);
+  if (!p) return HIPBFV_E_POINTER;
+  p->plain = plain;
+  return HIPBFV_S_OK;
+}
+
+long EncParams_GetPlainModulus(void* h, void** modulus) {
+  ParamsObj* p = as<ParamsObj>(h, kMagicParams);
+  if (!p || !modulus) return HIPBFV_E_POINTER;
+  *modulus = new ModulusObj(p->plain);
+  return HIPBFV_S_OK;
+}
+
+long EncParams_GetScheme(void* h, uint8_t* scheme) {
+  ParamsObj* p = as<ParamsObj>(h, kMagicParams);
+  if (!p || !scheme) return HIPBFV_E_POINTER;
+  *scheme = p->scheme;
+  return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ SEALContext
+static long make_context(u64 n, const std::vector<u64>& coeff, u64 plain, int sec, void** out) {
+  if (sec != 0) {
+    const int maxbits = max_coeff_bit_count(n, sec);
+    int total = 0;
+    for (u64 q : coeff) total += 64 - __builtin_clzll(q | 1);
+    if (!maxbits || total > maxbits) return fail(HIPBFV_E_INVALIDARG, "parameters do not meet the requested security level");
+  }
+  std::string err;
+  Context* c = Context::create((u32)n, coeff, plain, g_device, &err);
+  if (!c) return fail(HIPBFV_E_INVALIDARG, err.c_str());
+  ContextObj* o = new ContextObj();
+  o->ctx.reset(c);
+  *out = o;
+  return HIPBFV_S_OK;
+}
+
+long SEALContext_Create(void* params, bool expand_mod_chain, int sec_level, void** context) {
+  (void)expand_mod_chain;  // the evaluator path never mod-switches (sunscreen_fhe_program/src/operation.rs:12-94)
+  ParamsObj* p = as<ParamsObj>(params, kMagicParams);
+  if (!p || !context) return HIPBFV_E_POINTER;
+  if (p->n > 0xFFFFFFFFull) return fail(HIPBFV_E_INVALIDARG, "invalid degree");
+  return make_context(p->n, p->coeff, p->plain, sec_level, context);
+}
+
+long SEALContext_Destroy(void* h) {
+  ContextObj* c = as<ContextObj>(h, kMagicContext);
+  if (!c) return HIPBFV_E_POINTER;
+  delete c;
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Context_Create(uint64_t n, const uint64_t* coeff, uint64_t count, uint64_t plain, void** context) {
+  if (!coeff || !context) return HIPBFV_E_POINTER;
+  if (n > 0xFFFFFFFFull) return fail(HIPBFV_E_INVALIDARG, "invalid degree");
+  return make_context(n, std::vector<u64>(coeff, coeff + count), plain, 0, context);
+}
+
+long hipbfv_Context_Info(void* h, uint64_t* n, uint64_t* K, uint64_t* KK, uint64_t* t) {
+  ContextObj* c = as<ContextObj>(h, kMagicContext);
+  if (!c) return HIPBFV_E_POINTER;
+  if (n) *n = c->ctx->n();
+  if (K) *K = c->ctx->K();
+  if (KK) *KK = c->ctx->KK();
+  if (t) *t = c->ctx->t();
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Context_GetPrime(void* h, uint64_t index, uint64_t* value) {
+  ContextObj* c = as<ContextObj>(h, kMagicContext);
+  if (!c || !value) return HIPBFV_E_POINTER;
+  if (index >= c->ctx->key_primes().size()) return fail(HIPBFV_E_INVALIDARG, "prime index out of range");
+  *value = c->ctx->key_primes()[index];
+  return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ Plaintext
+long Plaintext_Create1(void* pool, void** out) {
+  (void)pool;
+  if (!out) return HIPBFV_E_POINTER;
+  *out = new PlainObj();
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_Create5(void* copy, void** out) {
+  PlainObj* p = as<PlainObj>(copy, kMagicPlain);
+  if (!p || !out) return HIPBFV_E_POINTER;
+  PlainObj* n = new PlainObj();
+  n->coeffs = p->coeffs;
+  *out = n;
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_Destroy(void* h) {
+  PlainObj* p = as<PlainObj>(h, kMagicPlain);
+  if (!p) return HIPBFV_E_POINTER;
+  delete p;
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_CoeffCount(void* h, uint64_t* count) {
+  PlainObj* p = as<PlainObj>(h, kMagicPlain);
+  if (!p || !count) return HIPBFV_E_POINTER;
+  *count = p->coeffs.size();
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_CoeffAt(void* h, uint64_t index, uint64_t* coeff) {
+  PlainObj* p = as<PlainObj>(h, kMagicPlain);
+  if (!p || !coeff) return HIPBFV_E_POINTER;
+  if (index >= p->coeffs.size()) return fail(HIPBFV_E_INVALIDARG, "coefficient index out of range");
+  *coeff = p->coeffs[index];
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_SetCoeffAt(void* h, uint64_t index, uint64_t value) {
+  PlainObj* p = as<PlainObj>(h, kMagicPlain);
+  if (!p) return HIPBFV_E_POINTER;
+  if (index >= p->coeffs.size()) return fail(HIPBFV_E_INVALIDARG, "coefficient index out of range");
+  p->coeffs[index] = value;
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_Resize(void* h, uint64_t count) {
+  PlainObj* p = as<PlainObj>(h, kMagicPlain);
+  if (!p) return HIPBFV_E_POINTER;
+  if (count > (1u << 20)) return fail(HIPBFV_E_INVALIDARG, "plaintext too large");
+  p->coeffs.resize(count, 0);
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_IsNTTForm(void* h, bool* is_ntt) {
+  PlainObj* p = as<PlainObj>(h, kMagicPlain);
+  if (!p || !is_ntt) return HIPBFV_E_POINTER;
+  *is_ntt = false;
+  return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ Ciphertext
+long Ciphertext_Create1(void* pool, void** out) {
+  (void)pool;
+  if (!out) return HIPBFV_E_POINTER;
+  *out = new CipherObj();
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_Create2(void* copy, void** out) {
+  CipherObj* c = as<CipherObj>(copy, kMagicCipher);
+  if (!c || !out) return HIPBFV_E_POINTER;
+  CipherObj* n = new CipherObj();
+  if (c->dev) {
+    u64* buf = g_buffers.get(c->words);
+    if (!buf) {
+      delete n;
+      return from_status(kOutOfMemory);
+    }
+    if (hipMemcpy(buf, c->dev, c->words * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+      g_buffers.put(buf, c->words);
+      delete n;
+      return from_status(kHipError);
+    }
+    n->adopt(c->ctx, c->size, buf, c->words);
+  }
+  *out = n;
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_Destroy(void* h) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c) return HIPBFV_E_POINTER;
+  delete c;
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_Size(void* h, uint64_t* size) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !size) return HIPBFV_E_POINTER;
+  *size = c->size;
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_CoeffModulusSize(void* h, uint64_t* k) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !k) return HIPBFV_E_POINTER;
+  *k = c->ctx ? c->ctx->K() : 0;
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_PolyModulusDegree(void* h, uint64_t* n) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !n) return HIPBFV_E_POINTER;
+  *n = c->ctx ? c->ctx->n() : 0;
+  return HIPBFV_S_OK;
+}
+
+static long ensure_host(CipherObj* c) {
+  if (c->host_valid) return HIPBFV_S_OK;
+  c->host.resize(c->words);
+  if (c->words && hipMemcpy(c->host.data(), c->dev, c->words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess)
+    return from_status(kHipError);
+  c->host_valid = true;
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_GetDataAt1(void* h, uint64_t index, uint64_t* data) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !data) return HIPBFV_E_POINTER;
+  if (index >= c->words) return fail(HIPBFV_E_INVALIDARG, "index out of range");
+  long hr = ensure_host(c);
+  if (hr != HIPBFV_S_OK) return hr;
+  *data = c->host[index];
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_GetDataAt2(void* h, uint64_t poly_index, uint64_t coeff_index, uint64_t* data) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !data) return HIPBFV_E_POINTER;
+  if (!c->ctx || poly_index >= c->size || coeff_index >= c->ctx->n()) return fail(HIPBFV_E_INVALIDARG, "index out of range");
+  long hr = ensure_host(c);
+  if (hr != HIPBFV_S_OK) return hr;
+  const size_t K = c->ctx->K(), n = c->ctx->n();
+  for (size_t i = 0; i < K; i++) data[i] = c->host[(poly_index * K + i) * n + coeff_index];
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_IsNTTForm(void* h, bool* is_ntt) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !is_ntt) return HIPBFV_E_POINTER;
+  *is_ntt = false;  // BFV ciphertexts stay in coefficient form between operations (evaluator_base.rs:46-53)
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Ciphertext_Assign(void* h, void* context, uint64_t size, const uint64_t* host_data) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!c || !x || !host_data) return HIPBFV_E_POINTER;
+  if (size < 2 || size > 16) return fail(HIPBFV_E_INVALIDARG, "ciphertext size must be in [2, 16]");
+  const size_t words = x->ctx->ct_words(size);
+  const size_t K = x->ctx->K(), n = x->ctx->n();
+  for (size_t p = 0; p < size * K; p++) {
+    const u64 q = x->ctx->key_primes()[p % K];
+    for (size_t k = 0; k < n; k++)
+      if (host_data[p * n + k] >= q) return fail(HIPBFV_E_INVALIDARG, "ciphertext coefficient is not reduced modulo its prime");
+  }
+  u64* buf = g_buffers.get(words);
+  if (!buf) return from_status(kOutOfMemory);
+  if (hipMemcpy(buf, host_data, words * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) {
+    g_buffers.put(buf, words);
+    return from_status(kHipError);
+  }
+  c->adopt(x->ctx, (u32)size, buf, words);
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Ciphertext_Export(void* h, uint64_t* host_data, uint64_t capacity_words) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !host_data) return HIPBFV_E_POINTER;
+  if (capacity_words < c->words) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
+  if (c->words && hipMemcpy(host_data, c->dev, c->words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess)
+    return from_status(kHipError);
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Ciphertext_DevicePtr(void* h, uint64_t** device_ptr) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !device_ptr) return HIPBFV_E_POINTER;
+  *device_ptr = (uint64_t*)c->dev;
+  return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ KSwitchKeys
+long KSwitchKeys_Create1(void** out) {
+  if (!out) return HIPBFV_E_POINTER;
+  *out = new KeysObj();
+  return HIPBFV_S_OK;
+}
+
+long KSwitchKeys_Create2(void* copy, void** out) {
+  KeysObj* k = as<KeysObj>(copy, kMagicKeys);
+  if (!k || !out) return HIPBFV_E_POINTER;
+  KeysObj* n = new KeysObj();
+  n->ctx = k->ctx;
+  for (auto& kv : k->keys) {
+    u64* buf = g_buffers.get(k->ctx->key_words());
+    if (!buf || hipMemcpy(buf, kv.second, k->ctx->key_words() * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+      if (buf) g_buffers.put(buf, k->ctx->key_words());
+      delete n;
+      return from_status(buf ? kHipError : kOutOfMemory);
+    }
+    n->keys[kv.first] = buf;
+  }
+  *out = n;
+  return HIPBFV_S_OK;
+}
+
+long KSwitchKeys_Destroy(void* h) {
+  KeysObj* k = as<KeysObj>(h, kMagicKeys);
+  if (!k) return HIPBFV_E_POINTER;
+  delete k;
+  return HIPBFV_S_OK;
+}
+
+static long assign_key(KeysObj* k, ContextObj* x, u32 index, const uint64_t* host_data) {
+  if (x->ctx->KK() < 2) return fail(HIPBFV_E_INVALIDARG, "these parameters do not support key switching");
+  if (k->ctx && k->ctx.get() != x->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "keys belong to a different context");
+  const size_t words = x->ctx->key_words();
+  const size_t KK = x->ctx->KK(), n = x->ctx->n();
+  for (size_t p = 0; p < words / n; p++) {
+    const u64 q = x->ctx->key_primes()[p % KK];
+    for (size_t i = 0; i < n; i++)
+      if (host_data[p * n + i] >= q) return fail(HIPBFV_E_INVALIDARG, "key coefficient is not reduced modulo its prime");
+  }
+  u64* buf = g_buffers.get(words);
+  if (!buf) return from_status(kOutOfMemory);
+  if (hipMemcpy(buf, host_data, words * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) {
+    g_buffers.put(buf, words);
+    return from_status(kHipError);
+  }
+  k->ctx = x->ctx;
+  auto it = k->keys.find(index);
+  if (it != k->keys.end()) g_buffers.put(it->second, words);
+  k->keys[index] = buf;
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_KSwitchKeys_AssignRelin(void* h, void* context, const uint64_t* host_data) {
+  KeysObj* k = as<KeysObj>(h, kMagicKeys);
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!k || !x || !host_data) return HIPBFV_E_POINTER;
+  return assign_key(k, x, 0, host_data);
+}
+
+long hipbfv_KSwitchKeys_AssignGalois(void* h, void* context, uint32_t elt, const uint64_t* host_data) {
+  KeysObj* k = as<KeysObj>(h, kMagicKeys);
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!k || !x || !host_data) return HIPBFV_E_POINTER;
+  if (!(elt & 1) || elt >= 2 * x->ctx->n()) return fail(HIPBFV_E_INVALIDARG, "invalid Galois element");
+  return assign_key(k, x, (elt - 1) >> 1, host_data);
+}
+
+long hipbfv_KSwitchKeys_DevicePtr(void* h, uint64_t index, uint64_t** device_ptr) {
+  KeysObj* k = as<KeysObj>(h, kMagicKeys);
+  if (!k || !device_ptr) return HIPBFV_E_POINTER;
+  *device_ptr = (uint64_t*)k->find((u32)index);
+  return *device_ptr ? HIPBFV_S_OK : fail(HIPBFV_E_INVALIDARG, "key not present");
+}
+
+// ------------------------------------------------------------------ Evaluator (handle level, synchronous)
+long Evaluator_Create(void* context, void** out) {
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!x || !out) return HIPBFV_E_POINTER;
+  EvalObj* e = new EvalObj();
+  e->ctx = x->ctx;
+  e->ev.reset(new Evaluator(x->ctx.get()));
+  *out = e;
+  return HIPBFV_S_OK;
+}
+
+long Evaluator_Destroy(void* h) {
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  if (!e) return HIPBFV_E_POINTER;
+  delete e;
+  return HIPBFV_S_OK;
+}
+
+long Evaluator_Negate(void* h, void* a, void* dst) {
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
+  if (!e || !x || !d) return HIPBFV_E_POINTER;
+  if (!same_context(x, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  hipStream_t s = thread_stream();
+  u64* buf = g_buffers.get(x->words);
+  if (!buf) return from_status(kOutOfMemory);
+  int st = e->ev->negate(x->dev, buf, x->size, 1, s);
+  if (st) {
+    g_buffers.put(buf, x->words);
+    return from_status(st);
+  }
+  return finish_result(e, d, x->size, buf, x->words, s, false);
+}
+
+// add/sub with SEAL's size rule: the result has max(size) polynomials; extra ones are copied (negated for sub)
+static long add_sub(void* h, void* a, void* b, void* dst, bool sub) {
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  CipherObj *x = as<CipherObj>(a, kMagicCipher), *y = as<CipherObj>(b, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
+  if (!e || !x || !y || !d) return HIPBFV_E_POINTER;
+  if (!same_context(x, e) || !same_context(y, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  hipStream_t s = thread_stream();
+  const u32 smax = std::max(x->size, y->size), smin = std::min(x->size, y->size);
+  const size_t words = e->ctx->ct_words(smax), common = e->ctx->ct_words(smin);
+  u64* buf = g_buffers.get(words);
+  if (!buf) return from_status(kOutOfMemory);
+  int st = sub ? e->ev->sub(x->dev, y->dev, buf, smin, 1, s) : e->ev->add(x->dev, y->dev, buf, smin, 1, s);
+  if (st == kOk && smax > smin) {
+    const CipherObj* big = x->size > y->size ? x : y;
+    if (sub && big == y)  // negate the extra polynomials of the subtrahend
+      st = e->ev->negate(y->dev + common, buf + common, smax - smin, 1, s);
+    else if (hipMemcpyAsync(buf + common, big->dev + common, (words - common) * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess)
+      st = kHipError;
+  }
+  if (st) {
+    g_buffers.put(buf, words);
+    return from_status(st);
+  }
+  return finish_result(e, d, smax, buf, words, s, true);
+}
+
+long Evaluator_Add(void* h, void* a, void* b, void* dst) { return add_sub(h, a, b, dst, false); }
+long Evaluator_Sub(void* h, void* a, void* b, void* dst) { return add_sub(h, a, b, dst, true); }
+
+long Evaluator_AddMany(void* h, uint64_t count, void** cts, void* dst) {
+  if (!cts) return HIPBFV_E_POINTER;
+  if (count == 0) return fail(HIPBFV_E_INVALIDARG, "encrypteds cannot be empty");
+  void* acc = nullptr;
+  long hr = Ciphertext_Create2(cts[0], &acc);
+  if (hr != HIPBFV_S_OK) return hr;
+  for (uint64_t i = 1; i < count && hr == HIPBFV_S_OK; i++) hr = Evaluator_Add(h, acc, cts[i], acc);
+  if (hr == HIPBFV_S_OK) {
+    CipherObj *a = as<CipherObj>(acc, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
+    if (!d)
+      hr = HIPBFV_E_POINTER;
+    else {
+      u64* buf = a->dev;
+      const size_t w = a->words;
+      a->dev = nullptr;
+      a->words = 0;
+      d->adopt(a->ctx, a->size, buf, w);
+    }
+  }
+  Ciphertext_Destroy(acc);
+  return hr;
+}
+
+long Evaluator_Multiply(void* h, void* a, void* b, void* dst, void* pool) {
+  (void)pool;
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  CipherObj *x = as<CipherObj>(a, kMagicCipher), *y = as<CipherObj>(b, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
+  if (!e || !x || !y || !d) return HIPBFV_E_POINTER;
+  if (!same_context(x, e) || !same_context(y, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  hipStream_t s = thread_stream();
+  const u32 sd = x->size + y->size - 1;
+  const size_t words = e->ctx->ct_words(sd);
+  u64* buf = g_buffers.get(words);
+  if (!buf) return from_status(kOutOfMemory);
+  int st = e->ev->multiply(x->dev, x->size, y->dev, y->size, buf, 1, s);
+  if (st) {
+    g_buffers.put(buf, words);
+    return from_status(st);
+  }
+  return finish_result(e, d, sd, buf, words, s, true);
+}
+
+long Evaluator_Square(void* h, void* a, void* dst, void* pool) { return Evaluator_Multiply(h, a, a, dst, pool); }
+
+long Evaluator_Relinearize(void* h, void* a, void* keys, void* dst, void* pool) {
+  (void)pool;
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
+  KeysObj* k = as<KeysObj>(keys, kMagicKeys);
+  if (!e || !x || !d || !k) return HIPBFV_E_POINTER;
+  if (!same_context(x, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  if (x->size == 2) {  // nothing to do: SEAL returns a copy
+    if (d == x) return HIPBFV_S_OK;
+    u64* buf = g_buffers.get(x->words);
+    if (!buf) return from_status(kOutOfMemory);
+    if (hipMemcpy(buf, x->dev, x->words * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+      g_buffers.put(buf, x->words);
+      return from_status(kHipError);
+    }
+    d->adopt(x->ctx, 2, buf, x->words);
+    return HIPBFV_S_OK;
+  }
+  // seal_fhe creates exactly one relinearization key (key_generator.rs:450-452): only size 3 -> 2
+  if (x->size != 3) return fail(HIPBFV_E_INVALIDARG, "not enough relinearization keys");
+  if (k->ctx.get() != e->ctx.get() || !k->find(0)) return fail(HIPBFV_E_INVALIDARG, "relin_keys is not valid for encryption parameters");
+  hipStream_t s = thread_stream();
+  const size_t words = e->ctx->ct_words(2);
+  u64* buf = g_buffers.get(words);
+  if (!buf) return from_status(kOutOfMemory);
+  int st = e->ev->relinearize(x->dev, k->find(0), buf, 1, s);
+  if (st) {
+    g_buffers.put(buf, words);
+    return from_status(st);
+  }
+  return finish_result(e, d, 2, buf, words, s, true);
+}
+
+// SEAL Evaluator::multiply_many: pairwise products with relinearisation, results appended to the work list
+long Evaluator_MultiplyMany(void* h, uint64_t count, void** cts, void* keys, void* dst, void* pool) {
+  if (!cts) return HIPBFV_E_POINTER;
+  if (count == 0) return fail(HIPBFV_E_INVALIDARG, "encrypteds vector must not be empty");
+  CipherObj* d = as<CipherObj>(dst, kMagicCipher);
+  if (!d) return HIPBFV_E_POINTER;
+  std::vector<void*> work;
+  long hr = HIPBFV_S_OK;
+  auto cleanup = [&]() {
+    for (void* w : work) Ciphertext_Destroy(w);
+  };
+  if (count == 1) {
+    void* c = nullptr;
+    hr = Ciphertext_Create2(cts[0], &c);
+    if (hr != HIPBFV_S_OK) return hr;
+    work.push_back(c);
+  } else {
+    for (uint64_t i = 0; i + 1 < count && hr == HIPBFV_S_OK; i += 2) {
+      void* t = nullptr;
+      hr = Ciphertext_Create1(nullptr, &t);
+      if (hr != HIPBFV_S_OK) break;
+      work.push_back(t);
+      hr = Evaluator_Multiply(h, cts[i], cts[i + 1], t, pool);
+      if (hr == HIPBFV_S_OK) hr = Evaluator_Relinearize(h, t, keys, t, pool);
+    }
+    if (hr == HIPBFV_S_OK && (count & 1)) {
+      void* c = nullptr;
+      hr = Ciphertext_Create2(cts[count - 1], &c);
+      if (hr == HIPBFV_S_OK) work.push_back(c);
+    }
+    for (size_t i = 0; hr == HIPBFV_S_OK && i + 1 < work.size(); i += 2) {
+      void* t = nullptr;
+      hr = Ciphertext_Create1(nullptr, &t);
+      if (hr != HIPBFV_S_OK) break;
+      work.push_back(t);
+      hr = Evaluator_Multiply(h, work[i], work[i + 1], t, pool);
+      if (hr == HIPBFV_S_OK) hr = Evaluator_Relinearize(h, t, keys, t, pool);
+    }
+  }
+  if (hr == HIPBFV_S_OK) {
+    CipherObj* last = as<CipherObj>(work.back(), kMagicCipher);
+    u64* buf = last->dev;
+    const size_t w = last->words;
+    last->dev = nullptr;
+    last->words = 0;
+    d->adopt(last->ctx, last->size, buf, w);
+  }
+  cleanup();
+  return hr;
+}
+
+long Evaluator_Exponentiate(void* h, void* a, uint64_t exponent, void* keys, void* dst, void* pool) {
+  if (exponent == 0) return fail(HIPBFV_E_INVALIDARG, "exponent cannot be 0");
+  if (exponent > 4096) return fail(HIPBFV_E_INVALIDARG, "exponent too large");
+  std::vector<void*> v((size_t)exponent, a);
+  return Evaluator_MultiplyMany(h, exponent, v.data(), keys, dst, pool);
+}
+
+static long plain_to_device(EvalObj* e, PlainObj* p, u64** out, size_t* nonzero, size_t* last_nonzero) {
+  const size_t n = e->ctx->n();
+  if (p->coeffs.size() > n) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
+  std::vector<u64> padded(n, 0);
+  *nonzero = 0;
+  *last_nonzero = 0;
+  for (size_t i = 0; i < p->coeffs.size(); i++) {
+    if (p->coeffs[i] >= e->ctx->t()) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
+    padded[i] = p->coeffs[i];
+    if (padded[i]) {
+      (*nonzero)++;
+      *last_nonzero = i;
+    }
+  }
+  u64* buf = g_buffers.get(n);
+  if (!buf) return from_status(kOutOfMemory);
+  if (hipMemcpy(buf, padded.data(), n * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) {
+    g_buffers.put(buf, n);
+    return from_status(kHipError);
+  }
+  *out = buf;
+  return HIPBFV_S_OK;
+}
+
+static long plain_op(void* h, void* a, void* plain, void* dst, int which) {
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
+  PlainObj* p = as<PlainObj>(plain, kMagicPlain);
+  if (!e || !x || !d || !p) return HIPBFV_E_POINTER;
+  if (!same_context(x, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  u64* dplain = nullptr;
+  size_t nonzero = 0, last = 0;
+  long hr = plain_to_device(e, p, &dplain, &nonzero, &last);
+  if (hr != HIPBFV_S_OK) return hr;
+  hipStream_t s = thread_stream();
+  u64* buf = g_buffers.get(x->words);
+  if (!buf) {
+    g_buffers.put(dplain, e->ctx->n());
+    return from_status(kOutOfMemory);
+  }
+  int st;
+  if (which == 0)
+    st = e->ev->add_plain(x->dev, x->size, dplain, 0, buf, 1, s);
+  else if (which == 1)
+    st = e->ev->sub_plain(x->dev, x->size, dplain, 0, buf, 1, s);
+  else if (nonzero == 1)
+    st = e->ev->multiply_plain_mono(x->dev, x->size, p->coeffs[last], (u32)last, buf, 1, s);
+  else
+    st = e->ev->multiply_plain(x->dev, x->size, dplain, 0, buf, 1, s);
+  if (st) {
+    (void)hipStreamSynchronize(s);
+    g_buffers.put(buf, x->words);
+    g_buffers.put(dplain, e->ctx->n());
+    return from_status(st);
+  }
+  hr = finish_result(e, d, x->size, buf, x->words, s, true);
+  g_buffers.put(dplain, e->ctx->n());
+  return hr;
+}
+
+long Evaluator_AddPlain(void* h, void* a, void* plain, void* dst) { return plain_op(h, a, plain, dst, 0); }
+long Evaluator_SubPlain(void* h, void* a, void* plain, void* dst) { return plain_op(h, a, plain, dst, 1); }
+long Evaluator_MultiplyPlain(void* h, void* a, void* plain, void* dst, void* pool) {
+  (void)pool;
+  return plain_op(h, a, plain, dst, 2);
+}
+
+// one Galois automorphism + key switch on a handle (SEAL apply_galois_inplace)
+static long galois_handle(EvalObj* e, CipherObj* x, u32 elt, KeysObj* k, CipherObj* d) {
+  const u64* key = k->find((elt - 1) >> 1);
+  if (!key) return from_status(kNoKey);
+  hipStream_t s = thread_stream();
+  const size_t words = e->ctx->ct_words(2);
+  u64* buf = g_buffers.get(words);
+  if (!buf) return from_status(kOutOfMemory);
+  int st = e->ev->apply_galois(x->dev, elt, key, buf, 1, s);
+  if (st) {
+    g_buffers.put(buf, words);
+    return from_status(st);
+  }
+  return finish_result(e, d, 2, buf, words, s, true);
+}
+
+// SEAL Evaluator::rotate_internal: use the key for `steps` if present, else the NAF decomposition
+static long rotate_internal(EvalObj* e, CipherObj* x, int steps, KeysObj* k, CipherObj* d) {
+  if (steps == 0) return HIPBFV_S_OK;
+  const u32 elt = e->ev->galois_elt_from_step(steps);
+  if (!elt) return fail(HIPBFV_E_INVALIDARG, "step count too large");
+  if (k->find((elt - 1) >> 1)) return galois_handle(e, x, elt, k, d);
+  std::vector<int> naf;
+  {
+    const bool neg = steps < 0;
+    int v = neg ? -steps : steps;
+    for (int i = 0; v; i++) {
+      const int zi = (v & 1) ? 2 - (v & 3) : 0;
+      v = (v - zi) >> 1;
+      if (zi) naf.push_back((neg ? -zi : zi) * (1 << i));
+    }
+  }
+  if (naf.size() == 1) return fail(HIPBFV_E_INVALIDARG, "Galois key not present");
+  for (int part : naf) {
+    if ((u32)(part < 0 ? -part : part) == (e->ctx->n() >> 1)) continue;
+    long hr = rotate_internal(e, d, part, k, d);
+    if (hr != HIPBFV_S_OK) return hr;
+  }
+  return HIPBFV_S_OK;
+}
+
+static long rotate_common(void* h, void* a, bool columns, int steps, void* keys, void* dst) {
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
+  KeysObj* k = as<KeysObj>(keys, kMagicKeys);
+  if (!e || !x || !d || !k) return HIPBFV_E_POINTER;
+  if (!same_context(x, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  if (!e->ctx->batching()) return fail(HIPBFV_COR_E_INVALIDOPERATION, "encryption parameters do not support batching");
+  if (x->size != 2) return fail(HIPBFV_E_INVALIDARG, "encrypted size must be 2");
+  if (k->ctx && k->ctx.get() != e->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "galois_keys is not valid for encryption parameters");
+  if (columns) return galois_handle(e, x, 2 * e->ctx->n() - 1, k, d);
+  if (d != x) {  // work on a copy in the destination so that the NAF chain can run in place
+    u64* buf = g_buffers.get(x->words);
+    if (!buf) return from_status(kOutOfMemory);
+    if (hipMemcpy(buf, x->dev, x->words * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+      g_buffers.put(buf, x->words);
+      return from_status(kHipError);
+    }
+    d->adopt(x->ctx, 2, buf, x->words);
+  }
+  return rotate_internal(e, d, steps, k, d);
+}
+
+long Evaluator_RotateRows(void* h, void* a, int steps, void* keys, void* dst, void* pool) {
+  (void)pool;
+  return rotate_common(h, a, false, steps, keys, dst);
+}
+
+long Evaluator_RotateColumns(void* h, void* a, void* keys, void* dst, void* pool) {
+  (void)pool;
+  return rotate_common(h, a, true, 0, keys, dst);
+}
+
+// ------------------------------------------------------------------ batched device-pointer API
+#define EVAL_OR_RETURN(h)                      \
+  EvalObj* e = as<EvalObj>(h, kMagicEval);     \
+  if (!e) return HIPBFV_E_POINTER;
+
+static const u64* key_or_null(void* keys, EvalObj* e, u32 index) {
+  KeysObj* k = as<KeysObj>(keys, kMagicKeys);
+  if (!k || k->ctx.get() != e->ctx.get()) return nullptr;
+  return k->find(index);
+}
+
+long hipbfv_batch_multiply(void* h, const uint64_t* a, uint64_t sa, const uint64_t* b, uint64_t sb, uint64_t* out, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!a || !b || !out) return HIPBFV_E_POINTER;
+  return from_status(e->ev->multiply((const u64*)a, (u32)sa, (const u64*)b, (u32)sb, (u64*)out, count, (hipStream_t)stream));
+}
+
+long hipbfv_batch_relinearize(void* h, const uint64_t* ct3, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!ct3 || !out2) return HIPBFV_E_POINTER;
+  const u64* rk = key_or_null(keys, e, 0);
+  if (!rk) return from_status(kNoKey);
+  return from_status(e->ev->relinearize((const u64*)ct3, rk, (u64*)out2, count, (hipStream_t)stream));
+}
+
+long hipbfv_batch_multiply_relin(void* h, const uint64_t* a, const uint64_t* b, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!a || !b || !out2) return HIPBFV_E_POINTER;
+  const u64* rk = key_or_null(keys, e, 0);
+  if (!rk) return from_status(kNoKey);
+  return from_status(e->ev->multiply_relin((const u64*)a, (const u64*)b, rk, (u64*)out2, count, (hipStream_t)stream));
+}
+
+long hipbfv_batch_apply_galois(void* h, const uint64_t* ct2, uint32_t elt, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!ct2 || !out2) return HIPBFV_E_POINTER;
+  if (!(elt & 1) || elt >= 2 * e->ctx->n()) return from_status(kInvalidArg);
+  const u64* key = key_or_null(keys, e, (elt - 1) >> 1);
+  if (!key) return from_status(kNoKey);
+  return from_status(e->ev->apply_galois((const u64*)ct2, elt, key, (u64*)out2, count, (hipStream_t)stream));
+}
+
+// all items rotate by the same step (each Galois key is streamed once per batch); NAF chain like SEAL
+static long batch_rotate_internal(EvalObj* e, const u64* in, int steps, void* keys, u64* out, uint64_t count, hipStream_t s) {
+  if (steps == 0) return HIPBFV_S_OK;
+  const u32 elt = e->ev->galois_elt_from_step(steps);
+  if (!elt) return fail(HIPBFV_E_INVALIDARG, "step count too large");
+  if (const u64* key = key_or_null(keys, e, (elt - 1) >> 1))
+    return from_status(e->ev->apply_galois(in, elt, key, out, count, s));
+  std::vector<int> naf;
+  const bool neg = steps < 0;
+  int v = neg ? -steps : steps;
+  for (int i = 0; v; i++) {
+    const int zi = (v & 1) ? 2 - (v & 3) : 0;
+    v = (v - zi) >> 1;
+    if (zi) naf.push_back((neg ? -zi : zi) * (1 << i));
+  }
+  if (naf.size() == 1) return from_status(kNoKey);
+  const u64* cur = in;
+  for (int part : naf) {
+    if ((u32)(part < 0 ? -part : part) == (e->ctx->n() >> 1)) continue;
+    long hr = batch_rotate_internal(e, cur, part, keys, out, count, s);
+    if (hr != HIPBFV_S_OK) return hr;
+    cur = out;
+  }
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_batch_rotate_rows(void* h, const uint64_t* ct2, int steps, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!ct2 || !out2) return HIPBFV_E_POINTER;
+  if (!e->ctx->batching()) return fail(HIPBFV_COR_E_INVALIDOPERATION, "encryption parameters do not support batching");
+  hipStream_t s = (hipStream_t)stream;
+  if (steps == 0) {
+    if ((const u64*)ct2 != (u64*)out2 &&
+        hipMemcpyAsync(out2, ct2, count * e->ctx->ct_words(2) * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return from_status(kHipError);
+    return HIPBFV_S_OK;
+  }
+  return batch_rotate_internal(e, (const u64*)ct2, steps, keys, (u64*)out2, count, s);
+}
+
+long hipbfv_batch_rotate_columns(void* h, const uint64_t* ct2, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!e->ctx->batching()) return fail(HIPBFV_COR_E_INVALIDOPERATION, "encryption parameters do not support batching");
+  return hipbfv_batch_apply_galois(h, ct2, 2 * e->ctx->n() - 1, keys, out2, count, stream);
+}
+
+long hipbfv_batch_add(void* h, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t size, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!a || !b || !out) return HIPBFV_E_POINTER;
+  return from_status(e->ev->add((const u64*)a, (const u64*)b, (u64*)out, (u32)size, count, (hipStream_t)stream));
+}
+
+long hipbfv_batch_sub(void* h, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t size, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!a || !b || !out) return HIPBFV_E_POINTER;
+  return from_status(e->ev->sub((const u64*)a, (const u64*)b, (u64*)out, (u32)size, count, (hipStream_t)stream));
+}
+
+long hipbfv_batch_negate(void* h, const uint64_t* a, uint64_t* out, uint64_t size, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!a || !out) return HIPBFV_E_POINTER;
+  return from_status(e->ev->negate((const u64*)a, (u64*)out, (u32)size, count, (hipStream_t)stream));
+}
+
+long hipbfv_batch_add_plain(void* h, const uint64_t* ct, uint64_t size, const uint64_t* plain, uint64_t pstride, uint64_t* out, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!ct || !plain || !out) return HIPBFV_E_POINTER;
+  return from_status(e->ev->add_plain((const u64*)ct, (u32)size, (const u64*)plain, pstride, (u64*)out, count, (hipStream_t)stream));
+}
+
+long hipbfv_batch_sub_plain(void* h, const uint64_t* ct, uint64_t size, const uint64_t* plain, uint64_t pstride, uint64_t* out, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!ct || !plain || !out) return HIPBFV_E_POINTER;
+  return from_status(e->ev->sub_plain((const u64*)ct, (u32)size, (const u64*)plain, pstride, (u64*)out, count, (hipStream_t)stream));
+}
+
+long hipbfv_batch_multiply_plain(void* h, const uint64_t* ct, uint64_t size, const uint64_t* plain, uint64_t pstride, uint64_t* out, uint64_t count, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!ct || !plain || !out) return HIPBFV_E_POINTER;
+  return from_status(e->ev->multiply_plain((const u64*)ct, (u32)size, (const u64*)plain, pstride, (u64*)out, count, (hipStream_t)stream));
+}
+
+long hipbfv_batch_ntt(void* h, uint64_t* data, uint64_t polys, uint64_t nprimes, bool inverse, void* stream) {
+  EVAL_OR_RETURN(h);
+  if (!data) return HIPBFV_E_POINTER;
+  return from_status(e->ev->ntt((u64*)data, polys, (u32)nprimes, inverse, (hipStream_t)stream));
+}
+
+long hipbfv_set_chunk_ops(void* h, uint64_t chunk) {
+  EVAL_OR_RETURN(h);
+  e->ev->set_chunk_ops(chunk);
+  return HIPBFV_S_OK;
+}
+
+}  // extern "C"

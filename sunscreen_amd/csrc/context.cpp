@@ -1,0 +1,357 @@
+// sunscreen_amd/csrc/context.cpp -- see context.hpp.
+#include "context.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+namespace hipbfv {
+
+namespace {
+
+typedef unsigned __int128 u128;
+
+inline u64 mulm(u64 a, u64 b, u64 q) { return (u64)((u128)a * b % q); }
+
+u64 powm(u64 b, u64 e, u64 q) {
+  u64 r = 1 % q;
+  b %= q;
+  for (; e; e >>= 1) {
+    if (e & 1) r = mulm(r, b, q);
+    b = mulm(b, b, q);
+  }
+  return r;
+}
+
+// modular inverse for any modulus coprime to a (q may be composite, e.g. 2^32 or a non-prime t)
+bool invm(u64 a, u64 q, u64* out) {
+  __int128 r0 = q, r1 = a % q, s0 = 0, s1 = 1;
+  while (r1 != 0) {
+    __int128 k = r0 / r1, tmp = r0 - k * r1;
+    r0 = r1;
+    r1 = tmp;
+    tmp = s0 - k * s1;
+    s0 = s1;
+    s1 = tmp;
+  }
+  if (r0 != 1) return false;
+  if (s0 < 0) s0 += q;
+  *out = (u64)s0;
+  return true;
+}
+
+inline MulOp make_mulop(u64 w, u64 q) {
+  MulOp m;
+  m.w = w;
+  m.wq = (u64)(((u128)w << 64) / q);
+  return m;
+}
+
+inline u32 bit_reverse(u32 v, int bits) {
+  u32 r = 0;
+  for (int i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i);
+  return r;
+}
+
+// product of a list of moduli reduced mod m, optionally skipping one index
+u64 prod_mod(const std::vector<u64>& base, u64 m, int skip = -1) {
+  u64 p = 1 % m;
+  for (size_t i = 0; i < base.size(); i++)
+    if ((int)i != skip) p = mulm(p, base[i] % m, m);
+  return p;
+}
+
+// little-endian multi-word integer, just enough for q = prod(q_i), floor(q/t), q mod m
+struct BigUint {
+  std::vector<u64> w{0};
+  void mul(u64 v) {
+    u64 carry = 0;
+    for (auto& x : w) {
+      u128 p = (u128)x * v + carry;
+      x = (u64)p;
+      carry = (u64)(p >> 64);
+    }
+    if (carry) w.push_back(carry);
+  }
+  u64 divmod(u64 d) {  // *this /= d, returns remainder
+    u64 rem = 0;
+    for (size_t i = w.size(); i-- > 0;) {
+      u128 cur = ((u128)rem << 64) | w[i];
+      w[i] = (u64)(cur / d);
+      rem = (u64)(cur % d);
+    }
+    while (w.size() > 1 && w.back() == 0) w.pop_back();
+    return rem;
+  }
+  u64 mod(u64 d) const {
+    u64 rem = 0;
+    for (size_t i = w.size(); i-- > 0;) rem = (u64)((((u128)rem << 64) | w[i]) % d);
+    return rem;
+  }
+  int bits() const { return (int)(64 * (w.size() - 1)) + (w.back() ? 64 - __builtin_clzll(w.back()) : 0); }
+};
+
+}  // namespace
+
+bool is_prime_u64(u64 v) {
+  if (v < 2) return false;
+  for (u64 p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+    if (v == p) return true;
+    if (v % p == 0) return false;
+  }
+  u64 d = v - 1;
+  int s = 0;
+  while ((d & 1) == 0) d >>= 1, s++;
+  for (u64 a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+    u64 x = powm(a, d, v);
+    if (x == 1 || x == v - 1) continue;
+    bool witness = true;
+    for (int r = 1; r < s && witness; r++) {
+      x = mulm(x, x, v);
+      if (x == v - 1) witness = false;
+    }
+    if (witness) return false;
+  }
+  return true;
+}
+
+std::vector<u64> find_primes(u64 factor, int bits, size_t count) {
+  std::vector<u64> out;
+  if (bits < 2 || bits > 62 || factor == 0) return out;
+  const u64 floor_v = 1ull << (bits - 1);
+  u64 cand = ((1ull << bits) - 1) / factor * factor + 1;
+  while (out.size() < count && cand > floor_v) {
+    if (is_prime_u64(cand)) out.push_back(cand);
+    if (cand < factor) break;
+    cand -= factor;
+  }
+  return out;
+}
+
+u64 minimal_primitive_root(u64 two_n, u64 q) {
+  if ((q - 1) % two_n) return 0;
+  const u64 cof = (q - 1) / two_n;
+  u64 gen = 0;
+  for (u64 g = 2; g < 4096 && !gen; g++) {
+    u64 c = powm(g, cof, q);
+    if (powm(c, two_n >> 1, q) == q - 1) gen = c;
+  }
+  if (!gen) return 0;
+  // every primitive 2n-th root is an odd power of gen: take the numerically smallest
+  const u64 step = mulm(gen, gen, q);
+  u64 best = gen, cur = gen;
+  for (u64 i = 1; i < (two_n >> 1); i++) {
+    cur = mulm(cur, step, q);
+    best = std::min(best, cur);
+  }
+  return best;
+}
+
+// SEAL's default BFV coefficient moduli (util/globals.cpp); n <= 8192 @128 pinned by
+// logproof/src/rings.rs:36-125, (1024,{192,256}) by seal_fhe/src/encryption_parameters.rs:340-365.
+std::vector<u64> default_coeff_modulus(u64 n, int sec) {
+  if (sec == 128) {
+    switch (n) {
+      case 1024: return {0x7e00001};
+      case 2048: return {0x3fffffff000001};
+      case 4096: return {0xffffee001, 0xffffc4001, 0x1ffffe0001};
+      case 8192: return {0x7fffffd8001, 0x7fffffc8001, 0xfffffffc001, 0xffffff6c001, 0xfffffebc001};
+      case 16384:
+        return {0xfffffffd8001,  0xfffffffa0001,  0xfffffff00001,  0x1fffffff68001, 0x1fffffff50001,
+                0x1ffffffee8001, 0x1ffffffea0001, 0x1ffffffe88001, 0x1ffffffe48001};
+      case 32768:
+        return {0x7fffffffe90001, 0x7fffffffbf0001, 0x7fffffffbd0001, 0x7fffffffba0001,
+                0x7fffffffaa0001, 0x7fffffffa50001, 0x7fffffff9f0001, 0x7fffffff7e0001,
+                0x7fffffff770001, 0x7fffffff380001, 0x7fffffff330001, 0x7fffffff2d0001,
+                0x7fffffff170001, 0x7fffffff150001, 0x7ffffffef00001, 0xfffffffff70001};
+      default: return {};
+    }
+  }
+  if (sec == 192 && n == 1024) return {0x7f001};
+  if (sec == 256 && n == 1024) return {0x3001};
+  return {};
+}
+
+// SEAL CoeffModulus::MaxBitCount (HomomorphicEncryption.org security standard tables)
+int max_coeff_bit_count(u64 n, int sec) {
+  static const int t128[] = {27, 54, 109, 218, 438, 881};
+  static const int t192[] = {19, 37, 75, 152, 305, 611};
+  static const int t256[] = {14, 29, 58, 118, 237, 476};
+  int idx = -1;
+  for (int i = 0; i < 6; i++)
+    if (n == (1024ull << i)) idx = i;
+  if (idx < 0) return 0;
+  if (sec == 128) return t128[idx];
+  if (sec == 192) return t192[idx];
+  if (sec == 256) return t256[idx];
+  return 0;
+}
+
+Context::~Context() {
+  if (dev_) (void)hipFree(dev_);
+  if (tw_fwd_) (void)hipFree(tw_fwd_);
+  if (tw_inv_) (void)hipFree(tw_inv_);
+}
+
+Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int device, std::string* err) {
+  auto fail = [&](const char* m) -> Context* {
+    if (err) *err = m;
+    return nullptr;
+  };
+  if (n < 1024 || n > 32768 || (n & (n - 1))) return fail("poly_modulus_degree must be a power of two in [1024, 32768]");
+  if (key_primes.empty() || key_primes.size() > (size_t)kMaxKey) return fail("invalid coefficient modulus count");
+  if (t < 2 || t >= (1ull << 60)) return fail("invalid plain modulus");
+  const u64 two_n = 2ull * n;
+  for (size_t i = 0; i < key_primes.size(); i++) {
+    u64 q = key_primes[i];
+    if (q < 2 || q >= (1ull << 60) || !is_prime_u64(q) || (q - 1) % two_n) return fail("coefficient modulus primes must be < 2^60 and == 1 mod 2n");
+    for (size_t j = 0; j < i; j++)
+      if (key_primes[j] == q) return fail("coefficient modulus primes must be distinct");
+  }
+  std::unique_ptr<Context> c(new Context());
+  c->device_ = device;
+  c->key_primes_ = key_primes;
+  DevCtx& h = c->host_;
+  h.n = n;
+  h.logn = 31 - __builtin_clz(n);
+  h.KK = (u32)key_primes.size();
+  h.K = h.KK > 1 ? h.KK - 1 : 1;
+  h.t = t;
+  const u32 K = h.K, KK = h.KK;
+  std::vector<u64> q(key_primes.begin(), key_primes.begin() + K);
+
+  // q as a big integer
+  BigUint Q;
+  Q.w[0] = 1;
+  for (u64 p : q) Q.mul(p);
+  const int q_bits = Q.bits();
+  const int t_bits = 64 - __builtin_clzll(t);
+  for (u64 p : q)
+    if (t % p == 0) return fail("plain modulus must be coprime to the coefficient modulus");
+
+  // auxiliary base: |B| = K, one more if K*n*t*q^2 could overflow q*B*m_sk (SEAL RNSTool::initialize)
+  h.nB = K;
+  if (32 + t_bits + q_bits >= 61 * (int)K + 61) h.nB++;
+  h.S = h.nB + 1;
+  h.P = KK + h.S;
+  if (h.S > (u32)kMaxBsk) return fail("too many primes");
+  std::vector<u64> aux = find_primes(two_n, 61, h.nB + 2);
+  if (aux.size() != h.nB + 2) return fail("cannot find auxiliary primes");
+  const u64 m_sk = aux[0];
+  std::vector<u64> B(aux.begin() + 2, aux.end());
+  std::vector<u64> Bsk = B;
+  Bsk.push_back(m_sk);
+  const u64 m_tilde = 1ull << 32;
+
+  // per-modulus constants and NTT tables
+  std::vector<u64> all;
+  all.insert(all.end(), key_primes.begin(), key_primes.end());
+  all.insert(all.end(), Bsk.begin(), Bsk.end());
+  std::vector<MulOp> twf((size_t)h.P * n), twi((size_t)h.P * n);
+  for (u32 m = 0; m < h.P; m++) {
+    const u64 p = all[m];
+    DevMod& dm = h.mod[m];
+    dm.q = p;
+    dm.q2 = p << 1;
+    u128 ratio = (~(u128)0) / p;  // p is odd: floor((2^128-1)/p) == floor(2^128/p)
+    dm.bar_lo = (u64)ratio;
+    dm.bar_hi = (u64)(ratio >> 64);
+    u64 ninv;
+    if (!invm(n, p, &ninv)) return fail("n not invertible");
+    dm.ninv = make_mulop(ninv, p);
+    const u64 psi = minimal_primitive_root(two_n, p);
+    if (!psi) return fail("no primitive root");
+    u64 ipsi;
+    invm(psi, p, &ipsi);
+    u64 pw = 1, ipw = 1;
+    for (u32 i = 0; i < n; i++) {
+      const u32 k = bit_reverse(i, h.logn);
+      twf[(size_t)m * n + k] = make_mulop(pw, p);
+      twi[(size_t)m * n + k] = make_mulop(ipw, p);
+      pw = mulm(pw, psi, p);
+      ipw = mulm(ipw, ipsi, p);
+    }
+  }
+
+  // ---- BEHZ constants ----
+  for (u32 i = 0; i < K; i++) {
+    u64 inv_punct;
+    if (!invm(prod_mod(q, q[i], (int)i), q[i], &inv_punct)) return fail("base not coprime");
+    h.ext_scale[i] = make_mulop(mulm(m_tilde % q[i], inv_punct, q[i]), q[i]);
+    h.q_to_mtilde[i] = (u32)prod_mod(q, m_tilde, (int)i);
+    const u64 nt = mulm(h.mod[i].ninv.w, t % q[i], q[i]);
+    h.intt_scale_q[i] = make_mulop(mulm(nt, inv_punct, q[i]), q[i]);
+    h.B_mod_q[i] = prod_mod(B, q[i]);
+    for (u32 j = 0; j < h.nB; j++) h.B_to_q[i][j] = prod_mod(B, q[i], (int)j);
+  }
+  {
+    u64 inv;
+    if (!invm(prod_mod(q, m_tilde), m_tilde, &inv)) return fail("q not invertible mod m_tilde");
+    h.neg_inv_q_mod_mtilde = (u32)((m_tilde - inv) & (m_tilde - 1));
+  }
+  for (u32 j = 0; j < h.S; j++) {
+    const u64 p = Bsk[j];
+    for (u32 i = 0; i < K; i++) h.q_to_bsk[j][i] = prod_mod(q, p, (int)i);
+    h.q_mod_bsk[j] = prod_mod(q, p);
+    u64 inv;
+    invm(m_tilde % p, p, &inv);
+    h.inv_mtilde_mod_bsk[j] = make_mulop(inv, p);
+    invm(h.q_mod_bsk[j], p, &inv);
+    h.inv_q_mod_bsk[j] = make_mulop(inv, p);
+    h.intt_scale_bsk[j] = make_mulop(mulm(h.mod[KK + j].ninv.w, t % p, p), p);
+  }
+  for (u32 j = 0; j < h.nB; j++) {
+    u64 inv;
+    invm(prod_mod(B, B[j], (int)j), B[j], &inv);
+    h.inv_punct_B[j] = make_mulop(inv, B[j]);
+    h.B_to_msk[j] = prod_mod(B, m_sk, (int)j);
+  }
+  {
+    u64 inv;
+    invm(prod_mod(B, m_sk), m_sk, &inv);
+    h.inv_B_mod_msk = make_mulop(inv, m_sk);
+  }
+
+  // ---- key switching ----
+  if (KK > 1) {
+    const u64 qsp = key_primes[KK - 1];
+    h.qsp_half = qsp >> 1;
+    for (u32 i = 0; i < K; i++) {
+      h.qsp_half_mod_q[i] = h.qsp_half % q[i];
+      u64 inv;
+      invm(qsp % q[i], q[i], &inv);
+      h.inv_qsp_mod_q[i] = make_mulop(inv, q[i]);
+    }
+  }
+
+  // ---- plaintext scaling ----
+  {
+    BigUint Qt = Q;
+    h.q_mod_t = Qt.divmod(t);  // Qt = floor(q/t)
+    h.t_half_up = (t + 1) >> 1;
+    h.fast_plain_lift = 1;
+    for (u32 i = 0; i < K; i++) {
+      h.q_div_t_mod_q[i] = Qt.mod(q[i]);
+      if (t >= q[i]) h.fast_plain_lift = 0;
+    }
+  }
+  c->batching_ = is_prime_u64(t) && (t - 1) % two_n == 0;
+
+  // ---- upload ----
+  if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
+  const size_t tw_bytes = twf.size() * sizeof(MulOp);
+  if (hipMalloc((void**)&c->tw_fwd_, tw_bytes) != hipSuccess || hipMalloc((void**)&c->tw_inv_, tw_bytes) != hipSuccess ||
+      hipMalloc((void**)&c->dev_, sizeof(DevCtx)) != hipSuccess)
+    return fail("hipMalloc failed");
+  h.tw_fwd = c->tw_fwd_;
+  h.tw_inv = c->tw_inv_;
+  if (hipMemcpy(c->tw_fwd_, twf.data(), tw_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->tw_inv_, twi.data(), tw_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->dev_, &h, sizeof(DevCtx), hipMemcpyHostToDevice) != hipSuccess)
+    return fail("hipMemcpy failed");
+  return c.release();
+}
+
+}  // namespace hipbfv

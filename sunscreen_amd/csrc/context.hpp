@@ -1,0 +1,55 @@
+// sunscreen_amd/csrc/context.hpp -- host-side BFV context: parameter validation, prime/root
+// search and the precomputed tables that are uploaded once to HBM.
+//
+// Replaces what SEALContext_Create builds inside SEAL for the reference
+// (seal_fhe/src/context.rs:63-80 -> bindgen::SEALContext_Create): NTTTables per prime and the
+// RNSTool constants of the first data level.  Written from the published algorithms
+// (Harvey NTT tables, BEHZ base conversion, hybrid key switching); shares no code with oracle/.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "devctx.hpp"
+
+namespace hipbfv {
+
+bool is_prime_u64(u64 v);
+// primes == 1 (mod factor), descending from just below 2^bits
+std::vector<u64> find_primes(u64 factor, int bits, size_t count);
+u64 minimal_primitive_root(u64 two_n, u64 q);
+std::vector<u64> default_coeff_modulus(u64 n, int sec_level);
+int max_coeff_bit_count(u64 n, int sec_level);
+
+class Context {
+ public:
+  // key_primes: data-level primes followed by the special prime (a single prime = no key switching)
+  static Context* create(u32 n, const std::vector<u64>& key_primes, u64 plain_modulus, int device, std::string* err);
+  ~Context();
+
+  u32 n() const { return host_.n; }
+  u32 K() const { return host_.K; }
+  u32 KK() const { return host_.KK; }
+  u32 S() const { return host_.S; }
+  u64 t() const { return host_.t; }
+  int device() const { return device_; }
+  const DevCtx& host() const { return host_; }
+  const DevCtx* dev() const { return dev_; }
+  const std::vector<u64>& key_primes() const { return key_primes_; }
+  bool batching() const { return batching_; }
+  size_t ct_words(size_t size) const { return size * (size_t)host_.K * host_.n; }
+  size_t key_words() const { return (size_t)host_.K * 2 * host_.KK * host_.n; }
+
+ private:
+  Context() = default;
+  DevCtx host_{};
+  DevCtx* dev_ = nullptr;
+  MulOp* tw_fwd_ = nullptr;
+  MulOp* tw_inv_ = nullptr;
+  int device_ = 0;
+  bool batching_ = false;
+  std::vector<u64> key_primes_;
+};
+
+}  // namespace hipbfv

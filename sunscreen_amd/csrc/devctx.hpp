@@ -1,0 +1,79 @@
+// sunscreen_amd/csrc/devctx.hpp -- plain-old-data tables shared by host code and HIP kernels.
+//
+// One DevCtx describes one BFV context (SEALContext_Create: seal_fhe/src/context.rs:63-80):
+// the key-level primes (data primes then the special prime), the BEHZ auxiliary base
+// Bsk = B u {m_sk}, and every per-modulus constant the kernels need.  It lives in device
+// global memory; kernels receive a `const DevCtx*` (uniform loads -> SGPRs).
+#pragma once
+#include <cstdint>
+
+namespace hipbfv {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int kMaxKey = 17;   // key-level primes (n=32768 default: 16)
+constexpr int kMaxBsk = 18;   // |B| + 1
+constexpr int kMaxMod = kMaxKey + kMaxBsk;
+
+// A constant multiplicand with its Shoup quotient floor(w * 2^64 / q).
+struct MulOp {
+  u64 w;
+  u64 wq;
+};
+
+struct DevMod {
+  u64 q;
+  u64 q2;       // 2q
+  u64 bar_lo;   // floor(2^128 / q), low word
+  u64 bar_hi;   // floor(2^128 / q), high word
+  MulOp ninv;   // n^{-1} mod q
+};
+
+struct DevCtx {
+  u32 n, logn;
+  u32 K;    // data-level primes
+  u32 KK;   // key-level primes (K + 1, or 1 when there is no special prime)
+  u32 nB;   // |B|
+  u32 S;    // |Bsk| = nB + 1
+  u32 P;    // KK + S moduli in `mod`
+  u32 pad0;
+  u64 t;    // plain modulus
+
+  // moduli: [0, KK) key-level primes, [KK, KK+S) Bsk primes (B..., m_sk)
+  DevMod mod[kMaxMod];
+  // twiddles: tw_fwd[m*n + k] = psi_m^{bitrev(k)}, tw_inv[m*n + k] = psi_m^{-bitrev(k)} (k >= 1)
+  const MulOp* tw_fwd;
+  const MulOp* tw_inv;
+
+  // ---- BEHZ multiply (SEAL RNSTool) ----
+  MulOp ext_scale[kMaxKey];            // m_tilde * (q/q_i)^{-1} mod q_i
+  u64 q_to_bsk[kMaxBsk][kMaxKey];      // (q/q_i) mod Bsk_j
+  u32 q_to_mtilde[kMaxKey];            // (q/q_i) mod 2^32
+  u32 neg_inv_q_mod_mtilde;            // -(q^{-1}) mod 2^32
+  u32 pad1;
+  u64 q_mod_bsk[kMaxBsk];              // q mod Bsk_j
+  MulOp inv_mtilde_mod_bsk[kMaxBsk];   // m_tilde^{-1} mod Bsk_j
+  MulOp intt_scale_q[kMaxKey];         // n^{-1} * t * (q/q_i)^{-1} mod q_i  (INTT epilogue before fast_floor)
+  MulOp intt_scale_bsk[kMaxBsk];       // n^{-1} * t mod Bsk_j
+  MulOp inv_q_mod_bsk[kMaxBsk];        // q^{-1} mod Bsk_j
+  MulOp inv_punct_B[kMaxBsk];          // (B/B_j)^{-1} mod B_j
+  u64 B_to_q[kMaxKey][kMaxBsk];        // (B/B_j) mod q_i
+  u64 B_to_msk[kMaxBsk];               // (B/B_j) mod m_sk
+  MulOp inv_B_mod_msk;                 // B^{-1} mod m_sk
+  u64 B_mod_q[kMaxKey];                // B mod q_i
+
+  // ---- key switching (special prime = mod[KK-1]) ----
+  u64 qsp_half;                        // q_sp >> 1
+  u64 qsp_half_mod_q[kMaxKey];         // (q_sp >> 1) mod q_i
+  MulOp inv_qsp_mod_q[kMaxKey];        // q_sp^{-1} mod q_i
+
+  // ---- plaintext lifting / scaling ----
+  u64 q_div_t_mod_q[kMaxKey];          // floor(q/t) mod q_i
+  u64 q_mod_t;                         // q mod t
+  u64 t_half_up;                       // (t + 1) >> 1
+  u32 fast_plain_lift;                 // t < every q_i
+  u32 pad2;
+};
+
+}  // namespace hipbfv

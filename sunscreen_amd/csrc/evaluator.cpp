@@ -1,0 +1,374 @@
+// sunscreen_amd/csrc/evaluator.cpp -- see evaluator.hpp.
+#include "evaluator.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace hipbfv {
+
+#define HB_CHECK(expr)                         \
+  do {                                         \
+    hipError_t e__ = (expr);                   \
+    if (e__ != hipSuccess) return kHipError;   \
+  } while (0)
+
+// ------------------------------------------------------------------ ScratchPool
+
+ScratchPool::~ScratchPool() { trim(); }
+
+void ScratchPool::trim() {
+  std::lock_guard<std::mutex> g(mu_);
+  for (auto it = blocks_.begin(); it != blocks_.end();) {
+    if (!it->busy) {
+      (void)hipEventSynchronize(it->ev);
+      (void)hipEventDestroy(it->ev);
+      (void)hipFree(it->ptr);
+      it = blocks_.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
+void* ScratchPool::acquire(size_t bytes, hipStream_t s) {
+  if (bytes == 0) bytes = 256;
+  std::lock_guard<std::mutex> g(mu_);
+  Block* best = nullptr;
+  for (auto& b : blocks_)
+    if (!b.busy && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+  if (best) {
+    best->busy = true;
+    // a block last used on another stream may still be read by kernels queued there
+    if (best->last != s) (void)hipStreamWaitEvent(s, best->ev, 0);
+    return best->ptr;
+  }
+  Block nb{};
+  if (hipMalloc(&nb.ptr, bytes) != hipSuccess) {
+    // free cached blocks and retry once
+    for (auto it = blocks_.begin(); it != blocks_.end();) {
+      if (!it->busy) {
+        (void)hipEventSynchronize(it->ev);
+        (void)hipEventDestroy(it->ev);
+        (void)hipFree(it->ptr);
+        it = blocks_.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    if (hipMalloc(&nb.ptr, bytes) != hipSuccess) return nullptr;
+  }
+  nb.bytes = bytes;
+  nb.last = s;
+  nb.busy = true;
+  if (hipEventCreateWithFlags(&nb.ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipFree(nb.ptr);
+    return nullptr;
+  }
+  blocks_.push_back(nb);
+  return nb.ptr;
+}
+
+void ScratchPool::release(void* p, hipStream_t s) {
+  std::lock_guard<std::mutex> g(mu_);
+  for (auto& b : blocks_) {
+    if (b.ptr == p) {
+      b.last = s;
+      (void)hipEventRecord(b.ev, s);
+      b.busy = false;
+      return;
+    }
+  }
+}
+
+namespace {
+struct ScratchGuard {
+  ScratchPool& pool;
+  hipStream_t s;
+  void* p;
+  ScratchGuard(ScratchPool& pl, size_t bytes, hipStream_t st) : pool(pl), s(st), p(pl.acquire(bytes, st)) {}
+  ~ScratchGuard() {
+    if (p) pool.release(p, s);
+  }
+};
+
+NttPlan make_plan(u32 div, const std::vector<u32>& mods) {
+  NttPlan pl{};
+  pl.div = div;
+  pl.period = (u32)mods.size();
+  for (size_t i = 0; i < mods.size(); i++) pl.mod[i] = (unsigned char)mods[i];
+  return pl;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ Evaluator
+
+Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
+  // Chunk so that the per-chunk scratch stays around 1 GiB (kernel-to-kernel intermediates are
+  // re-read immediately, so smaller chunks keep more of them in the 256 MiB Infinity Cache).
+  const DevCtx& h = ctx_->host();
+  const size_t R = h.K + h.S;
+  const size_t per_op = (size_t)(4 * R + 3 * R + 3 * h.K + (size_t)h.KK * h.K + 2 * h.KK) * h.n * sizeof(u64);
+  size_t c = ((size_t)1 << 30) / per_op;
+  if (const char* env = std::getenv("HIPBFV_CHUNK_OPS")) c = (size_t)std::strtoull(env, nullptr, 10);
+  chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 2048));
+}
+
+u32 Evaluator::galois_elt_from_step(int step) const {
+  const u32 n = ctx_->n(), m = 2 * n;
+  if (step == 0) return m - 1;
+  const u32 pos = (u32)(step < 0 ? -(long)step : (long)step);
+  if (pos >= (n >> 1)) return 0;
+  const u32 e = step < 0 ? (n >> 1) - pos : pos;
+  u64 g = 1;
+  for (u32 i = 0; i < e; i++) g = (g * 3) & (m - 1);
+  return (u32)g;
+}
+
+int Evaluator::ntt(u64* data, size_t polys, u32 nprimes, bool inverse, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (nprimes == 0 || nprimes > h.KK) return kInvalidArg;
+  if (h.logn > 14) return kUnsupported;
+  std::vector<u32> mods(nprimes);
+  for (u32 i = 0; i < nprimes; i++) mods[i] = i;
+  const NttPlan plan = make_plan(1, mods);
+  const size_t step = (65535 / nprimes) * nprimes;
+  for (size_t off = 0; off < polys; off += step) {
+    const size_t cnt = std::min(step, polys - off);
+    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, data + off * h.n, cnt, plan, inverse, 0, s));
+  }
+  return kOk;
+}
+
+int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (sa < 2 || sb < 2 || sa + sb > 16) return kInvalidArg;
+  if (h.logn > 14) return kUnsupported;
+  const u32 n = h.n, K = h.K, S = h.S, R = K + S, sd = sa + sb - 1;
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / (R * (sa + sb))));
+  const size_t ext_words = (size_t)(sa + sb) * R * n, d_words = (size_t)sd * R * n;
+  ScratchGuard sg(pool_, chunk * (ext_words + d_words) * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* ext = (u64*)sg.p;
+  u64* D = ext + chunk * ext_words;
+  std::vector<u32> mods;
+  for (u32 i = 0; i < K; i++) mods.push_back(i);
+  for (u32 j = 0; j < S; j++) mods.push_back(h.KK + j);
+  const NttPlan plan = make_plan(1, mods);
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    HB_CHECK(launch_behz_extend(ctx_->dev(), n, K, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));
+    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, ext, c * (sa + sb) * R, plan, false, 0, s));
+    HB_CHECK(launch_tensor(ctx_->dev(), n, R, ext, sa, sb, D, c, s));
+    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, D, c * sd * R, plan, true, 1, s));
+    HB_CHECK(launch_behz_floor_sk(ctx_->dev(), n, K, D, out + off * sd * K * n, c * sd, s));
+  }
+  return kOk;
+}
+
+size_t Evaluator::ks_scratch_words() const {
+  const DevCtx& h = ctx_->host();
+  return ((size_t)h.KK * h.K + 2 * (size_t)h.KK) * h.n;
+}
+
+// out2[op] = base[op] (masked) + modDown( sum_J NTT(target_J) (.) key[J] ); scratch >= count * ks_scratch_words()
+int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, const u64* base, size_t bstride, u32 base_mask,
+                          u64* out2, size_t count, u64* scratch, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  const u32 n = h.n, K = h.K, KK = h.KK;
+  u64* T = scratch;
+  u64* ACC = scratch + count * (size_t)KK * K * n;
+  std::vector<u32> mods;
+  for (u32 i = 0; i < KK; i++) mods.push_back(i);
+  HB_CHECK(launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));
+  HB_CHECK(launch_ntt(ctx_->dev(), h.logn, T, count * KK * K, make_plan(K, mods), false, 0, s));
+  HB_CHECK(launch_ks_mac(ctx_->dev(), n, KK, T, key, ACC, count, s));
+  HB_CHECK(launch_ntt(ctx_->dev(), h.logn, ACC, count * 2 * KK, make_plan(1, mods), true, 0, s));
+  HB_CHECK(launch_ks_moddown(ctx_->dev(), n, ACC, base, bstride, base_mask, out2, count, s));
+  return kOk;
+}
+
+int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.KK < 2 || !rk) return kNoKey;
+  if (h.logn > 14) return kUnsupported;
+  const u32 n = h.n, K = h.K;
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / ((size_t)h.KK * K)));
+  ScratchGuard sg(pool_, chunk * ks_scratch_words() * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  const size_t cs = (size_t)3 * K * n;
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    const u64* ct = ct3 + off * cs;
+    int rc = key_switch(ct + (size_t)2 * K * n, cs, rk, ct, cs, 3u, out2 + off * 2 * K * n, c, (u64*)sg.p, s);
+    if (rc) return rc;
+  }
+  return kOk;
+}
+
+int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.KK < 2 || !rk) return kNoKey;
+  const size_t cs = (size_t)3 * h.K * h.n;
+  const size_t chunk = chunk_ops_;
+  ScratchGuard sg(pool_, chunk * cs * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    int rc = multiply(a + off * 2 * h.K * h.n, 2, b + off * 2 * h.K * h.n, 2, (u64*)sg.p, c, s);
+    if (rc) return rc;
+    rc = relinearize((const u64*)sg.p, rk, out2 + off * 2 * h.K * h.n, c, s);
+    if (rc) return rc;
+  }
+  return kOk;
+}
+
+int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  const u32 n = h.n, K = h.K;
+  if (!(elt & 1) || elt >= 2 * n) return kInvalidArg;
+  if (h.KK < 2 || !key) return kNoKey;
+  if (h.logn > 14) return kUnsupported;
+  // g^{-1} mod 2n (Newton iteration, g odd)
+  u64 inv = 1;
+  for (int i = 0; i < 6; i++) inv = inv * (2 - (u64)elt * inv);
+  const u32 ginv = (u32)(inv & (2 * n - 1));
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / ((size_t)h.KK * K)));
+  const size_t rot_words = (size_t)2 * K * n;
+  ScratchGuard sg(pool_, chunk * (rot_words + ks_scratch_words()) * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* rot = (u64*)sg.p;
+  u64* ks = rot + chunk * rot_words;
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    HB_CHECK(launch_galois(ctx_->dev(), n, ct2 + off * rot_words, rot, c * 2, ginv, s));
+    // base = (sigma(c0), 0); target = sigma(c1)
+    int rc = key_switch(rot + (size_t)K * n, rot_words, key, rot, rot_words, 1u, out2 + off * rot_words, c, ks, s);
+    if (rc) return rc;
+  }
+  return kOk;
+}
+
+static int eltwise_chunks(const DevCtx* dev, u32 n, u32 K, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode, hipStream_t s) {
+  const size_t step = (65535 / K) * K;
+  for (size_t off = 0; off < residue_polys; off += step) {
+    const size_t cnt = std::min(step, residue_polys - off);
+    HB_CHECK(launch_eltwise(dev, n, a + off * n, b ? b + off * n : nullptr, out + off * n, cnt, mode, s));
+  }
+  return kOk;
+}
+
+int Evaluator::add(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s) {
+  if (size < 2) return kInvalidArg;
+  return eltwise_chunks(ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 0, s);
+}
+
+int Evaluator::sub(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s) {
+  if (size < 2) return kInvalidArg;
+  return eltwise_chunks(ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 1, s);
+}
+
+int Evaluator::negate(const u64* a, u64* out, u32 size, size_t count, hipStream_t s) {
+  if (size < 1) return kInvalidArg;
+  return eltwise_chunks(ctx_->dev(), ctx_->n(), ctx_->K(), a, nullptr, out, count * size * ctx_->K(), 2, s);
+}
+
+static int plain_addsub(Context* ctx, const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, int sub, hipStream_t s) {
+  if (size < 2) return kInvalidArg;
+  const size_t cs = ctx->ct_words(size);
+  if (out != ct) HB_CHECK(hipMemcpyAsync(out, ct, count * cs * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  for (size_t off = 0; off < count; off += 65535) {
+    const size_t c = std::min<size_t>(65535, count - off);
+    HB_CHECK(launch_plain_addsub(ctx->dev(), ctx->n(), out + off * cs, cs, plain + off * pstride, pstride, c, sub, s));
+  }
+  return kOk;
+}
+
+int Evaluator::add_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s) {
+  return plain_addsub(ctx_, ct, size, plain, pstride, out, count, 0, s);
+}
+
+int Evaluator::sub_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s) {
+  return plain_addsub(ctx_, ct, size, plain, pstride, out, count, 1, s);
+}
+
+int Evaluator::multiply_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (size < 2) return kInvalidArg;
+  if (h.logn > 14) return kUnsupported;
+  const u32 n = h.n, K = h.K;
+  const size_t cs = ctx_->ct_words(size);
+  const bool shared = pstride == 0;
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / ((size_t)size * K)));
+  ScratchGuard sg(pool_, (shared ? 1 : chunk) * (size_t)K * n * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* pl = (u64*)sg.p;
+  std::vector<u32> mods;
+  for (u32 i = 0; i < K; i++) mods.push_back(i);
+  const NttPlan plan = make_plan(1, mods);
+  if (shared) {
+    HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain, 0, pl, 1, s));
+    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, pl, K, plan, false, 0, s));
+  }
+  if (out != ct) HB_CHECK(hipMemcpyAsync(out, ct, count * cs * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    if (!shared) {
+      HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain + off * pstride, pstride, pl, c, s));
+      HB_CHECK(launch_ntt(ctx_->dev(), h.logn, pl, c * K, plan, false, 0, s));
+    }
+    u64* x = out + off * cs;
+    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, x, c * size * K, plan, false, 0, s));
+    HB_CHECK(launch_dyadic_plain(ctx_->dev(), n, K, x, size, pl, shared ? 0 : (size_t)K * n, c, s));
+    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, x, c * size * K, plan, true, 0, s));
+  }
+  return kOk;
+}
+
+int Evaluator::multiply_plain_mono(const u64* ct, u32 size, u64 coeff, u32 exponent, u64* out, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (size < 2 || exponent >= h.n || coeff == 0 || coeff >= h.t) return kInvalidArg;
+  const u32 n = h.n, K = h.K;
+  // SEAL multiply_plain_normal, monomial branch: with the fast plain lift the coefficient is used as is,
+  // otherwise values >= (t+1)/2 are lifted to (coeff - t) mod q_i.
+  std::vector<u64> rns(K);
+  for (u32 i = 0; i < K; i++) {
+    const u64 q = h.mod[i].q;
+    if (h.fast_plain_lift || coeff < h.t_half_up)
+      rns[i] = coeff % q;
+    else {
+      const u64 d = (h.t - coeff) % q;
+      rns[i] = d ? q - d : 0;
+    }
+  }
+  const size_t cs = ctx_->ct_words(size);
+  const bool inplace = out == ct;
+  ScratchGuard sg(pool_, (K + (inplace ? count * cs : 0)) * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* d_rns = (u64*)sg.p;
+  HB_CHECK(hipMemcpyAsync(d_rns, rns.data(), K * sizeof(u64), hipMemcpyHostToDevice, s));
+  HB_CHECK(hipStreamSynchronize(s));  // rns is a host temporary
+  const u64* src = ct;
+  if (inplace) {
+    u64* tmp = d_rns + K;
+    HB_CHECK(hipMemcpyAsync(tmp, ct, count * cs * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    src = tmp;
+  }
+  const size_t total = count * size * K, step = (65535 / K) * K;
+  for (size_t off = 0; off < total; off += step) {
+    const size_t cnt = std::min(step, total - off);
+    HB_CHECK(launch_mono_mul(ctx_->dev(), n, src + off * n, out + off * n, cnt, d_rns, exponent, s));
+  }
+  return kOk;
+}
+
+int Evaluator::nonzero_tail(const u64* ct, u32 size, u32* flags, size_t count, hipStream_t s) {
+  if (size < 2) return kInvalidArg;
+  const size_t cs = ctx_->ct_words(size), skip = ctx_->ct_words(1);
+  for (size_t off = 0; off < count; off += 65535) {
+    const size_t c = std::min<size_t>(65535, count - off);
+    HB_CHECK(launch_nonzero_tail(ct + off * cs, cs, skip, flags + off, c, s));
+  }
+  return kOk;
+}
+
+}  // namespace hipbfv

@@ -1,0 +1,89 @@
+// sunscreen_amd/csrc/evaluator.hpp -- the GPU batch executor for the Evaluator operations.
+//
+// Mirrors the operation set of `trait seal_fhe::Evaluator` (seal_fhe/src/evaluator.rs:7-280) with an
+// extra leading batch dimension that the reference does not have: every method processes `count`
+// independent ciphertexts laid out contiguously in HBM (u64[count][size][K][N]) with one sequence of
+// kernel launches, instead of one FFI call per graph node (sunscreen_runtime/src/run.rs:160-341).
+// All pointers are device pointers; all work is enqueued on the given HIP stream and is asynchronous.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "context.hpp"
+#include "kernels.hpp"
+
+namespace hipbfv {
+
+enum Status : int {
+  kOk = 0,
+  kInvalidArg = -1,
+  kTransparent = -2,
+  kNoKey = -3,
+  kOutOfMemory = -4,
+  kHipError = -5,
+  kUnsupported = -6,
+};
+
+// Stream-aware caching allocator for kernel scratch space.
+class ScratchPool {
+ public:
+  ~ScratchPool();
+  void* acquire(size_t bytes, hipStream_t s);
+  void release(void* p, hipStream_t s);
+  void trim();
+
+ private:
+  struct Block {
+    void* ptr;
+    size_t bytes;
+    hipStream_t last;
+    hipEvent_t ev;
+    bool busy;
+  };
+  std::mutex mu_;
+  std::vector<Block> blocks_;
+};
+
+class Evaluator {
+ public:
+  explicit Evaluator(Context* ctx);
+  Context* ctx() const { return ctx_; }
+
+  // ---- SURVEY 8a rows a1-a5, batched ----
+  int multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, size_t count, hipStream_t s);
+  int relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s);
+  int multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s);
+  // out2 = (sigma_g(c0), 0) + switch_key(sigma_g(c1), key)
+  int apply_galois(const u64* ct2, u32 galois_elt, const u64* key, u64* out2, size_t count, hipStream_t s);
+  int add(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s);
+  int sub(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s);
+  int negate(const u64* a, u64* out, u32 size, size_t count, hipStream_t s);
+  // plain: u64[count][N] (pstride = N) or one shared plaintext (pstride = 0), coefficients < t, zero padded
+  int add_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s);
+  int sub_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s);
+  int multiply_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s);
+  // monomial fast path of SEAL multiply_plain_normal: plaintext = coeff * x^exponent
+  int multiply_plain_mono(const u64* ct, u32 size, u64 coeff, u32 exponent, u64* out, size_t count, hipStream_t s);
+  // flags[i] = 1 if ciphertext i is NOT transparent (some word of polys 1.. is non-zero); flags must be zeroed
+  int nonzero_tail(const u64* ct, u32 size, u32* flags, size_t count, hipStream_t s);
+
+  // ---- NTT entry points (BASELINE config 2) ----
+  // data: u64[polys][N]; polynomial p uses key-level prime (p % nprimes)
+  int ntt(u64* data, size_t polys, u32 nprimes, bool inverse, hipStream_t s);
+
+  u32 galois_elt_from_step(int step) const;  // 0 if |step| >= n/2
+  size_t chunk_ops() const { return chunk_ops_; }
+  void set_chunk_ops(size_t c) { chunk_ops_ = c ? c : 1; }
+
+ private:
+  int key_switch(const u64* target, size_t tstride, const u64* key, const u64* base, size_t bstride, u32 base_mask, u64* out2,
+                 size_t count, u64* scratch, hipStream_t s);
+  size_t ks_scratch_words() const;
+  Context* ctx_;
+  ScratchPool pool_;
+  size_t chunk_ops_;
+};
+
+}  // namespace hipbfv

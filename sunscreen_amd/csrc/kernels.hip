@@ -1,0 +1,664 @@
+// sunscreen_amd/csrc/kernels.hip -- hand-written gfx950 kernels for the BFV hot path.
+//
+// What each kernel replaces in the reference (all inside SEAL behind seal_fhe::Evaluator):
+//   ntt_fwd / ntt_inv        NTTTables + ntt_negacyclic_harvey (context.rs:63-80 builds them)
+//   behz_extend              RNSTool::fastbconv_m_tilde + sm_mrq        (Evaluator_Multiply, evaluator_base.rs:198-212)
+//   tensor                   behz_ciphertext_product (dyadic)            (same)
+//   behz_floor_sk            RNSTool::fast_floor + fastbconv_sk          (same)
+//   ks_decompose/mac/moddown Evaluator::switch_key_inplace               (Evaluator_Relinearize / RotateRows / RotateColumns,
+//                                                                          bfv_evaluator.rs:148-244)
+//   galois                   GaloisTool::apply_galois                    (bfv_evaluator.rs:177-247)
+//   eltwise / plain kernels  add/sub/negate/add_plain/sub_plain/multiply_plain (evaluator_base.rs:89-404)
+//
+// Data layout everywhere: u64[...][residue][N] with the coefficient index fastest, so that a
+// wavefront's 64 lanes touch 512 contiguous bytes (coefficient-parallel kernels) or one
+// workgroup owns one residue polynomial (NTT kernels, staged through LDS).
+#include <hip/hip_runtime.h>
+
+#include "devarith.hpp"
+#include "kernels.hpp"
+
+namespace hipbfv {
+
+// =====================================================================================
+// NTT: one workgroup per residue polynomial, N/16 threads, 16 coefficients per thread.
+// The log2(N) radix-2 stages are grouped into ceil(logn/4) register passes; between passes
+// the polynomial is exchanged through LDS (padded by one word per 32 to spread the strided
+// accesses of the late passes over the banks).
+// =====================================================================================
+
+constexpr int kElemsPerThread = 16;
+
+__device__ __forceinline__ u32 lds_pos(u32 e) { return e + (e >> 5); }
+
+template <int LOGN>
+struct NttShape {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int T = N / kElemsPerThread;
+  static constexpr int NPASS = (LOGN + 3) / 4;
+  static constexpr int BASE = LOGN / NPASS;
+  static constexpr int EXTRA = LOGN % NPASS;
+  static constexpr int LDS_WORDS = N + (N >> 5);
+  // radix (number of stages) of pass p, and the number of stages before it
+  static constexpr int radix(int p) { return BASE + (p < EXTRA ? 1 : 0); }
+  static constexpr int before(int p) { return p * BASE + (p < EXTRA ? p : EXTRA); }
+};
+
+// element index handled by virtual thread vt in a pass that covers bit positions [LOW, LOW+R)
+template <int LOW, int R>
+__device__ __forceinline__ u32 elem_index(u32 vt, u32 k) {
+  const u32 lo = vt & ((1u << LOW) - 1u);
+  const u32 hi = vt >> LOW;
+  return (hi << (LOW + R)) | (k << LOW) | lo;
+}
+
+// ---- forward (Cooley-Tukey, gap shrinking). Values lazy in [0,4q). ----
+template <int LOGN, int S0, int R>
+__device__ __forceinline__ void fwd_pass_compute(u64 (&v)[kElemsPerThread], u32 tid, const MulOp* __restrict__ tw, u64 q, u64 q2) {
+  constexpr int T = NttShape<LOGN>::T;
+  constexpr int G = kElemsPerThread >> R;
+  constexpr int LOW = LOGN - S0 - R;
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const u32 vt = tid + g * T;
+    const u32 hi = vt >> LOW;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const int half = 1 << (R - 1 - j);
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) {
+        if (k & half) continue;
+        const u32 widx = (1u << (S0 + j)) + ((hi << j) | (u32)(k >> (R - j)));
+        const MulOp w = tw[widx];
+        u64& X = v[g * (1 << R) + k];
+        u64& Y = v[g * (1 << R) + k + half];
+        const u64 x = X >= q2 ? X - q2 : X;
+        const u64 t = mul_shoup_lazy(Y, w.w, w.wq, q);
+        X = x + t;
+        Y = x + q2 - t;
+      }
+    }
+  }
+}
+
+template <int LOGN, int PASS>
+struct FwdPasses {
+  // run passes PASS..NPASS-1 with data resident in LDS on entry to every pass but the first
+  static __device__ __forceinline__ void run(u64 (&v)[kElemsPerThread], u64* smem, u32 tid, const MulOp* tw, u64 q, u64 q2) {
+    using Sh = NttShape<LOGN>;
+    constexpr int R = Sh::radix(PASS);
+    constexpr int S0 = Sh::before(PASS);
+    constexpr int LOW = LOGN - S0 - R;
+    constexpr int G = kElemsPerThread >> R;
+    if (PASS > 0) {
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
+    }
+    fwd_pass_compute<LOGN, S0, R>(v, tid, tw, q, q2);
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[g * (1 << R) + k];
+    if constexpr (PASS + 1 < Sh::NPASS) FwdPasses<LOGN, PASS + 1>::run(v, smem, tid, tw, q, q2);
+  }
+};
+
+// Forward NTT of one polynomial: src (global, canonical) -> LDS (lazy [0,4q)); caller copies out.
+template <int LOGN>
+__device__ __forceinline__ void ntt_fwd_to_lds(const u64* __restrict__ src, u64* smem, u32 tid, const MulOp* tw, u64 q) {
+  using Sh = NttShape<LOGN>;
+  constexpr int R0 = Sh::radix(0);
+  constexpr int LOW0 = LOGN - R0;
+  constexpr int G0 = kElemsPerThread >> R0;
+  u64 v[kElemsPerThread];
+#pragma unroll
+  for (int g = 0; g < G0; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R0); k++) v[g * (1 << R0) + k] = src[elem_index<LOW0, R0>(tid + g * Sh::T, k)];
+  FwdPasses<LOGN, 0>::run(v, smem, tid, tw, q, q << 1);
+  __syncthreads();
+}
+
+// ---- inverse (Gentleman-Sande, gap growing). Values lazy in [0,2q). ----
+template <int LOGN, int LOW, int R>
+__device__ __forceinline__ void inv_pass_compute(u64 (&v)[kElemsPerThread], u32 tid, const MulOp* __restrict__ tw, u64 q, u64 q2) {
+  constexpr int T = NttShape<LOGN>::T;
+  constexpr int G = kElemsPerThread >> R;
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const u32 vt = tid + g * T;
+    const u32 hi = vt >> LOW;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const int half = 1 << j;
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) {
+        if (k & half) continue;
+        // global gap 2^(LOW+j): m = N >> (LOW+j+1) blocks, block index = element >> (LOW+j+1)
+        const u32 widx = (1u << (LOGN - 1 - LOW - j)) + ((hi << (R - 1 - j)) | (u32)(k >> (j + 1)));
+        const MulOp w = tw[widx];
+        u64& X = v[g * (1 << R) + k];
+        u64& Y = v[g * (1 << R) + k + half];
+        const u64 u = X, y = Y;
+        const u64 s = u + y;
+        X = s >= q2 ? s - q2 : s;
+        Y = mul_shoup_lazy(u + q2 - y, w.w, w.wq, q);
+      }
+    }
+  }
+}
+
+template <int LOGN, int PASS>
+struct InvPasses {
+  // inverse pass PASS covers the same bit window as forward pass NPASS-1-PASS
+  static __device__ __forceinline__ void run(u64 (&v)[kElemsPerThread], u64* smem, u32 tid, const MulOp* tw, u64 q, u64 q2) {
+    using Sh = NttShape<LOGN>;
+    constexpr int FP = Sh::NPASS - 1 - PASS;
+    constexpr int R = Sh::radix(FP);
+    constexpr int LOW = LOGN - Sh::before(FP) - R;
+    constexpr int G = kElemsPerThread >> R;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
+    inv_pass_compute<LOGN, LOW, R>(v, tid, tw, q, q2);
+    if constexpr (PASS + 1 < Sh::NPASS) {
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[g * (1 << R) + k];
+      InvPasses<LOGN, PASS + 1>::run(v, smem, tid, tw, q, q2);
+    }
+  }
+};
+
+// Inverse NTT of the polynomial resident in LDS; the last pass leaves each thread holding the
+// elements elem_index<LOGN-R, R>(tid + g*T, k), which the caller scales and stores (coalesced).
+template <int LOGN>
+__device__ __forceinline__ void ntt_inv_from_lds(u64 (&v)[kElemsPerThread], u64* smem, u32 tid, const MulOp* tw, u64 q) {
+  InvPasses<LOGN, 0>::run(v, smem, tid, tw, q, q << 1);
+}
+
+__device__ __forceinline__ u32 plan_mod(const NttPlan& plan, u32 poly) { return plan.mod[(poly / plan.div) % plan.period]; }
+
+template <int LOGN>
+__global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx* __restrict__ ctx, u64* data, NttPlan plan) {
+  using Sh = NttShape<LOGN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u64* smem = reinterpret_cast<u64*>(smem_raw);
+  const u32 tid = threadIdx.x;
+  const u32 poly = blockIdx.x;
+  const u32 m = plan_mod(plan, poly);
+  const u64 q = ctx->mod[m].q, q2 = q << 1;
+  u64* x = data + (size_t)poly * Sh::N;
+  ntt_fwd_to_lds<LOGN>(x, smem, tid, ctx->tw_fwd + (size_t)m * Sh::N, q);
+  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) {
+    u64 val = smem[lds_pos(e)];
+    val = val >= q2 ? val - q2 : val;
+    x[e] = val >= q ? val - q : val;
+  }
+}
+
+// scale_mode: 0 = n^{-1}; 1 = BEHZ epilogue (n^{-1} * t [* (q/q_i)^{-1}]), see DevCtx::intt_scale_*
+template <int LOGN>
+__global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx* __restrict__ ctx, u64* data, NttPlan plan, int scale_mode) {
+  using Sh = NttShape<LOGN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u64* smem = reinterpret_cast<u64*>(smem_raw);
+  const u32 tid = threadIdx.x;
+  const u32 poly = blockIdx.x;
+  const u32 m = plan_mod(plan, poly);
+  const u64 q = ctx->mod[m].q;
+  u64* x = data + (size_t)poly * Sh::N;
+  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) smem[lds_pos(e)] = x[e];
+  u64 v[kElemsPerThread];
+  ntt_inv_from_lds<LOGN>(v, smem, tid, ctx->tw_inv + (size_t)m * Sh::N, q);
+  MulOp sc = ctx->mod[m].ninv;
+  if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
+  constexpr int R = Sh::radix(0);
+  constexpr int LOW = LOGN - R;
+  constexpr int G = kElemsPerThread >> R;
+#pragma unroll
+  for (int g = 0; g < G; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) x[elem_index<LOW, R>(tid + g * Sh::T, k)] = mul_shoup(v[g * (1 << R) + k], sc.w, sc.wq, q);
+}
+
+template <int LOGN>
+static hipError_t launch_ntt_t(const DevCtx* ctx, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
+  using Sh = NttShape<LOGN>;
+  const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
+  if (inverse) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done = true;
+    }
+    ntt_inv_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, data, plan, scale_mode);
+  } else {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done = true;
+    }
+    ntt_fwd_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, data, plan);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_ntt(const DevCtx* ctx, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
+  if (polys == 0) return hipSuccess;
+  switch (logn) {
+    case 10: return launch_ntt_t<10>(ctx, data, polys, plan, inverse, scale_mode, s);
+    case 11: return launch_ntt_t<11>(ctx, data, polys, plan, inverse, scale_mode, s);
+    case 12: return launch_ntt_t<12>(ctx, data, polys, plan, inverse, scale_mode, s);
+    case 13: return launch_ntt_t<13>(ctx, data, polys, plan, inverse, scale_mode, s);
+    case 14: return launch_ntt_t<14>(ctx, data, polys, plan, inverse, scale_mode, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// =====================================================================================
+// Coefficient-parallel kernels.  Thread = one coefficient index k of one (op, poly); the
+// residues of that coefficient are N words apart, so every load/store is a 512-byte
+// wavefront transaction.
+// =====================================================================================
+
+constexpr int kCoefThreads = 256;
+
+// ---- BEHZ step 1+2: base q -> q u Bsk with Montgomery reduction of the q-overflow ----
+// in0: u64[ops][sa][K][N], in1: u64[ops][sb][K][N]  (ciphertext polynomials, coefficient form)
+// out: u64[ops][sa+sb][K+S][N]                      (q residues copied, then Bsk residues)
+template <int KMAX>
+__global__ __launch_bounds__(kCoefThreads) void behz_extend_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in0, u32 sa,
+                                                                   const u64* __restrict__ in1, u32 sb, u64* __restrict__ out) {
+  const u32 n = ctx->n, K = ctx->K, S = ctx->S, KK = ctx->KK;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 poly = blockIdx.y;  // global poly index: op * (sa+sb) + p
+  const u32 op = poly / (sa + sb), p = poly % (sa + sb);
+  const u64* src = p < sa ? in0 + ((size_t)op * sa + p) * K * n : in1 + ((size_t)op * sb + (p - sa)) * K * n;
+  u64* dst = out + (size_t)poly * (K + S) * n;
+  if (k >= n) return;
+  u64 y[KMAX];
+  u32 rm = 0;
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const u64 x = src[(size_t)i * n + k];
+      dst[(size_t)i * n + k] = x;
+      y[i] = mul_shoup(x, ctx->ext_scale[i], ctx->mod[i].q);
+      rm += (u32)y[i] * ctx->q_to_mtilde[i];
+    }
+  }
+  rm *= ctx->neg_inv_q_mod_mtilde;  // r_mtilde = -x/q mod 2^32
+  for (u32 j = 0; j < S; j++) {
+    const DevMod& pm = ctx->mod[KK + j];
+    u128 acc = 0;
+#pragma unroll
+    for (int i = 0; i < KMAX; i++)
+      if ((u32)i < K) acc += (u128)y[i] * ctx->q_to_bsk[j][i];
+    u64 rc = rm;
+    if (rm >= 0x80000000u) rc += pm.q - 0x100000000ull;  // centred representative
+    acc += (u128)rc * ctx->q_mod_bsk[j];
+    const u64 v = reduce128(acc, pm);
+    dst[(size_t)(K + j) * n + k] = mul_shoup(v, ctx->inv_mtilde_mod_bsk[j], pm.q);
+  }
+}
+
+// ---- BEHZ step 4: dyadic tensor product per residue: d_p = sum_{i+j=p} a_i * b_j ----
+// ext: u64[ops][sa+sb][R][N] (NTT form, a polys then b polys), D: u64[ops][sa+sb-1][R][N]
+__global__ __launch_bounds__(kCoefThreads) void tensor_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ext, u32 sa, u32 sb,
+                                                              u64* __restrict__ D) {
+  const u32 n = ctx->n, R = ctx->K + ctx->S;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 r = blockIdx.y, op = blockIdx.z;
+  if (k >= n) return;
+  const u32 m = r < ctx->K ? r : ctx->KK + (r - ctx->K);
+  const DevMod& pm = ctx->mod[m];
+  const u64* A = ext + ((size_t)op * (sa + sb)) * R * n + (size_t)r * n + k;
+  u64* d = D + ((size_t)op * (sa + sb - 1)) * R * n + (size_t)r * n + k;
+  if (sa == 2 && sb == 2) {
+    const u64 a0 = A[0], a1 = A[(size_t)R * n], b0 = A[(size_t)2 * R * n], b1 = A[(size_t)3 * R * n];
+    d[0] = reduce128((u128)a0 * b0, pm);
+    d[(size_t)R * n] = reduce128((u128)a0 * b1 + (u128)a1 * b0, pm);
+    d[(size_t)2 * R * n] = reduce128((u128)a1 * b1, pm);
+    return;
+  }
+  for (u32 p = 0; p + 1 < sa + sb; p++) {
+    u128 acc = 0;
+    for (u32 i = 0; i < sa; i++) {
+      if (p < i || p - i >= sb) continue;
+      acc += (u128)A[(size_t)i * R * n] * A[(size_t)(sa + p - i) * R * n];
+    }
+    d[(size_t)p * R * n] = reduce128(acc, pm);
+  }
+}
+
+// ---- BEHZ steps 7+8: fast_floor (q u Bsk -> Bsk) then Shenoy-Kumaresan (Bsk -> q) ----
+// D: u64[npoly][K+S][N] after the scaled inverse NTT; out: u64[npoly][K][N]
+template <int KMAX>
+__global__ __launch_bounds__(kCoefThreads) void behz_floor_sk_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ D, u64* __restrict__ out) {
+  const u32 n = ctx->n, K = ctx->K, S = ctx->S, KK = ctx->KK, nB = ctx->nB;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 poly = blockIdx.y;
+  if (k >= n) return;
+  const u64* d = D + (size_t)poly * (K + S) * n;
+  u64 y[KMAX];
+#pragma unroll
+  for (int i = 0; i < KMAX; i++)
+    if ((u32)i < K) y[i] = d[(size_t)i * n + k];  // already x * t * (q/q_i)^{-1} mod q_i
+  u64 yb[KMAX + 1];
+  u64 fl_msk = 0;
+#pragma unroll
+  for (int j = 0; j < KMAX + 2; j++) {
+    if ((u32)j < S) {
+      const DevMod& pm = ctx->mod[KK + j];
+      u128 acc = 0;
+#pragma unroll
+      for (int i = 0; i < KMAX; i++)
+        if ((u32)i < K) acc += (u128)y[i] * ctx->q_to_bsk[j][i];
+      const u64 conv = reduce128(acc, pm);
+      const u64 fl = mul_shoup(d[(size_t)(K + j) * n + k] + pm.q - conv, ctx->inv_q_mod_bsk[j], pm.q);
+      if ((u32)j < nB) {
+        if (j < KMAX + 1) yb[j < KMAX + 1 ? j : 0] = mul_shoup(fl, ctx->inv_punct_B[j], pm.q);
+      } else {
+        fl_msk = fl;
+      }
+    }
+  }
+  // alpha_sk
+  const DevMod& msk = ctx->mod[KK + nB];
+  u128 acc = 0;
+#pragma unroll
+  for (int j = 0; j < KMAX + 1; j++)
+    if ((u32)j < nB) acc += (u128)yb[j] * ctx->B_to_msk[j];
+  const u64 alpha = mul_shoup(reduce128(acc, msk) + msk.q - fl_msk, ctx->inv_B_mod_msk, msk.q);
+  const bool neg = alpha > (msk.q >> 1);
+  u64* o = out + (size_t)poly * K * n;
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const DevMod& qm = ctx->mod[i];
+      u128 a = 0;
+#pragma unroll
+      for (int j = 0; j < KMAX + 1; j++)
+        if ((u32)j < nB) a += (u128)yb[j] * ctx->B_to_q[i][j];
+      if (neg)
+        a += (u128)(msk.q - alpha) * ctx->B_mod_q[i];
+      else
+        a += (u128)alpha * (qm.q - ctx->B_mod_q[i]);
+      o[(size_t)i * n + k] = reduce128(a, qm);
+    }
+  }
+}
+
+// ---- key switching ----
+// target: u64[ops][K][N] with op stride `tstride` words; T: u64[ops][KK][K][N]
+__global__ __launch_bounds__(kCoefThreads) void ks_decompose_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ target,
+                                                                    size_t tstride, u64* __restrict__ T) {
+  const u32 n = ctx->n, K = ctx->K, KK = ctx->KK;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 J = blockIdx.y, op = blockIdx.z;
+  if (k >= n) return;
+  const u64 x = target[(size_t)op * tstride + (size_t)J * n + k];
+  const u64 qJ = ctx->mod[J].q;
+  for (u32 I = 0; I < KK; I++) {
+    const DevMod& mI = ctx->mod[I];
+    T[(((size_t)op * KK + I) * K + J) * n + k] = qJ <= mI.q ? x : reduce64(x, mI);
+  }
+}
+
+// ACC[op][c][I][k] = sum_J T[op][I][J][k] * key[J][c][I][k]   (128-bit lazy sum, one reduction)
+__global__ __launch_bounds__(kCoefThreads) void ks_mac_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ T,
+                                                              const u64* __restrict__ key, u64* __restrict__ ACC) {
+  const u32 n = ctx->n, K = ctx->K, KK = ctx->KK;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 I = blockIdx.y, op = blockIdx.z;
+  if (k >= n) return;
+  const DevMod& mI = ctx->mod[I];
+  u128 a0 = 0, a1 = 0;
+  for (u32 J = 0; J < K; J++) {
+    const u64 tv = T[(((size_t)op * KK + I) * K + J) * n + k];
+    a0 += (u128)tv * key[(((size_t)J * 2 + 0) * KK + I) * n + k];
+    a1 += (u128)tv * key[(((size_t)J * 2 + 1) * KK + I) * n + k];
+  }
+  ACC[(((size_t)op * 2 + 0) * KK + I) * n + k] = reduce128(a0, mI);
+  ACC[(((size_t)op * 2 + 1) * KK + I) * n + k] = reduce128(a1, mI);
+}
+
+// out[op][c][J] = base[op][c][J] + (ACC[op][c][J] - round-fix(ACC[op][c][sp])) * q_sp^{-1}
+// base: op stride bstride words, poly stride K*N; base_mask bit c = 0 means "treat base poly c as zero"
+__global__ __launch_bounds__(kCoefThreads) void ks_moddown_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ACC,
+                                                                  const u64* __restrict__ base, size_t bstride, u32 base_mask,
+                                                                  u64* __restrict__ out) {
+  const u32 n = ctx->n, K = ctx->K, KK = ctx->KK;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 c = blockIdx.y, op = blockIdx.z;
+  if (k >= n) return;
+  const DevMod& sp = ctx->mod[KK - 1];
+  const u64* acc = ACC + ((size_t)op * 2 + c) * KK * n;
+  const u64 tl = add_mod(acc[(size_t)(KK - 1) * n + k], ctx->qsp_half, sp.q);
+  for (u32 J = 0; J < K; J++) {
+    const DevMod& mj = ctx->mod[J];
+    u64 tk = sp.q > mj.q ? reduce64(tl, mj) : tl;
+    tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+    u64 d = sub_mod(acc[(size_t)J * n + k], tk, mj.q);
+    d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
+    const u64 b = ((base_mask >> c) & 1u) ? base[(size_t)op * bstride + ((size_t)c * K + J) * n + k] : 0;
+    out[(((size_t)op * 2 + c) * K + J) * n + k] = add_mod(b, d, mj.q);
+  }
+}
+
+// ---- Galois automorphism x -> x^g in coefficient form (gather form) ----
+// in/out: u64[npoly][K][N]; ginv = g^{-1} mod 2N
+__global__ __launch_bounds__(kCoefThreads) void galois_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in, u64* __restrict__ out, u32 ginv) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 o = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 poly = blockIdx.y;
+  if (o >= n) return;
+  const u32 kk = (u32)(((u64)o * ginv) & (2 * n - 1));
+  const bool negate = kk >= n;
+  const u32 src = negate ? kk - n : kk;
+  for (u32 i = 0; i < K; i++) {
+    const u64 v = in[((size_t)poly * K + i) * n + src];
+    out[((size_t)poly * K + i) * n + o] = negate ? neg_mod(v, ctx->mod[i].q) : v;
+  }
+}
+
+// ---- element-wise ciphertext ops ----
+// mode 0: a+b, 1: a-b, 2: -a.  polys laid out u64[npoly][K][N]
+__global__ __launch_bounds__(kCoefThreads) void eltwise_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ a, const u64* __restrict__ b,
+                                                               u64* __restrict__ out, int mode) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 res = blockIdx.y;  // global residue-poly index
+  if (k >= n) return;
+  const u64 q = ctx->mod[res % K].q;
+  const size_t off = (size_t)res * n + k;
+  u64 r;
+  if (mode == 0)
+    r = add_mod(a[off], b[off], q);
+  else if (mode == 1)
+    r = sub_mod(a[off], b[off], q);
+  else
+    r = neg_mod(a[off], q);
+  out[off] = r;
+}
+
+// c0 +/-= round(q/t * m)  (SEAL multiply_add_plain_with_scaling_variant); ct u64[ops][size][K][N]
+// plain u64[ops or 1][N] (values < t, zero padded); pstride = 0 broadcasts one plaintext
+__global__ __launch_bounds__(kCoefThreads) void plain_addsub_kernel(const DevCtx* __restrict__ ctx, u64* __restrict__ ct, size_t ctstride,
+                                                                    const u64* __restrict__ plain, size_t pstride, int sub) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 op = blockIdx.y;
+  if (k >= n) return;
+  const u64 m = plain[(size_t)op * pstride + k];
+  const u64 t = ctx->t;
+  const u128 num = (u128)m * ctx->q_mod_t + ctx->t_half_up;
+  const u64 fix = (u64)(num / t);
+  for (u32 i = 0; i < K; i++) {
+    const DevMod& qm = ctx->mod[i];
+    const u64 v = reduce128((u128)m * ctx->q_div_t_mod_q[i] + fix, qm);
+    u64* d = ct + (size_t)op * ctstride + (size_t)i * n + k;
+    *d = sub ? sub_mod(*d, v, qm.q) : add_mod(*d, v, qm.q);
+  }
+}
+
+// lift plaintext coefficients (mod t, centred) to every q_i: out u64[ops][K][N]
+__global__ __launch_bounds__(kCoefThreads) void plain_lift_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ plain, size_t pstride,
+                                                                  u64* __restrict__ out) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 op = blockIdx.y;
+  if (k >= n) return;
+  const u64 m = plain[(size_t)op * pstride + k];
+  const bool upper = m >= ctx->t_half_up;
+  for (u32 i = 0; i < K; i++) {
+    const DevMod& qm = ctx->mod[i];
+    u64 v;
+    if (!upper)
+      v = reduce64(m, qm);
+    else
+      v = neg_mod(reduce64(ctx->t - m, qm), qm.q);
+    out[((size_t)op * K + i) * n + k] = v;
+  }
+}
+
+// x[op][p][i][k] = x * pl[op or 0][i][k] mod q_i (both NTT form)
+__global__ __launch_bounds__(kCoefThreads) void dyadic_plain_kernel(const DevCtx* __restrict__ ctx, u64* __restrict__ x, u32 size,
+                                                                    const u64* __restrict__ pl, size_t plstride) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 i = blockIdx.y, op = blockIdx.z;
+  if (k >= n) return;
+  const DevMod& qm = ctx->mod[i];
+  const u64 pv = pl[(size_t)op * plstride + (size_t)i * n + k];
+  for (u32 p = 0; p < size; p++) {
+    u64* d = x + (((size_t)op * size + p) * K + i) * n + k;
+    *d = mul_mod(*d, pv, qm);
+  }
+}
+
+// negacyclic multiply by the monomial coeff * x^e (SEAL negacyclic_multiply_poly_mono_coeffmod)
+// coeff_rns: u64[K] per-prime scalar (device)
+__global__ __launch_bounds__(kCoefThreads) void mono_mul_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in, u64* __restrict__ out,
+                                                                const u64* __restrict__ coeff_rns, u32 e) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 res = blockIdx.y;
+  if (k >= n) return;
+  const u32 i = res % K;
+  const DevMod& qm = ctx->mod[i];
+  u64 v = mul_mod(in[(size_t)res * n + k], coeff_rns[i], qm);
+  u32 idx = k + e;
+  if (idx >= n) {
+    idx -= n;
+    v = neg_mod(v, qm.q);
+  }
+  out[(size_t)res * n + idx] = v;
+}
+
+// flags[op] |= 1 if any word of polys 1..size-1 of ciphertext op is non-zero (transparent check)
+__global__ __launch_bounds__(kCoefThreads) void nonzero_tail_kernel(const u64* __restrict__ ct, size_t words_per_ct, size_t skip_words,
+                                                                    u32* __restrict__ flags) {
+  const u32 op = blockIdx.y;
+  const u64* p = ct + (size_t)op * words_per_ct + skip_words;
+  const size_t len = words_per_ct - skip_words;
+  bool nz = false;
+  for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < len; i += (size_t)gridDim.x * kCoefThreads) nz |= p[i] != 0;
+  if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&flags[op], 1u);
+}
+
+// =====================================================================================
+// host launchers
+// =====================================================================================
+
+static inline dim3 coef_grid(u32 n, u32 y, u32 z = 1) { return dim3((n + kCoefThreads - 1) / kCoefThreads, y, z); }
+
+template <int KMAX>
+static void launch_extend_t(const DevCtx* ctx, u32 n, const u64* in0, u32 sa, const u64* in1, u32 sb, size_t ops, u64* out, hipStream_t s) {
+  behz_extend_kernel<KMAX><<<coef_grid(n, (u32)(ops * (sa + sb))), kCoefThreads, 0, s>>>(ctx, in0, sa, in1, sb, out);
+}
+
+hipError_t launch_behz_extend(const DevCtx* ctx, u32 n, u32 K, const u64* in0, u32 sa, const u64* in1, u32 sb, size_t ops, u64* out, hipStream_t s) {
+  if (K <= 4)
+    launch_extend_t<4>(ctx, n, in0, sa, in1, sb, ops, out, s);
+  else if (K <= 8)
+    launch_extend_t<8>(ctx, n, in0, sa, in1, sb, ops, out, s);
+  else
+    launch_extend_t<16>(ctx, n, in0, sa, in1, sb, ops, out, s);
+  return hipGetLastError();
+}
+
+hipError_t launch_tensor(const DevCtx* ctx, u32 n, u32 R, const u64* ext, u32 sa, u32 sb, u64* D, size_t ops, hipStream_t s) {
+  tensor_kernel<<<coef_grid(n, R, (u32)ops), kCoefThreads, 0, s>>>(ctx, ext, sa, sb, D);
+  return hipGetLastError();
+}
+
+hipError_t launch_behz_floor_sk(const DevCtx* ctx, u32 n, u32 K, const u64* D, u64* out, size_t polys, hipStream_t s) {
+  if (K <= 4)
+    behz_floor_sk_kernel<4><<<coef_grid(n, (u32)polys), kCoefThreads, 0, s>>>(ctx, D, out);
+  else if (K <= 8)
+    behz_floor_sk_kernel<8><<<coef_grid(n, (u32)polys), kCoefThreads, 0, s>>>(ctx, D, out);
+  else
+    behz_floor_sk_kernel<16><<<coef_grid(n, (u32)polys), kCoefThreads, 0, s>>>(ctx, D, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_ks_decompose(const DevCtx* ctx, u32 n, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
+  ks_decompose_kernel<<<coef_grid(n, K, (u32)ops), kCoefThreads, 0, s>>>(ctx, target, tstride, T);
+  return hipGetLastError();
+}
+
+hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s) {
+  ks_mac_kernel<<<coef_grid(n, KK, (u32)ops), kCoefThreads, 0, s>>>(ctx, T, key, ACC);
+  return hipGetLastError();
+}
+
+hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, u64* out, size_t ops, hipStream_t s) {
+  ks_moddown_kernel<<<coef_grid(n, 2, (u32)ops), kCoefThreads, 0, s>>>(ctx, ACC, base, bstride, base_mask, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_galois(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t polys, u32 ginv, hipStream_t s) {
+  galois_kernel<<<coef_grid(n, (u32)polys), kCoefThreads, 0, s>>>(ctx, in, out, ginv);
+  return hipGetLastError();
+}
+
+hipError_t launch_eltwise(const DevCtx* ctx, u32 n, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode, hipStream_t s) {
+  // caller guarantees residue_polys <= 65535 and that `a` starts at a residue index that is a multiple of K
+  eltwise_kernel<<<coef_grid(n, (u32)residue_polys), kCoefThreads, 0, s>>>(ctx, a, b, out, mode);
+  return hipGetLastError();
+}
+
+hipError_t launch_plain_addsub(const DevCtx* ctx, u32 n, u64* ct, size_t ctstride, const u64* plain, size_t pstride, size_t ops, int sub, hipStream_t s) {
+  plain_addsub_kernel<<<coef_grid(n, (u32)ops), kCoefThreads, 0, s>>>(ctx, ct, ctstride, plain, pstride, sub);
+  return hipGetLastError();
+}
+
+hipError_t launch_plain_lift(const DevCtx* ctx, u32 n, const u64* plain, size_t pstride, u64* out, size_t ops, hipStream_t s) {
+  plain_lift_kernel<<<coef_grid(n, (u32)ops), kCoefThreads, 0, s>>>(ctx, plain, pstride, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_dyadic_plain(const DevCtx* ctx, u32 n, u32 K, u64* x, u32 size, const u64* pl, size_t plstride, size_t ops, hipStream_t s) {
+  dyadic_plain_kernel<<<coef_grid(n, K, (u32)ops), kCoefThreads, 0, s>>>(ctx, x, size, pl, plstride);
+  return hipGetLastError();
+}
+
+hipError_t launch_mono_mul(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t residue_polys, const u64* coeff_rns, u32 e, hipStream_t s) {
+  mono_mul_kernel<<<coef_grid(n, (u32)residue_polys), kCoefThreads, 0, s>>>(ctx, in, out, coeff_rns, e);
+  return hipGetLastError();
+}
+
+hipError_t launch_nonzero_tail(const u64* ct, size_t words_per_ct, size_t skip_words, u32* flags, size_t ops, hipStream_t s) {
+  nonzero_tail_kernel<<<dim3(64, (u32)ops), kCoefThreads, 0, s>>>(ct, words_per_ct, skip_words, flags);
+  return hipGetLastError();
+}
+
+}  // namespace hipbfv

@@ -1,0 +1,534 @@
+"""Host-side mirror of the `seal_fhe` crate surface for the evaluator path, on top of the C ABI.
+
+The reference's host layer for this path is the Rust crate `seal_fhe` (seal_fhe/src/*.rs); no Rust
+toolchain exists in this environment, so the same interface is mirrored here in Python with the
+same type and method names, argument meaning and error behaviour, each method calling exactly the
+C entry point the Rust method calls (cited per method).  This lets the parity tests read like the
+reference's own tests (seal_fhe/src/bfv_evaluator.rs:322-970).
+
+Nothing here computes on the CPU: every operation is a call into libhipbfv.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+class HipBfvError(Exception):
+    """Mirror of seal_fhe::Error (seal_fhe/src/error.rs:10-78)."""
+
+    NAMES = {
+        _lib.E_POINTER: "InvalidPointer",
+        _lib.E_INVALIDARG: "InvalidArgument",
+        _lib.E_OUTOFMEMORY: "OutOfMemory",
+        _lib.E_UNEXPECTED: "Unexpected",
+        _lib.COR_E_IO: "InternalError",
+        _lib.COR_E_INVALIDOPERATION: "InternalError",
+    }
+
+    def __init__(self, hresult: int, detail: str = ""):
+        self.hresult = hresult & 0xFFFFFFFF
+        self.kind = self.NAMES.get(self.hresult, "Unknown")
+        super().__init__(f"{self.kind} (0x{self.hresult:08X}){': ' + detail if detail else ''}")
+
+
+def _check(hr: int) -> None:
+    """convert_seal_error (seal_fhe/src/error.rs:82-91)."""
+    if hr != 0:
+        raise HipBfvError(hr, _lib.last_error())
+
+
+class SecurityLevel:
+    """seal_fhe/src/context.rs:14-40"""
+
+    NONE = 0
+    TC128 = 128
+    TC192 = 192
+    TC256 = 256
+
+
+class Modulus:
+    """seal_fhe/src/modulus.rs:95-131"""
+
+    def __init__(self, value: int):
+        self._h = C.c_void_p()
+        _check(_lib.load().Modulus_Create1(value, C.byref(self._h)))
+
+    @classmethod
+    def _adopt(cls, handle: int) -> "Modulus":
+        m = cls.__new__(cls)
+        m._h = C.c_void_p(handle)
+        return m
+
+    def value(self) -> int:
+        v = C.c_uint64()
+        _check(_lib.load().Modulus_Value(self._h, C.byref(v)))
+        return v.value
+
+    def get_handle(self):
+        return self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().Modulus_Destroy(self._h)
+            self._h = None
+
+    def __eq__(self, other):
+        return isinstance(other, Modulus) and self.value() == other.value()
+
+    def __repr__(self):
+        return f"Modulus({self.value()})"
+
+
+class CoefficientModulus:
+    """seal_fhe/src/modulus.rs:149-250"""
+
+    @staticmethod
+    def create(degree: int, bit_sizes: Sequence[int]) -> list[Modulus]:
+        n = len(bit_sizes)
+        bits = (C.c_int * n)(*bit_sizes)
+        out = (C.c_void_p * n)()
+        _check(_lib.load().CoeffModulus_Create1(degree, n, bits, out))
+        return [Modulus._adopt(out[i]) for i in range(n)]
+
+    @staticmethod
+    def bfv_default(degree: int, security_level: int = SecurityLevel.TC128) -> list[Modulus]:
+        length = C.c_uint64()
+        L = _lib.load()
+        _check(L.CoeffModulus_BFVDefault(degree, security_level, C.byref(length), None))
+        out = (C.c_void_p * length.value)()
+        _check(L.CoeffModulus_BFVDefault(degree, security_level, C.byref(length), out))
+        return [Modulus._adopt(out[i]) for i in range(length.value)]
+
+    @staticmethod
+    def max_bit_count(degree: int, security_level: int = SecurityLevel.TC128) -> int:
+        bits = C.c_int()
+        _check(_lib.load().CoeffModulus_MaxBitCount(degree, security_level, C.byref(bits)))
+        return bits.value
+
+
+class PlainModulus:
+    """seal_fhe/src/modulus.rs:252-275"""
+
+    @staticmethod
+    def batching(degree: int, bit_size: int) -> Modulus:
+        return CoefficientModulus.create(degree, [bit_size])[0]
+
+    @staticmethod
+    def raw(val: int) -> Modulus:
+        return Modulus(val)
+
+
+class EncryptionParameters:
+    """seal_fhe/src/encryption_parameters.rs:60-200 (BFV only)"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def get_handle(self):
+        return self._h
+
+    def get_poly_modulus_degree(self) -> int:
+        v = C.c_uint64()
+        _check(_lib.load().EncParams_GetPolyModulusDegree(self._h, C.byref(v)))
+        return v.value
+
+    def get_plain_modulus(self) -> Modulus:
+        h = C.c_void_p()
+        _check(_lib.load().EncParams_GetPlainModulus(self._h, C.byref(h)))
+        return Modulus._adopt(h.value)
+
+    def get_coefficient_modulus(self) -> list[Modulus]:
+        L = _lib.load()
+        n = C.c_uint64()
+        _check(L.EncParams_GetCoeffModulus(self._h, C.byref(n), None))
+        out = (C.c_void_p * n.value)()
+        _check(L.EncParams_GetCoeffModulus(self._h, C.byref(n), out))
+        return [Modulus._adopt(out[i]) for i in range(n.value)]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().EncParams_Destroy(self._h)
+            self._h = None
+
+
+class BfvEncryptionParametersBuilder:
+    """seal_fhe/src/encryption_parameters.rs:205-330"""
+
+    def __init__(self):
+        self._degree = None
+        self._coeff = None
+        self._plain = None
+
+    def set_poly_modulus_degree(self, degree: int):
+        self._degree = degree
+        return self
+
+    def set_coefficient_modulus(self, modulus: Sequence[Modulus]):
+        self._coeff = list(modulus)
+        return self
+
+    def set_plain_modulus(self, modulus: Modulus):
+        self._plain = modulus
+        return self
+
+    def set_plain_modulus_u64(self, modulus: int):
+        self._plain = int(modulus)
+        return self
+
+    def build(self) -> EncryptionParameters:
+        if self._degree is None:
+            raise ValueError("DegreeNotSet")
+        if self._coeff is None:
+            raise ValueError("CoefficientModulusNotSet")
+        if self._plain is None:
+            raise ValueError("PlainModulusNotSet")
+        L = _lib.load()
+        h = C.c_void_p()
+        _check(L.EncParams_Create1(1, C.byref(h)))
+        p = EncryptionParameters(h)
+        _check(L.EncParams_SetPolyModulusDegree(h, self._degree))
+        arr = (C.c_void_p * len(self._coeff))(*[m.get_handle() for m in self._coeff])
+        _check(L.EncParams_SetCoeffModulus(h, len(self._coeff), arr))
+        if isinstance(self._plain, Modulus):
+            _check(L.EncParams_SetPlainModulus1(h, self._plain.get_handle()))
+        else:
+            _check(L.EncParams_SetPlainModulus2(h, self._plain))
+        return p
+
+
+class Context:
+    """seal_fhe/src/context.rs:45-115"""
+
+    def __init__(self, params: EncryptionParameters, expand_mod_chain: bool = True, security_level: int = SecurityLevel.TC128):
+        self._h = C.c_void_p()
+        _check(_lib.load().SEALContext_Create(params.get_handle(), expand_mod_chain, security_level, C.byref(self._h)))
+        self._query()
+
+    @classmethod
+    def new_insecure(cls, params: EncryptionParameters, expand_mod_chain: bool = True) -> "Context":
+        return cls(params, expand_mod_chain, SecurityLevel.NONE)
+
+    @classmethod
+    def from_raw(cls, poly_modulus_degree: int, coeff_modulus: Iterable[int], plain_modulus: int) -> "Context":
+        """hipbfv extension: build a context from plain integers (no security-level check)."""
+        c = cls.__new__(cls)
+        cm = np.ascontiguousarray(np.asarray(list(coeff_modulus), dtype=np.uint64))
+        c._h = C.c_void_p()
+        _check(
+            _lib.load().hipbfv_Context_Create(
+                poly_modulus_degree, cm.ctypes.data_as(_lib.u64p), cm.size, plain_modulus, C.byref(c._h)
+            )
+        )
+        c._query()
+        return c
+
+    def _query(self):
+        n, K, KK, t = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(_lib.load().hipbfv_Context_Info(self._h, C.byref(n), C.byref(K), C.byref(KK), C.byref(t)))
+        self.poly_modulus_degree, self.K, self.KK, self.plain_modulus = n.value, K.value, KK.value, t.value
+        v = C.c_uint64()
+        self.key_primes = []
+        for i in range(self.KK):
+            _check(_lib.load().hipbfv_Context_GetPrime(self._h, i, C.byref(v)))
+            self.key_primes.append(v.value)
+
+    def get_handle(self):
+        return self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().SEALContext_Destroy(self._h)
+            self._h = None
+
+
+class Plaintext:
+    """seal_fhe/src/plaintext_ciphertext.rs:36-300"""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(_lib.load().Plaintext_Create1(None, C.byref(self._h)))
+
+    @classmethod
+    def from_coefficients(cls, coeffs: Sequence[int]) -> "Plaintext":
+        p = cls()
+        p.resize(len(coeffs))
+        for i, c in enumerate(coeffs):
+            if c:
+                p.set_coefficient(i, int(c))
+        return p
+
+    def get_handle(self):
+        return self._h
+
+    def resize(self, count: int):
+        _check(_lib.load().Plaintext_Resize(self._h, count))
+
+    def len(self) -> int:
+        v = C.c_uint64()
+        _check(_lib.load().Plaintext_CoeffCount(self._h, C.byref(v)))
+        return v.value
+
+    __len__ = len
+
+    def get_coefficient(self, index: int) -> int:
+        v = C.c_uint64()
+        _check(_lib.load().Plaintext_CoeffAt(self._h, index, C.byref(v)))
+        return v.value
+
+    def set_coefficient(self, index: int, value: int):
+        _check(_lib.load().Plaintext_SetCoeffAt(self._h, index, value))
+
+    def is_ntt_form(self) -> bool:
+        v = C.c_bool()
+        _check(_lib.load().Plaintext_IsNTTForm(self._h, C.byref(v)))
+        return v.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().Plaintext_Destroy(self._h)
+            self._h = None
+
+
+class Ciphertext:
+    """seal_fhe/src/plaintext_ciphertext.rs:326-504"""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(_lib.load().Ciphertext_Create1(None, C.byref(self._h)))
+
+    @classmethod
+    def from_array(cls, ctx: Context, data: np.ndarray) -> "Ciphertext":
+        """hipbfv extension (stands in for Ciphertext::from_bytes): data = uint64[size][K][N]."""
+        data = np.ascontiguousarray(np.asarray(data, dtype=np.uint64))
+        assert data.ndim == 3 and data.shape[1] == ctx.K and data.shape[2] == ctx.poly_modulus_degree, data.shape
+        c = cls()
+        _check(_lib.load().hipbfv_Ciphertext_Assign(c._h, ctx.get_handle(), data.shape[0], data.ctypes.data_as(_lib.u64p)))
+        return c
+
+    def to_array(self) -> np.ndarray:
+        size, K, n = self.num_polynomials(), self.coeff_modulus_size(), self.poly_modulus_degree()
+        out = np.zeros((size, K, n), dtype=np.uint64)
+        _check(_lib.load().hipbfv_Ciphertext_Export(self._h, out.ctypes.data_as(_lib.u64p), out.size))
+        return out
+
+    def clone(self) -> "Ciphertext":
+        c = Ciphertext.__new__(Ciphertext)
+        c._h = C.c_void_p()
+        _check(_lib.load().Ciphertext_Create2(self._h, C.byref(c._h)))
+        return c
+
+    def get_handle(self):
+        return self._h
+
+    def num_polynomials(self) -> int:
+        v = C.c_uint64()
+        _check(_lib.load().Ciphertext_Size(self._h, C.byref(v)))
+        return v.value
+
+    def coeff_modulus_size(self) -> int:
+        v = C.c_uint64()
+        _check(_lib.load().Ciphertext_CoeffModulusSize(self._h, C.byref(v)))
+        return v.value
+
+    def poly_modulus_degree(self) -> int:
+        v = C.c_uint64()
+        _check(_lib.load().Ciphertext_PolyModulusDegree(self._h, C.byref(v)))
+        return v.value
+
+    def get_data(self, index: int) -> int:
+        v = C.c_uint64()
+        _check(_lib.load().Ciphertext_GetDataAt1(self._h, index, C.byref(v)))
+        return v.value
+
+    def get_coefficient(self, poly_index: int, coeff_index: int) -> list[int]:
+        k = self.coeff_modulus_size()
+        buf = (C.c_uint64 * k)()
+        _check(_lib.load().Ciphertext_GetDataAt2(self._h, poly_index, coeff_index, buf))
+        return [int(x) for x in buf]
+
+    def is_ntt_form(self) -> bool:
+        v = C.c_bool()
+        _check(_lib.load().Ciphertext_IsNTTForm(self._h, C.byref(v)))
+        return v.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().Ciphertext_Destroy(self._h)
+            self._h = None
+
+
+class _KSwitchKeys:
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(_lib.load().KSwitchKeys_Create1(C.byref(self._h)))
+
+    def get_handle(self):
+        return self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().KSwitchKeys_Destroy(self._h)
+            self._h = None
+
+
+class RelinearizationKeys(_KSwitchKeys):
+    """seal_fhe/src/key_generator.rs:467-575"""
+
+    @classmethod
+    def from_array(cls, ctx: Context, key: np.ndarray) -> "RelinearizationKeys":
+        """hipbfv extension (stands in for RelinearizationKeys::from_bytes): key = uint64[K][2][K+1][N]."""
+        key = np.ascontiguousarray(np.asarray(key, dtype=np.uint64))
+        assert key.shape == (ctx.K, 2, ctx.KK, ctx.poly_modulus_degree), key.shape
+        k = cls()
+        _check(_lib.load().hipbfv_KSwitchKeys_AssignRelin(k._h, ctx.get_handle(), key.ctypes.data_as(_lib.u64p)))
+        return k
+
+
+class GaloisKeys(_KSwitchKeys):
+    """seal_fhe/src/key_generator.rs:631-729"""
+
+    @classmethod
+    def from_arrays(cls, ctx: Context, keys: dict[int, np.ndarray]) -> "GaloisKeys":
+        """hipbfv extension: keys maps Galois element -> uint64[K][2][K+1][N]."""
+        g = cls()
+        for elt, key in keys.items():
+            key = np.ascontiguousarray(np.asarray(key, dtype=np.uint64))
+            assert key.shape == (ctx.K, 2, ctx.KK, ctx.poly_modulus_degree), key.shape
+            _check(_lib.load().hipbfv_KSwitchKeys_AssignGalois(g._h, ctx.get_handle(), int(elt), key.ctypes.data_as(_lib.u64p)))
+        return g
+
+
+class BFVEvaluator:
+    """Mirror of `impl Evaluator for BFVEvaluator` (seal_fhe/src/bfv_evaluator.rs:12-248,
+    evaluator_base.rs:55-407).  Out-of-place methods allocate an empty Ciphertext and let the callee
+    size it; `_inplace` methods pass the operand handle as the destination, exactly like the crate."""
+
+    def __init__(self, ctx: Context):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        _check(_lib.load().Evaluator_Create(ctx.get_handle(), C.byref(self._h)))  # evaluator_base.rs:74-80
+
+    def get_handle(self):
+        return self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().Evaluator_Destroy(self._h)
+            self._h = None
+
+    # -- negate / add / sub (evaluator_base.rs:89-182)
+    def negate_inplace(self, a: Ciphertext) -> None:
+        _check(_lib.load().Evaluator_Negate(self._h, a._h, a._h))
+
+    def negate(self, a: Ciphertext) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_Negate(self._h, a._h, out._h))
+        return out
+
+    def add_inplace(self, a: Ciphertext, b: Ciphertext) -> None:
+        _check(_lib.load().Evaluator_Add(self._h, a._h, b._h, a._h))
+
+    def add(self, a: Ciphertext, b: Ciphertext) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_Add(self._h, a._h, b._h, out._h))
+        return out
+
+    def add_many(self, a: Sequence[Ciphertext]) -> Ciphertext:
+        out = Ciphertext()
+        arr = (C.c_void_p * len(a))(*[x._h for x in a])
+        _check(_lib.load().Evaluator_AddMany(self._h, len(a), arr, out._h))
+        return out
+
+    def sub_inplace(self, a: Ciphertext, b: Ciphertext) -> None:
+        _check(_lib.load().Evaluator_Sub(self._h, a._h, b._h, a._h))
+
+    def sub(self, a: Ciphertext, b: Ciphertext) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_Sub(self._h, a._h, b._h, out._h))
+        return out
+
+    # -- multiply / square (evaluator_base.rs:184-260)
+    def multiply_inplace(self, a: Ciphertext, b: Ciphertext) -> None:
+        _check(_lib.load().Evaluator_Multiply(self._h, a._h, b._h, a._h, None))
+
+    def multiply(self, a: Ciphertext, b: Ciphertext) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_Multiply(self._h, a._h, b._h, out._h, None))
+        return out
+
+    def multiply_many(self, a: Sequence[Ciphertext], relin_keys: RelinearizationKeys) -> Ciphertext:
+        out = Ciphertext()
+        arr = (C.c_void_p * len(a))(*[x._h for x in a])
+        _check(_lib.load().Evaluator_MultiplyMany(self._h, len(a), arr, relin_keys._h, out._h, None))
+        return out
+
+    def square_inplace(self, a: Ciphertext) -> None:
+        _check(_lib.load().Evaluator_Square(self._h, a._h, a._h, None))
+
+    def square(self, a: Ciphertext) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_Square(self._h, a._h, out._h, None))
+        return out
+
+    def exponentiate(self, a: Ciphertext, exponent: int, relin_keys: RelinearizationKeys) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_Exponentiate(self._h, a._h, exponent, relin_keys._h, out._h, None))
+        return out
+
+    def exponentiate_inplace(self, a: Ciphertext, exponent: int, relin_keys: RelinearizationKeys) -> None:
+        _check(_lib.load().Evaluator_Exponentiate(self._h, a._h, exponent, relin_keys._h, a._h, None))
+
+    # -- plaintext operands (evaluator_base.rs:320-404)
+    def add_plain(self, a: Ciphertext, b: Plaintext) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_AddPlain(self._h, a._h, b._h, out._h))
+        return out
+
+    def add_plain_inplace(self, a: Ciphertext, b: Plaintext) -> None:
+        _check(_lib.load().Evaluator_AddPlain(self._h, a._h, b._h, a._h))
+
+    def sub_plain(self, a: Ciphertext, b: Plaintext) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_SubPlain(self._h, a._h, b._h, out._h))
+        return out
+
+    def sub_plain_inplace(self, a: Ciphertext, b: Plaintext) -> None:
+        _check(_lib.load().Evaluator_SubPlain(self._h, a._h, b._h, a._h))
+
+    def multiply_plain(self, a: Ciphertext, b: Plaintext) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_MultiplyPlain(self._h, a._h, b._h, out._h, None))
+        return out
+
+    def multiply_plain_inplace(self, a: Ciphertext, b: Plaintext) -> None:
+        _check(_lib.load().Evaluator_MultiplyPlain(self._h, a._h, b._h, a._h, None))
+
+    # -- key switching (bfv_evaluator.rs:143-247)
+    def relinearize_inplace(self, a: Ciphertext, relin_keys: RelinearizationKeys) -> None:
+        _check(_lib.load().Evaluator_Relinearize(self._h, a._h, relin_keys._h, a._h, None))
+
+    def relinearize(self, a: Ciphertext, relin_keys: RelinearizationKeys) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_Relinearize(self._h, a._h, relin_keys._h, out._h, None))
+        return out
+
+    def rotate_rows(self, a: Ciphertext, steps: int, galois_keys: GaloisKeys) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_RotateRows(self._h, a._h, steps, galois_keys._h, out._h, None))
+        return out
+
+    def rotate_rows_inplace(self, a: Ciphertext, steps: int, galois_keys: GaloisKeys) -> None:
+        _check(_lib.load().Evaluator_RotateRows(self._h, a._h, steps, galois_keys._h, a._h, None))
+
+    def rotate_columns(self, a: Ciphertext, galois_keys: GaloisKeys) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_RotateColumns(self._h, a._h, galois_keys._h, out._h, None))
+        return out
+
+    def rotate_columns_inplace(self, a: Ciphertext, galois_keys: GaloisKeys) -> None:
+        _check(_lib.load().Evaluator_RotateColumns(self._h, a._h, galois_keys._h, a._h, None))

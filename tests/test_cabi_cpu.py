@@ -1,0 +1,108 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/hipbfv.h declares,
+and host-only entry points (parameter objects, prime generation, plaintext handles) behave like the
+reference's (seal_fhe/src/modulus.rs:279-313, encryption_parameters.rs:340-365).  No compute call
+needs a GPU here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sunscreen_amd import _lib
+
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "hipbfv.h")).read()
+    declared = re.findall(r"^long\s+([A-Za-z_0-9]+)\s*\(", header, flags=re.M)
+    assert len(declared) >= 70
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/hipbfv.h but not exported"
+    assert set(declared) == set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped package must not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "sunscreen_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                for line in text.splitlines():
+                    code = line.split("//")[0].split("#")[0] if not f.endswith(".py") else line.split("#")[0]
+                    assert "import oracle" not in code and "from oracle" not in code and "liboracle" not in code and "ora_" not in code, (f, line)
+
+
+def test_modulus_and_prime_generation_known_answers():
+    from sunscreen_amd import CoefficientModulus, Modulus, PlainModulus, SecurityLevel
+
+    assert PlainModulus.batching(1024, 20).value() == 1038337
+    assert PlainModulus.batching(8192, 17).value() == 114689
+    assert [m.value() for m in CoefficientModulus.create(8192, [50, 30, 30, 50, 50])] == [
+        1125899905744897,
+        1073643521,
+        1073692673,
+        1125899906629633,
+        1125899906826241,
+    ]
+    assert [m.value() for m in CoefficientModulus.bfv_default(1024, SecurityLevel.TC128)] == [132120577]
+    assert [m.value() for m in CoefficientModulus.bfv_default(1024, SecurityLevel.TC192)] == [520193]
+    assert [m.value() for m in CoefficientModulus.bfv_default(1024, SecurityLevel.TC256)] == [12289]
+    assert [m.value() for m in CoefficientModulus.bfv_default(8192)] == [
+        0x7FFFFFD8001,
+        0x7FFFFFC8001,
+        0xFFFFFFFC001,
+        0xFFFFFF6C001,
+        0xFFFFFEBC001,
+    ]
+    assert CoefficientModulus.max_bit_count(8192) == 218
+    assert Modulus(12345).value() == 12345
+    assert Modulus(5) == Modulus(5)
+
+
+def test_prime_search_matches_oracle_on_a_sweep():
+    from oracle import bfv_oracle as O
+    from sunscreen_amd import CoefficientModulus
+
+    for n, bits in [(1024, [27]), (4096, [36, 36, 37]), (16384, [48, 48, 49, 49, 49]), (32768, [55, 55, 56]), (8192, [60, 20, 60])]:
+        assert [m.value() for m in CoefficientModulus.create(n, bits)] == O.coeff_modulus_create(n, bits)
+
+
+def test_params_builder_and_plaintext_handles():
+    from sunscreen_amd import BfvEncryptionParametersBuilder, CoefficientModulus, HipBfvError, PlainModulus, Plaintext
+
+    p = (
+        BfvEncryptionParametersBuilder()
+        .set_poly_modulus_degree(4096)
+        .set_coefficient_modulus(CoefficientModulus.bfv_default(4096))
+        .set_plain_modulus_u64(262144)
+        .build()
+    )
+    assert p.get_poly_modulus_degree() == 4096
+    assert p.get_plain_modulus().value() == 262144
+    assert [m.value() for m in p.get_coefficient_modulus()] == [0xFFFFEE001, 0xFFFFC4001, 0x1FFFFE0001]
+    with pytest.raises(ValueError):
+        BfvEncryptionParametersBuilder().set_poly_modulus_degree(4096).build()
+    pt = Plaintext()
+    assert pt.len() == 0 and not pt.is_ntt_form()
+    pt.resize(4)
+    pt.set_coefficient(2, 77)
+    assert pt.get_coefficient(2) == 77 and pt.get_coefficient(0) == 0
+    with pytest.raises(HipBfvError) as ei:
+        pt.get_coefficient(9)
+    assert ei.value.kind == "InvalidArgument"
+
+
+def test_null_and_wrong_type_handles_are_rejected():
+    from sunscreen_amd import _lib
+
+    lib = _lib.load()
+    out = C.c_uint64()
+    assert lib.Modulus_Value(None, C.byref(out)) & 0xFFFFFFFF == _lib.E_POINTER
+    h = C.c_void_p()
+    assert lib.Plaintext_Create1(None, C.byref(h)) == 0
+    # a Plaintext handle passed where a Modulus is expected
+    assert lib.Modulus_Value(h, C.byref(out)) & 0xFFFFFFFF == _lib.E_POINTER
+    assert lib.Plaintext_Destroy(h) == 0

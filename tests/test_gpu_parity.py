@@ -1,0 +1,292 @@
+"""GPU parity tests: the HIP path (through the C ABI) must equal the CPU oracle bit for bit.
+
+Every test calls libhipbfv.so (sunscreen_amd/lib) -- never the oracle -- for the product result and
+uses the oracle only as the checker.  Sizes are kept where the oracle finishes in seconds; full
+BASELINE sizes are covered by size-independent properties in test_gpu_properties.py.
+"""
+import numpy as np
+import pytest
+
+from oracle import bfv_oracle as O
+from tests.bfv_helpers import oracle_for, params
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, galois=None, seed=11):
+    import torch  # noqa: F401
+    from sunscreen_amd import Context, GaloisKeys, RelinearizationKeys
+    from sunscreen_amd.batch import BatchEvaluator
+
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    O.seed(seed)
+    sk, pk, rk, gk = o.keygen(galois_elts=galois)
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    rkd = RelinearizationKeys.from_array(ctx, rk) if rk is not None else None
+    gkd = GaloisKeys.from_arrays(ctx, gk) if gk else None
+    return o, sk, pk, rk, gk, ctx, ev, rkd, gkd
+
+
+def _rand_cts(o, pk, count, rng, lo=0, hi=100):
+    vals = rng.integers(lo, hi, (count, o.n)).astype(np.uint64)
+    if o.t > 1 and hasattr(o, "batch_encode"):
+        try:
+            cts = np.stack([o.encrypt(pk, o.batch_encode(v % o.t)) for v in vals])
+        except ValueError:
+            cts = np.stack([o.encrypt(pk, v % o.t) for v in vals])
+    return vals, cts
+
+
+@pytest.mark.parametrize("name", ["default_1024_14", "default_2048_14", "default_4096_16", "default_8192_17", "default_16384_17"])
+def test_ntt_forward_inverse_bit_exact(name):
+    import torch
+    from sunscreen_amd import Context
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    rng = np.random.default_rng(n)
+    KK = len(primes)
+    polys = 3 * KK + 1
+    x = np.stack([rng.integers(0, primes[p % KK], n, dtype=np.uint64) for p in range(polys)])
+    # edge rows: all zeros, all q-1, single one
+    x[0] = 0
+    x[1 % polys] = primes[1 % KK] - 1
+    d = to_device(x)
+    ev.ntt(d, KK, inverse=False)
+    got = to_host(d)
+    for p in range(polys):
+        assert (got[p] == o.ntt(p % KK, x[p])).all(), (name, p)
+    ev.ntt(d, KK, inverse=True)
+    torch.cuda.synchronize()
+    assert (to_host(d) == x).all()
+
+
+def test_ntt_reproduces_seal_secret_key_fixture():
+    """The HIP forward NTT of the fixture's ternary secret key equals the bits SEAL serialised
+    (seal_fhe/tests/data/secret_key.bin via tests/golden/seal_key_fixture.npz)."""
+    import hashlib
+    import os
+
+    from sunscreen_amd import Context
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "seal_key_fixture.npz"))
+    primes = [int(p) for p in g["primes"]]
+    ctx = Context.from_raw(8192, primes, O.plain_batching(8192, 32))
+    ev = BatchEvaluator(ctx)
+    s = g["sk_ternary"].astype(np.int64)
+    x = np.stack([np.where(s < 0, q + s, s).astype(np.uint64) for q in primes])
+    d = to_device(x)
+    ev.ntt(d, 5)
+    y = to_host(d)
+    for j in range(5):
+        assert hashlib.sha256(y[j].astype("<u8").tobytes()).hexdigest() == str(g["sk_sha256"][j])
+
+
+@pytest.mark.parametrize("name", ["default_4096_16", "default_8192_17", "seal_fhe_unit", "simple_multiply", "default_16384_17"])
+def test_multiply_relinearize_bit_exact(name):
+    from sunscreen_amd.batch import to_device, to_host
+
+    o, sk, pk, rk, gk, ctx, ev, rkd, gkd = _setup(name)
+    rng = np.random.default_rng(5)
+    count = 3
+    va, a = _rand_cts(o, pk, count, rng)
+    vb, b = _rand_cts(o, pk, count, rng)
+    da, db = to_device(a), to_device(b)
+    m = to_host(ev.multiply(da, db))
+    r = to_host(ev.relinearize(to_device(m), rkd))
+    fused = to_host(ev.multiply_relin(da, db, rkd))
+    for i in range(count):
+        om = o.multiply(a[i], b[i])
+        assert (m[i] == om).all(), (name, i)
+        orl = o.relinearize(om, rk)
+        assert (r[i] == orl).all(), (name, i)
+        assert (fused[i] == orl).all(), (name, i)
+        if o.t % (2 * o.n) == 1:
+            assert (o.batch_decode(o.decrypt(fused[i], sk)) == (va[i] * vb[i]) % o.t).all()
+
+
+def test_multiply_general_sizes_and_chunking():
+    from sunscreen_amd.batch import to_device, to_host
+
+    o, sk, pk, rk, gk, ctx, ev, rkd, gkd = _setup("default_4096_16")
+    rng = np.random.default_rng(6)
+    va, a = _rand_cts(o, pk, 5, rng, 0, 8)
+    c3 = np.stack([o.multiply(x, x) for x in a])
+    ev.set_chunk_ops(2)  # 5 items -> chunks of 2,2,1
+    got = to_host(ev.multiply(to_device(c3), to_device(a)))
+    assert got.shape[1] == 4
+    for i in range(5):
+        assert (got[i] == o.multiply(c3[i], a[i])).all()
+    got2 = to_host(ev.multiply_relin(to_device(a), to_device(a), rkd))
+    for i in range(5):
+        assert (got2[i] == o.relinearize(c3[i], rk)).all()
+
+
+@pytest.mark.parametrize("name", ["default_4096_16", "seal_fhe_unit"])
+def test_rotations_bit_exact(name):
+    from sunscreen_amd.batch import to_device, to_host
+
+    o, sk, pk, rk, gk, ctx, ev, rkd, gkd = _setup(name, galois="all")
+    rng = np.random.default_rng(8)
+    va, a = _rand_cts(o, pk, 2, rng)
+    da = to_device(a)
+    for steps in (1, -1, 4, 3, -5):
+        got = to_host(ev.rotate_rows(da, steps, gkd))
+        for i in range(2):
+            assert (got[i] == o.rotate_rows(a[i], steps, gk)).all(), (name, steps)
+    got = to_host(ev.rotate_columns(da, gkd))
+    for i in range(2):
+        assert (got[i] == o.rotate_columns(a[i], gk)).all()
+    # in place
+    ev.rotate_rows(da, 7, gkd, out=da)
+    got = to_host(da)
+    for i in range(2):
+        assert (got[i] == o.rotate_rows(a[i], 7, gk)).all()
+
+
+@pytest.mark.parametrize("name", ["default_4096_16", "seal_fhe_unit", "simple_multiply"])
+def test_eltwise_and_plain_ops_bit_exact(name):
+    from sunscreen_amd.batch import to_device, to_host
+
+    o, sk, pk, rk, gk, ctx, ev, rkd, gkd = _setup(name)
+    rng = np.random.default_rng(9)
+    count = 3
+    va, a = _rand_cts(o, pk, count, rng)
+    vb, b = _rand_cts(o, pk, count, rng)
+    da, db = to_device(a), to_device(b)
+    plain = rng.integers(0, o.t, (count, o.n)).astype(np.uint64)
+    plain[0, ::2] = 0
+    plain[1, :] = o.t - 1
+    dp = to_device(plain)
+    res = {
+        "add": to_host(ev.add(da, db)),
+        "sub": to_host(ev.sub(da, db)),
+        "neg": to_host(ev.negate(da)),
+        "addp": to_host(ev.add_plain(da, dp)),
+        "subp": to_host(ev.sub_plain(da, dp)),
+        "mulp": to_host(ev.multiply_plain(da, dp)),
+        "mulp_shared": to_host(ev.multiply_plain(da, dp[2])),
+    }
+    for i in range(count):
+        assert (res["add"][i] == o.add(a[i], b[i])).all()
+        assert (res["sub"][i] == o.sub(a[i], b[i])).all()
+        assert (res["neg"][i] == o.negate(a[i])).all()
+        assert (res["addp"][i] == o.add_plain(a[i], plain[i])).all()
+        assert (res["subp"][i] == o.sub_plain(a[i], plain[i])).all()
+        assert (res["mulp"][i] == o.multiply_plain(a[i], plain[i])).all()
+        assert (res["mulp_shared"][i] == o.multiply_plain(a[i], plain[2])).all()
+
+
+def test_handle_level_api_mirrors_seal_fhe():
+    """The SEAL-named C entry points, driven through the seal_fhe mirror (sunscreen_amd/seal.py), on the
+    reference's unit-test parameters (seal_fhe/src/bfv_evaluator.rs:255-282)."""
+    from sunscreen_amd import (
+        BFVEvaluator,
+        BfvEncryptionParametersBuilder,
+        Ciphertext,
+        CoefficientModulus,
+        Context,
+        GaloisKeys,
+        HipBfvError,
+        PlainModulus,
+        Plaintext,
+        RelinearizationKeys,
+        SecurityLevel,
+    )
+
+    params_ = (
+        BfvEncryptionParametersBuilder()
+        .set_poly_modulus_degree(8192)
+        .set_coefficient_modulus(CoefficientModulus.create(8192, [50, 30, 30, 50, 50]))
+        .set_plain_modulus(PlainModulus.batching(8192, 32))
+        .build()
+    )
+    ctx = Context(params_, False, SecurityLevel.TC128)
+    assert ctx.key_primes == [1125899905744897, 1073643521, 1073692673, 1125899906629633, 1125899906826241]
+    o = oracle_for("seal_fhe_unit")
+    assert ctx.plain_modulus == o.t
+    O.seed(21)
+    sk, pk, rk, gk = o.keygen(galois_elts="all")
+    ev = BFVEvaluator(ctx)
+    rkd = RelinearizationKeys.from_array(ctx, rk)
+    gkd = GaloisKeys.from_arrays(ctx, gk)
+    n = o.n
+    va = np.array([n // 2 - i for i in range(n)], dtype=np.int64)
+    vb = np.array([16 - i % 32 for i in range(n)], dtype=np.int64)
+    a_np = o.encrypt(pk, o.batch_encode((va % o.t).astype(np.uint64)))
+    b_np = o.encrypt(pk, o.batch_encode((vb % o.t).astype(np.uint64)))
+    a, b = Ciphertext.from_array(ctx, a_np), Ciphertext.from_array(ctx, b_np)
+    assert a.num_polynomials() == 2 and a.coeff_modulus_size() == 4 and not a.is_ntt_form()
+    assert a.get_data(5) == int(a_np.reshape(-1)[5])
+    assert a.get_coefficient(1, 7) == [int(a_np[1, i, 7]) for i in range(4)]
+
+    def dec(ct):
+        v = o.batch_decode(o.decrypt(ct.to_array(), sk)).astype(np.int64)
+        return np.where(v > o.t // 2, v - o.t, v)
+
+    assert (ev.negate(a).to_array() == o.negate(a_np)).all()
+    assert (ev.add(a, b).to_array() == o.add(a_np, b_np)).all()
+    assert (ev.sub(a, b).to_array() == o.sub(a_np, b_np)).all()
+    m = ev.multiply(a, b)
+    assert m.num_polynomials() == 3
+    assert (m.to_array() == o.multiply(a_np, b_np)).all()
+    r = ev.relinearize(m, rkd)
+    assert r.num_polynomials() == 2
+    assert (r.to_array() == o.relinearize(o.multiply(a_np, b_np), rk)).all()
+    assert (dec(r) == va * vb).all()
+    # in-place variants alias the destination with the operand
+    c = a.clone()
+    ev.multiply_inplace(c, b)
+    ev.relinearize_inplace(c, rkd)
+    assert (c.to_array() == r.to_array()).all()
+    sq = ev.square(b)
+    assert (sq.to_array() == o.multiply(b_np, b_np)).all()
+    # add of size 3 and size 2
+    mixed = ev.add(m, a)
+    assert (mixed.to_array() == o.add(o.multiply(a_np, b_np), a_np)).all()
+    mixed = ev.sub(a, m)
+    assert (mixed.to_array() == o.sub(a_np, o.multiply(a_np, b_np))).all()
+    # add_many / multiply_many / exponentiate
+    s3 = ev.add_many([a, b, a])
+    assert (s3.to_array() == o.add(o.add(a_np, b_np), a_np)).all()
+    small = Ciphertext.from_array(ctx, b_np)
+    e3 = ev.exponentiate(small, 3, rkd)
+    assert (dec(e3) == vb**3).all()
+    mm = ev.multiply_many([b, b, b, b], rkd)
+    assert (dec(mm) == vb**4).all()
+    # plaintext operands
+    pb = o.batch_encode((vb % o.t).astype(np.uint64))
+    p = Plaintext.from_coefficients([int(x) for x in pb])
+    assert p.len() == n and p.get_coefficient(3) == int(pb[3])
+    assert (ev.add_plain(a, p).to_array() == o.add_plain(a_np, pb)).all()
+    assert (ev.sub_plain(a, p).to_array() == o.sub_plain(a_np, pb)).all()
+    assert (ev.multiply_plain(a, p).to_array() == o.multiply_plain(a_np, pb)).all()
+    mono = Plaintext.from_coefficients([0, 0, 0, o.t - 2])
+    assert (ev.multiply_plain(a, mono).to_array() == o.multiply_plain(a_np, np.array([0, 0, 0, o.t - 2], dtype=np.uint64))).all()
+    zero = Plaintext.from_coefficients([0])
+    with pytest.raises(HipBfvError) as ei:
+        ev.multiply_plain(a, zero)  # transparent result (sunscreen/tests/features.rs:8-34)
+    assert ei.value.kind == "InternalError"
+    # rotations (bfv_evaluator.rs:880-970)
+    rot = ev.rotate_rows(a, -1, gkd)
+    assert (rot.to_array() == o.rotate_rows(a_np, -1, gk)).all()
+    d = dec(rot)
+    assert va[0] == d[1] and va[1] == d[2] and va[4096] == d[4097]
+    rot3 = ev.rotate_rows(a, 3, gkd)  # NAF chain
+    assert (rot3.to_array() == o.rotate_rows(a_np, 3, gk)).all()
+    cols = ev.rotate_columns(a, gkd)
+    assert (cols.to_array() == o.rotate_columns(a_np, gk)).all()
+    c = a.clone()
+    ev.rotate_columns_inplace(c, gkd)
+    assert (c.to_array() == cols.to_array()).all()
+    with pytest.raises(HipBfvError) as ei:
+        ev.rotate_rows(a, 1, GaloisKeys())
+    assert ei.value.kind == "InvalidArgument"
+    with pytest.raises(HipBfvError):
+        ev.relinearize(ev.multiply(m, a), rkd)  # size 4: "not enough relinearization keys"
