@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- BFV ct x ct multiply + relinearize throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: `--batch` (default 4096) independent
+ciphertext pairs, n=8192, SEAL default 128-bit parameters (K=4 data primes + 1 special prime,
+t = batching(8192,17) = 114689) -- BASELINE.json configs[2], the configuration the metric is quoted
+on.  Inputs are resident in HBM before the timed region.  `--workload ntt` runs configs[1]
+(batched forward+inverse NTT, n=8192, 3 primes, 4096 polynomials) instead.
+
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank processes its own
+`--batch` items (weak scaling, no data-path collective); time = max over ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="ciphertext pairs (or polynomials for --workload ntt) per GPU per step")
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--workload", choices=["mulrelin", "ntt"], default="mulrelin")
+    ap.add_argument("--chunk", type=int, default=0, help="override the executor's chunk size (ops per launch group)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="ops in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from sunscreen_amd import Context, RelinearizationKeys, _lib
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    _lib.load().hipbfv_set_device(local_rank)
+    # the oracle is the checker and the CPU baseline only
+    from oracle import bfv_oracle as O
+
+    n = args.n
+    primes = O.bfv_default(n)
+    t = O.plain_batching(n, 17)
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    if args.chunk:
+        ev.set_chunk_ops(args.chunk)
+    K, KK = ctx.K, ctx.KK
+    B = args.batch
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EA10001 + rank)
+
+    def uniform_residues(shape_prefix, nres, primes_):
+        # uniform canonical residues per prime: valid ciphertext / polynomial bit patterns
+        out = torch.empty(shape_prefix + (nres, n), dtype=torch.int64, device=dev)
+        for i in range(nres):
+            out[..., i, :] = torch.randint(0, primes_[i % len(primes_)], shape_prefix + (n,), generator=gen, device=dev, dtype=torch.int64)
+        return out
+
+    result = {}
+    if args.workload == "mulrelin":
+        o = O.Oracle(n, primes, t)
+        O.seed(0xBF5 + 17)
+        sk, pk, rk, _ = o.keygen()
+        rkd = RelinearizationKeys.from_array(ctx, rk)
+        a = uniform_residues((B, 2), K, primes)
+        b = uniform_residues((B, 2), K, primes)
+        # a few genuine encryptions at the head of the batch: parity + decrypt check against the oracle
+        ncheck = 0 if args.no_check else 4
+        rng = np.random.default_rng(rank)
+        va = rng.integers(0, 257, (ncheck, n)).astype(np.uint64)
+        vb = rng.integers(0, 257, (ncheck, n)).astype(np.uint64)
+        if ncheck:
+            ea = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in va])
+            eb = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vb])
+            a[:ncheck] = to_device(ea, dev)
+            b[:ncheck] = to_device(eb, dev)
+        out = torch.empty((B, 2, K, n), dtype=torch.int64, device=dev)
+
+        def step():
+            ev.multiply_relin(a, b, rkd, out=out)
+
+        unit_bytes = 48 * K * n  # read 2 ciphertexts, write 1 (compulsory HBM traffic per op)
+        units_per_step = B
+        metric, unit = "bfv_mul_relin_ops_per_sec", "ops/s"
+        workload = f"BFV ct*ct multiply+relinearize, n={n}, K={K}+1 SEAL default 128-bit primes, t={t}, batch={B} pairs/GPU"
+    else:
+        nprimes = 3
+        data = uniform_residues((B,), nprimes, primes[:nprimes]).reshape(B * nprimes, n).contiguous()
+        ref = data.clone()
+
+        def step():
+            ev.ntt(data, nprimes, inverse=False)
+            ev.ntt(data, nprimes, inverse=True)
+
+        unit_bytes = 16 * n  # one single-residue transform: read + write
+        units_per_step = 2 * B * nprimes
+        metric, unit = "ntt_single_residue_transforms_per_sec", "NTT/s"
+        workload = f"batched forward+inverse negacyclic NTT, n={n}, {nprimes} primes, batch={B} polys/GPU"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev.profile(True)
+    ev.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    prof = ev.profile_read()
+    ev.profile(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- parity gate (after timing so that the timed region is exactly K steps) ----
+    parity = "skipped"
+    if args.workload == "mulrelin" and not args.no_check:
+        got = to_host(out[:ncheck])
+        for i in range(ncheck):
+            ref_i = o.relinearize(o.multiply(ea[i], eb[i]), rk)
+            assert (got[i] == ref_i).all(), "HIP result differs from the CPU oracle"
+            assert (o.batch_decode(o.decrypt(got[i], sk)) == (va[i] * vb[i]) % t).all()
+        # size-independent property on the whole batch: every output word is a canonical residue
+        for i in range(K):
+            assert int(out[:, :, i, :].max()) < primes[i] and int(out[:, :, i, :].min()) >= 0
+        parity = f"bit-exact vs oracle on {ncheck} items; all {B} outputs canonical"
+    elif args.workload == "ntt" and not args.no_check:
+        assert torch.equal(data, ref), "INTT(NTT(x)) != x"
+        parity = "INTT(NTT(x)) == x on the whole batch"
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_units = units_per_step * args.steps * world
+    value = total_units / elapsed
+    # dominant kernel by accumulated HIP-event time
+    dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+    roofline = None
+    if dom:
+        name, rec = dom
+        # algorithmic bytes of one launch of that kernel
+        per_unit = {
+            "ntt_fwd": 16 * n, "ntt_inv": 16 * n,                    # per residue polynomial: read + write
+            "behz_extend": 8 * n * (K + (K + ctx_S(ctx))),           # per polynomial: read K, write K+S residues
+            "tensor": 8 * n * 7 * (K + ctx_S(ctx)),                  # per op: read 4, write 3 extended polys
+            "behz_floor_sk": 8 * n * ((K + ctx_S(ctx)) + K),         # per polynomial
+            "ks_decompose": 8 * n * (K + KK * K), "ks_mac": 8 * n * (KK * K + 2 * KK), "ks_moddown": 8 * n * (2 * KK + 4 * K),
+        }.get(name, 16 * n)
+        avg_ms = rec["ms"] / rec["launches"]
+        bytes_per_launch = per_unit * rec["units"] / rec["launches"]
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {
+            "kernel": name,
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "avg_launch_ms": round(avg_ms, 4),
+            "launches": rec["launches"],
+            "algorithmic_bytes_per_launch": int(bytes_per_launch),
+        }
+    op_rate_gbs = unit_bytes * (value / world) / 1e9
+    cpu = None
+    if not args.no_cpu and world == 1:
+        cpu = cpu_baseline(args, O, n, primes, t)
+    line = {
+        "metric": metric,
+        "value": round(value, 2),
+        "unit": unit,
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": workload, "batch_per_gpu": B, "poly_modulus_degree": n, "coeff_modulus_primes": KK,
+                   "plain_modulus": t, "parallelism": f"batch-sharded x{world}", "chunk_ops": args.chunk or "auto"},
+        "roofline": roofline,
+        "whole_op_hbm": {"algorithmic_bytes_per_unit": unit_bytes, "achieved_GBps_per_gpu": round(op_rate_gbs, 1),
+                         "frac_of_peak": round(op_rate_gbs / HBM_PEAK_GBS, 4)},
+        "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+        "cpu_baseline": cpu,
+        "parity": parity,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def ctx_S(ctx):
+    # |Bsk| = |B| + 1 with |B| = K (+1 when K*61 bits are not enough; never for the default parameter sets)
+    return ctx.K + 1
+
+
+def cpu_baseline(args, O, n, primes, t):
+    """The CPU oracle (a port of SEAL's algorithms, NOT SEAL itself -- SEAL's source is absent from the
+    reference tree) timed on this host on a bounded sample of the same workload."""
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    o = O.Oracle(n, primes, t)
+    rng = np.random.default_rng(1)
+    K = o.K
+    if args.workload == "mulrelin":
+        O.seed(99)
+        sk, pk, rk, _ = o.keygen()
+        sample = args.cpu_sample or max(threads * 8, 64)
+        a = np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)]) for _ in range(2 * sample)]).reshape(sample, 2, K, n)
+        b = a[::-1].copy()
+        secs1, _ = o.bench_mul_relin(a[: max(8, sample // threads)], b[: max(8, sample // threads)], rk, threads=1)
+        one = max(8, sample // threads) / secs1
+        secs, _ = o.bench_mul_relin(a, b, rk, threads=threads)
+        return {"value": round(sample / secs, 2), "unit": "ops/s", "cores": threads, "kind": "port",
+                "sample": f"{sample} mul+relin ops (same parameters) with OpenMP over the batch on {threads} threads; "
+                          f"single-thread rate {one:.2f} ops/s on {max(8, sample // threads)} ops",
+                "single_thread_value": round(one, 2), "host_cpus": cores}
+    nprimes = 3
+    sample = args.cpu_sample or threads * 256
+    x = np.stack([rng.integers(0, primes[i % nprimes], n, dtype=np.uint64) for i in range(sample)])
+    secs1, _ = o.bench_ntt(x[: sample // threads], nprimes, threads=1)
+    secs, _ = o.bench_ntt(x, nprimes, threads=threads)
+    return {"value": round(2 * sample / secs, 2), "unit": "NTT/s", "cores": threads, "kind": "port",
+            "sample": f"{sample} polynomials forward+inverse on {threads} threads",
+            "single_thread_value": round(2 * (sample // threads) / secs1, 2), "host_cpus": cores}
+
+
+if __name__ == "__main__":
+    main()

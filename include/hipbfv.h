@@ -5,7 +5,7 @@
  * `seal_fhe::Evaluator` (seal_fhe/src/evaluator.rs:7-280) forwards to Microsoft SEAL's C API
  * through bindgen.  Part 1 re-exports the SEAL C entry points that the `seal_fhe` crate binds for
  * that path, with the same names, argument order, opaque `void*` handles and HRESULT return values,
- * so that `seal_fhe/src/*.rs` can link against this library unchanged.
+ * so that the files under `seal_fhe/src/` can link against this library unchanged.
  * Part 2 is the extension the reference API lacks: raw-array import/export for handles and the
  * batched, device-pointer entry points used by the GPU batch executor.
  *
@@ -169,6 +169,15 @@ long hipbfv_batch_multiply_plain(void *evaluator, const uint64_t *ct, uint64_t s
 /* forward / inverse negacyclic NTT of u64[polys][N]; polynomial p uses key-level prime (p % nprimes) */
 long hipbfv_batch_ntt(void *evaluator, uint64_t *data, uint64_t polys, uint64_t nprimes, bool inverse, void *stream);
 long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
+
+/* Per-kernel timing (HIP events recorded on the launch stream, around every kernel launch):
+ * total milliseconds, number of launches and work units (residue polynomials for the NTT kernels,
+ * polynomials or operations for the others) since the last reset. */
+long hipbfv_profile_enable(void *evaluator, bool enabled);
+long hipbfv_profile_reset(void *evaluator);
+long hipbfv_profile_kernel_count(uint32_t *count);
+long hipbfv_profile_read(void *evaluator, uint32_t kernel_id, char *name, uint64_t name_capacity, double *total_ms,
+                         uint64_t *launches, uint64_t *units);
 
 #ifdef __cplusplus
 }

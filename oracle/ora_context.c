@@ -157,7 +157,7 @@ uint64_t ora_invmod(uint64_t a, const ora_mod *m)
 }
 
 /* SEAL try_minimal_primitive_root: the smallest primitive 2n-th root of unity mod q.
- * Pinned bit-for-bit by the key fixtures seal_fhe/tests/data/*.bin. */
+ * Pinned bit-for-bit by the key fixtures seal_fhe/tests/data/ (SURVEY 8c). */
 uint64_t ora_minimal_primitive_root(uint32_t two_n, uint64_t q)
 {
     if ((q - 1) % two_n != 0) return 0;

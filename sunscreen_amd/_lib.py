@@ -109,6 +109,10 @@ _SIGNATURES = {
     "hipbfv_batch_multiply_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
     "hipbfv_batch_ntt": [vp, vp, u64, u64, C.c_bool, vp],
     "hipbfv_set_chunk_ops": [vp, u64],
+    "hipbfv_profile_enable": [vp, C.c_bool],
+    "hipbfv_profile_reset": [vp],
+    "hipbfv_profile_kernel_count": [C.POINTER(C.c_uint32)],
+    "hipbfv_profile_read": [vp, C.c_uint32, C.c_char_p, u64, C.POINTER(C.c_double), u64p, u64p],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -45,6 +45,26 @@ class BatchEvaluator:
     def set_chunk_ops(self, chunk: int) -> None:
         _check(_lib.load().hipbfv_set_chunk_ops(self._h, chunk))
 
+    # ---- per-kernel HIP-event timing (bench.py) ----
+    def profile(self, enabled: bool = True) -> None:
+        _check(_lib.load().hipbfv_profile_enable(self._h, enabled))
+
+    def profile_reset(self) -> None:
+        _check(_lib.load().hipbfv_profile_reset(self._h))
+
+    def profile_read(self) -> dict[str, dict]:
+        L = _lib.load()
+        cnt = C.c_uint32()
+        _check(L.hipbfv_profile_kernel_count(C.byref(cnt)))
+        out = {}
+        for i in range(cnt.value):
+            name = C.create_string_buffer(64)
+            ms, launches, units = C.c_double(), C.c_uint64(), C.c_uint64()
+            _check(L.hipbfv_profile_read(self._h, i, name, 64, C.byref(ms), C.byref(launches), C.byref(units)))
+            if launches.value:
+                out[name.value.decode()] = {"ms": ms.value, "launches": launches.value, "units": units.value}
+        return out
+
     def _shape_ok(self, t: torch.Tensor, size=None):
         assert t.dim() == 4 and t.shape[2] == self.K and t.shape[3] == self.n, tuple(t.shape)
         if size is not None:

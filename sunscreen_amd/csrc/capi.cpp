@@ -181,6 +181,15 @@ long sync_stream(hipStream_t s) {
   return HIPBFV_S_OK;
 }
 
+// Device-to-device copy that is complete when it returns.  A plain hipMemcpy(D2D) is only ordered on
+// the null stream, which the per-thread non-blocking streams do not synchronise with.
+hipError_t copy_d2d(void* dst, const void* src, size_t bytes) {
+  hipStream_t s = thread_stream();
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);
+}
+
 bool same_context(const CipherObj* a, const EvalObj* e) { return a->ctx && a->ctx.get() == e->ctx.get() && a->dev && a->size >= 2; }
 
 // transparent check of the finished result (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT); stream already holds the op
@@ -536,7 +545,7 @@ long Ciphertext_Create2(void* copy, void** out) {
       delete n;
       return from_status(kOutOfMemory);
     }
-    if (hipMemcpy(buf, c->dev, c->words * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+    if (copy_d2d(buf, c->dev, c->words * sizeof(u64)) != hipSuccess) {
       g_buffers.put(buf, c->words);
       delete n;
       return from_status(kHipError);
@@ -664,7 +673,7 @@ long KSwitchKeys_Create2(void* copy, void** out) {
   n->ctx = k->ctx;
   for (auto& kv : k->keys) {
     u64* buf = g_buffers.get(k->ctx->key_words());
-    if (!buf || hipMemcpy(buf, kv.second, k->ctx->key_words() * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+    if (!buf || copy_d2d(buf, kv.second, k->ctx->key_words() * sizeof(u64)) != hipSuccess) {
       if (buf) g_buffers.put(buf, k->ctx->key_words());
       delete n;
       return from_status(buf ? kHipError : kOutOfMemory);
@@ -845,7 +854,7 @@ long Evaluator_Relinearize(void* h, void* a, void* keys, void* dst, void* pool) 
     if (d == x) return HIPBFV_S_OK;
     u64* buf = g_buffers.get(x->words);
     if (!buf) return from_status(kOutOfMemory);
-    if (hipMemcpy(buf, x->dev, x->words * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+    if (copy_d2d(buf, x->dev, x->words * sizeof(u64)) != hipSuccess) {
       g_buffers.put(buf, x->words);
       return from_status(kHipError);
     }
@@ -1046,7 +1055,7 @@ static long rotate_common(void* h, void* a, bool columns, int steps, void* keys,
   if (d != x) {  // work on a copy in the destination so that the NAF chain can run in place
     u64* buf = g_buffers.get(x->words);
     if (!buf) return from_status(kOutOfMemory);
-    if (hipMemcpy(buf, x->dev, x->words * sizeof(u64), hipMemcpyDeviceToDevice) != hipSuccess) {
+    if (copy_d2d(buf, x->dev, x->words * sizeof(u64)) != hipSuccess) {
       g_buffers.put(buf, x->words);
       return from_status(kHipError);
     }
@@ -1193,6 +1202,41 @@ long hipbfv_batch_ntt(void* h, uint64_t* data, uint64_t polys, uint64_t nprimes,
   EVAL_OR_RETURN(h);
   if (!data) return HIPBFV_E_POINTER;
   return from_status(e->ev->ntt((u64*)data, polys, (u32)nprimes, inverse, (hipStream_t)stream));
+}
+
+long hipbfv_profile_enable(void* h, bool enabled) {
+  EVAL_OR_RETURN(h);
+  e->ev->profiler().collect();
+  e->ev->profiler().enabled = enabled;
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_profile_reset(void* h) {
+  EVAL_OR_RETURN(h);
+  e->ev->profiler().reset();
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_profile_kernel_count(uint32_t* count) {
+  if (!count) return HIPBFV_E_POINTER;
+  *count = kKernCount;
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_profile_read(void* h, uint32_t kernel_id, char* name, uint64_t name_capacity, double* total_ms, uint64_t* launches,
+                         uint64_t* units) {
+  EVAL_OR_RETURN(h);
+  if (kernel_id >= (uint32_t)kKernCount) return fail(HIPBFV_E_INVALIDARG, "kernel id out of range");
+  Profiler& p = e->ev->profiler();
+  p.collect();
+  if (name && name_capacity) {
+    std::strncpy(name, kernel_name((int)kernel_id), name_capacity - 1);
+    name[name_capacity - 1] = 0;
+  }
+  if (total_ms) *total_ms = p.total_ms[kernel_id];
+  if (launches) *launches = p.launches[kernel_id];
+  if (units) *units = p.units[kernel_id];
+  return HIPBFV_S_OK;
 }
 
 long hipbfv_set_chunk_ops(void* h, uint64_t chunk) {

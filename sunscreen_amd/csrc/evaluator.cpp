@@ -100,6 +100,77 @@ NttPlan make_plan(u32 div, const std::vector<u32>& mods) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------ Profiler
+
+const char* kernel_name(int id) {
+  static const char* names[kKernCount] = {"ntt_fwd",   "ntt_inv",    "behz_extend", "tensor",  "behz_floor_sk", "ks_decompose",
+                                          "ks_mac",    "ks_moddown", "galois",      "eltwise", "plain"};
+  return id >= 0 && id < kKernCount ? names[id] : "?";
+}
+
+Profiler::~Profiler() {
+  for (auto& r : recs_) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (auto e : free_) (void)hipEventDestroy(e);
+}
+
+hipEvent_t Profiler::get_event() {
+  if (!free_.empty()) {
+    hipEvent_t e = free_.back();
+    free_.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void Profiler::begin(int id, size_t units_, hipStream_t s) {
+  if (!enabled) return;
+  std::lock_guard<std::mutex> g(mu_);
+  Rec r{id, units_, get_event(), get_event()};
+  (void)hipEventRecord(r.a, s);
+  recs_.push_back(r);
+}
+
+void Profiler::end(hipStream_t s) {
+  if (!enabled) return;
+  std::lock_guard<std::mutex> g(mu_);
+  if (!recs_.empty()) (void)hipEventRecord(recs_.back().b, s);
+}
+
+void Profiler::collect() {
+  std::lock_guard<std::mutex> g(mu_);
+  for (auto& r : recs_) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      total_ms[r.id] += ms;
+      launches[r.id] += 1;
+      units[r.id] += r.units;
+    }
+    free_.push_back(r.a);
+    free_.push_back(r.b);
+  }
+  recs_.clear();
+}
+
+void Profiler::reset() {
+  collect();
+  for (int i = 0; i < kKernCount; i++) total_ms[i] = 0, launches[i] = 0, units[i] = 0;
+}
+
+// launch `expr` bracketed by profiler events
+#define HB_LAUNCH(id, units, expr)  \
+  do {                              \
+    prof_.begin(id, units, s);      \
+    hipError_t e__ = (expr);        \
+    prof_.end(s);                   \
+    if (e__ != hipSuccess) return kHipError; \
+  } while (0)
+
 // ------------------------------------------------------------------ Evaluator
 
 Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
@@ -134,7 +205,7 @@ int Evaluator::ntt(u64* data, size_t polys, u32 nprimes, bool inverse, hipStream
   const size_t step = (65535 / nprimes) * nprimes;
   for (size_t off = 0; off < polys; off += step) {
     const size_t cnt = std::min(step, polys - off);
-    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, data + off * h.n, cnt, plan, inverse, 0, s));
+    HB_LAUNCH((inverse ? kKernNttInv : kKernNttFwd), cnt, launch_ntt(ctx_->dev(), h.logn, data + off * h.n, cnt, plan, inverse, 0, s));
   }
   return kOk;
 }
@@ -156,11 +227,11 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   const NttPlan plan = make_plan(1, mods);
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
-    HB_CHECK(launch_behz_extend(ctx_->dev(), n, K, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));
-    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, ext, c * (sa + sb) * R, plan, false, 0, s));
-    HB_CHECK(launch_tensor(ctx_->dev(), n, R, ext, sa, sb, D, c, s));
-    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, D, c * sd * R, plan, true, 1, s));
-    HB_CHECK(launch_behz_floor_sk(ctx_->dev(), n, K, D, out + off * sd * K * n, c * sd, s));
+    HB_LAUNCH(kKernBehzExtend, c * (sa + sb), launch_behz_extend(ctx_->dev(), n, K, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));
+    HB_LAUNCH(kKernNttFwd, c * (sa + sb) * R, launch_ntt(ctx_->dev(), h.logn, ext, c * (sa + sb) * R, plan, false, 0, s));
+    HB_LAUNCH(kKernTensor, c, launch_tensor(ctx_->dev(), n, R, ext, sa, sb, D, c, s));
+    HB_LAUNCH(kKernNttInv, c * sd * R, launch_ntt(ctx_->dev(), h.logn, D, c * sd * R, plan, true, 1, s));
+    HB_LAUNCH(kKernBehzFloorSk, c * sd, launch_behz_floor_sk(ctx_->dev(), n, K, D, out + off * sd * K * n, c * sd, s));
   }
   return kOk;
 }
@@ -179,11 +250,11 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
   u64* ACC = scratch + count * (size_t)KK * K * n;
   std::vector<u32> mods;
   for (u32 i = 0; i < KK; i++) mods.push_back(i);
-  HB_CHECK(launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));
-  HB_CHECK(launch_ntt(ctx_->dev(), h.logn, T, count * KK * K, make_plan(K, mods), false, 0, s));
-  HB_CHECK(launch_ks_mac(ctx_->dev(), n, KK, T, key, ACC, count, s));
-  HB_CHECK(launch_ntt(ctx_->dev(), h.logn, ACC, count * 2 * KK, make_plan(1, mods), true, 0, s));
-  HB_CHECK(launch_ks_moddown(ctx_->dev(), n, ACC, base, bstride, base_mask, out2, count, s));
+  HB_LAUNCH(kKernKsDecompose, count, launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));
+  HB_LAUNCH(kKernNttFwd, count * KK * K, launch_ntt(ctx_->dev(), h.logn, T, count * KK * K, make_plan(K, mods), false, 0, s));
+  HB_LAUNCH(kKernKsMac, count, launch_ks_mac(ctx_->dev(), n, KK, T, key, ACC, count, s));
+  HB_LAUNCH(kKernNttInv, count * 2 * KK, launch_ntt(ctx_->dev(), h.logn, ACC, count * 2 * KK, make_plan(1, mods), true, 0, s));
+  HB_LAUNCH(kKernKsModdown, count, launch_ks_moddown(ctx_->dev(), n, ACC, base, bstride, base_mask, out2, count, s));
   return kOk;
 }
 
@@ -240,7 +311,7 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, 
   u64* ks = rot + chunk * rot_words;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
-    HB_CHECK(launch_galois(ctx_->dev(), n, ct2 + off * rot_words, rot, c * 2, ginv, s));
+    HB_LAUNCH(kKernGalois, c * 2, launch_galois(ctx_->dev(), n, ct2 + off * rot_words, rot, c * 2, ginv, s));
     // base = (sigma(c0), 0); target = sigma(c1)
     int rc = key_switch(rot + (size_t)K * n, rot_words, key, rot, rot_words, 1u, out2 + off * rot_words, c, ks, s);
     if (rc) return rc;
@@ -307,19 +378,19 @@ int Evaluator::multiply_plain(const u64* ct, u32 size, const u64* plain, size_t 
   const NttPlan plan = make_plan(1, mods);
   if (shared) {
     HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain, 0, pl, 1, s));
-    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, pl, K, plan, false, 0, s));
+    HB_LAUNCH(kKernNttFwd, K, launch_ntt(ctx_->dev(), h.logn, pl, K, plan, false, 0, s));
   }
   if (out != ct) HB_CHECK(hipMemcpyAsync(out, ct, count * cs * sizeof(u64), hipMemcpyDeviceToDevice, s));
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     if (!shared) {
       HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain + off * pstride, pstride, pl, c, s));
-      HB_CHECK(launch_ntt(ctx_->dev(), h.logn, pl, c * K, plan, false, 0, s));
+      HB_LAUNCH(kKernNttFwd, c * K, launch_ntt(ctx_->dev(), h.logn, pl, c * K, plan, false, 0, s));
     }
     u64* x = out + off * cs;
-    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, x, c * size * K, plan, false, 0, s));
+    HB_LAUNCH(kKernNttFwd, c * size * K, launch_ntt(ctx_->dev(), h.logn, x, c * size * K, plan, false, 0, s));
     HB_CHECK(launch_dyadic_plain(ctx_->dev(), n, K, x, size, pl, shared ? 0 : (size_t)K * n, c, s));
-    HB_CHECK(launch_ntt(ctx_->dev(), h.logn, x, c * size * K, plan, true, 0, s));
+    HB_LAUNCH(kKernNttInv, c * size * K, launch_ntt(ctx_->dev(), h.logn, x, c * size * K, plan, true, 0, s));
   }
   return kOk;
 }

@@ -46,9 +46,53 @@ class ScratchPool {
   std::vector<Block> blocks_;
 };
 
+// Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline figures).
+enum KernelId : int {
+  kKernNttFwd = 0,
+  kKernNttInv,
+  kKernBehzExtend,
+  kKernTensor,
+  kKernBehzFloorSk,
+  kKernKsDecompose,
+  kKernKsMac,
+  kKernKsModdown,
+  kKernGalois,
+  kKernEltwise,
+  kKernPlain,
+  kKernCount
+};
+const char* kernel_name(int id);
+
+class Profiler {
+ public:
+  ~Profiler();
+  bool enabled = false;
+  // record the start/stop events around one launch; `units` = work items of that launch (e.g. residue polys)
+  void begin(int id, size_t units, hipStream_t s);
+  void end(hipStream_t s);
+  // synchronise, accumulate finished records into the totals and recycle their events
+  void collect();
+  void reset();
+  double total_ms[kKernCount] = {};
+  unsigned long long launches[kKernCount] = {};
+  unsigned long long units[kKernCount] = {};
+
+ private:
+  struct Rec {
+    int id;
+    size_t units;
+    hipEvent_t a, b;
+  };
+  std::mutex mu_;
+  std::vector<Rec> recs_;
+  std::vector<hipEvent_t> free_;
+  hipEvent_t get_event();
+};
+
 class Evaluator {
  public:
   explicit Evaluator(Context* ctx);
+  Profiler& profiler() { return prof_; }
   Context* ctx() const { return ctx_; }
 
   // ---- SURVEY 8a rows a1-a5, batched ----
@@ -83,6 +127,7 @@ class Evaluator {
   size_t ks_scratch_words() const;
   Context* ctx_;
   ScratchPool pool_;
+  Profiler prof_;
   size_t chunk_ops_;
 };
 
