@@ -170,6 +170,25 @@ long hipbfv_batch_multiply_plain(void *evaluator, const uint64_t *ct, uint64_t s
 long hipbfv_batch_ntt(void *evaluator, uint64_t *data, uint64_t polys, uint64_t nprimes, bool inverse, void *stream);
 long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
 
+/* Batch executor for compiled FHE program graphs (replaces sunscreen_runtime/src/run.rs:100-357).
+ * Node kinds follow sunscreen_fhe_program::Operation (operation.rs:12-94) in this order:
+ * 0 ShiftLeft, 1 ShiftRight, 2 SwapRows, 3 Relinearize, 4 Multiply, 5 MultiplyPlaintext, 6 Add,
+ * 7 AddPlaintext, 8 Negate, 9 Sub, 10 SubPlaintext, 11 InputCiphertext(arg), 12 InputPlaintext(arg),
+ * 13 Literal::U64(arg), 14 OutputCiphertext.  Edge kinds: 0 Left, 1 Right, 2 Unary.
+ * LoadJson accepts the serde JSON form of `FheProgram` (petgraph StableGraph).
+ * Run executes the graph over `batch` independent input sets: input i is a device pointer to
+ * u64[batch][2][K][N] (kind 0) or to plaintexts u64[batch][N] / one shared u64[N] (kind 1, stride N / 0);
+ * one output buffer u64[batch][2][K][N] per OutputCiphertext node, in node order. Asynchronous on `stream`. */
+long hipbfv_Program_Create(void **program);
+long hipbfv_Program_Destroy(void *program);
+long hipbfv_Program_AddNode(void *program, uint32_t op, uint64_t arg, uint32_t *node_id);
+long hipbfv_Program_AddEdge(void *program, uint32_t src, uint32_t dst, uint32_t kind);
+long hipbfv_Program_LoadJson(void *program, const char *json, uint64_t length);
+long hipbfv_Program_NumOutputs(void *program, uint64_t *count);
+long hipbfv_Program_Run(void *program, void *evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t *input_kinds,
+                        const uint64_t *const *input_ptrs, const uint64_t *input_strides, void *relin_keys,
+                        void *galois_keys, uint64_t num_outputs, uint64_t *const *outputs, void *stream);
+
 /* Per-kernel timing (HIP events recorded on the launch stream, around every kernel launch):
  * total milliseconds, number of launches and work units (residue polynomials for the NTT kernels,
  * polynomials or operations for the others) since the last reset. */

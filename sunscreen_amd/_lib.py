@@ -109,6 +109,13 @@ _SIGNATURES = {
     "hipbfv_batch_multiply_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
     "hipbfv_batch_ntt": [vp, vp, u64, u64, C.c_bool, vp],
     "hipbfv_set_chunk_ops": [vp, u64],
+    "hipbfv_Program_Create": [vpp],
+    "hipbfv_Program_Destroy": [vp],
+    "hipbfv_Program_AddNode": [vp, C.c_uint32, u64, C.POINTER(C.c_uint32)],
+    "hipbfv_Program_AddEdge": [vp, C.c_uint32, C.c_uint32, C.c_uint32],
+    "hipbfv_Program_LoadJson": [vp, C.c_char_p, u64],
+    "hipbfv_Program_NumOutputs": [vp, u64p],
+    "hipbfv_Program_Run": [vp, vp, u64, u64, C.POINTER(C.c_uint32), vpp, u64p, vp, vp, u64, vpp, vp],
     "hipbfv_profile_enable": [vp, C.c_bool],
     "hipbfv_profile_reset": [vp],
     "hipbfv_profile_kernel_count": [C.POINTER(C.c_uint32)],

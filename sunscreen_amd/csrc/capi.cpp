@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "evaluator.hpp"
+#include "program.hpp"
 
 using namespace hipbfv;
 
@@ -54,6 +55,7 @@ enum Magic : uint32_t {
   kMagicCipher = 0x43504831,
   kMagicKeys = 0x4B535731,
   kMagicEval = 0x45564C31,
+  kMagicProgram = 0x50524731,
 };
 
 struct Obj {
@@ -167,6 +169,11 @@ struct EvalObj : Obj {
   std::shared_ptr<Context> ctx;
   std::unique_ptr<Evaluator> ev;
   EvalObj() : Obj(kMagicEval) {}
+};
+
+struct ProgramObj : Obj {
+  Program prog;
+  ProgramObj() : Obj(kMagicProgram) {}
 };
 
 // one non-blocking stream per host thread: concurrent handle-level calls do not serialise on the null stream
@@ -1202,6 +1209,76 @@ long hipbfv_batch_ntt(void* h, uint64_t* data, uint64_t polys, uint64_t nprimes,
   EVAL_OR_RETURN(h);
   if (!data) return HIPBFV_E_POINTER;
   return from_status(e->ev->ntt((u64*)data, polys, (u32)nprimes, inverse, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------ program graphs (batch executor)
+long hipbfv_Program_Create(void** out) {
+  if (!out) return HIPBFV_E_POINTER;
+  *out = new ProgramObj();
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Program_Destroy(void* h) {
+  ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
+  if (!p) return HIPBFV_E_POINTER;
+  delete p;
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Program_AddNode(void* h, uint32_t op, uint64_t arg, uint32_t* node_id) {
+  ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
+  if (!p || !node_id) return HIPBFV_E_POINTER;
+  if (op >= (uint32_t)kOpCount) return fail(HIPBFV_E_INVALIDARG, "unknown operation kind");
+  *node_id = (uint32_t)p->prog.add_node((OpKind)op, arg);
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Program_AddEdge(void* h, uint32_t src, uint32_t dst, uint32_t kind) {
+  ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
+  if (!p) return HIPBFV_E_POINTER;
+  if (kind > 2 || p->prog.add_edge((int)src, (int)dst, (EdgeKind)kind) != kOk) return fail(HIPBFV_E_INVALIDARG, "invalid edge");
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Program_LoadJson(void* h, const char* json, uint64_t length) {
+  ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
+  if (!p || !json) return HIPBFV_E_POINTER;
+  std::string err;
+  if (p->prog.load_json(json, length, &err) != kOk) return fail(HIPBFV_E_INVALIDARG, err.c_str());
+  if (p->prog.validate(&err) != kOk) return fail(HIPBFV_E_INVALIDARG, err.c_str());
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Program_NumOutputs(void* h, uint64_t* count) {
+  ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
+  if (!p || !count) return HIPBFV_E_POINTER;
+  *count = p->prog.num_outputs();
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t* input_kinds,
+                        const uint64_t* const* input_ptrs, const uint64_t* input_strides, void* relin_keys, void* galois_keys,
+                        uint64_t num_outputs, uint64_t* const* outputs, void* stream) {
+  ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
+  EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
+  if (!p || !e || (num_inputs && (!input_kinds || !input_ptrs || !input_strides)) || (num_outputs && !outputs)) return HIPBFV_E_POINTER;
+  std::vector<ProgramInput> ins(num_inputs);
+  for (uint64_t i = 0; i < num_inputs; i++) ins[i] = ProgramInput{(int)input_kinds[i], (const u64*)input_ptrs[i], (size_t)input_strides[i]};
+  const u64* rk = nullptr;
+  std::map<u32, const u64*> gk;
+  if (KeysObj* k = as<KeysObj>(relin_keys, kMagicKeys))
+    if (k->ctx.get() == e->ctx.get()) rk = k->find(0);
+  if (KeysObj* k = as<KeysObj>(galois_keys, kMagicKeys))
+    if (k->ctx.get() == e->ctx.get())
+      for (auto& kv : k->keys) gk[kv.first] = kv.second;
+  std::string err;
+  int st = p->prog.run(*e->ev, batch, ins.data(), ins.size(), rk, gk, (u64* const*)outputs, num_outputs, (hipStream_t)stream, &err);
+  if (st != kOk) {
+    long hr = from_status(st);
+    if (!err.empty()) tls_error = err;
+    return hr;
+  }
+  return HIPBFV_S_OK;
 }
 
 long hipbfv_profile_enable(void* h, bool enabled) {

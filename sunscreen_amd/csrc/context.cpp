@@ -1,9 +1,11 @@
 // sunscreen_amd/csrc/context.cpp -- see context.hpp.
 #include "context.hpp"
+#include "nttshape.hpp"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -92,6 +94,78 @@ struct BigUint {
   }
   int bits() const { return (int)(64 * (w.size() - 1)) + (w.back() ? 64 - __builtin_clzll(w.back()) : 0); }
 };
+
+inline MulOpD make_mulop_d(u64 w, u64 q) {
+  MulOpD m;
+  m.w = (double)w;
+  m.wq = (double)w / (double)q;
+  return m;
+}
+
+// FP64 arithmetic path: residues are exact integers held in doubles.  A twiddle product
+// T = Y*W - rint(Y*(W/q))*q is computed exactly (error-free product via fma) and satisfies
+// |T| <= q*(0.5 + |Y|*2^-52); butterflies only add and subtract, so magnitudes grow per stage and
+// every value must stay below 2^53.  This simulates the worst-case growth (in units of q) through the
+// kernel's pass structure and decides at which pass starts all values must be reduced mod q.
+bool plan_f64_path(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
+  if (q >= (1ull << 50)) return false;
+  const double limit = 0.98 * 9007199254740992.0 / (double)q;  // 2^53 / q with a margin
+  const double eps = (double)q / 4503599627370496.0;           // q * 2^-52
+  const int np = ntt_num_passes(logn);
+  // forward (Cooley-Tukey): X' = X + T, Y' = X - T
+  {
+    double M = 1.0;  // canonical input in [0,q)
+    u32 mask = 0;
+    for (int p = 0; p < np; p++) {
+      const int r = ntt_pass_radix(logn, p);
+      auto run = [&](double m, bool* ok) {
+        *ok = true;
+        for (int s = 0; s < r; s++) {
+          m = m + 0.5 + m * eps;
+          if (m > limit) *ok = false;
+        }
+        return m;
+      };
+      bool ok;
+      double m = run(M, &ok);
+      if (!ok) {
+        mask |= 1u << p;
+        m = run(0.5 + M * eps, &ok);
+        if (!ok) return false;
+      }
+      M = m;
+    }
+    *fwd_mask = mask;
+  }
+  // inverse (Gentleman-Sande): X' = X + Y, Y' = (X - Y) * W ; inverse pass p uses forward pass np-1-p's window
+  {
+    double M = 1.0;
+    u32 mask = 0;
+    for (int p = 0; p < np; p++) {
+      const int r = ntt_pass_radix(logn, np - 1 - p);
+      auto run = [&](double m, bool* ok) {
+        *ok = true;
+        for (int s = 0; s < r; s++) {
+          const double d = 2.0 * m;  // |X - Y| and |X + Y|
+          if (d > limit) *ok = false;
+          const double t = 0.5 + d * eps;
+          m = d > t ? d : t;
+        }
+        return m;
+      };
+      bool ok;
+      double m = run(M, &ok);
+      if (!ok) {
+        mask |= 1u << p;
+        m = run(0.5 + M * eps, &ok);
+        if (!ok) return false;
+      }
+      M = m;
+    }
+    *inv_mask = mask;
+  }
+  return true;
+}
 
 }  // namespace
 
@@ -261,6 +335,12 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     u64 ninv;
     if (!invm(n, p, &ninv)) return fail("n not invertible");
     dm.ninv = make_mulop(ninv, p);
+    dm.qd = (double)p;
+    dm.qinv = 1.0 / (double)p;
+    dm.ninv_d = make_mulop_d(ninv, p);
+    dm.use_f64 = plan_f64_path(p, (int)h.logn, &dm.fwd_reduce_mask, &dm.inv_reduce_mask) ? 1u : 0u;
+    if (const char* env = std::getenv("HIPBFV_NO_F64"))
+      if (env[0] == '1') dm.use_f64 = 0;
     const u64 psi = minimal_primitive_root(two_n, p);
     if (!psi) return fail("no primitive root");
     u64 ipsi;
@@ -268,8 +348,14 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     u64 pw = 1, ipw = 1;
     for (u32 i = 0; i < n; i++) {
       const u32 k = bit_reverse(i, h.logn);
-      twf[(size_t)m * n + k] = make_mulop(pw, p);
-      twi[(size_t)m * n + k] = make_mulop(ipw, p);
+      if (dm.use_f64) {
+        const MulOpD f = make_mulop_d(pw, p), b = make_mulop_d(ipw, p);
+        std::memcpy(&twf[(size_t)m * n + k], &f, sizeof(MulOp));
+        std::memcpy(&twi[(size_t)m * n + k], &b, sizeof(MulOp));
+      } else {
+        twf[(size_t)m * n + k] = make_mulop(pw, p);
+        twi[(size_t)m * n + k] = make_mulop(ipw, p);
+      }
       pw = mulm(pw, psi, p);
       ipw = mulm(ipw, ipsi, p);
     }
@@ -283,6 +369,7 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     h.q_to_mtilde[i] = (u32)prod_mod(q, m_tilde, (int)i);
     const u64 nt = mulm(h.mod[i].ninv.w, t % q[i], q[i]);
     h.intt_scale_q[i] = make_mulop(mulm(nt, inv_punct, q[i]), q[i]);
+    h.intt_scale_q_d[i] = make_mulop_d(mulm(nt, inv_punct, q[i]), q[i]);
     h.B_mod_q[i] = prod_mod(B, q[i]);
     for (u32 j = 0; j < h.nB; j++) h.B_to_q[i][j] = prod_mod(B, q[i], (int)j);
   }

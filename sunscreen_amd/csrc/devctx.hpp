@@ -22,12 +22,27 @@ struct MulOp {
   u64 wq;
 };
 
+// The same constant for the FP64 arithmetic path: w and w/q as doubles (exact integer w < 2^50).
+struct MulOpD {
+  double w;
+  double wq;
+};
+
 struct DevMod {
   u64 q;
   u64 q2;       // 2q
   u64 bar_lo;   // floor(2^128 / q), low word
   u64 bar_hi;   // floor(2^128 / q), high word
   MulOp ninv;   // n^{-1} mod q
+  // FP64 path (primes < 2^50 whose range simulation succeeds, see context.cpp): residues are held as
+  // exact integers in doubles; *_reduce_mask bit p = "reduce every value mod q at the start of pass p".
+  u32 use_f64;
+  u32 fwd_reduce_mask;
+  u32 inv_reduce_mask;
+  u32 pad;
+  double qd;     // (double) q
+  double qinv;   // 1.0 / q
+  MulOpD ninv_d; // n^{-1} mod q
 };
 
 struct DevCtx {
@@ -42,7 +57,8 @@ struct DevCtx {
 
   // moduli: [0, KK) key-level primes, [KK, KK+S) Bsk primes (B..., m_sk)
   DevMod mod[kMaxMod];
-  // twiddles: tw_fwd[m*n + k] = psi_m^{bitrev(k)}, tw_inv[m*n + k] = psi_m^{-bitrev(k)} (k >= 1)
+  // twiddles: tw_fwd[m*n + k] = psi_m^{bitrev(k)}, tw_inv[m*n + k] = psi_m^{-bitrev(k)} (k >= 1);
+  // for moduli with use_f64 the 16-byte entries hold MulOpD instead of MulOp
   const MulOp* tw_fwd;
   const MulOp* tw_inv;
 
@@ -55,6 +71,7 @@ struct DevCtx {
   u64 q_mod_bsk[kMaxBsk];              // q mod Bsk_j
   MulOp inv_mtilde_mod_bsk[kMaxBsk];   // m_tilde^{-1} mod Bsk_j
   MulOp intt_scale_q[kMaxKey];         // n^{-1} * t * (q/q_i)^{-1} mod q_i  (INTT epilogue before fast_floor)
+  MulOpD intt_scale_q_d[kMaxKey];      // same constant for the FP64 path
   MulOp intt_scale_bsk[kMaxBsk];       // n^{-1} * t mod Bsk_j
   MulOp inv_q_mod_bsk[kMaxBsk];        // q^{-1} mod Bsk_j
   MulOp inv_punct_B[kMaxBsk];          // (B/B_j)^{-1} mod B_j

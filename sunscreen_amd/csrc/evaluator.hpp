@@ -93,6 +93,7 @@ class Evaluator {
  public:
   explicit Evaluator(Context* ctx);
   Profiler& profiler() { return prof_; }
+  ScratchPool& scratch() { return pool_; }
   Context* ctx() const { return ctx_; }
 
   // ---- SURVEY 8a rows a1-a5, batched ----

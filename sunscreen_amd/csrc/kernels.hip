@@ -17,6 +17,7 @@
 
 #include "devarith.hpp"
 #include "kernels.hpp"
+#include "nttshape.hpp"
 
 namespace hipbfv {
 
@@ -27,21 +28,17 @@ namespace hipbfv {
 // accesses of the late passes over the banks).
 // =====================================================================================
 
-constexpr int kElemsPerThread = 16;
-
 __device__ __forceinline__ u32 lds_pos(u32 e) { return e + (e >> 5); }
 
 template <int LOGN>
 struct NttShape {
   static constexpr int N = 1 << LOGN;
   static constexpr int T = N / kElemsPerThread;
-  static constexpr int NPASS = (LOGN + 3) / 4;
-  static constexpr int BASE = LOGN / NPASS;
-  static constexpr int EXTRA = LOGN % NPASS;
+  static constexpr int NPASS = ntt_num_passes(LOGN);
   static constexpr int LDS_WORDS = N + (N >> 5);
   // radix (number of stages) of pass p, and the number of stages before it
-  static constexpr int radix(int p) { return BASE + (p < EXTRA ? 1 : 0); }
-  static constexpr int before(int p) { return p * BASE + (p < EXTRA ? p : EXTRA); }
+  static constexpr int radix(int p) { return ntt_pass_radix(LOGN, p); }
+  static constexpr int before(int p) { return ntt_stages_before(LOGN, p); }
 };
 
 // element index handled by virtual thread vt in a pass that covers bit positions [LOW, LOW+R)
@@ -52,9 +49,76 @@ __device__ __forceinline__ u32 elem_index(u32 vt, u32 k) {
   return (hi << (LOW + R)) | (k << LOW) | lo;
 }
 
-// ---- forward (Cooley-Tukey, gap shrinking). Values lazy in [0,4q). ----
-template <int LOGN, int S0, int R>
-__device__ __forceinline__ void fwd_pass_compute(u64 (&v)[kElemsPerThread], u32 tid, const MulOp* __restrict__ tw, u64 q, u64 q2) {
+// ---- arithmetic policies -------------------------------------------------------------
+// ArithI: 64-bit integers, Harvey lazy butterflies with Shoup twiddles (any prime < 2^62).
+struct ArithI {
+  using V = u64;
+  using Tw = MulOp;
+  u64 q, q2;
+  __device__ __forceinline__ explicit ArithI(const DevMod& m) : q(m.q), q2(m.q << 1) {}
+  __device__ __forceinline__ V from_u64(u64 x) const { return x; }
+  __device__ __forceinline__ V reduce(V v) const { return v; }  // lazy invariants hold without it
+  // forward: X,Y in [0,4q) -> [0,4q)
+  __device__ __forceinline__ void fwd(V& X, V& Y, const Tw& w) const {
+    const u64 x = X >= q2 ? X - q2 : X;
+    const u64 t = mul_shoup_lazy(Y, w.w, w.wq, q);
+    X = x + t;
+    Y = x + q2 - t;
+  }
+  // inverse: X,Y in [0,2q) -> [0,2q)
+  __device__ __forceinline__ void inv(V& X, V& Y, const Tw& w) const {
+    const u64 u = X, y = Y, s = u + y;
+    X = s >= q2 ? s - q2 : s;
+    Y = mul_shoup_lazy(u + q2 - y, w.w, w.wq, q);
+  }
+  __device__ __forceinline__ u64 canonical(V v) const {  // v in [0,4q)
+    v = v >= q2 ? v - q2 : v;
+    return v >= q ? v - q : v;
+  }
+  __device__ __forceinline__ u64 scale_canonical(V v, const Tw& sc) const { return mul_shoup(v, sc.w, sc.wq, q); }
+};
+
+// ArithD: residues as exact integers in doubles (primes < 2^50).  T = Y*W - rint(Y*(W/q))*q is exact:
+// the product is split error-free with an fma, the quotient estimate is off by at most
+// 0.5 + |Y|*2^-52, and every intermediate is an integer below 2^53 (range plan: context.cpp).
+struct ArithD {
+  using V = double;
+  using Tw = MulOpD;
+  double q, qinv;
+  __device__ __forceinline__ explicit ArithD(const DevMod& m) : q(m.qd), qinv(m.qinv) {}
+  __device__ __forceinline__ V from_u64(u64 x) const {
+    // exact for x < 2^52: plant the integer in the mantissa of 2^52 and subtract 2^52
+    return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0;
+  }
+  __device__ __forceinline__ V mul_const(V y, const Tw& w) const {
+    const double qf = rint(y * w.wq);
+    const double xh = y * w.w;
+    const double xl = fma(y, w.w, -xh);
+    return fma(-qf, q, xh) + xl;
+  }
+  __device__ __forceinline__ V reduce(V v) const { return fma(-rint(v * qinv), q, v); }
+  __device__ __forceinline__ void fwd(V& X, V& Y, const Tw& w) const {
+    const double t = mul_const(Y, w), x = X;
+    X = x + t;
+    Y = x - t;
+  }
+  __device__ __forceinline__ void inv(V& X, V& Y, const Tw& w) const {
+    const double u = X, y = Y;
+    X = u + y;
+    Y = mul_const(u - y, w);
+  }
+  __device__ __forceinline__ u64 to_u64(V v) const {  // v an integer in (-q, q)
+    v = v < 0.0 ? v + q : v;
+    return (u64)__double_as_longlong(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
+  }
+  __device__ __forceinline__ u64 canonical(V v) const { return to_u64(reduce(v)); }
+  __device__ __forceinline__ u64 scale_canonical(V v, const Tw& sc) const { return to_u64(reduce(mul_const(v, sc))); }
+};
+
+// ---- forward (Cooley-Tukey, gap shrinking) ----
+template <class A, int LOGN, int S0, int R>
+__device__ __forceinline__ void fwd_pass_compute(const A& ar, typename A::V (&v)[kElemsPerThread], u32 tid,
+                                                 const typename A::Tw* __restrict__ tw) {
   constexpr int T = NttShape<LOGN>::T;
   constexpr int G = kElemsPerThread >> R;
   constexpr int LOW = LOGN - S0 - R;
@@ -69,22 +133,18 @@ __device__ __forceinline__ void fwd_pass_compute(u64 (&v)[kElemsPerThread], u32 
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
         const u32 widx = (1u << (S0 + j)) + ((hi << j) | (u32)(k >> (R - j)));
-        const MulOp w = tw[widx];
-        u64& X = v[g * (1 << R) + k];
-        u64& Y = v[g * (1 << R) + k + half];
-        const u64 x = X >= q2 ? X - q2 : X;
-        const u64 t = mul_shoup_lazy(Y, w.w, w.wq, q);
-        X = x + t;
-        Y = x + q2 - t;
+        const typename A::Tw w = tw[widx];
+        ar.fwd(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w);
       }
     }
   }
 }
 
-template <int LOGN, int PASS>
+template <class A, int LOGN, int PASS>
 struct FwdPasses {
   // run passes PASS..NPASS-1 with data resident in LDS on entry to every pass but the first
-  static __device__ __forceinline__ void run(u64 (&v)[kElemsPerThread], u64* smem, u32 tid, const MulOp* tw, u64 q, u64 q2) {
+  static __device__ __forceinline__ void run(const A& ar, typename A::V (&v)[kElemsPerThread], typename A::V* smem, u32 tid,
+                                             const typename A::Tw* tw, u32 reduce_mask) {
     using Sh = NttShape<LOGN>;
     constexpr int R = Sh::radix(PASS);
     constexpr int S0 = Sh::before(PASS);
@@ -97,34 +157,40 @@ struct FwdPasses {
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
     }
-    fwd_pass_compute<LOGN, S0, R>(v, tid, tw, q, q2);
+    if ((reduce_mask >> PASS) & 1u) {
+#pragma unroll
+      for (int e = 0; e < kElemsPerThread; e++) v[e] = ar.reduce(v[e]);
+    }
+    fwd_pass_compute<A, LOGN, S0, R>(ar, v, tid, tw);
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[g * (1 << R) + k];
-    if constexpr (PASS + 1 < Sh::NPASS) FwdPasses<LOGN, PASS + 1>::run(v, smem, tid, tw, q, q2);
+    if constexpr (PASS + 1 < Sh::NPASS) FwdPasses<A, LOGN, PASS + 1>::run(ar, v, smem, tid, tw, reduce_mask);
   }
 };
 
-// Forward NTT of one polynomial: src (global, canonical) -> LDS (lazy [0,4q)); caller copies out.
-template <int LOGN>
-__device__ __forceinline__ void ntt_fwd_to_lds(const u64* __restrict__ src, u64* smem, u32 tid, const MulOp* tw, u64 q) {
+// Forward NTT of one polynomial: src (global, canonical u64) -> LDS (policy representation, lazy).
+template <class A, int LOGN>
+__device__ __forceinline__ void ntt_fwd_to_lds(const A& ar, const u64* __restrict__ src, typename A::V* smem, u32 tid,
+                                               const typename A::Tw* tw, u32 reduce_mask) {
   using Sh = NttShape<LOGN>;
   constexpr int R0 = Sh::radix(0);
   constexpr int LOW0 = LOGN - R0;
   constexpr int G0 = kElemsPerThread >> R0;
-  u64 v[kElemsPerThread];
+  typename A::V v[kElemsPerThread];
 #pragma unroll
   for (int g = 0; g < G0; g++)
 #pragma unroll
-    for (int k = 0; k < (1 << R0); k++) v[g * (1 << R0) + k] = src[elem_index<LOW0, R0>(tid + g * Sh::T, k)];
-  FwdPasses<LOGN, 0>::run(v, smem, tid, tw, q, q << 1);
+    for (int k = 0; k < (1 << R0); k++) v[g * (1 << R0) + k] = ar.from_u64(src[elem_index<LOW0, R0>(tid + g * Sh::T, k)]);
+  FwdPasses<A, LOGN, 0>::run(ar, v, smem, tid, tw, reduce_mask);
   __syncthreads();
 }
 
-// ---- inverse (Gentleman-Sande, gap growing). Values lazy in [0,2q). ----
-template <int LOGN, int LOW, int R>
-__device__ __forceinline__ void inv_pass_compute(u64 (&v)[kElemsPerThread], u32 tid, const MulOp* __restrict__ tw, u64 q, u64 q2) {
+// ---- inverse (Gentleman-Sande, gap growing) ----
+template <class A, int LOGN, int LOW, int R>
+__device__ __forceinline__ void inv_pass_compute(const A& ar, typename A::V (&v)[kElemsPerThread], u32 tid,
+                                                 const typename A::Tw* __restrict__ tw) {
   constexpr int T = NttShape<LOGN>::T;
   constexpr int G = kElemsPerThread >> R;
 #pragma unroll
@@ -139,22 +205,18 @@ __device__ __forceinline__ void inv_pass_compute(u64 (&v)[kElemsPerThread], u32 
         if (k & half) continue;
         // global gap 2^(LOW+j): m = N >> (LOW+j+1) blocks, block index = element >> (LOW+j+1)
         const u32 widx = (1u << (LOGN - 1 - LOW - j)) + ((hi << (R - 1 - j)) | (u32)(k >> (j + 1)));
-        const MulOp w = tw[widx];
-        u64& X = v[g * (1 << R) + k];
-        u64& Y = v[g * (1 << R) + k + half];
-        const u64 u = X, y = Y;
-        const u64 s = u + y;
-        X = s >= q2 ? s - q2 : s;
-        Y = mul_shoup_lazy(u + q2 - y, w.w, w.wq, q);
+        const typename A::Tw w = tw[widx];
+        ar.inv(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w);
       }
     }
   }
 }
 
-template <int LOGN, int PASS>
+template <class A, int LOGN, int PASS>
 struct InvPasses {
   // inverse pass PASS covers the same bit window as forward pass NPASS-1-PASS
-  static __device__ __forceinline__ void run(u64 (&v)[kElemsPerThread], u64* smem, u32 tid, const MulOp* tw, u64 q, u64 q2) {
+  static __device__ __forceinline__ void run(const A& ar, typename A::V (&v)[kElemsPerThread], typename A::V* smem, u32 tid,
+                                             const typename A::Tw* tw, u32 reduce_mask) {
     using Sh = NttShape<LOGN>;
     constexpr int FP = Sh::NPASS - 1 - PASS;
     constexpr int R = Sh::radix(FP);
@@ -165,42 +227,70 @@ struct InvPasses {
     for (int g = 0; g < G; g++)
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
-    inv_pass_compute<LOGN, LOW, R>(v, tid, tw, q, q2);
+    if ((reduce_mask >> PASS) & 1u) {
+#pragma unroll
+      for (int e = 0; e < kElemsPerThread; e++) v[e] = ar.reduce(v[e]);
+    }
+    inv_pass_compute<A, LOGN, LOW, R>(ar, v, tid, tw);
     if constexpr (PASS + 1 < Sh::NPASS) {
 #pragma unroll
       for (int g = 0; g < G; g++)
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[g * (1 << R) + k];
-      InvPasses<LOGN, PASS + 1>::run(v, smem, tid, tw, q, q2);
+      InvPasses<A, LOGN, PASS + 1>::run(ar, v, smem, tid, tw, reduce_mask);
     }
   }
 };
 
 // Inverse NTT of the polynomial resident in LDS; the last pass leaves each thread holding the
 // elements elem_index<LOGN-R, R>(tid + g*T, k), which the caller scales and stores (coalesced).
-template <int LOGN>
-__device__ __forceinline__ void ntt_inv_from_lds(u64 (&v)[kElemsPerThread], u64* smem, u32 tid, const MulOp* tw, u64 q) {
-  InvPasses<LOGN, 0>::run(v, smem, tid, tw, q, q << 1);
+template <class A, int LOGN>
+__device__ __forceinline__ void ntt_inv_from_lds(const A& ar, typename A::V (&v)[kElemsPerThread], typename A::V* smem, u32 tid,
+                                                 const typename A::Tw* tw, u32 reduce_mask) {
+  InvPasses<A, LOGN, 0>::run(ar, v, smem, tid, tw, reduce_mask);
 }
 
 __device__ __forceinline__ u32 plan_mod(const NttPlan& plan, u32 poly) { return plan.mod[(poly / plan.div) % plan.period]; }
+
+template <class A, int LOGN>
+__device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid) {
+  using Sh = NttShape<LOGN>;
+  const A ar(dm);
+  ntt_fwd_to_lds<A, LOGN>(ar, x, smem, tid, tw, dm.fwd_reduce_mask);
+  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) x[e] = ar.canonical(smem[lds_pos(e)]);
+}
 
 template <int LOGN>
 __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx* __restrict__ ctx, u64* data, NttPlan plan) {
   using Sh = NttShape<LOGN>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  u64* smem = reinterpret_cast<u64*>(smem_raw);
   const u32 tid = threadIdx.x;
   const u32 poly = blockIdx.x;
   const u32 m = plan_mod(plan, poly);
-  const u64 q = ctx->mod[m].q, q2 = q << 1;
+  const DevMod& dm = ctx->mod[m];
   u64* x = data + (size_t)poly * Sh::N;
-  ntt_fwd_to_lds<LOGN>(x, smem, tid, ctx->tw_fwd + (size_t)m * Sh::N, q);
-  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) {
-    u64 val = smem[lds_pos(e)];
-    val = val >= q2 ? val - q2 : val;
-    x[e] = val >= q ? val - q : val;
-  }
+  const MulOp* tw = ctx->tw_fwd + (size_t)m * Sh::N;
+  if (dm.use_f64)
+    ntt_fwd_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem_raw), tid);
+  else
+    ntt_fwd_body<ArithI, LOGN>(dm, tw, x, reinterpret_cast<u64*>(smem_raw), tid);
+}
+
+template <class A, int LOGN>
+__device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Tw& sc, u64* x,
+                                             typename A::V* smem, u32 tid) {
+  using Sh = NttShape<LOGN>;
+  const A ar(dm);
+  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) smem[lds_pos(e)] = ar.from_u64(x[e]);
+  typename A::V v[kElemsPerThread];
+  ntt_inv_from_lds<A, LOGN>(ar, v, smem, tid, tw, dm.inv_reduce_mask);
+  constexpr int R = Sh::radix(0);
+  constexpr int LOW = LOGN - R;
+  constexpr int G = kElemsPerThread >> R;
+#pragma unroll
+  for (int g = 0; g < G; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) x[elem_index<LOW, R>(tid + g * Sh::T, k)] = ar.scale_canonical(v[g * (1 << R) + k], sc);
 }
 
 // scale_mode: 0 = n^{-1}; 1 = BEHZ epilogue (n^{-1} * t [* (q/q_i)^{-1}]), see DevCtx::intt_scale_*
@@ -208,24 +298,21 @@ template <int LOGN>
 __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx* __restrict__ ctx, u64* data, NttPlan plan, int scale_mode) {
   using Sh = NttShape<LOGN>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  u64* smem = reinterpret_cast<u64*>(smem_raw);
   const u32 tid = threadIdx.x;
   const u32 poly = blockIdx.x;
   const u32 m = plan_mod(plan, poly);
-  const u64 q = ctx->mod[m].q;
+  const DevMod& dm = ctx->mod[m];
   u64* x = data + (size_t)poly * Sh::N;
-  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) smem[lds_pos(e)] = x[e];
-  u64 v[kElemsPerThread];
-  ntt_inv_from_lds<LOGN>(v, smem, tid, ctx->tw_inv + (size_t)m * Sh::N, q);
-  MulOp sc = ctx->mod[m].ninv;
-  if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
-  constexpr int R = Sh::radix(0);
-  constexpr int LOW = LOGN - R;
-  constexpr int G = kElemsPerThread >> R;
-#pragma unroll
-  for (int g = 0; g < G; g++)
-#pragma unroll
-    for (int k = 0; k < (1 << R); k++) x[elem_index<LOW, R>(tid + g * Sh::T, k)] = mul_shoup(v[g * (1 << R) + k], sc.w, sc.wq, q);
+  const MulOp* tw = ctx->tw_inv + (size_t)m * Sh::N;
+  if (dm.use_f64) {
+    MulOpD sc = dm.ninv_d;
+    if (scale_mode == 1) sc = ctx->intt_scale_q_d[m];  // f64 moduli are key-level primes
+    ntt_inv_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), sc, x, reinterpret_cast<double*>(smem_raw), tid);
+  } else {
+    MulOp sc = dm.ninv;
+    if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
+    ntt_inv_body<ArithI, LOGN>(dm, tw, sc, x, reinterpret_cast<u64*>(smem_raw), tid);
+  }
 }
 
 template <int LOGN>

@@ -1,0 +1,565 @@
+// sunscreen_amd/csrc/program.cpp -- the GPU batch executor for compiled FHE program graphs.
+//
+// Replaces the reference's graph interpreter (sunscreen_runtime/src/run.rs:100-357,
+// `run_program_unchecked` + the rayon `traverse` at run.rs:372-472): instead of one evaluator FFI
+// call per node per ciphertext, one graph is executed over `batch` independent input sets, one
+// sequence of kernel launches per node, with every intermediate ciphertext device-resident.
+// The graph uses the reference's node kinds (sunscreen_fhe_program/src/operation.rs:12-94) and edge
+// kinds Left/Right/Unary (sunscreen_compiler_common/src/context.rs:60-85); `load_json` accepts the serde
+// JSON form of `FheProgram` (petgraph StableGraph: {"nodes":[{"operation":..}],"edges":[[src,dst,"Left"]]}).
+#include "program.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+
+namespace hipbfv {
+
+namespace {
+
+// ---------------------------------------------------------------- minimal JSON reader
+struct JValue {
+  enum Kind { kNull, kBool, kNum, kStr, kArr, kObj } kind = kNull;
+  bool b = false;
+  double num = 0;
+  unsigned long long unum = 0;
+  std::string str;
+  std::vector<JValue> arr;
+  std::vector<std::pair<std::string, JValue>> obj;
+  const JValue* get(const char* key) const {
+    for (auto& kv : obj)
+      if (kv.first == key) return &kv.second;
+    return nullptr;
+  }
+};
+
+struct JParser {
+  const char* p;
+  const char* end;
+  bool ok = true;
+  void ws() {
+    while (p < end && std::isspace((unsigned char)*p)) p++;
+  }
+  bool lit(const char* s) {
+    size_t n = std::strlen(s);
+    if ((size_t)(end - p) >= n && std::strncmp(p, s, n) == 0) {
+      p += n;
+      return true;
+    }
+    return false;
+  }
+  JValue parse() {
+    JValue v;
+    ws();
+    if (p >= end) {
+      ok = false;
+      return v;
+    }
+    if (*p == '{') {
+      v.kind = JValue::kObj;
+      p++;
+      ws();
+      if (p < end && *p == '}') {
+        p++;
+        return v;
+      }
+      while (ok) {
+        ws();
+        JValue k = parse();
+        if (k.kind != JValue::kStr) {
+          ok = false;
+          break;
+        }
+        ws();
+        if (p >= end || *p != ':') {
+          ok = false;
+          break;
+        }
+        p++;
+        v.obj.emplace_back(k.str, parse());
+        ws();
+        if (p < end && *p == ',') {
+          p++;
+          continue;
+        }
+        if (p < end && *p == '}') {
+          p++;
+          break;
+        }
+        ok = false;
+      }
+    } else if (*p == '[') {
+      v.kind = JValue::kArr;
+      p++;
+      ws();
+      if (p < end && *p == ']') {
+        p++;
+        return v;
+      }
+      while (ok) {
+        v.arr.push_back(parse());
+        ws();
+        if (p < end && *p == ',') {
+          p++;
+          continue;
+        }
+        if (p < end && *p == ']') {
+          p++;
+          break;
+        }
+        ok = false;
+      }
+    } else if (*p == '"') {
+      v.kind = JValue::kStr;
+      p++;
+      while (p < end && *p != '"') {
+        if (*p == '\\' && p + 1 < end) p++;
+        v.str.push_back(*p++);
+      }
+      if (p >= end)
+        ok = false;
+      else
+        p++;
+    } else if (lit("true")) {
+      v.kind = JValue::kBool;
+      v.b = true;
+    } else if (lit("false")) {
+      v.kind = JValue::kBool;
+    } else if (lit("null")) {
+      v.kind = JValue::kNull;
+    } else {
+      char* e = nullptr;
+      v.kind = JValue::kNum;
+      v.num = std::strtod(p, &e);
+      if (e == p) {
+        ok = false;
+        return v;
+      }
+      if (*p != '-') v.unum = std::strtoull(p, nullptr, 10);
+      p = e;
+    }
+    return v;
+  }
+};
+
+const struct {
+  const char* name;
+  OpKind kind;
+} kOpNames[] = {
+    {"ShiftLeft", kOpShiftLeft},       {"ShiftRight", kOpShiftRight}, {"SwapRows", kOpSwapRows},
+    {"Relinearize", kOpRelinearize},   {"Multiply", kOpMultiply},     {"MultiplyPlaintext", kOpMultiplyPlaintext},
+    {"Add", kOpAdd},                   {"AddPlaintext", kOpAddPlaintext}, {"Negate", kOpNegate},
+    {"Sub", kOpSub},                   {"SubPlaintext", kOpSubPlaintext}, {"InputCiphertext", kOpInputCiphertext},
+    {"InputPlaintext", kOpInputPlaintext}, {"Literal", kOpLiteralU64},    {"OutputCiphertext", kOpOutputCiphertext},
+};
+
+bool op_from_name(const std::string& s, OpKind* k) {
+  for (auto& e : kOpNames)
+    if (s == e.name) {
+      *k = e.kind;
+      return true;
+    }
+  return false;
+}
+
+}  // namespace
+
+int Program::add_node(OpKind op, u64 arg) {
+  nodes_.push_back(Node{op, arg, -1, -1});
+  return (int)nodes_.size() - 1;
+}
+
+int Program::add_edge(int src, int dst, EdgeKind kind) {
+  if (src < 0 || dst < 0 || src >= (int)nodes_.size() || dst >= (int)nodes_.size() || src == dst) return kInvalidArg;
+  Node& d = nodes_[dst];
+  if (kind == kEdgeRight) {
+    if (d.right >= 0) return kInvalidArg;
+    d.right = src;
+  } else {
+    if (d.left >= 0) return kInvalidArg;
+    d.left = src;
+  }
+  return kOk;
+}
+
+int Program::load_json(const char* text, size_t len, std::string* err) {
+  JParser jp{text, text + len};
+  JValue root = jp.parse();
+  auto fail = [&](const char* m) {
+    if (err) *err = m;
+    return (int)kInvalidArg;
+  };
+  if (!jp.ok || root.kind != JValue::kObj) return fail("malformed JSON");
+  const JValue* g = root.get("graph") ? root.get("graph") : &root;
+  const JValue* nodes = g->get("nodes");
+  const JValue* edges = g->get("edges");
+  if (!nodes || !edges || nodes->kind != JValue::kArr || edges->kind != JValue::kArr) return fail("graph needs nodes and edges");
+  const JValue* holes = g->get("node_holes");
+  if (holes && holes->kind == JValue::kArr && !holes->arr.empty()) return fail("graphs with node holes are not supported");
+  nodes_.clear();
+  for (const JValue& nv : nodes->arr) {
+    const JValue* op = nv.kind == JValue::kObj ? nv.get("operation") : nullptr;
+    if (!op) return fail("node without operation");
+    OpKind kind;
+    u64 arg = 0;
+    if (op->kind == JValue::kStr) {  // unit variant
+      if (!op_from_name(op->str, &kind)) return fail("unknown operation");
+      if (kind == kOpInputCiphertext || kind == kOpInputPlaintext || kind == kOpLiteralU64) return fail("operation needs a payload");
+    } else if (op->kind == JValue::kObj && op->obj.size() == 1) {  // {"InputCiphertext": 0} / {"Literal": {"U64": 3}}
+      if (!op_from_name(op->obj[0].first, &kind)) return fail("unknown operation");
+      const JValue& payload = op->obj[0].second;
+      if (kind == kOpLiteralU64) {
+        const JValue* u = payload.kind == JValue::kObj ? payload.get("U64") : nullptr;
+        if (!u) return fail("only Literal::U64 is supported (plaintext literals need the SEAL wire format)");
+        arg = u->unum;
+      } else if (kind == kOpInputCiphertext || kind == kOpInputPlaintext) {
+        if (payload.kind != JValue::kNum) return fail("input index must be a number");
+        arg = payload.unum;
+      } else {
+        return fail("unexpected payload");
+      }
+    } else {
+      return fail("malformed operation");
+    }
+    add_node(kind, arg);
+  }
+  for (const JValue& ev : edges->arr) {
+    if (ev.kind != JValue::kArr || ev.arr.size() != 3 || ev.arr[2].kind != JValue::kStr) return fail("malformed edge");
+    EdgeKind ek;
+    if (ev.arr[2].str == "Left")
+      ek = kEdgeLeft;
+    else if (ev.arr[2].str == "Right")
+      ek = kEdgeRight;
+    else if (ev.arr[2].str == "Unary")
+      ek = kEdgeUnary;
+    else
+      return fail("unsupported edge kind");
+    if (add_edge((int)ev.arr[0].unum, (int)ev.arr[1].unum, ek) != kOk) return fail("invalid edge");
+  }
+  return kOk;
+}
+
+int Program::validate(std::string* err) const {
+  auto fail = [&](const char* m) {
+    if (err) *err = m;
+    return (int)kInvalidArg;
+  };
+  for (const Node& nd : nodes_) {
+    switch (nd.op) {
+      case kOpInputCiphertext:
+      case kOpInputPlaintext:
+      case kOpLiteralU64:
+        if (nd.left >= 0 || nd.right >= 0) return fail("input/literal nodes take no operands");
+        break;
+      case kOpNegate:
+      case kOpSwapRows:
+      case kOpRelinearize:
+      case kOpOutputCiphertext:
+        if (nd.left < 0 || nd.right >= 0) return fail("unary node needs exactly one operand");
+        break;
+      default:
+        if (nd.left < 0 || nd.right < 0) return fail("binary node needs a left and a right operand");
+    }
+  }
+  return kOk;
+}
+
+size_t Program::num_outputs() const {
+  size_t c = 0;
+  for (const Node& nd : nodes_) c += nd.op == kOpOutputCiphertext;
+  return c;
+}
+
+// Kahn topological order (the reference walks the same dependency structure with rayon: run.rs:372-472)
+bool Program::topo_order(std::vector<int>* order) const {
+  const int n = (int)nodes_.size();
+  std::vector<int> indeg(n, 0);
+  std::vector<std::vector<int>> users(n);
+  for (int i = 0; i < n; i++) {
+    for (int src : {nodes_[i].left, nodes_[i].right})
+      if (src >= 0) {
+        indeg[i]++;
+        users[src].push_back(i);
+      }
+  }
+  std::vector<int> ready;
+  for (int i = n - 1; i >= 0; i--)
+    if (!indeg[i]) ready.push_back(i);
+  order->clear();
+  while (!ready.empty()) {
+    int v = ready.back();
+    ready.pop_back();
+    order->push_back(v);
+    for (int u : users[v])
+      if (--indeg[u] == 0) ready.push_back(u);
+  }
+  return (int)order->size() == n;
+}
+
+int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
+                 const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs_given, hipStream_t s,
+                 std::string* err) const {
+  auto fail = [&](int code, const char* m) {
+    if (err) *err = m;
+    return code;
+  };
+  if (int rc = validate(err)) return rc;
+  if (num_outputs_given != num_outputs()) return fail(kInvalidArg, "wrong number of output buffers");
+  std::vector<int> order;
+  if (!topo_order(&order)) return fail(kInvalidArg, "program graph has a cycle");
+  Context* ctx = ev.ctx();
+  const size_t n = ctx->n();
+  const int nn = (int)nodes_.size();
+
+  struct Value {
+    const u64* ct = nullptr;  // device ciphertext batch
+    u32 size = 0;
+    bool owned = false;       // allocated from the scratch pool by this run
+    const u64* plain = nullptr;
+    size_t pstride = 0;
+    int uses = 0;
+  };
+  std::vector<Value> val(nn);
+  for (int i = 0; i < nn; i++)
+    for (int src : {nodes_[i].left, nodes_[i].right})
+      if (src >= 0) val[src].uses++;
+
+  ScratchPool& pool = ev.scratch();
+  std::vector<void*> live;
+  auto alloc_ct = [&](u32 size) -> u64* {
+    void* p = pool.acquire(batch * ctx->ct_words(size) * sizeof(u64), s);
+    if (p) live.push_back(p);
+    return (u64*)p;
+  };
+  auto release = [&](int node) {
+    Value& v = val[node];
+    if (--v.uses == 0 && v.owned) {
+      pool.release((void*)v.ct, s);
+      live.erase(std::remove(live.begin(), live.end(), (void*)v.ct), live.end());
+      v.owned = false;
+    }
+  };
+  auto cleanup = [&](int code, const char* m) {
+    for (void* p : live) pool.release(p, s);
+    return fail(code, m);
+  };
+  auto galois_key = [&](u32 elt) -> const u64* {
+    auto it = galois_keys.find((elt - 1) >> 1);
+    return it == galois_keys.end() ? nullptr : it->second;
+  };
+  // rotate `in` by `steps` into `out` following SEAL's rotate_internal (direct key or NAF chain)
+  std::function<int(const u64*, int, u64*)> rotate = [&](const u64* in, int steps, u64* out) -> int {
+    if (steps == 0) {
+      if (in != out && hipMemcpyAsync(out, in, batch * ctx->ct_words(2) * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return kHipError;
+      return kOk;
+    }
+    const u32 elt = ev.galois_elt_from_step(steps);
+    if (!elt) return kInvalidArg;
+    if (const u64* key = galois_key(elt)) return ev.apply_galois(in, elt, key, out, batch, s);
+    std::vector<int> naf;
+    const bool neg = steps < 0;
+    int v = neg ? -steps : steps;
+    for (int i = 0; v; i++) {
+      const int zi = (v & 1) ? 2 - (v & 3) : 0;
+      v = (v - zi) >> 1;
+      if (zi) naf.push_back((neg ? -zi : zi) * (1 << i));
+    }
+    if (naf.size() == 1) return kNoKey;
+    const u64* cur = in;
+    for (int part : naf) {
+      if ((size_t)(part < 0 ? -part : part) == (n >> 1)) continue;
+      int rc = rotate(cur, part, out);
+      if (rc) return rc;
+      cur = out;
+    }
+    return kOk;
+  };
+
+  size_t out_idx = 0;
+  std::vector<int> out_slot(nn, -1);
+  for (int i = 0; i < nn; i++)
+    if (nodes_[i].op == kOpOutputCiphertext) out_slot[i] = (int)out_idx++;
+
+  // a Multiply consumed only by one Relinearize is executed as the fused multiply_relin
+  std::vector<int> fused_into(nn, -1);
+  for (int i = 0; i < nn; i++) {
+    if (nodes_[i].op == kOpRelinearize) {
+      const int m = nodes_[i].left;
+      if (nodes_[m].op == kOpMultiply && val[m].uses == 1) fused_into[m] = i;
+    }
+  }
+
+  for (int id : order) {
+    const Node& nd = nodes_[id];
+    Value& v = val[id];
+    const Value* L = nd.left >= 0 ? &val[nd.left] : nullptr;
+    const Value* R = nd.right >= 0 ? &val[nd.right] : nullptr;
+    int rc = kOk;
+    switch (nd.op) {
+      case kOpInputCiphertext:
+      case kOpInputPlaintext: {
+        if (nd.arg >= num_inputs) return cleanup(kInvalidArg, "input index out of range");
+        const ProgramInput& in = inputs[nd.arg];
+        if (nd.op == kOpInputCiphertext) {
+          if (in.kind != 0 || !in.ptr) return cleanup(kInvalidArg, "argument is not a ciphertext");
+          v.ct = in.ptr;
+          v.size = 2;
+        } else {
+          if (in.kind != 1 || !in.ptr) return cleanup(kInvalidArg, "argument is not a plaintext");
+          v.plain = in.ptr;
+          v.pstride = in.stride;
+        }
+        continue;
+      }
+      case kOpLiteralU64:
+        continue;
+      case kOpOutputCiphertext: {
+        if (!L->ct || L->size != 2) return cleanup(kInvalidArg, "program output must be a size-2 ciphertext");
+        if (hipMemcpyAsync(outputs[out_slot[id]], L->ct, batch * ctx->ct_words(2) * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess)
+          return cleanup(kHipError, "copy failed");
+        release(nd.left);
+        continue;
+      }
+      default:
+        break;
+    }
+    if (!L || !L->ct) return cleanup(kInvalidArg, "left operand is not a ciphertext");
+    switch (nd.op) {
+      case kOpMultiply: {
+        if (!R->ct) return cleanup(kInvalidArg, "right operand is not a ciphertext");
+        if (fused_into[id] >= 0) {  // executed when the Relinearize node is reached
+          continue;
+        }
+        v.size = L->size + R->size - 1;
+        u64* out = alloc_ct(v.size);
+        if (!out) return cleanup(kOutOfMemory, "out of device memory");
+        rc = ev.multiply(L->ct, L->size, R->ct, R->size, out, batch, s);
+        v.ct = out;
+        v.owned = true;
+        break;
+      }
+      case kOpRelinearize: {
+        const Node& mnode = nodes_[nd.left];
+        u64* out = alloc_ct(2);
+        if (!out) return cleanup(kOutOfMemory, "out of device memory");
+        v.size = 2;
+        if (fused_into[nd.left] == id) {
+          const Value& A = val[mnode.left];
+          const Value& B = val[mnode.right];
+          if (A.size != 2 || B.size != 2) {
+            // general sizes: unfused fallback
+            u64* tmp = alloc_ct(A.size + B.size - 1);
+            if (!tmp) return cleanup(kOutOfMemory, "out of device memory");
+            rc = ev.multiply(A.ct, A.size, B.ct, B.size, tmp, batch, s);
+            if (!rc) rc = A.size + B.size - 1 == 3 ? ev.relinearize(tmp, relin_key, out, batch, s) : (int)kInvalidArg;
+            pool.release(tmp, s);
+            live.erase(std::remove(live.begin(), live.end(), (void*)tmp), live.end());
+          } else {
+            rc = relin_key ? ev.multiply_relin(A.ct, B.ct, relin_key, out, batch, s) : (int)kNoKey;
+          }
+          v.ct = out;
+          v.owned = true;
+          if (rc) return cleanup(rc, "multiply+relinearize failed");
+          release(mnode.left);
+          release(mnode.right);
+          val[nd.left].uses = 0;
+          continue;
+        }
+        if (L->size == 2) {
+          if (hipMemcpyAsync(out, L->ct, batch * ctx->ct_words(2) * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = kHipError;
+        } else if (L->size == 3) {
+          rc = relin_key ? ev.relinearize(L->ct, relin_key, out, batch, s) : (int)kNoKey;
+        } else {
+          rc = kInvalidArg;
+        }
+        v.ct = out;
+        v.owned = true;
+        break;
+      }
+      case kOpAdd:
+      case kOpSub: {
+        if (!R->ct) return cleanup(kInvalidArg, "right operand is not a ciphertext");
+        if (L->size != R->size) return cleanup(kInvalidArg, "add/sub of different ciphertext sizes is not supported in batched programs");
+        v.size = L->size;
+        u64* out = alloc_ct(v.size);
+        if (!out) return cleanup(kOutOfMemory, "out of device memory");
+        rc = nd.op == kOpAdd ? ev.add(L->ct, R->ct, out, v.size, batch, s) : ev.sub(L->ct, R->ct, out, v.size, batch, s);
+        v.ct = out;
+        v.owned = true;
+        break;
+      }
+      case kOpNegate: {
+        v.size = L->size;
+        u64* out = alloc_ct(v.size);
+        if (!out) return cleanup(kOutOfMemory, "out of device memory");
+        rc = ev.negate(L->ct, out, v.size, batch, s);
+        v.ct = out;
+        v.owned = true;
+        break;
+      }
+      case kOpAddPlaintext:
+      case kOpSubPlaintext:
+      case kOpMultiplyPlaintext: {
+        if (!R->plain) return cleanup(kInvalidArg, "right operand is not a plaintext");
+        v.size = L->size;
+        u64* out = alloc_ct(v.size);
+        if (!out) return cleanup(kOutOfMemory, "out of device memory");
+        if (nd.op == kOpAddPlaintext)
+          rc = ev.add_plain(L->ct, L->size, R->plain, R->pstride, out, batch, s);
+        else if (nd.op == kOpSubPlaintext)
+          rc = ev.sub_plain(L->ct, L->size, R->plain, R->pstride, out, batch, s);
+        else
+          rc = ev.multiply_plain(L->ct, L->size, R->plain, R->pstride, out, batch, s);
+        v.ct = out;
+        v.owned = true;
+        break;
+      }
+      case kOpShiftLeft:
+      case kOpShiftRight: {
+        if (nodes_[nd.right].op != kOpLiteralU64) return cleanup(kInvalidArg, "shift amount must be a Literal::U64 (run.rs:177-183)");
+        if (L->size != 2) return cleanup(kInvalidArg, "rotation needs a size-2 ciphertext");
+        if (!ctx->batching()) return cleanup(kUnsupported, "encryption parameters do not support batching");
+        const int k = (int)nodes_[nd.right].arg;
+        v.size = 2;
+        u64* out = alloc_ct(2);
+        if (!out) return cleanup(kOutOfMemory, "out of device memory");
+        rc = rotate(L->ct, nd.op == kOpShiftLeft ? k : -k, out);
+        v.ct = out;
+        v.owned = true;
+        break;
+      }
+      case kOpSwapRows: {
+        if (L->size != 2) return cleanup(kInvalidArg, "rotation needs a size-2 ciphertext");
+        if (!ctx->batching()) return cleanup(kUnsupported, "encryption parameters do not support batching");
+        const u32 elt = 2 * (u32)n - 1;
+        const u64* key = galois_key(elt);
+        if (!key) return cleanup(kNoKey, "Galois key for the column rotation is missing");
+        v.size = 2;
+        u64* out = alloc_ct(2);
+        if (!out) return cleanup(kOutOfMemory, "out of device memory");
+        rc = ev.apply_galois(L->ct, elt, key, out, batch, s);
+        v.ct = out;
+        v.owned = true;
+        break;
+      }
+      default:
+        return cleanup(kInvalidArg, "unsupported operation");
+    }
+    if (rc) return cleanup(rc, "operation failed");
+    if (nd.left >= 0) release(nd.left);
+    if (nd.right >= 0 && nodes_[nd.right].op != kOpLiteralU64) release(nd.right);
+    if (v.uses == 0 && v.owned) {  // dead value (pruned graphs should not have any)
+      pool.release((void*)v.ct, s);
+      live.erase(std::remove(live.begin(), live.end(), (void*)v.ct), live.end());
+      v.owned = false;
+    }
+  }
+  for (void* p : live) pool.release(p, s);
+  return kOk;
+}
+
+}  // namespace hipbfv

@@ -1,0 +1,187 @@
+"""Batch executor for compiled FHE program graphs (host mirror of csrc/program.cpp).
+
+The reference executes a compiled `FheProgram` with `run_program_unchecked`
+(sunscreen_runtime/src/run.rs:100-357): one evaluator call per node for ONE set of inputs.
+`FheProgram.run` executes the same graph over a batch of independent input sets on the GPU.
+Graphs are built node by node (the reference's tests do the same, run.rs:595-881) or loaded from the
+serde JSON form of `FheProgram`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import Sequence
+
+import torch
+
+from . import _lib
+from .batch import BatchEvaluator, _ptr, _stream
+from .seal import GaloisKeys, RelinearizationKeys, _check
+
+OPS = [
+    "ShiftLeft", "ShiftRight", "SwapRows", "Relinearize", "Multiply", "MultiplyPlaintext", "Add", "AddPlaintext",
+    "Negate", "Sub", "SubPlaintext", "InputCiphertext", "InputPlaintext", "Literal", "OutputCiphertext",
+]
+EDGES = {"Left": 0, "Right": 1, "Unary": 2}
+
+
+class FheProgram:
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(_lib.load().hipbfv_Program_Create(C.byref(self._h)))
+        self.nodes: list[tuple[str, int]] = []
+        self.edges: list[tuple[int, int, str]] = []
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().hipbfv_Program_Destroy(self._h)
+            self._h = None
+
+    # -- construction (names follow sunscreen_fhe_program::FheProgramTrait, lib.rs:170-250)
+    def _node(self, op: str, arg: int = 0) -> int:
+        nid = C.c_uint32()
+        _check(_lib.load().hipbfv_Program_AddNode(self._h, OPS.index(op), arg, C.byref(nid)))
+        self.nodes.append((op, arg))
+        return nid.value
+
+    def _edge(self, src: int, dst: int, kind: str) -> None:
+        _check(_lib.load().hipbfv_Program_AddEdge(self._h, src, dst, EDGES[kind]))
+        self.edges.append((src, dst, kind))
+
+    def _binary(self, op: str, left: int, right: int) -> int:
+        n = self._node(op)
+        self._edge(left, n, "Left")
+        self._edge(right, n, "Right")
+        return n
+
+    def _unary(self, op: str, x: int) -> int:
+        n = self._node(op)
+        self._edge(x, n, "Unary")
+        return n
+
+    def append_input_ciphertext(self, index: int) -> int:
+        return self._node("InputCiphertext", index)
+
+    def append_input_plaintext(self, index: int) -> int:
+        return self._node("InputPlaintext", index)
+
+    def append_input_literal(self, value: int) -> int:
+        return self._node("Literal", value)
+
+    def append_add(self, a, b):
+        return self._binary("Add", a, b)
+
+    def append_sub(self, a, b):
+        return self._binary("Sub", a, b)
+
+    def append_multiply(self, a, b):
+        return self._binary("Multiply", a, b)
+
+    def append_add_plaintext(self, a, b):
+        return self._binary("AddPlaintext", a, b)
+
+    def append_sub_plaintext(self, a, b):
+        return self._binary("SubPlaintext", a, b)
+
+    def append_multiply_plaintext(self, a, b):
+        return self._binary("MultiplyPlaintext", a, b)
+
+    def append_rotate_left(self, a, literal):
+        return self._binary("ShiftLeft", a, literal)
+
+    def append_rotate_right(self, a, literal):
+        return self._binary("ShiftRight", a, literal)
+
+    def append_negate(self, a):
+        return self._unary("Negate", a)
+
+    def append_swap_rows(self, a):
+        return self._unary("SwapRows", a)
+
+    def append_relinearize(self, a):
+        return self._unary("Relinearize", a)
+
+    def append_output_ciphertext(self, a):
+        return self._unary("OutputCiphertext", a)
+
+    # -- serde JSON form of FheProgram
+    @classmethod
+    def from_json(cls, text: str) -> "FheProgram":
+        p = cls()
+        raw = text.encode()
+        _check(_lib.load().hipbfv_Program_LoadJson(p._h, raw, len(raw)))
+        g = json.loads(text)
+        g = g.get("graph", g)
+        for nd in g["nodes"]:
+            op = nd["operation"]
+            if isinstance(op, str):
+                p.nodes.append((op, 0))
+            else:
+                (name, payload), = op.items()
+                p.nodes.append((name, payload["U64"] if isinstance(payload, dict) else payload))
+        p.edges = [tuple(e) for e in g["edges"]]
+        return p
+
+    def to_json(self) -> str:
+        def enc(op, arg):
+            if op in ("InputCiphertext", "InputPlaintext"):
+                return {op: arg}
+            if op == "Literal":
+                return {"Literal": {"U64": arg}}
+            return op
+
+        return json.dumps(
+            {
+                "graph": {
+                    "nodes": [{"operation": enc(op, arg)} for op, arg in self.nodes],
+                    "node_holes": [],
+                    "edge_property": "directed",
+                    "edges": [list(e) for e in self.edges],
+                },
+                "data": "Bfv",
+            }
+        )
+
+    def num_outputs(self) -> int:
+        n = C.c_uint64()
+        _check(_lib.load().hipbfv_Program_NumOutputs(self._h, C.byref(n)))
+        return n.value
+
+    def run(
+        self,
+        ev: BatchEvaluator,
+        inputs: Sequence[torch.Tensor],
+        relin_keys: RelinearizationKeys | None = None,
+        galois_keys: GaloisKeys | None = None,
+    ) -> list[torch.Tensor]:
+        """inputs[i]: int64[batch,2,K,N] ciphertext batch, or int64[batch,N] / int64[N] plaintext(s)."""
+        batch = None
+        for t in inputs:
+            if t.dim() == 4:
+                batch = t.shape[0]
+        assert batch is not None, "need at least one ciphertext argument"
+        n_in = len(inputs)
+        kinds = (C.c_uint32 * n_in)()
+        ptrs = (C.c_void_p * n_in)()
+        strides = (C.c_uint64 * n_in)()
+        for i, t in enumerate(inputs):
+            if t.dim() == 4:
+                assert t.shape[0] == batch and t.shape[1] == 2
+                kinds[i], strides[i] = 0, 0
+            else:
+                kinds[i] = 1
+                strides[i] = 0 if t.dim() == 1 or t.shape[0] == 1 else ev.n
+            ptrs[i] = _ptr(t)
+        n_out = self.num_outputs()
+        dev = inputs[0].device
+        outs = [torch.empty((batch, 2, ev.K, ev.n), dtype=torch.int64, device=dev) for _ in range(n_out)]
+        optrs = (C.c_void_p * n_out)(*[_ptr(o) for o in outs])
+        _check(
+            _lib.load().hipbfv_Program_Run(
+                self._h, ev._h, batch, n_in, kinds, ptrs, strides,
+                relin_keys.get_handle() if relin_keys is not None else None,
+                galois_keys.get_handle() if galois_keys is not None else None,
+                n_out, optrs, _stream(),
+            )
+        )
+        return outs

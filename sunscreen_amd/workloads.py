@@ -1,0 +1,65 @@
+"""Program graphs of the reference's BFV examples used by BASELINE.json configs 4 and 5.
+
+Each builder returns an `FheProgram` with the node structure the Sunscreen compiler emits for the
+example (a Relinearize after every Multiply: sunscreen_backend/src/transforms/insert_relinearizations.rs:45-60).
+"""
+from __future__ import annotations
+
+from .program import FheProgram
+
+
+def _mul(p: FheProgram, a: int, b: int) -> int:
+    return p.append_relinearize(p.append_multiply(a, b))
+
+
+def chi_sq_optimized() -> FheProgram:
+    """examples/chi_sq/src/main.rs:59-88 `chi_sq_optimized_impl`: 3 inputs -> (alpha, b1, b2, b3);
+    6 mul+relin, 8 add, 1 sub."""
+    p = FheProgram()
+    n0, n1, n2 = (p.append_input_ciphertext(i) for i in range(3))
+    x = p.append_add(p.append_add(n0, n0), n1)
+    y = p.append_add(p.append_add(n2, n2), n1)
+    n02 = _mul(p, n0, n2)
+    n02 = p.append_add(n02, n02)
+    n02 = p.append_add(n02, n02)
+    n1sq = _mul(p, n1, n1)
+    alpha = p.append_sub(n02, n1sq)
+    alpha = _mul(p, alpha, alpha)
+    b1 = _mul(p, x, x)
+    b1 = p.append_add(b1, b1)
+    b2 = _mul(p, x, y)
+    b3 = _mul(p, y, y)
+    b3 = p.append_add(b3, b3)
+    for out in (alpha, b1, b2, b3):
+        p.append_output_ciphertext(out)
+    return p
+
+
+def dot_product(lanes: int) -> FheProgram:
+    """examples/dot_prod/src/main.rs:38-75: c = a*b; log2(lanes) rotate-and-add steps; + swap_rows."""
+    p = FheProgram()
+    a, b = p.append_input_ciphertext(0), p.append_input_ciphertext(1)
+    c = _mul(p, a, b)
+    shift = 1
+    while shift < lanes:
+        c = p.append_add(c, p.append_rotate_left(c, p.append_input_literal(shift)))
+        shift *= 2
+    c = p.append_add(c, p.append_swap_rows(c))
+    p.append_output_ciphertext(c)
+    return p
+
+
+def pir_row(columns: int) -> FheProgram:
+    """One row of examples/pir/src/main.rs:16-45: sum_j (col_query_j * db_j) where db_j are plaintext
+    arguments, then multiplied by the row query.  Inputs: 0 = row query (ct), 1..columns = column
+    queries (ct), columns+1..2*columns = database plaintexts."""
+    p = FheProgram()
+    row = p.append_input_ciphertext(0)
+    acc = None
+    for j in range(columns):
+        cq = p.append_input_ciphertext(1 + j)
+        db = p.append_input_plaintext(1 + columns + j)
+        term = p.append_multiply_plaintext(cq, db)
+        acc = term if acc is None else p.append_add(acc, term)
+    p.append_output_ciphertext(_mul(p, acc, row))
+    return p

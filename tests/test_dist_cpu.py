@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing used by bench.py --gpus N."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+from sunscreen_amd.dist import shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_the_batch():
+    for total in (0, 1, 7, 8, 1024, 4097):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_range(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            for (a, b), (c, d) in zip(blocks, blocks[1:]):
+                assert b == c
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_timing_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(
+        textwrap.dedent(
+            """
+            import sys, time
+            sys.path.insert(0, %r)
+            import torch, torch.distributed as dist
+            from sunscreen_amd import dist as D
+            rank, local_rank, world = D.init("gloo")
+            assert world == 2
+            total = 9
+            lo, hi = D.shard_range(total, rank, world)
+            # each rank "processes" its block: result item i = i * 10 + per-item payload
+            local = torch.stack([torch.full((2, 3), i * 10, dtype=torch.int64) for i in range(lo, hi)])
+            calls = []
+            def step():
+                calls.append(1)
+                time.sleep(0.01 * (rank + 1))   # rank 1 is slower: the reported time must be the max
+            elapsed = D.timed_steps(step, steps=3, warmup=1)
+            assert len(calls) == 4
+            assert elapsed >= 0.06 - 1e-3, elapsed
+            full = D.gather_results(local, total)
+            assert full.shape == (total, 2, 3)
+            assert [int(full[i, 0, 0]) for i in range(total)] == [i * 10 for i in range(total)]
+            dist.barrier()
+            dist.destroy_process_group()
+            print("rank", rank, "ok")
+            """
+        )
+        % ROOT
+    )
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [
+        subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        for r in range(2)
+    ]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o

@@ -1,0 +1,131 @@
+"""GPU batch executor (program graphs) vs the oracle interpreter, bit for bit, plus the semantic results
+of the reference's examples (examples/chi_sq, examples/dot_prod, examples/pir; run.rs:595-881)."""
+import numpy as np
+import pytest
+
+from oracle import bfv_oracle as O
+from tests.bfv_helpers import oracle_for, params
+from tests.oracle_program import run_program
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(name, galois=None, seed=3):
+    from sunscreen_amd import Context, GaloisKeys, RelinearizationKeys
+    from sunscreen_amd.batch import BatchEvaluator
+
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    O.seed(seed)
+    sk, pk, rk, gk = o.keygen(galois_elts=galois)
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    return o, sk, pk, rk, gk, ev, RelinearizationKeys.from_array(ctx, rk), (GaloisKeys.from_arrays(ctx, gk) if gk else None)
+
+
+def _signed(o, v):
+    v = v.astype(np.int64)
+    return np.where(v > o.t // 2, v - o.t, v)
+
+
+def test_chi_sq_graph_batched():
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.workloads import chi_sq_optimized
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_8192_17")
+    prog = chi_sq_optimized()
+    assert prog.num_outputs() == 4
+    batch = 3
+    rng = np.random.default_rng(1)
+    vals = rng.integers(0, 7, (3, batch, o.n)).astype(np.uint64)
+    vals[:, 0, :] = np.array([2, 7, 9], dtype=np.uint64)[:, None]  # the example's own inputs (main.rs:236-238)
+    cts = [np.stack([o.encrypt(pk, o.batch_encode(vals[a, i])) for i in range(batch)]) for a in range(3)]
+    outs = prog.run(ev, [to_device(c) for c in cts], rkd)
+    outs = [to_host(t) for t in outs]
+    for i in range(batch):
+        ref = run_program(o, prog.nodes, prog.edges, [c[i] for c in cts], rk)
+        n0, n1, n2 = (vals[a, i].astype(np.int64) for a in range(3))
+        x, y = 2 * n0 + n1, 2 * n2 + n1
+        expect = [(4 * n0 * n2 - n1 * n1) ** 2, 2 * x * x, x * y, 2 * y * y]
+        for k in range(4):
+            assert (outs[k][i] == ref[k]).all(), (i, k)
+            assert (_signed(o, o.batch_decode(o.decrypt(outs[k][i], sk))) == expect[k]).all()
+    d0 = [int(_signed(o, o.batch_decode(o.decrypt(outs[k][0], sk)))[0]) for k in range(4)]
+    assert d0 == [529, 242, 275, 1250]  # examples/chi_sq/src/main.rs expected values for (2, 7, 9)
+
+
+def test_dot_product_graph_rotations_and_json_roundtrip():
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.program import FheProgram
+    from sunscreen_amd.workloads import dot_product
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_4096_16", galois="all")
+    lanes = o.n // 2
+    prog = FheProgram.from_json(dot_product(lanes).to_json())  # through the serde JSON form
+    batch = 2
+    rng = np.random.default_rng(2)
+    va = rng.integers(0, 4, (batch, o.n)).astype(np.uint64)
+    vb = rng.integers(0, 4, (batch, o.n)).astype(np.uint64)
+    ca = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in va])
+    cb = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vb])
+    (out,) = prog.run(ev, [to_device(ca), to_device(cb)], rkd, gkd)
+    out = to_host(out)
+    for i in range(batch):
+        (ref,) = run_program(o, prog.nodes, prog.edges, [ca[i], cb[i]], rk, gk)
+        assert (out[i] == ref).all()
+        dot = int((va[i].astype(np.int64) * vb[i].astype(np.int64)).sum()) % o.t
+        assert (o.batch_decode(o.decrypt(out[i], sk)) == dot).all()
+
+
+def test_pir_row_graph_with_plaintext_arguments():
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.workloads import pir_row
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("simple_multiply")
+    cols = 4
+    prog = pir_row(cols)
+    batch = 2
+    rng = np.random.default_rng(4)
+
+    def enc_scalar(v):
+        p = np.zeros(o.n, dtype=np.uint64)
+        p[0] = v % o.t
+        return p
+
+    sel = 2
+    row_q = np.stack([o.encrypt(pk, enc_scalar(1)) for _ in range(batch)])
+    col_q = [np.stack([o.encrypt(pk, enc_scalar(1 if j == sel else 0)) for _ in range(batch)]) for j in range(cols)]
+    db_vals = rng.integers(1, 400, (cols, batch))
+    db = [np.stack([enc_scalar(int(db_vals[j, i])) for i in range(batch)]) for j in range(cols)]
+    inputs = [to_device(row_q)] + [to_device(c) for c in col_q] + [to_device(d) for d in db]
+    (out,) = prog.run(ev, inputs, rkd)
+    out = to_host(out)
+    for i in range(batch):
+        (ref,) = run_program(o, prog.nodes, prog.edges, [row_q[i]] + [c[i] for c in col_q] + [d[i] for d in db], rk)
+        assert (out[i] == ref).all()
+        assert int(o.decrypt(out[i], sk)[0]) == int(db_vals[sel, i])
+
+
+def test_program_errors():
+    from sunscreen_amd import HipBfvError
+    from sunscreen_amd.batch import to_device
+    from sunscreen_amd.program import FheProgram
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_4096_16")
+    p = FheProgram()
+    a = p.append_input_ciphertext(0)
+    p.append_output_ciphertext(p.append_rotate_left(a, p.append_input_literal(1)))
+    ct = to_device(np.stack([o.encrypt(pk, np.zeros(1, dtype=np.uint64))]))
+    with pytest.raises(HipBfvError):  # MissingGaloisKeys (run.rs:188-190)
+        p.run(ev, [ct], rkd, None)
+    with pytest.raises(HipBfvError):
+        FheProgram.from_json('{"graph": {"nodes": [{"operation": "Frobnicate"}], "edges": []}}')
+    cyc = FheProgram()
+    x = cyc.append_input_ciphertext(0)
+    n1 = cyc._node("Negate")
+    n2 = cyc._node("Negate")
+    cyc._edge(n2, n1, "Unary")
+    cyc._edge(n1, n2, "Unary")
+    cyc.append_output_ciphertext(n2)
+    with pytest.raises(HipBfvError):
+        cyc.run(ev, [ct], rkd)
