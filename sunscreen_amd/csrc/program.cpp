@@ -427,7 +427,8 @@ int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t
       default:
         break;
     }
-    if (!L || !L->ct) return cleanup(kInvalidArg, "left operand is not a ciphertext");
+    const bool fused_relin = nd.op == kOpRelinearize && fused_into[nd.left] == id;
+    if (!L || (!L->ct && !fused_relin)) return cleanup(kInvalidArg, "left operand is not a ciphertext");
     switch (nd.op) {
       case kOpMultiply: {
         if (!R->ct) return cleanup(kInvalidArg, "right operand is not a ciphertext");
