@@ -107,17 +107,17 @@ inline MulOpD make_mulop_d(u64 w, u64 q) {
 // |T| <= q*(0.5 + |Y|*2^-52); butterflies only add and subtract, so magnitudes grow per stage and
 // every value must stay below 2^53.  This simulates the worst-case growth (in units of q) through the
 // kernel's pass structure and decides at which pass starts all values must be reduced mod q.
-bool plan_f64_path(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
+bool plan_f64_path(u64 q, int logn, int ept, u32* fwd_mask, u32* inv_mask) {
   if (q >= (1ull << 50)) return false;
   const double limit = 0.98 * 9007199254740992.0 / (double)q;  // 2^53 / q with a margin
   const double eps = (double)q / 4503599627370496.0;           // q * 2^-52
-  const int np = ntt_num_passes(logn);
+  const int np = ntt_num_passes(logn, ept);
   // forward (Cooley-Tukey): X' = X + T, Y' = X - T
   {
     double M = 1.0;  // canonical input in [0,q)
     u32 mask = 0;
     for (int p = 0; p < np; p++) {
-      const int r = ntt_pass_radix(logn, p);
+      const int r = ntt_pass_radix(logn, p, ept);
       auto run = [&](double m, bool* ok) {
         *ok = true;
         for (int s = 0; s < r; s++) {
@@ -142,7 +142,7 @@ bool plan_f64_path(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
     double M = 1.0;
     u32 mask = 0;
     for (int p = 0; p < np; p++) {
-      const int r = ntt_pass_radix(logn, np - 1 - p);
+      const int r = ntt_pass_radix(logn, np - 1 - p, ept);
       auto run = [&](double m, bool* ok) {
         *ok = true;
         for (int s = 0; s < r; s++) {
@@ -338,7 +338,10 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     dm.qd = (double)p;
     dm.qinv = 1.0 / (double)p;
     dm.ninv_d = make_mulop_d(ninv, p);
-    dm.use_f64 = plan_f64_path(p, (int)h.logn, &dm.fwd_reduce_mask, &dm.inv_reduce_mask) ? 1u : 0u;
+    dm.use_f64 = plan_f64_path(p, (int)h.logn, 16, &dm.fwd_reduce_mask, &dm.inv_reduce_mask) &&
+                         plan_f64_path(p, (int)h.logn, 8, &dm.fwd_reduce_mask8, &dm.inv_reduce_mask8)
+                     ? 1u
+                     : 0u;
     if (const char* env = std::getenv("HIPBFV_NO_F64"))
       if (env[0] == '1') dm.use_f64 = 0;
     const u64 psi = minimal_primitive_root(two_n, p);

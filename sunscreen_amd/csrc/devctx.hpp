@@ -37,9 +37,11 @@ struct DevMod {
   // FP64 path (primes < 2^50 whose range simulation succeeds, see context.cpp): residues are held as
   // exact integers in doubles; *_reduce_mask bit p = "reduce every value mod q at the start of pass p".
   u32 use_f64;
-  u32 fwd_reduce_mask;
+  u32 fwd_reduce_mask;   // pass structure with 16 elements per thread (stand-alone transforms)
   u32 inv_reduce_mask;
-  u32 pad;
+  u32 fwd_reduce_mask8;  // pass structure with 8 elements per thread (fused kernels)
+  u32 inv_reduce_mask8;
+  u32 pad[3];
   double qd;     // (double) q
   double qinv;   // 1.0 / q
   MulOpD ninv_d; // n^{-1} mod q

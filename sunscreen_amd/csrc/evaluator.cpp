@@ -95,6 +95,7 @@ NttPlan make_plan(u32 div, const std::vector<u32>& mods) {
   NttPlan pl{};
   pl.div = div;
   pl.period = (u32)mods.size();
+  if (const char* env = std::getenv("HIPBFV_DBG")) pl.dbg = (u32)std::atoi(env);
   for (size_t i = 0; i < mods.size(); i++) pl.mod[i] = (unsigned char)mods[i];
   return pl;
 }
@@ -104,7 +105,8 @@ NttPlan make_plan(u32 div, const std::vector<u32>& mods) {
 
 const char* kernel_name(int id) {
   static const char* names[kKernCount] = {"ntt_fwd",   "ntt_inv",    "behz_extend", "tensor",  "behz_floor_sk", "ks_decompose",
-                                          "ks_mac",    "ks_moddown", "galois",      "eltwise", "plain"};
+                                          "ks_mac",    "ks_moddown", "galois",      "eltwise", "plain",         "ks_fused",
+                                          "mul_fused"};
   return id >= 0 && id < kKernCount ? names[id] : "?";
 }
 
@@ -182,6 +184,8 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   size_t c = ((size_t)1 << 30) / per_op;
   if (const char* env = std::getenv("HIPBFV_CHUNK_OPS")) c = (size_t)std::strtoull(env, nullptr, 10);
   chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 2048));
+  if (const char* env = std::getenv("HIPBFV_FUSED_KS")) fused_ks_ = env[0] == '1';
+  if (const char* env = std::getenv("HIPBFV_NO_FUSED_MUL")) fused_mul_ = env[0] != '1';
 }
 
 u32 Evaluator::galois_elt_from_step(int step) const {
@@ -205,7 +209,7 @@ int Evaluator::ntt(u64* data, size_t polys, u32 nprimes, bool inverse, hipStream
   const size_t step = (65535 / nprimes) * nprimes;
   for (size_t off = 0; off < polys; off += step) {
     const size_t cnt = std::min(step, polys - off);
-    HB_LAUNCH((inverse ? kKernNttInv : kKernNttFwd), cnt, launch_ntt(ctx_->dev(), h.logn, data + off * h.n, cnt, plan, inverse, 0, s));
+    HB_LAUNCH((inverse ? kKernNttInv : kKernNttFwd), cnt, launch_ntt(ctx_->dev(), (inverse ? h.tw_inv : h.tw_fwd), h.logn, data + off * h.n, cnt, plan, inverse, 0, s));
   }
   return kOk;
 }
@@ -228,9 +232,9 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     HB_LAUNCH(kKernBehzExtend, c * (sa + sb), launch_behz_extend(ctx_->dev(), n, K, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));
-    HB_LAUNCH(kKernNttFwd, c * (sa + sb) * R, launch_ntt(ctx_->dev(), h.logn, ext, c * (sa + sb) * R, plan, false, 0, s));
+    HB_LAUNCH(kKernNttFwd, c * (sa + sb) * R, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, ext, c * (sa + sb) * R, plan, false, 0, s));
     HB_LAUNCH(kKernTensor, c, launch_tensor(ctx_->dev(), n, R, ext, sa, sb, D, c, s));
-    HB_LAUNCH(kKernNttInv, c * sd * R, launch_ntt(ctx_->dev(), h.logn, D, c * sd * R, plan, true, 1, s));
+    HB_LAUNCH(kKernNttInv, c * sd * R, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, D, c * sd * R, plan, true, 1, s));
     HB_LAUNCH(kKernBehzFloorSk, c * sd, launch_behz_floor_sk(ctx_->dev(), n, K, D, out + off * sd * K * n, c * sd, s));
   }
   return kOk;
@@ -250,10 +254,18 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
   u64* ACC = scratch + count * (size_t)KK * K * n;
   std::vector<u32> mods;
   for (u32 i = 0; i < KK; i++) mods.push_back(i);
+  bool all_f64 = fused_ks_ && h.logn <= 13;  // N = 16384 needs <= 128 VGPRs at 1024 threads: unfused path
+  for (u32 i = 0; i < KK; i++) all_f64 = all_f64 && h.mod[i].use_f64;
+  if (all_f64) {
+    // fused decompose + NTT + key MAC + INTT: K*KK forward and 2*KK inverse transforms per op
+    HB_LAUNCH(kKernKsFused, count * KK * (K + 2), launch_ks_fused(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, KK, target, tstride, key, ACC, count, s));
+    HB_LAUNCH(kKernKsModdown, count, launch_ks_moddown(ctx_->dev(), n, ACC, base, bstride, base_mask, out2, count, s));
+    return kOk;
+  }
   HB_LAUNCH(kKernKsDecompose, count, launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));
-  HB_LAUNCH(kKernNttFwd, count * KK * K, launch_ntt(ctx_->dev(), h.logn, T, count * KK * K, make_plan(K, mods), false, 0, s));
+  HB_LAUNCH(kKernNttFwd, count * KK * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, T, count * KK * K, make_plan(K, mods), false, 0, s));
   HB_LAUNCH(kKernKsMac, count, launch_ks_mac(ctx_->dev(), n, KK, T, key, ACC, count, s));
-  HB_LAUNCH(kKernNttInv, count * 2 * KK, launch_ntt(ctx_->dev(), h.logn, ACC, count * 2 * KK, make_plan(1, mods), true, 0, s));
+  HB_LAUNCH(kKernNttInv, count * 2 * KK, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, ACC, count * 2 * KK, make_plan(1, mods), true, 0, s));
   HB_LAUNCH(kKernKsModdown, count, launch_ks_moddown(ctx_->dev(), n, ACC, base, bstride, base_mask, out2, count, s));
   return kOk;
 }
@@ -378,19 +390,19 @@ int Evaluator::multiply_plain(const u64* ct, u32 size, const u64* plain, size_t 
   const NttPlan plan = make_plan(1, mods);
   if (shared) {
     HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain, 0, pl, 1, s));
-    HB_LAUNCH(kKernNttFwd, K, launch_ntt(ctx_->dev(), h.logn, pl, K, plan, false, 0, s));
+    HB_LAUNCH(kKernNttFwd, K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, pl, K, plan, false, 0, s));
   }
   if (out != ct) HB_CHECK(hipMemcpyAsync(out, ct, count * cs * sizeof(u64), hipMemcpyDeviceToDevice, s));
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     if (!shared) {
       HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain + off * pstride, pstride, pl, c, s));
-      HB_LAUNCH(kKernNttFwd, c * K, launch_ntt(ctx_->dev(), h.logn, pl, c * K, plan, false, 0, s));
+      HB_LAUNCH(kKernNttFwd, c * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, pl, c * K, plan, false, 0, s));
     }
     u64* x = out + off * cs;
-    HB_LAUNCH(kKernNttFwd, c * size * K, launch_ntt(ctx_->dev(), h.logn, x, c * size * K, plan, false, 0, s));
+    HB_LAUNCH(kKernNttFwd, c * size * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, x, c * size * K, plan, false, 0, s));
     HB_CHECK(launch_dyadic_plain(ctx_->dev(), n, K, x, size, pl, shared ? 0 : (size_t)K * n, c, s));
-    HB_LAUNCH(kKernNttInv, c * size * K, launch_ntt(ctx_->dev(), h.logn, x, c * size * K, plan, true, 0, s));
+    HB_LAUNCH(kKernNttInv, c * size * K, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, x, c * size * K, plan, true, 0, s));
   }
   return kOk;
 }

@@ -59,6 +59,8 @@ enum KernelId : int {
   kKernGalois,
   kKernEltwise,
   kKernPlain,
+  kKernKsFused,
+  kKernMulFused,
   kKernCount
 };
 const char* kernel_name(int id);
@@ -130,6 +132,8 @@ class Evaluator {
   ScratchPool pool_;
   Profiler prof_;
   size_t chunk_ops_;
+  bool fused_ks_ = false;  // experimental fused key-switch kernel (HIPBFV_FUSED_KS=1): register-bound, not yet a win
+  bool fused_mul_ = true;
 };
 
 }  // namespace hipbfv

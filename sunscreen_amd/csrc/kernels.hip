@@ -24,21 +24,29 @@ namespace hipbfv {
 // =====================================================================================
 // NTT: one workgroup per residue polynomial, N/16 threads, 16 coefficients per thread.
 // The log2(N) radix-2 stages are grouped into ceil(logn/4) register passes; between passes
-// the polynomial is exchanged through LDS (padded by one word per 32 to spread the strided
-// accesses of the late passes over the banks).
+// the polynomial is exchanged through LDS (XOR-swizzled so that the strided accesses of every
+// pass are bank-conflict free).
 // =====================================================================================
 
-__device__ __forceinline__ u32 lds_pos(u32 e) { return e + (e >> 5); }
+// LDS placement of coefficient e: an XOR swizzle of the low five (bank) bits with bits 5..8, chosen so
+// that every access pattern of every pass (strides 1, 8, 16 words and the split 8+64 / 16+256 patterns of
+// the middle passes) maps the 32 lanes of a half-wave to 32 distinct 8-byte banks.  bank = e[0:5] ^
+// (e5 ? 00001) ^ (e6 ? 01010) ^ (e7 ? 10100) ^ (e8 ? 11000); it is a bijection on each 32-word block.
+__device__ __forceinline__ u32 lds_pos(u32 e) {
+  const u32 m = ((e >> 5) & 1u) ^ (((e >> 6) & 1u) * 0x0Au) ^ (((e >> 7) & 1u) * 0x14u) ^ (((e >> 8) & 1u) * 0x18u);
+  return e ^ m;
+}
 
-template <int LOGN>
+template <int LOGN, int EPT = kElemsPerThread>
 struct NttShape {
   static constexpr int N = 1 << LOGN;
-  static constexpr int T = N / kElemsPerThread;
-  static constexpr int NPASS = ntt_num_passes(LOGN);
-  static constexpr int LDS_WORDS = N + (N >> 5);
+  static constexpr int E = EPT;
+  static constexpr int T = N / EPT;
+  static constexpr int NPASS = ntt_num_passes(LOGN, EPT);
+  static constexpr int LDS_WORDS = N;
   // radix (number of stages) of pass p, and the number of stages before it
-  static constexpr int radix(int p) { return ntt_pass_radix(LOGN, p); }
-  static constexpr int before(int p) { return ntt_stages_before(LOGN, p); }
+  static constexpr int radix(int p) { return ntt_pass_radix(LOGN, p, EPT); }
+  static constexpr int before(int p) { return ntt_stages_before(LOGN, p, EPT); }
 };
 
 // element index handled by virtual thread vt in a pass that covers bit positions [LOW, LOW+R)
@@ -97,6 +105,13 @@ struct ArithD {
     return fma(-qf, q, xh) + xl;
   }
   __device__ __forceinline__ V reduce(V v) const { return fma(-rint(v * qinv), q, v); }
+  // a*b mod q for two variable operands (|a*b| < 2^105): |result| <= q*(0.5 + |a*b/q|*2^-52)
+  __device__ __forceinline__ V mul_var(V a, V b) const {
+    const double xh = a * b;
+    const double xl = fma(a, b, -xh);
+    const double qf = rint(xh * qinv);
+    return fma(-qf, q, xh) + xl;
+  }
   __device__ __forceinline__ void fwd(V& X, V& Y, const Tw& w) const {
     const double t = mul_const(Y, w), x = X;
     X = x + t;
@@ -116,16 +131,19 @@ struct ArithD {
 };
 
 // ---- forward (Cooley-Tukey, gap shrinking) ----
-template <class A, int LOGN, int S0, int R>
-__device__ __forceinline__ void fwd_pass_compute(const A& ar, typename A::V (&v)[kElemsPerThread], u32 tid,
+template <class A, int LOGN, int EPT, int S0, int R>
+__device__ __forceinline__ void fwd_pass_compute(const A& ar, typename A::V (&v)[EPT], u32 tid,
                                                  const typename A::Tw* __restrict__ tw) {
-  constexpr int T = NttShape<LOGN>::T;
-  constexpr int G = kElemsPerThread >> R;
+  constexpr int T = NttShape<LOGN, EPT>::T;
+  constexpr int G = EPT >> R;
   constexpr int LOW = LOGN - S0 - R;
 #pragma unroll
   for (int g = 0; g < G; g++) {
     const u32 vt = tid + g * T;
-    const u32 hi = vt >> LOW;
+    u32 hi = vt >> LOW;
+    // LOW >= 6: the 64 lanes of a wavefront share `hi`, so the twiddle index is wave-uniform and the
+    // loads go through the scalar cache (s_load) instead of 64 identical vector loads
+    if constexpr (LOW >= 6) hi = __builtin_amdgcn_readfirstlane(hi);
 #pragma unroll
     for (int j = 0; j < R; j++) {
       const int half = 1 << (R - 1 - j);
@@ -140,16 +158,17 @@ __device__ __forceinline__ void fwd_pass_compute(const A& ar, typename A::V (&v)
   }
 }
 
-template <class A, int LOGN, int PASS>
+template <class A, int LOGN, int EPT, int PASS, bool KEEP_REGS = false>
 struct FwdPasses {
-  // run passes PASS..NPASS-1 with data resident in LDS on entry to every pass but the first
-  static __device__ __forceinline__ void run(const A& ar, typename A::V (&v)[kElemsPerThread], typename A::V* smem, u32 tid,
+  // run passes PASS..NPASS-1 with data resident in LDS on entry to every pass but the first.
+  // KEEP_REGS: the last pass leaves its results in v (element ((tid + g*T) << R) | k) instead of LDS.
+  static __device__ __forceinline__ void run(const A& ar, typename A::V (&v)[EPT], typename A::V* smem, u32 tid,
                                              const typename A::Tw* tw, u32 reduce_mask) {
-    using Sh = NttShape<LOGN>;
+    using Sh = NttShape<LOGN, EPT>;
     constexpr int R = Sh::radix(PASS);
     constexpr int S0 = Sh::before(PASS);
     constexpr int LOW = LOGN - S0 - R;
-    constexpr int G = kElemsPerThread >> R;
+    constexpr int G = EPT >> R;
     if (PASS > 0) {
       __syncthreads();
 #pragma unroll
@@ -159,14 +178,16 @@ struct FwdPasses {
     }
     if ((reduce_mask >> PASS) & 1u) {
 #pragma unroll
-      for (int e = 0; e < kElemsPerThread; e++) v[e] = ar.reduce(v[e]);
+      for (int e = 0; e < EPT; e++) v[e] = ar.reduce(v[e]);
     }
-    fwd_pass_compute<A, LOGN, S0, R>(ar, v, tid, tw);
+    fwd_pass_compute<A, LOGN, EPT, S0, R>(ar, v, tid, tw);
+    if constexpr (!(KEEP_REGS && PASS + 1 == Sh::NPASS)) {
 #pragma unroll
-    for (int g = 0; g < G; g++)
+      for (int g = 0; g < G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << R); k++) smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[g * (1 << R) + k];
-    if constexpr (PASS + 1 < Sh::NPASS) FwdPasses<A, LOGN, PASS + 1>::run(ar, v, smem, tid, tw, reduce_mask);
+        for (int k = 0; k < (1 << R); k++) smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[g * (1 << R) + k];
+    }
+    if constexpr (PASS + 1 < Sh::NPASS) FwdPasses<A, LOGN, EPT, PASS + 1, KEEP_REGS>::run(ar, v, smem, tid, tw, reduce_mask);
   }
 };
 
@@ -175,6 +196,7 @@ template <class A, int LOGN>
 __device__ __forceinline__ void ntt_fwd_to_lds(const A& ar, const u64* __restrict__ src, typename A::V* smem, u32 tid,
                                                const typename A::Tw* tw, u32 reduce_mask) {
   using Sh = NttShape<LOGN>;
+  constexpr int EPT = kElemsPerThread;
   constexpr int R0 = Sh::radix(0);
   constexpr int LOW0 = LOGN - R0;
   constexpr int G0 = kElemsPerThread >> R0;
@@ -183,20 +205,21 @@ __device__ __forceinline__ void ntt_fwd_to_lds(const A& ar, const u64* __restric
   for (int g = 0; g < G0; g++)
 #pragma unroll
     for (int k = 0; k < (1 << R0); k++) v[g * (1 << R0) + k] = ar.from_u64(src[elem_index<LOW0, R0>(tid + g * Sh::T, k)]);
-  FwdPasses<A, LOGN, 0>::run(ar, v, smem, tid, tw, reduce_mask);
+  FwdPasses<A, LOGN, EPT, 0>::run(ar, v, smem, tid, tw, reduce_mask);
   __syncthreads();
 }
 
 // ---- inverse (Gentleman-Sande, gap growing) ----
-template <class A, int LOGN, int LOW, int R>
-__device__ __forceinline__ void inv_pass_compute(const A& ar, typename A::V (&v)[kElemsPerThread], u32 tid,
+template <class A, int LOGN, int EPT, int LOW, int R>
+__device__ __forceinline__ void inv_pass_compute(const A& ar, typename A::V (&v)[EPT], u32 tid,
                                                  const typename A::Tw* __restrict__ tw) {
-  constexpr int T = NttShape<LOGN>::T;
-  constexpr int G = kElemsPerThread >> R;
+  constexpr int T = NttShape<LOGN, EPT>::T;
+  constexpr int G = EPT >> R;
 #pragma unroll
   for (int g = 0; g < G; g++) {
     const u32 vt = tid + g * T;
-    const u32 hi = vt >> LOW;
+    u32 hi = vt >> LOW;
+    if constexpr (LOW >= 6) hi = __builtin_amdgcn_readfirstlane(hi);  // wave-uniform twiddles -> scalar loads
 #pragma unroll
     for (int j = 0; j < R; j++) {
       const int half = 1 << j;
@@ -212,32 +235,35 @@ __device__ __forceinline__ void inv_pass_compute(const A& ar, typename A::V (&v)
   }
 }
 
-template <class A, int LOGN, int PASS>
+template <class A, int LOGN, int EPT, int PASS, bool FROM_REGS = false>
 struct InvPasses {
-  // inverse pass PASS covers the same bit window as forward pass NPASS-1-PASS
-  static __device__ __forceinline__ void run(const A& ar, typename A::V (&v)[kElemsPerThread], typename A::V* smem, u32 tid,
+  // inverse pass PASS covers the same bit window as forward pass NPASS-1-PASS.
+  // FROM_REGS: pass 0 takes its input from v (the layout a KEEP_REGS forward transform leaves) instead of LDS.
+  static __device__ __forceinline__ void run(const A& ar, typename A::V (&v)[EPT], typename A::V* smem, u32 tid,
                                              const typename A::Tw* tw, u32 reduce_mask) {
-    using Sh = NttShape<LOGN>;
+    using Sh = NttShape<LOGN, EPT>;
     constexpr int FP = Sh::NPASS - 1 - PASS;
     constexpr int R = Sh::radix(FP);
     constexpr int LOW = LOGN - Sh::before(FP) - R;
-    constexpr int G = kElemsPerThread >> R;
+    constexpr int G = EPT >> R;
     __syncthreads();
+    if constexpr (!(FROM_REGS && PASS == 0)) {
 #pragma unroll
-    for (int g = 0; g < G; g++)
+      for (int g = 0; g < G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
+        for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
+    }
     if ((reduce_mask >> PASS) & 1u) {
 #pragma unroll
-      for (int e = 0; e < kElemsPerThread; e++) v[e] = ar.reduce(v[e]);
+      for (int e = 0; e < EPT; e++) v[e] = ar.reduce(v[e]);
     }
-    inv_pass_compute<A, LOGN, LOW, R>(ar, v, tid, tw);
+    inv_pass_compute<A, LOGN, EPT, LOW, R>(ar, v, tid, tw);
     if constexpr (PASS + 1 < Sh::NPASS) {
 #pragma unroll
       for (int g = 0; g < G; g++)
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[g * (1 << R) + k];
-      InvPasses<A, LOGN, PASS + 1>::run(ar, v, smem, tid, tw, reduce_mask);
+      InvPasses<A, LOGN, EPT, PASS + 1, FROM_REGS>::run(ar, v, smem, tid, tw, reduce_mask);
     }
   }
 };
@@ -247,21 +273,36 @@ struct InvPasses {
 template <class A, int LOGN>
 __device__ __forceinline__ void ntt_inv_from_lds(const A& ar, typename A::V (&v)[kElemsPerThread], typename A::V* smem, u32 tid,
                                                  const typename A::Tw* tw, u32 reduce_mask) {
-  InvPasses<A, LOGN, 0>::run(ar, v, smem, tid, tw, reduce_mask);
+  InvPasses<A, LOGN, kElemsPerThread, 0>::run(ar, v, smem, tid, tw, reduce_mask);
 }
 
 __device__ __forceinline__ u32 plan_mod(const NttPlan& plan, u32 poly) { return plan.mod[(poly / plan.div) % plan.period]; }
 
 template <class A, int LOGN>
-__device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid) {
+__device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid, u32 dbg) {
   using Sh = NttShape<LOGN>;
   const A ar(dm);
+  if (dbg == 1) {  // EXPERIMENT: memory only (load -> LDS -> store), no butterflies
+    for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) smem[lds_pos(e)] = ar.from_u64(x[e]);
+    __syncthreads();
+    for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) x[e] = ar.canonical(smem[lds_pos(e)]);
+    return;
+  }
+  if (dbg == 2) {  // EXPERIMENT: compute only (no global traffic except one word per thread)
+    typename A::V v[kElemsPerThread];
+#pragma unroll
+    for (int e = 0; e < kElemsPerThread; e++) v[e] = ar.from_u64((u64)(tid * 16 + e));
+    FwdPasses<A, LOGN, kElemsPerThread, 0>::run(ar, v, smem, tid, tw, dm.fwd_reduce_mask);
+    __syncthreads();
+    x[tid] = ar.canonical(smem[lds_pos(tid)]);
+    return;
+  }
   ntt_fwd_to_lds<A, LOGN>(ar, x, smem, tid, tw, dm.fwd_reduce_mask);
   for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) x[e] = ar.canonical(smem[lds_pos(e)]);
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx* __restrict__ ctx, u64* data, NttPlan plan) {
+__global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase, u64* data, NttPlan plan) {
   using Sh = NttShape<LOGN>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const u32 tid = threadIdx.x;
@@ -269,11 +310,11 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx
   const u32 m = plan_mod(plan, poly);
   const DevMod& dm = ctx->mod[m];
   u64* x = data + (size_t)poly * Sh::N;
-  const MulOp* tw = ctx->tw_fwd + (size_t)m * Sh::N;
+  const MulOp* tw = twbase + (size_t)m * Sh::N;  // kernel argument: known global address space, scalar loads possible
   if (dm.use_f64)
-    ntt_fwd_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem_raw), tid);
+    ntt_fwd_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem_raw), tid, plan.dbg);
   else
-    ntt_fwd_body<ArithI, LOGN>(dm, tw, x, reinterpret_cast<u64*>(smem_raw), tid);
+    ntt_fwd_body<ArithI, LOGN>(dm, tw, x, reinterpret_cast<u64*>(smem_raw), tid, plan.dbg);
 }
 
 template <class A, int LOGN>
@@ -295,7 +336,7 @@ __device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A:
 
 // scale_mode: 0 = n^{-1}; 1 = BEHZ epilogue (n^{-1} * t [* (q/q_i)^{-1}]), see DevCtx::intt_scale_*
 template <int LOGN>
-__global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx* __restrict__ ctx, u64* data, NttPlan plan, int scale_mode) {
+__global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase, u64* data, NttPlan plan, int scale_mode) {
   using Sh = NttShape<LOGN>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const u32 tid = threadIdx.x;
@@ -303,7 +344,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
   const u32 m = plan_mod(plan, poly);
   const DevMod& dm = ctx->mod[m];
   u64* x = data + (size_t)poly * Sh::N;
-  const MulOp* tw = ctx->tw_inv + (size_t)m * Sh::N;
+  const MulOp* tw = twbase + (size_t)m * Sh::N;
   if (dm.use_f64) {
     MulOpD sc = dm.ninv_d;
     if (scale_mode == 1) sc = ctx->intt_scale_q_d[m];  // f64 moduli are key-level primes
@@ -316,7 +357,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
 }
 
 template <int LOGN>
-static hipError_t launch_ntt_t(const DevCtx* ctx, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
+static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
   using Sh = NttShape<LOGN>;
   const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
   if (inverse) {
@@ -325,26 +366,26 @@ static hipError_t launch_ntt_t(const DevCtx* ctx, u64* data, size_t polys, const
       (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done = true;
     }
-    ntt_inv_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, data, plan, scale_mode);
+    ntt_inv_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan, scale_mode);
   } else {
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done = true;
     }
-    ntt_fwd_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, data, plan);
+    ntt_fwd_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_ntt(const DevCtx* ctx, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
+hipError_t launch_ntt(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
   if (polys == 0) return hipSuccess;
   switch (logn) {
-    case 10: return launch_ntt_t<10>(ctx, data, polys, plan, inverse, scale_mode, s);
-    case 11: return launch_ntt_t<11>(ctx, data, polys, plan, inverse, scale_mode, s);
-    case 12: return launch_ntt_t<12>(ctx, data, polys, plan, inverse, scale_mode, s);
-    case 13: return launch_ntt_t<13>(ctx, data, polys, plan, inverse, scale_mode, s);
-    case 14: return launch_ntt_t<14>(ctx, data, polys, plan, inverse, scale_mode, s);
+    case 10: return launch_ntt_t<10>(ctx, tw, data, polys, plan, inverse, scale_mode, s);
+    case 11: return launch_ntt_t<11>(ctx, tw, data, polys, plan, inverse, scale_mode, s);
+    case 12: return launch_ntt_t<12>(ctx, tw, data, polys, plan, inverse, scale_mode, s);
+    case 13: return launch_ntt_t<13>(ctx, tw, data, polys, plan, inverse, scale_mode, s);
+    case 14: return launch_ntt_t<14>(ctx, tw, data, polys, plan, inverse, scale_mode, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -659,6 +700,121 @@ __global__ __launch_bounds__(kCoefThreads) void nonzero_tail_kernel(const u64* _
   bool nz = false;
   for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < len; i += (size_t)gridDim.x * kCoefThreads) nz |= p[i] != 0;
   if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&flags[op], 1u);
+}
+
+// =====================================================================================
+// Fused key-switch inner product (FP64 path, all key-level primes < 2^50):
+// one workgroup per (op, key prime I) computes
+//     ACC[op][c][I] = INTT_I( sum_J NTT_I(target_J mod q_I) (.) key[J][c][I] ),  c = 0,1
+// keeping the K forward transforms, the two accumulators and the two inverse transforms on chip:
+// HBM sees K reads of the target (L2 hits for all but the first prime), the key rows (shared by the
+// whole batch, L2/MALL resident) and two polynomial writes, instead of the decompose -> NTT -> MAC ->
+// INTT round trips of the unfused path.  Replaces the inner loops of SEAL switch_key_inplace.
+// =====================================================================================
+template <int LOGN, int EPT>
+__global__ __launch_bounds__((NttShape<LOGN, EPT>::T)) void ks_fused_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+                                                                      const MulOp* __restrict__ twi_base, const u64* __restrict__ target,
+                                                                      size_t tstride, const u64* __restrict__ key, u64* __restrict__ ACC,
+                                                                      u32 ops) {
+  using Sh = NttShape<LOGN, EPT>;
+  using A = ArithD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* smem = reinterpret_cast<double*>(smem_raw);
+  const u32 tid = threadIdx.x;
+  const u32 K = ctx->K, KK = ctx->KK;
+  // blocks of one op share an XCD (block b runs on XCD b % 8): the K target polynomials are then served
+  // by that XCD's L2 for KK-1 of the KK workgroups that read them
+  const u32 b = blockIdx.x;
+  const u32 xcd = b & 7u, slot = b >> 3;
+  const u32 I = slot % KK;
+  const u32 op = (slot / KK) * 8u + xcd;
+  if (op >= ops) return;
+  const DevMod& dm = ctx->mod[I];
+  const A ar(dm);
+  const MulOpD* twf = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * Sh::N);
+  const MulOpD* twi = reinterpret_cast<const MulOpD*>(twi_base + (size_t)I * Sh::N);
+  constexpr int R0 = Sh::radix(0);
+  constexpr int LOW0 = LOGN - R0;
+  constexpr int G0 = EPT >> R0;
+  constexpr int RL = Sh::radix(Sh::NPASS - 1);
+  constexpr int GL = EPT >> RL;
+  double acc0[EPT], acc1[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; e++) acc0[e] = 0.0, acc1[e] = 0.0;
+  for (u32 J = 0; J < K; J++) {
+    const u64* src = target + (size_t)op * tstride + (size_t)J * Sh::N;
+    const bool need_reduce = ctx->mod[J].q > dm.q;
+    double v[EPT];
+#pragma unroll
+    for (int g = 0; g < G0; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R0); k++) {
+        double x = ar.from_u64(src[elem_index<LOW0, R0>(tid + g * Sh::T, k)]);
+        v[g * (1 << R0) + k] = need_reduce ? ar.reduce(x) : x;
+      }
+    if (J > 0) __syncthreads();  // the previous transform's last pass may still be reading LDS
+    FwdPasses<A, LOGN, EPT, 0, true>::run(ar, v, smem, tid, twf, EPT == 16 ? dm.fwd_reduce_mask : dm.fwd_reduce_mask8);
+    const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
+    const u64* k1 = key + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
+#pragma unroll
+    for (int g = 0; g < GL; g++) {
+      const u32 base = (tid + g * Sh::T) << RL;
+#pragma unroll
+      for (int k = 0; k < (1 << RL); k += 2) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
+        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
+        const int e = g * (1 << RL) + k;
+        acc0[e] += ar.mul_var(v[e], ar.from_u64(a.x));
+        acc0[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(a.y));
+        acc1[e] += ar.mul_var(v[e], ar.from_u64(c.x));
+        acc1[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(c.y));
+      }
+    }
+    if ((J & 3u) == 3u) {
+#pragma unroll
+      for (int e = 0; e < EPT; e++) acc0[e] = ar.reduce(acc0[e]), acc1[e] = ar.reduce(acc1[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; e++) acc0[e] = ar.reduce(acc0[e]), acc1[e] = ar.reduce(acc1[e]);
+  constexpr int GO = EPT >> R0;
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    double (&acc)[EPT] = c ? acc1 : acc0;
+    InvPasses<A, LOGN, EPT, 0, true>::run(ar, acc, smem, tid, twi, EPT == 16 ? dm.inv_reduce_mask : dm.inv_reduce_mask8);
+    u64* dst = ACC + (((size_t)op * 2 + c) * KK + I) * Sh::N;
+#pragma unroll
+    for (int g = 0; g < GO; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R0); k++) dst[elem_index<LOW0, R0>(tid + g * Sh::T, k)] = ar.scale_canonical(acc[g * (1 << R0) + k], dm.ninv_d);
+  }
+}
+
+template <int LOGN, int EPT>
+static hipError_t launch_ks_fused_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, const u64* target, size_t tstride, const u64* key, u64* ACC, size_t ops, u32 KK,
+                                    hipStream_t s) {
+  using Sh = NttShape<LOGN, EPT>;
+  const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)ks_fused_kernel<LOGN, EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const size_t ops8 = (ops + 7) / 8 * 8;
+  ks_fused_kernel<LOGN, EPT><<<dim3((unsigned)(ops8 * KK)), dim3(Sh::T), lds, s>>>(ctx, twf, twi, target, tstride, key, ACC, (u32)ops);
+  return hipGetLastError();
+}
+
+hipError_t launch_ks_fused(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 KK, const u64* target, size_t tstride, const u64* key, u64* ACC, size_t ops,
+                           hipStream_t s) {
+  switch (logn) {
+    case 10: return launch_ks_fused_t<10, 8>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
+    case 11: return launch_ks_fused_t<11, 8>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
+    case 12: return launch_ks_fused_t<12, 8>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
+    case 13: return launch_ks_fused_t<13, 8>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
+    case 14: return launch_ks_fused_t<14, 16>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 // =====================================================================================

@@ -11,15 +11,18 @@ namespace hipbfv {
 struct NttPlan {
   u32 div;
   u32 period;
+  u32 dbg;  // experiment knob (0 = normal)
   unsigned char mod[kMaxMod];
 };
 
-hipError_t launch_ntt(const DevCtx* ctx, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s);
+hipError_t launch_ntt(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s);
 hipError_t launch_behz_extend(const DevCtx* ctx, u32 n, u32 K, const u64* in0, u32 sa, const u64* in1, u32 sb, size_t ops, u64* out, hipStream_t s);
 hipError_t launch_tensor(const DevCtx* ctx, u32 n, u32 R, const u64* ext, u32 sa, u32 sb, u64* D, size_t ops, hipStream_t s);
 hipError_t launch_behz_floor_sk(const DevCtx* ctx, u32 n, u32 K, const u64* D, u64* out, size_t polys, hipStream_t s);
 hipError_t launch_ks_decompose(const DevCtx* ctx, u32 n, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
 hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s);
+hipError_t launch_ks_fused(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 KK, const u64* target, size_t tstride, const u64* key, u64* ACC, size_t ops,
+                           hipStream_t s);
 hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, u64* out, size_t ops, hipStream_t s);
 hipError_t launch_galois(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t polys, u32 ginv, hipStream_t s);
 hipError_t launch_eltwise(const DevCtx* ctx, u32 n, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode, hipStream_t s);
