@@ -186,6 +186,15 @@ def main():
         avg_ms = rec["ms"] / rec["launches"]
         bytes_per_launch = per_unit * rec["units"] / rec["launches"]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        # measured HBM bytes per launch from the committed PMC profile of this workload (FETCH_SIZE x2 + WRITE_SIZE,
+        # collected in separate rocprofv3 --pmc passes: tools/gpu_round_report.sh, tools/pmc_traffic.py)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+            if name in pmc and n == 8192:
+                traffic = int(pmc[name]["hbm_bytes_per_unit"] * rec["units"] / rec["launches"])
+        except Exception:
+            traffic = None
         roofline = {
             "kernel": name,
             "bound": "hbm",
@@ -193,7 +202,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "avg_launch_ms": round(avg_ms, 4),
             "launches": rec["launches"],
             "algorithmic_bytes_per_launch": int(bytes_per_launch),

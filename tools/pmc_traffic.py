@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 FETCH_SIZE / WRITE_SIZE summaries (tools/rocprof_summary.py --pmc output) plus the
+kernel-trace stats into profiles/pmc_traffic.json: measured HBM bytes per work unit for each kernel.
+
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B);
+WRITE_SIZE is used as reported (it matched the known byte count of the NTT kernels to 6 %).
+usage: tools/pmc_traffic.py <pmc_fetch.txt> <pmc_write.txt> <units.json> > profiles/pmc_traffic.json
+units.json maps kernel short name -> average work units per dispatch (from a bench line's profiler output).
+"""
+import json
+import re
+import sys
+
+
+def parse(path, counter):
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r"^(?:void )?hipbfv::([a-z_0-9]+)", line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.match(r"^\s+(\S+)\s+([0-9.]+)", line)
+        if m and cur and m.group(1) == counter:
+            out[cur.replace("_kernel", "")] = float(m.group(2))
+    return out
+
+
+def main():
+    fetch = parse(sys.argv[1], "FETCH_SIZE")
+    write = parse(sys.argv[2], "WRITE_SIZE")
+    units = json.load(open(sys.argv[3]))
+    res = {}
+    for k in fetch:
+        if k not in units or k not in write:
+            continue
+        rd = fetch[k] * 1024 * 2
+        wr = write[k] * 1024
+        res[k] = {
+            "fetch_bytes_per_dispatch": rd,
+            "write_bytes_per_dispatch": wr,
+            "units_per_dispatch": units[k],
+            "hbm_bytes_per_unit": (rd + wr) / units[k],
+        }
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 on gfx950", "kernels": res}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
