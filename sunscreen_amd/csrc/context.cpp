@@ -167,6 +167,71 @@ bool plan_f64_path(u64 q, int logn, int ept, u32* fwd_mask, u32* inv_mask) {
   return true;
 }
 
+// Same growth simulation for the split (head / middle / tail) structure of nttshape.hpp.
+bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
+  if (q >= (1ull << 50) || !split_supported(logn)) return false;
+  const double limit = 0.98 * 9007199254740992.0 / (double)q;
+  const double eps = (double)q / 4503599627370496.0;
+  {  // forward: head does kHeadLog stages from canonical input, then the middle passes
+    double M = 1.0;
+    for (int s = 0; s < kHeadLog; s++) {
+      M = M + 0.5 + M * eps;
+      if (M > limit) return false;
+    }
+    u32 mask = 0;
+    for (int p = 0; p < split_fwd_passes(logn); p++) {
+      const int r = split_fwd_radix(logn, p);
+      auto run = [&](double m, bool* ok) {
+        *ok = true;
+        for (int s = 0; s < r; s++) {
+          m = m + 0.5 + m * eps;
+          if (m > limit) *ok = false;
+        }
+        return m;
+      };
+      bool ok;
+      double m = run(M, &ok);
+      if (!ok) {
+        mask |= 1u << p;
+        m = run(0.5 + M * eps, &ok);
+        if (!ok) return false;
+      }
+      M = m;
+    }
+    // the middle kernels multiply these values by key / operand residues: |a*b| must stay below 2^105
+    if (M * (double)q * (double)q * M > 4.0e31) return false;
+    *fwd_mask = mask;
+  }
+  {  // inverse: middle passes from products / accumulators (|x| <= 2.5 q), then kTailLog stages in the tail
+    double M = 2.5;
+    u32 mask = 0;
+    auto run = [&](double m, int r, bool* ok) {
+      *ok = true;
+      for (int s = 0; s < r; s++) {
+        const double d = 2.0 * m;
+        if (d > limit) *ok = false;
+        const double t = 0.5 + d * eps;
+        m = d > t ? d : t;
+      }
+      return m;
+    };
+    for (int p = 0; p <= split_inv_passes(logn); p++) {
+      const bool tail = p == split_inv_passes(logn);
+      const int r = tail ? kTailLog : split_inv_radix(logn, p);
+      bool ok;
+      double m = run(M, r, &ok);
+      if (!ok) {
+        mask |= tail ? (1u << 8) : (1u << p);
+        m = run(0.5 + M * eps, r, &ok);
+        if (!ok) return false;
+      }
+      M = m;
+    }
+    *inv_mask = mask;
+  }
+  return true;
+}
+
 }  // namespace
 
 bool is_prime_u64(u64 v) {
@@ -342,8 +407,9 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
                          plan_f64_path(p, (int)h.logn, 8, &dm.fwd_reduce_mask8, &dm.inv_reduce_mask8)
                      ? 1u
                      : 0u;
+    dm.split_ok = dm.use_f64 && plan_f64_split(p, (int)h.logn, &dm.split_fwd_mask, &dm.split_inv_mask) ? 1u : 0u;
     if (const char* env = std::getenv("HIPBFV_NO_F64"))
-      if (env[0] == '1') dm.use_f64 = 0;
+      if (env[0] == '1') dm.use_f64 = 0, dm.split_ok = 0;
     const u64 psi = minimal_primitive_root(two_n, p);
     if (!psi) return fail("no primitive root");
     u64 ipsi;

@@ -41,7 +41,11 @@ struct DevMod {
   u32 inv_reduce_mask;
   u32 fwd_reduce_mask8;  // pass structure with 8 elements per thread (fused kernels)
   u32 inv_reduce_mask8;
-  u32 pad[3];
+  // split transforms (nttshape.hpp): bit p = reduce at the start of middle pass p; bit 8 = reduce at the start of the tail
+  u32 split_fwd_mask;
+  u32 split_inv_mask;
+  u32 split_ok;          // the FP64 range plan of the split structure succeeded
+
   double qd;     // (double) q
   double qinv;   // 1.0 / q
   MulOpD ninv_d; // n^{-1} mod q

@@ -106,7 +106,8 @@ NttPlan make_plan(u32 div, const std::vector<u32>& mods) {
 const char* kernel_name(int id) {
   static const char* names[kKernCount] = {"ntt_fwd",   "ntt_inv",    "behz_extend", "tensor",  "behz_floor_sk", "ks_decompose",
                                           "ks_mac",    "ks_moddown", "galois",      "eltwise", "plain",         "ks_fused",
-                                          "mul_fused"};
+                                          "mul_fused", "ks_head",    "ks_mid",      "ks_tail", "mul_head",      "mul_mid",
+                                          "mul_tail"};
   return id >= 0 && id < kKernCount ? names[id] : "?";
 }
 
@@ -176,16 +177,18 @@ void Profiler::reset() {
 // ------------------------------------------------------------------ Evaluator
 
 Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
-  // Chunk so that the per-chunk scratch stays around 1 GiB (kernel-to-kernel intermediates are
-  // re-read immediately, so smaller chunks keep more of them in the 256 MiB Infinity Cache).
   const DevCtx& h = ctx_->host();
   const size_t R = h.K + h.S;
   const size_t per_op = (size_t)(4 * R + 3 * R + 3 * h.K + (size_t)h.KK * h.K + 2 * h.KK) * h.n * sizeof(u64);
-  size_t c = ((size_t)1 << 30) / per_op;
+  // up to 8 GiB of scratch per chunk (of 288 GB): launches of >= 1024 ops amortise the tail of each kernel
+  size_t c = ((size_t)8 << 30) / per_op;
   if (const char* env = std::getenv("HIPBFV_CHUNK_OPS")) c = (size_t)std::strtoull(env, nullptr, 10);
-  chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 2048));
+  chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 1024));
   if (const char* env = std::getenv("HIPBFV_FUSED_KS")) fused_ks_ = env[0] == '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_MUL")) fused_mul_ = env[0] != '1';
+  if (const char* env = std::getenv("HIPBFV_STREAMS")) nstreams_ = (size_t)std::max(1, std::atoi(env));
+  if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS")) split_ks_ = env[0] != '1';
+  if (const char* env = std::getenv("HIPBFV_NO_SPLIT_MUL")) split_mul_ = env[0] != '1';
 }
 
 u32 Evaluator::galois_elt_from_step(int step) const {
@@ -229,8 +232,16 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   for (u32 i = 0; i < K; i++) mods.push_back(i);
   for (u32 j = 0; j < S; j++) mods.push_back(h.KK + j);
   const NttPlan plan = make_plan(1, mods);
+  const bool split = split_mul_ && sa == 2 && sb == 2 && K <= 4 && h.logn >= 12 && h.logn <= 14;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
+    if (split) {
+      // head / middle / tail split transforms (kernels_split.hip): 3 launches instead of 5, 40 % less HBM traffic
+      HB_LAUNCH(kKernMulHead, c * 4, launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, a + off * 2 * K * n, b + off * 2 * K * n, ext, c, s));
+      HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, R, ext, D, c, s));
+      HB_LAUNCH(kKernMulTail, c * 3, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, D, out + off * 3 * K * n, c, s));
+      continue;
+    }
     HB_LAUNCH(kKernBehzExtend, c * (sa + sb), launch_behz_extend(ctx_->dev(), n, K, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));
     HB_LAUNCH(kKernNttFwd, c * (sa + sb) * R, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, ext, c * (sa + sb) * R, plan, false, 0, s));
     HB_LAUNCH(kKernTensor, c, launch_tensor(ctx_->dev(), n, R, ext, sa, sb, D, c, s));
@@ -254,6 +265,15 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
   u64* ACC = scratch + count * (size_t)KK * K * n;
   std::vector<u32> mods;
   for (u32 i = 0; i < KK; i++) mods.push_back(i);
+  bool split_ok = split_ks_ && h.logn >= 12 && h.logn <= 14;
+  for (u32 i = 0; i < KK; i++) split_ok = split_ok && h.mod[i].split_ok;
+  if (split_ok) {
+    // head / middle / tail split transforms (kernels_split.hip): 3 launches, no whole-polynomial NTT round trips
+    HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, K, target, tstride, T, count, s));
+    HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, KK, T, key, ACC, count, s));
+    HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, ACC, base, bstride, base_mask, out2, count, s));
+    return kOk;
+  }
   bool all_f64 = fused_ks_ && h.logn <= 13;  // N = 16384 needs <= 128 VGPRs at 1024 threads: unfused path
   for (u32 i = 0; i < KK; i++) all_f64 = all_f64 && h.mod[i].use_f64;
   if (all_f64) {
@@ -291,16 +311,58 @@ int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t coun
 int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (h.KK < 2 || !rk) return kNoKey;
-  const size_t cs = (size_t)3 * h.K * h.n;
+  const size_t cs = (size_t)3 * h.K * h.n, c2 = (size_t)2 * h.K * h.n;
   const size_t chunk = chunk_ops_;
-  ScratchGuard sg(pool_, chunk * cs * sizeof(u64), s);
-  if (!sg.p) return kOutOfMemory;
-  for (size_t off = 0; off < count; off += chunk) {
+  // Independent chunks are issued round-robin on a few internal streams: the HBM-bound head / tail kernels of
+  // one chunk then overlap the VALU-bound middle kernels of another instead of alternating with them.
+  const size_t nchunks = (count + chunk - 1) / chunk;
+  const size_t ns = std::min<size_t>(nstreams_, nchunks);
+  if (ns <= 1) {
+    ScratchGuard sg(pool_, std::min(chunk, count) * cs * sizeof(u64), s);
+    if (!sg.p) return kOutOfMemory;
+    for (size_t off = 0; off < count; off += chunk) {
+      const size_t c = std::min(chunk, count - off);
+      int rc = multiply(a + off * c2, 2, b + off * c2, 2, (u64*)sg.p, c, s);
+      if (rc) return rc;
+      rc = relinearize((const u64*)sg.p, rk, out2 + off * c2, c, s);
+      if (rc) return rc;
+    }
+    return kOk;
+  }
+  if (int rc = ensure_streams(ns)) return rc;
+  HB_CHECK(hipEventRecord(fork_ev_, s));
+  std::vector<void*> tmp(ns, nullptr);
+  int rc = kOk;
+  for (size_t i = 0; i < ns && rc == kOk; i++) {
+    HB_CHECK(hipStreamWaitEvent(aux_[i], fork_ev_, 0));
+    tmp[i] = pool_.acquire(chunk * cs * sizeof(u64), aux_[i]);
+    if (!tmp[i]) rc = kOutOfMemory;
+  }
+  size_t idx = 0;
+  for (size_t off = 0; off < count && rc == kOk; off += chunk, idx++) {
     const size_t c = std::min(chunk, count - off);
-    int rc = multiply(a + off * 2 * h.K * h.n, 2, b + off * 2 * h.K * h.n, 2, (u64*)sg.p, c, s);
-    if (rc) return rc;
-    rc = relinearize((const u64*)sg.p, rk, out2 + off * 2 * h.K * h.n, c, s);
-    if (rc) return rc;
+    hipStream_t st = aux_[idx % ns];
+    rc = multiply(a + off * c2, 2, b + off * c2, 2, (u64*)tmp[idx % ns], c, st);
+    if (rc == kOk) rc = relinearize((const u64*)tmp[idx % ns], rk, out2 + off * c2, c, st);
+  }
+  for (size_t i = 0; i < ns; i++) {
+    if (tmp[i]) pool_.release(tmp[i], aux_[i]);
+    (void)hipEventRecord(join_ev_[i], aux_[i]);
+    (void)hipStreamWaitEvent(s, join_ev_[i], 0);
+  }
+  return rc;
+}
+
+int Evaluator::ensure_streams(size_t n) {
+  std::lock_guard<std::mutex> g(stream_mu_);
+  if (!fork_ev_ && hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming) != hipSuccess) return kHipError;
+  while (aux_.size() < n) {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return kHipError;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return kHipError;
+    aux_.push_back(st);
+    join_ev_.push_back(ev);
   }
   return kOk;
 }

@@ -61,6 +61,12 @@ enum KernelId : int {
   kKernPlain,
   kKernKsFused,
   kKernMulFused,
+  kKernKsHead,
+  kKernKsMid,
+  kKernKsTail,
+  kKernMulHead,
+  kKernMulMid,
+  kKernMulTail,
   kKernCount
 };
 const char* kernel_name(int id);
@@ -128,12 +134,20 @@ class Evaluator {
   int key_switch(const u64* target, size_t tstride, const u64* key, const u64* base, size_t bstride, u32 base_mask, u64* out2,
                  size_t count, u64* scratch, hipStream_t s);
   size_t ks_scratch_words() const;
+  int ensure_streams(size_t n);
+  std::mutex stream_mu_;
+  std::vector<hipStream_t> aux_;
+  std::vector<hipEvent_t> join_ev_;
+  hipEvent_t fork_ev_ = nullptr;
+  size_t nstreams_ = 1;  // >1: chunks round-robin on internal streams (measured: no gain on MI355X, kept for experiments)
   Context* ctx_;
   ScratchPool pool_;
   Profiler prof_;
   size_t chunk_ops_;
   bool fused_ks_ = false;  // experimental fused key-switch kernel (HIPBFV_FUSED_KS=1): register-bound, not yet a win
   bool fused_mul_ = true;
+  bool split_ks_ = true;   // head / middle / tail split transforms for key switching (kernels_split.hip)
+  bool split_mul_ = true;  // ... and for the BEHZ multiply
 };
 
 }  // namespace hipbfv

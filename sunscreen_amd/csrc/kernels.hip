@@ -17,6 +17,8 @@
 
 #include "devarith.hpp"
 #include "kernels.hpp"
+#include "behzcore.hpp"
+#include "nttcore.hpp"
 #include "nttshape.hpp"
 
 namespace hipbfv {
@@ -27,108 +29,6 @@ namespace hipbfv {
 // the polynomial is exchanged through LDS (XOR-swizzled so that the strided accesses of every
 // pass are bank-conflict free).
 // =====================================================================================
-
-// LDS placement of coefficient e: an XOR swizzle of the low five (bank) bits with bits 5..8, chosen so
-// that every access pattern of every pass (strides 1, 8, 16 words and the split 8+64 / 16+256 patterns of
-// the middle passes) maps the 32 lanes of a half-wave to 32 distinct 8-byte banks.  bank = e[0:5] ^
-// (e5 ? 00001) ^ (e6 ? 01010) ^ (e7 ? 10100) ^ (e8 ? 11000); it is a bijection on each 32-word block.
-__device__ __forceinline__ u32 lds_pos(u32 e) {
-  const u32 m = ((e >> 5) & 1u) ^ (((e >> 6) & 1u) * 0x0Au) ^ (((e >> 7) & 1u) * 0x14u) ^ (((e >> 8) & 1u) * 0x18u);
-  return e ^ m;
-}
-
-template <int LOGN, int EPT = kElemsPerThread>
-struct NttShape {
-  static constexpr int N = 1 << LOGN;
-  static constexpr int E = EPT;
-  static constexpr int T = N / EPT;
-  static constexpr int NPASS = ntt_num_passes(LOGN, EPT);
-  static constexpr int LDS_WORDS = N;
-  // radix (number of stages) of pass p, and the number of stages before it
-  static constexpr int radix(int p) { return ntt_pass_radix(LOGN, p, EPT); }
-  static constexpr int before(int p) { return ntt_stages_before(LOGN, p, EPT); }
-};
-
-// element index handled by virtual thread vt in a pass that covers bit positions [LOW, LOW+R)
-template <int LOW, int R>
-__device__ __forceinline__ u32 elem_index(u32 vt, u32 k) {
-  const u32 lo = vt & ((1u << LOW) - 1u);
-  const u32 hi = vt >> LOW;
-  return (hi << (LOW + R)) | (k << LOW) | lo;
-}
-
-// ---- arithmetic policies -------------------------------------------------------------
-// ArithI: 64-bit integers, Harvey lazy butterflies with Shoup twiddles (any prime < 2^62).
-struct ArithI {
-  using V = u64;
-  using Tw = MulOp;
-  u64 q, q2;
-  __device__ __forceinline__ explicit ArithI(const DevMod& m) : q(m.q), q2(m.q << 1) {}
-  __device__ __forceinline__ V from_u64(u64 x) const { return x; }
-  __device__ __forceinline__ V reduce(V v) const { return v; }  // lazy invariants hold without it
-  // forward: X,Y in [0,4q) -> [0,4q)
-  __device__ __forceinline__ void fwd(V& X, V& Y, const Tw& w) const {
-    const u64 x = X >= q2 ? X - q2 : X;
-    const u64 t = mul_shoup_lazy(Y, w.w, w.wq, q);
-    X = x + t;
-    Y = x + q2 - t;
-  }
-  // inverse: X,Y in [0,2q) -> [0,2q)
-  __device__ __forceinline__ void inv(V& X, V& Y, const Tw& w) const {
-    const u64 u = X, y = Y, s = u + y;
-    X = s >= q2 ? s - q2 : s;
-    Y = mul_shoup_lazy(u + q2 - y, w.w, w.wq, q);
-  }
-  __device__ __forceinline__ u64 canonical(V v) const {  // v in [0,4q)
-    v = v >= q2 ? v - q2 : v;
-    return v >= q ? v - q : v;
-  }
-  __device__ __forceinline__ u64 scale_canonical(V v, const Tw& sc) const { return mul_shoup(v, sc.w, sc.wq, q); }
-};
-
-// ArithD: residues as exact integers in doubles (primes < 2^50).  T = Y*W - rint(Y*(W/q))*q is exact:
-// the product is split error-free with an fma, the quotient estimate is off by at most
-// 0.5 + |Y|*2^-52, and every intermediate is an integer below 2^53 (range plan: context.cpp).
-struct ArithD {
-  using V = double;
-  using Tw = MulOpD;
-  double q, qinv;
-  __device__ __forceinline__ explicit ArithD(const DevMod& m) : q(m.qd), qinv(m.qinv) {}
-  __device__ __forceinline__ V from_u64(u64 x) const {
-    // exact for x < 2^52: plant the integer in the mantissa of 2^52 and subtract 2^52
-    return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0;
-  }
-  __device__ __forceinline__ V mul_const(V y, const Tw& w) const {
-    const double qf = rint(y * w.wq);
-    const double xh = y * w.w;
-    const double xl = fma(y, w.w, -xh);
-    return fma(-qf, q, xh) + xl;
-  }
-  __device__ __forceinline__ V reduce(V v) const { return fma(-rint(v * qinv), q, v); }
-  // a*b mod q for two variable operands (|a*b| < 2^105): |result| <= q*(0.5 + |a*b/q|*2^-52)
-  __device__ __forceinline__ V mul_var(V a, V b) const {
-    const double xh = a * b;
-    const double xl = fma(a, b, -xh);
-    const double qf = rint(xh * qinv);
-    return fma(-qf, q, xh) + xl;
-  }
-  __device__ __forceinline__ void fwd(V& X, V& Y, const Tw& w) const {
-    const double t = mul_const(Y, w), x = X;
-    X = x + t;
-    Y = x - t;
-  }
-  __device__ __forceinline__ void inv(V& X, V& Y, const Tw& w) const {
-    const double u = X, y = Y;
-    X = u + y;
-    Y = mul_const(u - y, w);
-  }
-  __device__ __forceinline__ u64 to_u64(V v) const {  // v an integer in (-q, q)
-    v = v < 0.0 ? v + q : v;
-    return (u64)__double_as_longlong(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
-  }
-  __device__ __forceinline__ u64 canonical(V v) const { return to_u64(reduce(v)); }
-  __device__ __forceinline__ u64 scale_canonical(V v, const Tw& sc) const { return to_u64(reduce(mul_const(v, sc))); }
-};
 
 // ---- forward (Cooley-Tukey, gap shrinking) ----
 template <class A, int LOGN, int EPT, int S0, int R>
@@ -404,37 +304,25 @@ constexpr int kCoefThreads = 256;
 template <int KMAX>
 __global__ __launch_bounds__(kCoefThreads) void behz_extend_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in0, u32 sa,
                                                                    const u64* __restrict__ in1, u32 sb, u64* __restrict__ out) {
-  const u32 n = ctx->n, K = ctx->K, S = ctx->S, KK = ctx->KK;
+  const u32 n = ctx->n, K = ctx->K, S = ctx->S;
   const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
   const u32 poly = blockIdx.y;  // global poly index: op * (sa+sb) + p
   const u32 op = poly / (sa + sb), p = poly % (sa + sb);
   const u64* src = p < sa ? in0 + ((size_t)op * sa + p) * K * n : in1 + ((size_t)op * sb + (p - sa)) * K * n;
   u64* dst = out + (size_t)poly * (K + S) * n;
   if (k >= n) return;
-  u64 y[KMAX];
-  u32 rm = 0;
+  u64 x[KMAX], e[KMAX + 2];
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
     if ((u32)i < K) {
-      const u64 x = src[(size_t)i * n + k];
-      dst[(size_t)i * n + k] = x;
-      y[i] = mul_shoup(x, ctx->ext_scale[i], ctx->mod[i].q);
-      rm += (u32)y[i] * ctx->q_to_mtilde[i];
+      x[i] = src[(size_t)i * n + k];
+      dst[(size_t)i * n + k] = x[i];
     }
   }
-  rm *= ctx->neg_inv_q_mod_mtilde;  // r_mtilde = -x/q mod 2^32
-  for (u32 j = 0; j < S; j++) {
-    const DevMod& pm = ctx->mod[KK + j];
-    u128 acc = 0;
+  behz_extend_coeff<KMAX>(ctx, x, e);
 #pragma unroll
-    for (int i = 0; i < KMAX; i++)
-      if ((u32)i < K) acc += (u128)y[i] * ctx->q_to_bsk[j][i];
-    u64 rc = rm;
-    if (rm >= 0x80000000u) rc += pm.q - 0x100000000ull;  // centred representative
-    acc += (u128)rc * ctx->q_mod_bsk[j];
-    const u64 v = reduce128(acc, pm);
-    dst[(size_t)(K + j) * n + k] = mul_shoup(v, ctx->inv_mtilde_mod_bsk[j], pm.q);
-  }
+  for (int j = 0; j < KMAX + 2; j++)
+    if ((u32)j < S) dst[(size_t)(K + j) * n + k] = e[j];
 }
 
 // ---- BEHZ step 4: dyadic tensor product per residue: d_p = sum_{i+j=p} a_i * b_j ----
@@ -470,58 +358,23 @@ __global__ __launch_bounds__(kCoefThreads) void tensor_kernel(const DevCtx* __re
 // D: u64[npoly][K+S][N] after the scaled inverse NTT; out: u64[npoly][K][N]
 template <int KMAX>
 __global__ __launch_bounds__(kCoefThreads) void behz_floor_sk_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ D, u64* __restrict__ out) {
-  const u32 n = ctx->n, K = ctx->K, S = ctx->S, KK = ctx->KK, nB = ctx->nB;
+  const u32 n = ctx->n, K = ctx->K, S = ctx->S;
   const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
   const u32 poly = blockIdx.y;
   if (k >= n) return;
   const u64* d = D + (size_t)poly * (K + S) * n;
-  u64 y[KMAX];
+  u64 y[KMAX], xb[KMAX + 2], r[KMAX];
 #pragma unroll
   for (int i = 0; i < KMAX; i++)
     if ((u32)i < K) y[i] = d[(size_t)i * n + k];  // already x * t * (q/q_i)^{-1} mod q_i
-  u64 yb[KMAX + 1];
-  u64 fl_msk = 0;
 #pragma unroll
-  for (int j = 0; j < KMAX + 2; j++) {
-    if ((u32)j < S) {
-      const DevMod& pm = ctx->mod[KK + j];
-      u128 acc = 0;
-#pragma unroll
-      for (int i = 0; i < KMAX; i++)
-        if ((u32)i < K) acc += (u128)y[i] * ctx->q_to_bsk[j][i];
-      const u64 conv = reduce128(acc, pm);
-      const u64 fl = mul_shoup(d[(size_t)(K + j) * n + k] + pm.q - conv, ctx->inv_q_mod_bsk[j], pm.q);
-      if ((u32)j < nB) {
-        if (j < KMAX + 1) yb[j < KMAX + 1 ? j : 0] = mul_shoup(fl, ctx->inv_punct_B[j], pm.q);
-      } else {
-        fl_msk = fl;
-      }
-    }
-  }
-  // alpha_sk
-  const DevMod& msk = ctx->mod[KK + nB];
-  u128 acc = 0;
-#pragma unroll
-  for (int j = 0; j < KMAX + 1; j++)
-    if ((u32)j < nB) acc += (u128)yb[j] * ctx->B_to_msk[j];
-  const u64 alpha = mul_shoup(reduce128(acc, msk) + msk.q - fl_msk, ctx->inv_B_mod_msk, msk.q);
-  const bool neg = alpha > (msk.q >> 1);
+  for (int j = 0; j < KMAX + 2; j++)
+    if ((u32)j < S) xb[j] = d[(size_t)(K + j) * n + k];
+  behz_floor_sk_coeff<KMAX>(ctx, y, xb, r);
   u64* o = out + (size_t)poly * K * n;
 #pragma unroll
-  for (int i = 0; i < KMAX; i++) {
-    if ((u32)i < K) {
-      const DevMod& qm = ctx->mod[i];
-      u128 a = 0;
-#pragma unroll
-      for (int j = 0; j < KMAX + 1; j++)
-        if ((u32)j < nB) a += (u128)yb[j] * ctx->B_to_q[i][j];
-      if (neg)
-        a += (u128)(msk.q - alpha) * ctx->B_mod_q[i];
-      else
-        a += (u128)alpha * (qm.q - ctx->B_mod_q[i]);
-      o[(size_t)i * n + k] = reduce128(a, qm);
-    }
-  }
+  for (int i = 0; i < KMAX; i++)
+    if ((u32)i < K) o[(size_t)i * n + k] = r[i];
 }
 
 // ---- key switching ----

@@ -1,0 +1,675 @@
+// sunscreen_amd/csrc/kernels_split.hip -- "head / middle / tail" split-transform kernels.
+//
+// A negacyclic NTT of N = 2^L points is L radix-2 stages.  The first kHeadLog stages (gaps >= N/8) and the
+// last kTailLog stages of the inverse (gaps >= N/4) are the only ones that couple distant coefficients;
+// all stages in between act inside contiguous blocks of N/4 coefficients.  So instead of one LDS-resident
+// whole-polynomial transform per residue (kernels.hip), the pipeline is cut at those two places:
+//
+//   head   : coefficient-parallel producer (RNS decomposition / base extension) that ALSO performs the first
+//            three forward stages on the 8 coefficients {t + k*N/8} it owns (wave-uniform twiddles);
+//   middle : one workgroup per (op, prime, block of N/4 coefficients): remaining forward stages, the pointwise
+//            work (key multiply-accumulate / tensor product), first L-2 inverse stages -- 16 KB of LDS per
+//            polynomial block instead of 64 KB, no whole-polynomial round trips through HBM;
+//   tail   : coefficient-parallel consumer that performs the last two inverse stages on the 4 coefficients
+//            {t + k*N/4} it owns, scales, and runs the per-coefficient epilogue (mod-down / BEHZ floor).
+//
+// Intermediates between the three kernels are stored in the arithmetic policy's native lazy representation
+// (IEEE doubles holding exact integers for the FP64 path) -- they never leave this file.
+//
+// This file: key switching (SEAL Evaluator::switch_key_inplace; Evaluator_Relinearize / RotateRows /
+// RotateColumns, seal_fhe/src/bfv_evaluator.rs:148-244) for contexts whose key-level primes all take the
+// FP64 path.
+#include <hip/hip_runtime.h>
+
+#include "behzcore.hpp"
+#include "kernels.hpp"
+#include "nttcore.hpp"
+
+namespace hipbfv {
+
+// LDS placement inside a block: XOR swizzle found by tools/lds_swizzle_search.py -- conflict free for every
+// pass window of the middle kernels at L = 12, 13, 14 (bank bits ^= e5*00101 ^ e6*01010 ^ e7*10001).
+__device__ __forceinline__ u32 blk_pos(u32 e) {
+  const u32 m = (((e >> 5) & 1u) * 0x05u) ^ (((e >> 6) & 1u) * 0x0Au) ^ (((e >> 7) & 1u) * 0x11u);
+  return e ^ m;
+}
+
+template <int L>
+struct SplitShape {
+  static constexpr int N = 1 << L;
+  static constexpr int LB = L - kTailLog;
+  static constexpr int BLOCK = 1 << LB;           // coefficients per middle workgroup
+  static constexpr int TPB = BLOCK / kBlkEPT;     // threads per middle workgroup
+  static constexpr int NBLK = 1 << kTailLog;      // blocks per polynomial
+  static constexpr int NPF = split_fwd_passes(L);
+  static constexpr int NPI = split_inv_passes(L);
+};
+
+// One pass of a middle kernel over the index window [LOW, LOW+R).  `blk` is the block index inside the
+// polynomial; virtual threads are numbered globally so that twiddle indices are those of the full transform.
+template <class A, int L, int LOW, int R>
+struct BlkPass {
+  using Sh = SplitShape<L>;
+  static constexpr int G = kBlkEPT >> R;
+  static __device__ __forceinline__ u32 vt(u32 tid, u32 blk, int g) { return blk * (u32)(Sh::BLOCK >> R) + tid + (u32)g * Sh::TPB; }
+  static __device__ __forceinline__ u32 elem(u32 tid, u32 blk, int g, int k) { return elem_index<LOW, R>(vt(tid, blk, g), (u32)k); }
+  static __device__ __forceinline__ void load_lds(typename A::V (&v)[kBlkEPT], const typename A::V* smem, u32 tid, u32 blk) {
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[blk_pos(elem(tid, blk, g, k) & (Sh::BLOCK - 1))];
+  }
+  static __device__ __forceinline__ void store_lds(const typename A::V (&v)[kBlkEPT], typename A::V* smem, u32 tid, u32 blk) {
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) smem[blk_pos(elem(tid, blk, g, k) & (Sh::BLOCK - 1))] = v[g * (1 << R) + k];
+  }
+  // forward stages S0..S0+R-1, S0 = L - LOW - R
+  static __device__ __forceinline__ void fwd(const A& ar, typename A::V (&v)[kBlkEPT], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
+    constexpr int S0 = L - LOW - R;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      u32 hi = vt(tid, blk, g) >> LOW;
+      if constexpr (LOW >= 6) hi = __builtin_amdgcn_readfirstlane(hi);
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const int half = 1 << (R - 1 - j);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+          if (k & half) continue;
+          const typename A::Tw w = tw[(1u << (S0 + j)) + ((hi << j) | (u32)(k >> (R - j)))];
+          ar.fwd(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w);
+        }
+      }
+    }
+  }
+  // inverse stages with global gaps 2^LOW .. 2^(LOW+R-1)
+  static __device__ __forceinline__ void inv(const A& ar, typename A::V (&v)[kBlkEPT], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      u32 hi = vt(tid, blk, g) >> LOW;
+      if constexpr (LOW >= 6) hi = __builtin_amdgcn_readfirstlane(hi);
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const int half = 1 << j;
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+          if (k & half) continue;
+          const typename A::Tw w = tw[(1u << (L - 1 - LOW - j)) + ((hi << (R - 1 - j)) | (u32)(k >> (j + 1)))];
+          ar.inv(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w);
+        }
+      }
+    }
+  }
+};
+
+template <class A>
+__device__ __forceinline__ void reduce_all(const A& ar, typename A::V (&v)[kBlkEPT]) {
+#pragma unroll
+  for (int e = 0; e < kBlkEPT; e++) v[e] = ar.reduce(v[e]);
+}
+
+// Remaining forward stages of one block.  On entry v holds the block's values in the layout of forward
+// middle pass 0 (window split_fwd_low(L,0)); on exit v holds the last pass's results (window LOW = 0).
+template <class A, int L, int P>
+__device__ __forceinline__ void mid_forward(const A& ar, typename A::V (&v)[kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+                                            const typename A::Tw* tw, u32 mask) {
+  constexpr int R = split_fwd_radix(L, P);
+  constexpr int LOW = split_fwd_low(L, P);
+  using Pass = BlkPass<A, L, LOW, R>;
+  if constexpr (P > 0) {
+    __syncthreads();
+    Pass::load_lds(v, smem, tid, blk);
+  }
+  if ((mask >> P) & 1u) reduce_all(ar, v);
+  Pass::fwd(ar, v, tid, blk, tw);
+  if constexpr (P + 1 < SplitShape<L>::NPF) {
+    Pass::store_lds(v, smem, tid, blk);
+    mid_forward<A, L, P + 1>(ar, v, smem, tid, blk, tw, mask);
+  }
+}
+
+// First L-2 inverse stages of one block.  On entry v holds values in the layout mid_forward leaves
+// (window LOW = 0); on exit v holds the results of the last middle pass (window split_inv_low(L, NPI-1)).
+template <class A, int L, int P>
+__device__ __forceinline__ void mid_inverse(const A& ar, typename A::V (&v)[kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+                                            const typename A::Tw* tw, u32 mask) {
+  constexpr int R = split_inv_radix(L, P);
+  constexpr int LOW = split_inv_low(L, P);
+  using Pass = BlkPass<A, L, LOW, R>;
+  if constexpr (P > 0) {
+    __syncthreads();
+    Pass::load_lds(v, smem, tid, blk);
+  }
+  if ((mask >> P) & 1u) reduce_all(ar, v);
+  Pass::inv(ar, v, tid, blk, tw);
+  if constexpr (P + 1 < SplitShape<L>::NPI) {
+    Pass::store_lds(v, smem, tid, blk);
+    mid_inverse<A, L, P + 1>(ar, v, smem, tid, blk, tw, mask);
+  }
+}
+
+constexpr int kHeadThreads = 256;
+
+// -------------------------------------------------------------------------------------------------
+// key switch, head: T[op][I][J] = first three forward stages over q_I of (target_J mod q_I)
+// grid: (N/8/256, K, ops)
+// -------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+                                                               const u64* __restrict__ target, size_t tstride, double* __restrict__ T) {
+  constexpr u32 N = 1u << L, Q = N >> kHeadLog;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 J = blockIdx.y, op = blockIdx.z;
+  const u32 K = ctx->K, KK = ctx->KK;
+  const u64* src = target + (size_t)op * tstride + (size_t)J * N + t;
+  u64 x[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) x[k] = src[(size_t)k * Q];
+  const u64 qJ = ctx->mod[J].q;
+  for (u32 I = 0; I < KK; I++) {
+    const DevMod& dm = ctx->mod[I];
+    const ArithD ar(dm);
+    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * N);
+    const bool need_reduce = qJ > dm.q;
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const double d = ar.from_u64(x[k]);
+      v[k] = need_reduce ? ar.reduce(d) : d;
+    }
+    // stages 0..2 of the forward transform: element k*N/8 + t, twiddle index 2^j + (k >> (3-j))
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int half = 4 >> j;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (k & half) continue;
+        ar.fwd(v[k], v[k + half], tw[(1u << j) + (u32)(k >> (3 - j))]);
+      }
+    }
+    double* dst = T + (((size_t)op * KK + I) * K + J) * N + t;
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[(size_t)k * Q] = v[k];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// key switch, middle: per (op, I, block): finish the K forward transforms, multiply-accumulate with the
+// key rows, run the block-local inverse stages of both accumulators.
+// grid: ops8 * KK * NBLK (op-major swizzle so that the blocks of one op share an XCD's L2)
+// -------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__((SplitShape<L>::TPB)) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+                                                                       const MulOp* __restrict__ twi_base, const double* __restrict__ T,
+                                                                       const u64* __restrict__ key, double* __restrict__ ACC, u32 ops) {
+  using Sh = SplitShape<L>;
+  using A = ArithD;
+  __shared__ double smem[Sh::BLOCK];
+  const u32 tid = threadIdx.x;
+  const u32 K = ctx->K, KK = ctx->KK;
+  const u32 b = blockIdx.x;
+  const u32 xcd = b & 7u, slot = b >> 3;
+  const u32 blk = slot % Sh::NBLK;
+  const u32 I = (slot / Sh::NBLK) % KK;
+  const u32 op = (slot / (Sh::NBLK * KK)) * 8u + xcd;
+  if (op >= ops) return;
+  const DevMod& dm = ctx->mod[I];
+  const A ar(dm);
+  const MulOpD* twf = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * Sh::N);
+  const MulOpD* twi = reinterpret_cast<const MulOpD*>(twi_base + (size_t)I * Sh::N);
+  constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
+  using First = BlkPass<A, L, LOWF0, RF0>;
+  constexpr int RL = split_fwd_radix(L, Sh::NPF - 1);  // last forward window: LOW = 0
+  using Last = BlkPass<A, L, 0, RL>;
+  double acc0[kBlkEPT], acc1[kBlkEPT];
+#pragma unroll
+  for (int e = 0; e < kBlkEPT; e++) acc0[e] = 0.0, acc1[e] = 0.0;
+  for (u32 J = 0; J < K; J++) {
+    const double* src = T + (((size_t)op * KK + I) * K + J) * Sh::N;
+    double v[kBlkEPT];
+#pragma unroll
+    for (int g = 0; g < First::G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << RF0); k++) v[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+    if (J > 0) __syncthreads();  // the previous transform's last pass may still be reading LDS
+    // The twiddles do not depend on J: without this the compiler hoists every twiddle load of all passes out
+    // of the loop and keeps ~100 registers of them alive (spilling to scratch).  Re-materialise the pointer.
+    const MulOpD* twf_j = twf;
+    asm volatile("" : "+s"(twf_j));
+    mid_forward<A, L, 0>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
+    const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
+    const u64* k1 = key + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
+#pragma unroll
+    for (int g = 0; g < Last::G; g++) {
+      const u32 base = Last::elem(tid, blk, g, 0);
+#pragma unroll
+      for (int k = 0; k < (1 << RL); k += 2) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
+        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
+        const int e = g * (1 << RL) + k;
+        acc0[e] += ar.mul_var(v[e], ar.from_u64(a.x));
+        acc0[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(a.y));
+        acc1[e] += ar.mul_var(v[e], ar.from_u64(c.x));
+        acc1[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(c.y));
+      }
+    }
+    if ((J & 3u) == 3u) {
+      reduce_all(ar, acc0);
+      reduce_all(ar, acc1);
+    }
+  }
+  reduce_all(ar, acc0);
+  reduce_all(ar, acc1);
+  constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
+  using Out = BlkPass<A, L, LOWI, RI>;
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    double(&acc)[kBlkEPT] = c ? acc1 : acc0;
+    __syncthreads();
+    const MulOpD* twi_c = twi;
+    asm volatile("" : "+s"(twi_c));
+    mid_inverse<A, L, 0>(ar, acc, smem, tid, blk, twi_c, dm.split_inv_mask);
+    double* dst = ACC + (((size_t)op * 2 + c) * KK + I) * Sh::N;
+#pragma unroll
+    for (int g = 0; g < Out::G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << RI); k++) dst[Out::elem(tid, blk, g, k)] = acc[g * (1 << RI) + k];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// key switch, tail: last two inverse stages + n^{-1} on the coefficients {t + k*N/4}, then SEAL's mod-down
+// by the special prime with rounding, added to the base ciphertext.
+// grid: (N/4/256, 2, ops)
+// -------------------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ void tail_inverse4(const ArithD& ar, double (&v)[4], const MulOpD* __restrict__ tw, bool reduce_first) {
+  if (reduce_first) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
+  }
+  // window [L-2, L): stage j = 0 pairs (0,1),(2,3) with twiddles 2 + (k>>1); stage j = 1 pairs (0,2),(1,3) with twiddle 1
+  ar.inv(v[0], v[1], tw[2]);
+  ar.inv(v[2], v[3], tw[3]);
+  ar.inv(v[0], v[2], tw[1]);
+  ar.inv(v[1], v[3], tw[1]);
+}
+
+template <int L>
+__global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+                                                               const double* __restrict__ ACC, const u64* __restrict__ base, size_t bstride,
+                                                               u32 base_mask, u64* __restrict__ out) {
+  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 c = blockIdx.y, op = blockIdx.z;
+  const u32 K = ctx->K, KK = ctx->KK;
+  const double* acc = ACC + ((size_t)op * 2 + c) * KK * N + t;
+  // special prime first
+  u64 tl[4];
+  {
+    const DevMod& sp = ctx->mod[KK - 1];
+    const ArithD ar(sp);
+    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK - 1) * N);
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = acc[(size_t)(KK - 1) * N + (size_t)k * Q];
+    tail_inverse4<L>(ar, v, tw, (sp.split_inv_mask >> 8) & 1u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
+  }
+  const u64 qsp = ctx->mod[KK - 1].q;
+  for (u32 J = 0; J < K; J++) {
+    const DevMod& mj = ctx->mod[J];
+    const ArithD ar(mj);
+    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)J * N);
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = acc[(size_t)J * N + (size_t)k * Q];
+    tail_inverse4<L>(ar, v, tw, (mj.split_inv_mask >> 8) & 1u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
+      u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
+      tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+      u64 d = sub_mod(a, tk, mj.q);
+      d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
+      const size_t off = ((size_t)c * K + J) * N + t + (size_t)k * Q;
+      const u64 bv = ((base_mask >> c) & 1u) ? base[(size_t)op * bstride + off] : 0;
+      out[((size_t)op * 2) * K * N + off] = add_mod(bv, d, mj.q);
+    }
+  }
+}
+
+// =================================================================================================
+// BEHZ multiply (2 x 2 -> 3), split pipeline.  Replaces behz_extend -> ntt_fwd -> tensor -> ntt_inv ->
+// behz_floor_sk of the whole-polynomial path (SEAL bfv_multiply; Evaluator_Multiply,
+// seal_fhe/src/evaluator_base.rs:198-212).  Residue r < K uses prime q_r (FP64 path when its range plan
+// succeeded, integer path otherwise), residue K + j uses the 61-bit auxiliary prime Bsk_j (integer path).
+// =================================================================================================
+
+__device__ __forceinline__ bool residue_is_f64(const DevMod& dm) { return dm.use_f64 && dm.split_ok; }
+
+// A pointer the compiler can prove wave-uniform (scalar loads stay possible) but cannot hoist loads through:
+// used to keep twiddle loads inside the transform that consumes them.
+template <class T>
+__device__ __forceinline__ const T* opaque_uniform(const T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  unsigned long long r = ((unsigned long long)hi << 32) | lo;
+  asm volatile("" : "+s"(r));
+  return reinterpret_cast<const T*>(r);
+}
+
+// first three forward stages on the eight values {t + k*N/8}; native (lazy) representation out
+template <class A>
+__device__ __forceinline__ void head_fwd8(const A& ar, typename A::V (&v)[8], const typename A::Tw* __restrict__ tw) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int half = 4 >> j;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (k & half) continue;
+      ar.fwd(v[k], v[k + half], tw[(1u << j) + (u32)(k >> (3 - j))]);
+    }
+  }
+}
+
+// mul head: grid (N/8/256, 4 polys (a0,a1,b0,b1), ops); ext = [ops][4][K+S][N] in native representation
+template <int L, int KMAX>
+__global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+                                                                const u64* __restrict__ in0, const u64* __restrict__ in1,
+                                                                u64* __restrict__ ext) {
+  constexpr u32 N = 1u << L, Q = N >> kHeadLog;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 poly = blockIdx.y, op = blockIdx.z;
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
+  const u64* src = (poly < 2 ? in0 + ((size_t)op * 2 + poly) * K * N : in1 + ((size_t)op * 2 + (poly - 2)) * K * N) + t;
+  u64* dst = ext + ((size_t)op * 4 + poly) * R * N + t;
+  u64 x[KMAX][8];
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[i][k] = (u32)i < K ? src[(size_t)i * N + (size_t)k * Q] : 0;
+  }
+  // q residues: just the three head stages
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const DevMod& dm = ctx->mod[i];
+      const MulOp* tw = twf_base + (size_t)i * N;
+      if (residue_is_f64(dm)) {
+        const ArithD ar(dm);
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = ar.from_u64(x[i][k]);
+        head_fwd8(ar, v, reinterpret_cast<const MulOpD*>(tw));
+        double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+      } else {
+        const ArithI ar(dm);
+        u64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = x[i][k];
+        head_fwd8(ar, v, tw);
+        u64* o = dst + (size_t)i * N;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+      }
+    }
+  }
+  // auxiliary base: extend every owned coefficient, then the head stages per Bsk prime
+  u64 ev[KMAX + 2][8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    u64 xr[KMAX], er[KMAX + 2];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) xr[i] = x[i][k];
+#pragma unroll
+    for (int j = 0; j < KMAX + 2; j++) er[j] = 0;
+    behz_extend_coeff<KMAX>(ctx, xr, er);
+#pragma unroll
+    for (int j = 0; j < KMAX + 2; j++) ev[j][k] = er[j];
+  }
+#pragma unroll
+  for (int j = 0; j < KMAX + 2; j++) {
+    if ((u32)j < S) {
+      const DevMod& dm = ctx->mod[KK + j];
+      const ArithI ar(dm);
+      u64 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = ev[j][k];
+      head_fwd8(ar, v, twf_base + (size_t)(KK + j) * N);
+      u64* o = dst + (size_t)(K + j) * N;
+#pragma unroll
+      for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+    }
+  }
+}
+
+// mul middle body for one (op, residue, block)
+template <class A, int L>
+__device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi, const typename A::V* ext_r,
+                                             size_t poly_stride, typename A::V* D_r, size_t dpoly_stride, typename A::V* smem,
+                                             typename A::V* park, u32 tid, u32 blk) {
+  using Sh = SplitShape<L>;
+  const A ar(dm);
+  constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
+  using First = BlkPass<A, L, LOWF0, RF0>;
+  constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
+  using Out = BlkPass<A, L, LOWI, RI>;
+  typename A::V a1[kBlkEPT], d0[kBlkEPT], d1[kBlkEPT], v[kBlkEPT];
+  auto load_fwd = [&](int poly, typename A::V(&dst)[kBlkEPT], bool sync_first) {
+    const typename A::V* src = ext_r + (size_t)poly * poly_stride;
+#pragma unroll
+    for (int g = 0; g < First::G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+    if (sync_first) __syncthreads();
+    const typename A::Tw* tw = opaque_uniform(twf);  // keep the twiddle loads inside this transform
+    mid_forward<A, L, 0>(ar, dst, smem, tid, blk, tw, dm.split_fwd_mask);
+  };
+  load_fwd(0, v, false);  // a0 -> parked in LDS (thread-private slots)
+#pragma unroll
+  for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB + tid] = v[e];
+  load_fwd(1, a1, true);
+  load_fwd(2, v, true);  // b0
+#pragma unroll
+  for (int e = 0; e < kBlkEPT; e++) {
+    d0[e] = ar.mul_var(park[e * Sh::TPB + tid], v[e]);
+    d1[e] = ar.mul_var(a1[e], v[e]);
+  }
+  load_fwd(3, v, true);  // b1
+#pragma unroll
+  for (int e = 0; e < kBlkEPT; e++) {
+    d1[e] = ar.mul_add(park[e * Sh::TPB + tid], v[e], d1[e]);
+    a1[e] = ar.mul_var(a1[e], v[e]);  // d2
+  }
+  auto inv_store = [&](typename A::V(&d)[kBlkEPT], int poly) {
+    __syncthreads();
+    const typename A::Tw* tw = opaque_uniform(twi);
+    mid_inverse<A, L, 0>(ar, d, smem, tid, blk, tw, dm.split_inv_mask);
+    typename A::V* dst = D_r + (size_t)poly * dpoly_stride;
+#pragma unroll
+    for (int g = 0; g < Out::G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << RI); k++) dst[Out::elem(tid, blk, g, k)] = d[g * (1 << RI) + k];
+  };
+  inv_store(d0, 0);
+  inv_store(d1, 1);
+  inv_store(a1, 2);
+}
+
+// grid: ops * R * NBLK workgroups of TPB threads; D = [ops][3][R][N] native representation
+template <int L>
+__global__ __launch_bounds__((SplitShape<L>::TPB), 3) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+                                                                        const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
+                                                                        u64* __restrict__ D) {
+  using Sh = SplitShape<L>;
+  __shared__ u64 smem[Sh::BLOCK];
+  __shared__ u64 park[Sh::BLOCK];
+  const u32 tid = threadIdx.x;
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
+  const u32 b = blockIdx.x;
+  const u32 blk = b % Sh::NBLK;
+  const u32 r = (b / Sh::NBLK) % R;
+  const u32 op = b / (Sh::NBLK * R);
+  const u32 m = r < K ? r : KK + (r - K);
+  const DevMod& dm = ctx->mod[m];
+  const u64* ext_r = ext + ((size_t)op * 4 * R + r) * Sh::N;
+  u64* D_r = D + ((size_t)op * 3 * R + r) * Sh::N;
+  const size_t ps = (size_t)R * Sh::N;
+  const MulOp* twf = twf_base + (size_t)m * Sh::N;
+  const MulOp* twi = twi_base + (size_t)m * Sh::N;
+  if (residue_is_f64(dm))
+    mul_mid_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
+                            reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
+                            reinterpret_cast<double*>(smem), reinterpret_cast<double*>(park), tid, blk);
+  else
+    mul_mid_body<ArithI, L>(dm, twf, twi, ext_r, ps, D_r, ps, smem, park, tid, blk);
+}
+
+// last two inverse stages + BEHZ scaling on {t + k*N/4}: canonical residues out
+template <class A>
+__device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V* __restrict__ src, size_t Q, const typename A::Tw* __restrict__ tw,
+                                                const typename A::Tw& sc, bool reduce_first, u64 (&out)[4]) {
+  typename A::V v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = src[(size_t)k * Q];
+  if (reduce_first) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
+  }
+  ar.inv(v[0], v[1], tw[2]);
+  ar.inv(v[2], v[3], tw[3]);
+  ar.inv(v[0], v[2], tw[1]);
+  ar.inv(v[1], v[3], tw[1]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[k] = ar.scale_canonical(v[k], sc);
+}
+
+// mul tail: grid (N/4/256, 3 polys, ops); out = [ops][3][K][N] canonical
+template <int L, int KMAX>
+__global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+                                                                const u64* __restrict__ D, u64* __restrict__ out) {
+  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 poly = blockIdx.y, op = blockIdx.z;
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
+  const u64* d = D + ((size_t)op * 3 + poly) * R * N + t;
+  u64 y[4][KMAX], xb[4][KMAX + 2];
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const DevMod& dm = ctx->mod[i];
+      u64 o[4];
+      if (residue_is_f64(dm)) {
+        const ArithD ar(dm);
+        tail_inv4_scale(ar, reinterpret_cast<const double*>(d + (size_t)i * N), Q, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
+                        ctx->intt_scale_q_d[i], (dm.split_inv_mask >> 8) & 1u, o);
+      } else {
+        const ArithI ar(dm);
+        tail_inv4_scale(ar, d + (size_t)i * N, Q, twi_base + (size_t)i * N, ctx->intt_scale_q[i], false, o);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) y[k][i] = o[k];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KMAX + 2; j++) {
+    if ((u32)j < S) {
+      const DevMod& dm = ctx->mod[KK + j];
+      const ArithI ar(dm);
+      u64 o[4];
+      tail_inv4_scale(ar, d + (size_t)(K + j) * N, Q, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], false, o);
+#pragma unroll
+      for (int k = 0; k < 4; k++) xb[k][j] = o[k];
+    }
+  }
+  u64* o = out + ((size_t)op * 3 + poly) * K * N + t;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    u64 r[KMAX];
+    behz_floor_sk_coeff<KMAX>(ctx, y[k], xb[k], r);
+#pragma unroll
+    for (int i = 0; i < KMAX; i++)
+      if ((u32)i < K) o[(size_t)i * N + (size_t)k * Q] = r[i];
+  }
+}
+
+// scratch layout (same size as the unfused path): T = double[ops][KK][K][N], ACC = double[ops][2][KK][N]
+#define SPLIT_DISPATCH(fn, ...)              \
+  switch (logn) {                            \
+    case 12: return fn<12>(__VA_ARGS__);     \
+    case 13: return fn<13>(__VA_ARGS__);     \
+    case 14: return fn<14>(__VA_ARGS__);     \
+    default: return hipErrorInvalidValue;    \
+  }
+
+template <int L>
+static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
+  ks_head_kernel<L><<<dim3((1u << L) / 8 / kHeadThreads, K, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twf, target, tstride,
+                                                                                                   reinterpret_cast<double*>(T));
+  return hipGetLastError();
+}
+hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(ks_head_t, ctx, twf, K, target, tstride, T, ops, s)
+}
+
+template <int L>
+static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops,
+                           hipStream_t s) {
+  using Sh = SplitShape<L>;
+  const size_t ops8 = (ops + 7) / 8 * 8;
+  ks_mid_kernel<L><<<dim3((unsigned)(ops8 * KK * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key,
+                                                                               reinterpret_cast<double*>(ACC), (u32)ops);
+  return hipGetLastError();
+}
+hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops,
+                         hipStream_t s) {
+  SPLIT_DISPATCH(ks_mid_t, ctx, twf, twi, KK, T, key, ACC, ops, s)
+}
+
+template <int L>
+static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, u64* out2, size_t ops,
+                            hipStream_t s) {
+  ks_tail_kernel<L><<<dim3((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base,
+                                                                                                   bstride, base_mask, out2);
+  return hipGetLastError();
+}
+hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, u64* out2,
+                          size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(ks_tail_t, ctx, twi, ACC, base, bstride, base_mask, out2, ops, s)
+}
+
+template <int L>
+static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, const u64* a, const u64* b, u64* ext, size_t ops, hipStream_t s) {
+  mul_head_kernel<L, 4><<<dim3((1u << L) / 8 / kHeadThreads, 4, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+  return hipGetLastError();
+}
+hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, const u64* a, const u64* b, u64* ext, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mul_head_t, ctx, twf, a, b, ext, ops, s)
+}
+
+template <int L>
+static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 R, const u64* ext, u64* D, size_t ops, hipStream_t s) {
+  using Sh = SplitShape<L>;
+  mul_mid_kernel<L><<<dim3((unsigned)(ops * R * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D);
+  return hipGetLastError();
+}
+hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 R, const u64* ext, u64* D, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mul_mid_t, ctx, twf, twi, R, ext, D, ops, s)
+}
+
+template <int L>
+static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, const u64* D, u64* out, size_t ops, hipStream_t s) {
+  mul_tail_kernel<L, 4><<<dim3((1u << L) / 4 / kHeadThreads, 3, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twi, D, out);
+  return hipGetLastError();
+}
+hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* D, u64* out, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mul_tail_t, ctx, twi, D, out, ops, s)
+}
+
+}  // namespace hipbfv

@@ -1,0 +1,118 @@
+// sunscreen_amd/csrc/nttcore.hpp -- device-side building blocks shared by the NTT kernels
+// (kernels.hip: whole-polynomial transforms; kernels_split.hip: head / middle / tail split transforms).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "devarith.hpp"
+#include "nttshape.hpp"
+
+namespace hipbfv {
+
+// LDS placement of coefficient e: an XOR swizzle of the low five (bank) bits with bits 5..8, chosen so
+// that every access pattern of every pass (strides 1, 8, 16 words and the split 8+64 / 16+256 patterns of
+// the middle passes) maps the 32 lanes of a half-wave to 32 distinct 8-byte banks.  bank = e[0:5] ^
+// (e5 ? 00001) ^ (e6 ? 01010) ^ (e7 ? 10100) ^ (e8 ? 11000); it is a bijection on each 32-word block.
+__device__ __forceinline__ u32 lds_pos(u32 e) {
+  const u32 m = ((e >> 5) & 1u) ^ (((e >> 6) & 1u) * 0x0Au) ^ (((e >> 7) & 1u) * 0x14u) ^ (((e >> 8) & 1u) * 0x18u);
+  return e ^ m;
+}
+
+template <int LOGN, int EPT = kElemsPerThread>
+struct NttShape {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int E = EPT;
+  static constexpr int T = N / EPT;
+  static constexpr int NPASS = ntt_num_passes(LOGN, EPT);
+  static constexpr int LDS_WORDS = N;
+  // radix (number of stages) of pass p, and the number of stages before it
+  static constexpr int radix(int p) { return ntt_pass_radix(LOGN, p, EPT); }
+  static constexpr int before(int p) { return ntt_stages_before(LOGN, p, EPT); }
+};
+
+// element index handled by virtual thread vt in a pass that covers bit positions [LOW, LOW+R)
+template <int LOW, int R>
+__device__ __forceinline__ u32 elem_index(u32 vt, u32 k) {
+  const u32 lo = vt & ((1u << LOW) - 1u);
+  const u32 hi = vt >> LOW;
+  return (hi << (LOW + R)) | (k << LOW) | lo;
+}
+
+// ---- arithmetic policies -------------------------------------------------------------
+// ArithI: 64-bit integers, Harvey lazy butterflies with Shoup twiddles (any prime < 2^62).
+struct ArithI {
+  using V = u64;
+  using Tw = MulOp;
+  u64 q, q2;
+  const DevMod* dm;
+  __device__ __forceinline__ explicit ArithI(const DevMod& m) : q(m.q), q2(m.q << 1), dm(&m) {}
+  // products of lazy operands (< 4q each): canonical results
+  __device__ __forceinline__ V mul_var(V a, V b) const { return reduce128((u128)a * b, *dm); }
+  __device__ __forceinline__ V mul_add(V a, V b, V c) const { return reduce128((u128)a * b + c, *dm); }
+  __device__ __forceinline__ V from_u64(u64 x) const { return x; }
+  __device__ __forceinline__ V reduce(V v) const { return v; }  // lazy invariants hold without it
+  // forward: X,Y in [0,4q) -> [0,4q)
+  __device__ __forceinline__ void fwd(V& X, V& Y, const Tw& w) const {
+    const u64 x = X >= q2 ? X - q2 : X;
+    const u64 t = mul_shoup_lazy(Y, w.w, w.wq, q);
+    X = x + t;
+    Y = x + q2 - t;
+  }
+  // inverse: X,Y in [0,2q) -> [0,2q)
+  __device__ __forceinline__ void inv(V& X, V& Y, const Tw& w) const {
+    const u64 u = X, y = Y, s = u + y;
+    X = s >= q2 ? s - q2 : s;
+    Y = mul_shoup_lazy(u + q2 - y, w.w, w.wq, q);
+  }
+  __device__ __forceinline__ u64 canonical(V v) const {  // v in [0,4q)
+    v = v >= q2 ? v - q2 : v;
+    return v >= q ? v - q : v;
+  }
+  __device__ __forceinline__ u64 scale_canonical(V v, const Tw& sc) const { return mul_shoup(v, sc.w, sc.wq, q); }
+};
+
+// ArithD: residues as exact integers in doubles (primes < 2^50).  T = Y*W - rint(Y*(W/q))*q is exact:
+// the product is split error-free with an fma, the quotient estimate is off by at most
+// 0.5 + |Y|*2^-52, and every intermediate is an integer below 2^53 (range plan: context.cpp).
+struct ArithD {
+  using V = double;
+  using Tw = MulOpD;
+  double q, qinv;
+  __device__ __forceinline__ explicit ArithD(const DevMod& m) : q(m.qd), qinv(m.qinv) {}
+  __device__ __forceinline__ V from_u64(u64 x) const {
+    // exact for x < 2^52: plant the integer in the mantissa of 2^52 and subtract 2^52
+    return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0;
+  }
+  __device__ __forceinline__ V mul_const(V y, const Tw& w) const {
+    const double qf = rint(y * w.wq);
+    const double xh = y * w.w;
+    const double xl = fma(y, w.w, -xh);
+    return fma(-qf, q, xh) + xl;
+  }
+  __device__ __forceinline__ V reduce(V v) const { return fma(-rint(v * qinv), q, v); }
+  // a*b mod q for two variable operands (|a*b| < 2^105): |result| <= q*(0.5 + |a*b/q|*2^-52)
+  __device__ __forceinline__ V mul_var(V a, V b) const {
+    const double xh = a * b;
+    const double xl = fma(a, b, -xh);
+    const double qf = rint(xh * qinv);
+    return fma(-qf, q, xh) + xl;
+  }
+  __device__ __forceinline__ V mul_add(V a, V b, V c) const { return reduce(mul_var(a, b) + c); }
+  __device__ __forceinline__ void fwd(V& X, V& Y, const Tw& w) const {
+    const double t = mul_const(Y, w), x = X;
+    X = x + t;
+    Y = x - t;
+  }
+  __device__ __forceinline__ void inv(V& X, V& Y, const Tw& w) const {
+    const double u = X, y = Y;
+    X = u + y;
+    Y = mul_const(u - y, w);
+  }
+  __device__ __forceinline__ u64 to_u64(V v) const {  // v an integer in (-q, q)
+    v = v < 0.0 ? v + q : v;
+    return (u64)__double_as_longlong(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
+  }
+  __device__ __forceinline__ u64 canonical(V v) const { return to_u64(reduce(v)); }
+  __device__ __forceinline__ u64 scale_canonical(V v, const Tw& sc) const { return to_u64(reduce(mul_const(v, sc))); }
+};
+
+}  // namespace hipbfv

@@ -18,4 +18,35 @@ constexpr int ntt_stages_before(int logn, int p, int ept = kElemsPerThread) {
   return p * (logn / ntt_num_passes(logn, ept)) + (p < logn % ntt_num_passes(logn, ept) ? p : logn % ntt_num_passes(logn, ept));
 }
 
+
+// ---- split ("head / middle / tail") transforms -------------------------------------------------
+// The first kHeadLog forward stages (gaps >= N/8) are done by the coefficient-parallel producer kernel,
+// the last kTailLog inverse stages (gaps >= N/4) by the coefficient-parallel consumer kernel; everything
+// in between is local to contiguous blocks of N/4 coefficients and runs in one "middle" kernel per block
+// with 8 elements per thread.  Pass radices of the middle kernel:
+constexpr int kHeadLog = 3;
+constexpr int kTailLog = 2;
+constexpr int kBlkEPT = 8;
+constexpr int split_fwd_passes(int logn) { return (logn - kHeadLog + 2) / 3; }
+constexpr int split_inv_passes(int logn) { return (logn - kTailLog + 2) / 3; }
+constexpr int split_fwd_radix(int logn, int p) {
+  // logn-3 stages: 9 -> 3,3,3 ; 10 -> 3,3,2,2 ; 11 -> 2,3,3,3
+  return logn - kHeadLog == 9 ? 3 : logn - kHeadLog == 10 ? (p < 2 ? 3 : 2) : (p == 0 ? 2 : 3);
+}
+constexpr int split_inv_radix(int logn, int p) {
+  // logn-2 stages, first radix == last forward radix: 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3
+  return logn - kTailLog == 10 ? (p < 2 ? 3 : 2) : logn - kTailLog == 11 ? (p == 0 ? 2 : 3) : 3;
+}
+constexpr int split_fwd_low(int logn, int p) {  // lowest index bit of the window of forward middle pass p
+  int s = kHeadLog;
+  for (int i = 0; i <= p; i++) s += split_fwd_radix(logn, i);
+  return logn - s;
+}
+constexpr int split_inv_low(int logn, int p) {
+  int s = 0;
+  for (int i = 0; i < p; i++) s += split_inv_radix(logn, i);
+  return s;
+}
+constexpr bool split_supported(int logn) { return logn >= 12 && logn <= 14; }
+
 }  // namespace hipbfv
