@@ -131,7 +131,11 @@ bool plan_f64_path(u64 q, int logn, int ept, u32* fwd_mask, u32* inv_mask) {
       if (!ok) {
         mask |= 1u << p;
         m = run(0.5 + M * eps, &ok);
-        if (!ok) return false;
+        if (!ok) {  // bit p+16: reduce twice at the start of pass p
+          mask |= 1u << (p + 16);
+          m = run(0.5 + (0.5 + M * eps) * eps, &ok);
+          if (!ok) return false;
+        }
       }
       M = m;
     }
@@ -158,7 +162,11 @@ bool plan_f64_path(u64 q, int logn, int ept, u32* fwd_mask, u32* inv_mask) {
       if (!ok) {
         mask |= 1u << p;
         m = run(0.5 + M * eps, &ok);
-        if (!ok) return false;
+        if (!ok) {  // bit p+16: reduce twice at the start of pass p
+          mask |= 1u << (p + 16);
+          m = run(0.5 + (0.5 + M * eps) * eps, &ok);
+          if (!ok) return false;
+        }
       }
       M = m;
     }
@@ -194,7 +202,11 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
       if (!ok) {
         mask |= 1u << p;
         m = run(0.5 + M * eps, &ok);
-        if (!ok) return false;
+        if (!ok) {  // reduce twice: the second reduction starts from a value already close to q/2
+          mask |= 1u << (p + 16);
+          m = run(0.5 + (0.5 + M * eps) * eps, &ok);
+          if (!ok) return false;
+        }
       }
       M = m;
     }
@@ -223,7 +235,11 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
       if (!ok) {
         mask |= tail ? (1u << 8) : (1u << p);
         m = run(0.5 + M * eps, r, &ok);
-        if (!ok) return false;
+        if (!ok) {
+          mask |= tail ? (1u << 24) : (1u << (p + 16));
+          m = run(0.5 + (0.5 + M * eps) * eps, r, &ok);
+          if (!ok) return false;
+        }
       }
       M = m;
     }
@@ -403,10 +419,8 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     dm.qd = (double)p;
     dm.qinv = 1.0 / (double)p;
     dm.ninv_d = make_mulop_d(ninv, p);
-    dm.use_f64 = plan_f64_path(p, (int)h.logn, 16, &dm.fwd_reduce_mask, &dm.inv_reduce_mask) &&
-                         plan_f64_path(p, (int)h.logn, 8, &dm.fwd_reduce_mask8, &dm.inv_reduce_mask8)
-                     ? 1u
-                     : 0u;
+    dm.use_f64 = plan_f64_path(p, (int)h.logn, 16, &dm.fwd_reduce_mask, &dm.inv_reduce_mask) ? 1u : 0u;
+    dm.ept8_ok = dm.use_f64 && plan_f64_path(p, (int)h.logn, 8, &dm.fwd_reduce_mask8, &dm.inv_reduce_mask8) ? 1u : 0u;
     dm.split_ok = dm.use_f64 && plan_f64_split(p, (int)h.logn, &dm.split_fwd_mask, &dm.split_inv_mask) ? 1u : 0u;
     if (const char* env = std::getenv("HIPBFV_NO_F64"))
       if (env[0] == '1') dm.use_f64 = 0, dm.split_ok = 0;

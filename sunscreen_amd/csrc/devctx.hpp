@@ -45,6 +45,8 @@ struct DevMod {
   u32 split_fwd_mask;
   u32 split_inv_mask;
   u32 split_ok;          // the FP64 range plan of the split structure succeeded
+  u32 ept8_ok;           // ... of the 8-elements-per-thread whole-polynomial structure (experimental fused kernel)
+  u32 pad_[3];
 
   double qd;     // (double) q
   double qinv;   // 1.0 / q

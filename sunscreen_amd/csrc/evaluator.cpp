@@ -275,7 +275,7 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
     return kOk;
   }
   bool all_f64 = fused_ks_ && h.logn <= 13;  // N = 16384 needs <= 128 VGPRs at 1024 threads: unfused path
-  for (u32 i = 0; i < KK; i++) all_f64 = all_f64 && h.mod[i].use_f64;
+  for (u32 i = 0; i < KK; i++) all_f64 = all_f64 && h.mod[i].use_f64 && h.mod[i].ept8_ok;
   if (all_f64) {
     // fused decompose + NTT + key MAC + INTT: K*KK forward and 2*KK inverse transforms per op
     HB_LAUNCH(kKernKsFused, count * KK * (K + 2), launch_ks_fused(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, KK, target, tstride, key, ACC, count, s));

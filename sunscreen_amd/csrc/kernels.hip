@@ -80,6 +80,10 @@ struct FwdPasses {
 #pragma unroll
       for (int e = 0; e < EPT; e++) v[e] = ar.reduce(v[e]);
     }
+    if ((reduce_mask >> (PASS + 16)) & 1u) {  // very wide primes: a second reduction (context.cpp range plan)
+#pragma unroll
+      for (int e = 0; e < EPT; e++) v[e] = ar.reduce(v[e]);
+    }
     fwd_pass_compute<A, LOGN, EPT, S0, R>(ar, v, tid, tw);
     if constexpr (!(KEEP_REGS && PASS + 1 == Sh::NPASS)) {
 #pragma unroll
@@ -154,6 +158,10 @@ struct InvPasses {
         for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
     }
     if ((reduce_mask >> PASS) & 1u) {
+#pragma unroll
+      for (int e = 0; e < EPT; e++) v[e] = ar.reduce(v[e]);
+    }
+    if ((reduce_mask >> (PASS + 16)) & 1u) {  // very wide primes: a second reduction (context.cpp range plan)
 #pragma unroll
       for (int e = 0; e < EPT; e++) v[e] = ar.reduce(v[e]);
     }

@@ -123,6 +123,7 @@ __device__ __forceinline__ void mid_forward(const A& ar, typename A::V (&v)[kBlk
     Pass::load_lds(v, smem, tid, blk);
   }
   if ((mask >> P) & 1u) reduce_all(ar, v);
+  if ((mask >> (P + 16)) & 1u) reduce_all(ar, v);  // very wide primes: a second reduction (context.cpp range plan)
   Pass::fwd(ar, v, tid, blk, tw);
   if constexpr (P + 1 < SplitShape<L>::NPF) {
     Pass::store_lds(v, smem, tid, blk);
@@ -143,6 +144,7 @@ __device__ __forceinline__ void mid_inverse(const A& ar, typename A::V (&v)[kBlk
     Pass::load_lds(v, smem, tid, blk);
   }
   if ((mask >> P) & 1u) reduce_all(ar, v);
+  if ((mask >> (P + 16)) & 1u) reduce_all(ar, v);
   Pass::inv(ar, v, tid, blk, tw);
   if constexpr (P + 1 < SplitShape<L>::NPI) {
     Pass::store_lds(v, smem, tid, blk);
@@ -285,8 +287,12 @@ __global__ __launch_bounds__((SplitShape<L>::TPB)) void ks_mid_kernel(const DevC
 // grid: (N/4/256, 2, ops)
 // -------------------------------------------------------------------------------------------------
 template <int L>
-__device__ __forceinline__ void tail_inverse4(const ArithD& ar, double (&v)[4], const MulOpD* __restrict__ tw, bool reduce_first) {
-  if (reduce_first) {
+__device__ __forceinline__ void tail_inverse4(const ArithD& ar, double (&v)[4], const MulOpD* __restrict__ tw, u32 mask) {
+  if ((mask >> 8) & 1u) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
+  }
+  if ((mask >> 24) & 1u) {
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
   }
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     double v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = acc[(size_t)(KK - 1) * N + (size_t)k * Q];
-    tail_inverse4<L>(ar, v, tw, (sp.split_inv_mask >> 8) & 1u);
+    tail_inverse4<L>(ar, v, tw, sp.split_inv_mask);
 #pragma unroll
     for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
   }
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     double v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = acc[(size_t)J * N + (size_t)k * Q];
-    tail_inverse4<L>(ar, v, tw, (mj.split_inv_mask >> 8) & 1u);
+    tail_inverse4<L>(ar, v, tw, mj.split_inv_mask);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
@@ -534,11 +540,15 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 3) void mul_mid_kernel(const 
 // last two inverse stages + BEHZ scaling on {t + k*N/4}: canonical residues out
 template <class A>
 __device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V* __restrict__ src, size_t Q, const typename A::Tw* __restrict__ tw,
-                                                const typename A::Tw& sc, bool reduce_first, u64 (&out)[4]) {
+                                                const typename A::Tw& sc, u32 mask, u64 (&out)[4]) {
   typename A::V v[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) v[k] = src[(size_t)k * Q];
-  if (reduce_first) {
+  if ((mask >> 8) & 1u) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
+  }
+  if ((mask >> 24) & 1u) {
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
   }
@@ -568,10 +578,10 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
       if (residue_is_f64(dm)) {
         const ArithD ar(dm);
         tail_inv4_scale(ar, reinterpret_cast<const double*>(d + (size_t)i * N), Q, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
-                        ctx->intt_scale_q_d[i], (dm.split_inv_mask >> 8) & 1u, o);
+                        ctx->intt_scale_q_d[i], dm.split_inv_mask, o);
       } else {
         const ArithI ar(dm);
-        tail_inv4_scale(ar, d + (size_t)i * N, Q, twi_base + (size_t)i * N, ctx->intt_scale_q[i], false, o);
+        tail_inv4_scale(ar, d + (size_t)i * N, Q, twi_base + (size_t)i * N, ctx->intt_scale_q[i], 0u, o);
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) y[k][i] = o[k];
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
       const DevMod& dm = ctx->mod[KK + j];
       const ArithI ar(dm);
       u64 o[4];
-      tail_inv4_scale(ar, d + (size_t)(K + j) * N, Q, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], false, o);
+      tail_inv4_scale(ar, d + (size_t)(K + j) * N, Q, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], 0u, o);
 #pragma unroll
       for (int k = 0; k < 4; k++) xb[k][j] = o[k];
     }
