@@ -32,7 +32,7 @@ __device__ __forceinline__ void behz_extend_coeff(const DevCtx* __restrict__ ctx
       u64 rc = rm;
       if (rm >= 0x80000000u) rc += pm.q - 0x100000000ull;  // centred representative
       acc += (u128)rc * ctx->q_mod_bsk[j];
-      out[j] = mul_shoup(reduce128(acc, pm), ctx->inv_mtilde_mod_bsk[j], pm.q);
+      out[j] = mul_shoup(reduce128_fast(acc, pm), ctx->inv_mtilde_mod_bsk[j], pm.q);
     }
   }
 }
@@ -54,7 +54,7 @@ __device__ __forceinline__ void behz_floor_sk_coeff(const DevCtx* __restrict__ c
 #pragma unroll
       for (int i = 0; i < KMAX; i++)
         if ((u32)i < K) acc += (u128)y[i] * ctx->q_to_bsk[j][i];
-      const u64 conv = reduce128(acc, pm);
+      const u64 conv = reduce128_fast(acc, pm);
       const u64 fl = mul_shoup(xb[j] + pm.q - conv, ctx->inv_q_mod_bsk[j], pm.q);
       if ((u32)j < nB) {
         if (j < KMAX + 1) yb[j < KMAX + 1 ? j : 0] = mul_shoup(fl, ctx->inv_punct_B[j], pm.q);
@@ -68,7 +68,7 @@ __device__ __forceinline__ void behz_floor_sk_coeff(const DevCtx* __restrict__ c
 #pragma unroll
   for (int j = 0; j < KMAX + 1; j++)
     if ((u32)j < nB) acc += (u128)yb[j] * ctx->B_to_msk[j];
-  const u64 alpha = mul_shoup(reduce128(acc, msk) + msk.q - fl_msk, ctx->inv_B_mod_msk, msk.q);
+  const u64 alpha = mul_shoup(reduce128_fast(acc, msk) + msk.q - fl_msk, ctx->inv_B_mod_msk, msk.q);
   const bool neg = alpha > (msk.q >> 1);
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {

@@ -416,6 +416,10 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     u64 ninv;
     if (!invm(n, p, &ninv)) return fail("n not invertible");
     dm.ninv = make_mulop(ninv, p);
+    dm.pm_c = 0;
+    if ((p >> 60) == 1 && ((1ull << 61) - p) < (1ull << 28)) dm.pm_c = (u32)((1ull << 61) - p);
+    if (const char* env = std::getenv("HIPBFV_NO_PM61"))
+      if (env[0] == '1') dm.pm_c = 0;
     dm.qd = (double)p;
     dm.qinv = 1.0 / (double)p;
     dm.ninv_d = make_mulop_d(ninv, p);

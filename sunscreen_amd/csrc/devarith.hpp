@@ -56,6 +56,22 @@ __device__ __forceinline__ u64 reduce128(u128 x, const DevMod& m) {
   return r >= m.q ? r - m.q : r;
 }
 
+// x mod (2^61 - c) for x < 2^127 and c < 2^28: 2^64 = 8c and 2^61 = c (mod q), so fold twice
+__device__ __forceinline__ u64 reduce128_pm61(u128 x, u64 q, u32 c) {
+  const u64 h = (u64)(x >> 64), l = (u64)x;
+  const u128 y = (u128)h * (u64)(c << 3) + l;                 // < 2^94 + 2^64
+  const u64 yh = (u64)(y >> 61), yl = (u64)y & ((1ull << 61) - 1);  // yh < 2^34
+  u64 z = yl + yh * (u64)c;                                   // < 2^61 + 2^62
+  z = z >= 2 * q ? z - 2 * q : z;
+  return z >= q ? z - q : z;
+}
+
+// 128-bit reduction that takes the pseudo-Mersenne shortcut when the modulus allows it (wave-uniform branch)
+__device__ __forceinline__ u64 reduce128_fast(u128 x, const DevMod& m) {
+  if (m.pm_c) return reduce128_pm61(x, m.q, m.pm_c);
+  return reduce128(x, m);
+}
+
 __device__ __forceinline__ u64 mul_mod(u64 a, u64 b, const DevMod& m) { return reduce128((u128)a * b, m); }
 
 }  // namespace hipbfv

@@ -46,7 +46,10 @@ struct DevMod {
   u32 split_inv_mask;
   u32 split_ok;          // the FP64 range plan of the split structure succeeded
   u32 ept8_ok;           // ... of the 8-elements-per-thread whole-polynomial structure (experimental fused kernel)
-  u32 pad_[3];
+  // pseudo-Mersenne form q = 2^61 - pm_c with pm_c < 2^28 (every SEAL auxiliary prime): 128-bit values are
+  // reduced by folding at bit 64 (2^64 = 8*pm_c) and at bit 61 instead of a two-word Barrett; 0 = not applicable
+  u32 pm_c;
+  u32 pad_[2];
 
   double qd;     // (double) q
   double qinv;   // 1.0 / q

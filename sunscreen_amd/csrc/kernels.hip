@@ -347,9 +347,9 @@ __global__ __launch_bounds__(kCoefThreads) void tensor_kernel(const DevCtx* __re
   u64* d = D + ((size_t)op * (sa + sb - 1)) * R * n + (size_t)r * n + k;
   if (sa == 2 && sb == 2) {
     const u64 a0 = A[0], a1 = A[(size_t)R * n], b0 = A[(size_t)2 * R * n], b1 = A[(size_t)3 * R * n];
-    d[0] = reduce128((u128)a0 * b0, pm);
-    d[(size_t)R * n] = reduce128((u128)a0 * b1 + (u128)a1 * b0, pm);
-    d[(size_t)2 * R * n] = reduce128((u128)a1 * b1, pm);
+    d[0] = reduce128_fast((u128)a0 * b0, pm);
+    d[(size_t)R * n] = reduce128_fast((u128)a0 * b1 + (u128)a1 * b0, pm);
+    d[(size_t)2 * R * n] = reduce128_fast((u128)a1 * b1, pm);
     return;
   }
   for (u32 p = 0; p + 1 < sa + sb; p++) {

@@ -46,8 +46,8 @@ struct ArithI {
   const DevMod* dm;
   __device__ __forceinline__ explicit ArithI(const DevMod& m) : q(m.q), q2(m.q << 1), dm(&m) {}
   // products of lazy operands (< 4q each): canonical results
-  __device__ __forceinline__ V mul_var(V a, V b) const { return reduce128((u128)a * b, *dm); }
-  __device__ __forceinline__ V mul_add(V a, V b, V c) const { return reduce128((u128)a * b + c, *dm); }
+  __device__ __forceinline__ V mul_var(V a, V b) const { return reduce128_fast((u128)a * b, *dm); }
+  __device__ __forceinline__ V mul_add(V a, V b, V c) const { return reduce128_fast((u128)a * b + c, *dm); }
   __device__ __forceinline__ V from_u64(u64 x) const { return x; }
   __device__ __forceinline__ V reduce(V v) const { return v; }  // lazy invariants hold without it
   // forward: X,Y in [0,4q) -> [0,4q)
