@@ -488,6 +488,15 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     h.inv_B_mod_msk = make_mulop(inv, m_sk);
   }
 
+  h.mid_nd = h.mid_ni = 0;
+  for (u32 r = 0; r < K + h.S; r++) {
+    const u32 m = r < K ? r : KK + (r - K);
+    if (h.mod[m].use_f64 && h.mod[m].split_ok)
+      h.mid_res_d[h.mid_nd++] = (unsigned char)r;
+    else
+      h.mid_res_i[h.mid_ni++] = (unsigned char)r;
+  }
+
   // ---- key switching ----
   if (KK > 1) {
     const u64 qsp = key_primes[KK - 1];

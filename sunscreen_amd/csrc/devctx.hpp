@@ -91,6 +91,11 @@ struct DevCtx {
   MulOp inv_B_mod_msk;                 // B^{-1} mod m_sk
   u64 B_mod_q[kMaxKey];                // B mod q_i
 
+  // split multiply: residue indices (0..K+S-1) handled by the FP64 / integer middle kernel
+  unsigned char mid_res_d[kMaxMod];
+  unsigned char mid_res_i[kMaxMod];
+  u32 mid_nd, mid_ni;
+
   // ---- key switching (special prime = mod[KK-1]) ----
   u64 qsp_half;                        // q_sp >> 1
   u64 qsp_half_mod_q[kMaxKey];         // (q_sp >> 1) mod q_i

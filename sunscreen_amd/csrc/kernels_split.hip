@@ -153,6 +153,12 @@ __device__ __forceinline__ void mid_inverse(const A& ar, typename A::V (&v)[kBlk
 }
 
 constexpr int kHeadThreads = 256;
+#ifndef MID_WAVES_D
+#define MID_WAVES_D 2
+#endif
+#ifndef MID_WAVES_I
+#define MID_WAVES_I 3
+#endif
 
 // -------------------------------------------------------------------------------------------------
 // key switch, head: T[op][I][J] = first three forward stages over q_I of (target_J mod q_I)
@@ -508,11 +514,13 @@ __device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A:
   inv_store(a1, 2);
 }
 
-// grid: ops * R * NBLK workgroups of TPB threads; D = [ops][3][R][N] native representation
-template <int L>
-__global__ __launch_bounds__((SplitShape<L>::TPB), 3) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
-                                                                        const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
-                                                                        u64* __restrict__ D) {
+// grid: ops * nres * NBLK workgroups of TPB threads; D = [ops][3][R][N] native representation.
+// Two instantiations (separate register allocations): FP64 residues (r in [0, K)) and integer residues.
+// POLICY_D selects which residues this launch handles: r0 = first residue, nres = number of residues.
+template <int L, bool POLICY_D>
+__global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D : MID_WAVES_I)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+                                                                           const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
+                                                                           u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres) {
   using Sh = SplitShape<L>;
   __shared__ u64 smem[Sh::BLOCK];
   __shared__ u64 park[Sh::BLOCK];
@@ -520,8 +528,8 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 3) void mul_mid_kernel(const 
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   const u32 b = blockIdx.x;
   const u32 blk = b % Sh::NBLK;
-  const u32 r = (b / Sh::NBLK) % R;
-  const u32 op = b / (Sh::NBLK * R);
+  const u32 r = residues[(b / Sh::NBLK) % nres];
+  const u32 op = b / (Sh::NBLK * nres);
   const u32 m = r < K ? r : KK + (r - K);
   const DevMod& dm = ctx->mod[m];
   const u64* ext_r = ext + ((size_t)op * 4 * R + r) * Sh::N;
@@ -529,7 +537,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 3) void mul_mid_kernel(const 
   const size_t ps = (size_t)R * Sh::N;
   const MulOp* twf = twf_base + (size_t)m * Sh::N;
   const MulOp* twi = twi_base + (size_t)m * Sh::N;
-  if (residue_is_f64(dm))
+  if constexpr (POLICY_D)
     mul_mid_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                             reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                             reinterpret_cast<double*>(smem), reinterpret_cast<double*>(park), tid, blk);
@@ -664,13 +672,17 @@ hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, const 
 }
 
 template <int L>
-static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 R, const u64* ext, u64* D, size_t ops, hipStream_t s) {
+static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, const unsigned char* res_d, u32 nd, const unsigned char* res_i,
+                            u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s) {
   using Sh = SplitShape<L>;
-  mul_mid_kernel<L><<<dim3((unsigned)(ops * R * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D);
+  if (nd) mul_mid_kernel<L, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+  if (ni) mul_mid_kernel<L, false><<<dim3((unsigned)(ops * ni * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
   return hipGetLastError();
 }
-hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 R, const u64* ext, u64* D, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mul_mid_t, ctx, twf, twi, R, ext, D, ops, s)
+// res_d / res_i: device arrays listing the residue indices (0..R-1) handled by the FP64 / integer instantiation
+hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, const unsigned char* res_d, u32 nd,
+                          const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mul_mid_t, ctx, twf, twi, res_d, nd, res_i, ni, ext, D, ops, s)
 }
 
 template <int L>
