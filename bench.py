@@ -176,12 +176,17 @@ def main():
     if dom:
         name, rec = dom
         # algorithmic bytes of one launch of that kernel
+        S_, R_ = ctx_S(ctx), K + ctx_S(ctx)
         per_unit = {
+            # whole-polynomial path (kernels.hip)
             "ntt_fwd": 16 * n, "ntt_inv": 16 * n,                    # per residue polynomial: read + write
-            "behz_extend": 8 * n * (K + (K + ctx_S(ctx))),           # per polynomial: read K, write K+S residues
-            "tensor": 8 * n * 7 * (K + ctx_S(ctx)),                  # per op: read 4, write 3 extended polys
-            "behz_floor_sk": 8 * n * ((K + ctx_S(ctx)) + K),         # per polynomial
+            "behz_extend": 8 * n * (K + R_),                         # per polynomial: read K, write K+S residues
+            "tensor": 8 * n * 7 * R_,                                # per op: read 4, write 3 extended polys
+            "behz_floor_sk": 8 * n * (R_ + K),                       # per polynomial
             "ks_decompose": 8 * n * (K + KK * K), "ks_mac": 8 * n * (KK * K + 2 * KK), "ks_moddown": 8 * n * (2 * KK + 4 * K),
+            # split path (kernels_split.hip); units: polynomials for mul_head / mul_tail, ops otherwise
+            "mul_head": 8 * n * (K + R_), "mul_mid": 8 * n * 7 * R_, "mul_tail": 8 * n * (R_ + K),
+            "ks_head": 8 * n * (K + KK * K), "ks_mid": 8 * n * (KK * K + 2 * KK), "ks_tail": 8 * n * (2 * KK + 4 * K),
         }.get(name, 16 * n)
         avg_ms = rec["ms"] / rec["launches"]
         bytes_per_launch = per_unit * rec["units"] / rec["launches"]

