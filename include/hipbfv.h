@@ -78,6 +78,10 @@ long Plaintext_CoeffAt(void *thisptr, uint64_t index, uint64_t *coeff);
 long Plaintext_SetCoeffAt(void *thisptr, uint64_t index, uint64_t value);
 long Plaintext_Resize(void *thisptr, uint64_t coeff_count);
 long Plaintext_IsNTTForm(void *thisptr, bool *is_ntt_form);
+/* SEAL 4.0 wire format; compr_mode 0 = none, 2 = zstd (seal_fhe/src/plaintext_ciphertext.rs:100-160) */
+long Plaintext_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+long Plaintext_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
+long Plaintext_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 
 /* ---- Ciphertext (seal_fhe/src/plaintext_ciphertext.rs:326-504) ---- */
 long Ciphertext_Create1(void *pool, void **cipher);
@@ -89,11 +93,19 @@ long Ciphertext_PolyModulusDegree(void *thisptr, uint64_t *poly_modulus_degree);
 long Ciphertext_GetDataAt1(void *thisptr, uint64_t index, uint64_t *data);
 long Ciphertext_GetDataAt2(void *thisptr, uint64_t poly_index, uint64_t coeff_index, uint64_t *data);
 long Ciphertext_IsNTTForm(void *thisptr, bool *is_ntt_form);
+/* SEAL 4.0 wire format (seal_fhe/src/plaintext_ciphertext.rs:451-497) */
+long Ciphertext_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+long Ciphertext_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
+long Ciphertext_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 
 /* ---- KSwitchKeys: RelinKeys and GaloisKeys (seal_fhe/src/key_generator.rs:467-729) ---- */
 long KSwitchKeys_Create1(void **kswitch_keys);
 long KSwitchKeys_Create2(void *copy, void **kswitch_keys);
 long KSwitchKeys_Destroy(void *thisptr);
+/* SEAL 4.0 wire format (seal_fhe/src/key_generator.rs:493-573, 649-729) */
+long KSwitchKeys_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+long KSwitchKeys_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
+long KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 
 /* ---- Evaluator (seal_fhe/src/evaluator_base.rs:55-407, bfv_evaluator.rs:12-248) ---- */
 long Evaluator_Create(void *seal_context, void **evaluator);
@@ -139,6 +151,19 @@ long hipbfv_Ciphertext_DevicePtr(void *cipher, uint64_t **device_ptr);
 long hipbfv_KSwitchKeys_AssignRelin(void *keys, void *context, const uint64_t *host_data);
 long hipbfv_KSwitchKeys_AssignGalois(void *keys, void *context, uint32_t galois_elt, const uint64_t *host_data);
 long hipbfv_KSwitchKeys_DevicePtr(void *keys, uint64_t index, uint64_t **device_ptr); /* index 0 = relin, (elt-1)/2 = galois */
+
+/* Host-only helpers of the SEAL 4.0 wire format (no device access; used by the CPU tests against the
+ * reference's binary fixtures): parms_id = BLAKE2b-256([scheme=1, n, primes..., t]); decode/encode one object. */
+long hipbfv_wire_parms_id(uint64_t poly_modulus_degree, const uint64_t *primes, uint64_t count, uint64_t plain_modulus,
+                          uint8_t *out32);
+long hipbfv_wire_decode_ciphertext(const uint8_t *in, uint64_t in_size, uint8_t *parms_id32, bool *is_ntt, uint64_t *size,
+                                   uint64_t *poly_modulus_degree, uint64_t *coeff_modulus_size, uint64_t *data,
+                                   uint64_t capacity_words, int64_t *in_bytes);
+long hipbfv_wire_encode_ciphertext(const uint8_t *parms_id32, bool is_ntt, uint64_t size, uint64_t poly_modulus_degree,
+                                   uint64_t coeff_modulus_size, const uint64_t *data, uint8_t compr_mode, uint8_t *out,
+                                   uint64_t capacity, int64_t *out_bytes);
+long hipbfv_wire_decode_plaintext(const uint8_t *in, uint64_t in_size, uint8_t *parms_id32, uint64_t *coeff_count,
+                                  uint64_t *coeffs, uint64_t capacity_words, int64_t *in_bytes);
 
 /* Batched entry points: device pointers, `count` independent ciphertexts u64[count][size][K][N],
  * enqueued asynchronously on `stream` (a hipStream_t; NULL = default stream). */

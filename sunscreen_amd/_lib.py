@@ -63,6 +63,19 @@ _SIGNATURES = {
     "Ciphertext_GetDataAt1": [vp, u64, u64p],
     "Ciphertext_GetDataAt2": [vp, u64, u64, u64p],
     "Ciphertext_IsNTTForm": [vp, C.POINTER(C.c_bool)],
+    "Plaintext_SaveSize": [vp, C.c_uint8, C.POINTER(C.c_int64)],
+    "Plaintext_Save": [vp, C.c_char_p, u64, C.c_uint8, C.POINTER(C.c_int64)],
+    "Plaintext_Load": [vp, vp, C.c_char_p, u64, C.POINTER(C.c_int64)],
+    "Ciphertext_SaveSize": [vp, C.c_uint8, C.POINTER(C.c_int64)],
+    "Ciphertext_Save": [vp, C.c_char_p, u64, C.c_uint8, C.POINTER(C.c_int64)],
+    "Ciphertext_Load": [vp, vp, C.c_char_p, u64, C.POINTER(C.c_int64)],
+    "KSwitchKeys_SaveSize": [vp, C.c_uint8, C.POINTER(C.c_int64)],
+    "KSwitchKeys_Save": [vp, C.c_char_p, u64, C.c_uint8, C.POINTER(C.c_int64)],
+    "KSwitchKeys_Load": [vp, vp, C.c_char_p, u64, C.POINTER(C.c_int64)],
+    "hipbfv_wire_parms_id": [u64, u64p, u64, u64, C.c_char_p],
+    "hipbfv_wire_decode_ciphertext": [C.c_char_p, u64, C.c_char_p, C.POINTER(C.c_bool), u64p, u64p, u64p, u64p, u64, C.POINTER(C.c_int64)],
+    "hipbfv_wire_encode_ciphertext": [C.c_char_p, C.c_bool, u64, u64, u64, u64p, C.c_uint8, C.c_char_p, u64, C.POINTER(C.c_int64)],
+    "hipbfv_wire_decode_plaintext": [C.c_char_p, u64, C.c_char_p, u64p, u64p, u64, C.POINTER(C.c_int64)],
     "KSwitchKeys_Create1": [vpp],
     "KSwitchKeys_Create2": [vp, vpp],
     "KSwitchKeys_Destroy": [vp],

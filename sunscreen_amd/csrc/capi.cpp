@@ -17,6 +17,7 @@
 
 #include "evaluator.hpp"
 #include "program.hpp"
+#include "wire.hpp"
 
 using namespace hipbfv;
 
@@ -1209,6 +1210,226 @@ long hipbfv_batch_ntt(void* h, uint64_t* data, uint64_t polys, uint64_t nprimes,
   EVAL_OR_RETURN(h);
   if (!data) return HIPBFV_E_POINTER;
   return from_status(e->ev->ntt((u64*)data, polys, (u32)nprimes, inverse, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------ SEAL 4.0 wire format (wire.cpp)
+static long from_wire(int rc) {
+  switch (rc) {
+    case kWireOk: return HIPBFV_S_OK;
+    case kWireBadArg: return fail(HIPBFV_E_INVALIDARG, "unsupported compression mode");
+    case kWireNoZstd: return fail(HIPBFV_COR_E_IO, "libzstd.so.1 is not available: only compr_mode 0 (none) can be used");
+    default: return fail(HIPBFV_COR_E_IO, "malformed or truncated SEAL object");
+  }
+}
+
+static void data_level_parms_id(const Context& c, uint8_t out[32]) { seal_parms_id(c.n(), c.key_primes().data(), c.K(), c.t(), out); }
+static void key_level_parms_id(const Context& c, uint8_t out[32]) { seal_parms_id(c.n(), c.key_primes().data(), c.KK(), c.t(), out); }
+
+long hipbfv_wire_parms_id(uint64_t n, const uint64_t* primes, uint64_t count, uint64_t plain_modulus, uint8_t* out32) {
+  if (!primes || !out32) return HIPBFV_E_POINTER;
+  seal_parms_id(n, reinterpret_cast<const unsigned long long*>(primes), count, plain_modulus, out32);
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_wire_decode_ciphertext(const uint8_t* in, uint64_t in_size, uint8_t* parms_id32, bool* is_ntt, uint64_t* size, uint64_t* n,
+                                   uint64_t* k, uint64_t* data, uint64_t capacity_words, int64_t* in_bytes) {
+  if (!in) return HIPBFV_E_POINTER;
+  WireCiphertext ct;
+  size_t used = 0;
+  if (int rc = wire_unpack_ciphertext(in, in_size, &ct, &used)) return from_wire(rc);
+  if (parms_id32) std::memcpy(parms_id32, ct.parms_id, 32);
+  if (is_ntt) *is_ntt = ct.is_ntt;
+  if (size) *size = ct.size;
+  if (n) *n = ct.n;
+  if (k) *k = ct.k;
+  if (in_bytes) *in_bytes = (int64_t)used;
+  if (data) {
+    if (capacity_words < ct.data.size()) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
+    std::memcpy(data, ct.data.data(), ct.data.size() * 8);
+  }
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_wire_encode_ciphertext(const uint8_t* parms_id32, bool is_ntt, uint64_t size, uint64_t n, uint64_t k, const uint64_t* data,
+                                   uint8_t compr_mode, uint8_t* out, uint64_t capacity, int64_t* out_bytes) {
+  if (!parms_id32 || !data || !out_bytes) return HIPBFV_E_POINTER;
+  std::vector<uint8_t> buf;
+  if (int rc = wire_pack_ciphertext(parms_id32, is_ntt, size, n, k, reinterpret_cast<const unsigned long long*>(data), compr_mode, &buf)) return from_wire(rc);
+  *out_bytes = (int64_t)buf.size();
+  if (!out) return HIPBFV_S_OK;  // size query
+  if (capacity < buf.size()) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
+  std::memcpy(out, buf.data(), buf.size());
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_wire_decode_plaintext(const uint8_t* in, uint64_t in_size, uint8_t* parms_id32, uint64_t* coeff_count, uint64_t* coeffs,
+                                  uint64_t capacity_words, int64_t* in_bytes) {
+  if (!in) return HIPBFV_E_POINTER;
+  WirePlaintext pt;
+  size_t used = 0;
+  if (int rc = wire_unpack_plaintext(in, in_size, &pt, &used)) return from_wire(rc);
+  if (parms_id32) std::memcpy(parms_id32, pt.parms_id, 32);
+  if (coeff_count) *coeff_count = pt.coeffs.size();
+  if (in_bytes) *in_bytes = (int64_t)used;
+  if (coeffs) {
+    if (capacity_words < pt.coeffs.size()) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
+    std::memcpy(coeffs, pt.coeffs.data(), pt.coeffs.size() * 8);
+  }
+  return HIPBFV_S_OK;
+}
+
+// upper bound of the serialised size, like SEAL's save_size()
+long Ciphertext_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !result) return HIPBFV_E_POINTER;
+  const size_t raw = 16 + 32 + 1 + 8 * 5 + 16 + 8 + c->words * 8;
+  *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  if (!c || !outptr || !out_bytes) return HIPBFV_E_POINTER;
+  if (!c->ctx || !c->dev) return fail(HIPBFV_E_INVALIDARG, "ciphertext is empty");
+  long hr = ensure_host(c);
+  if (hr != HIPBFV_S_OK) return hr;
+  uint8_t pid[32];
+  data_level_parms_id(*c->ctx, pid);
+  std::vector<uint8_t> buf;
+  if (int rc = wire_pack_ciphertext(pid, false, c->size, c->ctx->n(), c->ctx->K(), c->host.data(), compr_mode, &buf)) return from_wire(rc);
+  if (size < buf.size()) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
+  std::memcpy(outptr, buf.data(), buf.size());
+  *out_bytes = (int64_t)buf.size();
+  return HIPBFV_S_OK;
+}
+
+long Ciphertext_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+  CipherObj* c = as<CipherObj>(h, kMagicCipher);
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!c || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
+  WireCiphertext ct;
+  size_t used = 0;
+  if (int rc = wire_unpack_ciphertext(inptr, size, &ct, &used)) return from_wire(rc);
+  uint8_t pid[32];
+  data_level_parms_id(*x->ctx, pid);
+  if (std::memcmp(pid, ct.parms_id, 32) != 0 || ct.is_ntt || ct.n != x->ctx->n() || ct.k != x->ctx->K() || ct.size < 2)
+    return fail(HIPBFV_E_INVALIDARG, "ciphertext data is invalid for the encryption parameters");
+  long hr = hipbfv_Ciphertext_Assign(h, context, ct.size, reinterpret_cast<const uint64_t*>(ct.data.data()));
+  if (hr != HIPBFV_S_OK) return hr;
+  *in_bytes = (int64_t)used;
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+  PlainObj* p = as<PlainObj>(h, kMagicPlain);
+  if (!p || !result) return HIPBFV_E_POINTER;
+  const size_t raw = 16 + 32 + 16 + 16 + 8 + p->coeffs.size() * 8;
+  *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+  PlainObj* p = as<PlainObj>(h, kMagicPlain);
+  if (!p || !outptr || !out_bytes) return HIPBFV_E_POINTER;
+  const uint8_t zero[32] = {0};  // BFV plaintexts in coefficient form carry parms_id_zero
+  std::vector<uint8_t> buf;
+  if (int rc = wire_pack_plaintext(zero, p->coeffs.data(), p->coeffs.size(), compr_mode, &buf)) return from_wire(rc);
+  if (size < buf.size()) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
+  std::memcpy(outptr, buf.data(), buf.size());
+  *out_bytes = (int64_t)buf.size();
+  return HIPBFV_S_OK;
+}
+
+long Plaintext_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+  PlainObj* p = as<PlainObj>(h, kMagicPlain);
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!p || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
+  WirePlaintext pt;
+  size_t used = 0;
+  if (int rc = wire_unpack_plaintext(inptr, size, &pt, &used)) return from_wire(rc);
+  const uint8_t zero[32] = {0};
+  if (std::memcmp(pt.parms_id, zero, 32) != 0) return fail(HIPBFV_E_INVALIDARG, "NTT-form plaintexts are not used by BFV evaluation");
+  if (pt.coeffs.size() > x->ctx->n()) return fail(HIPBFV_E_INVALIDARG, "plaintext data is invalid for the encryption parameters");
+  for (u64 v : pt.coeffs)
+    if (v >= x->ctx->t()) return fail(HIPBFV_E_INVALIDARG, "plaintext data is invalid for the encryption parameters");
+  p->coeffs = pt.coeffs;
+  *in_bytes = (int64_t)used;
+  return HIPBFV_S_OK;
+}
+
+static long keys_to_host(KeysObj* k, std::vector<std::vector<u64>>* host, std::vector<std::vector<const u64*>>* ptrs) {
+  const size_t KK = k->ctx->KK(), K = k->ctx->K(), n = k->ctx->n();
+  u32 max_index = 0;
+  for (auto& kv : k->keys) max_index = std::max(max_index, kv.first);
+  ptrs->assign(k->keys.empty() ? 0 : max_index + 1, {});
+  for (auto& kv : k->keys) {
+    host->emplace_back(k->ctx->key_words());
+    std::vector<u64>& buf = host->back();
+    if (hipMemcpy(buf.data(), kv.second, buf.size() * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return from_status(kHipError);
+    for (size_t J = 0; J < K; J++) (*ptrs)[kv.first].push_back(buf.data() + J * 2 * KK * n);
+  }
+  return HIPBFV_S_OK;
+}
+
+long KSwitchKeys_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+  KeysObj* k = as<KeysObj>(h, kMagicKeys);
+  if (!k || !result) return HIPBFV_E_POINTER;
+  size_t raw = 16 + 32 + 8;
+  if (k->ctx) {
+    u32 max_index = 0;
+    for (auto& kv : k->keys) max_index = std::max(max_index, kv.first);
+    raw += 8 * (size_t)(max_index + 1);
+    raw += k->keys.size() * k->ctx->K() * (16 + 32 + 1 + 40 + 24 + 2 * k->ctx->KK() * k->ctx->n() * 8);
+  }
+  *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
+  return HIPBFV_S_OK;
+}
+
+long KSwitchKeys_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+  KeysObj* k = as<KeysObj>(h, kMagicKeys);
+  if (!k || !outptr || !out_bytes) return HIPBFV_E_POINTER;
+  if (!k->ctx) return fail(HIPBFV_E_INVALIDARG, "keys are empty");
+  std::vector<std::vector<u64>> host;
+  host.reserve(k->keys.size());
+  std::vector<std::vector<const u64*>> ptrs;
+  long hr = keys_to_host(k, &host, &ptrs);
+  if (hr != HIPBFV_S_OK) return hr;
+  uint8_t pid[32];
+  key_level_parms_id(*k->ctx, pid);
+  std::vector<uint8_t> buf;
+  if (int rc = wire_pack_kswitch(pid, k->ctx->n(), k->ctx->KK(), ptrs, compr_mode, &buf)) return from_wire(rc);
+  if (size < buf.size()) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
+  std::memcpy(outptr, buf.data(), buf.size());
+  *out_bytes = (int64_t)buf.size();
+  return HIPBFV_S_OK;
+}
+
+long KSwitchKeys_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+  KeysObj* k = as<KeysObj>(h, kMagicKeys);
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!k || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
+  WireKSwitchKeys ks;
+  size_t used = 0;
+  if (int rc = wire_unpack_kswitch(inptr, size, &ks, &used)) return from_wire(rc);
+  uint8_t pid[32];
+  key_level_parms_id(*x->ctx, pid);
+  if (std::memcmp(pid, ks.parms_id, 32) != 0) return fail(HIPBFV_E_INVALIDARG, "keys are invalid for the encryption parameters");
+  const size_t KK = x->ctx->KK(), K = x->ctx->K(), n = x->ctx->n();
+  std::vector<u64> flat(x->ctx->key_words());
+  for (size_t index = 0; index < ks.keys.size(); index++) {
+    const auto& entry = ks.keys[index];
+    if (entry.empty()) continue;
+    if (entry.size() != K) return fail(HIPBFV_E_INVALIDARG, "keys are invalid for the encryption parameters");
+    for (size_t J = 0; J < K; J++) {
+      const WireCiphertext& pk = entry[J];
+      if (!pk.is_ntt || pk.size != 2 || pk.n != n || pk.k != KK) return fail(HIPBFV_E_INVALIDARG, "keys are invalid for the encryption parameters");
+      std::memcpy(flat.data() + J * 2 * KK * n, pk.data.data(), 2 * KK * n * 8);
+    }
+    long hr = assign_key(k, x, (u32)index, reinterpret_cast<const uint64_t*>(flat.data()));
+    if (hr != HIPBFV_S_OK) return hr;
+  }
+  *in_bytes = (int64_t)used;
+  return HIPBFV_S_OK;
 }
 
 // ------------------------------------------------------------------ program graphs (batch executor)

@@ -288,6 +288,22 @@ class Plaintext:
         _check(_lib.load().Plaintext_IsNTTForm(self._h, C.byref(v)))
         return v.value
 
+    def as_bytes(self, compression: int = 2) -> bytes:
+        L = _lib.load()
+        size = C.c_int64()
+        _check(L.Plaintext_SaveSize(self._h, compression, C.byref(size)))
+        buf = C.create_string_buffer(size.value)
+        written = C.c_int64()
+        _check(L.Plaintext_Save(self._h, buf, size.value, compression, C.byref(written)))
+        return buf.raw[: written.value]
+
+    @classmethod
+    def from_bytes(cls, ctx: "Context", data: bytes) -> "Plaintext":
+        p = cls()
+        read = C.c_int64()
+        _check(_lib.load().Plaintext_Load(p._h, ctx.get_handle(), data, len(data), C.byref(read)))
+        return p
+
     def __del__(self):
         if getattr(self, "_h", None):
             _lib.load().Plaintext_Destroy(self._h)
@@ -356,6 +372,24 @@ class Ciphertext:
         _check(_lib.load().Ciphertext_IsNTTForm(self._h, C.byref(v)))
         return v.value
 
+    def as_bytes(self, compression: int = 2) -> bytes:
+        """SEAL 4.0 wire format, zstd by default (seal_fhe/src/plaintext_ciphertext.rs:451-477)."""
+        L = _lib.load()
+        size = C.c_int64()
+        _check(L.Ciphertext_SaveSize(self._h, compression, C.byref(size)))
+        buf = C.create_string_buffer(size.value)
+        written = C.c_int64()
+        _check(L.Ciphertext_Save(self._h, buf, size.value, compression, C.byref(written)))
+        return buf.raw[: written.value]
+
+    @classmethod
+    def from_bytes(cls, ctx: "Context", data: bytes) -> "Ciphertext":
+        """seal_fhe/src/plaintext_ciphertext.rs:479-497"""
+        c = cls()
+        read = C.c_int64()
+        _check(_lib.load().Ciphertext_Load(c._h, ctx.get_handle(), data, len(data), C.byref(read)))
+        return c
+
     def __del__(self):
         if getattr(self, "_h", None):
             _lib.load().Ciphertext_Destroy(self._h)
@@ -374,6 +408,27 @@ class _KSwitchKeys:
         if getattr(self, "_h", None):
             _lib.load().KSwitchKeys_Destroy(self._h)
             self._h = None
+
+
+def _keys_as_bytes(self, compression: int = 2) -> bytes:
+    L = _lib.load()
+    size = C.c_int64()
+    _check(L.KSwitchKeys_SaveSize(self._h, compression, C.byref(size)))
+    buf = C.create_string_buffer(size.value)
+    written = C.c_int64()
+    _check(L.KSwitchKeys_Save(self._h, buf, size.value, compression, C.byref(written)))
+    return buf.raw[: written.value]
+
+
+def _keys_from_bytes(cls, ctx: "Context", data: bytes):
+    k = cls()
+    read = C.c_int64()
+    _check(_lib.load().KSwitchKeys_Load(k._h, ctx.get_handle(), data, len(data), C.byref(read)))
+    return k
+
+
+_KSwitchKeys.as_bytes = _keys_as_bytes
+_KSwitchKeys.from_bytes = classmethod(_keys_from_bytes)
 
 
 class RelinearizationKeys(_KSwitchKeys):

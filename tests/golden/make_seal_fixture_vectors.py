@@ -5,7 +5,8 @@ Input  (read-only, only present in the build container):
     /root/reference/seal_fhe/tests/data/secret_key.bin   (SEAL 4.0 SecretKey, zstd)
     /root/reference/seal_fhe/tests/data/public_key.bin   (SEAL 4.0 PublicKey, zstd)
   loaded by the reference's `deterministic` test seal_fhe/src/encryptor_decryptor.rs:886-933 with
-  parameters n=8192, CoeffModulus::create(8192,[50,30,30,50,50]), PlainModulus::batching(8192,32).
+  parameters n=8192, CoeffModulus::create(8192,[50,30,30,50,50]), PlainModulus::batching(8192,20)
+  (the key material does not depend on the plain modulus; only the parms_id in the header does).
 
 Output: tests/golden/seal_key_fixture.npz  (a few KB) holding
     primes        the five key-level primes

@@ -290,3 +290,45 @@ def test_handle_level_api_mirrors_seal_fhe():
     assert ei.value.kind == "InvalidArgument"
     with pytest.raises(HipBfvError):
         ev.relinearize(ev.multiply(m, a), rkd)  # size 4: "not enough relinearization keys"
+
+
+def test_wire_format_roundtrip_on_handles():
+    """Ciphertext / RelinKeys / GaloisKeys / Plaintext through the SEAL 4.0 wire format (zstd and uncompressed):
+    as_bytes -> from_bytes reproduces the object and the evaluator accepts it (plaintext_ciphertext.rs:451-497,
+    key_generator.rs:493-573)."""
+    from sunscreen_amd import BFVEvaluator, Ciphertext, Context, GaloisKeys, HipBfvError, Plaintext, RelinearizationKeys
+
+    n, primes, t = params("default_4096_16")
+    o = oracle_for("default_4096_16")
+    O.seed(41)
+    sk, pk, rk, gk = o.keygen(galois_elts=[3, 2 * n - 1])
+    ctx = Context.from_raw(n, primes, t)
+    ev = BFVEvaluator(ctx)
+    rng = np.random.default_rng(1)
+    va = rng.integers(0, 50, n).astype(np.uint64)
+    a_np = o.encrypt(pk, o.batch_encode(va))
+    a = Ciphertext.from_array(ctx, a_np)
+    for compr in (0, 2):
+        blob = a.as_bytes(compr)
+        assert blob[:5] == bytes([0x5E, 0xA1, 16, 4, 0]) and blob[5] == compr
+        assert int.from_bytes(blob[8:16], "little") == len(blob)
+        b = Ciphertext.from_bytes(ctx, blob)
+        assert (b.to_array() == a_np).all() and b.num_polynomials() == 2
+    rkd = RelinearizationKeys.from_bytes(ctx, RelinearizationKeys.from_array(ctx, rk).as_bytes())
+    gkd = GaloisKeys.from_bytes(ctx, GaloisKeys.from_arrays(ctx, gk).as_bytes(0))
+    m = ev.relinearize(ev.multiply(a, a), rkd)
+    assert (m.to_array() == o.relinearize(o.multiply(a_np, a_np), rk)).all()
+    r = ev.rotate_rows(m, 1, gkd)
+    assert (r.to_array() == o.rotate_rows(o.relinearize(o.multiply(a_np, a_np), rk), 1, gk)).all()
+    c = ev.rotate_columns(a, gkd)
+    assert (c.to_array() == o.rotate_columns(a_np, gk)).all()
+    p = Plaintext.from_coefficients([1, 2, 3, 0, 5])
+    q = Plaintext.from_bytes(ctx, p.as_bytes())
+    assert q.len() == 5 and [q.get_coefficient(i) for i in range(5)] == [1, 2, 3, 0, 5]
+    # a ciphertext of other parameters is rejected (parms_id mismatch)
+    other = Context.from_raw(n, primes, O.plain_batching(n, 17))
+    with pytest.raises(HipBfvError) as ei:
+        Ciphertext.from_bytes(other, a.as_bytes())
+    assert ei.value.kind == "InvalidArgument"
+    with pytest.raises(HipBfvError):
+        Ciphertext.from_bytes(ctx, a.as_bytes()[:-5])
