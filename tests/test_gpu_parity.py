@@ -332,3 +332,56 @@ def test_wire_format_roundtrip_on_handles():
     assert ei.value.kind == "InvalidArgument"
     with pytest.raises(HipBfvError):
         Ciphertext.from_bytes(ctx, a.as_bytes()[:-5])
+
+
+@pytest.mark.parametrize(
+    "n,bits,tbits",
+    [
+        (2048, [54], 14),            # single prime, no special prime: multiply works, key switching does not
+        (1024, [27], 0),             # smallest supported degree, non-batching plain modulus
+        (4096, [58, 59, 60], 16),    # wide user primes: integer path everywhere (no FP64), generic Barrett
+        (8192, [36, 36, 37, 38], 20),  # K = 3
+        (16384, [40, 40, 40, 40, 40, 41], 17),  # K = 5 > 4: whole-polynomial multiply + split key switch
+    ],
+)
+def test_multiply_edge_parameter_sets(n, bits, tbits):
+    from sunscreen_amd import Context, HipBfvError, RelinearizationKeys
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    primes = O.coeff_modulus_create(n, bits)
+    t = O.plain_batching(n, tbits) if tbits else 64
+    o = O.Oracle(n, primes, t)
+    O.seed(n + len(bits))
+    sk, pk, rk, _ = o.keygen()
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    rng = np.random.default_rng(n)
+    msgs = rng.integers(0, min(t, 16), (2, 2, n)).astype(np.uint64)
+    a = np.stack([o.encrypt(pk, msgs[0, i]) for i in range(2)])
+    b = np.stack([o.encrypt(pk, msgs[1, i]) for i in range(2)])
+    m = to_host(ev.multiply(to_device(a), to_device(b)))
+    for i in range(2):
+        assert (m[i] == o.multiply(a[i], b[i])).all()
+    if rk is not None:
+        rkd = RelinearizationKeys.from_array(ctx, rk)
+        r = to_host(ev.multiply_relin(to_device(a), to_device(b), rkd))
+        for i in range(2):
+            assert (r[i] == o.relinearize(o.multiply(a[i], b[i]), rk)).all()
+    else:
+        with pytest.raises(HipBfvError):
+            RelinearizationKeys.from_array(ctx, np.zeros((1, 2, 1, n), dtype=np.uint64))
+
+
+def test_unsupported_degree_is_reported():
+    from sunscreen_amd import Context, HipBfvError
+    from sunscreen_amd.batch import BatchEvaluator
+
+    n = 32768
+    ctx = Context.from_raw(n, O.bfv_default(n), O.plain_batching(n, 17))
+    ev = BatchEvaluator(ctx)
+    import torch
+
+    x = torch.zeros((1, 2, ctx.K, n), dtype=torch.int64, device="cuda:0")
+    with pytest.raises(HipBfvError) as ei:
+        ev.multiply(x, x)
+    assert ei.value.kind == "InternalError"  # COR_E_INVALIDOPERATION: N = 32768 needs the two-kernel NTT
