@@ -177,7 +177,7 @@ bool plan_f64_path(u64 q, int logn, int ept, u32* fwd_mask, u32* inv_mask) {
 
 // Same growth simulation for the split (head / middle / tail) structure of nttshape.hpp.
 bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
-  if (q >= (1ull << 50) || !split_supported(logn)) return false;
+  if (q >= (1ull << 50) || logn < 12 || logn > 15) return false;
   const double limit = 0.98 * 9007199254740992.0 / (double)q;
   const double eps = (double)q / 4503599627370496.0;
   {  // forward: head does kHeadLog stages from canonical input, then the middle passes

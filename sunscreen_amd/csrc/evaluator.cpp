@@ -205,7 +205,7 @@ u32 Evaluator::galois_elt_from_step(int step) const {
 int Evaluator::ntt(u64* data, size_t polys, u32 nprimes, bool inverse, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (nprimes == 0 || nprimes > h.KK) return kInvalidArg;
-  if (h.logn > 14) return kUnsupported;
+  if (h.logn > 15) return kUnsupported;
   std::vector<u32> mods(nprimes);
   for (u32 i = 0; i < nprimes; i++) mods[i] = i;
   const NttPlan plan = make_plan(1, mods);
@@ -220,7 +220,7 @@ int Evaluator::ntt(u64* data, size_t polys, u32 nprimes, bool inverse, hipStream
 int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, size_t count, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (sa < 2 || sb < 2 || sa + sb > 16) return kInvalidArg;
-  if (h.logn > 14) return kUnsupported;
+  if (h.logn > 15) return kUnsupported;
   const u32 n = h.n, K = h.K, S = h.S, R = K + S, sd = sa + sb - 1;
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / (R * (sa + sb))));
   const size_t ext_words = (size_t)(sa + sb) * R * n, d_words = (size_t)sd * R * n;
@@ -293,7 +293,7 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
 int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (h.KK < 2 || !rk) return kNoKey;
-  if (h.logn > 14) return kUnsupported;
+  if (h.logn > 15) return kUnsupported;
   const u32 n = h.n, K = h.K;
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / ((size_t)h.KK * K)));
   ScratchGuard sg(pool_, chunk * ks_scratch_words() * sizeof(u64), s);
@@ -372,7 +372,7 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, 
   const u32 n = h.n, K = h.K;
   if (!(elt & 1) || elt >= 2 * n) return kInvalidArg;
   if (h.KK < 2 || !key) return kNoKey;
-  if (h.logn > 14) return kUnsupported;
+  if (h.logn > 15) return kUnsupported;
   // g^{-1} mod 2n (Newton iteration, g odd)
   u64 inv = 1;
   for (int i = 0; i < 6; i++) inv = inv * (2 - (u64)elt * inv);
@@ -439,7 +439,7 @@ int Evaluator::sub_plain(const u64* ct, u32 size, const u64* plain, size_t pstri
 int Evaluator::multiply_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (size < 2) return kInvalidArg;
-  if (h.logn > 14) return kUnsupported;
+  if (h.logn > 15) return kUnsupported;
   const u32 n = h.n, K = h.K;
   const size_t cs = ctx_->ct_words(size);
   const bool shared = pstride == 0;

@@ -294,6 +294,7 @@ hipError_t launch_ntt(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, s
     case 12: return launch_ntt_t<12>(ctx, tw, data, polys, plan, inverse, scale_mode, s);
     case 13: return launch_ntt_t<13>(ctx, tw, data, polys, plan, inverse, scale_mode, s);
     case 14: return launch_ntt_t<14>(ctx, tw, data, polys, plan, inverse, scale_mode, s);
+    case 15: return launch_ntt_split(ctx, tw, logn, data, polys, plan, inverse, scale_mode, s);  // 256 KB polynomials: two kernels
     default: return hipErrorInvalidValue;
   }
 }

@@ -23,6 +23,9 @@ hipError_t launch_ks_decompose(const DevCtx* ctx, u32 n, u32 K, const u64* targe
 hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s);
 hipError_t launch_ks_fused(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 KK, const u64* target, size_t tstride, const u64* key, u64* ACC, size_t ops,
                            hipStream_t s);
+// two-kernel stand-alone transforms for N = 32768 (kernels_split.hip)
+hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse,
+                            int scale_mode, hipStream_t s);
 // split (head / middle / tail) key switch, kernels_split.hip
 hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
 hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops,

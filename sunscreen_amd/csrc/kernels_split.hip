@@ -617,6 +617,172 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
   }
 }
 
+// =================================================================================================
+// Stand-alone two-kernel transforms for N = 32768, whose 256 KB residue polynomials do not fit one CU's LDS:
+// forward = head stages (streaming) + block-local rest; inverse = block-local stages + tail stages (streaming).
+// The intermediate lives in place in the data buffer, in the policy's native representation.
+// =================================================================================================
+__device__ __forceinline__ u32 plan_mod_split(const NttPlan& plan, u32 poly) { return plan.mod[(poly / plan.div) % plan.period]; }
+
+// grid (N/8/256, polys)
+template <int L>
+__global__ __launch_bounds__(kHeadThreads) void ntt_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base, u64* data,
+                                                                NttPlan plan) {
+  constexpr u32 N = 1u << L, Q = N >> kHeadLog;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 poly = blockIdx.y;
+  const u32 m = plan_mod_split(plan, poly);
+  const DevMod& dm = ctx->mod[m];
+  u64* x = data + (size_t)poly * N + t;
+  const MulOp* tw = twf_base + (size_t)m * N;
+  if (residue_is_f64(dm)) {
+    const ArithD ar(dm);
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ar.from_u64(x[(size_t)k * Q]);
+    head_fwd8(ar, v, reinterpret_cast<const MulOpD*>(tw));
+    double* o = reinterpret_cast<double*>(x);
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+  } else {
+    const ArithI ar(dm);
+    u64 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = x[(size_t)k * Q];
+    head_fwd8(ar, v, tw);
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[(size_t)k * Q] = v[k];
+  }
+}
+
+template <class A, int L>
+__device__ __forceinline__ void ntt_midfwd_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid, u32 blk) {
+  using Sh = SplitShape<L>;
+  const A ar(dm);
+  constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
+  using First = BlkPass<A, L, LOWF0, RF0>;
+  constexpr int RL = split_fwd_radix(L, Sh::NPF - 1);
+  using Last = BlkPass<A, L, 0, RL>;
+  typename A::V v[kBlkEPT];
+  const typename A::V* src = reinterpret_cast<const typename A::V*>(x);
+#pragma unroll
+  for (int g = 0; g < First::G; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << RF0); k++) v[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+  mid_forward<A, L, 0>(ar, v, smem, tid, blk, tw, dm.split_fwd_mask);
+#pragma unroll
+  for (int g = 0; g < Last::G; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << RL); k++) x[Last::elem(tid, blk, g, k)] = ar.canonical(v[g * (1 << RL) + k]);
+}
+
+// grid: polys * NBLK
+template <int L>
+__global__ __launch_bounds__((SplitShape<L>::TPB)) void ntt_midfwd_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+                                                                           u64* data, NttPlan plan) {
+  using Sh = SplitShape<L>;
+  __shared__ u64 smem[Sh::BLOCK];
+  const u32 blk = blockIdx.x % Sh::NBLK, poly = blockIdx.x / Sh::NBLK;
+  const u32 m = plan_mod_split(plan, poly);
+  const DevMod& dm = ctx->mod[m];
+  u64* x = data + (size_t)poly * Sh::N;
+  const MulOp* tw = twf_base + (size_t)m * Sh::N;
+  if (residue_is_f64(dm))
+    ntt_midfwd_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem), threadIdx.x, blk);
+  else
+    ntt_midfwd_body<ArithI, L>(dm, tw, x, smem, threadIdx.x, blk);
+}
+
+template <class A, int L>
+__device__ __forceinline__ void ntt_midinv_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid, u32 blk) {
+  using Sh = SplitShape<L>;
+  const A ar(dm);
+  constexpr int R0 = split_inv_radix(L, 0);
+  using In = BlkPass<A, L, 0, R0>;
+  constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
+  using Out = BlkPass<A, L, LOWI, RI>;
+  typename A::V v[kBlkEPT];
+#pragma unroll
+  for (int g = 0; g < In::G; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R0); k++) v[g * (1 << R0) + k] = ar.from_u64(x[In::elem(tid, blk, g, k)]);
+  mid_inverse<A, L, 0>(ar, v, smem, tid, blk, tw, dm.split_inv_mask);
+  typename A::V* dst = reinterpret_cast<typename A::V*>(x);
+#pragma unroll
+  for (int g = 0; g < Out::G; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << RI); k++) dst[Out::elem(tid, blk, g, k)] = v[g * (1 << RI) + k];
+}
+
+template <int L>
+__global__ __launch_bounds__((SplitShape<L>::TPB)) void ntt_midinv_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+                                                                           u64* data, NttPlan plan) {
+  using Sh = SplitShape<L>;
+  __shared__ u64 smem[Sh::BLOCK];
+  const u32 blk = blockIdx.x % Sh::NBLK, poly = blockIdx.x / Sh::NBLK;
+  const u32 m = plan_mod_split(plan, poly);
+  const DevMod& dm = ctx->mod[m];
+  u64* x = data + (size_t)poly * Sh::N;
+  const MulOp* tw = twi_base + (size_t)m * Sh::N;
+  if (residue_is_f64(dm))
+    ntt_midinv_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem), threadIdx.x, blk);
+  else
+    ntt_midinv_body<ArithI, L>(dm, tw, x, smem, threadIdx.x, blk);
+}
+
+// grid (N/4/256, polys); scale_mode as in ntt_inv_kernel
+template <int L>
+__global__ __launch_bounds__(kHeadThreads) void ntt_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base, u64* data,
+                                                                NttPlan plan, int scale_mode) {
+  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 poly = blockIdx.y;
+  const u32 m = plan_mod_split(plan, poly);
+  const DevMod& dm = ctx->mod[m];
+  u64* x = data + (size_t)poly * N + t;
+  const MulOp* tw = twi_base + (size_t)m * N;
+  u64 o[4];
+  if (residue_is_f64(dm)) {
+    const ArithD ar(dm);
+    const MulOpD sc = scale_mode == 1 ? ctx->intt_scale_q_d[m] : dm.ninv_d;
+    tail_inv4_scale(ar, reinterpret_cast<const double*>(x), Q, reinterpret_cast<const MulOpD*>(tw), sc, dm.split_inv_mask, o);
+  } else {
+    const ArithI ar(dm);
+    MulOp sc = dm.ninv;
+    if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
+    tail_inv4_scale(ar, x, Q, tw, sc, 0u, o);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) x[(size_t)k * Q] = o[k];
+}
+
+template <int L>
+static hipError_t ntt_split_t(const DevCtx* ctx, const MulOp* tw, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode,
+                              hipStream_t s) {
+  using Sh = SplitShape<L>;
+  // gridDim.y <= 65535: chunk the polynomial range (chunks start at multiples of div*period so the plan stays aligned)
+  const size_t unit = (size_t)plan.div * plan.period;
+  const size_t step = unit <= 32768 ? (32768 / unit) * unit : unit;
+  for (size_t off = 0; off < polys; off += step) {
+    const size_t cnt = polys - off < step ? polys - off : step;
+    u64* d = data + off * Sh::N;
+    if (!inverse) {
+      ntt_head_kernel<L><<<dim3(Sh::N / 8 / kHeadThreads, (unsigned)cnt), kHeadThreads, 0, s>>>(ctx, tw, d, plan);
+      ntt_midfwd_kernel<L><<<dim3((unsigned)(cnt * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, tw, d, plan);
+    } else {
+      ntt_midinv_kernel<L><<<dim3((unsigned)(cnt * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, tw, d, plan);
+      ntt_tail_kernel<L><<<dim3(Sh::N / 4 / kHeadThreads, (unsigned)cnt), kHeadThreads, 0, s>>>(ctx, tw, d, plan, scale_mode);
+    }
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse,
+                            int scale_mode, hipStream_t s) {
+  if (logn == 15) return ntt_split_t<15>(ctx, tw, data, polys, plan, inverse, scale_mode, s);
+  return hipErrorInvalidValue;
+}
+
 // scratch layout (same size as the unfused path): T = double[ops][KK][K][N], ACC = double[ops][2][KK][N]
 #define SPLIT_DISPATCH(fn, ...)              \
   switch (logn) {                            \

@@ -30,12 +30,12 @@ constexpr int kBlkEPT = 8;
 constexpr int split_fwd_passes(int logn) { return (logn - kHeadLog + 2) / 3; }
 constexpr int split_inv_passes(int logn) { return (logn - kTailLog + 2) / 3; }
 constexpr int split_fwd_radix(int logn, int p) {
-  // logn-3 stages: 9 -> 3,3,3 ; 10 -> 3,3,2,2 ; 11 -> 2,3,3,3
-  return logn - kHeadLog == 9 ? 3 : logn - kHeadLog == 10 ? (p < 2 ? 3 : 2) : (p == 0 ? 2 : 3);
+  // logn-3 stages: 9 -> 3,3,3 ; 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3
+  return logn - kHeadLog == 10 ? (p < 2 ? 3 : 2) : logn - kHeadLog == 11 ? (p == 0 ? 2 : 3) : 3;
 }
 constexpr int split_inv_radix(int logn, int p) {
-  // logn-2 stages, first radix == last forward radix: 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3
-  return logn - kTailLog == 10 ? (p < 2 ? 3 : 2) : logn - kTailLog == 11 ? (p == 0 ? 2 : 3) : 3;
+  // logn-2 stages, first radix == last forward radix: 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3 ; 13 -> 3,3,3,2,2
+  return logn - kTailLog == 10 ? (p < 2 ? 3 : 2) : logn - kTailLog == 11 ? (p == 0 ? 2 : 3) : logn - kTailLog == 13 ? (p < 3 ? 3 : 2) : 3;
 }
 constexpr int split_fwd_low(int logn, int p) {  // lowest index bit of the window of forward middle pass p
   int s = kHeadLog;

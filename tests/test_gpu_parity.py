@@ -372,16 +372,39 @@ def test_multiply_edge_parameter_sets(n, bits, tbits):
             RelinearizationKeys.from_array(ctx, np.zeros((1, 2, 1, n), dtype=np.uint64))
 
 
-def test_unsupported_degree_is_reported():
-    from sunscreen_amd import Context, HipBfvError
-    from sunscreen_amd.batch import BatchEvaluator
+def test_largest_degree_n32768_two_kernel_ntt():
+    """n = 32768 (SEAL default: 16 primes, K = 15): residue polynomials (256 KB) exceed one CU's LDS, so the
+    transforms run as two kernels each (head + block-local / block-local + tail).  sunscreen/src/params.rs:37
+    lists 32768 as the largest lattice dimension the compiler tries."""
+    from sunscreen_amd import Context, GaloisKeys, RelinearizationKeys
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
 
     n = 32768
-    ctx = Context.from_raw(n, O.bfv_default(n), O.plain_batching(n, 17))
+    primes = O.bfv_default(n)
+    t = O.plain_batching(n, 17)
+    o = O.Oracle(n, primes, t)
+    O.seed(15)
+    sk, pk, rk, gk = o.keygen(galois_elts=[3])
+    ctx = Context.from_raw(n, primes, t)
+    assert ctx.K == 15 and ctx.KK == 16
     ev = BatchEvaluator(ctx)
-    import torch
-
-    x = torch.zeros((1, 2, ctx.K, n), dtype=torch.int64, device="cuda:0")
-    with pytest.raises(HipBfvError) as ei:
-        ev.multiply(x, x)
-    assert ei.value.kind == "InternalError"  # COR_E_INVALIDOPERATION: N = 32768 needs the two-kernel NTT
+    rng = np.random.default_rng(15)
+    # NTT round trip and parity for every key-level prime
+    x = np.stack([rng.integers(0, primes[p % 16], n, dtype=np.uint64) for p in range(17)])
+    d = to_device(x)
+    ev.ntt(d, 16)
+    got = to_host(d)
+    for p in range(17):
+        assert (got[p] == o.ntt(p % 16, x[p])).all(), p
+    ev.ntt(d, 16, inverse=True)
+    assert (to_host(d) == x).all()
+    va = rng.integers(0, 100, n).astype(np.uint64)
+    vb = rng.integers(0, 100, n).astype(np.uint64)
+    a = np.stack([o.encrypt(pk, o.batch_encode(va))])
+    b = np.stack([o.encrypt(pk, o.batch_encode(vb))])
+    r = to_host(ev.multiply_relin(to_device(a), to_device(b), RelinearizationKeys.from_array(ctx, rk)))
+    ref = o.relinearize(o.multiply(a[0], b[0]), rk)
+    assert (r[0] == ref).all()
+    assert (o.batch_decode(o.decrypt(r[0], sk)) == (va * vb) % t).all()
+    g = to_host(ev.rotate_rows(to_device(a), 1, GaloisKeys.from_arrays(ctx, gk)))
+    assert (g[0] == o.rotate_rows(a[0], 1, gk)).all()

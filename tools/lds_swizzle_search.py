@@ -20,8 +20,8 @@ def varying_bits(low, r):
 
 def schedules(L):
     lf, li = L - 3, L - 2  # stages done in the middle kernel (forward after a radix-8 head, inverse before a radix-4 tail)
-    fwd = {10: [3, 3, 2, 2], 9: [3, 3, 3], 11: [2, 3, 3, 3], 8: [3, 3, 2], 7: [3, 2, 2]}[lf]
-    inv = {11: [2, 3, 3, 3], 10: [3, 3, 2, 2], 12: [3, 3, 3, 3], 9: [2, 3, 2, 2], 8: [2, 2, 2, 2]}[li]
+    fwd = {10: [3, 3, 2, 2], 9: [3, 3, 3], 11: [2, 3, 3, 3], 12: [3, 3, 3, 3], 8: [3, 3, 2], 7: [3, 2, 2]}[lf]
+    inv = {11: [2, 3, 3, 3], 10: [3, 3, 2, 2], 12: [3, 3, 3, 3], 13: [3, 3, 3, 2, 2], 9: [2, 3, 2, 2], 8: [2, 2, 2, 2]}[li]
     pats = []
     s0 = 3
     for r in fwd:
