@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
 // -------------------------------------------------------------------------------------------------
 // key switch, middle: per (op, I, block): finish the K forward transforms, multiply-accumulate with the
 // key rows, run the block-local inverse stages of both accumulators.
-// grid: ops8 * KK * NBLK (op-major swizzle so that the blocks of one op share an XCD's L2)
+// grid: ops8 * KK * NBLK (slice-major per XCD, see the index computation)
 // -------------------------------------------------------------------------------------------------
 template <int L>
 __global__ __launch_bounds__((SplitShape<L>::TPB)) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
@@ -218,10 +218,14 @@ __global__ __launch_bounds__((SplitShape<L>::TPB)) void ks_mid_kernel(const DevC
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, KK = ctx->KK;
   const u32 b = blockIdx.x;
+  // Workgroups are dealt round-robin to the 8 XCDs.  Within one XCD consecutive workgroups walk the ops of ONE
+  // (I, blk) slice, so the K * 2 key rows of that slice (the only re-used global data) stay in that XCD's L2.
   const u32 xcd = b & 7u, slot = b >> 3;
-  const u32 blk = slot % Sh::NBLK;
-  const u32 I = (slot / Sh::NBLK) % KK;
-  const u32 op = (slot / (Sh::NBLK * KK)) * 8u + xcd;
+  const u32 per = (ops + 7u) >> 3;
+  const u32 op = (slot % per) * 8u + xcd;
+  const u32 ib = slot / per;
+  const u32 blk = ib % Sh::NBLK;
+  const u32 I = ib / Sh::NBLK;
   if (op >= ops) return;
   const DevMod& dm = ctx->mod[I];
   const A ar(dm);
@@ -607,13 +611,22 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
     }
   }
   u64* o = out + ((size_t)op * 3 + poly) * K * N + t;
-#pragma unroll
+  // The per-coefficient epilogue is too large to unroll four times; a rolled loop must not index y/xb by k
+  // (dynamic indexing puts them in scratch), so each trip consumes row 0 and the rows rotate down.
+#pragma unroll 1
   for (int k = 0; k < 4; k++) {
     u64 r[KMAX];
-    behz_floor_sk_coeff<KMAX>(ctx, y[k], xb[k], r);
+    behz_floor_sk_coeff<KMAX>(ctx, y[0], xb[0], r);
 #pragma unroll
     for (int i = 0; i < KMAX; i++)
       if ((u32)i < K) o[(size_t)i * N + (size_t)k * Q] = r[i];
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+#pragma unroll
+      for (int i = 0; i < KMAX; i++) y[kk][i] = y[kk + 1][i];
+#pragma unroll
+      for (int j = 0; j < KMAX + 2; j++) xb[kk][j] = xb[kk + 1][j];
+    }
   }
 }
 

@@ -21,7 +21,9 @@ def parse(path, counter):
             continue
         m = re.match(r"^\s+(\S+)\s+([0-9.]+)", line)
         if m and cur and m.group(1) == counter:
-            out[cur.replace("_kernel", "")] = float(m.group(2))
+            # template variants of one kernel (e.g. mul_mid<..,true/false>) are one profiler record in bench.py: sum them
+            key = cur.replace("_kernel", "")
+            out[key] = out.get(key, 0.0) + float(m.group(2))
     return out
 
 
