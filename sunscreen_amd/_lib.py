@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhipbfv.so")
+# HIPBFV_LIB selects another build of the same library (kernel tuning A/B runs, tools/build_variant.sh)
+LIB_PATH = os.environ.get("HIPBFV_LIB") or os.path.join(_HERE, "lib", "libhipbfv.so")
 
 S_OK = 0
 E_POINTER = 0x80004003

@@ -84,6 +84,59 @@ struct BlkPass {
       }
     }
   }
+  // The same stages with the twiddles fetched separately (load_tw_*) so that the fetch can be issued a pass ahead
+  // of its use: w[g*NW + slot], forward slot of (stage j, c) = 2^j - 1 + c, inverse slot = 2^R - 2^(R-j) + c.
+  static constexpr int NW = (1 << R) - 1;
+  static __device__ __forceinline__ void load_tw_fwd(typename A::Tw (&w)[kBlkEPT - 1], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
+    constexpr int S0 = L - LOW - R;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      u32 hi = vt(tid, blk, g) >> LOW;
+      if constexpr (LOW >= 6) hi = __builtin_amdgcn_readfirstlane(hi);
+#pragma unroll
+      for (int j = 0; j < R; j++)
+#pragma unroll
+        for (int c = 0; c < (1 << j); c++) w[g * NW + (1 << j) - 1 + c] = tw[(1u << (S0 + j)) + ((hi << j) | (u32)c)];
+    }
+  }
+  static __device__ __forceinline__ void fwd_tw(const A& ar, typename A::V (&v)[kBlkEPT], const typename A::Tw (&w)[kBlkEPT - 1]) {
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const int half = 1 << (R - 1 - j);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+          if (k & half) continue;
+          ar.fwd(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w[g * NW + (1 << j) - 1 + (k >> (R - j))]);
+        }
+      }
+  }
+  static __device__ __forceinline__ void load_tw_inv(typename A::Tw (&w)[kBlkEPT - 1], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      u32 hi = vt(tid, blk, g) >> LOW;
+      if constexpr (LOW >= 6) hi = __builtin_amdgcn_readfirstlane(hi);
+#pragma unroll
+      for (int j = 0; j < R; j++)
+#pragma unroll
+        for (int c = 0; c < (1 << (R - 1 - j)); c++)
+          w[g * NW + (1 << R) - (1 << (R - j)) + c] = tw[(1u << (L - 1 - LOW - j)) + ((hi << (R - 1 - j)) | (u32)c)];
+    }
+  }
+  static __device__ __forceinline__ void inv_tw(const A& ar, typename A::V (&v)[kBlkEPT], const typename A::Tw (&w)[kBlkEPT - 1]) {
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const int half = 1 << j;
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+          if (k & half) continue;
+          ar.inv(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w[g * NW + (1 << R) - (1 << (R - j)) + (k >> (j + 1))]);
+        }
+      }
+  }
   // inverse stages with global gaps 2^LOW .. 2^(LOW+R-1)
   static __device__ __forceinline__ void inv(const A& ar, typename A::V (&v)[kBlkEPT], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
 #pragma unroll
@@ -110,6 +163,73 @@ __device__ __forceinline__ void reduce_all(const A& ar, typename A::V (&v)[kBlkE
   for (int e = 0; e < kBlkEPT; e++) v[e] = ar.reduce(v[e]);
 }
 
+// TW_PIPE_D / TW_PIPE_I (FP64 / integer policy): 0 = every pass fetches its twiddles when it needs them; 1 = the next pass's twiddles are fetched
+// before the LDS exchange that precedes it; 2 = before the current pass's butterflies (needs both sets live).
+#ifndef TW_PIPE_D
+#define TW_PIPE_D 1
+#endif
+#ifndef TW_PIPE_I
+#define TW_PIPE_I 1
+#endif
+template <class A>
+struct TwPipe {
+  static constexpr int value = TW_PIPE_I;
+};
+template <>
+struct TwPipe<ArithD> {
+  static constexpr int value = TW_PIPE_D;
+};
+
+template <class A, int L, int P>
+__device__ __forceinline__ void mid_forward_p(const A& ar, typename A::V (&v)[kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+                                              const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[kBlkEPT - 1]) {
+  constexpr int R = split_fwd_radix(L, P);
+  constexpr int LOW = split_fwd_low(L, P);
+  using Pass = BlkPass<A, L, LOW, R>;
+  constexpr bool more = P + 1 < SplitShape<L>::NPF;
+  constexpr int PN = more ? P + 1 : P;
+  using Next = BlkPass<A, L, split_fwd_low(L, PN), split_fwd_radix(L, PN)>;
+  typename A::Tw wn[kBlkEPT - 1];
+  if constexpr (P > 0) {
+    __syncthreads();
+    Pass::load_lds(v, smem, tid, blk);
+  }
+  if constexpr (more && TwPipe<A>::value == 2) Next::load_tw_fwd(wn, tid, blk, tw);
+  if ((mask >> P) & 1u) reduce_all(ar, v);
+  if ((mask >> (P + 16)) & 1u) reduce_all(ar, v);  // very wide primes: a second reduction (context.cpp range plan)
+  Pass::fwd_tw(ar, v, w);
+  if constexpr (more) {
+    if constexpr (TwPipe<A>::value != 2) Next::load_tw_fwd(wn, tid, blk, tw);
+    Pass::store_lds(v, smem, tid, blk);
+    mid_forward_p<A, L, PN>(ar, v, smem, tid, blk, tw, mask, wn);
+  }
+}
+
+template <class A, int L, int P>
+__device__ __forceinline__ void mid_inverse_p(const A& ar, typename A::V (&v)[kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+                                              const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[kBlkEPT - 1]) {
+  constexpr int R = split_inv_radix(L, P);
+  constexpr int LOW = split_inv_low(L, P);
+  using Pass = BlkPass<A, L, LOW, R>;
+  constexpr bool more = P + 1 < SplitShape<L>::NPI;
+  constexpr int PN = more ? P + 1 : P;
+  using Next = BlkPass<A, L, split_inv_low(L, PN), split_inv_radix(L, PN)>;
+  typename A::Tw wn[kBlkEPT - 1];
+  if constexpr (P > 0) {
+    __syncthreads();
+    Pass::load_lds(v, smem, tid, blk);
+  }
+  if constexpr (more && TwPipe<A>::value == 2) Next::load_tw_inv(wn, tid, blk, tw);
+  if ((mask >> P) & 1u) reduce_all(ar, v);
+  if ((mask >> (P + 16)) & 1u) reduce_all(ar, v);
+  Pass::inv_tw(ar, v, w);
+  if constexpr (more) {
+    if constexpr (TwPipe<A>::value != 2) Next::load_tw_inv(wn, tid, blk, tw);
+    Pass::store_lds(v, smem, tid, blk);
+    mid_inverse_p<A, L, PN>(ar, v, smem, tid, blk, tw, mask, wn);
+  }
+}
+
 // Remaining forward stages of one block.  On entry v holds the block's values in the layout of forward
 // middle pass 0 (window split_fwd_low(L,0)); on exit v holds the last pass's results (window LOW = 0).
 template <class A, int L, int P>
@@ -118,16 +238,24 @@ __device__ __forceinline__ void mid_forward(const A& ar, typename A::V (&v)[kBlk
   constexpr int R = split_fwd_radix(L, P);
   constexpr int LOW = split_fwd_low(L, P);
   using Pass = BlkPass<A, L, LOW, R>;
-  if constexpr (P > 0) {
-    __syncthreads();
-    Pass::load_lds(v, smem, tid, blk);
-  }
-  if ((mask >> P) & 1u) reduce_all(ar, v);
-  if ((mask >> (P + 16)) & 1u) reduce_all(ar, v);  // very wide primes: a second reduction (context.cpp range plan)
-  Pass::fwd(ar, v, tid, blk, tw);
-  if constexpr (P + 1 < SplitShape<L>::NPF) {
-    Pass::store_lds(v, smem, tid, blk);
-    mid_forward<A, L, P + 1>(ar, v, smem, tid, blk, tw, mask);
+  if constexpr (TwPipe<A>::value != 0) {
+    static_assert(P == 0, "pipelined transforms start at pass 0");
+    typename A::Tw w[kBlkEPT - 1];
+    Pass::load_tw_fwd(w, tid, blk, tw);
+    mid_forward_p<A, L, 0>(ar, v, smem, tid, blk, tw, mask, w);
+  } else {
+    if constexpr (P > 0) {
+      __syncthreads();
+      Pass::load_lds(v, smem, tid, blk);
+    }
+    if ((mask >> P) & 1u) reduce_all(ar, v);
+    if ((mask >> (P + 16)) & 1u) reduce_all(ar, v);
+    Pass::fwd(ar, v, tid, blk, tw);
+    if constexpr (P + 1 < SplitShape<L>::NPF) {
+      Pass::store_lds(v, smem, tid, blk);
+      constexpr int PN = TwPipe<A>::value != 0 ? 0 : P + 1;
+      mid_forward<A, L, PN>(ar, v, smem, tid, blk, tw, mask);
+    }
   }
 }
 
@@ -139,16 +267,24 @@ __device__ __forceinline__ void mid_inverse(const A& ar, typename A::V (&v)[kBlk
   constexpr int R = split_inv_radix(L, P);
   constexpr int LOW = split_inv_low(L, P);
   using Pass = BlkPass<A, L, LOW, R>;
-  if constexpr (P > 0) {
-    __syncthreads();
-    Pass::load_lds(v, smem, tid, blk);
-  }
-  if ((mask >> P) & 1u) reduce_all(ar, v);
-  if ((mask >> (P + 16)) & 1u) reduce_all(ar, v);
-  Pass::inv(ar, v, tid, blk, tw);
-  if constexpr (P + 1 < SplitShape<L>::NPI) {
-    Pass::store_lds(v, smem, tid, blk);
-    mid_inverse<A, L, P + 1>(ar, v, smem, tid, blk, tw, mask);
+  if constexpr (TwPipe<A>::value != 0) {
+    static_assert(P == 0, "pipelined transforms start at pass 0");
+    typename A::Tw w[kBlkEPT - 1];
+    Pass::load_tw_inv(w, tid, blk, tw);
+    mid_inverse_p<A, L, 0>(ar, v, smem, tid, blk, tw, mask, w);
+  } else {
+    if constexpr (P > 0) {
+      __syncthreads();
+      Pass::load_lds(v, smem, tid, blk);
+    }
+    if ((mask >> P) & 1u) reduce_all(ar, v);
+    if ((mask >> (P + 16)) & 1u) reduce_all(ar, v);
+    Pass::inv(ar, v, tid, blk, tw);
+    if constexpr (P + 1 < SplitShape<L>::NPI) {
+      Pass::store_lds(v, smem, tid, blk);
+      constexpr int PN = TwPipe<A>::value != 0 ? 0 : P + 1;
+      mid_inverse<A, L, PN>(ar, v, smem, tid, blk, tw, mask);
+    }
   }
 }
 
@@ -158,6 +294,15 @@ constexpr int kHeadThreads = 256;
 #endif
 #ifndef MID_WAVES_I
 #define MID_WAVES_I 3
+#endif
+#ifndef KS_MID_PREFETCH
+#define KS_MID_PREFETCH 0
+#endif
+#ifndef KS_MID_WAVES
+#define KS_MID_WAVES 3
+#endif
+#ifndef MID_PREFETCH_D
+#define MID_PREFETCH_D false
 #endif
 
 // -------------------------------------------------------------------------------------------------
@@ -209,7 +354,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
 // grid: ops8 * KK * NBLK (slice-major per XCD, see the index computation)
 // -------------------------------------------------------------------------------------------------
 template <int L>
-__global__ __launch_bounds__((SplitShape<L>::TPB)) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+__global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                        const MulOp* __restrict__ twi_base, const double* __restrict__ T,
                                                                        const u64* __restrict__ key, double* __restrict__ ACC, u32 ops) {
   using Sh = SplitShape<L>;
@@ -238,19 +383,14 @@ __global__ __launch_bounds__((SplitShape<L>::TPB)) void ks_mid_kernel(const DevC
   double acc0[kBlkEPT], acc1[kBlkEPT];
 #pragma unroll
   for (int e = 0; e < kBlkEPT; e++) acc0[e] = 0.0, acc1[e] = 0.0;
-  for (u32 J = 0; J < K; J++) {
+  auto load_src = [&](u32 J, double(&dst)[kBlkEPT]) {
     const double* src = T + (((size_t)op * KK + I) * K + J) * Sh::N;
-    double v[kBlkEPT];
 #pragma unroll
     for (int g = 0; g < First::G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << RF0); k++) v[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
-    if (J > 0) __syncthreads();  // the previous transform's last pass may still be reading LDS
-    // The twiddles do not depend on J: without this the compiler hoists every twiddle load of all passes out
-    // of the loop and keeps ~100 registers of them alive (spilling to scratch).  Re-materialise the pointer.
-    const MulOpD* twf_j = twf;
-    asm volatile("" : "+s"(twf_j));
-    mid_forward<A, L, 0>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
+      for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+  };
+  auto load_keys = [&](u32 J, ulonglong2(&ka)[kBlkEPT / 2], ulonglong2(&kc)[kBlkEPT / 2]) {
     const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
     const u64* k1 = key + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
 #pragma unroll
@@ -258,19 +398,52 @@ __global__ __launch_bounds__((SplitShape<L>::TPB)) void ks_mid_kernel(const DevC
       const u32 base = Last::elem(tid, blk, g, 0);
 #pragma unroll
       for (int k = 0; k < (1 << RL); k += 2) {
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
-        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
-        const int e = g * (1 << RL) + k;
-        acc0[e] += ar.mul_var(v[e], ar.from_u64(a.x));
-        acc0[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(a.y));
-        acc1[e] += ar.mul_var(v[e], ar.from_u64(c.x));
-        acc1[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(c.y));
+        ka[(g * (1 << RL) + k) / 2] = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
+        kc[(g * (1 << RL) + k) / 2] = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
       }
+    }
+  };
+  double v[kBlkEPT];
+#if KS_MID_PREFETCH >= 2
+  double vn[kBlkEPT];
+  load_src(0, v);
+#endif
+  for (u32 J = 0; J < K; J++) {
+    ulonglong2 ka[kBlkEPT / 2], kc[kBlkEPT / 2];
+#if KS_MID_PREFETCH >= 2
+    load_keys(J, ka, kc);
+    if (J + 1 < K) load_src(J + 1, vn);
+#elif KS_MID_PREFETCH == 1
+    load_src(J, v);
+    load_keys(J, ka, kc);  // in flight during the transform (barriers only wait on LDS traffic)
+#else
+    load_src(J, v);
+#endif
+    if (J > 0) __syncthreads();  // the previous transform's last pass may still be reading LDS
+    // The twiddles do not depend on J: without this the compiler hoists every twiddle load of all passes out
+    // of the loop and keeps ~100 registers of them alive (spilling to scratch).  Re-materialise the pointer.
+    const MulOpD* twf_j = twf;
+    asm volatile("" : "+s"(twf_j));
+    mid_forward<A, L, 0>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
+#if KS_MID_PREFETCH == 0
+    load_keys(J, ka, kc);
+#endif
+#pragma unroll
+    for (int h = 0; h < kBlkEPT / 2; h++) {
+      const int e = 2 * h;
+      acc0[e] += ar.mul_var(v[e], ar.from_u64(ka[h].x));
+      acc0[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(ka[h].y));
+      acc1[e] += ar.mul_var(v[e], ar.from_u64(kc[h].x));
+      acc1[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(kc[h].y));
     }
     if ((J & 3u) == 3u) {
       reduce_all(ar, acc0);
       reduce_all(ar, acc1);
     }
+#if KS_MID_PREFETCH >= 2
+#pragma unroll
+    for (int e = 0; e < kBlkEPT; e++) v[e] = vn[e];
+#endif
   }
   reduce_all(ar, acc0);
   reduce_all(ar, acc1);
@@ -466,7 +639,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
 }
 
 // mul middle body for one (op, residue, block)
-template <class A, int L>
+template <class A, int L, bool PREFETCH>
 __device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi, const typename A::V* ext_r,
                                              size_t poly_stride, typename A::V* D_r, size_t dpoly_stride, typename A::V* smem,
                                              typename A::V* park, u32 tid, u32 blk) {
@@ -477,31 +650,63 @@ __device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A:
   constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
   using Out = BlkPass<A, L, LOWI, RI>;
   typename A::V a1[kBlkEPT], d0[kBlkEPT], d1[kBlkEPT], v[kBlkEPT];
-  auto load_fwd = [&](int poly, typename A::V(&dst)[kBlkEPT], bool sync_first) {
+  auto issue = [&](int poly, typename A::V(&dst)[kBlkEPT]) {
     const typename A::V* src = ext_r + (size_t)poly * poly_stride;
 #pragma unroll
     for (int g = 0; g < First::G; g++)
 #pragma unroll
       for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+  };
+  auto fwd = [&](typename A::V(&dst)[kBlkEPT], bool sync_first) {
     if (sync_first) __syncthreads();
     const typename A::Tw* tw = opaque_uniform(twf);  // keep the twiddle loads inside this transform
     mid_forward<A, L, 0>(ar, dst, smem, tid, blk, tw, dm.split_fwd_mask);
   };
-  load_fwd(0, v, false);  // a0 -> parked in LDS (thread-private slots)
+  if constexpr (PREFETCH) {
+    // The loads of the next polynomial are in flight while the current one is transformed (barriers only wait
+    // on LDS traffic); costs one more 8-element array.
+    typename A::V w[kBlkEPT];
+    issue(0, v);
+    issue(1, a1);
+    fwd(v, false);  // a0 -> parked in LDS (thread-private slots)
 #pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB + tid] = v[e];
-  load_fwd(1, a1, true);
-  load_fwd(2, v, true);  // b0
+    for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB + tid] = v[e];
+    issue(2, v);
+    fwd(a1, true);
+    issue(3, w);
+    fwd(v, true);  // b0
 #pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) {
-    d0[e] = ar.mul_var(park[e * Sh::TPB + tid], v[e]);
-    d1[e] = ar.mul_var(a1[e], v[e]);
-  }
-  load_fwd(3, v, true);  // b1
+    for (int e = 0; e < kBlkEPT; e++) {
+      d0[e] = ar.mul_var(park[e * Sh::TPB + tid], v[e]);
+      d1[e] = ar.mul_var(a1[e], v[e]);
+    }
+    fwd(w, true);  // b1
 #pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) {
-    d1[e] = ar.mul_add(park[e * Sh::TPB + tid], v[e], d1[e]);
-    a1[e] = ar.mul_var(a1[e], v[e]);  // d2
+    for (int e = 0; e < kBlkEPT; e++) {
+      d1[e] = ar.mul_add(park[e * Sh::TPB + tid], w[e], d1[e]);
+      a1[e] = ar.mul_var(a1[e], w[e]);  // d2
+    }
+  } else {
+    issue(0, v);
+    fwd(v, false);  // a0 -> parked in LDS (thread-private slots)
+#pragma unroll
+    for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB + tid] = v[e];
+    issue(1, a1);
+    fwd(a1, true);
+    issue(2, v);
+    fwd(v, true);  // b0
+#pragma unroll
+    for (int e = 0; e < kBlkEPT; e++) {
+      d0[e] = ar.mul_var(park[e * Sh::TPB + tid], v[e]);
+      d1[e] = ar.mul_var(a1[e], v[e]);
+    }
+    issue(3, v);
+    fwd(v, true);  // b1
+#pragma unroll
+    for (int e = 0; e < kBlkEPT; e++) {
+      d1[e] = ar.mul_add(park[e * Sh::TPB + tid], v[e], d1[e]);
+      a1[e] = ar.mul_var(a1[e], v[e]);  // d2
+    }
   }
   auto inv_store = [&](typename A::V(&d)[kBlkEPT], int poly) {
     __syncthreads();
@@ -542,11 +747,11 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D : MID
   const MulOp* twf = twf_base + (size_t)m * Sh::N;
   const MulOp* twi = twi_base + (size_t)m * Sh::N;
   if constexpr (POLICY_D)
-    mul_mid_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
+    mul_mid_body<ArithD, L, MID_PREFETCH_D>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                             reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                             reinterpret_cast<double*>(smem), reinterpret_cast<double*>(park), tid, blk);
   else
-    mul_mid_body<ArithI, L>(dm, twf, twi, ext_r, ps, D_r, ps, smem, park, tid, blk);
+    mul_mid_body<ArithI, L, false>(dm, twf, twi, ext_r, ps, D_r, ps, smem, park, tid, blk);
 }
 
 // last two inverse stages + BEHZ scaling on {t + k*N/4}: canonical residues out
