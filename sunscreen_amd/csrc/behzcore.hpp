@@ -3,6 +3,7 @@
 // pipelines execute the identical arithmetic.
 #pragma once
 #include "devarith.hpp"
+#include "nttcore.hpp"
 
 namespace hipbfv {
 
@@ -83,6 +84,94 @@ __device__ __forceinline__ void behz_floor_sk_coeff(const DevCtx* __restrict__ c
       else
         a += (u128)alpha * (qm.q - ctx->B_mod_q[i]);
       out[i] = reduce128(a, qm);
+    }
+  }
+}
+
+// ---- the same two conversions in exact FP64 arithmetic (DevCtx::aux_f64: every modulus involved is below 2^50) ----
+// Values are integers held in doubles; mul_var / mul_const (ArithD) give |result| <= p*(0.5 + tiny), sums of a
+// few such terms stay far below 2^53, so every step is exact.  Where SEAL's result depends on WHICH representative
+// of a residue enters a base conversion (the y_i below), the canonical one in [0, p) is formed first.
+__device__ __forceinline__ double canonical_d(const ArithD& ar, double v) {
+  const double r = ar.reduce(v);
+  return r < 0.0 ? r + ar.q : r;
+}
+
+// x[i] = canonical residue mod q_i as a double  ->  out[j] = a representative mod Bsk_j with |out[j]| < Bsk_j
+template <int KMAX>
+__device__ __forceinline__ void behz_extend_coeff_d(const DevCtx* __restrict__ ctx, const double (&x)[KMAX], double (&out)[KMAX + 2]) {
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK;
+  double y[KMAX];
+  u32 rm = 0;
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const ArithD ar(ctx->mod[i]);
+      double v = ar.mul_const(x[i], ctx->ext_scale_d[i]);
+      v = v < 0.0 ? v + ar.q : v;  // mul_const leaves |v| <= q*(0.5 + tiny): canonical after one conditional add
+      y[i] = v;
+      rm += (u32)ar.to_bits(v) * ctx->q_to_mtilde[i];
+    }
+  }
+  rm *= ctx->neg_inv_q_mod_mtilde;  // r_mtilde = -x/q mod 2^32
+  const double rc = (double)(int)rm;  // centred representative in [-2^31, 2^31)
+#pragma unroll
+  for (int j = 0; j < KMAX + 2; j++) {
+    if ((u32)j < S) {
+      const ArithD ar(ctx->mod[KK + j]);
+      double acc = ar.mul_var(rc, ctx->q_mod_bsk_d[j]);
+#pragma unroll
+      for (int i = 0; i < KMAX; i++)
+        if ((u32)i < K) acc += ar.mul_var(y[i], ctx->q_to_bsk_d[j][i]);
+      out[j] = ar.mul_const(ar.reduce(acc), ctx->inv_mtilde_mod_bsk_d[j]);
+    }
+  }
+}
+
+// y[i] = x*t*(q/q_i)^{-1} mod q_i, any representative with |y[i]| < 2^52; xb[j] = x*t mod Bsk_j likewise;
+// out[i] = canonical residue (u64) of floor(t*x/q) mod q_i, identical to behz_floor_sk_coeff
+template <int KMAX>
+__device__ __forceinline__ void behz_floor_sk_coeff_d(const DevCtx* __restrict__ ctx, const double (&y)[KMAX], const double (&xb)[KMAX + 2],
+                                                      u64 (&out)[KMAX]) {
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, nB = ctx->nB;
+  double yc[KMAX];
+#pragma unroll
+  for (int i = 0; i < KMAX; i++)
+    if ((u32)i < K) yc[i] = canonical_d(ArithD(ctx->mod[i]), y[i]);
+  double yb[KMAX + 1];
+  double fl_msk = 0.0;
+#pragma unroll
+  for (int j = 0; j < KMAX + 2; j++) {
+    if ((u32)j < S) {
+      const ArithD ar(ctx->mod[KK + j]);
+      double conv = 0.0;
+#pragma unroll
+      for (int i = 0; i < KMAX; i++)
+        if ((u32)i < K) conv += ar.mul_var(yc[i], ctx->q_to_bsk_d[j][i]);
+      const double fl = ar.mul_const(ar.reduce(ar.reduce(xb[j]) - conv), ctx->inv_q_mod_bsk_d[j]);
+      if ((u32)j < nB) {
+        if (j < KMAX + 1) yb[j < KMAX + 1 ? j : 0] = canonical_d(ar, ar.mul_const(fl, ctx->inv_punct_B_d[j]));
+      } else {
+        fl_msk = fl;
+      }
+    }
+  }
+  const ArithD am(ctx->mod[KK + nB]);
+  double acc = -fl_msk;
+#pragma unroll
+  for (int j = 0; j < KMAX + 1; j++)
+    if ((u32)j < nB) acc += am.mul_var(yb[j], ctx->B_to_msk_d[j]);
+  // alpha_sk as the small signed integer it stands for (SEAL branches on alpha_sk > m_sk/2 to the same effect)
+  const double alpha = am.reduce(am.mul_const(am.reduce(acc), ctx->inv_B_mod_msk_d));
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const ArithD ar(ctx->mod[i]);
+      double a = -ar.mul_var(alpha, ctx->B_mod_q_d[i]);
+#pragma unroll
+      for (int j = 0; j < KMAX + 1; j++)
+        if ((u32)j < nB) a += ar.mul_var(yb[j], ctx->B_to_q_d[i][j]);
+      out[i] = ar.canonical(a);
     }
   }
 }

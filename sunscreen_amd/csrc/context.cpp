@@ -386,16 +386,61 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
   for (u64 p : q)
     if (t % p == 0) return fail("plain modulus must be coprime to the coefficient modulus");
 
-  // auxiliary base: |B| = K, one more if K*n*t*q^2 could overflow q*B*m_sk (SEAL RNSTool::initialize)
-  h.nB = K;
-  if (32 + t_bits + q_bits >= 61 * (int)K + 61) h.nB++;
+  // auxiliary base.  SEAL (RNSTool::initialize) takes |B| = K 61-bit primes, one more when
+  // 32 + bits(t) + bits(q) >= 61*(K+1), plus m_sk.  The BEHZ result does not depend on WHICH auxiliary primes
+  // are used: every value that passes through Bsk is an integer determined by the q-residues alone (the
+  // q -> Bsk conversions add a multiple of q that depends only on the base q; the Bsk -> q conversion is made
+  // exact by the m_sk correction), provided B*m_sk exceeds the same bound 2^(32 + bits(t) + bits(q)) SEAL sizes
+  // its base for.  When every data prime takes the FP64 path the library therefore picks its own base of
+  // primes below 2^48 satisfying that bound, so that the auxiliary residues run on the FP64 pipe as well
+  // (bit-identical results; tests compare against the oracle, which keeps SEAL's base).
+  const int need_bits = 32 + t_bits + q_bits;
+  std::vector<u64> B;
+  u64 m_sk = 0;
+  bool own_base = false;
+  {
+    bool want = true;
+    if (const char* env = std::getenv("HIPBFV_SEAL_AUX")) want = env[0] != '1';
+    if (const char* env = std::getenv("HIPBFV_NO_F64"))
+      if (env[0] == '1') want = false;
+    auto fp64_ok = [&](u64 p) {
+      u32 a, b;
+      if (!plan_f64_path(p, (int)h.logn, 16, &a, &b)) return false;
+      if (h.logn >= 12 && h.logn <= 15 && !plan_f64_split(p, (int)h.logn, &a, &b)) return false;
+      return true;
+    };
+    for (u64 p : q) want = want && fp64_ok(p);
+    for (u32 cnt = 2; want && !own_base && cnt <= (u32)kMaxBsk; cnt++) {
+      int bits = (need_bits + 1 + (int)cnt - 1) / (int)cnt + 1;  // cnt primes >= 2^(bits-1): product >= 2^(need_bits+1)
+      if (bits > 48) continue;
+      if (bits < 36) bits = 36;
+      std::vector<u64> cand = find_primes(two_n, bits, cnt + key_primes.size());
+      std::vector<u64> pick;
+      for (u64 p : cand) {
+        if (pick.size() == cnt) break;
+        if (std::find(key_primes.begin(), key_primes.end(), p) != key_primes.end() || t % p == 0 || !fp64_ok(p)) continue;
+        pick.push_back(p);
+      }
+      if (pick.size() != cnt) continue;
+      own_base = true;
+      m_sk = pick[0];
+      B.assign(pick.begin() + 1, pick.end());
+    }
+  }
+  if (own_base) {
+    h.nB = (u32)B.size();
+  } else {
+    h.nB = K;
+    if (need_bits >= 61 * (int)K + 61) h.nB++;
+    std::vector<u64> aux = find_primes(two_n, 61, h.nB + 2);
+    if (aux.size() != h.nB + 2) return fail("cannot find auxiliary primes");
+    m_sk = aux[0];
+    B.assign(aux.begin() + 2, aux.end());
+  }
+  h.aux_f64 = own_base ? 1u : 0u;
   h.S = h.nB + 1;
   h.P = KK + h.S;
   if (h.S > (u32)kMaxBsk) return fail("too many primes");
-  std::vector<u64> aux = find_primes(two_n, 61, h.nB + 2);
-  if (aux.size() != h.nB + 2) return fail("cannot find auxiliary primes");
-  const u64 m_sk = aux[0];
-  std::vector<u64> B(aux.begin() + 2, aux.end());
   std::vector<u64> Bsk = B;
   Bsk.push_back(m_sk);
   const u64 m_tilde = 1ull << 32;
@@ -475,6 +520,7 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     invm(h.q_mod_bsk[j], p, &inv);
     h.inv_q_mod_bsk[j] = make_mulop(inv, p);
     h.intt_scale_bsk[j] = make_mulop(mulm(h.mod[KK + j].ninv.w, t % p, p), p);
+    h.intt_scale_bsk_d[j] = make_mulop_d(h.intt_scale_bsk[j].w, p);  // meaningful for FP64-path moduli only
   }
   for (u32 j = 0; j < h.nB; j++) {
     u64 inv;
@@ -486,6 +532,26 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     u64 inv;
     invm(prod_mod(B, m_sk), m_sk, &inv);
     h.inv_B_mod_msk = make_mulop(inv, m_sk);
+  }
+
+  if (h.aux_f64) {
+    for (u32 i = 0; i < K; i++) {
+      h.ext_scale_d[i] = make_mulop_d(h.ext_scale[i].w, q[i]);
+      h.B_mod_q_d[i] = (double)h.B_mod_q[i];
+      for (u32 j = 0; j < h.nB; j++) h.B_to_q_d[i][j] = (double)h.B_to_q[i][j];
+    }
+    for (u32 j = 0; j < h.S; j++) {
+      const u64 p = Bsk[j];
+      for (u32 i = 0; i < K; i++) h.q_to_bsk_d[j][i] = (double)h.q_to_bsk[j][i];
+      h.q_mod_bsk_d[j] = (double)h.q_mod_bsk[j];
+      h.inv_mtilde_mod_bsk_d[j] = make_mulop_d(h.inv_mtilde_mod_bsk[j].w, p);
+      h.inv_q_mod_bsk_d[j] = make_mulop_d(h.inv_q_mod_bsk[j].w, p);
+    }
+    for (u32 j = 0; j < h.nB; j++) {
+      h.inv_punct_B_d[j] = make_mulop_d(h.inv_punct_B[j].w, B[j]);
+      h.B_to_msk_d[j] = (double)h.B_to_msk[j];
+    }
+    h.inv_B_mod_msk_d = make_mulop_d(h.inv_B_mod_msk.w, m_sk);
   }
 
   h.mid_nd = h.mid_ni = 0;

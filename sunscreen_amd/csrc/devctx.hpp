@@ -91,6 +91,23 @@ struct DevCtx {
   MulOp inv_B_mod_msk;                 // B^{-1} mod m_sk
   u64 B_mod_q[kMaxKey];                // B mod q_i
 
+  // FP64 copies of the conversion constants, valid when aux_f64 != 0: every data prime and every Bsk prime
+  // takes the FP64 split path, the auxiliary base is the library's own (context.cpp), and the head / tail
+  // kernels run the BEHZ conversions in exact double arithmetic
+  u32 aux_f64;
+  u32 pad3;
+  MulOpD ext_scale_d[kMaxKey];
+  double q_to_bsk_d[kMaxBsk][kMaxKey];
+  double q_mod_bsk_d[kMaxBsk];
+  MulOpD inv_mtilde_mod_bsk_d[kMaxBsk];
+  MulOpD intt_scale_bsk_d[kMaxBsk];
+  MulOpD inv_q_mod_bsk_d[kMaxBsk];
+  MulOpD inv_punct_B_d[kMaxBsk];
+  double B_to_q_d[kMaxKey][kMaxBsk];
+  double B_to_msk_d[kMaxBsk];
+  MulOpD inv_B_mod_msk_d;
+  double B_mod_q_d[kMaxKey];
+
   // split multiply: residue indices (0..K+S-1) handled by the FP64 / integer middle kernel
   unsigned char mid_res_d[kMaxMod];
   unsigned char mid_res_i[kMaxMod];

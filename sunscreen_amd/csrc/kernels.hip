@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
   const MulOp* tw = twbase + (size_t)m * Sh::N;
   if (dm.use_f64) {
     MulOpD sc = dm.ninv_d;
-    if (scale_mode == 1) sc = ctx->intt_scale_q_d[m];  // f64 moduli are key-level primes
+    if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q_d[m] : ctx->intt_scale_bsk_d[m - ctx->KK];
     ntt_inv_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), sc, x, reinterpret_cast<double*>(smem_raw), tid);
   } else {
     MulOp sc = dm.ninv;
@@ -328,6 +328,16 @@ __global__ __launch_bounds__(kCoefThreads) void behz_extend_kernel(const DevCtx*
       dst[(size_t)i * n + k] = x[i];
     }
   }
+  if (ctx->aux_f64) {  // the library's own FP64 auxiliary base (context.cpp): exact double arithmetic, canonical words out
+    double xd[KMAX], ed[KMAX + 2];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) xd[i] = (u32)i < K ? ArithD::from_u64(x[i]) : 0.0;
+    behz_extend_coeff_d<KMAX>(ctx, xd, ed);
+#pragma unroll
+    for (int j = 0; j < KMAX + 2; j++)
+      if ((u32)j < S) dst[(size_t)(K + j) * n + k] = ArithD(ctx->mod[ctx->KK + j]).to_u64(ed[j]);
+    return;
+  }
   behz_extend_coeff<KMAX>(ctx, x, e);
 #pragma unroll
   for (int j = 0; j < KMAX + 2; j++)
@@ -379,7 +389,16 @@ __global__ __launch_bounds__(kCoefThreads) void behz_floor_sk_kernel(const DevCt
 #pragma unroll
   for (int j = 0; j < KMAX + 2; j++)
     if ((u32)j < S) xb[j] = d[(size_t)(K + j) * n + k];
-  behz_floor_sk_coeff<KMAX>(ctx, y, xb, r);
+  if (ctx->aux_f64) {
+    double yd[KMAX], xd[KMAX + 2];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) yd[i] = (u32)i < K ? ArithD::from_u64(y[i]) : 0.0;
+#pragma unroll
+    for (int j = 0; j < KMAX + 2; j++) xd[j] = (u32)j < S ? ArithD::from_u64(xb[j]) : 0.0;
+    behz_floor_sk_coeff_d<KMAX>(ctx, yd, xd, r);
+  } else {
+    behz_floor_sk_coeff<KMAX>(ctx, y, xb, r);
+  }
   u64* o = out + (size_t)poly * K * n;
 #pragma unroll
   for (int i = 0; i < KMAX; i++)

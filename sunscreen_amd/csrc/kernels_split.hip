@@ -566,7 +566,9 @@ __device__ __forceinline__ void head_fwd8(const A& ar, typename A::V (&v)[8], co
 }
 
 // mul head: grid (N/8/256, 4 polys (a0,a1,b0,b1), ops); ext = [ops][4][K+S][N] in native representation
-template <int L, int KMAX>
+// AUXD (DevCtx::aux_f64): every residue, auxiliary base included, takes the FP64 policy and the base extension
+// itself runs in FP64 (behz_extend_coeff_d).
+template <int L, int KMAX, bool AUXD>
 __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
                                                                 u64* __restrict__ ext) {
@@ -576,6 +578,53 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   const u64* src = (poly < 2 ? in0 + ((size_t)op * 2 + poly) * K * N : in1 + ((size_t)op * 2 + (poly - 2)) * K * N) + t;
   u64* dst = ext + ((size_t)op * 4 + poly) * R * N + t;
+  if constexpr (AUXD) {
+    double x[KMAX][8];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) x[i][k] = (u32)i < K ? ArithD::from_u64(src[(size_t)i * N + (size_t)k * Q]) : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+      if ((u32)i < K) {
+        const ArithD ar(ctx->mod[i]);
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = x[i][k];
+        head_fwd8(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)i * N));
+        double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+      }
+    }
+    double ev[KMAX + 2][8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      double xr[KMAX], er[KMAX + 2];
+#pragma unroll
+      for (int i = 0; i < KMAX; i++) xr[i] = x[i][k];
+#pragma unroll
+      for (int j = 0; j < KMAX + 2; j++) er[j] = 0.0;
+      behz_extend_coeff_d<KMAX>(ctx, xr, er);
+#pragma unroll
+      for (int j = 0; j < KMAX + 2; j++) ev[j][k] = er[j];
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX + 2; j++) {
+      if ((u32)j < S) {
+        const ArithD ar(ctx->mod[KK + j]);
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = ev[j][k];
+        head_fwd8(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N));
+        double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+      }
+    }
+    return;
+  }
   u64 x[KMAX][8];
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
@@ -777,8 +826,30 @@ __device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V
   for (int k = 0; k < 4; k++) out[k] = ar.scale_canonical(v[k], sc);
 }
 
+// the same for the FP64 epilogue: reduced doubles out (|out| <= q/2)
+__device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const double* __restrict__ src, size_t Q, const MulOpD* __restrict__ tw,
+                                                  const MulOpD& sc, u32 mask, double (&out)[4]) {
+  double v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = src[(size_t)k * Q];
+  if ((mask >> 8) & 1u) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
+  }
+  if ((mask >> 24) & 1u) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
+  }
+  ar.inv(v[0], v[1], tw[2]);
+  ar.inv(v[2], v[3], tw[3]);
+  ar.inv(v[0], v[2], tw[1]);
+  ar.inv(v[1], v[3], tw[1]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[k] = ar.reduce(ar.mul_const(v[k], sc));
+}
+
 // mul tail: grid (N/4/256, 3 polys, ops); out = [ops][3][K][N] canonical
-template <int L, int KMAX>
+template <int L, int KMAX, bool AUXD>
 __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                 const u64* __restrict__ D, u64* __restrict__ out) {
   constexpr u32 N = 1u << L, Q = N >> kTailLog;
@@ -786,22 +857,64 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
   const u32 poly = blockIdx.y, op = blockIdx.z;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   const u64* d = D + ((size_t)op * 3 + poly) * R * N + t;
+  u64* o = out + ((size_t)op * 3 + poly) * K * N + t;
+  if constexpr (AUXD) {
+    double y[4][KMAX], xb[4][KMAX + 2];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+      if ((u32)i < K) {
+        const DevMod& dm = ctx->mod[i];
+        double r4[4];
+        tail_inv4_scale_d(ArithD(dm), reinterpret_cast<const double*>(d + (size_t)i * N), Q,
+                          reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) y[k][i] = r4[k];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX + 2; j++) {
+      if ((u32)j < S) {
+        const DevMod& dm = ctx->mod[KK + j];
+        double r4[4];
+        tail_inv4_scale_d(ArithD(dm), reinterpret_cast<const double*>(d + (size_t)(K + j) * N), Q,
+                          reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j], dm.split_inv_mask, r4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) xb[k][j] = r4[k];
+      }
+    }
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+      u64 r[KMAX];
+      behz_floor_sk_coeff_d<KMAX>(ctx, y[0], xb[0], r);
+#pragma unroll
+      for (int i = 0; i < KMAX; i++)
+        if ((u32)i < K) o[(size_t)i * N + (size_t)k * Q] = r[i];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+#pragma unroll
+        for (int i = 0; i < KMAX; i++) y[kk][i] = y[kk + 1][i];
+#pragma unroll
+        for (int j = 0; j < KMAX + 2; j++) xb[kk][j] = xb[kk + 1][j];
+      }
+    }
+    return;
+  }
   u64 y[4][KMAX], xb[4][KMAX + 2];
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
     if ((u32)i < K) {
       const DevMod& dm = ctx->mod[i];
-      u64 o[4];
+      u64 r4[4];
       if (residue_is_f64(dm)) {
         const ArithD ar(dm);
         tail_inv4_scale(ar, reinterpret_cast<const double*>(d + (size_t)i * N), Q, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
-                        ctx->intt_scale_q_d[i], dm.split_inv_mask, o);
+                        ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
       } else {
         const ArithI ar(dm);
-        tail_inv4_scale(ar, d + (size_t)i * N, Q, twi_base + (size_t)i * N, ctx->intt_scale_q[i], 0u, o);
+        tail_inv4_scale(ar, d + (size_t)i * N, Q, twi_base + (size_t)i * N, ctx->intt_scale_q[i], 0u, r4);
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) y[k][i] = o[k];
+      for (int k = 0; k < 4; k++) y[k][i] = r4[k];
     }
   }
 #pragma unroll
@@ -809,13 +922,12 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
     if ((u32)j < S) {
       const DevMod& dm = ctx->mod[KK + j];
       const ArithI ar(dm);
-      u64 o[4];
-      tail_inv4_scale(ar, d + (size_t)(K + j) * N, Q, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], 0u, o);
+      u64 r4[4];
+      tail_inv4_scale(ar, d + (size_t)(K + j) * N, Q, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], 0u, r4);
 #pragma unroll
-      for (int k = 0; k < 4; k++) xb[k][j] = o[k];
+      for (int k = 0; k < 4; k++) xb[k][j] = r4[k];
     }
   }
-  u64* o = out + ((size_t)op * 3 + poly) * K * N + t;
   // The per-coefficient epilogue is too large to unroll four times; a rolled loop must not index y/xb by k
   // (dynamic indexing puts them in scratch), so each trip consumes row 0 and the rows rotate down.
 #pragma unroll 1
@@ -962,7 +1074,7 @@ __global__ __launch_bounds__(kHeadThreads) void ntt_tail_kernel(const DevCtx* __
   u64 o[4];
   if (residue_is_f64(dm)) {
     const ArithD ar(dm);
-    const MulOpD sc = scale_mode == 1 ? ctx->intt_scale_q_d[m] : dm.ninv_d;
+    const MulOpD sc = scale_mode == 1 ? (m < ctx->KK ? ctx->intt_scale_q_d[m] : ctx->intt_scale_bsk_d[m - ctx->KK]) : dm.ninv_d;
     tail_inv4_scale(ar, reinterpret_cast<const double*>(x), Q, reinterpret_cast<const MulOpD*>(tw), sc, dm.split_inv_mask, o);
   } else {
     const ArithI ar(dm);
@@ -1047,12 +1159,18 @@ hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u
 }
 
 template <int L>
-static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, const u64* a, const u64* b, u64* ext, size_t ops, hipStream_t s) {
-  mul_head_kernel<L, 4><<<dim3((1u << L) / 8 / kHeadThreads, 4, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, const u64* a, const u64* b, u64* ext, size_t ops, hipStream_t s) {
+  const dim3 grid((1u << L) / 8 / kHeadThreads, 4, (unsigned)ops);
+  if (aux_f64)
+    mul_head_kernel<L, 4, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+  else
+    mul_head_kernel<L, 4, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   return hipGetLastError();
 }
-hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, const u64* a, const u64* b, u64* ext, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mul_head_t, ctx, twf, a, b, ext, ops, s)
+// aux_f64: DevCtx::aux_f64 of the context behind `ctx` (selects the all-FP64 instantiation)
+hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, const u64* a, const u64* b, u64* ext, size_t ops,
+                           hipStream_t s) {
+  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, a, b, ext, ops, s)
 }
 
 template <int L>
@@ -1070,12 +1188,16 @@ hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi,
 }
 
 template <int L>
-static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, const u64* D, u64* out, size_t ops, hipStream_t s) {
-  mul_tail_kernel<L, 4><<<dim3((1u << L) / 4 / kHeadThreads, 3, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twi, D, out);
+static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, const u64* D, u64* out, size_t ops, hipStream_t s) {
+  const dim3 grid((1u << L) / 4 / kHeadThreads, 3, (unsigned)ops);
+  if (aux_f64)
+    mul_tail_kernel<L, 4, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+  else
+    mul_tail_kernel<L, 4, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
   return hipGetLastError();
 }
-hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* D, u64* out, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mul_tail_t, ctx, twi, D, out, ops, s)
+hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, const u64* D, u64* out, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, D, out, ops, s)
 }
 
 }  // namespace hipbfv

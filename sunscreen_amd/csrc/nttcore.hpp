@@ -48,7 +48,7 @@ struct ArithI {
   // products of lazy operands (< 4q each): canonical results
   __device__ __forceinline__ V mul_var(V a, V b) const { return reduce128_fast((u128)a * b, *dm); }
   __device__ __forceinline__ V mul_add(V a, V b, V c) const { return reduce128_fast((u128)a * b + c, *dm); }
-  __device__ __forceinline__ V from_u64(u64 x) const { return x; }
+  static __device__ __forceinline__ V from_u64(u64 x) { return x; }
   __device__ __forceinline__ V reduce(V v) const { return v; }  // lazy invariants hold without it
   // forward: X,Y in [0,4q) -> [0,4q)
   __device__ __forceinline__ void fwd(V& X, V& Y, const Tw& w) const {
@@ -78,7 +78,7 @@ struct ArithD {
   using Tw = MulOpD;
   double q, qinv;
   __device__ __forceinline__ explicit ArithD(const DevMod& m) : q(m.qd), qinv(m.qinv) {}
-  __device__ __forceinline__ V from_u64(u64 x) const {
+  static __device__ __forceinline__ V from_u64(u64 x) {
     // exact for x < 2^52: plant the integer in the mantissa of 2^52 and subtract 2^52
     return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0;
   }
@@ -107,9 +107,12 @@ struct ArithD {
     X = u + y;
     Y = mul_const(u - y, w);
   }
+  static __device__ __forceinline__ u64 to_bits(V v) {  // v an integer in [0, 2^52)
+    return (u64)__double_as_longlong(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
+  }
   __device__ __forceinline__ u64 to_u64(V v) const {  // v an integer in (-q, q)
     v = v < 0.0 ? v + q : v;
-    return (u64)__double_as_longlong(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
+    return to_bits(v);
   }
   __device__ __forceinline__ u64 canonical(V v) const { return to_u64(reduce(v)); }
   __device__ __forceinline__ u64 scale_canonical(V v, const Tw& sc) const { return to_u64(reduce(mul_const(v, sc))); }

@@ -119,13 +119,29 @@ def test_config3_mul_relin_full_batch_properties():
     assert torch.equal(ev.negate(ev.negate(a)), a)
 
 
+def _extreme_rows(primes, K, n):
+    """Operand pairs at the edges of the BEHZ bounds: every residue q_i - 1, all zero, and alternating."""
+    import numpy as np
+
+    hi = np.stack([np.full((2, n), q - 1, dtype=np.int64) for q in primes[:K]], axis=1)  # [2, K, n]
+    zero = np.zeros_like(hi)
+    alt = hi.copy()
+    alt[:, :, ::2] = 0
+    one = np.zeros_like(hi)
+    one[:, :, 0] = 1
+    return np.stack([hi, hi, alt, zero, one]), np.stack([hi, alt, alt, hi, hi])
+
+
 def test_split_and_whole_polynomial_paths_agree():
     """The head/middle/tail kernels and the whole-polynomial kernels are two implementations of the same
-    arithmetic: run the same inputs through both (second process with the split paths disabled)."""
+    arithmetic, and the library's own FP64 auxiliary base must give the same bits as SEAL's 61-bit base:
+    run the same inputs (random pairs plus operands at the edges of the BEHZ bounds) through every variant in
+    separate processes, and check the edge cases against the oracle (which always uses SEAL's base)."""
     script = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
 from tests.bfv_helpers import params
+from tests.test_gpu_properties import _extreme_rows
 from sunscreen_amd import Context, RelinearizationKeys, GaloisKeys
 from sunscreen_amd.batch import BatchEvaluator
 from oracle import bfv_oracle as O
@@ -137,21 +153,48 @@ a = torch.empty((9, 2, ctx.K, n), dtype=torch.int64, device="cuda:0"); b = torch
 for i, q in enumerate(primes[:ctx.K]):
     a[:, :, i, :] = torch.randint(0, q, (9, 2, n), generator=gen, device="cuda:0", dtype=torch.int64)
     b[:, :, i, :] = torch.randint(0, q, (9, 2, n), generator=gen, device="cuda:0", dtype=torch.int64)
+xa, xb = _extreme_rows(primes, ctx.K, n)
+a = torch.cat([a, torch.from_numpy(xa).cuda()]); b = torch.cat([b, torch.from_numpy(xb).cuda()])
 r = ev.multiply_relin(a, b, RelinearizationKeys.from_array(ctx, rk))
+m = ev.multiply(a, b)
 g = ev.apply_galois(a, 3, GaloisKeys.from_arrays(ctx, gk))
 torch.cuda.synchronize()
-np.save(sys.argv[1], np.concatenate([r.cpu().numpy().ravel(), g.cpu().numpy().ravel()]))
+np.save(sys.argv[1], np.concatenate([r.cpu().numpy().ravel(), m.cpu().numpy().ravel(), g.cpu().numpy().ravel()]))
 """ % ROOT
     import tempfile
 
+    variants = (
+        ("split", {}),
+        ("whole", {"HIPBFV_NO_SPLIT_MUL": "1", "HIPBFV_NO_SPLIT_KS": "1"}),
+        ("seal_aux", {"HIPBFV_SEAL_AUX": "1"}),
+        ("seal_aux_whole", {"HIPBFV_SEAL_AUX": "1", "HIPBFV_NO_SPLIT_MUL": "1", "HIPBFV_NO_SPLIT_KS": "1"}),
+        ("int", {"HIPBFV_NO_F64": "1", "HIPBFV_NO_PM61": "1"}),
+    )
     outs = []
     with tempfile.TemporaryDirectory() as td:
-        for tag, env in (("split", {}), ("whole", {"HIPBFV_NO_SPLIT_MUL": "1", "HIPBFV_NO_SPLIT_KS": "1"}), ("int", {"HIPBFV_NO_F64": "1", "HIPBFV_NO_PM61": "1"})):
+        for tag, env in variants:
             path = os.path.join(td, tag + ".npy")
             subprocess.check_call([sys.executable, "-c", script, path], env=dict(os.environ, **env))
             outs.append(np.load(path))
-    assert (outs[0] == outs[1]).all()
-    assert (outs[0] == outs[2]).all()
+    for (tag, _), out in zip(variants[1:], outs[1:]):
+        assert (outs[0] == out).all(), tag
+    # the edge-case pairs against the oracle
+    from oracle import bfv_oracle as O
+    from tests.bfv_helpers import params
+
+    n, primes, t = params("default_8192_17")
+    o = O.Oracle(n, primes, t)
+    O.seed(9)
+    sk, pk, rk, gk = o.keygen(galois_elts=[3])
+    K = len(primes) - 1
+    xa, xb = _extreme_rows(primes, K, n)
+    count = 9 + len(xa)
+    r = outs[0][: count * 2 * K * n].reshape(count, 2, K, n)
+    m = outs[0][count * 2 * K * n : count * 5 * K * n].reshape(count, 3, K, n)
+    for i in range(len(xa)):
+        om = o.multiply(xa[i].astype(np.uint64), xb[i].astype(np.uint64))
+        assert (m[9 + i].astype(np.uint64) == om).all(), i
+        assert (r[9 + i].astype(np.uint64) == o.relinearize(om, rk)).all(), i
 
 
 def test_concurrent_host_threads_on_one_evaluator():
