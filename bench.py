@@ -244,8 +244,8 @@ def main():
 
 
 def ctx_S(ctx):
-    # |Bsk| = |B| + 1 with |B| = K (+1 when K*61 bits are not enough; never for the default parameter sets)
-    return ctx.K + 1
+    # |Bsk| of the context's auxiliary base (hipbfv_Context_AuxBase)
+    return len(ctx.aux_primes)
 
 
 def cpu_baseline(args, O, n, primes, t):

@@ -142,6 +142,11 @@ long hipbfv_Context_Create(uint64_t poly_modulus_degree, const uint64_t *coeff_m
 long hipbfv_Context_Info(void *context, uint64_t *poly_modulus_degree, uint64_t *data_primes, uint64_t *key_primes,
                          uint64_t *plain_modulus);
 long hipbfv_Context_GetPrime(void *context, uint64_t index, uint64_t *value); /* key-level prime `index` */
+/* The BEHZ auxiliary base Bsk = B u {m_sk} this context multiplies in (internal to Evaluator_Multiply; SEAL's
+ * RNSTool keeps its own privately, native/src/seal/util/rns.h).  *fp64_base = 1 when the library chose its own
+ * FP64-pipe primes (same size bound as SEAL's rule, bit-identical products), 0 when it uses SEAL's 61-bit primes.
+ * primes may be NULL; otherwise capacity >= *count words, B first, m_sk last. */
+long hipbfv_Context_AuxBase(void *context, uint64_t *count, uint64_t *primes, uint64_t capacity, int *fp64_base);
 
 /* Raw-array import/export for handles (host memory; stands in for X_Load/X_Save until the SEAL wire
  * format lands -- SURVEY 8f row 2) */

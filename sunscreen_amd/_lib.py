@@ -103,6 +103,7 @@ _SIGNATURES = {
     "hipbfv_Context_Create": [u64, u64p, u64, u64, vpp],
     "hipbfv_Context_Info": [vp, u64p, u64p, u64p, u64p],
     "hipbfv_Context_GetPrime": [vp, u64, u64p],
+    "hipbfv_Context_AuxBase": [vp, u64p, u64p, u64, C.POINTER(C.c_int)],
     "hipbfv_Ciphertext_Assign": [vp, vp, u64, u64p],
     "hipbfv_Ciphertext_Export": [vp, u64p, u64],
     "hipbfv_Ciphertext_DevicePtr": [vp, C.POINTER(u64p)],

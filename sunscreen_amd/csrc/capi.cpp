@@ -473,6 +473,19 @@ long hipbfv_Context_GetPrime(void* h, uint64_t index, uint64_t* value) {
   return HIPBFV_S_OK;
 }
 
+long hipbfv_Context_AuxBase(void* h, uint64_t* count, uint64_t* primes, uint64_t capacity, int* fp64_base) {
+  ContextObj* c = as<ContextObj>(h, kMagicContext);
+  if (!c || !count) return HIPBFV_E_POINTER;
+  const hipbfv::DevCtx& d = c->ctx->host();
+  *count = d.S;
+  if (fp64_base) *fp64_base = d.aux_f64 ? 1 : 0;
+  if (primes) {
+    if (capacity < d.S) return fail(HIPBFV_E_INVALIDARG, "capacity too small");
+    for (uint32_t j = 0; j < d.S; j++) primes[j] = d.mod[d.KK + j].q;
+  }
+  return HIPBFV_S_OK;
+}
+
 // ------------------------------------------------------------------ Plaintext
 long Plaintext_Create1(void* pool, void** out) {
   (void)pool;

@@ -427,6 +427,9 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       B.assign(pick.begin() + 1, pick.end());
     }
   }
+  // the split multiply (kernels_split.hip) is instantiated for at most 4 data and 6 auxiliary primes: a large plain
+  // modulus can make the own base longer than that, and then SEAL's shorter 61-bit base keeps the faster pipeline
+  if (own_base && K <= 4 && h.logn >= 12 && h.logn <= 14 && B.size() + 1 > 6) own_base = false;
   if (own_base) {
     h.nB = (u32)B.size();
   } else {

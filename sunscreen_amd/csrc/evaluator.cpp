@@ -232,7 +232,9 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   for (u32 i = 0; i < K; i++) mods.push_back(i);
   for (u32 j = 0; j < S; j++) mods.push_back(h.KK + j);
   const NttPlan plan = make_plan(1, mods);
-  const bool split = split_mul_ && sa == 2 && sb == 2 && K <= 4 && h.logn >= 12 && h.logn <= 14;
+  // the per-coefficient kernels are instantiated for KMAX data primes and KMAX + 2 auxiliary primes
+  const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
+  const bool split = split_mul_ && sa == 2 && sb == 2 && kneed <= 4 && h.logn >= 12 && h.logn <= 14;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     if (split) {
@@ -242,11 +244,11 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
       HB_LAUNCH(kKernMulTail, c * 3, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, h.aux_f64 != 0, D, out + off * 3 * K * n, c, s));
       continue;
     }
-    HB_LAUNCH(kKernBehzExtend, c * (sa + sb), launch_behz_extend(ctx_->dev(), n, K, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));
+    HB_LAUNCH(kKernBehzExtend, c * (sa + sb), launch_behz_extend(ctx_->dev(), n, kneed, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));
     HB_LAUNCH(kKernNttFwd, c * (sa + sb) * R, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, ext, c * (sa + sb) * R, plan, false, 0, s));
     HB_LAUNCH(kKernTensor, c, launch_tensor(ctx_->dev(), n, R, ext, sa, sb, D, c, s));
     HB_LAUNCH(kKernNttInv, c * sd * R, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, D, c * sd * R, plan, true, 1, s));
-    HB_LAUNCH(kKernBehzFloorSk, c * sd, launch_behz_floor_sk(ctx_->dev(), n, K, D, out + off * sd * K * n, c * sd, s));
+    HB_LAUNCH(kKernBehzFloorSk, c * sd, launch_behz_floor_sk(ctx_->dev(), n, kneed, D, out + off * sd * K * n, c * sd, s));
   }
   return kOk;
 }

@@ -709,6 +709,7 @@ static void launch_extend_t(const DevCtx* ctx, u32 n, const u64* in0, u32 sa, co
   behz_extend_kernel<KMAX><<<coef_grid(n, (u32)(ops * (sa + sb))), kCoefThreads, 0, s>>>(ctx, in0, sa, in1, sb, out);
 }
 
+// K here: max(data primes, auxiliary primes - 2), selects the instantiation
 hipError_t launch_behz_extend(const DevCtx* ctx, u32 n, u32 K, const u64* in0, u32 sa, const u64* in1, u32 sb, size_t ops, u64* out, hipStream_t s) {
   if (K <= 4)
     launch_extend_t<4>(ctx, n, in0, sa, in1, sb, ops, out, s);

@@ -295,14 +295,8 @@ constexpr int kHeadThreads = 256;
 #ifndef MID_WAVES_I
 #define MID_WAVES_I 3
 #endif
-#ifndef KS_MID_PREFETCH
-#define KS_MID_PREFETCH 0
-#endif
 #ifndef KS_MID_WAVES
 #define KS_MID_WAVES 3
-#endif
-#ifndef MID_PREFETCH_D
-#define MID_PREFETCH_D false
 #endif
 
 // -------------------------------------------------------------------------------------------------
@@ -404,30 +398,16 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
     }
   };
   double v[kBlkEPT];
-#if KS_MID_PREFETCH >= 2
-  double vn[kBlkEPT];
-  load_src(0, v);
-#endif
   for (u32 J = 0; J < K; J++) {
     ulonglong2 ka[kBlkEPT / 2], kc[kBlkEPT / 2];
-#if KS_MID_PREFETCH >= 2
-    load_keys(J, ka, kc);
-    if (J + 1 < K) load_src(J + 1, vn);
-#elif KS_MID_PREFETCH == 1
     load_src(J, v);
-    load_keys(J, ka, kc);  // in flight during the transform (barriers only wait on LDS traffic)
-#else
-    load_src(J, v);
-#endif
     if (J > 0) __syncthreads();  // the previous transform's last pass may still be reading LDS
     // The twiddles do not depend on J: without this the compiler hoists every twiddle load of all passes out
     // of the loop and keeps ~100 registers of them alive (spilling to scratch).  Re-materialise the pointer.
     const MulOpD* twf_j = twf;
     asm volatile("" : "+s"(twf_j));
     mid_forward<A, L, 0>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
-#if KS_MID_PREFETCH == 0
     load_keys(J, ka, kc);
-#endif
 #pragma unroll
     for (int h = 0; h < kBlkEPT / 2; h++) {
       const int e = 2 * h;
@@ -440,10 +420,6 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
       reduce_all(ar, acc0);
       reduce_all(ar, acc1);
     }
-#if KS_MID_PREFETCH >= 2
-#pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) v[e] = vn[e];
-#endif
   }
   reduce_all(ar, acc0);
   reduce_all(ar, acc1);
@@ -688,7 +664,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
 }
 
 // mul middle body for one (op, residue, block)
-template <class A, int L, bool PREFETCH>
+template <class A, int L>
 __device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi, const typename A::V* ext_r,
                                              size_t poly_stride, typename A::V* D_r, size_t dpoly_stride, typename A::V* smem,
                                              typename A::V* park, u32 tid, u32 blk) {
@@ -711,51 +687,25 @@ __device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A:
     const typename A::Tw* tw = opaque_uniform(twf);  // keep the twiddle loads inside this transform
     mid_forward<A, L, 0>(ar, dst, smem, tid, blk, tw, dm.split_fwd_mask);
   };
-  if constexpr (PREFETCH) {
-    // The loads of the next polynomial are in flight while the current one is transformed (barriers only wait
-    // on LDS traffic); costs one more 8-element array.
-    typename A::V w[kBlkEPT];
-    issue(0, v);
-    issue(1, a1);
-    fwd(v, false);  // a0 -> parked in LDS (thread-private slots)
+  issue(0, v);
+  fwd(v, false);  // a0 -> parked in LDS (thread-private slots)
 #pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB + tid] = v[e];
-    issue(2, v);
-    fwd(a1, true);
-    issue(3, w);
-    fwd(v, true);  // b0
+  for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB + tid] = v[e];
+  issue(1, a1);
+  fwd(a1, true);
+  issue(2, v);
+  fwd(v, true);  // b0
 #pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) {
-      d0[e] = ar.mul_var(park[e * Sh::TPB + tid], v[e]);
-      d1[e] = ar.mul_var(a1[e], v[e]);
-    }
-    fwd(w, true);  // b1
+  for (int e = 0; e < kBlkEPT; e++) {
+    d0[e] = ar.mul_var(park[e * Sh::TPB + tid], v[e]);
+    d1[e] = ar.mul_var(a1[e], v[e]);
+  }
+  issue(3, v);
+  fwd(v, true);  // b1
 #pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) {
-      d1[e] = ar.mul_add(park[e * Sh::TPB + tid], w[e], d1[e]);
-      a1[e] = ar.mul_var(a1[e], w[e]);  // d2
-    }
-  } else {
-    issue(0, v);
-    fwd(v, false);  // a0 -> parked in LDS (thread-private slots)
-#pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB + tid] = v[e];
-    issue(1, a1);
-    fwd(a1, true);
-    issue(2, v);
-    fwd(v, true);  // b0
-#pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) {
-      d0[e] = ar.mul_var(park[e * Sh::TPB + tid], v[e]);
-      d1[e] = ar.mul_var(a1[e], v[e]);
-    }
-    issue(3, v);
-    fwd(v, true);  // b1
-#pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) {
-      d1[e] = ar.mul_add(park[e * Sh::TPB + tid], v[e], d1[e]);
-      a1[e] = ar.mul_var(a1[e], v[e]);  // d2
-    }
+  for (int e = 0; e < kBlkEPT; e++) {
+    d1[e] = ar.mul_add(park[e * Sh::TPB + tid], v[e], d1[e]);
+    a1[e] = ar.mul_var(a1[e], v[e]);  // d2
   }
   auto inv_store = [&](typename A::V(&d)[kBlkEPT], int poly) {
     __syncthreads();
@@ -796,11 +746,11 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D : MID
   const MulOp* twf = twf_base + (size_t)m * Sh::N;
   const MulOp* twi = twi_base + (size_t)m * Sh::N;
   if constexpr (POLICY_D)
-    mul_mid_body<ArithD, L, MID_PREFETCH_D>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
+    mul_mid_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                             reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                             reinterpret_cast<double*>(smem), reinterpret_cast<double*>(park), tid, blk);
   else
-    mul_mid_body<ArithI, L, false>(dm, twf, twi, ext_r, ps, D_r, ps, smem, park, tid, blk);
+    mul_mid_body<ArithI, L>(dm, twf, twi, ext_r, ps, D_r, ps, smem, park, tid, blk);
 }
 
 // last two inverse stages + BEHZ scaling on {t + k*N/4}: canonical residues out

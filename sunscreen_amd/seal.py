@@ -236,6 +236,12 @@ class Context:
         for i in range(self.KK):
             _check(_lib.load().hipbfv_Context_GetPrime(self._h, i, C.byref(v)))
             self.key_primes.append(v.value)
+        cnt, own = C.c_uint64(), C.c_int()
+        _check(_lib.load().hipbfv_Context_AuxBase(self._h, C.byref(cnt), None, 0, C.byref(own)))
+        buf = (C.c_uint64 * cnt.value)()
+        _check(_lib.load().hipbfv_Context_AuxBase(self._h, C.byref(cnt), buf, cnt.value, C.byref(own)))
+        self.aux_primes = list(buf)  # B..., m_sk (internal to multiply; see include/hipbfv.h)
+        self.aux_fp64 = bool(own.value)
 
     def get_handle(self):
         return self._h

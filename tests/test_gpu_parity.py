@@ -372,6 +372,56 @@ def test_multiply_edge_parameter_sets(n, bits, tbits):
             RelinearizationKeys.from_array(ctx, np.zeros((1, 2, 1, n), dtype=np.uint64))
 
 
+def test_auxiliary_base_choice_and_bound():
+    """The BEHZ auxiliary base is internal to multiply.  FP64-capable data primes -> the library's own base of
+    primes below 2^48 whose product covers the same bound SEAL sizes its base for (2^(32 + bits(t) + bits(q)));
+    wide data primes -> SEAL's own 61-bit base, identical to the oracle's."""
+    from sunscreen_amd import Context
+
+    n, primes, t = params("default_8192_17")
+    ctx = Context.from_raw(n, primes, t)
+    assert ctx.aux_fp64 and len(ctx.aux_primes) >= 2
+    q = 1
+    for p in primes[:-1]:
+        q *= p
+    prod = 1
+    for p in ctx.aux_primes:
+        assert p < 2**48 and p % (2 * n) == 1 and p not in primes and O.is_prime(p)
+        prod *= p
+    assert len(set(ctx.aux_primes)) == len(ctx.aux_primes)
+    assert prod.bit_length() > 32 + t.bit_length() + q.bit_length()
+    wide = O.coeff_modulus_create(4096, [58, 59, 60])
+    ctx2 = Context.from_raw(4096, wide, O.plain_batching(4096, 16))
+    o2 = O.Oracle(4096, wide, O.plain_batching(4096, 16))
+    assert not ctx2.aux_fp64 and ctx2.aux_primes == [int(p) for p in o2.bsk]
+
+
+@pytest.mark.parametrize("n,tbits", [(8192, 40), (8192, 50), (4096, 30), (16384, 45)])
+def test_multiply_large_plain_modulus_own_base(n, tbits):
+    """Large plain moduli push the integers that pass through the auxiliary base towards its size bound
+    (floor(t*c/q) grows with t): the own-base product must still equal the oracle's (SEAL-base) product, on
+    random operands and on operands with every residue at q_i - 1."""
+    from sunscreen_amd import Context
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    primes = O.bfv_default(n)
+    t = O.plain_batching(n, tbits)
+    o = O.Oracle(n, primes, t)
+    ctx = Context.from_raw(n, primes, t)
+    assert ctx.aux_fp64
+    ev = BatchEvaluator(ctx)
+    K = len(primes) - 1
+    rng = np.random.default_rng(tbits)
+    a = np.stack([rng.integers(0, q, (3, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    b = np.stack([rng.integers(0, q, (3, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    for i, q in enumerate(primes[:K]):
+        a[2, :, i, :] = q - 1
+        b[2, :, i, :] = q - 1
+    m = to_host(ev.multiply(to_device(a), to_device(b)))
+    for i in range(3):
+        assert (m[i] == o.multiply(a[i], b[i])).all(), i
+
+
 def test_largest_degree_n32768_two_kernel_ntt():
     """n = 32768 (SEAL default: 16 primes, K = 15): residue polynomials (256 KB) exceed one CU's LDS, so the
     transforms run as two kernels each (head + block-local / block-local + tail).  sunscreen/src/params.rs:37
