@@ -148,8 +148,7 @@ long hipbfv_Context_GetPrime(void *context, uint64_t index, uint64_t *value); /*
  * primes may be NULL; otherwise capacity >= *count words, B first, m_sk last. */
 long hipbfv_Context_AuxBase(void *context, uint64_t *count, uint64_t *primes, uint64_t capacity, int *fp64_base);
 
-/* Raw-array import/export for handles (host memory; stands in for X_Load/X_Save until the SEAL wire
- * format lands -- SURVEY 8f row 2) */
+/* Raw-array import/export for handles (host memory): the no-serialisation alternative to X_Load / X_Save */
 long hipbfv_Ciphertext_Assign(void *cipher, void *context, uint64_t size, const uint64_t *host_data);
 long hipbfv_Ciphertext_Export(void *cipher, uint64_t *host_data, uint64_t capacity_words);
 long hipbfv_Ciphertext_DevicePtr(void *cipher, uint64_t **device_ptr);
