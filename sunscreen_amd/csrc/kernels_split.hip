@@ -21,6 +21,8 @@
 // FP64 path.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "behzcore.hpp"
 #include "kernels.hpp"
 #include "nttcore.hpp"
@@ -165,6 +167,12 @@ __device__ __forceinline__ void reduce_all(const A& ar, typename A::V (&v)[kBlkE
 
 // TW_PIPE_D / TW_PIPE_I (FP64 / integer policy): 0 = every pass fetches its twiddles when it needs them; 1 = the next pass's twiddles are fetched
 // before the LDS exchange that precedes it; 2 = before the current pass's butterflies (needs both sets live).
+#ifndef MID_BATCHED_D
+#define MID_BATCHED_D true
+#endif
+#ifndef MID_BATCHED_I
+#define MID_BATCHED_I false
+#endif
 #ifndef TW_PIPE_D
 #define TW_PIPE_D 1
 #endif
@@ -288,6 +296,88 @@ __device__ __forceinline__ void mid_inverse(const A& ar, typename A::V (&v)[kBlk
   }
 }
 
+// The same transforms for NP polynomials of one (residue, block) at once, pass by pass: one barrier and one set
+// of twiddle fetches per pass serves all NP polynomials, their butterflies are independent instruction streams
+// the scheduler can interleave, and the NP global loads / stores are in flight together.  smem: NP regions of
+// BLOCK elements.
+template <class A, int L, int P, int NP>
+__device__ __forceinline__ void mid_forward_multi_p(const A& ar, typename A::V (&v)[NP][kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+                                                    const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[kBlkEPT - 1]) {
+  using Sh = SplitShape<L>;
+  constexpr int R = split_fwd_radix(L, P);
+  constexpr int LOW = split_fwd_low(L, P);
+  using Pass = BlkPass<A, L, LOW, R>;
+  constexpr bool more = P + 1 < Sh::NPF;
+  constexpr int PN = more ? P + 1 : P;
+  using Next = BlkPass<A, L, split_fwd_low(L, PN), split_fwd_radix(L, PN)>;
+  typename A::Tw wn[kBlkEPT - 1];
+  if constexpr (P > 0) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NP; i++) Pass::load_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
+  }
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
+    if ((mask >> P) & 1u) reduce_all(ar, v[i]);
+    if ((mask >> (P + 16)) & 1u) reduce_all(ar, v[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NP; i++) Pass::fwd_tw(ar, v[i], w);
+  if constexpr (more) {
+    Next::load_tw_fwd(wn, tid, blk, tw);
+#pragma unroll
+    for (int i = 0; i < NP; i++) Pass::store_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
+    mid_forward_multi_p<A, L, PN, NP>(ar, v, smem, tid, blk, tw, mask, wn);
+  }
+}
+template <class A, int L, int NP>
+__device__ __forceinline__ void mid_forward_multi(const A& ar, typename A::V (&v)[NP][kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+                                                  const typename A::Tw* tw, u32 mask) {
+  using Pass = BlkPass<A, L, split_fwd_low(L, 0), split_fwd_radix(L, 0)>;
+  typename A::Tw w[kBlkEPT - 1];
+  Pass::load_tw_fwd(w, tid, blk, tw);
+  mid_forward_multi_p<A, L, 0, NP>(ar, v, smem, tid, blk, tw, mask, w);
+}
+
+template <class A, int L, int P, int NP>
+__device__ __forceinline__ void mid_inverse_multi_p(const A& ar, typename A::V (&v)[NP][kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+                                                    const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[kBlkEPT - 1]) {
+  using Sh = SplitShape<L>;
+  constexpr int R = split_inv_radix(L, P);
+  constexpr int LOW = split_inv_low(L, P);
+  using Pass = BlkPass<A, L, LOW, R>;
+  constexpr bool more = P + 1 < Sh::NPI;
+  constexpr int PN = more ? P + 1 : P;
+  using Next = BlkPass<A, L, split_inv_low(L, PN), split_inv_radix(L, PN)>;
+  typename A::Tw wn[kBlkEPT - 1];
+  if constexpr (P > 0) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NP; i++) Pass::load_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
+  }
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
+    if ((mask >> P) & 1u) reduce_all(ar, v[i]);
+    if ((mask >> (P + 16)) & 1u) reduce_all(ar, v[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NP; i++) Pass::inv_tw(ar, v[i], w);
+  if constexpr (more) {
+    Next::load_tw_inv(wn, tid, blk, tw);
+#pragma unroll
+    for (int i = 0; i < NP; i++) Pass::store_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
+    mid_inverse_multi_p<A, L, PN, NP>(ar, v, smem, tid, blk, tw, mask, wn);
+  }
+}
+template <class A, int L, int NP>
+__device__ __forceinline__ void mid_inverse_multi(const A& ar, typename A::V (&v)[NP][kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+                                                  const typename A::Tw* tw, u32 mask) {
+  using Pass = BlkPass<A, L, split_inv_low(L, 0), split_inv_radix(L, 0)>;
+  typename A::Tw w[kBlkEPT - 1];
+  Pass::load_tw_inv(w, tid, blk, tw);
+  mid_inverse_multi_p<A, L, 0, NP>(ar, v, smem, tid, blk, tw, mask, w);
+}
+
 constexpr int kHeadThreads = 256;
 #ifndef MID_WAVES_D
 #define MID_WAVES_D 2
@@ -296,7 +386,7 @@ constexpr int kHeadThreads = 256;
 #define MID_WAVES_I 3
 #endif
 #ifndef KS_MID_WAVES
-#define KS_MID_WAVES 3
+#define KS_MID_WAVES 2
 #endif
 
 // -------------------------------------------------------------------------------------------------
@@ -353,7 +443,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
                                                                        const u64* __restrict__ key, double* __restrict__ ACC, u32 ops) {
   using Sh = SplitShape<L>;
   using A = ArithD;
-  __shared__ double smem[Sh::BLOCK];
+  __shared__ double smem[4 * Sh::BLOCK];
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, KK = ctx->KK;
   const u32 b = blockIdx.x;
@@ -374,9 +464,9 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
   using First = BlkPass<A, L, LOWF0, RF0>;
   constexpr int RL = split_fwd_radix(L, Sh::NPF - 1);  // last forward window: LOW = 0
   using Last = BlkPass<A, L, 0, RL>;
-  double acc0[kBlkEPT], acc1[kBlkEPT];
+  double acc[2][kBlkEPT];
 #pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) acc0[e] = 0.0, acc1[e] = 0.0;
+  for (int e = 0; e < kBlkEPT; e++) acc[0][e] = 0.0, acc[1][e] = 0.0;
   auto load_src = [&](u32 J, double(&dst)[kBlkEPT]) {
     const double* src = T + (((size_t)op * KK + I) * K + J) * Sh::N;
 #pragma unroll
@@ -397,46 +487,57 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
       }
     }
   };
-  double v[kBlkEPT];
-  for (u32 J = 0; J < K; J++) {
+  auto mac = [&](u32 J, const double(&v)[kBlkEPT]) {
     ulonglong2 ka[kBlkEPT / 2], kc[kBlkEPT / 2];
-    load_src(J, v);
-    if (J > 0) __syncthreads();  // the previous transform's last pass may still be reading LDS
-    // The twiddles do not depend on J: without this the compiler hoists every twiddle load of all passes out
-    // of the loop and keeps ~100 registers of them alive (spilling to scratch).  Re-materialise the pointer.
-    const MulOpD* twf_j = twf;
-    asm volatile("" : "+s"(twf_j));
-    mid_forward<A, L, 0>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
     load_keys(J, ka, kc);
 #pragma unroll
     for (int h = 0; h < kBlkEPT / 2; h++) {
       const int e = 2 * h;
-      acc0[e] += ar.mul_var(v[e], ar.from_u64(ka[h].x));
-      acc0[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(ka[h].y));
-      acc1[e] += ar.mul_var(v[e], ar.from_u64(kc[h].x));
-      acc1[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(kc[h].y));
+      acc[0][e] += ar.mul_var(v[e], ar.from_u64(ka[h].x));
+      acc[0][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(ka[h].y));
+      acc[1][e] += ar.mul_var(v[e], ar.from_u64(kc[h].x));
+      acc[1][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(kc[h].y));
     }
     if ((J & 3u) == 3u) {
-      reduce_all(ar, acc0);
-      reduce_all(ar, acc1);
+      reduce_all(ar, acc[0]);
+      reduce_all(ar, acc[1]);
     }
+  };
+  // digits are transformed in groups of 4 / 2 / 1, each group advanced pass by pass (mid_forward_multi)
+  auto group = [&](u32 J0, auto np_tag) {
+    constexpr int NP = decltype(np_tag)::value;
+    double v[NP][kBlkEPT];
+#pragma unroll
+    for (int i = 0; i < NP; i++) load_src(J0 + i, v[i]);
+    if (J0 > 0) __syncthreads();  // the previous group's last pass may still be reading LDS
+    // The twiddles do not depend on the group: without this the compiler hoists every twiddle load of all passes
+    // out of the loop and keeps ~100 registers of them alive.  Re-materialise the pointer.
+    const MulOpD* twf_j = twf;
+    asm volatile("" : "+s"(twf_j));
+    mid_forward_multi<A, L, NP>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
+#pragma unroll
+    for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
+  };
+  u32 J = 0;
+  for (; J + 4 <= K; J += 4) group(J, std::integral_constant<int, 4>{});
+  if (J + 2 <= K) {
+    group(J, std::integral_constant<int, 2>{});
+    J += 2;
   }
-  reduce_all(ar, acc0);
-  reduce_all(ar, acc1);
+  if (J < K) group(J, std::integral_constant<int, 1>{});
+  reduce_all(ar, acc[0]);
+  reduce_all(ar, acc[1]);
   constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
   using Out = BlkPass<A, L, LOWI, RI>;
+  __syncthreads();
+  mid_inverse_multi<A, L, 2>(ar, acc, smem, tid, blk, twi, dm.split_inv_mask);
 #pragma unroll
   for (int c = 0; c < 2; c++) {
-    double(&acc)[kBlkEPT] = c ? acc1 : acc0;
-    __syncthreads();
-    const MulOpD* twi_c = twi;
-    asm volatile("" : "+s"(twi_c));
-    mid_inverse<A, L, 0>(ar, acc, smem, tid, blk, twi_c, dm.split_inv_mask);
     double* dst = ACC + (((size_t)op * 2 + c) * KK + I) * Sh::N;
 #pragma unroll
     for (int g = 0; g < Out::G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << RI); k++) dst[Out::elem(tid, blk, g, k)] = acc[g * (1 << RI) + k];
+      for (int k = 0; k < (1 << RI); k++) dst[Out::elem(tid, blk, g, k)] = acc[c][g * (1 << RI) + k];
   }
 }
 
@@ -722,6 +823,47 @@ __device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A:
   inv_store(a1, 2);
 }
 
+// The same work with the four forward transforms (and then the three inverse ones) advanced together, pass by
+// pass (mid_forward_multi): smem = 4 regions of BLOCK elements, nothing is parked.
+template <class A, int L>
+__device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi,
+                                                     const typename A::V* ext_r, size_t poly_stride, typename A::V* D_r, size_t dpoly_stride,
+                                                     typename A::V* smem, u32 tid, u32 blk) {
+  using Sh = SplitShape<L>;
+  const A ar(dm);
+  constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
+  using First = BlkPass<A, L, LOWF0, RF0>;
+  constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
+  using Out = BlkPass<A, L, LOWI, RI>;
+  typename A::V v[4][kBlkEPT];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const typename A::V* src = ext_r + (size_t)i * poly_stride;
+#pragma unroll
+    for (int g = 0; g < First::G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << RF0); k++) v[i][g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+  }
+  mid_forward_multi<A, L, 4>(ar, v, smem, tid, blk, twf, dm.split_fwd_mask);
+  typename A::V d[3][kBlkEPT];
+#pragma unroll
+  for (int e = 0; e < kBlkEPT; e++) {
+    d[0][e] = ar.mul_var(v[0][e], v[2][e]);
+    d[1][e] = ar.mul_add(v[0][e], v[3][e], ar.mul_var(v[1][e], v[2][e]));
+    d[2][e] = ar.mul_var(v[1][e], v[3][e]);
+  }
+  __syncthreads();  // the last forward pass may still be reading the exchange buffer
+  mid_inverse_multi<A, L, 3>(ar, d, smem, tid, blk, twi, dm.split_inv_mask);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    typename A::V* dst = D_r + (size_t)i * dpoly_stride;
+#pragma unroll
+    for (int g = 0; g < Out::G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << RI); k++) dst[Out::elem(tid, blk, g, k)] = d[i][g * (1 << RI) + k];
+  }
+}
+
 // grid: ops * nres * NBLK workgroups of TPB threads; D = [ops][3][R][N] native representation.
 // Two instantiations (separate register allocations): FP64 residues (r in [0, K)) and integer residues.
 // POLICY_D selects which residues this launch handles: r0 = first residue, nres = number of residues.
@@ -730,8 +872,9 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D : MID
                                                                            const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
                                                                            u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres) {
   using Sh = SplitShape<L>;
-  __shared__ u64 smem[Sh::BLOCK];
-  __shared__ u64 park[Sh::BLOCK];
+  constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
+  __shared__ u64 smem[(batched ? 4 : 1) * Sh::BLOCK];
+  __shared__ u64 park[batched ? 1 : Sh::BLOCK];
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   const u32 b = blockIdx.x;
@@ -745,7 +888,13 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D : MID
   const size_t ps = (size_t)R * Sh::N;
   const MulOp* twf = twf_base + (size_t)m * Sh::N;
   const MulOp* twi = twi_base + (size_t)m * Sh::N;
-  if constexpr (POLICY_D)
+  if constexpr (batched && POLICY_D)
+    mul_mid_body_batched<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
+                                    reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
+                                    reinterpret_cast<double*>(smem), tid, blk);
+  else if constexpr (batched)
+    mul_mid_body_batched<ArithI, L>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
+  else if constexpr (POLICY_D)
     mul_mid_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                             reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                             reinterpret_cast<double*>(smem), reinterpret_cast<double*>(park), tid, blk);
