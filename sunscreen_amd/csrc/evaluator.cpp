@@ -234,14 +234,14 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   const NttPlan plan = make_plan(1, mods);
   // the per-coefficient kernels are instantiated for KMAX data primes and KMAX + 2 auxiliary primes
   const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
-  const bool split = split_mul_ && sa == 2 && sb == 2 && kneed <= 4 && h.logn >= 12 && h.logn <= 14;
+  const bool split = split_mul_ && sa == 2 && sb == 2 && (kneed <= 4 || (kneed <= 8 && h.aux_f64)) && h.logn >= 12 && h.logn <= 14;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     if (split) {
       // head / middle / tail split transforms (kernels_split.hip): 3 launches instead of 5, 40 % less HBM traffic
-      HB_LAUNCH(kKernMulHead, c * 4, launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, h.aux_f64 != 0, a + off * 2 * K * n, b + off * 2 * K * n, ext, c, s));
+      HB_LAUNCH(kKernMulHead, c * 4, launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, h.aux_f64 != 0, kneed, a + off * 2 * K * n, b + off * 2 * K * n, ext, c, s));
       HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s));
-      HB_LAUNCH(kKernMulTail, c * 3, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, h.aux_f64 != 0, D, out + off * 3 * K * n, c, s));
+      HB_LAUNCH(kKernMulTail, c * 3, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, h.aux_f64 != 0, kneed, D, out + off * 3 * K * n, c, s));
       continue;
     }
     HB_LAUNCH(kKernBehzExtend, c * (sa + sb), launch_behz_extend(ctx_->dev(), n, kneed, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));

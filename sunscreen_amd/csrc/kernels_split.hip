@@ -1258,18 +1258,22 @@ hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u
 }
 
 template <int L>
-static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, const u64* a, const u64* b, u64* ext, size_t ops, hipStream_t s) {
+static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
+                             hipStream_t s) {
   const dim3 grid((1u << L) / 8 / kHeadThreads, 4, (unsigned)ops);
-  if (aux_f64)
+  if (kneed > 4)  // only the all-FP64 instantiation exists for 5..8 data primes (evaluator.cpp checks)
+    mul_head_kernel<L, 8, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+  else if (aux_f64)
     mul_head_kernel<L, 4, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   else
     mul_head_kernel<L, 4, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   return hipGetLastError();
 }
 // aux_f64: DevCtx::aux_f64 of the context behind `ctx` (selects the all-FP64 instantiation)
-hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, const u64* a, const u64* b, u64* ext, size_t ops,
+// kneed: max(data primes, auxiliary primes - 2) -- selects the 4- or 8-prime instantiation
+hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
                            hipStream_t s) {
-  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, a, b, ext, ops, s)
+  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, kneed, a, b, ext, ops, s)
 }
 
 template <int L>
@@ -1287,16 +1291,19 @@ hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi,
 }
 
 template <int L>
-static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, const u64* D, u64* out, size_t ops, hipStream_t s) {
+static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, u32 kneed, const u64* D, u64* out, size_t ops, hipStream_t s) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, 3, (unsigned)ops);
-  if (aux_f64)
+  if (kneed > 4)
+    mul_tail_kernel<L, 8, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+  else if (aux_f64)
     mul_tail_kernel<L, 4, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
   else
     mul_tail_kernel<L, 4, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
   return hipGetLastError();
 }
-hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, const u64* D, u64* out, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, D, out, ops, s)
+hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, u32 kneed, const u64* D, u64* out, size_t ops,
+                           hipStream_t s) {
+  SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, kneed, D, out, ops, s)
 }
 
 }  // namespace hipbfv
