@@ -472,7 +472,6 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     dm.qinv = 1.0 / (double)p;
     dm.ninv_d = make_mulop_d(ninv, p);
     dm.use_f64 = plan_f64_path(p, (int)h.logn, 16, &dm.fwd_reduce_mask, &dm.inv_reduce_mask) ? 1u : 0u;
-    dm.ept8_ok = dm.use_f64 && plan_f64_path(p, (int)h.logn, 8, &dm.fwd_reduce_mask8, &dm.inv_reduce_mask8) ? 1u : 0u;
     dm.split_ok = dm.use_f64 && plan_f64_split(p, (int)h.logn, &dm.split_fwd_mask, &dm.split_inv_mask) ? 1u : 0u;
     if (const char* env = std::getenv("HIPBFV_NO_F64"))
       if (env[0] == '1') dm.use_f64 = 0, dm.split_ok = 0;

@@ -39,17 +39,14 @@ struct DevMod {
   u32 use_f64;
   u32 fwd_reduce_mask;   // pass structure with 16 elements per thread (stand-alone transforms)
   u32 inv_reduce_mask;
-  u32 fwd_reduce_mask8;  // pass structure with 8 elements per thread (fused kernels)
-  u32 inv_reduce_mask8;
   // split transforms (nttshape.hpp): bit p = reduce at the start of middle pass p; bit 8 = reduce at the start of the tail
   u32 split_fwd_mask;
   u32 split_inv_mask;
   u32 split_ok;          // the FP64 range plan of the split structure succeeded
-  u32 ept8_ok;           // ... of the 8-elements-per-thread whole-polynomial structure (experimental fused kernel)
   // pseudo-Mersenne form q = 2^61 - pm_c with pm_c < 2^28 (every SEAL auxiliary prime): 128-bit values are
   // reduced by folding at bit 64 (2^64 = 8*pm_c) and at bit 61 instead of a two-word Barrett; 0 = not applicable
   u32 pm_c;
-  u32 pad_[2];
+  u32 pad_[1];
 
   double qd;     // (double) q
   double qinv;   // 1.0 / q

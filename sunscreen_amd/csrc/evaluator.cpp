@@ -95,7 +95,6 @@ NttPlan make_plan(u32 div, const std::vector<u32>& mods) {
   NttPlan pl{};
   pl.div = div;
   pl.period = (u32)mods.size();
-  if (const char* env = std::getenv("HIPBFV_DBG")) pl.dbg = (u32)std::atoi(env);
   for (size_t i = 0; i < mods.size(); i++) pl.mod[i] = (unsigned char)mods[i];
   return pl;
 }
@@ -105,8 +104,8 @@ NttPlan make_plan(u32 div, const std::vector<u32>& mods) {
 
 const char* kernel_name(int id) {
   static const char* names[kKernCount] = {"ntt_fwd",   "ntt_inv",    "behz_extend", "tensor",  "behz_floor_sk", "ks_decompose",
-                                          "ks_mac",    "ks_moddown", "galois",      "eltwise", "plain",         "ks_fused",
-                                          "mul_fused", "ks_head",    "ks_mid",      "ks_tail", "mul_head",      "mul_mid",
+                                          "ks_mac",    "ks_moddown", "galois",      "eltwise", "plain",
+                                          "ks_head",    "ks_mid",      "ks_tail", "mul_head",      "mul_mid",
                                           "mul_tail"};
   return id >= 0 && id < kKernCount ? names[id] : "?";
 }
@@ -184,8 +183,6 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   size_t c = ((size_t)8 << 30) / per_op;
   if (const char* env = std::getenv("HIPBFV_CHUNK_OPS")) c = (size_t)std::strtoull(env, nullptr, 10);
   chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 1024));
-  if (const char* env = std::getenv("HIPBFV_FUSED_KS")) fused_ks_ = env[0] == '1';
-  if (const char* env = std::getenv("HIPBFV_NO_FUSED_MUL")) fused_mul_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_STREAMS")) nstreams_ = (size_t)std::max(1, std::atoi(env));
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS")) split_ks_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_MUL")) split_mul_ = env[0] != '1';
@@ -274,14 +271,6 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
     HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, K, target, tstride, T, count, s));
     HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, KK, T, key, ACC, count, s));
     HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, ACC, base, bstride, base_mask, out2, count, s));
-    return kOk;
-  }
-  bool all_f64 = fused_ks_ && h.logn <= 13;  // N = 16384 needs <= 128 VGPRs at 1024 threads: unfused path
-  for (u32 i = 0; i < KK; i++) all_f64 = all_f64 && h.mod[i].use_f64 && h.mod[i].ept8_ok;
-  if (all_f64) {
-    // fused decompose + NTT + key MAC + INTT: K*KK forward and 2*KK inverse transforms per op
-    HB_LAUNCH(kKernKsFused, count * KK * (K + 2), launch_ks_fused(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, KK, target, tstride, key, ACC, count, s));
-    HB_LAUNCH(kKernKsModdown, count, launch_ks_moddown(ctx_->dev(), n, ACC, base, bstride, base_mask, out2, count, s));
     return kOk;
   }
   HB_LAUNCH(kKernKsDecompose, count, launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));

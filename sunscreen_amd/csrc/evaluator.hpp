@@ -59,8 +59,6 @@ enum KernelId : int {
   kKernGalois,
   kKernEltwise,
   kKernPlain,
-  kKernKsFused,
-  kKernMulFused,
   kKernKsHead,
   kKernKsMid,
   kKernKsTail,
@@ -144,8 +142,6 @@ class Evaluator {
   ScratchPool pool_;
   Profiler prof_;
   size_t chunk_ops_;
-  bool fused_ks_ = false;  // experimental fused key-switch kernel (HIPBFV_FUSED_KS=1): register-bound, not yet a win
-  bool fused_mul_ = true;
   bool split_ks_ = true;   // head / middle / tail split transforms for key switching (kernels_split.hip)
   bool split_mul_ = true;  // ... and for the BEHZ multiply
 };

@@ -187,24 +187,9 @@ __device__ __forceinline__ void ntt_inv_from_lds(const A& ar, typename A::V (&v)
 __device__ __forceinline__ u32 plan_mod(const NttPlan& plan, u32 poly) { return plan.mod[(poly / plan.div) % plan.period]; }
 
 template <class A, int LOGN>
-__device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid, u32 dbg) {
+__device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid) {
   using Sh = NttShape<LOGN>;
   const A ar(dm);
-  if (dbg == 1) {  // EXPERIMENT: memory only (load -> LDS -> store), no butterflies
-    for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) smem[lds_pos(e)] = ar.from_u64(x[e]);
-    __syncthreads();
-    for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) x[e] = ar.canonical(smem[lds_pos(e)]);
-    return;
-  }
-  if (dbg == 2) {  // EXPERIMENT: compute only (no global traffic except one word per thread)
-    typename A::V v[kElemsPerThread];
-#pragma unroll
-    for (int e = 0; e < kElemsPerThread; e++) v[e] = ar.from_u64((u64)(tid * 16 + e));
-    FwdPasses<A, LOGN, kElemsPerThread, 0>::run(ar, v, smem, tid, tw, dm.fwd_reduce_mask);
-    __syncthreads();
-    x[tid] = ar.canonical(smem[lds_pos(tid)]);
-    return;
-  }
   ntt_fwd_to_lds<A, LOGN>(ar, x, smem, tid, tw, dm.fwd_reduce_mask);
   for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) x[e] = ar.canonical(smem[lds_pos(e)]);
 }
@@ -220,9 +205,9 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx
   u64* x = data + (size_t)poly * Sh::N;
   const MulOp* tw = twbase + (size_t)m * Sh::N;  // kernel argument: known global address space, scalar loads possible
   if (dm.use_f64)
-    ntt_fwd_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem_raw), tid, plan.dbg);
+    ntt_fwd_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem_raw), tid);
   else
-    ntt_fwd_body<ArithI, LOGN>(dm, tw, x, reinterpret_cast<u64*>(smem_raw), tid, plan.dbg);
+    ntt_fwd_body<ArithI, LOGN>(dm, tw, x, reinterpret_cast<u64*>(smem_raw), tid);
 }
 
 template <class A, int LOGN>
@@ -581,121 +566,6 @@ __global__ __launch_bounds__(kCoefThreads) void nonzero_tail_kernel(const u64* _
   bool nz = false;
   for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < len; i += (size_t)gridDim.x * kCoefThreads) nz |= p[i] != 0;
   if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&flags[op], 1u);
-}
-
-// =====================================================================================
-// Fused key-switch inner product (FP64 path, all key-level primes < 2^50):
-// one workgroup per (op, key prime I) computes
-//     ACC[op][c][I] = INTT_I( sum_J NTT_I(target_J mod q_I) (.) key[J][c][I] ),  c = 0,1
-// keeping the K forward transforms, the two accumulators and the two inverse transforms on chip:
-// HBM sees K reads of the target (L2 hits for all but the first prime), the key rows (shared by the
-// whole batch, L2/MALL resident) and two polynomial writes, instead of the decompose -> NTT -> MAC ->
-// INTT round trips of the unfused path.  Replaces the inner loops of SEAL switch_key_inplace.
-// =====================================================================================
-template <int LOGN, int EPT>
-__global__ __launch_bounds__((NttShape<LOGN, EPT>::T)) void ks_fused_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
-                                                                      const MulOp* __restrict__ twi_base, const u64* __restrict__ target,
-                                                                      size_t tstride, const u64* __restrict__ key, u64* __restrict__ ACC,
-                                                                      u32 ops) {
-  using Sh = NttShape<LOGN, EPT>;
-  using A = ArithD;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* smem = reinterpret_cast<double*>(smem_raw);
-  const u32 tid = threadIdx.x;
-  const u32 K = ctx->K, KK = ctx->KK;
-  // blocks of one op share an XCD (block b runs on XCD b % 8): the K target polynomials are then served
-  // by that XCD's L2 for KK-1 of the KK workgroups that read them
-  const u32 b = blockIdx.x;
-  const u32 xcd = b & 7u, slot = b >> 3;
-  const u32 I = slot % KK;
-  const u32 op = (slot / KK) * 8u + xcd;
-  if (op >= ops) return;
-  const DevMod& dm = ctx->mod[I];
-  const A ar(dm);
-  const MulOpD* twf = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * Sh::N);
-  const MulOpD* twi = reinterpret_cast<const MulOpD*>(twi_base + (size_t)I * Sh::N);
-  constexpr int R0 = Sh::radix(0);
-  constexpr int LOW0 = LOGN - R0;
-  constexpr int G0 = EPT >> R0;
-  constexpr int RL = Sh::radix(Sh::NPASS - 1);
-  constexpr int GL = EPT >> RL;
-  double acc0[EPT], acc1[EPT];
-#pragma unroll
-  for (int e = 0; e < EPT; e++) acc0[e] = 0.0, acc1[e] = 0.0;
-  for (u32 J = 0; J < K; J++) {
-    const u64* src = target + (size_t)op * tstride + (size_t)J * Sh::N;
-    const bool need_reduce = ctx->mod[J].q > dm.q;
-    double v[EPT];
-#pragma unroll
-    for (int g = 0; g < G0; g++)
-#pragma unroll
-      for (int k = 0; k < (1 << R0); k++) {
-        double x = ar.from_u64(src[elem_index<LOW0, R0>(tid + g * Sh::T, k)]);
-        v[g * (1 << R0) + k] = need_reduce ? ar.reduce(x) : x;
-      }
-    if (J > 0) __syncthreads();  // the previous transform's last pass may still be reading LDS
-    FwdPasses<A, LOGN, EPT, 0, true>::run(ar, v, smem, tid, twf, EPT == 16 ? dm.fwd_reduce_mask : dm.fwd_reduce_mask8);
-    const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
-    const u64* k1 = key + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
-#pragma unroll
-    for (int g = 0; g < GL; g++) {
-      const u32 base = (tid + g * Sh::T) << RL;
-#pragma unroll
-      for (int k = 0; k < (1 << RL); k += 2) {
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
-        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
-        const int e = g * (1 << RL) + k;
-        acc0[e] += ar.mul_var(v[e], ar.from_u64(a.x));
-        acc0[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(a.y));
-        acc1[e] += ar.mul_var(v[e], ar.from_u64(c.x));
-        acc1[e + 1] += ar.mul_var(v[e + 1], ar.from_u64(c.y));
-      }
-    }
-    if ((J & 3u) == 3u) {
-#pragma unroll
-      for (int e = 0; e < EPT; e++) acc0[e] = ar.reduce(acc0[e]), acc1[e] = ar.reduce(acc1[e]);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < EPT; e++) acc0[e] = ar.reduce(acc0[e]), acc1[e] = ar.reduce(acc1[e]);
-  constexpr int GO = EPT >> R0;
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    double (&acc)[EPT] = c ? acc1 : acc0;
-    InvPasses<A, LOGN, EPT, 0, true>::run(ar, acc, smem, tid, twi, EPT == 16 ? dm.inv_reduce_mask : dm.inv_reduce_mask8);
-    u64* dst = ACC + (((size_t)op * 2 + c) * KK + I) * Sh::N;
-#pragma unroll
-    for (int g = 0; g < GO; g++)
-#pragma unroll
-      for (int k = 0; k < (1 << R0); k++) dst[elem_index<LOW0, R0>(tid + g * Sh::T, k)] = ar.scale_canonical(acc[g * (1 << R0) + k], dm.ninv_d);
-  }
-}
-
-template <int LOGN, int EPT>
-static hipError_t launch_ks_fused_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, const u64* target, size_t tstride, const u64* key, u64* ACC, size_t ops, u32 KK,
-                                    hipStream_t s) {
-  using Sh = NttShape<LOGN, EPT>;
-  const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)ks_fused_kernel<LOGN, EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
-  const size_t ops8 = (ops + 7) / 8 * 8;
-  ks_fused_kernel<LOGN, EPT><<<dim3((unsigned)(ops8 * KK)), dim3(Sh::T), lds, s>>>(ctx, twf, twi, target, tstride, key, ACC, (u32)ops);
-  return hipGetLastError();
-}
-
-hipError_t launch_ks_fused(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 KK, const u64* target, size_t tstride, const u64* key, u64* ACC, size_t ops,
-                           hipStream_t s) {
-  switch (logn) {
-    case 10: return launch_ks_fused_t<10, 8>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
-    case 11: return launch_ks_fused_t<11, 8>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
-    case 12: return launch_ks_fused_t<12, 8>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
-    case 13: return launch_ks_fused_t<13, 8>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
-    case 14: return launch_ks_fused_t<14, 16>(ctx, twf, twi, target, tstride, key, ACC, ops, KK, s);
-    default: return hipErrorInvalidValue;
-  }
 }
 
 // =====================================================================================

@@ -11,7 +11,6 @@ namespace hipbfv {
 struct NttPlan {
   u32 div;
   u32 period;
-  u32 dbg;  // experiment knob (0 = normal)
   unsigned char mod[kMaxMod];
 };
 
@@ -21,8 +20,6 @@ hipError_t launch_tensor(const DevCtx* ctx, u32 n, u32 R, const u64* ext, u32 sa
 hipError_t launch_behz_floor_sk(const DevCtx* ctx, u32 n, u32 K, const u64* D, u64* out, size_t polys, hipStream_t s);
 hipError_t launch_ks_decompose(const DevCtx* ctx, u32 n, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
 hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s);
-hipError_t launch_ks_fused(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 KK, const u64* target, size_t tstride, const u64* key, u64* ACC, size_t ops,
-                           hipStream_t s);
 // two-kernel stand-alone transforms for N = 32768 (kernels_split.hip)
 hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse,
                             int scale_mode, hipStream_t s);
