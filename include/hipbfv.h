@@ -203,7 +203,8 @@ long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
  * Node kinds follow sunscreen_fhe_program::Operation (operation.rs:12-94) in this order:
  * 0 ShiftLeft, 1 ShiftRight, 2 SwapRows, 3 Relinearize, 4 Multiply, 5 MultiplyPlaintext, 6 Add,
  * 7 AddPlaintext, 8 Negate, 9 Sub, 10 SubPlaintext, 11 InputCiphertext(arg), 12 InputPlaintext(arg),
- * 13 Literal::U64(arg), 14 OutputCiphertext.  Edge kinds: 0 Left, 1 Right, 2 Unary.
+ * 13 Literal::U64(arg), 14 OutputCiphertext (15 Literal::Plaintext: hipbfv_Program_AddPlaintextLiteral / JSON only).
+ * Edge kinds: 0 Left, 1 Right, 2 Unary.
  * LoadJson accepts the serde JSON form of `FheProgram` (petgraph StableGraph).
  * Run executes the graph over `batch` independent input sets: input i is a device pointer to
  * u64[batch][2][K][N] (kind 0) or to plaintexts u64[batch][N] / one shared u64[N] (kind 1, stride N / 0);
@@ -211,6 +212,11 @@ long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
 long hipbfv_Program_Create(void **program);
 long hipbfv_Program_Destroy(void *program);
 long hipbfv_Program_AddNode(void *program, uint32_t op, uint64_t arg, uint32_t *node_id);
+/* Literal::Plaintext(bytes) node: `bytes` is what the compiler stores in the graph -- bincode of
+ * InnerPlaintext::Seal([WithContext{Params, SEAL-serialised Plaintext}]) (sunscreen_fhe_program/src/literal.rs:8-18,
+ * sunscreen/src/fhe/mod.rs:370-376, decoded by the reference at sunscreen_runtime/src/run.rs:312-328).  The
+ * parameters inside are checked against the evaluator's context when the program runs. */
+long hipbfv_Program_AddPlaintextLiteral(void *program, const uint8_t *bytes, uint64_t length, uint32_t *node_id);
 long hipbfv_Program_AddEdge(void *program, uint32_t src, uint32_t dst, uint32_t kind);
 long hipbfv_Program_LoadJson(void *program, const char *json, uint64_t length);
 long hipbfv_Program_NumOutputs(void *program, uint64_t *count);

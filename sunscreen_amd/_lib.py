@@ -127,6 +127,7 @@ _SIGNATURES = {
     "hipbfv_Program_Create": [vpp],
     "hipbfv_Program_Destroy": [vp],
     "hipbfv_Program_AddNode": [vp, C.c_uint32, u64, C.POINTER(C.c_uint32)],
+    "hipbfv_Program_AddPlaintextLiteral": [vp, C.c_char_p, u64, C.POINTER(C.c_uint32)],
     "hipbfv_Program_AddEdge": [vp, C.c_uint32, C.c_uint32, C.c_uint32],
     "hipbfv_Program_LoadJson": [vp, C.c_char_p, u64],
     "hipbfv_Program_NumOutputs": [vp, u64p],

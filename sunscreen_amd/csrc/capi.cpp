@@ -1462,8 +1462,19 @@ long hipbfv_Program_Destroy(void* h) {
 long hipbfv_Program_AddNode(void* h, uint32_t op, uint64_t arg, uint32_t* node_id) {
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   if (!p || !node_id) return HIPBFV_E_POINTER;
-  if (op >= (uint32_t)kOpCount) return fail(HIPBFV_E_INVALIDARG, "unknown operation kind");
+  if (op >= (uint32_t)kOpCount || op == (uint32_t)kOpLiteralPlaintext)
+    return fail(HIPBFV_E_INVALIDARG, "unknown operation kind (plaintext literals: hipbfv_Program_AddPlaintextLiteral)");
   *node_id = (uint32_t)p->prog.add_node((OpKind)op, arg);
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_Program_AddPlaintextLiteral(void* h, const uint8_t* bytes, uint64_t length, uint32_t* node_id) {
+  ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
+  if (!p || !bytes || !node_id) return HIPBFV_E_POINTER;
+  std::string err;
+  const int id = p->prog.add_plaintext_literal(bytes, (size_t)length, &err);
+  if (id < 0) return fail(HIPBFV_E_INVALIDARG, err.c_str());
+  *node_id = (uint32_t)id;
   return HIPBFV_S_OK;
 }
 

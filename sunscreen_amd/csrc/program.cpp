@@ -9,6 +9,8 @@
 // JSON form of `FheProgram` (petgraph StableGraph: {"nodes":[{"operation":..}],"edges":[[src,dst,"Left"]]}).
 #include "program.hpp"
 
+#include "wire.hpp"
+
 #include <algorithm>
 #include <cctype>
 #include <cstdlib>
@@ -172,6 +174,48 @@ int Program::add_node(OpKind op, u64 arg) {
   return (int)nodes_.size() - 1;
 }
 
+// bincode 1.x default configuration: little-endian fixed-width integers, u64 sequence lengths, u32 enum variant index
+int Program::add_plaintext_literal(const uint8_t* bytes, size_t len, std::string* err) {
+  auto fail = [&](const char* m) {
+    if (err) *err = m;
+    return -1;
+  };
+  size_t pos = 0;
+  auto rd = [&](size_t width, u64* out) {
+    if (len - pos < width) return false;
+    u64 v = 0;
+    for (size_t i = 0; i < width; i++) v |= (u64)bytes[pos + i] << (8 * i);
+    pos += width;
+    *out = v;
+    return true;
+  };
+  u64 variant, count, n, nprimes, t, scheme, sec, blob;
+  if (!rd(4, &variant) || variant != 0) return fail("plaintext literal: not InnerPlaintext::Seal");
+  if (!rd(8, &count) || count != 1) return fail("plaintext literal: must hold exactly one plaintext (run.rs:319-322)");
+  PlainLiteral lit;
+  if (!rd(8, &n) || !rd(8, &nprimes) || nprimes > 64) return fail("plaintext literal: malformed Params");
+  lit.n = n;
+  for (u64 i = 0; i < nprimes; i++) {
+    u64 p;
+    if (!rd(8, &p)) return fail("plaintext literal: malformed Params");
+    lit.primes.push_back(p);
+  }
+  if (!rd(8, &t) || !rd(4, &scheme) || !rd(4, &sec) || scheme != 0) return fail("plaintext literal: malformed Params");
+  lit.t = t;
+  if (!rd(8, &blob) || blob != len - pos) return fail("plaintext literal: malformed data field");
+  WirePlaintext wp;
+  size_t used = 0;
+  if (wire_unpack_plaintext(bytes + pos, (size_t)blob, &wp, &used) != kWireOk || used != blob)
+    return fail("plaintext literal: not a SEAL plaintext");
+  if (wp.coeffs.size() > n) return fail("plaintext literal: more coefficients than the polynomial degree");
+  for (unsigned long long c : wp.coeffs) {
+    if (c >= t) return fail("plaintext literal: coefficient not below the plain modulus");
+    lit.coeffs.push_back((u64)c);
+  }
+  literals_.push_back(std::move(lit));
+  return add_node(kOpLiteralPlaintext, literals_.size() - 1);
+}
+
 int Program::add_edge(int src, int dst, EdgeKind kind) {
   if (src < 0 || dst < 0 || src >= (int)nodes_.size() || dst >= (int)nodes_.size() || src == dst) return kInvalidArg;
   Node& d = nodes_[dst];
@@ -200,6 +244,7 @@ int Program::load_json(const char* text, size_t len, std::string* err) {
   const JValue* holes = g->get("node_holes");
   if (holes && holes->kind == JValue::kArr && !holes->arr.empty()) return fail("graphs with node holes are not supported");
   nodes_.clear();
+  literals_.clear();
   for (const JValue& nv : nodes->arr) {
     const JValue* op = nv.kind == JValue::kObj ? nv.get("operation") : nullptr;
     if (!op) return fail("node without operation");
@@ -213,7 +258,22 @@ int Program::load_json(const char* text, size_t len, std::string* err) {
       const JValue& payload = op->obj[0].second;
       if (kind == kOpLiteralU64) {
         const JValue* u = payload.kind == JValue::kObj ? payload.get("U64") : nullptr;
-        if (!u) return fail("only Literal::U64 is supported (plaintext literals need the SEAL wire format)");
+        const JValue* pl = payload.kind == JValue::kObj ? payload.get("Plaintext") : nullptr;
+        if (pl) {  // serde_json writes Vec<u8> as an array of numbers
+          if (pl->kind != JValue::kArr) return fail("Literal::Plaintext must be a byte array");
+          std::vector<uint8_t> bytes;
+          for (const JValue& b : pl->arr) {
+            if (b.kind != JValue::kNum || b.unum > 255) return fail("Literal::Plaintext must be a byte array");
+            bytes.push_back((uint8_t)b.unum);
+          }
+          std::string lerr;
+          if (add_plaintext_literal(bytes.data(), bytes.size(), &lerr) < 0) {
+            if (err) *err = lerr;
+            return (int)kInvalidArg;
+          }
+          continue;
+        }
+        if (!u) return fail("Literal must be U64 or Plaintext");
         arg = u->unum;
       } else if (kind == kOpInputCiphertext || kind == kOpInputPlaintext) {
         if (payload.kind != JValue::kNum) return fail("input index must be a number");
@@ -252,6 +312,7 @@ int Program::validate(std::string* err) const {
       case kOpInputCiphertext:
       case kOpInputPlaintext:
       case kOpLiteralU64:
+      case kOpLiteralPlaintext:
         if (nd.left >= 0 || nd.right >= 0) return fail("input/literal nodes take no operands");
         break;
       case kOpNegate:
@@ -417,6 +478,23 @@ int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t
       }
       case kOpLiteralU64:
         continue;
+      case kOpLiteralPlaintext: {
+        const PlainLiteral& lit = literals_[nd.arg];
+        const std::vector<u64>& kp = ctx->key_primes();
+        if (lit.n != n || lit.t != ctx->host().t || lit.primes.size() != kp.size() || !std::equal(kp.begin(), kp.end(), lit.primes.begin()))
+          return cleanup(kInvalidArg, "plaintext literal was built for different encryption parameters");
+        u64* dev = (u64*)pool.acquire(n * sizeof(u64), s);
+        if (!dev) return cleanup(kOutOfMemory, "scratch allocation failed");
+        live.push_back(dev);
+        std::vector<u64> host(n, 0);
+        std::copy(lit.coeffs.begin(), lit.coeffs.end(), host.begin());
+        // ordered after earlier users of the recycled buffer on this stream; drained so `host` may go out of scope
+        if (hipMemcpyAsync(dev, host.data(), n * sizeof(u64), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+          return cleanup(kHipError, "copy failed");
+        v.plain = dev;
+        v.pstride = 0;  // one plaintext shared by the whole batch
+        continue;
+      }
       case kOpOutputCiphertext: {
         if (!L->ct || L->size != 2) return cleanup(kInvalidArg, "program output must be a size-2 ciphertext");
         if (hipMemcpyAsync(outputs[out_slot[id]], L->ct, batch * ctx->ct_words(2) * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess)

@@ -1,5 +1,6 @@
 // sunscreen_amd/csrc/program.hpp -- batched execution of FHE program graphs (see program.cpp).
 #pragma once
+#include <cstdint>
 #include <functional>
 #include <map>
 #include <string>
@@ -26,6 +27,7 @@ enum OpKind : int {
   kOpInputPlaintext,    // arg = argument index
   kOpLiteralU64,        // arg = value
   kOpOutputCiphertext,
+  kOpLiteralPlaintext,  // arg = index into the program's literal table (Literal::Plaintext, literal.rs:8-18)
   kOpCount
 };
 
@@ -43,6 +45,9 @@ struct ProgramInput {
 class Program {
  public:
   int add_node(OpKind op, u64 arg);
+  // Literal::Plaintext(bytes): bytes = bincode(InnerPlaintext::Seal([WithContext{Params, SEAL-serialised Plaintext}]))
+  // exactly as the compiler stores it (sunscreen/src/fhe/mod.rs:370-376, decoded at sunscreen_runtime/src/run.rs:312-328)
+  int add_plaintext_literal(const uint8_t* bytes, size_t len, std::string* err);
   int add_edge(int src, int dst, EdgeKind kind);
   int load_json(const char* text, size_t len, std::string* err);
   int validate(std::string* err) const;
@@ -59,8 +64,14 @@ class Program {
     u64 arg;
     int left, right;  // operand node ids (unary operand in `left`)
   };
+  struct PlainLiteral {
+    u64 n, t;
+    std::vector<u64> primes;  // Params::coeff_modulus (key-level primes)
+    std::vector<u64> coeffs;
+  };
   bool topo_order(std::vector<int>* order) const;
   std::vector<Node> nodes_;
+  std::vector<PlainLiteral> literals_;
 };
 
 }  // namespace hipbfv

@@ -25,6 +25,20 @@ OPS = [
 EDGES = {"Left": 0, "Right": 1, "Unary": 2}
 
 
+def encode_plaintext_literal(n: int, key_primes: Sequence[int], t: int, seal_plaintext_bytes: bytes, security_level: int = 0) -> bytes:
+    """bincode 1.x (little-endian, fixed-width, u64 lengths, u32 variant indices) of
+    InnerPlaintext::Seal(vec![WithContext { params: Params { lattice_dimension, coeff_modulus, plain_modulus,
+    scheme_type: Bfv, security_level }, data: <SEAL-serialised Plaintext> }]) -- sunscreen_runtime/src/lib.rs:37-42,
+    serialization.rs:16-60, metadata.rs:72-97.  security_level is the variant index (0 = TC128)."""
+    import struct
+
+    out = struct.pack("<IQ", 0, 1)
+    out += struct.pack("<QQ", n, len(key_primes)) + struct.pack("<%dQ" % len(key_primes), *key_primes)
+    out += struct.pack("<QII", t, 0, security_level)
+    out += struct.pack("<Q", len(seal_plaintext_bytes)) + bytes(seal_plaintext_bytes)
+    return out
+
+
 class FheProgram:
     def __init__(self):
         self._h = C.c_void_p()
@@ -67,6 +81,15 @@ class FheProgram:
 
     def append_input_literal(self, value: int) -> int:
         return self._node("Literal", value)
+
+    def append_plaintext_literal(self, inner_plaintext_bytes: bytes) -> int:
+        """Literal::Plaintext(bytes): bincode of InnerPlaintext::Seal([WithContext{Params, SEAL plaintext}]) as
+        the compiler stores it (sunscreen/src/fhe/mod.rs:370-376); see `encode_plaintext_literal`."""
+        nid = C.c_uint32()
+        raw = bytes(inner_plaintext_bytes)
+        _check(_lib.load().hipbfv_Program_AddPlaintextLiteral(self._h, raw, len(raw), C.byref(nid)))
+        self.nodes.append(("Literal", {"Plaintext": list(raw)}))
+        return nid.value
 
     def append_add(self, a, b):
         return self._binary("Add", a, b)
@@ -118,7 +141,7 @@ class FheProgram:
                 p.nodes.append((op, 0))
             else:
                 (name, payload), = op.items()
-                p.nodes.append((name, payload["U64"] if isinstance(payload, dict) else payload))
+                p.nodes.append((name, payload.get("U64", payload) if isinstance(payload, dict) else payload))
         p.edges = [tuple(e) for e in g["edges"]]
         return p
 
@@ -127,7 +150,7 @@ class FheProgram:
             if op in ("InputCiphertext", "InputPlaintext"):
                 return {op: arg}
             if op == "Literal":
-                return {"Literal": {"U64": arg}}
+                return {"Literal": arg if isinstance(arg, dict) else {"U64": arg}}
             return op
 
         return json.dumps(

@@ -5,7 +5,9 @@ one oracle call per node, for ONE input set."""
 import numpy as np
 
 
-def run_program(o, nodes, edges, inputs, rk=None, gk=None):
+def run_program(o, nodes, edges, inputs, rk=None, gk=None, literals=None):
+    """literals: node index -> plaintext coefficient array, for Literal::Plaintext nodes (the checker is told the
+    coefficients directly; decoding the bincode/SEAL bytes is the product's job)."""
     n = len(nodes)
     left, right = [None] * n, [None] * n
     for s, d, kind in edges:
@@ -21,7 +23,7 @@ def run_program(o, nodes, edges, inputs, rk=None, gk=None):
         if op in ("InputCiphertext", "InputPlaintext"):
             val[i] = inputs[arg]
         elif op == "Literal":
-            val[i] = arg
+            val[i] = literals[i] if isinstance(arg, dict) else arg
         elif op == "Add":
             val[i] = o.add(L, R)
         elif op == "Sub":

@@ -106,3 +106,24 @@ def test_null_and_wrong_type_handles_are_rejected():
     # a Plaintext handle passed where a Modulus is expected
     assert lib.Modulus_Value(h, C.byref(out)) & 0xFFFFFFFF == _lib.E_POINTER
     assert lib.Plaintext_Destroy(h) == 0
+
+
+def test_plaintext_literal_decoding_is_host_only():
+    """Literal::Plaintext nodes (bincode of InnerPlaintext around the SEAL wire format) are decoded when the graph
+    is built -- no device needed; malformed bytes are rejected with E_INVALIDARG."""
+    from sunscreen_amd import HipBfvError, Plaintext
+    from sunscreen_amd.program import FheProgram, encode_plaintext_literal
+
+    n, primes, t = 4096, [68719403009, 68719230977, 137438822401], 65537
+    blob = encode_plaintext_literal(n, primes, t, Plaintext.from_coefficients([1, 2, 3]).as_bytes())
+    p = FheProgram()
+    a = p.append_input_ciphertext(0)
+    lit = p.append_plaintext_literal(blob)
+    p.append_output_ciphertext(p.append_add_plaintext(a, lit))
+    q = FheProgram.from_json(p.to_json())
+    assert q.nodes == p.nodes and q.num_outputs() == 1
+    too_big = encode_plaintext_literal(n, primes, 3, Plaintext.from_coefficients([1, 2, 3]).as_bytes())  # coefficient >= t
+    for junk in (b"", blob[:20], blob[:-3], b"\x01" + blob[1:], too_big):
+        with pytest.raises(HipBfvError) as ei:
+            FheProgram().append_plaintext_literal(junk)
+        assert ei.value.kind == "InvalidArgument"

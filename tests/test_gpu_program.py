@@ -106,6 +106,59 @@ def test_pir_row_graph_with_plaintext_arguments():
         assert int(o.decrypt(out[i], sk)[0]) == int(db_vals[sel, i])
 
 
+def test_plaintext_literal_nodes():
+    """`a + b * 7`-style programs carry their constants as Literal::Plaintext(bytes) nodes
+    (sunscreen/tests/fhe_program_tests.rs:283-310; bytes = bincode(InnerPlaintext) holding Params + the SEAL wire
+    format, sunscreen/src/fhe/mod.rs:370-376).  Build one through the API and through JSON."""
+    from sunscreen_amd import HipBfvError, Plaintext
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.program import FheProgram, encode_plaintext_literal
+
+    name = "default_4096_16"
+    n, primes, t = params(name)
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx(name)
+    rng = np.random.default_rng(8)
+    lit_vals = rng.integers(0, 50, o.n).astype(np.uint64)
+    lit_coeffs = o.batch_encode(lit_vals)
+    seal_bytes = Plaintext.from_coefficients([int(c) for c in lit_coeffs]).as_bytes()
+    blob = encode_plaintext_literal(n, primes, t, seal_bytes)
+
+    p = FheProgram()
+    a = p.append_input_ciphertext(0)
+    b = p.append_input_ciphertext(1)
+    lit = p.append_plaintext_literal(blob)
+    m = p.append_multiply_plaintext(b, lit)
+    p.append_output_ciphertext(p.append_add(a, p.append_add_plaintext(m, lit)))
+    q = FheProgram.from_json(p.to_json())  # serde_json writes the literal as an array of byte values
+    assert q.nodes == p.nodes
+
+    batch = 2
+    va = rng.integers(0, 100, (batch, o.n)).astype(np.uint64)
+    vb = rng.integers(0, 100, (batch, o.n)).astype(np.uint64)
+    ca = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in va])
+    cb = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vb])
+    for prog in (p, q):
+        (out,) = prog.run(ev, [to_device(ca), to_device(cb)], rkd)
+        out = to_host(out)
+        for i in range(batch):
+            (ref,) = run_program(o, prog.nodes, prog.edges, [ca[i], cb[i]], rk, literals={lit: lit_coeffs})
+            assert (out[i] == ref).all()
+            assert (o.batch_decode(o.decrypt(out[i], sk)) == (va[i] + vb[i] * lit_vals + lit_vals) % o.t).all()
+
+    # a literal built for other parameters is rejected when the program runs (the reference re-creates a context
+    # from the literal's own Params, serialization.rs:62-140; here the evaluator's context is the only one)
+    other = FheProgram()
+    x = other.append_input_ciphertext(0)
+    bad = other.append_plaintext_literal(encode_plaintext_literal(n, primes, t + 2, Plaintext.from_coefficients([1]).as_bytes()))
+    other.append_output_ciphertext(other.append_add_plaintext(x, bad))
+    with pytest.raises(HipBfvError):
+        other.run(ev, [to_device(ca)], rkd)
+    # malformed bytes are rejected when the node is added
+    for junk in (b"", blob[:20], blob[:-3], b"\x01" + blob[1:]):
+        with pytest.raises(HipBfvError):
+            FheProgram().append_plaintext_literal(junk)
+
+
 def test_program_errors():
     from sunscreen_amd import HipBfvError
     from sunscreen_amd.batch import to_device
