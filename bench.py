@@ -33,7 +33,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="ciphertext pairs (or polynomials for --workload ntt) per GPU per step")
     ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--workload", choices=["mulrelin", "ntt"], default="mulrelin")
+    ap.add_argument("--workload", choices=["mulrelin", "ntt", "chi_sq", "dot_prod"], default="mulrelin",
+                    help="mulrelin = the headline; ntt = batched transforms; chi_sq / dot_prod = whole program graphs "
+                         "(examples/chi_sq, examples/dot_prod) through the batch graph executor (SURVEY 8d configs 4 / 5b)")
     ap.add_argument("--chunk", type=int, default=0, help="override the executor's chunk size (ops per launch group)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="ops in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -110,6 +112,44 @@ def main():
         units_per_step = B
         metric, unit = "bfv_mul_relin_ops_per_sec", "ops/s"
         workload = f"BFV ct*ct multiply+relinearize, n={n}, K={K}+1 SEAL default 128-bit primes, t={t}, batch={B} pairs/GPU"
+    elif args.workload in ("chi_sq", "dot_prod"):
+        from sunscreen_amd import GaloisKeys
+        from sunscreen_amd.workloads import chi_sq_optimized, dot_product
+        from oracle.program_interp import run_program
+
+        o = O.Oracle(n, primes, t)
+        O.seed(0xC415 + 17)
+        if args.workload == "chi_sq":
+            prog, nin, elts = chi_sq_optimized(), 3, None
+            lanes = 0
+        else:
+            lanes = n // 2
+            prog, nin = dot_product(lanes), 2
+            elts = sorted({o.galois_elt_from_step(1 << i) for i in range(lanes.bit_length() - 1)} | {2 * n - 1})
+        sk, pk, rk, gk = o.keygen(galois_elts=elts)
+        rkd = RelinearizationKeys.from_array(ctx, rk)
+        gkd = GaloisKeys.from_arrays(ctx, gk) if gk else None
+        ins = [uniform_residues((B, 2), K, primes) for _ in range(nin)]
+        ncheck = 0 if args.no_check else 2
+        rng = np.random.default_rng(rank)
+        vals = rng.integers(0, 7, (nin, ncheck, n)).astype(np.uint64)
+        enc = [np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vals[a]]) if ncheck else None for a in range(nin)]
+        for a in range(nin):
+            if ncheck:
+                ins[a][:ncheck] = to_device(enc[a], dev)
+        outs_holder = []
+
+        def step():
+            outs_holder[:] = prog.run(ev, ins, rkd, gkd)
+
+        nout = prog.num_outputs()
+        unit_bytes = 16 * K * n * (nin + nout)  # compulsory traffic of one program run: read the inputs, write the outputs
+        units_per_step = B
+        metric, unit = f"fhe_program_{args.workload}_runs_per_sec", "programs/s"
+        nmul = sum(1 for op, _ in prog.nodes if op == "Multiply")
+        nrot = sum(1 for op, _ in prog.nodes if op in ("ShiftLeft", "ShiftRight", "SwapRows"))
+        workload = (f"FheProgram graph examples/{args.workload} ({len(prog.nodes)} nodes: {nmul} mul+relin, {nrot} rotations), n={n}, "
+                    f"K={K}+1 SEAL default primes, t={t}, batch={B} input sets/GPU")
     else:
         nprimes = 3
         data = uniform_residues((B,), nprimes, primes[:nprimes]).reshape(B * nprimes, n).contiguous()
@@ -159,6 +199,12 @@ def main():
         for i in range(K):
             assert int(out[:, :, i, :].max()) < primes[i] and int(out[:, :, i, :].min()) >= 0
         parity = f"bit-exact vs oracle on {ncheck} items; all {B} outputs canonical"
+    elif args.workload in ("chi_sq", "dot_prod") and not args.no_check:
+        for i in range(ncheck):
+            refs = run_program(o, prog.nodes, prog.edges, [e[i] for e in enc], rk, gk)
+            for k in range(nout):
+                assert (to_host(outs_holder[k][i : i + 1])[0] == refs[k]).all(), "HIP program result differs from the CPU oracle"
+        parity = f"bit-exact vs the oracle graph interpreter on {ncheck} input sets x {nout} outputs"
     elif args.workload == "ntt" and not args.no_check:
         assert torch.equal(data, ref), "INTT(NTT(x)) != x"
         parity = "INTT(NTT(x)) == x on the whole batch"
@@ -187,6 +233,7 @@ def main():
             # split path (kernels_split.hip); units: polynomials for mul_head / mul_tail, ops otherwise
             "mul_head": 8 * n * (K + R_), "mul_mid": 8 * n * 7 * R_, "mul_tail": 8 * n * (R_ + K),
             "ks_head": 8 * n * (K + KK * K), "ks_mid": 8 * n * (KK * K + 2 * KK), "ks_tail": 8 * n * (2 * KK + 4 * K),
+            "galois": 16 * n * K, "eltwise": 24 * n,                 # per polynomial / per residue polynomial (2 reads + 1 write)
         }.get(name, 16 * n)
         avg_ms = rec["ms"] / rec["launches"]
         bytes_per_launch = per_unit * rec["units"] / rec["launches"]
@@ -269,6 +316,34 @@ def cpu_baseline(args, O, n, primes, t):
                 "sample": f"{sample} mul+relin ops (same parameters) with OpenMP over the batch on {threads} threads; "
                           f"single-thread rate {one:.2f} ops/s on {max(8, sample // threads)} ops",
                 "single_thread_value": round(one, 2), "host_cpus": cores}
+    if args.workload in ("chi_sq", "dot_prod"):
+        from concurrent.futures import ThreadPoolExecutor
+
+        from oracle.program_interp import run_program
+        from sunscreen_amd.workloads import chi_sq_optimized, dot_product
+
+        O.seed(98)
+        if args.workload == "chi_sq":
+            prog, nin, elts = chi_sq_optimized(), 3, None
+        else:
+            lanes = n // 2
+            prog, nin = dot_product(lanes), 2
+            elts = sorted({o.galois_elt_from_step(1 << i) for i in range(lanes.bit_length() - 1)} | {2 * n - 1})
+        sk, pk, rk, gk = o.keygen(galois_elts=elts)
+        sample = args.cpu_sample or threads
+        ins = [[np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)]) for _ in range(2)]) for _ in range(nin)]
+               for _ in range(sample)]
+        t0 = time.perf_counter()
+        run_program(o, prog.nodes, prog.edges, ins[0], rk, gk)
+        one = 1.0 / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:  # the oracle's C calls release the GIL
+            list(ex.map(lambda x: run_program(o, prog.nodes, prog.edges, x, rk, gk), ins))
+        secs = time.perf_counter() - t0
+        return {"value": round(sample / secs, 3), "unit": "programs/s", "cores": threads, "kind": "port",
+                "sample": f"{sample} program runs on {threads} host threads (one oracle call per graph node, as run.rs does); "
+                          f"single-thread rate {one:.3f} programs/s",
+                "single_thread_value": round(one, 3), "host_cpus": cores}
     nprimes = 3
     sample = args.cpu_sample or threads * 256
     x = np.stack([rng.integers(0, primes[i % nprimes], n, dtype=np.uint64) for i in range(sample)])

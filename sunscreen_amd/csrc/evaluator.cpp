@@ -384,28 +384,29 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, 
   return kOk;
 }
 
-static int eltwise_chunks(const DevCtx* dev, u32 n, u32 K, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode, hipStream_t s) {
+static int eltwise_chunks(Profiler& prof_, const DevCtx* dev, u32 n, u32 K, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode,
+                          hipStream_t s) {
   const size_t step = (65535 / K) * K;
   for (size_t off = 0; off < residue_polys; off += step) {
     const size_t cnt = std::min(step, residue_polys - off);
-    HB_CHECK(launch_eltwise(dev, n, a + off * n, b ? b + off * n : nullptr, out + off * n, cnt, mode, s));
+    HB_LAUNCH(kKernEltwise, cnt, launch_eltwise(dev, n, a + off * n, b ? b + off * n : nullptr, out + off * n, cnt, mode, s));
   }
   return kOk;
 }
 
 int Evaluator::add(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s) {
   if (size < 2) return kInvalidArg;
-  return eltwise_chunks(ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 0, s);
+  return eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 0, s);
 }
 
 int Evaluator::sub(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s) {
   if (size < 2) return kInvalidArg;
-  return eltwise_chunks(ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 1, s);
+  return eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 1, s);
 }
 
 int Evaluator::negate(const u64* a, u64* out, u32 size, size_t count, hipStream_t s) {
   if (size < 1) return kInvalidArg;
-  return eltwise_chunks(ctx_->dev(), ctx_->n(), ctx_->K(), a, nullptr, out, count * size * ctx_->K(), 2, s);
+  return eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, nullptr, out, count * size * ctx_->K(), 2, s);
 }
 
 static int plain_addsub(Context* ctx, const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, int sub, hipStream_t s) {
