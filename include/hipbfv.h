@@ -107,6 +107,44 @@ long KSwitchKeys_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
 long KSwitchKeys_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
 long KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 
+/* ---- SecretKey / PublicKey (seal_fhe/src/key_generator.rs:200-430): handles + SEAL 4.0 wire format.
+ * Keys are produced by the client (KeyGenerator is not part of this library); data is key-level NTT form:
+ * SecretKey u64[K+1][N], PublicKey u64[2][K+1][N]. ---- */
+long SecretKey_Create1(void **key);
+long SecretKey_Create2(void *copy, void **key);
+long SecretKey_Destroy(void *thisptr);
+long SecretKey_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+long SecretKey_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
+long SecretKey_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+long PublicKey_Create1(void **key);
+long PublicKey_Create2(void *copy, void **key);
+long PublicKey_Destroy(void *thisptr);
+long PublicKey_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+long PublicKey_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
+long PublicKey_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+
+/* ---- BatchEncoder (seal_fhe/src/encoder.rs:50-215): slot vectors <-> plaintexts, transforms over Z_t on the device ---- */
+long BatchEncoder_Create(void *context, void **encoder);
+long BatchEncoder_Destroy(void *thisptr);
+long BatchEncoder_Encode1(void *thisptr, uint64_t count, uint64_t *values, void *destination);
+long BatchEncoder_Encode2(void *thisptr, uint64_t count, int64_t *values, void *destination);
+long BatchEncoder_Decode1(void *thisptr, void *plain, uint64_t *count, uint64_t *destination, void *pool);
+long BatchEncoder_Decode2(void *thisptr, void *plain, uint64_t *count, int64_t *destination, void *pool);
+long BatchEncoder_GetSlotCount(void *thisptr, uint64_t *slot_count);
+
+/* ---- Decryptor (seal_fhe/src/encryptor_decryptor.rs:596-690): <ct, (1, s, s^2)> then SEAL's
+ * decrypt_scale_and_round in the base {t, gamma}; bit-identical plaintexts ---- */
+long Decryptor_Create(void *context, void *secret_key, void **decryptor);
+long Decryptor_Destroy(void *thisptr);
+long Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination);
+
+/* ---- Encryptor, public-key mode (seal_fhe/src/encryptor_decryptor.rs:140-260).  The randomness is the library's
+ * own (Philox4x32-10; ternary u, rounded Gaussian sigma 3.2 clipped at 19): ciphertexts are valid SEAL ciphertexts
+ * but, like SEAL's, not reproducible across implementations.  secret_key may be NULL; symmetric mode is not exported. ---- */
+long Encryptor_Create(void *context, void *public_key, void *secret_key, void **encryptor);
+long Encryptor_Destroy(void *thisptr);
+long Encryptor_Encrypt(void *thisptr, void *plaintext, void *destination, void *pool);
+
 /* ---- Evaluator (seal_fhe/src/evaluator_base.rs:55-407, bfv_evaluator.rs:12-248) ---- */
 long Evaluator_Create(void *seal_context, void **evaluator);
 long Evaluator_Destroy(void *thisptr);
@@ -155,6 +193,9 @@ long hipbfv_Ciphertext_DevicePtr(void *cipher, uint64_t **device_ptr);
 long hipbfv_KSwitchKeys_AssignRelin(void *keys, void *context, const uint64_t *host_data);
 long hipbfv_KSwitchKeys_AssignGalois(void *keys, void *context, uint32_t galois_elt, const uint64_t *host_data);
 long hipbfv_KSwitchKeys_DevicePtr(void *keys, uint64_t index, uint64_t **device_ptr); /* index 0 = relin, (elt-1)/2 = galois */
+long hipbfv_SecretKey_Assign(void *key, void *context, const uint64_t *host_data);  /* u64[K+1][N], NTT form */
+long hipbfv_PublicKey_Assign(void *key, void *context, const uint64_t *host_data);  /* u64[2][K+1][N], NTT form */
+long hipbfv_Encryptor_SetSeed(void *encryptor, uint64_t seed);                      /* reproducible runs (tests) */
 
 /* Host-only helpers of the SEAL 4.0 wire format (no device access; used by the CPU tests against the
  * reference's binary fixtures): parms_id = BLAKE2b-256([scheme=1, n, primes..., t]); decode/encode one object. */
@@ -197,6 +238,17 @@ long hipbfv_batch_multiply_plain(void *evaluator, const uint64_t *ct, uint64_t s
                                  uint64_t plain_stride, uint64_t *out, uint64_t count, void *stream);
 /* forward / inverse negacyclic NTT of u64[polys][N]; polynomial p uses key-level prime (p % nprimes) */
 long hipbfv_batch_ntt(void *evaluator, uint64_t *data, uint64_t polys, uint64_t nprimes, bool inverse, void *stream);
+/* The steps either side of the evaluator, batched on device buffers:
+ * encode / decode: values u64[count][N] (int64 when is_signed) <-> plaintexts u64[count][N];
+ * decrypt: ct u64[count][size][K][N] -> plaintexts u64[count][N] (zero padded);
+ * encrypt: plaintexts u64[count][N] (plain_stride = N) or one shared (0) -> ct u64[count][2][K][N]; item i uses the
+ * Philox counter first_op + i under `seed` (distinct (seed, op) pairs give independent randomness).
+ * encode synchronises the stream (it reports out-of-range values); the others are asynchronous. */
+long hipbfv_batch_encode(void *evaluator, const uint64_t *values, uint64_t *plain, uint64_t count, int is_signed, void *stream);
+long hipbfv_batch_decode(void *evaluator, const uint64_t *plain, uint64_t *values, uint64_t count, int is_signed, void *stream);
+long hipbfv_batch_decrypt(void *evaluator, const uint64_t *ct, uint32_t size, void *secret_key, uint64_t *plain, uint64_t count, void *stream);
+long hipbfv_batch_encrypt(void *evaluator, const uint64_t *plain, uint64_t plain_stride, void *public_key, uint64_t seed, uint64_t first_op,
+                          uint64_t *ct, uint64_t count, void *stream);
 long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
 
 /* Batch executor for compiled FHE program graphs (replaces sunscreen_runtime/src/run.rs:100-357).

@@ -8,16 +8,21 @@ Layers:
   batch.py        the GPU batch executor: the same operations over device-resident batches of ciphertexts
 """
 from .seal import (  # noqa: F401
+    BFVEncoder,
     BFVEvaluator,
     BfvEncryptionParametersBuilder,
     Ciphertext,
     CoefficientModulus,
     Context,
+    Decryptor,
+    Encryptor,
     GaloisKeys,
     HipBfvError,
     Modulus,
     PlainModulus,
     Plaintext,
+    PublicKey,
     RelinearizationKeys,
+    SecretKey,
     SecurityLevel,
 )

@@ -23,6 +23,7 @@ COR_E_INVALIDOPERATION = 0x80131509
 
 vp = C.c_void_p
 vpp = C.POINTER(C.c_void_p)
+i64p = C.POINTER(C.c_int64)
 u64 = C.c_uint64
 u64p = C.POINTER(C.c_uint64)
 
@@ -123,6 +124,25 @@ _SIGNATURES = {
     "hipbfv_batch_sub_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
     "hipbfv_batch_multiply_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
     "hipbfv_batch_ntt": [vp, vp, u64, u64, C.c_bool, vp],
+    "hipbfv_batch_encode": [vp, vp, vp, u64, C.c_int, vp],
+    "hipbfv_batch_decode": [vp, vp, vp, u64, C.c_int, vp],
+    "hipbfv_batch_decrypt": [vp, vp, C.c_uint32, vp, vp, u64, vp],
+    "hipbfv_batch_encrypt": [vp, vp, u64, vp, u64, u64, vp, u64, vp],
+    "hipbfv_SecretKey_Assign": [vp, vp, u64p],
+    "hipbfv_PublicKey_Assign": [vp, vp, u64p],
+    "hipbfv_Encryptor_SetSeed": [vp, u64],
+    "SecretKey_Create1": [vpp], "SecretKey_Create2": [vp, vpp], "SecretKey_Destroy": [vp],
+    "SecretKey_SaveSize": [vp, C.c_uint8, i64p], "SecretKey_Save": [vp, C.c_char_p, u64, C.c_uint8, i64p],
+    "SecretKey_Load": [vp, vp, C.c_char_p, u64, i64p],
+    "PublicKey_Create1": [vpp], "PublicKey_Create2": [vp, vpp], "PublicKey_Destroy": [vp],
+    "PublicKey_SaveSize": [vp, C.c_uint8, i64p], "PublicKey_Save": [vp, C.c_char_p, u64, C.c_uint8, i64p],
+    "PublicKey_Load": [vp, vp, C.c_char_p, u64, i64p],
+    "BatchEncoder_Create": [vp, vpp], "BatchEncoder_Destroy": [vp],
+    "BatchEncoder_Encode1": [vp, u64, u64p, vp], "BatchEncoder_Encode2": [vp, u64, C.POINTER(C.c_int64), vp],
+    "BatchEncoder_Decode1": [vp, vp, u64p, u64p, vp], "BatchEncoder_Decode2": [vp, vp, u64p, C.POINTER(C.c_int64), vp],
+    "BatchEncoder_GetSlotCount": [vp, u64p],
+    "Decryptor_Create": [vp, vp, vpp], "Decryptor_Destroy": [vp], "Decryptor_Decrypt": [vp, vp, vp],
+    "Encryptor_Create": [vp, vp, vp, vpp], "Encryptor_Destroy": [vp], "Encryptor_Encrypt": [vp, vp, vp, vp],
     "hipbfv_set_chunk_ops": [vp, u64],
     "hipbfv_Program_Create": [vpp],
     "hipbfv_Program_Destroy": [vp],

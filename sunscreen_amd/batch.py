@@ -157,6 +157,36 @@ class BatchEvaluator:
     def multiply_plain(self, ct, plain, out=None):
         return self._plain(_lib.load().hipbfv_batch_multiply_plain, ct, plain, out)
 
+    # ---- 8f row 3: the steps either side of the path, on device-resident batches ----
+    def encode(self, values: torch.Tensor, signed: bool = False) -> torch.Tensor:
+        """BatchEncoder: int64[batch, N] slot values -> int64[batch, N] plaintext coefficients."""
+        assert values.dim() == 2 and values.shape[1] == self.n
+        out = torch.empty_like(values)
+        _check(_lib.load().hipbfv_batch_encode(self._h, _ptr(values), _ptr(out), values.shape[0], int(signed), _stream()))
+        return out
+
+    def decode(self, plain: torch.Tensor, signed: bool = False) -> torch.Tensor:
+        assert plain.dim() == 2 and plain.shape[1] == self.n
+        out = torch.empty_like(plain)
+        _check(_lib.load().hipbfv_batch_decode(self._h, _ptr(plain), _ptr(out), plain.shape[0], int(signed), _stream()))
+        return out
+
+    def decrypt(self, ct: torch.Tensor, secret_key) -> torch.Tensor:
+        """int64[batch, size, K, N] -> int64[batch, N] plaintext coefficients (zero padded); secret_key: seal.SecretKey."""
+        assert ct.dim() == 4 and ct.shape[2] == self.K and ct.shape[3] == self.n
+        out = torch.empty((ct.shape[0], self.n), dtype=torch.int64, device=ct.device)
+        _check(_lib.load().hipbfv_batch_decrypt(self._h, _ptr(ct), ct.shape[1], secret_key.get_handle(), _ptr(out), ct.shape[0], _stream()))
+        return out
+
+    def encrypt(self, plain: torch.Tensor, public_key, seed: int, first_op: int = 0) -> torch.Tensor:
+        """int64[batch, N] (or one shared int64[N]) plaintexts -> fresh encryptions int64[batch', 2, K, N]."""
+        shared = plain.dim() == 1
+        count = 1 if shared else plain.shape[0]
+        out = torch.empty((count, 2, self.K, self.n), dtype=torch.int64, device=plain.device)
+        _check(_lib.load().hipbfv_batch_encrypt(self._h, _ptr(plain), 0 if shared else self.n, public_key.get_handle(), seed, first_op,
+                                                _ptr(out), count, _stream()))
+        return out
+
     # ---- a6: NTT entry points (BASELINE config 2) ----
     def ntt(self, data: torch.Tensor, nprimes: int, inverse: bool = False) -> torch.Tensor:
         """In-place negacyclic NTT of int64[polys, N]; polynomial p uses key-level prime p % nprimes."""

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -57,6 +58,11 @@ enum Magic : uint32_t {
   kMagicKeys = 0x4B535731,
   kMagicEval = 0x45564C31,
   kMagicProgram = 0x50524731,
+  kMagicSecretKey = 0x534B4531,
+  kMagicPublicKey = 0x504B4531,
+  kMagicEncoder = 0x42454E31,
+  kMagicDecryptor = 0x44454331,
+  kMagicEncryptor = 0x454E4331,
 };
 
 struct Obj {
@@ -170,6 +176,40 @@ struct EvalObj : Obj {
   std::shared_ptr<Context> ctx;
   std::unique_ptr<Evaluator> ev;
   EvalObj() : Obj(kMagicEval) {}
+};
+
+// SecretKey: u64[KK][N] NTT form (SEAL SecretKey data); PublicKey: u64[2][KK][N] NTT form.  The device buffer is
+// shared with every Decryptor / Encryptor created from the handle.
+struct KeyBuffer {
+  std::shared_ptr<Context> ctx;
+  u64* dev = nullptr;
+  size_t words = 0;
+  ~KeyBuffer() { g_buffers.put(dev, words); }
+};
+struct AsymKeyObj : Obj {
+  std::shared_ptr<KeyBuffer> key;
+  explicit AsymKeyObj(uint32_t magic) : Obj(magic) {}
+};
+
+struct EncoderObj : Obj {
+  std::shared_ptr<Context> ctx;
+  std::unique_ptr<Evaluator> ev;
+  EncoderObj() : Obj(kMagicEncoder) {}
+};
+struct DecryptorObj : Obj {
+  std::shared_ptr<Context> ctx;
+  std::unique_ptr<Evaluator> ev;
+  std::shared_ptr<KeyBuffer> sk;
+  DecryptorObj() : Obj(kMagicDecryptor) {}
+};
+struct EncryptorObj : Obj {
+  std::shared_ptr<Context> ctx;
+  std::unique_ptr<Evaluator> ev;
+  std::shared_ptr<KeyBuffer> pk;
+  u64 seed = 0;
+  std::mutex mu;
+  u64 next_op = 0;  // Philox counter: every encryption of one Encryptor uses fresh randomness
+  EncryptorObj() : Obj(kMagicEncryptor) {}
 };
 
 struct ProgramObj : Obj {
@@ -1565,6 +1605,384 @@ long hipbfv_set_chunk_ops(void* h, uint64_t chunk) {
   EVAL_OR_RETURN(h);
   e->ev->set_chunk_ops(chunk);
   return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ SecretKey / PublicKey (seal_fhe/src/key_generator.rs:200-430)
+static long asym_create(uint32_t magic, void** out) {
+  if (!out) return HIPBFV_E_POINTER;
+  *out = new AsymKeyObj(magic);
+  return HIPBFV_S_OK;
+}
+static long asym_copy(uint32_t magic, void* copy, void** out) {
+  AsymKeyObj* k = as<AsymKeyObj>(copy, magic);
+  if (!k || !out) return HIPBFV_E_POINTER;
+  AsymKeyObj* n = new AsymKeyObj(magic);
+  n->key = k->key;  // immutable once assigned: sharing is a deep copy as far as callers can tell
+  *out = n;
+  return HIPBFV_S_OK;
+}
+static long asym_destroy(uint32_t magic, void* h) {
+  AsymKeyObj* k = as<AsymKeyObj>(h, magic);
+  if (!k) return HIPBFV_E_POINTER;
+  delete k;
+  return HIPBFV_S_OK;
+}
+static long asym_assign(uint32_t magic, void* h, void* context, const uint64_t* host, size_t polys) {
+  AsymKeyObj* k = as<AsymKeyObj>(h, magic);
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!k || !x || !host) return HIPBFV_E_POINTER;
+  const Context& c = *x->ctx;
+  const size_t words = polys * c.KK() * c.n();
+  for (size_t p = 0; p < polys; p++)
+    for (size_t i = 0; i < c.KK(); i++) {
+      const u64 q = c.key_primes()[i];
+      const uint64_t* row = host + (p * c.KK() + i) * c.n();
+      for (size_t j = 0; j < c.n(); j++)
+        if (row[j] >= q) return fail(HIPBFV_E_INVALIDARG, "key data is invalid for the encryption parameters");
+    }
+  auto buf = std::make_shared<KeyBuffer>();
+  buf->ctx = x->ctx;
+  buf->words = words;
+  buf->dev = g_buffers.get(words);
+  if (!buf->dev) return from_status(kOutOfMemory);
+  if (hipMemcpy(buf->dev, host, words * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) return from_status(kHipError);
+  k->key = buf;
+  return HIPBFV_S_OK;
+}
+static long asym_to_host(AsymKeyObj* k, std::vector<u64>* host) {
+  if (!k->key || !k->key->dev) return fail(HIPBFV_E_INVALIDARG, "key is empty");
+  host->resize(k->key->words);
+  if (hipMemcpy(host->data(), k->key->dev, host->size() * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return from_status(kHipError);
+  return HIPBFV_S_OK;
+}
+
+long SecretKey_Create1(void** out) { return asym_create(kMagicSecretKey, out); }
+long SecretKey_Create2(void* copy, void** out) { return asym_copy(kMagicSecretKey, copy, out); }
+long SecretKey_Destroy(void* h) { return asym_destroy(kMagicSecretKey, h); }
+long PublicKey_Create1(void** out) { return asym_create(kMagicPublicKey, out); }
+long PublicKey_Create2(void* copy, void** out) { return asym_copy(kMagicPublicKey, copy, out); }
+long PublicKey_Destroy(void* h) { return asym_destroy(kMagicPublicKey, h); }
+long hipbfv_SecretKey_Assign(void* h, void* context, const uint64_t* host_data) { return asym_assign(kMagicSecretKey, h, context, host_data, 1); }
+long hipbfv_PublicKey_Assign(void* h, void* context, const uint64_t* host_data) { return asym_assign(kMagicPublicKey, h, context, host_data, 2); }
+
+// SecretKey is serialised as a Plaintext whose parms_id is the key level's (seal_fhe/tests/data/secret_key.bin)
+long SecretKey_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+  AsymKeyObj* k = as<AsymKeyObj>(h, kMagicSecretKey);
+  if (!k || !result) return HIPBFV_E_POINTER;
+  const size_t raw = 16 + 32 + 16 + 16 + 8 + (k->key ? k->key->words : 0) * 8;
+  *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
+  return HIPBFV_S_OK;
+}
+long SecretKey_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+  AsymKeyObj* k = as<AsymKeyObj>(h, kMagicSecretKey);
+  if (!k || !outptr || !out_bytes) return HIPBFV_E_POINTER;
+  std::vector<u64> host;
+  if (long hr = asym_to_host(k, &host)) return hr;
+  uint8_t pid[32];
+  key_level_parms_id(*k->key->ctx, pid);
+  std::vector<uint8_t> buf;
+  if (int rc = wire_pack_plaintext(pid, reinterpret_cast<const unsigned long long*>(host.data()), host.size(), compr_mode, &buf)) return from_wire(rc);
+  if (size < buf.size()) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
+  std::memcpy(outptr, buf.data(), buf.size());
+  *out_bytes = (int64_t)buf.size();
+  return HIPBFV_S_OK;
+}
+long SecretKey_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!as<AsymKeyObj>(h, kMagicSecretKey) || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
+  WirePlaintext pt;
+  size_t used = 0;
+  if (int rc = wire_unpack_plaintext(inptr, size, &pt, &used)) return from_wire(rc);
+  uint8_t pid[32];
+  key_level_parms_id(*x->ctx, pid);
+  if (std::memcmp(pid, pt.parms_id, 32) != 0 || pt.coeffs.size() != (size_t)x->ctx->KK() * x->ctx->n())
+    return fail(HIPBFV_E_INVALIDARG, "secret key data is invalid for the encryption parameters");
+  long hr = asym_assign(kMagicSecretKey, h, context, reinterpret_cast<const uint64_t*>(pt.coeffs.data()), 1);
+  if (hr == HIPBFV_S_OK) *in_bytes = (int64_t)used;
+  return hr;
+}
+
+// PublicKey is serialised as a size-2 NTT-form Ciphertext at the key level (seal_fhe/tests/data/public_key.bin)
+long PublicKey_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+  AsymKeyObj* k = as<AsymKeyObj>(h, kMagicPublicKey);
+  if (!k || !result) return HIPBFV_E_POINTER;
+  const size_t raw = 16 + 32 + 1 + 8 * 5 + 16 + 8 + (k->key ? k->key->words : 0) * 8;
+  *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
+  return HIPBFV_S_OK;
+}
+long PublicKey_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+  AsymKeyObj* k = as<AsymKeyObj>(h, kMagicPublicKey);
+  if (!k || !outptr || !out_bytes) return HIPBFV_E_POINTER;
+  std::vector<u64> host;
+  if (long hr = asym_to_host(k, &host)) return hr;
+  const Context& c = *k->key->ctx;
+  uint8_t pid[32];
+  key_level_parms_id(c, pid);
+  std::vector<uint8_t> buf;
+  if (int rc = wire_pack_ciphertext(pid, true, 2, c.n(), c.KK(), reinterpret_cast<const unsigned long long*>(host.data()), compr_mode, &buf))
+    return from_wire(rc);
+  if (size < buf.size()) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
+  std::memcpy(outptr, buf.data(), buf.size());
+  *out_bytes = (int64_t)buf.size();
+  return HIPBFV_S_OK;
+}
+long PublicKey_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!as<AsymKeyObj>(h, kMagicPublicKey) || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
+  WireCiphertext ct;
+  size_t used = 0;
+  if (int rc = wire_unpack_ciphertext(inptr, size, &ct, &used)) return from_wire(rc);
+  uint8_t pid[32];
+  key_level_parms_id(*x->ctx, pid);
+  if (std::memcmp(pid, ct.parms_id, 32) != 0 || !ct.is_ntt || ct.size != 2 || ct.n != x->ctx->n() || ct.k != x->ctx->KK())
+    return fail(HIPBFV_E_INVALIDARG, "public key data is invalid for the encryption parameters");
+  long hr = asym_assign(kMagicPublicKey, h, context, reinterpret_cast<const uint64_t*>(ct.data.data()), 2);
+  if (hr == HIPBFV_S_OK) *in_bytes = (int64_t)used;
+  return hr;
+}
+
+// ------------------------------------------------------------------ BatchEncoder (seal_fhe/src/encoder.rs:50-215)
+long BatchEncoder_Create(void* context, void** out) {
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!x || !out) return HIPBFV_E_POINTER;
+  if (!x->ctx->batching()) return fail(HIPBFV_E_INVALIDARG, "encryption parameters are not valid for batching");
+  EncoderObj* e = new EncoderObj();
+  e->ctx = x->ctx;
+  e->ev.reset(new Evaluator(x->ctx.get()));
+  *out = e;
+  return HIPBFV_S_OK;
+}
+long BatchEncoder_Destroy(void* h) {
+  EncoderObj* e = as<EncoderObj>(h, kMagicEncoder);
+  if (!e) return HIPBFV_E_POINTER;
+  delete e;
+  return HIPBFV_S_OK;
+}
+long BatchEncoder_GetSlotCount(void* h, uint64_t* count) {
+  EncoderObj* e = as<EncoderObj>(h, kMagicEncoder);
+  if (!e || !count) return HIPBFV_E_POINTER;
+  *count = e->ctx->n();
+  return HIPBFV_S_OK;
+}
+static long encode_common(void* h, uint64_t count, const uint64_t* values, void* plain, bool is_signed) {
+  EncoderObj* e = as<EncoderObj>(h, kMagicEncoder);
+  PlainObj* p = as<PlainObj>(plain, kMagicPlain);
+  if (!e || !p || (count && !values)) return HIPBFV_E_POINTER;
+  const size_t n = e->ctx->n();
+  if (count > n) return fail(HIPBFV_E_INVALIDARG, "values has invalid size");
+  std::vector<u64> slots(n, 0);
+  std::copy(values, values + count, slots.begin());
+  hipStream_t s = thread_stream();
+  u64* dev = g_buffers.get(2 * n);
+  if (!dev) return from_status(kOutOfMemory);
+  long hr = HIPBFV_S_OK;
+  u32 bad = 0;
+  if (hipMemcpyAsync(dev, slots.data(), n * sizeof(u64), hipMemcpyHostToDevice, s) != hipSuccess)
+    hr = from_status(kHipError);
+  else if (int st = e->ev->batch_encode(dev, dev + n, 1, is_signed, &bad, s))
+    hr = from_status(st);
+  else if (bad)
+    hr = fail(HIPBFV_E_INVALIDARG, "input value is larger than plain_modulus");
+  else {
+    p->coeffs.assign(n, 0);
+    if (hipMemcpy(p->coeffs.data(), dev + n, n * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) hr = from_status(kHipError);
+  }
+  g_buffers.put(dev, 2 * n);
+  return hr;
+}
+long BatchEncoder_Encode1(void* h, uint64_t count, uint64_t* values, void* plain) { return encode_common(h, count, values, plain, false); }
+long BatchEncoder_Encode2(void* h, uint64_t count, int64_t* values, void* plain) {
+  return encode_common(h, count, reinterpret_cast<const uint64_t*>(values), plain, true);
+}
+static long decode_common(void* h, void* plain, uint64_t* count, uint64_t* values, bool is_signed) {
+  EncoderObj* e = as<EncoderObj>(h, kMagicEncoder);
+  PlainObj* p = as<PlainObj>(plain, kMagicPlain);
+  if (!e || !p || !count || !values) return HIPBFV_E_POINTER;
+  const size_t n = e->ctx->n();
+  if (p->coeffs.size() > n) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
+  std::vector<u64> coeffs(n, 0);
+  std::copy(p->coeffs.begin(), p->coeffs.end(), coeffs.begin());
+  hipStream_t s = thread_stream();
+  u64* dev = g_buffers.get(2 * n);
+  if (!dev) return from_status(kOutOfMemory);
+  long hr = HIPBFV_S_OK;
+  if (hipMemcpyAsync(dev, coeffs.data(), n * sizeof(u64), hipMemcpyHostToDevice, s) != hipSuccess)
+    hr = from_status(kHipError);
+  else if (int st = e->ev->batch_decode(dev, dev + n, 1, is_signed, s))
+    hr = from_status(st);
+  else if (hipMemcpyAsync(values, dev + n, n * sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    hr = from_status(kHipError);
+  else
+    *count = n;
+  g_buffers.put(dev, 2 * n);
+  return hr;
+}
+long BatchEncoder_Decode1(void* h, void* plain, uint64_t* count, uint64_t* values, void* pool) {
+  (void)pool;
+  return decode_common(h, plain, count, values, false);
+}
+long BatchEncoder_Decode2(void* h, void* plain, uint64_t* count, int64_t* values, void* pool) {
+  (void)pool;
+  return decode_common(h, plain, count, reinterpret_cast<uint64_t*>(values), true);
+}
+
+// ------------------------------------------------------------------ Decryptor (seal_fhe/src/encryptor_decryptor.rs:596-690)
+long Decryptor_Create(void* context, void* secret_key, void** out) {
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  AsymKeyObj* k = as<AsymKeyObj>(secret_key, kMagicSecretKey);
+  if (!x || !k || !out) return HIPBFV_E_POINTER;
+  if (!k->key || k->key->ctx.get() != x->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "secret key is not valid for encryption parameters");
+  DecryptorObj* d = new DecryptorObj();
+  d->ctx = x->ctx;
+  d->ev.reset(new Evaluator(x->ctx.get()));
+  d->sk = k->key;
+  *out = d;
+  return HIPBFV_S_OK;
+}
+long Decryptor_Destroy(void* h) {
+  DecryptorObj* d = as<DecryptorObj>(h, kMagicDecryptor);
+  if (!d) return HIPBFV_E_POINTER;
+  delete d;
+  return HIPBFV_S_OK;
+}
+long Decryptor_Decrypt(void* h, void* encrypted, void* destination) {
+  DecryptorObj* d = as<DecryptorObj>(h, kMagicDecryptor);
+  CipherObj* c = as<CipherObj>(encrypted, kMagicCipher);
+  PlainObj* p = as<PlainObj>(destination, kMagicPlain);
+  if (!d || !c || !p) return HIPBFV_E_POINTER;
+  if (!c->ctx || c->ctx.get() != d->ctx.get() || !c->dev || c->size < 2)
+    return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  const size_t n = d->ctx->n();
+  hipStream_t s = thread_stream();
+  u64* dev = g_buffers.get(n);
+  if (!dev) return from_status(kOutOfMemory);
+  long hr = HIPBFV_S_OK;
+  std::vector<u64> host(n);
+  if (int st = d->ev->decrypt(c->dev, c->size, d->sk->dev, dev, 1, s))
+    hr = from_status(st);
+  else if (hipMemcpyAsync(host.data(), dev, n * sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    hr = from_status(kHipError);
+  g_buffers.put(dev, n);
+  if (hr != HIPBFV_S_OK) return hr;
+  // SEAL resizes the plaintext to its significant coefficient count (at least one coefficient)
+  size_t len = n;
+  while (len > 1 && host[len - 1] == 0) len--;
+  host.resize(len);
+  p->coeffs.swap(host);
+  return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ Encryptor, public-key mode (encryptor_decryptor.rs:140-260)
+long Encryptor_Create(void* context, void* public_key, void* secret_key, void** out) {
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!x || !out) return HIPBFV_E_POINTER;
+  AsymKeyObj* pk = as<AsymKeyObj>(public_key, kMagicPublicKey);
+  (void)secret_key;  // symmetric encryption stays client-side (Encryptor_EncryptSymmetric is not exported)
+  if (!pk) return fail(HIPBFV_E_INVALIDARG, "a public key is required");
+  if (!pk->key || pk->key->ctx.get() != x->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "public key is not valid for encryption parameters");
+  EncryptorObj* e = new EncryptorObj();
+  e->ctx = x->ctx;
+  e->ev.reset(new Evaluator(x->ctx.get()));
+  e->pk = pk->key;
+  // fresh seed per Encryptor from the OS (SEAL seeds its PRNG factory from std::random_device the same way)
+  {
+    FILE* f = std::fopen("/dev/urandom", "rb");
+    u64 sd = 0;
+    if (!f || std::fread(&sd, sizeof(sd), 1, f) != 1) sd = (u64)(uintptr_t)e ^ 0x9E3779B97F4A7C15ull;
+    if (f) std::fclose(f);
+    e->seed = sd;
+  }
+  *out = e;
+  return HIPBFV_S_OK;
+}
+long Encryptor_Destroy(void* h) {
+  EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
+  if (!e) return HIPBFV_E_POINTER;
+  delete e;
+  return HIPBFV_S_OK;
+}
+long hipbfv_Encryptor_SetSeed(void* h, uint64_t seed) {
+  EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
+  if (!e) return HIPBFV_E_POINTER;
+  std::lock_guard<std::mutex> g(e->mu);
+  e->seed = seed;
+  e->next_op = 0;
+  return HIPBFV_S_OK;
+}
+long Encryptor_Encrypt(void* h, void* plaintext, void* destination, void* pool) {
+  (void)pool;
+  EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
+  PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
+  CipherObj* c = as<CipherObj>(destination, kMagicCipher);
+  if (!e || !p || !c) return HIPBFV_E_POINTER;
+  const size_t n = e->ctx->n(), words = e->ctx->ct_words(2);
+  if (p->coeffs.size() > n) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
+  for (u64 v : p->coeffs)
+    if (v >= e->ctx->t()) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
+  u64 op, seed;
+  {
+    std::lock_guard<std::mutex> g(e->mu);
+    op = e->next_op++;
+    seed = e->seed;
+  }
+  std::vector<u64> coeffs(n, 0);
+  std::copy(p->coeffs.begin(), p->coeffs.end(), coeffs.begin());
+  hipStream_t s = thread_stream();
+  u64* pl = g_buffers.get(n);
+  u64* out = g_buffers.get(words);
+  if (!pl || !out) {
+    g_buffers.put(pl, n);
+    g_buffers.put(out, words);
+    return from_status(kOutOfMemory);
+  }
+  long hr = HIPBFV_S_OK;
+  if (hipMemcpyAsync(pl, coeffs.data(), n * sizeof(u64), hipMemcpyHostToDevice, s) != hipSuccess)
+    hr = from_status(kHipError);
+  else if (int st = e->ev->encrypt(pl, 0, e->pk->dev, seed, op, out, 1, s))
+    hr = from_status(st);
+  else
+    hr = sync_stream(s);
+  g_buffers.put(pl, n);
+  if (hr != HIPBFV_S_OK) {
+    g_buffers.put(out, words);
+    return hr;
+  }
+  c->adopt(e->ctx, 2, out, words);
+  return HIPBFV_S_OK;
+}
+
+// ------------------------------------------------------------------ batched device-pointer forms
+static Evaluator* eval_of(void* evaluator) {
+  EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
+  return e ? e->ev.get() : nullptr;
+}
+long hipbfv_batch_encode(void* evaluator, const uint64_t* values, uint64_t* plain, uint64_t count, int is_signed, void* stream) {
+  Evaluator* ev = eval_of(evaluator);
+  if (!ev || !values || !plain) return HIPBFV_E_POINTER;
+  u32 bad = 0;
+  if (int st = ev->batch_encode((const u64*)values, (u64*)plain, count, is_signed != 0, &bad, (hipStream_t)stream)) return from_status(st);
+  if (bad) return fail(HIPBFV_E_INVALIDARG, "input value is larger than plain_modulus");
+  return HIPBFV_S_OK;
+}
+long hipbfv_batch_decode(void* evaluator, const uint64_t* plain, uint64_t* values, uint64_t count, int is_signed, void* stream) {
+  Evaluator* ev = eval_of(evaluator);
+  if (!ev || !values || !plain) return HIPBFV_E_POINTER;
+  return from_status(ev->batch_decode((const u64*)plain, (u64*)values, count, is_signed != 0, (hipStream_t)stream));
+}
+long hipbfv_batch_decrypt(void* evaluator, const uint64_t* ct, uint32_t size, void* secret_key, uint64_t* plain, uint64_t count, void* stream) {
+  EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
+  AsymKeyObj* k = as<AsymKeyObj>(secret_key, kMagicSecretKey);
+  if (!e || !k || !ct || !plain) return HIPBFV_E_POINTER;
+  if (!k->key || k->key->ctx.get() != e->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "secret key is not valid for encryption parameters");
+  return from_status(e->ev->decrypt((const u64*)ct, size, k->key->dev, (u64*)plain, count, (hipStream_t)stream));
+}
+long hipbfv_batch_encrypt(void* evaluator, const uint64_t* plain, uint64_t plain_stride, void* public_key, uint64_t seed, uint64_t first_op,
+                          uint64_t* ct, uint64_t count, void* stream) {
+  EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
+  AsymKeyObj* k = as<AsymKeyObj>(public_key, kMagicPublicKey);
+  if (!e || !k || !ct || !plain) return HIPBFV_E_POINTER;
+  if (!k->key || k->key->ctx.get() != e->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "public key is not valid for encryption parameters");
+  return from_status(e->ev->encrypt((const u64*)plain, plain_stride, k->key->dev, seed, first_op, (u64*)ct, count, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -348,6 +348,7 @@ Context::~Context() {
   if (dev_) (void)hipFree(dev_);
   if (tw_fwd_) (void)hipFree(tw_fwd_);
   if (tw_inv_) (void)hipFree(tw_inv_);
+  if (batch_map_) (void)hipFree(batch_map_);
 }
 
 Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int device, std::string* err) {
@@ -452,24 +453,33 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
   std::vector<u64> all;
   all.insert(all.end(), key_primes.begin(), key_primes.end());
   all.insert(all.end(), Bsk.begin(), Bsk.end());
-  std::vector<MulOp> twf((size_t)h.P * n), twi((size_t)h.P * n);
-  for (u32 m = 0; m < h.P; m++) {
-    const u64 p = all[m];
-    DevMod& dm = h.mod[m];
+  // the plain modulus joins the table when it supports batching (BatchEncoder transforms over Z_t)
+  c->batching_ = is_prime_u64(t) && (t - 1) % two_n == 0;
+  h.batching = c->batching_ ? 1u : 0u;
+  h.t_mod = h.P;
+  if (c->batching_) all.push_back(t);
+  const u32 nmods = (u32)all.size();
+  auto fill_basic = [&](DevMod& dm, u64 p) {
     dm.q = p;
     dm.q2 = p << 1;
     u128 ratio = (~(u128)0) / p;  // p is odd: floor((2^128-1)/p) == floor(2^128/p)
     dm.bar_lo = (u64)ratio;
     dm.bar_hi = (u64)(ratio >> 64);
-    u64 ninv;
-    if (!invm(n, p, &ninv)) return fail("n not invertible");
-    dm.ninv = make_mulop(ninv, p);
     dm.pm_c = 0;
     if ((p >> 60) == 1 && ((1ull << 61) - p) < (1ull << 28)) dm.pm_c = (u32)((1ull << 61) - p);
     if (const char* env = std::getenv("HIPBFV_NO_PM61"))
       if (env[0] == '1') dm.pm_c = 0;
     dm.qd = (double)p;
     dm.qinv = 1.0 / (double)p;
+  };
+  std::vector<MulOp> twf((size_t)nmods * n), twi((size_t)nmods * n);
+  for (u32 m = 0; m < nmods; m++) {
+    const u64 p = all[m];
+    DevMod& dm = h.mod[m];
+    fill_basic(dm, p);
+    u64 ninv;
+    if (!invm(n, p, &ninv)) return fail("n not invertible");
+    dm.ninv = make_mulop(ninv, p);
     dm.ninv_d = make_mulop_d(ninv, p);
     dm.use_f64 = plan_f64_path(p, (int)h.logn, 16, &dm.fwd_reduce_mask, &dm.inv_reduce_mask) ? 1u : 0u;
     dm.split_ok = dm.use_f64 && plan_f64_split(p, (int)h.logn, &dm.split_fwd_mask, &dm.split_inv_mask) ? 1u : 0u;
@@ -588,7 +598,46 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       if (t >= q[i]) h.fast_plain_lift = 0;
     }
   }
-  c->batching_ = is_prime_u64(t) && (t - 1) % two_n == 0;
+  // ---- Decryptor: SEAL RNSTool::decrypt_scale_and_round in the base {t, gamma} ----
+  {
+    fill_basic(h.tm, t);
+    if (((~(u128)0) % t) == t - 1) {  // t divides 2^128 (a power of two): floor(2^128/t) is one more than floor((2^128-1)/t)
+      const u128 ratio = (~(u128)0) / t + 1;
+      h.tm.bar_lo = (u64)ratio;
+      h.tm.bar_hi = (u64)(ratio >> 64);
+    }
+    const std::vector<u64> g2 = find_primes(two_n, 61, 2);  // SEAL: [m_sk, gamma, B...] -> gamma is the second
+    if (g2.size() != 2) return fail("cannot find gamma");
+    const u64 gamma = g2[1];
+    fill_basic(h.gamma, gamma);
+    for (u32 i = 0; i < K; i++) {
+      u64 inv_punct;
+      invm(prod_mod(q, q[i], (int)i), q[i], &inv_punct);
+      const u64 tg = mulm(t % q[i], gamma % q[i], q[i]);
+      h.dec_scale_q[i] = make_mulop(mulm(tg, inv_punct, q[i]), q[i]);
+      h.q_to_t[i] = prod_mod(q, t, (int)i);
+      h.q_to_gamma[i] = prod_mod(q, gamma, (int)i);
+    }
+    u64 inv;
+    if (!invm(prod_mod(q, t), t, &inv)) return fail("q not invertible mod t");
+    h.neg_inv_q_mod_t = make_mulop((t - inv) % t, t);
+    invm(prod_mod(q, gamma), gamma, &inv);
+    h.neg_inv_q_mod_gamma = make_mulop(gamma - inv, gamma);
+    if (!invm(gamma % t, t, &inv)) return fail("gamma not invertible mod t");
+    h.inv_gamma_mod_t = make_mulop(inv, t);
+  }
+  // BatchEncoder matrix_reps_index_map (SEAL batchencoder.cpp; seal_fhe/src/encoder.rs:75-190)
+  std::vector<u32> bmap;
+  if (c->batching_) {
+    bmap.resize(n);
+    const u32 row = n >> 1, m2 = n << 1;
+    u64 pos = 1;
+    for (u32 i = 0; i < row; i++) {
+      bmap[i] = bit_reverse((u32)((pos - 1) >> 1), h.logn);
+      bmap[row | i] = bit_reverse((u32)((m2 - pos - 1) >> 1), h.logn);
+      pos = (pos * 3) & (m2 - 1);
+    }
+  }
 
   // ---- upload ----
   if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
@@ -602,6 +651,11 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       hipMemcpy(c->tw_inv_, twi.data(), tw_bytes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->dev_, &h, sizeof(DevCtx), hipMemcpyHostToDevice) != hipSuccess)
     return fail("hipMemcpy failed");
+  if (!bmap.empty()) {
+    if (hipMalloc((void**)&c->batch_map_, bmap.size() * sizeof(u32)) != hipSuccess ||
+        hipMemcpy(c->batch_map_, bmap.data(), bmap.size() * sizeof(u32), hipMemcpyHostToDevice) != hipSuccess)
+      return fail("hipMalloc failed");
+  }
   return c.release();
 }
 

@@ -38,6 +38,7 @@ class Context {
   const DevCtx* dev() const { return dev_; }
   const std::vector<u64>& key_primes() const { return key_primes_; }
   bool batching() const { return batching_; }
+  const u32* batch_index_map() const { return batch_map_; }  // device u32[n]: BatchEncoder matrix_reps_index_map
   size_t ct_words(size_t size) const { return size * (size_t)host_.K * host_.n; }
   size_t key_words() const { return (size_t)host_.K * 2 * host_.KK * host_.n; }
 
@@ -47,6 +48,7 @@ class Context {
   DevCtx* dev_ = nullptr;
   MulOp* tw_fwd_ = nullptr;
   MulOp* tw_inv_ = nullptr;
+  u32* batch_map_ = nullptr;
   int device_ = 0;
   bool batching_ = false;
   std::vector<u64> key_primes_;

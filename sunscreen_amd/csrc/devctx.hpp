@@ -14,7 +14,7 @@ typedef unsigned int u32;
 
 constexpr int kMaxKey = 17;   // key-level primes (n=32768 default: 16)
 constexpr int kMaxBsk = 18;   // |B| + 1
-constexpr int kMaxMod = kMaxKey + kMaxBsk;
+constexpr int kMaxMod = kMaxKey + kMaxBsk + 1;  // + the plain modulus (BatchEncoder transforms)
 
 // A constant multiplicand with its Shoup quotient floor(w * 2^64 / q).
 struct MulOp {
@@ -114,6 +114,18 @@ struct DevCtx {
   u64 qsp_half;                        // q_sp >> 1
   u64 qsp_half_mod_q[kMaxKey];         // (q_sp >> 1) mod q_i
   MulOp inv_qsp_mod_q[kMaxKey];        // q_sp^{-1} mod q_i
+
+  // ---- the steps either side of the evaluator (kernels_client.hip): BatchEncoder, Decryptor, Encryptor ----
+  u32 batching;                        // t is a prime == 1 (mod 2N): mod[t_mod] = t with NTT tables
+  u32 t_mod;                           // = KK + S
+  DevMod tm;                           // Barrett constants of t (valid for every t)
+  DevMod gamma;                        // SEAL's gamma: decrypt_scale_and_round works in the base {t, gamma}
+  MulOp dec_scale_q[kMaxKey];          // t * gamma * (q/q_i)^{-1} mod q_i
+  u64 q_to_t[kMaxKey];                 // (q/q_i) mod t
+  u64 q_to_gamma[kMaxKey];             // (q/q_i) mod gamma
+  MulOp neg_inv_q_mod_t;               // -(q^{-1}) mod t
+  MulOp neg_inv_q_mod_gamma;           // -(q^{-1}) mod gamma
+  MulOp inv_gamma_mod_t;               // gamma^{-1} mod t
 
   // ---- plaintext lifting / scaling ----
   u64 q_div_t_mod_q[kMaxKey];          // floor(q/t) mod q_i

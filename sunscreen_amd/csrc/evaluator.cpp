@@ -81,16 +81,6 @@ void ScratchPool::release(void* p, hipStream_t s) {
 }
 
 namespace {
-struct ScratchGuard {
-  ScratchPool& pool;
-  hipStream_t s;
-  void* p;
-  ScratchGuard(ScratchPool& pl, size_t bytes, hipStream_t st) : pool(pl), s(st), p(pl.acquire(bytes, st)) {}
-  ~ScratchGuard() {
-    if (p) pool.release(p, s);
-  }
-};
-
 NttPlan make_plan(u32 div, const std::vector<u32>& mods) {
   NttPlan pl{};
   pl.div = div;

@@ -95,6 +95,19 @@ class Profiler {
   hipEvent_t get_event();
 };
 
+// RAII lease of a scratch-pool buffer on a stream
+struct ScratchGuard {
+  ScratchPool& pool;
+  hipStream_t s;
+  void* p;
+  ScratchGuard(ScratchPool& pl, size_t bytes, hipStream_t st) : pool(pl), s(st), p(pl.acquire(bytes, st)) {}
+  ~ScratchGuard() {
+    if (p) pool.release(p, s);
+  }
+  ScratchGuard(const ScratchGuard&) = delete;
+  ScratchGuard& operator=(const ScratchGuard&) = delete;
+};
+
 class Evaluator {
  public:
   explicit Evaluator(Context* ctx);
@@ -119,6 +132,12 @@ class Evaluator {
   int multiply_plain_mono(const u64* ct, u32 size, u64 coeff, u32 exponent, u64* out, size_t count, hipStream_t s);
   // flags[i] = 1 if ciphertext i is NOT transparent (some word of polys 1.. is non-zero); flags must be zeroed
   int nonzero_tail(const u64* ct, u32 size, u32* flags, size_t count, hipStream_t s);
+
+  // ---- the steps either side of the path (evaluator_client.cpp) ----
+  int batch_encode(const u64* values, u64* plain, size_t count, bool is_signed, u32* bad_host, hipStream_t s);
+  int batch_decode(const u64* plain, u64* values, size_t count, bool is_signed, hipStream_t s);
+  int decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, size_t count, hipStream_t s);
+  int encrypt(const u64* plain, size_t pstride, const u64* pk, u64 seed, u64 first_op, u64* ct2, size_t count, hipStream_t s);
 
   // ---- NTT entry points (BASELINE config 2) ----
   // data: u64[polys][N]; polynomial p uses key-level prime (p % nprimes)

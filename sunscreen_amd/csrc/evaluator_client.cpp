@@ -1,0 +1,145 @@
+// sunscreen_amd/csrc/evaluator_client.cpp -- batched BatchEncoder / Decryptor / Encryptor on the device
+// (the steps either side of the evaluator path; kernels in kernels_client.hip).
+//
+// Reference interfaces: seal_fhe/src/encoder.rs:75-190 (BatchEncoder_Encode1/2, Decode1/2),
+// seal_fhe/src/encryptor_decryptor.rs:238-254 (Encryptor_Encrypt), :618-629 (Decryptor_Decrypt).
+#include <algorithm>
+#include <vector>
+
+#include "evaluator.hpp"
+#include "kernels.hpp"
+
+namespace hipbfv {
+
+namespace {
+#define HC_CHECK(expr)                      \
+  do {                                      \
+    if ((expr) != hipSuccess) return kHipError; \
+  } while (0)
+
+#define HB_LAUNCH_CLIENT(id, units, expr)     \
+  do {                                        \
+    prof_.begin(id, units, s);                \
+    hipError_t e__ = (expr);                  \
+    prof_.end(s);                             \
+    if (e__ != hipSuccess) return kHipError;  \
+  } while (0)
+
+NttPlan single_mod_plan(u32 m) {
+  NttPlan pl{};
+  pl.div = 1;
+  pl.period = 1;
+  pl.mod[0] = (unsigned char)m;
+  return pl;
+}
+NttPlan range_plan(u32 count) {
+  NttPlan pl{};
+  pl.div = 1;
+  pl.period = count;
+  for (u32 i = 0; i < count; i++) pl.mod[i] = (unsigned char)i;
+  return pl;
+}
+}  // namespace
+
+// plain[op] = BatchEncoder_Encode(values[op]); values: u64[count][N] (or int64 when is_signed); *bad_host != 0 if a
+// value lay outside the plain modulus (the plaintexts of such ops are not meaningful)
+int Evaluator::batch_encode(const u64* values, u64* plain, size_t count, bool is_signed, u32* bad_host, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (!ctx_->batching()) return kUnsupported;
+  ScratchGuard flag(pool_, sizeof(u32), s);
+  if (!flag.p) return kOutOfMemory;
+  HC_CHECK(hipMemsetAsync(flag.p, 0, sizeof(u32), s));
+  const NttPlan plan = single_mod_plan(h.t_mod);
+  for (size_t off = 0; off < count; off += 65535) {
+    const size_t c = std::min<size_t>(65535, count - off);
+    HC_CHECK(launch_batch_scatter(ctx_->dev(), h.n, ctx_->batch_index_map(), values + off * h.n, plain + off * h.n, c, is_signed ? 1 : 0, (u32*)flag.p, s));
+    HC_CHECK(launch_ntt(ctx_->dev(), h.tw_inv, h.logn, plain + off * h.n, c, plan, true, 0, s));
+  }
+  u32 bad = 0;
+  HC_CHECK(hipMemcpyAsync(&bad, flag.p, sizeof(u32), hipMemcpyDeviceToHost, s));
+  HC_CHECK(hipStreamSynchronize(s));
+  if (bad_host) *bad_host = bad;
+  return kOk;
+}
+
+int Evaluator::batch_decode(const u64* plain, u64* values, size_t count, bool is_signed, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (!ctx_->batching()) return kUnsupported;
+  const size_t chunk = std::min<size_t>(65535, std::max<size_t>(1, chunk_ops_ * 8));
+  ScratchGuard tmp(pool_, std::min(chunk, count) * h.n * sizeof(u64), s);
+  if (!tmp.p) return kOutOfMemory;
+  const NttPlan plan = single_mod_plan(h.t_mod);
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    HC_CHECK(hipMemcpyAsync(tmp.p, plain + off * h.n, c * h.n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    HC_CHECK(launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, (u64*)tmp.p, c, plan, false, 0, s));
+    HC_CHECK(launch_batch_gather(ctx_->dev(), h.n, ctx_->batch_index_map(), (const u64*)tmp.p, values + off * h.n, c, is_signed ? 1 : 0, s));
+  }
+  return kOk;
+}
+
+// plain[op] = Decryptor_Decrypt(ct[op]) ; ct: u64[count][size][K][N], sk: u64[KK][N] in NTT form (SEAL SecretKey data)
+int Evaluator::decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (size < 2 || !sk_ntt) return kInvalidArg;
+  if (h.logn > 15) return kUnsupported;
+  const u32 n = h.n, K = h.K;
+  const size_t per = (size_t)(size - 1) * K;  // transformed residue polynomials per op
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / std::max<size_t>(per, 1)));
+  const size_t cc = std::min(chunk, count);
+  ScratchGuard sg(pool_, cc * (per + K) * n * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* ctn = (u64*)sg.p;
+  u64* acc = ctn + cc * per * n;
+  const NttPlan plan = range_plan(K);
+  const size_t cs = ctx_->ct_words(size);
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    // polys 1.. of every op, NTT'd: c_p (.) s^p accumulates in the transform domain
+    HC_CHECK(hipMemcpy2DAsync(ctn, per * n * sizeof(u64), ct + off * cs + (size_t)K * n, cs * sizeof(u64), per * n * sizeof(u64), c,
+                              hipMemcpyDeviceToDevice, s));
+    HB_LAUNCH_CLIENT(kKernNttFwd, c * per, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, ctn, c * per, plan, false, 0, s));
+    HC_CHECK(launch_dot_secret(ctx_->dev(), n, K, ctn, size, sk_ntt, acc, c, s));
+    HB_LAUNCH_CLIENT(kKernNttInv, c * K, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, acc, c * K, plan, true, 0, s));
+    HC_CHECK(launch_decrypt_round(ctx_->dev(), n, ct + off * cs, size, acc, plain + off * n, c, s));
+  }
+  return kOk;
+}
+
+// ct2[op] = Encryptor_Encrypt(plain[op]) under the public key pk: u64[2][KK][N] (NTT form, key level).
+// Randomness: Philox4x32-10 keyed by `seed`, counter = (coefficient, first_op + op): reproducible and independent of
+// the chunking.  plain: u64[count][N] (pstride = N) or one shared plaintext (pstride = 0).
+int Evaluator::encrypt(const u64* plain, size_t pstride, const u64* pk, u64 seed, u64 first_op, u64* ct2, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (!pk) return kInvalidArg;
+  if (h.logn > 15) return kUnsupported;
+  const u32 n = h.n, K = h.K, KK = h.KK;
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / (2 * (size_t)KK)));
+  const size_t cc = std::min(chunk, count);
+  // u[KK] + e[2][KK] + c[2][KK] residue polynomials per op
+  ScratchGuard sg(pool_, cc * 5 * (size_t)KK * n * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* u = (u64*)sg.p;
+  u64* e = u + cc * (size_t)KK * n;
+  u64* c2 = e + cc * 2 * (size_t)KK * n;
+  const NttPlan plan = range_plan(KK);
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    HC_CHECK(launch_encrypt_sample(ctx_->dev(), n, seed, first_op + off, u, e, c, s));
+    HB_LAUNCH_CLIENT(kKernNttFwd, c * KK, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, u, c * KK, plan, false, 0, s));
+    HC_CHECK(launch_encrypt_dyadic(ctx_->dev(), n, KK, u, pk, c2, c, s));
+    HB_LAUNCH_CLIENT(kKernNttInv, c * 2 * KK, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, c2, c * 2 * KK, plan, true, 0, s));
+    HC_CHECK(launch_add_key_level(ctx_->dev(), n, c2, e, c * 2 * KK, s));
+    u64* out = ct2 + off * 2 * K * n;
+    if (KK > 1) {
+      // SEAL encrypts at the key level and divides-and-rounds by the special prime (mod_switch of the fresh encryption)
+      HC_CHECK(launch_ks_moddown(ctx_->dev(), n, c2, nullptr, 0, 0u, out, c, s));
+    } else {
+      HC_CHECK(hipMemcpyAsync(out, c2, c * 2 * (size_t)K * n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    }
+  }
+  // + round(q/t * m) with SEAL's rounding correction (multiply_add_plain_with_scaling_variant) == add_plain
+  return add_plain(ct2, 2, plain, pstride, ct2, count, s);
+}
+
+}  // namespace hipbfv

@@ -45,4 +45,14 @@ hipError_t launch_dyadic_plain(const DevCtx* ctx, u32 n, u32 K, u64* x, u32 size
 hipError_t launch_mono_mul(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t residue_polys, const u64* coeff_rns, u32 e, hipStream_t s);
 hipError_t launch_nonzero_tail(const u64* ct, size_t words_per_ct, size_t skip_words, u32* flags, size_t ops, hipStream_t s);
 
+// kernels_client.hip: BatchEncoder / Decryptor / Encryptor (coefficient-parallel parts)
+hipError_t launch_batch_scatter(const DevCtx* ctx, u32 n, const u32* map, const u64* values, u64* plain, size_t ops, int is_signed, u32* bad,
+                                hipStream_t s);
+hipError_t launch_batch_gather(const DevCtx* ctx, u32 n, const u32* map, const u64* tmp, u64* values, size_t ops, int is_signed, hipStream_t s);
+hipError_t launch_dot_secret(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 size, const u64* sk, u64* acc, size_t ops, hipStream_t s);
+hipError_t launch_decrypt_round(const DevCtx* ctx, u32 n, const u64* ct, u32 size, const u64* acc, u64* plain, size_t ops, hipStream_t s);
+hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, u64 seed, u64 op0, u64* u, u64* e, size_t ops, hipStream_t s);
+hipError_t launch_encrypt_dyadic(const DevCtx* ctx, u32 n, u32 KK, const u64* un, const u64* pk, u64* c, size_t ops, hipStream_t s);
+hipError_t launch_add_key_level(const DevCtx* ctx, u32 n, u64* c, const u64* e, size_t residue_polys, hipStream_t s);
+
 }  // namespace hipbfv

@@ -1,0 +1,213 @@
+// sunscreen_amd/csrc/kernels_client.hip -- the steps either side of the evaluator, batched:
+//   BatchEncoder_Encode / Decode        (seal_fhe/src/encoder.rs:75-190)        -> slot permutation + NTT over Z_t
+//   Decryptor_Decrypt                   (seal_fhe/src/encryptor_decryptor.rs:618-629) -> <ct, (1, s, s^2)> then
+//                                        SEAL RNSTool::decrypt_scale_and_round in the base {t, gamma}
+//   Encryptor_Encrypt (public key)      (seal_fhe/src/encryptor_decryptor.rs:238-254) -> u, e0, e1 sampling,
+//                                        (pk0*u + e0, pk1*u + e1) at key level, divide-and-round by the special prime
+// The transforms themselves are the library's NTT kernels (launch_ntt); this file holds the coefficient-parallel
+// kernels around them.  Coefficient-parallel layout as in kernels.hip: thread = coefficient, residues N apart.
+#include <hip/hip_runtime.h>
+
+#include "devarith.hpp"
+#include "kernels.hpp"
+
+namespace hipbfv {
+
+namespace {
+constexpr int kClientThreads = 256;
+inline dim3 cgrid(u32 n, u32 y, u32 z = 1) { return dim3((n + kClientThreads - 1) / kClientThreads, y, z); }
+}  // namespace
+
+// ---- BatchEncoder ----
+// plain[op][map[i]] = values[op][i] (mod t); is_signed: values are int64 in [-(t>>1), t>>1].  *bad |= 1 on a
+// value outside the plain modulus (SEAL throws std::invalid_argument).
+__global__ __launch_bounds__(kClientThreads) void batch_scatter_kernel(const DevCtx* __restrict__ ctx, const u32* __restrict__ map,
+                                                                       const u64* __restrict__ values, u64* __restrict__ plain, int is_signed,
+                                                                       u32* __restrict__ bad) {
+  const u32 n = ctx->n;
+  const u32 i = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 op = blockIdx.y;
+  if (i >= n) return;
+  const u64 t = ctx->t;
+  u64 v = values[(size_t)op * n + i];
+  if (is_signed) {
+    const long long sv = (long long)v;
+    const u64 mag = sv < 0 ? (u64)(-sv) : (u64)sv;
+    if (mag > (t >> 1)) {
+      atomicOr(bad, 1u);
+      v = 0;
+    } else {
+      v = sv < 0 ? t - mag : mag;
+    }
+  } else if (v >= t) {
+    atomicOr(bad, 1u);
+    v = 0;
+  }
+  plain[(size_t)op * n + map[i]] = v;
+}
+
+// values[op][i] = tmp[op][map[i]]; is_signed: representatives in (-(t>>1)-1, t>>1] as SEAL's Decode2
+__global__ __launch_bounds__(kClientThreads) void batch_gather_kernel(const DevCtx* __restrict__ ctx, const u32* __restrict__ map,
+                                                                      const u64* __restrict__ tmp, u64* __restrict__ values, int is_signed) {
+  const u32 n = ctx->n;
+  const u32 i = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 op = blockIdx.y;
+  if (i >= n) return;
+  const u64 t = ctx->t;
+  u64 v = tmp[(size_t)op * n + map[i]];
+  if (is_signed && v > (t >> 1)) v = (u64)((long long)v - (long long)t);
+  values[(size_t)op * n + i] = v;
+}
+
+// ---- Decryptor ----
+// acc[op][i] = sum_{p=1}^{size-1} ctn[op][p-1][i] (.) s_i^p   (everything in NTT form; s: u64[KK][N])
+__global__ __launch_bounds__(kClientThreads) void dot_secret_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 size,
+                                                                    const u64* __restrict__ sk, u64* __restrict__ acc) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 i = blockIdx.y, op = blockIdx.z;
+  if (x >= n) return;
+  const DevMod& dm = ctx->mod[i];
+  const u64 s1 = sk[(size_t)i * n + x];
+  u64 sp = s1, a = 0;
+  for (u32 p = 1; p < size; p++) {
+    const u64 c = ctn[(((size_t)op * (size - 1) + (p - 1)) * K + i) * n + x];
+    a = add_mod(a, mul_mod(c, sp, dm), dm.q);
+    sp = mul_mod(sp, s1, dm);
+  }
+  acc[((size_t)op * K + i) * n + x] = a;
+}
+
+// plain[op][x] = round(t * (c0 + acc) / q) mod t, SEAL RNSTool::decrypt_scale_and_round:
+//   y_i = phase_i * t * gamma * (q/q_i)^{-1} mod q_i ; fast base conversion q -> {t, gamma} ; times -q^{-1} ;
+//   centred gamma correction ; times gamma^{-1} mod t.
+__global__ __launch_bounds__(kClientThreads) void decrypt_round_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ct, u32 size,
+                                                                       const u64* __restrict__ acc, u64* __restrict__ plain) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 op = blockIdx.y;
+  if (x >= n) return;
+  u128 at = 0, ag = 0;
+  for (u32 i = 0; i < K; i++) {
+    const DevMod& dm = ctx->mod[i];
+    const u64 c0 = ct[((size_t)op * size * K + i) * n + x];
+    const u64 phase = add_mod(c0, acc[((size_t)op * K + i) * n + x], dm.q);
+    const u64 y = mul_shoup(phase, ctx->dec_scale_q[i], dm.q);
+    at += (u128)y * ctx->q_to_t[i];
+    ag += (u128)y * ctx->q_to_gamma[i];
+  }
+  const u64 t = ctx->t, gamma = ctx->gamma.q;
+  const u64 a = mul_shoup(reduce128(at, ctx->tm), ctx->neg_inv_q_mod_t, t);
+  const u64 g = mul_shoup(reduce128_fast(ag, ctx->gamma), ctx->neg_inv_q_mod_gamma, gamma);
+  u64 r;
+  if (g > (gamma >> 1))
+    r = add_mod(a, reduce64(gamma - g, ctx->tm), t);
+  else
+    r = sub_mod(a, reduce64(g, ctx->tm), t);
+  if (r) r = mul_shoup(r, ctx->inv_gamma_mod_t, t);
+  plain[(size_t)op * n + x] = r;
+}
+
+// ---- Encryptor ----
+// Philox4x32-10 (Salmon et al., SC'11): counter = (coefficient, op, stream, 0), key = seed
+__device__ __forceinline__ void philox4x32(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;
+    const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n1 = (u32)p1, n2 = (u32)(p0 >> 32) ^ c3 ^ k1, n3 = (u32)p0;
+    c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+// rounded Gaussian, sigma = 3.2, clipped to |x| <= 19 (the reference builds SEAL with SEAL_USE_GAUSSIAN_NOISE=ON,
+// seal_fhe/build.rs:50; the sampler is pinned statistically only -- SURVEY 8f row 3)
+__device__ __forceinline__ int gauss_noise(u32 a, u32 b) {
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777217.0f);
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+  float z = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2) * 3.2f;
+  z = fminf(fmaxf(z, -19.0f), 19.0f);
+  return (int)rintf(z);
+}
+
+__device__ __forceinline__ u64 small_to_residue(int v, u64 q) { return v < 0 ? q - (u64)(-v) : (u64)v; }
+
+// u[op][KK][N] = ternary polynomial in every key-level residue; e[op][2][KK][N] = the two error polynomials
+__global__ __launch_bounds__(kClientThreads) void encrypt_sample_kernel(const DevCtx* __restrict__ ctx, u64 seed, u64 op0, u64* __restrict__ u,
+                                                                        u64* __restrict__ e) {
+  const u32 n = ctx->n, KK = ctx->KK;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 op = blockIdx.y;
+  if (x >= n) return;
+  const u64 gop = op0 + op;
+  u32 r[4], w[4];
+  philox4x32(x, (u32)gop, (u32)(gop >> 32), 0u, (u32)seed, (u32)(seed >> 32), r);
+  philox4x32(x, (u32)gop, (u32)(gop >> 32), 1u, (u32)seed, (u32)(seed >> 32), w);
+  const int tern = (int)(((u64)r[0] * 3u) >> 32) - 1;
+  const int e0 = gauss_noise(r[1], r[2]), e1 = gauss_noise(r[3], w[0]);
+  for (u32 i = 0; i < KK; i++) {
+    const u64 q = ctx->mod[i].q;
+    u[((size_t)op * KK + i) * n + x] = small_to_residue(tern, q);
+    e[(((size_t)op * 2 + 0) * KK + i) * n + x] = small_to_residue(e0, q);
+    e[(((size_t)op * 2 + 1) * KK + i) * n + x] = small_to_residue(e1, q);
+  }
+}
+
+// c[op][j][i] = un[op][i] (.) pk[j][i]   (NTT form, key level)
+__global__ __launch_bounds__(kClientThreads) void encrypt_dyadic_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ un,
+                                                                        const u64* __restrict__ pk, u64* __restrict__ c) {
+  const u32 n = ctx->n, KK = ctx->KK;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 i = blockIdx.y, op = blockIdx.z;
+  if (x >= n) return;
+  const DevMod& dm = ctx->mod[i];
+  const u64 a = un[((size_t)op * KK + i) * n + x];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+    c[(((size_t)op * 2 + j) * KK + i) * n + x] = mul_mod(a, pk[((size_t)j * KK + i) * n + x], dm);
+}
+
+// c += e over [polys][KK][N] (key level residues)
+__global__ __launch_bounds__(kClientThreads) void add_key_level_kernel(const DevCtx* __restrict__ ctx, u64* __restrict__ c, const u64* __restrict__ e) {
+  const u32 n = ctx->n, KK = ctx->KK;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 res = blockIdx.y;
+  if (x >= n) return;
+  const size_t off = (size_t)res * n + x;
+  c[off] = add_mod(c[off], e[off], ctx->mod[res % KK].q);
+}
+
+// ---- launchers ----
+hipError_t launch_batch_scatter(const DevCtx* ctx, u32 n, const u32* map, const u64* values, u64* plain, size_t ops, int is_signed, u32* bad,
+                                hipStream_t s) {
+  batch_scatter_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, map, values, plain, is_signed, bad);
+  return hipGetLastError();
+}
+hipError_t launch_batch_gather(const DevCtx* ctx, u32 n, const u32* map, const u64* tmp, u64* values, size_t ops, int is_signed, hipStream_t s) {
+  batch_gather_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, map, tmp, values, is_signed);
+  return hipGetLastError();
+}
+hipError_t launch_dot_secret(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 size, const u64* sk, u64* acc, size_t ops, hipStream_t s) {
+  dot_secret_kernel<<<cgrid(n, K, (u32)ops), kClientThreads, 0, s>>>(ctx, ctn, size, sk, acc);
+  return hipGetLastError();
+}
+hipError_t launch_decrypt_round(const DevCtx* ctx, u32 n, const u64* ct, u32 size, const u64* acc, u64* plain, size_t ops, hipStream_t s) {
+  decrypt_round_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, ct, size, acc, plain);
+  return hipGetLastError();
+}
+hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, u64 seed, u64 op0, u64* u, u64* e, size_t ops, hipStream_t s) {
+  encrypt_sample_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, seed, op0, u, e);
+  return hipGetLastError();
+}
+hipError_t launch_encrypt_dyadic(const DevCtx* ctx, u32 n, u32 KK, const u64* un, const u64* pk, u64* c, size_t ops, hipStream_t s) {
+  encrypt_dyadic_kernel<<<cgrid(n, KK, (u32)ops), kClientThreads, 0, s>>>(ctx, un, pk, c);
+  return hipGetLastError();
+}
+hipError_t launch_add_key_level(const DevCtx* ctx, u32 n, u64* c, const u64* e, size_t residue_polys, hipStream_t s) {
+  add_key_level_kernel<<<cgrid(n, (u32)residue_polys), kClientThreads, 0, s>>>(ctx, c, e);
+  return hipGetLastError();
+}
+
+}  // namespace hipbfv

@@ -593,3 +593,141 @@ class BFVEvaluator:
 
     def rotate_columns_inplace(self, a: Ciphertext, galois_keys: GaloisKeys) -> None:
         _check(_lib.load().Evaluator_RotateColumns(self._h, a._h, galois_keys._h, a._h, None))
+
+# ---- the steps either side of the evaluator --------------------------------------------------
+class _AsymKey:
+    """SecretKey / PublicKey handles (seal_fhe/src/key_generator.rs:200-430).  Keys come from the client; the
+    library has no KeyGenerator."""
+
+    _prefix = ""
+    _polys = 1
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(getattr(_lib.load(), self._prefix + "_Create1")(C.byref(self._h)))
+
+    def get_handle(self):
+        return self._h
+
+    @classmethod
+    def from_array(cls, ctx: "Context", data: np.ndarray):
+        """data: uint64[(2,) K+1, N] key-level NTT-form residues (SEAL's in-memory layout)."""
+        k = cls()
+        arr = np.ascontiguousarray(np.asarray(data, dtype=np.uint64))
+        assert arr.size == cls._polys * ctx.KK * ctx.poly_modulus_degree, arr.shape
+        _check(getattr(_lib.load(), "hipbfv_" + cls._prefix + "_Assign")(k._h, ctx.get_handle(), arr.ctypes.data_as(_lib.u64p)))
+        return k
+
+    def as_bytes(self, compression: int = 2) -> bytes:
+        L = _lib.load()
+        size = C.c_int64()
+        _check(getattr(L, self._prefix + "_SaveSize")(self._h, compression, C.byref(size)))
+        buf = C.create_string_buffer(size.value)
+        written = C.c_int64()
+        _check(getattr(L, self._prefix + "_Save")(self._h, buf, size.value, compression, C.byref(written)))
+        return buf.raw[: written.value]
+
+    @classmethod
+    def from_bytes(cls, ctx: "Context", data: bytes):
+        k = cls()
+        read = C.c_int64()
+        _check(getattr(_lib.load(), cls._prefix + "_Load")(k._h, ctx.get_handle(), data, len(data), C.byref(read)))
+        return k
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            getattr(_lib.load(), self._prefix + "_Destroy")(self._h)
+            self._h = None
+
+
+class SecretKey(_AsymKey):
+    _prefix, _polys = "SecretKey", 1
+
+
+class PublicKey(_AsymKey):
+    _prefix, _polys = "PublicKey", 2
+
+
+class BFVEncoder:
+    """seal_fhe/src/encoder.rs:30-215 (BatchEncoder)."""
+
+    def __init__(self, ctx: "Context"):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        _check(_lib.load().BatchEncoder_Create(ctx.get_handle(), C.byref(self._h)))
+
+    def get_slot_count(self) -> int:
+        n = C.c_uint64()
+        _check(_lib.load().BatchEncoder_GetSlotCount(self._h, C.byref(n)))
+        return n.value
+
+    def encode_unsigned(self, data: Sequence[int]) -> Plaintext:
+        p = Plaintext()
+        arr = (C.c_uint64 * len(data))(*[int(v) for v in data])
+        _check(_lib.load().BatchEncoder_Encode1(self._h, len(data), arr, p.get_handle()))
+        return p
+
+    def encode_signed(self, data: Sequence[int]) -> Plaintext:
+        p = Plaintext()
+        arr = (C.c_int64 * len(data))(*[int(v) for v in data])
+        _check(_lib.load().BatchEncoder_Encode2(self._h, len(data), arr, p.get_handle()))
+        return p
+
+    def decode_unsigned(self, plaintext: Plaintext) -> list[int]:
+        n = self.get_slot_count()
+        out = (C.c_uint64 * n)()
+        size = C.c_uint64()
+        _check(_lib.load().BatchEncoder_Decode1(self._h, plaintext.get_handle(), C.byref(size), out, None))
+        return list(out[: size.value])
+
+    def decode_signed(self, plaintext: Plaintext) -> list[int]:
+        n = self.get_slot_count()
+        out = (C.c_int64 * n)()
+        size = C.c_uint64()
+        _check(_lib.load().BatchEncoder_Decode2(self._h, plaintext.get_handle(), C.byref(size), out, None))
+        return list(out[: size.value])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().BatchEncoder_Destroy(self._h)
+            self._h = None
+
+
+class Decryptor:
+    """seal_fhe/src/encryptor_decryptor.rs:596-690."""
+
+    def __init__(self, ctx: "Context", secret_key: SecretKey):
+        self._keep = (ctx, secret_key)
+        self._h = C.c_void_p()
+        _check(_lib.load().Decryptor_Create(ctx.get_handle(), secret_key.get_handle(), C.byref(self._h)))
+
+    def decrypt(self, ciphertext: "Ciphertext") -> Plaintext:
+        p = Plaintext()
+        _check(_lib.load().Decryptor_Decrypt(self._h, ciphertext.get_handle(), p.get_handle()))
+        return p
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().Decryptor_Destroy(self._h)
+            self._h = None
+
+
+class Encryptor:
+    """seal_fhe/src/encryptor_decryptor.rs:140-260, public-key mode (`Encryptor::with_public_key`)."""
+
+    def __init__(self, ctx: "Context", public_key: PublicKey, seed: int | None = None):
+        self._keep = (ctx, public_key)
+        self._h = C.c_void_p()
+        _check(_lib.load().Encryptor_Create(ctx.get_handle(), public_key.get_handle(), None, C.byref(self._h)))
+        if seed is not None:
+            _check(_lib.load().hipbfv_Encryptor_SetSeed(self._h, seed))
+
+    def encrypt(self, plaintext: Plaintext) -> "Ciphertext":
+        c = Ciphertext()
+        _check(_lib.load().Encryptor_Encrypt(self._h, plaintext.get_handle(), c.get_handle(), None))
+        return c
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().Encryptor_Destroy(self._h)
+            self._h = None

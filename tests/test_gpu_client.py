@@ -1,0 +1,222 @@
+"""The steps either side of the evaluator on the device: BatchEncoder, Decryptor, Encryptor.
+
+BatchEncoder and Decryptor are deterministic: bit-exact against the oracle.  Encryptor is randomised (the reference
+pins its sampler only statistically): ciphertexts must decrypt to the message under the ORACLE's decryptor with the
+noise budget of a fresh SEAL encryption, and the sampled polynomials must have the right distribution.
+Reference interfaces: seal_fhe/src/encoder.rs:50-215, seal_fhe/src/encryptor_decryptor.rs:140-260,596-690.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bfv_oracle as O
+from tests.bfv_helpers import make_vec, oracle_for, params
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, seed=21):
+    from sunscreen_amd import Context, PublicKey, SecretKey
+    from sunscreen_amd.batch import BatchEvaluator
+
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    O.seed(seed)
+    sk, pk, rk, _ = o.keygen()
+    ctx = Context.from_raw(n, primes, t)
+    return o, sk, pk, rk, ctx, BatchEvaluator(ctx), SecretKey.from_array(ctx, sk), PublicKey.from_array(ctx, pk)
+
+
+@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17", "default_2048_14"])
+def test_batch_encoder_matches_oracle(name):
+    from sunscreen_amd import BFVEncoder, HipBfvError, Plaintext
+    from sunscreen_amd.batch import to_device, to_host
+
+    o, sk, pk, rk, ctx, ev, skd, pkd = _setup(name)
+    n, t = o.n, o.t
+    rng = np.random.default_rng(3)
+    vals = rng.integers(0, t, (5, n), dtype=np.uint64)
+    vals[0] = 0
+    vals[1] = t - 1
+    vals[2] = np.arange(n, dtype=np.uint64) % t
+    enc = to_host(ev.encode(to_device(vals)))
+    for i in range(5):
+        assert (enc[i] == o.batch_encode(vals[i])).all(), (name, i)
+    dec = to_host(ev.decode(to_device(enc)))
+    assert (dec == vals).all()
+    # arbitrary plaintexts (not produced by encode) decode like the oracle
+    pl = rng.integers(0, t, (3, n), dtype=np.uint64)
+    d2 = to_host(ev.decode(to_device(pl)))
+    for i in range(3):
+        assert (d2[i] == o.batch_decode(pl[i])).all()
+    # signed view (Encode2 / Decode2): representatives in [-(t>>1), t>>1]
+    half = t >> 1
+    sv = rng.integers(-half, half + 1, (2, n)).astype(np.int64)
+    senc = ev.encode(to_device(sv.view(np.uint64)), signed=True)
+    assert (to_host(senc) == np.stack([o.batch_encode((v % t).astype(np.uint64)) for v in sv])).all()
+    assert (to_host(ev.decode(senc, signed=True)).view(np.int64) == sv).all()
+    # handle level, the seal_fhe unit-test vectors (bfv_evaluator.rs:284-302) and partial slot vectors
+    be = BFVEncoder(ctx)
+    assert be.get_slot_count() == n
+    v = [int(x) for x in make_vec(n)]  # n/2 - i: the seal_fhe unit tests' vector (every t here exceeds n)
+    p = be.encode_signed(v)
+    assert be.decode_signed(p) == v
+    assert be.decode_unsigned(p) == [x % t for x in v]
+    short = be.encode_unsigned([1, 2, 3])
+    assert be.decode_unsigned(short)[:4] == [1, 2, 3, 0]
+    with pytest.raises(HipBfvError) as ei:
+        be.encode_unsigned([t])
+    assert ei.value.kind == "InvalidArgument"
+    with pytest.raises(HipBfvError):
+        be.encode_signed([half + 1])
+    assert isinstance(p, Plaintext)
+
+
+def test_batch_encoder_requires_a_batching_plain_modulus():
+    from sunscreen_amd import BFVEncoder, Context, HipBfvError
+
+    ctx = Context.from_raw(4096, O.bfv_default(4096), 262144)  # BASELINE configs[0]: t = 2^18, no batching
+    with pytest.raises(HipBfvError):
+        BFVEncoder(ctx)
+
+
+@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17", "simple_multiply"])
+def test_decryptor_bit_exact(name):
+    from sunscreen_amd import Ciphertext, Decryptor, Plaintext
+    from sunscreen_amd.batch import to_device, to_host
+
+    o, sk, pk, rk, ctx, ev, skd, pkd = _setup(name)
+    n, t = o.n, o.t
+    rng = np.random.default_rng(5)
+    msgs = rng.integers(0, t, (4, n), dtype=np.uint64)
+    msgs[0, 3:] = 0  # short plaintext: SEAL trims the result to its significant coefficients
+    cts = np.stack([o.encrypt(pk, m) for m in msgs])
+    got = to_host(ev.decrypt(to_device(cts), skd))
+    for i in range(4):
+        assert (got[i] == o.decrypt(cts[i], sk)).all() and (got[i] == msgs[i]).all(), (name, i)
+    # size-3 ciphertexts (an unrelinearised product) and arbitrary residues (decryption of noise is still deterministic)
+    prod = np.stack([o.multiply(cts[1], cts[2]), o.multiply(cts[0], cts[3])])
+    got3 = to_host(ev.decrypt(to_device(prod), skd))
+    for i in range(2):
+        assert (got3[i] == o.decrypt(prod[i], sk)).all()
+    junk = np.stack([np.stack([rng.integers(0, q, (2, n), dtype=np.uint64) for q in o.primes[: o.K]], axis=1) for _ in range(2)])
+    gotj = to_host(ev.decrypt(to_device(junk), skd))
+    for i in range(2):
+        assert (gotj[i] == o.decrypt(junk[i], sk)).all()
+    # handle level
+    d = Decryptor(ctx, skd)
+    p = d.decrypt(Ciphertext.from_array(ctx, cts[0]))
+    assert isinstance(p, Plaintext) and p.len() == 3 and [p.get_coefficient(k) for k in range(3)] == [int(x) for x in msgs[0, :3]]
+
+
+@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17"])
+def test_encryptor_produces_fresh_seal_ciphertexts(name):
+    from sunscreen_amd import Ciphertext, Decryptor, Encryptor, Plaintext
+    from sunscreen_amd.batch import to_device, to_host
+
+    o, sk, pk, rk, ctx, ev, skd, pkd = _setup(name)
+    n, t = o.n, o.t
+    rng = np.random.default_rng(7)
+    batch = 6
+    msgs = rng.integers(0, t, (batch, n), dtype=np.uint64)
+    cts = to_host(ev.encrypt(to_device(msgs), pkd, seed=1234))
+    ref_budget = o.noise_budget(o.encrypt(pk, msgs[0]), sk)
+    for i in range(batch):
+        assert (o.decrypt(cts[i], sk) == msgs[i]).all(), (name, i)
+        assert abs(o.noise_budget(cts[i], sk) - ref_budget) <= 2, (name, i, ref_budget)
+        for k, q in enumerate(o.primes[: o.K]):
+            assert int(cts[i][:, k].max()) < q
+    # reproducible for equal (seed, op), independent otherwise
+    again = to_host(ev.encrypt(to_device(msgs), pkd, seed=1234))
+    assert (again == cts).all()
+    shifted = to_host(ev.encrypt(to_device(msgs[:2]), pkd, seed=1234, first_op=1))
+    assert (shifted[0] != cts[0]).any() and (o.decrypt(shifted[0], sk) == msgs[0]).all()
+    other = to_host(ev.encrypt(to_device(msgs[:1]), pkd, seed=99))
+    assert (other[0] != cts[0]).any()
+    # a shared plaintext
+    one = to_host(ev.encrypt(to_device(msgs[0]), pkd, seed=5))
+    assert one.shape == (1, 2, o.K, n) and (o.decrypt(one[0], sk) == msgs[0]).all()
+    # handle level: encrypt -> evaluator -> decrypt entirely through the SEAL-named C ABI
+    enc, dec = Encryptor(ctx, pkd, seed=42), Decryptor(ctx, skd)
+    pa, pb = Plaintext.from_coefficients([3]), Plaintext.from_coefficients([5, 1])
+    ca, cb = enc.encrypt(pa), enc.encrypt(pb)
+    assert (ca.to_array() != enc.encrypt(pa).to_array()).any()  # fresh randomness per call
+    from sunscreen_amd import BFVEvaluator, RelinearizationKeys
+
+    be = BFVEvaluator(ctx)
+    prod = be.relinearize(be.multiply(ca, cb), RelinearizationKeys.from_array(ctx, rk))
+    out = dec.decrypt(prod)
+    assert [out.get_coefficient(k) for k in range(out.len())] == [15 % t, 3]
+    assert isinstance(ca, Ciphertext)
+
+
+def test_encryption_noise_statistics():
+    """u is uniform ternary, e0 / e1 are rounded Gaussians with sigma 3.2 clipped at 19.  With a special prime the
+    fresh noise is divided by q_sp and only rounding error survives, so the sampler is checked on a parameter set
+    WITHOUT a special prime (n = 2048, one 54-bit prime: SEAL encrypts at the only level): with m = 0 the decryption
+    phase c0 + c1*s = u*e_pk + e0 + e1*s is a sum of 2N+1 products of small terms with standard deviation
+    sigma * sqrt(4N/3 + 1); a wrong ternary or Gaussian sampler moves it far outside a 10 % band."""
+    from sunscreen_amd.batch import to_device, to_host
+
+    o, sk, pk, rk, ctx, ev, skd, pkd = _setup("default_2048_14", seed=31)
+    assert o.KK == 1
+    n = o.n
+    zero = np.zeros((16, n), dtype=np.uint64)
+    cts = to_host(ev.encrypt(to_device(zero), pkd, seed=77))
+    q0 = o.primes[0]
+    devs = []
+    for ct in cts:
+        v = o.dot_with_secret(ct, sk)[0].astype(np.int64)  # phase mod q_0: the noise is far below q_0/2
+        devs.append(np.where(v > q0 // 2, v - q0, v))
+    v = np.concatenate(devs).astype(np.float64)
+    expect = 3.2 * np.sqrt(4 * n / 3 + 1)
+    assert abs(v.mean()) < 0.05 * expect
+    assert 0.9 * expect < v.std() < 1.1 * expect, (v.std(), expect)
+    # and with a special prime only the rounding error of the divide-and-round survives: sqrt((2N/3 + 1) / 12)
+    o2, sk2, pk2, _, _, ev2, _, pkd2 = _setup("default_4096_16", seed=32)
+    c2 = to_host(ev2.encrypt(to_device(np.zeros((8, o2.n), dtype=np.uint64)), pkd2, seed=78))
+    q = o2.primes[0]
+    w = np.concatenate([np.where((x := o2.dot_with_secret(c, sk2)[0].astype(np.int64)) > q // 2, x - q, x) for c in c2]).astype(np.float64)
+    expect2 = np.sqrt((2 * o2.n / 3 + 1) / 12 + 1)
+    assert 0.8 * expect2 < w.std() < 1.3 * expect2, (w.std(), expect2)
+
+
+def test_key_handles_wire_format_roundtrip():
+    """SecretKey / PublicKey cross the boundary in the SEAL 4.0 wire format (key_generator.rs:203-255,354-395): a
+    secret key serialises as a Plaintext, a public key as a key-level NTT-form Ciphertext.  The golden secret key of
+    seal_fhe/tests/data/secret_key.bin (tests/golden/seal_key_fixture.npz) must serialise to the fixture's words."""
+    from sunscreen_amd import Context, HipBfvError, PublicKey, SecretKey
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "seal_key_fixture.npz"))
+    n = 8192
+    primes = O.coeff_modulus_create(n, [50, 30, 30, 50, 50])
+    t = O.plain_batching(n, 20)
+    o = O.Oracle(n, primes, t)
+    ctx = Context.from_raw(n, primes, t)
+    tern = g["sk_ternary"].astype(np.int64)
+    sk = np.stack([o.ntt(i, np.where(tern < 0, q + tern, tern).astype(np.uint64)) for i, q in enumerate(primes)])
+    golden = [str(x) for x in g["sk_sha256"]]  # one digest per residue polynomial of the fixture
+    assert [hashlib.sha256(row.tobytes()).hexdigest() for row in sk] == golden
+    key = SecretKey.from_array(ctx, sk)
+    raw = key.as_bytes(compression=0)
+    assert raw[:8] == bytes([0x5E, 0xA1, 16, 4, 0, 0, 0, 0]) and len(raw) == int.from_bytes(raw[8:16], "little")
+    payload = raw[-sk.nbytes :]  # DynArray payload = the fixture's words
+    assert [hashlib.sha256(payload[i * n * 8 : (i + 1) * n * 8]).hexdigest() for i in range(len(primes))] == golden
+    back = SecretKey.from_bytes(ctx, key.as_bytes())
+    assert back.as_bytes(compression=0) == raw
+    O.seed(4)
+    _, pk, _, _ = o.keygen(relin=False)
+    pkh = PublicKey.from_array(ctx, pk)
+    blob = pkh.as_bytes()
+    assert PublicKey.from_bytes(ctx, blob).as_bytes(compression=0) == pkh.as_bytes(compression=0)
+    with pytest.raises(HipBfvError):  # a public key is not a secret key
+        SecretKey.from_bytes(ctx, blob)
+    other = Context.from_raw(4096, O.bfv_default(4096), O.plain_batching(4096, 16))
+    with pytest.raises(HipBfvError):  # parms_id mismatch
+        PublicKey.from_bytes(other, blob)
+    bad = sk.copy()
+    bad[1, 5] = primes[1]
+    with pytest.raises(HipBfvError):
+        SecretKey.from_array(ctx, bad)
