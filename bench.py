@@ -33,9 +33,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="ciphertext pairs (or polynomials for --workload ntt) per GPU per step")
     ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--workload", choices=["mulrelin", "ntt", "chi_sq", "dot_prod"], default="mulrelin",
+    ap.add_argument("--workload", choices=["mulrelin", "ntt", "chi_sq", "dot_prod", "e2e"], default="mulrelin",
                     help="mulrelin = the headline; ntt = batched transforms; chi_sq / dot_prod = whole program graphs "
-                         "(examples/chi_sq, examples/dot_prod) through the batch graph executor (SURVEY 8d configs 4 / 5b)")
+                         "(examples/chi_sq, examples/dot_prod) through the batch graph executor (SURVEY 8d configs 4 / 5b); "
+                         "e2e = encode + encrypt both operands, multiply + relinearize, decrypt + decode, all on the device")
     ap.add_argument("--chunk", type=int, default=0, help="override the executor's chunk size (ops per launch group)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="ops in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -112,6 +113,30 @@ def main():
         units_per_step = B
         metric, unit = "bfv_mul_relin_ops_per_sec", "ops/s"
         workload = f"BFV ct*ct multiply+relinearize, n={n}, K={K}+1 SEAL default 128-bit primes, t={t}, batch={B} pairs/GPU"
+    elif args.workload == "e2e":
+        from sunscreen_amd import PublicKey, SecretKey
+
+        o = O.Oracle(n, primes, t)
+        O.seed(0xE2E + 17)
+        sk, pk, rk, _ = o.keygen()
+        rkd = RelinearizationKeys.from_array(ctx, rk)
+        skd, pkd = SecretKey.from_array(ctx, sk), PublicKey.from_array(ctx, pk)
+        va = torch.randint(0, 257, (B, n), generator=gen, device=dev, dtype=torch.int64)
+        vb = torch.randint(0, 257, (B, n), generator=gen, device=dev, dtype=torch.int64)
+        holder = {}
+
+        def step():
+            ca = ev.encrypt(ev.encode(va), pkd, seed=0xA + rank, first_op=0)
+            cb = ev.encrypt(ev.encode(vb), pkd, seed=0xB + rank, first_op=0)
+            prod = ev.multiply_relin(ca, cb, rkd)
+            holder["ct"] = prod
+            holder["out"] = ev.decode(ev.decrypt(prod, skd))
+
+        unit_bytes = 32 * n + 8 * n  # compulsory: read two slot vectors, write one
+        units_per_step = B
+        metric, unit = "bfv_encrypt_mulrelin_decrypt_per_sec", "ops/s"
+        workload = (f"encode+encrypt x2 -> multiply+relinearize -> decrypt+decode on the device, n={n}, K={K}+1 SEAL default primes, "
+                    f"t={t}, batch={B} slot-vector pairs/GPU")
     elif args.workload in ("chi_sq", "dot_prod"):
         from sunscreen_amd import GaloisKeys
         from sunscreen_amd.workloads import chi_sq_optimized, dot_product
@@ -199,6 +224,13 @@ def main():
         for i in range(K):
             assert int(out[:, :, i, :].max()) < primes[i] and int(out[:, :, i, :].min()) >= 0
         parity = f"bit-exact vs oracle on {ncheck} items; all {B} outputs canonical"
+    elif args.workload == "e2e" and not args.no_check:
+        assert torch.equal(holder["out"], (va * vb) % t), "decoded products differ from the slot-wise products"
+        got = to_host(holder["ct"][:2])
+        pl = to_host(ev.decrypt(holder["ct"][:2], skd))
+        for i in range(2):
+            assert (pl[i] == o.decrypt(got[i], sk)).all(), "HIP decryption differs from the CPU oracle"
+        parity = f"all {B} decoded results equal the slot-wise products mod t; decryption bit-exact vs the oracle on 2 items"
     elif args.workload in ("chi_sq", "dot_prod") and not args.no_check:
         for i in range(ncheck):
             refs = run_program(o, prog.nodes, prog.edges, [e[i] for e in enc], rk, gk)
@@ -316,6 +348,29 @@ def cpu_baseline(args, O, n, primes, t):
                 "sample": f"{sample} mul+relin ops (same parameters) with OpenMP over the batch on {threads} threads; "
                           f"single-thread rate {one:.2f} ops/s on {max(8, sample // threads)} ops",
                 "single_thread_value": round(one, 2), "host_cpus": cores}
+    if args.workload == "e2e":
+        from concurrent.futures import ThreadPoolExecutor
+
+        O.seed(97)
+        sk, pk, rk, _ = o.keygen()
+        sample = args.cpu_sample or threads
+        vals = rng.integers(0, 257, (sample, 2, n)).astype(np.uint64)
+
+        def one(v):
+            ca, cb = o.encrypt(pk, o.batch_encode(v[0])), o.encrypt(pk, o.batch_encode(v[1]))
+            return o.batch_decode(o.decrypt(o.relinearize(o.multiply(ca, cb), rk), sk))
+
+        t0 = time.perf_counter()
+        one(vals[0])
+        single = 1.0 / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(one, vals))
+        secs = time.perf_counter() - t0
+        return {"value": round(sample / secs, 2), "unit": "ops/s", "cores": threads, "kind": "port",
+                "sample": f"{sample} encode+encrypt x2 / mul+relin / decrypt+decode pipelines on {threads} host threads; "
+                          f"single-thread rate {single:.2f} ops/s",
+                "single_thread_value": round(single, 2), "host_cpus": cores}
     if args.workload in ("chi_sq", "dot_prod"):
         from concurrent.futures import ThreadPoolExecutor
 

@@ -137,6 +137,7 @@ long BatchEncoder_GetSlotCount(void *thisptr, uint64_t *slot_count);
 long Decryptor_Create(void *context, void *secret_key, void **decryptor);
 long Decryptor_Destroy(void *thisptr);
 long Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination);
+long Decryptor_InvariantNoiseBudget(void *thisptr, void *encrypted, int *invariant_noise_budget);
 
 /* ---- Encryptor, public-key mode (seal_fhe/src/encryptor_decryptor.rs:140-260).  The randomness is the library's
  * own (Philox4x32-10; ternary u, rounded Gaussian sigma 3.2 clipped at 19): ciphertexts are valid SEAL ciphertexts

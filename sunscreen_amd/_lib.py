@@ -142,6 +142,7 @@ _SIGNATURES = {
     "BatchEncoder_Decode1": [vp, vp, u64p, u64p, vp], "BatchEncoder_Decode2": [vp, vp, u64p, C.POINTER(C.c_int64), vp],
     "BatchEncoder_GetSlotCount": [vp, u64p],
     "Decryptor_Create": [vp, vp, vpp], "Decryptor_Destroy": [vp], "Decryptor_Decrypt": [vp, vp, vp],
+    "Decryptor_InvariantNoiseBudget": [vp, vp, C.POINTER(C.c_int)],
     "Encryptor_Create": [vp, vp, vp, vpp], "Encryptor_Destroy": [vp], "Encryptor_Encrypt": [vp, vp, vp, vp],
     "hipbfv_set_chunk_ops": [vp, u64],
     "hipbfv_Program_Create": [vpp],

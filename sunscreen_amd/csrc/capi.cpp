@@ -1872,6 +1872,114 @@ long Decryptor_Decrypt(void* h, void* encrypted, void* destination) {
   return HIPBFV_S_OK;
 }
 
+// Decryptor::invariant_noise_budget (encryptor_decryptor.rs:640-660): bits(q) - bits(|t * phase mod q| centred, max over
+// coefficients) - 1, floored at 0.  The phase comes from the device; the multi-word arithmetic (one CRT composition
+// per coefficient) runs on the host -- a diagnostic, not a hot path.
+namespace {
+struct Big {
+  std::vector<u64> w;  // little-endian, fixed length
+  explicit Big(size_t len) : w(len, 0) {}
+  void add_mul(const Big& a, u64 m) {  // *this += a * m  (no overflow by construction: one spare word)
+    u64 carry = 0;
+    for (size_t i = 0; i < w.size(); i++) {
+      const unsigned __int128 p = (unsigned __int128)(i < a.w.size() ? a.w[i] : 0) * m + w[i] + carry;
+      w[i] = (u64)p;
+      carry = (u64)(p >> 64);
+    }
+  }
+  int cmp(const Big& o) const {
+    for (size_t i = w.size(); i-- > 0;) {
+      if (w[i] != o.w[i]) return w[i] < o.w[i] ? -1 : 1;
+    }
+    return 0;
+  }
+  void sub(const Big& o) {
+    u64 borrow = 0;
+    for (size_t i = 0; i < w.size(); i++) {
+      const unsigned __int128 d = (unsigned __int128)w[i] - o.w[i] - borrow;
+      w[i] = (u64)d;
+      borrow = (u64)(d >> 64) & 1;
+    }
+  }
+  int bits() const {
+    for (size_t i = w.size(); i-- > 0;)
+      if (w[i]) return (int)(64 * i) + 64 - __builtin_clzll(w[i]);
+    return 0;
+  }
+};
+u64 mulmod64(u64 a, u64 b, u64 q) { return (u64)((unsigned __int128)a * b % q); }
+u64 invmod64(u64 a, u64 q) {  // q prime
+  u64 r = 1, e = q - 2;
+  a %= q;
+  while (e) {
+    if (e & 1) r = mulmod64(r, a, q);
+    a = mulmod64(a, a, q);
+    e >>= 1;
+  }
+  return r;
+}
+}  // namespace
+
+long Decryptor_InvariantNoiseBudget(void* h, void* encrypted, int* budget) {
+  DecryptorObj* d = as<DecryptorObj>(h, kMagicDecryptor);
+  CipherObj* c = as<CipherObj>(encrypted, kMagicCipher);
+  if (!d || !c || !budget) return HIPBFV_E_POINTER;
+  if (!c->ctx || c->ctx.get() != d->ctx.get() || !c->dev || c->size < 2)
+    return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  const Context& cx = *d->ctx;
+  const size_t n = cx.n(), K = cx.K();
+  hipStream_t s = thread_stream();
+  u64* dev = g_buffers.get(K * n);
+  if (!dev) return from_status(kOutOfMemory);
+  std::vector<u64> ph(K * n);
+  long hr = HIPBFV_S_OK;
+  if (int st = d->ev->phase(c->dev, c->size, d->sk->dev, dev, 1, s))
+    hr = from_status(st);
+  else if (hipMemcpyAsync(ph.data(), dev, ph.size() * sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    hr = from_status(kHipError);
+  g_buffers.put(dev, K * n);
+  if (hr != HIPBFV_S_OK) return hr;
+  const std::vector<u64>& q = cx.key_primes();
+  const size_t len = K + 1;
+  Big Q(len);
+  Q.w[0] = 1;
+  for (size_t i = 0; i < K; i++) {
+    Big t2(len);
+    t2.add_mul(Q, q[i]);
+    Q = t2;
+  }
+  Big half = Q;  // floor(q / 2)
+  for (size_t i = 0; i < len; i++) half.w[i] = (Q.w[i] >> 1) | (i + 1 < len ? Q.w[i + 1] << 63 : 0);
+  std::vector<Big> punct(K, Big(len));  // q / q_i
+  std::vector<u64> scale(K);            // t * (q/q_i)^{-1} mod q_i
+  for (size_t i = 0; i < K; i++) {
+    punct[i].w[0] = 1;
+    u64 pm = 1;
+    for (size_t j = 0; j < K; j++) {
+      if (j == i) continue;
+      Big t2(len);
+      t2.add_mul(punct[i], q[j]);
+      punct[i] = t2;
+      pm = mulmod64(pm, q[j] % q[i], q[i]);
+    }
+    scale[i] = mulmod64(cx.t() % q[i], invmod64(pm, q[i]), q[i]);
+  }
+  int worst = 0;
+  for (size_t x = 0; x < n; x++) {
+    Big v(len);
+    for (size_t i = 0; i < K; i++) v.add_mul(punct[i], mulmod64(ph[i * n + x], scale[i], q[i]));
+    while (v.cmp(Q) >= 0) v.sub(Q);
+    if (v.cmp(half) > 0) {
+      Big r = Q;
+      r.sub(v);
+      v = r;
+    }
+    worst = std::max(worst, v.bits());
+  }
+  *budget = std::max(0, Q.bits() - worst - 1);
+  return HIPBFV_S_OK;
+}
+
 // ------------------------------------------------------------------ Encryptor, public-key mode (encryptor_decryptor.rs:140-260)
 long Encryptor_Create(void* context, void* public_key, void* secret_key, void** out) {
   ContextObj* x = as<ContextObj>(context, kMagicContext);

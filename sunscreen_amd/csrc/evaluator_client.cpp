@@ -106,6 +106,31 @@ int Evaluator::decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, s
   return kOk;
 }
 
+// phase[op][i] = (c0 + c1*s + c2*s^2 ...) mod q_i in coefficient form: u64[count][K][N].  The quantity SEAL's
+// Decryptor::invariant_noise_budget measures (diagnostics; not a hot path: one small launch per op for the last step)
+int Evaluator::phase(const u64* ct, u32 size, const u64* sk_ntt, u64* out, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (size < 2 || !sk_ntt) return kInvalidArg;
+  if (h.logn > 15) return kUnsupported;
+  const u32 n = h.n, K = h.K;
+  const size_t per = (size_t)(size - 1) * K;
+  ScratchGuard sg(pool_, per * n * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* ctn = (u64*)sg.p;
+  const NttPlan plan = range_plan(K);
+  const size_t cs = ctx_->ct_words(size);
+  for (size_t op = 0; op < count; op++) {
+    const u64* c = ct + op * cs;
+    u64* acc = out + op * (size_t)K * n;
+    HC_CHECK(hipMemcpyAsync(ctn, c + (size_t)K * n, per * n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    HC_CHECK(launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, ctn, per, plan, false, 0, s));
+    HC_CHECK(launch_dot_secret(ctx_->dev(), n, K, ctn, size, sk_ntt, acc, 1, s));
+    HC_CHECK(launch_ntt(ctx_->dev(), h.tw_inv, h.logn, acc, K, plan, true, 0, s));
+    HC_CHECK(launch_eltwise(ctx_->dev(), n, acc, c, acc, K, 0, s));
+  }
+  return kOk;
+}
+
 // ct2[op] = Encryptor_Encrypt(plain[op]) under the public key pk: u64[2][KK][N] (NTT form, key level).
 // Randomness: Philox4x32-10 keyed by `seed`, counter = (coefficient, first_op + op): reproducible and independent of
 // the chunking.  plain: u64[count][N] (pstride = N) or one shared plaintext (pstride = 0).

@@ -706,6 +706,11 @@ class Decryptor:
         _check(_lib.load().Decryptor_Decrypt(self._h, ciphertext.get_handle(), p.get_handle()))
         return p
 
+    def invariant_noise_budget(self, ciphertext: "Ciphertext") -> int:
+        b = C.c_int()
+        _check(_lib.load().Decryptor_InvariantNoiseBudget(self._h, ciphertext.get_handle(), C.byref(b)))
+        return b.value
+
     def __del__(self):
         if getattr(self, "_h", None):
             _lib.load().Decryptor_Destroy(self._h)

@@ -109,6 +109,11 @@ def test_decryptor_bit_exact(name):
     d = Decryptor(ctx, skd)
     p = d.decrypt(Ciphertext.from_array(ctx, cts[0]))
     assert isinstance(p, Plaintext) and p.len() == 3 and [p.get_coefficient(k) for k in range(3)] == [int(x) for x in msgs[0, :3]]
+    # invariant noise budget (encryptor_decryptor.rs:640-660; seal_fhe/tests/assumptions.rs:138-194 relies on it):
+    # fresh, after a multiplication (published cost of one multiply: 26-29 bits, Tables_of_things.md:7-14), exhausted
+    for arr in (cts[1], prod[0], junk[0]):
+        assert d.invariant_noise_budget(Ciphertext.from_array(ctx, arr)) == o.noise_budget(arr, sk), name
+    assert d.invariant_noise_budget(Ciphertext.from_array(ctx, junk[0])) == 0
 
 
 @pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17"])
