@@ -55,10 +55,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # validation knobs for boxes with fewer GPUs than ranks (not used by the driver): all ranks on device 0, gloo
+    if os.environ.get("HIPBFV_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("HIPBFV_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from sunscreen_amd import Context, RelinearizationKeys, _lib
     from sunscreen_amd.batch import BatchEvaluator, to_device, to_host

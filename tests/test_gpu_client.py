@@ -29,7 +29,7 @@ def _setup(name, seed=21):
     return o, sk, pk, rk, ctx, BatchEvaluator(ctx), SecretKey.from_array(ctx, sk), PublicKey.from_array(ctx, pk)
 
 
-@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17", "default_2048_14"])
+@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17", "default_2048_14", "default_32768_17"])
 def test_batch_encoder_matches_oracle(name):
     from sunscreen_amd import BFVEncoder, HipBfvError, Plaintext
     from sunscreen_amd.batch import to_device, to_host
@@ -82,7 +82,7 @@ def test_batch_encoder_requires_a_batching_plain_modulus():
         BFVEncoder(ctx)
 
 
-@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17", "simple_multiply"])
+@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17", "simple_multiply", "default_32768_17"])
 def test_decryptor_bit_exact(name):
     from sunscreen_amd import Ciphertext, Decryptor, Plaintext
     from sunscreen_amd.batch import to_device, to_host
@@ -116,7 +116,7 @@ def test_decryptor_bit_exact(name):
     assert d.invariant_noise_budget(Ciphertext.from_array(ctx, junk[0])) == 0
 
 
-@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17"])
+@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17", "default_32768_17"])
 def test_encryptor_produces_fresh_seal_ciphertexts(name):
     from sunscreen_amd import Ciphertext, Decryptor, Encryptor, Plaintext
     from sunscreen_amd.batch import to_device, to_host
