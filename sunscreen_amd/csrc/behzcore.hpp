@@ -176,4 +176,126 @@ __device__ __forceinline__ void behz_floor_sk_coeff_d(const DevCtx* __restrict__
   }
 }
 
+// ---- the FP64 conversions for NC coefficients at once (the head / tail kernels own 8 / 4 coefficients per thread):
+// every base-conversion constant is fetched once and applied to all NC coefficients (NC independent chains), and the
+// Shenoy-Kumaresan sums are accumulated as soon as each auxiliary residue is finished, so no per-residue arrays of
+// intermediate values stay live.  Same arithmetic, value for value, as the single-coefficient forms above.
+
+// x[i][k]: canonical residue of coefficient k mod q_i (double); ext(j, out): called once per auxiliary prime j with
+// out[k] = representative of the extended value mod Bsk_j, |out[k]| < Bsk_j
+template <int KMAX, int NC, class Sink>
+__device__ __forceinline__ void behz_extend_multi_d(const DevCtx* __restrict__ ctx, double (&x)[KMAX][NC], Sink&& ext) {
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK;
+  u32 rm[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) rm[k] = 0;
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const ArithD ar(ctx->mod[i]);
+      const MulOpD sc = ctx->ext_scale_d[i];
+      const u32 qm = ctx->q_to_mtilde[i];
+#pragma unroll
+      for (int k = 0; k < NC; k++) {
+        double v = ar.mul_const(x[i][k], sc);
+        v = v < 0.0 ? v + ar.q : v;
+        x[i][k] = v;  // y_i, canonical
+        rm[k] += (u32)ArithD::to_bits(v) * qm;
+      }
+    }
+  }
+  double rc[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) rc[k] = (double)(int)(rm[k] * ctx->neg_inv_q_mod_mtilde);
+#pragma unroll 1
+  for (u32 j = 0; j < S; j++) {
+    const ArithD ar(ctx->mod[KK + j]);
+    double acc[NC];
+    const double qmb = ctx->q_mod_bsk_d[j];
+#pragma unroll
+    for (int k = 0; k < NC; k++) acc[k] = ar.mul_var(rc[k], qmb);
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+      if ((u32)i < K) {
+        const double c = ctx->q_to_bsk_d[j][i];
+#pragma unroll
+        for (int k = 0; k < NC; k++) acc[k] += ar.mul_var(x[i][k], c);
+      }
+    }
+    const MulOpD inv = ctx->inv_mtilde_mod_bsk_d[j];
+#pragma unroll
+    for (int k = 0; k < NC; k++) acc[k] = ar.mul_const(ar.reduce(acc[k]), inv);
+    ext(j, acc);
+  }
+}
+
+// yc[i][k]: CANONICAL y_i of coefficient k (double); aux(j, xb): called once per auxiliary prime j, must fill
+// xb[k] = x*t mod Bsk_j (any representative with |xb| < 2^52); out[i][k] = canonical u64 result mod q_i
+template <int KMAX, int NC, class Source>
+__device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__ ctx, const double (&yc)[KMAX][NC], Source&& aux,
+                                                      u64 (&out)[KMAX][NC]) {
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, nB = ctx->nB;
+  double oacc[KMAX][NC], amsk[NC], flm[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) amsk[k] = 0.0, flm[k] = 0.0;
+#pragma unroll
+  for (int i = 0; i < KMAX; i++)
+#pragma unroll
+    for (int k = 0; k < NC; k++) oacc[i][k] = 0.0;
+#pragma unroll 1
+  for (u32 j = 0; j < S; j++) {
+    const ArithD ar(ctx->mod[KK + j]);
+    double fl[NC];
+    aux(j, fl);
+#pragma unroll
+    for (int k = 0; k < NC; k++) fl[k] = ar.reduce(fl[k]);
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+      if ((u32)i < K) {
+        const double c = ctx->q_to_bsk_d[j][i];
+#pragma unroll
+        for (int k = 0; k < NC; k++) fl[k] -= ar.mul_var(yc[i][k], c);
+      }
+    }
+    const MulOpD invq = ctx->inv_q_mod_bsk_d[j];
+#pragma unroll
+    for (int k = 0; k < NC; k++) fl[k] = ar.mul_const(ar.reduce(fl[k]), invq);
+    if (j < nB) {
+      const MulOpD ip = ctx->inv_punct_B_d[j];
+      const ArithD am(ctx->mod[KK + nB]);
+      const double bm = ctx->B_to_msk_d[j];
+#pragma unroll
+      for (int k = 0; k < NC; k++) {
+        fl[k] = canonical_d(ar, ar.mul_const(fl[k], ip));  // yb_j, canonical
+        amsk[k] += am.mul_var(fl[k], bm);
+      }
+#pragma unroll
+      for (int i = 0; i < KMAX; i++) {
+        if ((u32)i < K) {
+          const ArithD aq(ctx->mod[i]);
+          const double c = ctx->B_to_q_d[i][j];
+#pragma unroll
+          for (int k = 0; k < NC; k++) oacc[i][k] += aq.mul_var(fl[k], c);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NC; k++) flm[k] = fl[k];
+    }
+  }
+  const ArithD am(ctx->mod[KK + nB]);
+  double alpha[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) alpha[k] = am.reduce(am.mul_const(am.reduce(amsk[k] - flm[k]), ctx->inv_B_mod_msk_d));
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const ArithD aq(ctx->mod[i]);
+      const double bq = ctx->B_mod_q_d[i];
+#pragma unroll
+      for (int k = 0; k < NC; k++) out[i][k] = aq.canonical(oacc[i][k] - aq.mul_var(alpha[k], bq));
+    }
+  }
+}
+
 }  // namespace hipbfv

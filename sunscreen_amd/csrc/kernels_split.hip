@@ -675,31 +675,15 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
         for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
       }
     }
-    double ev[KMAX + 2][8];
+    // auxiliary base: extend all eight owned coefficients residue by residue (every conversion constant is
+    // fetched once), and run the head stages of each auxiliary residue as soon as it is complete
+    behz_extend_multi_d<KMAX, 8>(ctx, x, [&](u32 j, double(&ev)[8]) {
+      const ArithD ar(ctx->mod[KK + j]);
+      head_fwd8(ar, ev, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N));
+      double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      double xr[KMAX], er[KMAX + 2];
-#pragma unroll
-      for (int i = 0; i < KMAX; i++) xr[i] = x[i][k];
-#pragma unroll
-      for (int j = 0; j < KMAX + 2; j++) er[j] = 0.0;
-      behz_extend_coeff_d<KMAX>(ctx, xr, er);
-#pragma unroll
-      for (int j = 0; j < KMAX + 2; j++) ev[j][k] = er[j];
-    }
-#pragma unroll
-    for (int j = 0; j < KMAX + 2; j++) {
-      if ((u32)j < S) {
-        const ArithD ar(ctx->mod[KK + j]);
-        double v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = ev[j][k];
-        head_fwd8(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N));
-        double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
-#pragma unroll
-        for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
-      }
-    }
+      for (int k = 0; k < 8; k++) o[(size_t)k * Q] = ev[k];
+    });
     return;
   }
   u64 x[KMAX][8];
@@ -958,44 +942,34 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
   const u64* d = D + ((size_t)op * 3 + poly) * R * N + t;
   u64* o = out + ((size_t)op * 3 + poly) * K * N + t;
   if constexpr (AUXD) {
-    double y[4][KMAX], xb[4][KMAX + 2];
+    double yc[KMAX][4];
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
       if ((u32)i < K) {
         const DevMod& dm = ctx->mod[i];
+        const ArithD ar(dm);
         double r4[4];
-        tail_inv4_scale_d(ArithD(dm), reinterpret_cast<const double*>(d + (size_t)i * N), Q,
-                          reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
+        tail_inv4_scale_d(ar, reinterpret_cast<const double*>(d + (size_t)i * N), Q, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
+                          ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
 #pragma unroll
-        for (int k = 0; k < 4; k++) y[k][i] = r4[k];
+        for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
       }
     }
+    u64 res[KMAX][4];
+    behz_floor_sk_multi_d<KMAX, 4>(
+        ctx, yc,
+        [&](u32 j, double(&xb)[4]) {
+          const DevMod& dm = ctx->mod[KK + j];
+          tail_inv4_scale_d(ArithD(dm), reinterpret_cast<const double*>(d + (size_t)(K + j) * N), Q,
+                            reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j], dm.split_inv_mask, xb);
+        },
+        res);
 #pragma unroll
-    for (int j = 0; j < KMAX + 2; j++) {
-      if ((u32)j < S) {
-        const DevMod& dm = ctx->mod[KK + j];
-        double r4[4];
-        tail_inv4_scale_d(ArithD(dm), reinterpret_cast<const double*>(d + (size_t)(K + j) * N), Q,
-                          reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j], dm.split_inv_mask, r4);
+    for (int i = 0; i < KMAX; i++)
+      if ((u32)i < K) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) xb[k][j] = r4[k];
+        for (int k = 0; k < 4; k++) o[(size_t)i * N + (size_t)k * Q] = res[i][k];
       }
-    }
-#pragma unroll 1
-    for (int k = 0; k < 4; k++) {
-      u64 r[KMAX];
-      behz_floor_sk_coeff_d<KMAX>(ctx, y[0], xb[0], r);
-#pragma unroll
-      for (int i = 0; i < KMAX; i++)
-        if ((u32)i < K) o[(size_t)i * N + (size_t)k * Q] = r[i];
-#pragma unroll
-      for (int kk = 0; kk < 3; kk++) {
-#pragma unroll
-        for (int i = 0; i < KMAX; i++) y[kk][i] = y[kk + 1][i];
-#pragma unroll
-        for (int j = 0; j < KMAX + 2; j++) xb[kk][j] = xb[kk + 1][j];
-      }
-    }
     return;
   }
   u64 y[4][KMAX], xb[4][KMAX + 2];
