@@ -426,21 +426,22 @@ int Evaluator::multiply_plain(const u64* ct, u32 size, const u64* plain, size_t 
   const size_t cs = ctx_->ct_words(size);
   const bool shared = pstride == 0;
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / ((size_t)size * K)));
-  ScratchGuard sg(pool_, (shared ? 1 : chunk) * (size_t)K * n * sizeof(u64), s);
+  ScratchGuard sg(pool_, (shared ? 1 : chunk) * ((size_t)K * n * sizeof(u64) + sizeof(u32)), s);
   if (!sg.p) return kOutOfMemory;
   u64* pl = (u64*)sg.p;
+  u32* nonzero = (u32*)(pl + (shared ? 1 : chunk) * (size_t)K * n);  // per-plaintext non-zero counts (monomial detection)
   std::vector<u32> mods;
   for (u32 i = 0; i < K; i++) mods.push_back(i);
   const NttPlan plan = make_plan(1, mods);
   if (shared) {
-    HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain, 0, pl, 1, s));
+    HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain, 0, pl, 1, nonzero, s));
     HB_LAUNCH(kKernNttFwd, K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, pl, K, plan, false, 0, s));
   }
   if (out != ct) HB_CHECK(hipMemcpyAsync(out, ct, count * cs * sizeof(u64), hipMemcpyDeviceToDevice, s));
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     if (!shared) {
-      HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain + off * pstride, pstride, pl, c, s));
+      HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain + off * pstride, pstride, pl, c, nonzero, s));
       HB_LAUNCH(kKernNttFwd, c * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, pl, c * K, plan, false, 0, s));
     }
     u64* x = out + off * cs;

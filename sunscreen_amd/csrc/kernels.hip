@@ -504,14 +504,30 @@ __global__ __launch_bounds__(kCoefThreads) void plain_addsub_kernel(const DevCtx
 }
 
 // lift plaintext coefficients (mod t, centred) to every q_i: out u64[ops][K][N]
+// nonzero[op] = number of non-zero coefficients of plaintext op (must be zeroed by the caller)
+__global__ __launch_bounds__(kCoefThreads) void plain_count_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ plain, size_t pstride,
+                                                                   u32* __restrict__ nonzero) {
+  const u32 n = ctx->n;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 op = blockIdx.y;
+  const bool nz = k < n && plain[(size_t)op * pstride + k] != 0;
+  const unsigned long long ballot = __ballot(nz);
+  if ((threadIdx.x & 63u) == 0 && ballot) atomicAdd(&nonzero[op], (u32)__popcll(ballot));
+}
+
+// nonzero: optional per-op non-zero counts.  SEAL's multiply_plain has a monomial shortcut which, when every q_i
+// exceeds t (fast plain lift), multiplies by the coefficient AS IS -- without the centred lift of upper-half values
+// (SEAL evaluator.cpp multiply_plain_normal: "no need to adjust the monomial").  Lifting such a plaintext unadjusted
+// makes the general transform-domain product bit-identical to that shortcut.
 __global__ __launch_bounds__(kCoefThreads) void plain_lift_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ plain, size_t pstride,
-                                                                  u64* __restrict__ out) {
+                                                                  u64* __restrict__ out, const u32* __restrict__ nonzero) {
   const u32 n = ctx->n, K = ctx->K;
   const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
   const u32 op = blockIdx.y;
   if (k >= n) return;
   const u64 m = plain[(size_t)op * pstride + k];
-  const bool upper = m >= ctx->t_half_up;
+  const bool mono_as_is = nonzero && ctx->fast_plain_lift && nonzero[op] == 1;
+  const bool upper = m >= ctx->t_half_up && !mono_as_is;
   for (u32 i = 0; i < K; i++) {
     const DevMod& qm = ctx->mod[i];
     u64 v;
@@ -636,8 +652,14 @@ hipError_t launch_plain_addsub(const DevCtx* ctx, u32 n, u64* ct, size_t ctstrid
   return hipGetLastError();
 }
 
-hipError_t launch_plain_lift(const DevCtx* ctx, u32 n, const u64* plain, size_t pstride, u64* out, size_t ops, hipStream_t s) {
-  plain_lift_kernel<<<coef_grid(n, (u32)ops), kCoefThreads, 0, s>>>(ctx, plain, pstride, out);
+// nonzero: device u32[ops] scratch (zeroed here, filled with the per-plaintext non-zero counts) or nullptr = always centred lift
+hipError_t launch_plain_lift(const DevCtx* ctx, u32 n, const u64* plain, size_t pstride, u64* out, size_t ops, u32* nonzero, hipStream_t s) {
+  if (nonzero) {
+    hipError_t e = hipMemsetAsync(nonzero, 0, ops * sizeof(u32), s);
+    if (e != hipSuccess) return e;
+    plain_count_kernel<<<coef_grid(n, (u32)ops), kCoefThreads, 0, s>>>(ctx, plain, pstride, nonzero);
+  }
+  plain_lift_kernel<<<coef_grid(n, (u32)ops), kCoefThreads, 0, s>>>(ctx, plain, pstride, out, nonzero);
   return hipGetLastError();
 }
 

@@ -1,0 +1,97 @@
+"""Deterministic parameter fuzzing: a sweep of (degree, prime count, prime sizes, plain modulus) far outside the
+default sets, every evaluator operation compared bit for bit with the oracle.  Exercises the code-path selection
+(integer vs FP64 policy per modulus, own vs SEAL auxiliary base, split vs whole-polynomial pipelines, 4- / 8- / 16-prime
+kernel instantiations, fast vs generic plain lift)."""
+import numpy as np
+import pytest
+
+from oracle import bfv_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _configs():
+    rng = np.random.default_rng(20260925)
+    out = []
+    for _ in range(40):
+        n = int(rng.choice([1024, 2048, 4096, 8192, 16384, 32768]))
+        kk = int(rng.integers(1, 10)) if n < 32768 else int(rng.integers(2, 5))
+        style = rng.integers(0, 3)
+        if style == 0:  # all FP64-capable
+            bits = [int(b) for b in rng.integers(30, 50, kk)]
+        elif style == 1:  # all wide
+            bits = [int(b) for b in rng.integers(51, 61, kk)]
+        else:  # mixed
+            bits = [int(b) for b in rng.integers(30, 61, kk)]
+        # stay inside SEAL's 128-bit bound is not required for arithmetic parity; just keep n large enough for the prime count
+        tb = int(rng.integers(17, 41)) if n == 32768 else int(rng.integers(14, 41))
+        out.append((n, bits, tb))
+    return out
+
+
+@pytest.mark.parametrize("n,bits,tbits", _configs())
+def test_every_operation_on_random_parameter_sets(n, bits, tbits):
+    from sunscreen_amd import Context, GaloisKeys, HipBfvError, RelinearizationKeys, SecretKey
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    try:
+        primes = O.coeff_modulus_create(n, bits)
+    except Exception:
+        pytest.skip("not enough primes of the requested sizes")
+    t = O.plain_batching(n, tbits)
+    if not t:
+        t = (1 << tbits) - 1
+    if any(t % p == 0 for p in primes):
+        pytest.skip("plain modulus collides with a coefficient prime")
+    o = O.Oracle(n, primes, t)
+    O.seed(n + sum(bits))
+    batching = O.is_prime(t) and (t - 1) % (2 * n) == 0
+    elt = o.galois_elt_from_step(1) if batching and o.KK > 1 else None
+    sk, pk, rk, gk = o.keygen(galois_elts=[elt, 2 * n - 1] if elt else None)
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    K = o.K
+    rng = np.random.default_rng(n * 31 + len(bits))
+    a = np.stack([rng.integers(0, q, (2, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    b = np.stack([rng.integers(0, q, (2, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    da, db = to_device(a), to_device(b)
+    m = to_host(ev.multiply(da, db))
+    s = to_host(ev.add(da, db))
+    d = to_host(ev.sub(da, db))
+    for i in range(2):
+        assert (m[i] == o.multiply(a[i], b[i])).all(), ("multiply", n, bits, tbits)
+        assert (s[i] == o.add(a[i], b[i])).all() and (d[i] == o.sub(a[i], b[i])).all()
+    pl = rng.integers(0, t, (2, n), dtype=np.uint64)
+    pl[1, 1:] = 0
+    pl[1, 0] = max(1, pl[1, 0])  # a monomial: SEAL's multiply_plain shortcut
+    mp = to_host(ev.multiply_plain(da, to_device(pl)))
+    ap = to_host(ev.add_plain(da, to_device(pl)))
+    for i in range(2):
+        assert (mp[i] == o.multiply_plain(a[i], pl[i])).all(), ("multiply_plain", n, bits, tbits)
+        assert (ap[i] == o.add_plain(a[i], pl[i])).all()
+    if o.KK > 1:
+        rkd = RelinearizationKeys.from_array(ctx, rk)
+        r = to_host(ev.multiply_relin(da, db, rkd))
+        r2 = to_host(ev.relinearize(to_device(m), rkd))
+        for i in range(2):
+            ref = o.relinearize(o.multiply(a[i], b[i]), rk)
+            assert (r[i] == ref).all() and (r2[i] == ref).all(), ("relinearize", n, bits, tbits)
+        if elt:
+            gkd = GaloisKeys.from_arrays(ctx, gk)
+            rot = to_host(ev.rotate_rows(da, 1, gkd))
+            col = to_host(ev.rotate_columns(da, gkd))
+            for i in range(2):
+                assert (rot[i] == o.rotate_rows(a[i], 1, gk)).all(), ("rotate_rows", n, bits, tbits)
+                assert (col[i] == o.rotate_columns(a[i], gk)).all()
+    else:
+        with pytest.raises(HipBfvError):
+            RelinearizationKeys.from_array(ctx, np.zeros((1, 2, 1, n), dtype=np.uint64))
+    # decryption of arbitrary residues is deterministic: Decryptor parity on the same inputs
+    dec = to_host(ev.decrypt(da, SecretKey.from_array(ctx, sk)))
+    for i in range(2):
+        assert (dec[i] == o.decrypt(a[i], sk)).all(), ("decrypt", n, bits, tbits)
+    if batching:
+        vals = rng.integers(0, t, (2, n), dtype=np.uint64)
+        enc = to_host(ev.encode(to_device(vals)))
+        for i in range(2):
+            assert (enc[i] == o.batch_encode(vals[i])).all()
