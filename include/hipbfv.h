@@ -261,7 +261,10 @@ long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
  * LoadJson accepts the serde JSON form of `FheProgram` (petgraph StableGraph).
  * Run executes the graph over `batch` independent input sets: input i is a device pointer to
  * u64[batch][2][K][N] (kind 0) or to plaintexts u64[batch][N] / one shared u64[N] (kind 1, stride N / 0);
- * one output buffer u64[batch][2][K][N] per OutputCiphertext node, in node order. Asynchronous on `stream`. */
+ * one output buffer u64[batch][2][K][N] per OutputCiphertext node, in node order. Asynchronous on `stream`.
+ * The batched entry points (hipbfv_batch_*, Program_Run) do not scan results for transparent ciphertexts (that needs a
+ * device-to-host round trip per operation); the handle-level Evaluator_* functions do, as SEAL built with
+ * SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT does. */
 long hipbfv_Program_Create(void **program);
 long hipbfv_Program_Destroy(void *program);
 long hipbfv_Program_AddNode(void *program, uint32_t op, uint64_t arg, uint32_t *node_id);
