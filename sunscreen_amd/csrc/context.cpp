@@ -180,9 +180,9 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
   if (q >= (1ull << 50) || logn < 12 || logn > 15) return false;
   const double limit = 0.98 * 9007199254740992.0 / (double)q;
   const double eps = (double)q / 4503599627370496.0;
-  {  // forward: head does kHeadLog stages from canonical input, then the middle passes
+  {  // forward: head does head_log(logn) stages from canonical input, then the middle passes
     double M = 1.0;
-    for (int s = 0; s < kHeadLog; s++) {
+    for (int s = 0; s < head_log(logn); s++) {
       M = M + 0.5 + M * eps;
       if (M > limit) return false;
     }

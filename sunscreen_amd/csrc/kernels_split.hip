@@ -1,6 +1,6 @@
 // sunscreen_amd/csrc/kernels_split.hip -- "head / middle / tail" split-transform kernels.
 //
-// A negacyclic NTT of N = 2^L points is L radix-2 stages.  The first kHeadLog stages (gaps >= N/8) and the
+// A negacyclic NTT of N = 2^L points is L radix-2 stages.  The first head_log(L) stages (gaps >= N/8; N/4 at L = 14) and the
 // last kTailLog stages of the inverse (gaps >= N/4) are the only ones that couple distant coefficients;
 // all stages in between act inside contiguous blocks of N/4 coefficients.  So instead of one LDS-resident
 // whole-polynomial transform per residue (kernels.hip), the pipeline is cut at those two places:
@@ -396,39 +396,31 @@ constexpr int kHeadThreads = 256;
 template <int L>
 __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                const u64* __restrict__ target, size_t tstride, double* __restrict__ T) {
-  constexpr u32 N = 1u << L, Q = N >> kHeadLog;
+  constexpr int NC = 1 << head_log(L);
+  constexpr u32 N = 1u << L, Q = N / NC;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 J = blockIdx.y, op = blockIdx.z;
   const u32 K = ctx->K, KK = ctx->KK;
   const u64* src = target + (size_t)op * tstride + (size_t)J * N + t;
-  u64 x[8];
+  u64 x[NC];
 #pragma unroll
-  for (int k = 0; k < 8; k++) x[k] = src[(size_t)k * Q];
+  for (int k = 0; k < NC; k++) x[k] = src[(size_t)k * Q];
   const u64 qJ = ctx->mod[J].q;
   for (u32 I = 0; I < KK; I++) {
     const DevMod& dm = ctx->mod[I];
     const ArithD ar(dm);
     const MulOpD* tw = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * N);
     const bool need_reduce = qJ > dm.q;
-    double v[8];
+    double v[NC];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < NC; k++) {
       const double d = ar.from_u64(x[k]);
       v[k] = need_reduce ? ar.reduce(d) : d;
     }
-    // stages 0..2 of the forward transform: element k*N/8 + t, twiddle index 2^j + (k >> (3-j))
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int half = 4 >> j;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        if (k & half) continue;
-        ar.fwd(v[k], v[k + half], tw[(1u << j) + (u32)(k >> (3 - j))]);
-      }
-    }
+    head_fwd(ar, v, tw);
     double* dst = T + (((size_t)op * KK + I) * K + J) * N + t;
 #pragma unroll
-    for (int k = 0; k < 8; k++) dst[(size_t)k * Q] = v[k];
+    for (int k = 0; k < NC; k++) dst[(size_t)k * Q] = v[k];
   }
 }
 
@@ -628,16 +620,18 @@ __device__ __forceinline__ const T* opaque_uniform(const T* p) {
   return reinterpret_cast<const T*>(r);
 }
 
-// first three forward stages on the eight values {t + k*N/8}; native (lazy) representation out
-template <class A>
-__device__ __forceinline__ void head_fwd8(const A& ar, typename A::V (&v)[8], const typename A::Tw* __restrict__ tw) {
+// the first HL = log2(NC) forward stages on the NC values {t + k*N/NC}; native (lazy) representation out
+template <class A, int NC>
+__device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], const typename A::Tw* __restrict__ tw) {
+  constexpr int HL = NC == 8 ? 3 : NC == 4 ? 2 : 1;
+  static_assert(NC == (1 << HL), "head threads own 2, 4 or 8 coefficients");
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
-    const int half = 4 >> j;
+  for (int j = 0; j < HL; j++) {
+    const int half = (NC / 2) >> j;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < NC; k++) {
       if (k & half) continue;
-      ar.fwd(v[k], v[k + half], tw[(1u << j) + (u32)(k >> (3 - j))]);
+      ar.fwd(v[k], v[k + half], tw[(1u << j) + (u32)(k >> (HL - j))]);
     }
   }
 }
@@ -649,48 +643,49 @@ template <int L, int KMAX, bool AUXD>
 __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
                                                                 u64* __restrict__ ext) {
-  constexpr u32 N = 1u << L, Q = N >> kHeadLog;
+  constexpr int NC = 1 << head_log(L);
+  constexpr u32 N = 1u << L, Q = N / NC;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 poly = blockIdx.y, op = blockIdx.z;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   const u64* src = (poly < 2 ? in0 + ((size_t)op * 2 + poly) * K * N : in1 + ((size_t)op * 2 + (poly - 2)) * K * N) + t;
   u64* dst = ext + ((size_t)op * 4 + poly) * R * N + t;
   if constexpr (AUXD) {
-    double x[KMAX][8];
+    double x[KMAX][NC];
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) x[i][k] = (u32)i < K ? ArithD::from_u64(src[(size_t)i * N + (size_t)k * Q]) : 0.0;
+      for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? ArithD::from_u64(src[(size_t)i * N + (size_t)k * Q]) : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
       if ((u32)i < K) {
         const ArithD ar(ctx->mod[i]);
-        double v[8];
+        double v[NC];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = x[i][k];
-        head_fwd8(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)i * N));
+        for (int k = 0; k < NC; k++) v[k] = x[i][k];
+        head_fwd(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)i * N));
         double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+        for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
       }
     }
     // auxiliary base: extend all eight owned coefficients residue by residue (every conversion constant is
     // fetched once), and run the head stages of each auxiliary residue as soon as it is complete
-    behz_extend_multi_d<KMAX, 8>(ctx, x, [&](u32 j, double(&ev)[8]) {
+    behz_extend_multi_d<KMAX, NC>(ctx, x, [&](u32 j, double(&ev)[NC]) {
       const ArithD ar(ctx->mod[KK + j]);
-      head_fwd8(ar, ev, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N));
+      head_fwd(ar, ev, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N));
       double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
 #pragma unroll
-      for (int k = 0; k < 8; k++) o[(size_t)k * Q] = ev[k];
+      for (int k = 0; k < NC; k++) o[(size_t)k * Q] = ev[k];
     });
     return;
   }
-  u64 x[KMAX][8];
+  u64 x[KMAX][NC];
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) x[i][k] = (u32)i < K ? src[(size_t)i * N + (size_t)k * Q] : 0;
+    for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? src[(size_t)i * N + (size_t)k * Q] : 0;
   }
   // q residues: just the three head stages
 #pragma unroll
@@ -700,29 +695,29 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
       const MulOp* tw = twf_base + (size_t)i * N;
       if (residue_is_f64(dm)) {
         const ArithD ar(dm);
-        double v[8];
+        double v[NC];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = ar.from_u64(x[i][k]);
-        head_fwd8(ar, v, reinterpret_cast<const MulOpD*>(tw));
+        for (int k = 0; k < NC; k++) v[k] = ar.from_u64(x[i][k]);
+        head_fwd(ar, v, reinterpret_cast<const MulOpD*>(tw));
         double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+        for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
       } else {
         const ArithI ar(dm);
-        u64 v[8];
+        u64 v[NC];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = x[i][k];
-        head_fwd8(ar, v, tw);
+        for (int k = 0; k < NC; k++) v[k] = x[i][k];
+        head_fwd(ar, v, tw);
         u64* o = dst + (size_t)i * N;
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+        for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
       }
     }
   }
   // auxiliary base: extend every owned coefficient, then the head stages per Bsk prime
-  u64 ev[KMAX + 2][8];
+  u64 ev[KMAX + 2][NC];
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < NC; k++) {
     u64 xr[KMAX], er[KMAX + 2];
 #pragma unroll
     for (int i = 0; i < KMAX; i++) xr[i] = x[i][k];
@@ -737,13 +732,13 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
     if ((u32)j < S) {
       const DevMod& dm = ctx->mod[KK + j];
       const ArithI ar(dm);
-      u64 v[8];
+      u64 v[NC];
 #pragma unroll
-      for (int k = 0; k < 8; k++) v[k] = ev[j][k];
-      head_fwd8(ar, v, twf_base + (size_t)(KK + j) * N);
+      for (int k = 0; k < NC; k++) v[k] = ev[j][k];
+      head_fwd(ar, v, twf_base + (size_t)(KK + j) * N);
       u64* o = dst + (size_t)(K + j) * N;
 #pragma unroll
-      for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+      for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
     }
   }
 }
@@ -1031,7 +1026,8 @@ __device__ __forceinline__ u32 plan_mod_split(const NttPlan& plan, u32 poly) { r
 template <int L>
 __global__ __launch_bounds__(kHeadThreads) void ntt_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base, u64* data,
                                                                 NttPlan plan) {
-  constexpr u32 N = 1u << L, Q = N >> kHeadLog;
+  constexpr int NC = 1 << head_log(L);
+  constexpr u32 N = 1u << L, Q = N / NC;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 poly = blockIdx.y;
   const u32 m = plan_mod_split(plan, poly);
@@ -1040,21 +1036,21 @@ __global__ __launch_bounds__(kHeadThreads) void ntt_head_kernel(const DevCtx* __
   const MulOp* tw = twf_base + (size_t)m * N;
   if (residue_is_f64(dm)) {
     const ArithD ar(dm);
-    double v[8];
+    double v[NC];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = ar.from_u64(x[(size_t)k * Q]);
-    head_fwd8(ar, v, reinterpret_cast<const MulOpD*>(tw));
+    for (int k = 0; k < NC; k++) v[k] = ar.from_u64(x[(size_t)k * Q]);
+    head_fwd(ar, v, reinterpret_cast<const MulOpD*>(tw));
     double* o = reinterpret_cast<double*>(x);
 #pragma unroll
-    for (int k = 0; k < 8; k++) o[(size_t)k * Q] = v[k];
+    for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
   } else {
     const ArithI ar(dm);
-    u64 v[8];
+    u64 v[NC];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = x[(size_t)k * Q];
-    head_fwd8(ar, v, tw);
+    for (int k = 0; k < NC; k++) v[k] = x[(size_t)k * Q];
+    head_fwd(ar, v, tw);
 #pragma unroll
-    for (int k = 0; k < 8; k++) x[(size_t)k * Q] = v[k];
+    for (int k = 0; k < NC; k++) x[(size_t)k * Q] = v[k];
   }
 }
 
@@ -1170,7 +1166,7 @@ static hipError_t ntt_split_t(const DevCtx* ctx, const MulOp* tw, u64* data, siz
     const size_t cnt = polys - off < step ? polys - off : step;
     u64* d = data + off * Sh::N;
     if (!inverse) {
-      ntt_head_kernel<L><<<dim3(Sh::N / 8 / kHeadThreads, (unsigned)cnt), kHeadThreads, 0, s>>>(ctx, tw, d, plan);
+      ntt_head_kernel<L><<<dim3((Sh::N >> head_log(L)) / kHeadThreads, (unsigned)cnt), kHeadThreads, 0, s>>>(ctx, tw, d, plan);
       ntt_midfwd_kernel<L><<<dim3((unsigned)(cnt * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, tw, d, plan);
     } else {
       ntt_midinv_kernel<L><<<dim3((unsigned)(cnt * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, tw, d, plan);
@@ -1197,7 +1193,7 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
 
 template <int L>
 static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
-  ks_head_kernel<L><<<dim3((1u << L) / 8 / kHeadThreads, K, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twf, target, tstride,
+  ks_head_kernel<L><<<dim3(((1u << L) >> head_log(L)) / kHeadThreads, K, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twf, target, tstride,
                                                                                                    reinterpret_cast<double*>(T));
   return hipGetLastError();
 }
@@ -1234,7 +1230,7 @@ hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u
 template <int L>
 static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
                              hipStream_t s) {
-  const dim3 grid((1u << L) / 8 / kHeadThreads, 4, (unsigned)ops);
+  const dim3 grid(((1u << L) >> head_log(L)) / kHeadThreads, 4, (unsigned)ops);
   if (kneed > 4)  // only the all-FP64 instantiation exists for 5..8 data primes (evaluator.cpp checks)
     mul_head_kernel<L, 8, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   else if (aux_f64)

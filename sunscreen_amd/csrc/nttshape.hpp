@@ -20,25 +20,32 @@ constexpr int ntt_stages_before(int logn, int p, int ept = kElemsPerThread) {
 
 
 // ---- split ("head / middle / tail") transforms -------------------------------------------------
-// The first kHeadLog forward stages (gaps >= N/8) are done by the coefficient-parallel producer kernel,
+// The first head_log(logn) forward stages (gaps >= N/8, or N/4) are done by the coefficient-parallel producer kernel,
 // the last kTailLog inverse stages (gaps >= N/4) by the coefficient-parallel consumer kernel; everything
 // in between is local to contiguous blocks of N/4 coefficients and runs in one "middle" kernel per block
 // with 8 elements per thread.  Pass radices of the middle kernel:
-constexpr int kHeadLog = 3;
+// Head depth per degree: 3 stages (8 coefficients per head thread) except at N = 16384, where 2 stages (4 coefficients)
+// halve the head kernels' register footprint at K = 8 and the middle kernel absorbs the extra stage without an extra pass
+// (12 stages = 3,3,3,3 instead of 11 = 2,3,3,3).
+#ifndef HIPBFV_HEAD_LOG_14
+#define HIPBFV_HEAD_LOG_14 2
+#endif
+constexpr int head_log(int logn) { return logn == 14 ? HIPBFV_HEAD_LOG_14 : 3; }
+constexpr int kHeadLogMax = 3;
 constexpr int kTailLog = 2;
 constexpr int kBlkEPT = 8;
-constexpr int split_fwd_passes(int logn) { return (logn - kHeadLog + 2) / 3; }
+constexpr int split_fwd_passes(int logn) { return (logn - head_log(logn) + 2) / 3; }
 constexpr int split_inv_passes(int logn) { return (logn - kTailLog + 2) / 3; }
 constexpr int split_fwd_radix(int logn, int p) {
-  // logn-3 stages: 9 -> 3,3,3 ; 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3
-  return logn - kHeadLog == 10 ? (p < 2 ? 3 : 2) : logn - kHeadLog == 11 ? (p == 0 ? 2 : 3) : 3;
+  // remaining stages: 9 -> 3,3,3 ; 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3
+  return logn - head_log(logn) == 10 ? (p < 2 ? 3 : 2) : logn - head_log(logn) == 11 ? (p == 0 ? 2 : 3) : 3;
 }
 constexpr int split_inv_radix(int logn, int p) {
   // logn-2 stages, first radix == last forward radix: 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3 ; 13 -> 3,3,3,2,2
   return logn - kTailLog == 10 ? (p < 2 ? 3 : 2) : logn - kTailLog == 11 ? (p == 0 ? 2 : 3) : logn - kTailLog == 13 ? (p < 3 ? 3 : 2) : 3;
 }
 constexpr int split_fwd_low(int logn, int p) {  // lowest index bit of the window of forward middle pass p
-  int s = kHeadLog;
+  int s = head_log(logn);
   for (int i = 0; i <= p; i++) s += split_fwd_radix(logn, i);
   return logn - s;
 }
