@@ -45,6 +45,10 @@ struct SplitShape {
   static constexpr int NBLK = 1 << kTailLog;      // blocks per polynomial
   static constexpr int NPF = split_fwd_passes(L);
   static constexpr int NPI = split_inv_passes(L);
+  // the pointwise work (tensor product / key multiply-accumulate) happens on the register layout the last forward pass
+  // leaves, and the first inverse pass starts from it: both must use the window [0, R) with the same R
+  static_assert(split_fwd_radix(L, NPF - 1) == split_inv_radix(L, 0), "last forward and first inverse pass must share their window");
+  static_assert(split_fwd_low(L, NPF - 1) == 0 && split_inv_low(L, 0) == 0, "pointwise layout is the window at bit 0");
 };
 
 // One pass of a middle kernel over the index window [LOW, LOW+R).  `blk` is the block index inside the

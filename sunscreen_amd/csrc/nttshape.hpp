@@ -30,8 +30,9 @@ constexpr int ntt_stages_before(int logn, int p, int ept = kElemsPerThread) {
 #ifndef HIPBFV_HEAD_LOG_14
 #define HIPBFV_HEAD_LOG_14 2
 #endif
-// Only the validated structures are selectable: depth 2 was tried at N = 8192 as well and is NOT bit-exact there (the
-// 2,3,3,3 forward pass sequence on 2048-coefficient blocks is unverified) -- and mul_head is already at the copy rate.
+// Depth 2 is not selectable at N = 8192: its forward sequence would end with a radix-8 pass while the inverse starts
+// with a radix-4 one, and the pointwise work happens in the layout both must share (checked in SplitShape) -- and
+// mul_head is already at the copy rate there.
 static_assert(HIPBFV_HEAD_LOG_14 == 2 || HIPBFV_HEAD_LOG_14 == 3, "head depth at N = 16384 is 2 or 3");
 constexpr int head_log(int logn) { return logn == 14 ? HIPBFV_HEAD_LOG_14 : 3; }
 constexpr int kHeadLogMax = 3;
