@@ -33,10 +33,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="ciphertext pairs (or polynomials for --workload ntt) per GPU per step")
     ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--workload", choices=["mulrelin", "ntt", "chi_sq", "dot_prod", "e2e"], default="mulrelin",
+    ap.add_argument("--workload", choices=["mulrelin", "ntt", "chi_sq", "dot_prod", "e2e", "pir"], default="mulrelin",
                     help="mulrelin = the headline; ntt = batched transforms; chi_sq / dot_prod = whole program graphs "
                          "(examples/chi_sq, examples/dot_prod) through the batch graph executor (SURVEY 8d configs 4 / 5b); "
-                         "e2e = encode + encrypt both operands, multiply + relinearize, decrypt + decode, all on the device")
+                         "e2e = encode + encrypt both operands, multiply + relinearize, decrypt + decode, all on the device; "
+                         "pir = examples/pir lookup over a (--batch x --batch) plaintext database held in transform form (SURVEY 8d config 5a)")
     ap.add_argument("--chunk", type=int, default=0, help="override the executor's chunk size (ops per launch group)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="ops in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -140,6 +141,39 @@ def main():
         metric, unit = "bfv_encrypt_mulrelin_decrypt_per_sec", "ops/s"
         workload = (f"encode+encrypt x2 -> multiply+relinearize -> decrypt+decode on the device, n={n}, K={K}+1 SEAL default primes, "
                     f"t={t}, batch={B} slot-vector pairs/GPU")
+    elif args.workload == "pir":
+        from sunscreen_amd import PublicKey, SecretKey
+        from sunscreen_amd.workloads import pir_lookup
+
+        side = B  # sqrt(database size): --batch rows x --batch columns of plaintext entries
+        o = O.Oracle(n, primes, t)
+        O.seed(0x914 + 17)
+        sk, pk, rk, _ = o.keygen()
+        rkd = RelinearizationKeys.from_array(ctx, rk)
+        skd, pkd = SecretKey.from_array(ctx, sk), PublicKey.from_array(ctx, pk)
+        vals = torch.randint(1, 1000, (side, side), generator=gen, device=dev, dtype=torch.int64)
+        db_ntt = torch.empty((side, side, K, n), dtype=torch.int64, device=dev)
+        for i in range(side):  # scalar entries (value in coefficient 0), transformed once: the server's static state
+            row = torch.zeros((side, n), dtype=torch.int64, device=dev)
+            row[:, 0] = vals[i]
+            db_ntt[i] = ev.plain_to_ntt(row)
+        sel_r, sel_c = (7 + rank) % side, (side // 3 + rank) % side
+        onehot_c = torch.zeros((side, n), dtype=torch.int64, device=dev)
+        onehot_c[sel_c, 0] = 1
+        onehot_r = torch.zeros((side, n), dtype=torch.int64, device=dev)
+        onehot_r[sel_r, 0] = 1
+        cq = ev.encrypt(onehot_c, pkd, seed=0xC0 + rank)
+        rq = ev.encrypt(onehot_r, pkd, seed=0xD0 + rank)
+        holder = {}
+
+        def step():
+            holder["out"] = pir_lookup(ev, cq, rq, db_ntt, rkd)
+
+        unit_bytes = 8 * K * n  # compulsory traffic per database entry: its transform-domain residues, read once
+        units_per_step = side * side
+        metric, unit = "pir_db_entries_per_sec", "entries/s"
+        workload = (f"examples/pir lookup: {side}x{side} plaintext database in transform form ({side * side * K * n * 8 / 2**30:.1f} GiB), "
+                    f"one encrypted query per step, n={n}, K={K}+1 SEAL default primes, t={t}")
     elif args.workload in ("chi_sq", "dot_prod"):
         from sunscreen_amd import GaloisKeys
         from sunscreen_amd.workloads import chi_sq_optimized, dot_product
@@ -227,6 +261,11 @@ def main():
         for i in range(K):
             assert int(out[:, :, i, :].max()) < primes[i] and int(out[:, :, i, :].min()) >= 0
         parity = f"bit-exact vs oracle on {ncheck} items; all {B} outputs canonical"
+    elif args.workload == "pir" and not args.no_check:
+        got = to_host(ev.decrypt(holder["out"], skd))[0]
+        assert int(got[0]) == int(vals[sel_r, sel_c]) and not got[1:].any(), "PIR lookup returned the wrong entry"
+        assert (got == o.decrypt(to_host(holder["out"])[0], sk)).all()
+        parity = f"lookup decrypts to database[{sel_r}][{sel_c}]; decryption bit-exact vs the oracle (matrix-vector bits: tests/test_gpu_program.py)"
     elif args.workload == "e2e" and not args.no_check:
         assert torch.equal(holder["out"], (va * vb) % t), "decoded products differ from the slot-wise products"
         got = to_host(holder["ct"][:2])
@@ -351,6 +390,35 @@ def cpu_baseline(args, O, n, primes, t):
                 "sample": f"{sample} mul+relin ops (same parameters) with OpenMP over the batch on {threads} threads; "
                           f"single-thread rate {one:.2f} ops/s on {max(8, sample // threads)} ops",
                 "single_thread_value": round(one, 2), "host_cpus": cores}
+    if args.workload == "pir":
+        from concurrent.futures import ThreadPoolExecutor
+
+        O.seed(96)
+        sk, pk, rk, _ = o.keygen()
+        rows, cols = threads, 16  # a bounded slab of the same computation: rows x cols entries + one mul+relin per row
+        plains = np.zeros((rows, cols, n), dtype=np.uint64)
+        plains[:, :, 0] = rng.integers(1, 1000, (rows, cols))
+        zero = np.zeros(n, dtype=np.uint64)
+        cq = [o.encrypt(pk, zero) for _ in range(cols)]
+        rq = [o.encrypt(pk, zero) for _ in range(rows)]
+
+        def one_row(i):
+            col = o.multiply_plain(cq[0], plains[i, 0])
+            for j in range(1, cols):
+                col = o.add(col, o.multiply_plain(cq[j], plains[i, j]))
+            return o.relinearize(o.multiply(col, rq[i]), rk)
+
+        t0 = time.perf_counter()
+        one_row(0)
+        single = cols / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(one_row, range(rows)))
+        secs = time.perf_counter() - t0
+        return {"value": round(rows * cols / secs, 1), "unit": "entries/s", "cores": threads, "kind": "port",
+                "sample": f"{rows} database rows x {cols} columns (multiply_plain + add per entry, one mul+relin per row, node by node as "
+                          f"run.rs does) on {threads} host threads; single-thread rate {single:.1f} entries/s",
+                "single_thread_value": round(single, 1), "host_cpus": cores}
     if args.workload == "e2e":
         from concurrent.futures import ThreadPoolExecutor
 

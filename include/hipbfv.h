@@ -250,6 +250,16 @@ long hipbfv_batch_decode(void *evaluator, const uint64_t *plain, uint64_t *value
 long hipbfv_batch_decrypt(void *evaluator, const uint64_t *ct, uint32_t size, void *secret_key, uint64_t *plain, uint64_t count, void *stream);
 long hipbfv_batch_encrypt(void *evaluator, const uint64_t *plain, uint64_t plain_stride, void *public_key, uint64_t seed, uint64_t first_op,
                           uint64_t *ct, uint64_t count, void *stream);
+/* Plaintext-matrix x ciphertext-vector products in the transform domain -- the first loop nest of examples/pir
+ * (examples/pir/src/main.rs:16-45: col[i] = sum_j database[i][j] * col_query[j]).  plain_to_ntt transforms plaintexts
+ * the way Evaluator_MultiplyPlain does internally (a static database is transformed once); ct_to_ntt transforms every
+ * polynomial of the ciphertexts; dot_plain_ntt produces, for size-2 ciphertexts, out[row] = sum_j MultiplyPlain(ct_j,
+ * plain[row][j]) in coefficient form, bit-identical to the reference's sequence of multiply_plain and add.
+ * ctn: u64[cols][2][K][N], pntt: u64[rows][cols][K][N], out: u64[rows][2][K][N]. */
+long hipbfv_batch_plain_to_ntt(void *evaluator, const uint64_t *plain, uint64_t plain_stride, uint64_t *pntt, uint64_t count, void *stream);
+long hipbfv_batch_ct_to_ntt(void *evaluator, const uint64_t *ct, uint64_t size, uint64_t *ctn, uint64_t count, void *stream);
+long hipbfv_batch_dot_plain_ntt(void *evaluator, const uint64_t *ctn, uint64_t cols, const uint64_t *pntt, uint64_t rows, uint64_t *out,
+                                void *stream);
 long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
 
 /* Batch executor for compiled FHE program graphs (replaces sunscreen_runtime/src/run.rs:100-357).

@@ -125,6 +125,9 @@ _SIGNATURES = {
     "hipbfv_batch_multiply_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
     "hipbfv_batch_ntt": [vp, vp, u64, u64, C.c_bool, vp],
     "hipbfv_batch_encode": [vp, vp, vp, u64, C.c_int, vp],
+    "hipbfv_batch_plain_to_ntt": [vp, vp, u64, vp, u64, vp],
+    "hipbfv_batch_ct_to_ntt": [vp, vp, u64, vp, u64, vp],
+    "hipbfv_batch_dot_plain_ntt": [vp, vp, u64, vp, u64, vp, vp],
     "hipbfv_batch_decode": [vp, vp, vp, u64, C.c_int, vp],
     "hipbfv_batch_decrypt": [vp, vp, C.c_uint32, vp, vp, u64, vp],
     "hipbfv_batch_encrypt": [vp, vp, u64, vp, u64, u64, vp, u64, vp],

@@ -187,6 +187,30 @@ class BatchEvaluator:
                                                 _ptr(out), count, _stream()))
         return out
 
+    # ---- plaintext-matrix x ciphertext-vector products (examples/pir) ----
+    def plain_to_ntt(self, plain: torch.Tensor) -> torch.Tensor:
+        """int64[..., N] plaintexts -> int64[..., K, N]: the transform-domain operand multiply_plain builds internally."""
+        assert plain.shape[-1] == self.n
+        flat = plain.reshape(-1, self.n).contiguous()
+        out = torch.empty((flat.shape[0], self.K, self.n), dtype=torch.int64, device=plain.device)
+        _check(_lib.load().hipbfv_batch_plain_to_ntt(self._h, _ptr(flat), self.n, _ptr(out), flat.shape[0], _stream()))
+        return out.reshape(tuple(plain.shape[:-1]) + (self.K, self.n))
+
+    def ct_to_ntt(self, ct: torch.Tensor) -> torch.Tensor:
+        assert ct.dim() == 4 and ct.shape[2] == self.K and ct.shape[3] == self.n
+        out = torch.empty_like(ct)
+        _check(_lib.load().hipbfv_batch_ct_to_ntt(self._h, _ptr(ct), ct.shape[1], _ptr(out), ct.shape[0], _stream()))
+        return out
+
+    def dot_plain_ntt(self, ctn: torch.Tensor, pntt: torch.Tensor) -> torch.Tensor:
+        """ctn: int64[cols, 2, K, N] (ct_to_ntt), pntt: int64[rows, cols, K, N] (plain_to_ntt) ->
+        int64[rows, 2, K, N] = sum_j multiply_plain(ct_j, plain[row][j]), coefficient form."""
+        cols, rows = ctn.shape[0], pntt.shape[0]
+        assert ctn.shape[1] == 2 and pntt.shape[1] == cols and pntt.shape[2] == self.K
+        out = torch.empty((rows, 2, self.K, self.n), dtype=torch.int64, device=ctn.device)
+        _check(_lib.load().hipbfv_batch_dot_plain_ntt(self._h, _ptr(ctn), cols, _ptr(pntt), rows, _ptr(out), _stream()))
+        return out
+
     # ---- a6: NTT entry points (BASELINE config 2) ----
     def ntt(self, data: torch.Tensor, nprimes: int, inverse: bool = False) -> torch.Tensor:
         """In-place negacyclic NTT of int64[polys, N]; polynomial p uses key-level prime p % nprimes."""

@@ -2093,4 +2093,24 @@ long hipbfv_batch_encrypt(void* evaluator, const uint64_t* plain, uint64_t plain
   return from_status(e->ev->encrypt((const u64*)plain, plain_stride, k->key->dev, seed, first_op, (u64*)ct, count, (hipStream_t)stream));
 }
 
+// ------------------------------------------------------------------ plaintext-matrix x ciphertext-vector (PIR, examples/pir)
+long hipbfv_batch_plain_to_ntt(void* evaluator, const uint64_t* plain, uint64_t plain_stride, uint64_t* pntt, uint64_t count, void* stream) {
+  Evaluator* ev = eval_of(evaluator);
+  if (!ev || !plain || !pntt) return HIPBFV_E_POINTER;
+  return from_status(ev->plain_to_ntt((const u64*)plain, plain_stride, (u64*)pntt, count, (hipStream_t)stream));
+}
+long hipbfv_batch_ct_to_ntt(void* evaluator, const uint64_t* ct, uint64_t size, uint64_t* ctn, uint64_t count, void* stream) {
+  Evaluator* ev = eval_of(evaluator);
+  if (!ev || !ct || !ctn) return HIPBFV_E_POINTER;
+  if (size < 1) return fail(HIPBFV_E_INVALIDARG, "invalid ciphertext size");
+  return from_status(ev->ct_to_ntt((const u64*)ct, (u32)size, (u64*)ctn, count, (hipStream_t)stream));
+}
+long hipbfv_batch_dot_plain_ntt(void* evaluator, const uint64_t* ctn, uint64_t cols, const uint64_t* pntt, uint64_t rows, uint64_t* out,
+                                void* stream) {
+  Evaluator* ev = eval_of(evaluator);
+  if (!ev || !ctn || !pntt || !out) return HIPBFV_E_POINTER;
+  if (cols > 0xFFFFFFFFull || rows > 0xFFFFFFFFull) return fail(HIPBFV_E_INVALIDARG, "matrix too large");
+  return from_status(ev->dot_plain_ntt((const u64*)ctn, (u32)cols, (const u64*)pntt, (u32)rows, (u64*)out, (hipStream_t)stream));
+}
+
 }  // extern "C"

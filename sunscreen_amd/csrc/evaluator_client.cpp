@@ -106,6 +106,61 @@ int Evaluator::decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, s
   return kOk;
 }
 
+// ---- plaintext-matrix x ciphertext-vector products (the first loop nest of examples/pir/src/main.rs:16-45) ----
+// pntt[op][K][N] = NTT(centred lift of plain[op]) -- what SEAL's multiply_plain computes internally for its plaintext
+// operand (including the monomial rule, kernels.hip plain_lift_kernel).  A static database is transformed once.
+int Evaluator::plain_to_ntt(const u64* plain, size_t pstride, u64* pntt, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.logn > 15) return kUnsupported;
+  const u32 n = h.n, K = h.K;
+  const size_t chunk = std::max<size_t>(1, 65535 / K);
+  ScratchGuard nz(pool_, std::min(chunk, count) * sizeof(u32), s);
+  if (!nz.p) return kOutOfMemory;
+  const NttPlan plan = range_plan(K);
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    u64* out = pntt + off * (size_t)K * n;
+    HC_CHECK(launch_plain_lift(ctx_->dev(), n, plain + off * pstride, pstride, out, c, (u32*)nz.p, s));
+    HB_LAUNCH_CLIENT(kKernNttFwd, c * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, out, c * K, plan, false, 0, s));
+  }
+  return kOk;
+}
+
+// ctn = NTT of every polynomial of ct (u64[count][size][K][N]); may be in place
+int Evaluator::ct_to_ntt(const u64* ct, u32 size, u64* ctn, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.logn > 15) return kUnsupported;
+  const u32 K = h.K;
+  const size_t polys = count * size * K;
+  if (ctn != ct) HC_CHECK(hipMemcpyAsync(ctn, ct, polys * h.n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  const NttPlan plan = range_plan(K);
+  const size_t step = (65535 / K) * K;
+  for (size_t off = 0; off < polys; off += step) {
+    const size_t c = std::min(step, polys - off);
+    HB_LAUNCH_CLIENT(kKernNttFwd, c, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, ctn + off * h.n, c, plan, false, 0, s));
+  }
+  return kOk;
+}
+
+// out[row] = sum_j multiply_plain(ct_j, plain[row][j]) for size-2 ciphertexts, from the transformed operands:
+// ctn: u64[cols][2][K][N] (ct_to_ntt), pntt: u64[rows][cols][K][N] (plain_to_ntt), out: u64[rows][2][K][N] coefficient form.
+// Bit-identical to SEAL's sequence of multiply_plain and add (every step there is exact modular arithmetic).
+int Evaluator::dot_plain_ntt(const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* out, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.logn > 15) return kUnsupported;
+  if (!cols || !rows) return kInvalidArg;
+  const u32 n = h.n, K = h.K;
+  const NttPlan plan = range_plan(K);
+  const u32 step = 65535 / (2 * K) / 8 * 8;  // rows per launch: the inverse transform covers rows * 2 * K polynomials
+  for (u32 off = 0; off < rows; off += step) {
+    const u32 c = std::min(step, rows - off);
+    u64* o = out + (size_t)off * 2 * K * n;
+    HC_CHECK(launch_dot_plain(ctx_->dev(), n, K, ctn, cols, pntt + (size_t)off * cols * K * n, c, o, s));
+    HB_LAUNCH_CLIENT(kKernNttInv, (size_t)c * 2 * K, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, o, (size_t)c * 2 * K, plan, true, 0, s));
+  }
+  return kOk;
+}
+
 // phase[op][i] = (c0 + c1*s + c2*s^2 ...) mod q_i in coefficient form: u64[count][K][N].  The quantity SEAL's
 // Decryptor::invariant_noise_budget measures (diagnostics; not a hot path: one small launch per op for the last step)
 int Evaluator::phase(const u64* ct, u32 size, const u64* sk_ntt, u64* out, size_t count, hipStream_t s) {

@@ -179,7 +179,53 @@ __global__ __launch_bounds__(kClientThreads) void add_key_level_kernel(const Dev
   c[off] = add_mod(c[off], e[off], ctx->mod[res % KK].q);
 }
 
+// ---- plaintext-matrix x ciphertext-vector product in the transform domain (examples/pir/src/main.rs:16-45) ----
+// acc[row][p][i][x] = sum_j ctn[j][p][i][x] * pntt[row][j][i][x] mod q_i     (all NTT form, canonical residues)
+// One thread = one coefficient of one residue, RT consecutive rows and both ciphertext polynomials: every ciphertext
+// word is read once per RT rows, the plaintext matrix (the database) streams through exactly once.
+template <int RT>
+__global__ __launch_bounds__(kClientThreads) void dot_plain_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 cols,
+                                                                   const u64* __restrict__ pntt, u32 rows, u64* __restrict__ acc) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 i = blockIdx.y, r0 = blockIdx.z * RT;
+  if (x >= n) return;
+  const DevMod& dm = ctx->mod[i];
+  u128 a0[RT], a1[RT];
+#pragma unroll
+  for (int r = 0; r < RT; r++) a0[r] = 0, a1[r] = 0;
+  for (u32 j = 0; j < cols; j++) {
+    const u64 c0 = ctn[(((size_t)j * 2 + 0) * K + i) * n + x];
+    const u64 c1 = ctn[(((size_t)j * 2 + 1) * K + i) * n + x];
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      if (r0 + r < rows) {
+        const u64 pv = pntt[(((size_t)(r0 + r) * cols + j) * K + i) * n + x];
+        a0[r] += (u128)c0 * pv;
+        a1[r] += (u128)c1 * pv;
+      }
+    }
+    if ((j & 15u) == 15u) {  // products are below 2^122: sixteen of them fit 128 bits
+#pragma unroll
+      for (int r = 0; r < RT; r++) a0[r] = reduce128_fast(a0[r], dm), a1[r] = reduce128_fast(a1[r], dm);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RT; r++) {
+    if (r0 + r < rows) {
+      acc[((((size_t)(r0 + r)) * 2 + 0) * K + i) * n + x] = reduce128_fast(a0[r], dm);
+      acc[((((size_t)(r0 + r)) * 2 + 1) * K + i) * n + x] = reduce128_fast(a1[r], dm);
+    }
+  }
+}
+
 // ---- launchers ----
+hipError_t launch_dot_plain(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* acc, hipStream_t s) {
+  constexpr int RT = 8;  // rows per thread: the query ciphertexts are re-read once per RT database rows (16: fewer, fatter
+                         // workgroups -- measured slower)
+  dot_plain_kernel<RT><<<cgrid(n, K, (rows + RT - 1) / RT), kClientThreads, 0, s>>>(ctx, ctn, cols, pntt, rows, acc);
+  return hipGetLastError();
+}
 hipError_t launch_batch_scatter(const DevCtx* ctx, u32 n, const u32* map, const u64* values, u64* plain, size_t ops, int is_signed, u32* bad,
                                 hipStream_t s) {
   batch_scatter_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, map, values, plain, is_signed, bad);

@@ -63,3 +63,21 @@ def pir_row(columns: int) -> FheProgram:
         acc = term if acc is None else p.append_add(acc, term)
     p.append_output_ciphertext(_mul(p, acc, row))
     return p
+
+
+def pir_lookup(ev, col_query, row_query, db_ntt, relin_keys):
+    """examples/pir/src/main.rs:16-45 `lookup` for a sqrt(DB) x sqrt(DB) database, on the batch primitives instead of a
+    node-by-node graph: col[i] = sum_j database[i][j] * col_query[j] as ONE transform-domain matrix-vector product
+    (the column queries are transformed once, the pre-transformed database streams through once), then
+    sum_i col[i] * row_query[i] as one batched multiply+relinearize and a pairwise reduction.
+
+    col_query: int64[cols, 2, K, N], row_query: int64[rows, 2, K, N] (device), db_ntt: int64[rows, cols, K, N] from
+    BatchEvaluator.plain_to_ntt.  Returns int64[1, 2, K, N].  Bit-identical to the reference's evaluation order
+    except for the final summation order, which modular addition does not see."""
+    col = ev.dot_plain_ntt(ev.ct_to_ntt(col_query), db_ntt)
+    prod = ev.multiply_relin(col, row_query, relin_keys)
+    while prod.shape[0] > 1:
+        half = prod.shape[0] // 2
+        head = ev.add(prod[:half].contiguous(), prod[half : 2 * half].contiguous())
+        prod = head if prod.shape[0] == 2 * half else __import__("torch").cat([head, prod[2 * half :]])
+    return prod

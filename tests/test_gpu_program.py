@@ -106,6 +106,58 @@ def test_pir_row_graph_with_plaintext_arguments():
         assert int(o.decrypt(out[i], sk)[0]) == int(db_vals[sel, i])
 
 
+def test_pir_matrix_vector_product_in_the_transform_domain():
+    """examples/pir: col[i] = sum_j database[i][j] * col_query[j].  The batched primitive (one transform per query
+    ciphertext, database transformed once, accumulation before the inverse transform) must give the bits of the
+    reference's node-by-node multiply_plain / add sequence -- including SEAL's monomial rule for database entries that
+    are a single coefficient -- and the whole lookup must decrypt to the selected entry."""
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.workloads import pir_lookup
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_4096_16")
+    n, t = o.n, o.t
+    rows, cols = 5, 19  # 19 columns: exercises the lazy 128-bit accumulation across its 16-term reduction point
+    rng = np.random.default_rng(12)
+    db = rng.integers(1, t, (rows, cols, n), dtype=np.uint64)
+    db[0, 0, 1:] = 0
+    db[0, 0, 0] = t - 1          # monomial with an upper-half coefficient (the Signed encoding of -1)
+    db[1, 2, :] = 0
+    db[1, 2, 5] = 3              # monomial, small coefficient, x^5
+    db[2, 3, 7:] = 0             # short plaintext
+    colq = np.stack([o.encrypt(pk, o.batch_encode(rng.integers(0, 5, n).astype(np.uint64))) for _ in range(cols)])
+    ctn = ev.ct_to_ntt(to_device(colq))
+    dbn = ev.plain_to_ntt(to_device(db))
+    got = to_host(ev.dot_plain_ntt(ctn, dbn))
+    for i in range(rows):
+        ref = o.multiply_plain(colq[0], db[i, 0])
+        for j in range(1, cols):
+            ref = o.add(ref, o.multiply_plain(colq[j], db[i, j]))
+        assert (got[i] == ref).all(), i
+    # the full lookup with one-hot queries (scalar encoding as in the example: value in coefficient 0)
+    def scalar(v):
+        p = np.zeros(n, dtype=np.uint64)
+        p[0] = v % t
+        return p
+
+    vals = rng.integers(1, 1000, (rows, cols))
+    dbs = np.stack([np.stack([scalar(int(vals[i, j])) for j in range(cols)]) for i in range(rows)])
+    sel_r, sel_c = 3, 11
+    cq = np.stack([o.encrypt(pk, scalar(1 if j == sel_c else 0)) for j in range(cols)])
+    rq = np.stack([o.encrypt(pk, scalar(1 if i == sel_r else 0)) for i in range(rows)])
+    out = to_host(pir_lookup(ev, to_device(cq), to_device(rq), ev.plain_to_ntt(to_device(dbs)), rkd))
+    assert out.shape == (1, 2, o.K, n)
+    assert int(o.decrypt(out[0], sk)[0]) == int(vals[sel_r, sel_c])
+    # and bit for bit against the oracle evaluating the same expression
+    acc = None
+    for i in range(rows):
+        col = o.multiply_plain(cq[0], dbs[i, 0])
+        for j in range(1, cols):
+            col = o.add(col, o.multiply_plain(cq[j], dbs[i, j]))
+        term = o.relinearize(o.multiply(col, rq[i]), rk)
+        acc = term if acc is None else o.add(acc, term)
+    assert (out[0] == acc).all()
+
+
 def test_plaintext_literal_nodes():
     """`a + b * 7`-style programs carry their constants as Literal::Plaintext(bytes) nodes
     (sunscreen/tests/fhe_program_tests.rs:283-310; bytes = bincode(InnerPlaintext) holding Params + the SEAL wire
