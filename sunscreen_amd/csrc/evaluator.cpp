@@ -173,7 +173,6 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   size_t c = ((size_t)8 << 30) / per_op;
   if (const char* env = std::getenv("HIPBFV_CHUNK_OPS")) c = (size_t)std::strtoull(env, nullptr, 10);
   chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 1024));
-  if (const char* env = std::getenv("HIPBFV_STREAMS")) nstreams_ = (size_t)std::max(1, std::atoi(env));
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS")) split_ks_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_MUL")) split_mul_ = env[0] != '1';
 }
@@ -247,7 +246,7 @@ size_t Evaluator::ks_scratch_words() const {
 
 // out2[op] = base[op] (masked) + modDown( sum_J NTT(target_J) (.) key[J] ); scratch >= count * ks_scratch_words()
 int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, const u64* base, size_t bstride, u32 base_mask,
-                          u64* out2, size_t count, u64* scratch, hipStream_t s) {
+                          u64* out2, size_t count, u64* scratch, hipStream_t s, const u64* extra) {
   const DevCtx& h = ctx_->host();
   const u32 n = h.n, K = h.K, KK = h.KK;
   u64* T = scratch;
@@ -260,18 +259,19 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
     // head / middle / tail split transforms (kernels_split.hip): 3 launches, no whole-polynomial NTT round trips
     HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, K, target, tstride, T, count, s));
     HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, KK, T, key, ACC, count, s));
-    HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, ACC, base, bstride, base_mask, out2, count, s));
+    HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, ACC, base, bstride, base_mask, extra, out2, count, s));
     return kOk;
   }
   HB_LAUNCH(kKernKsDecompose, count, launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));
   HB_LAUNCH(kKernNttFwd, count * KK * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, T, count * KK * K, make_plan(K, mods), false, 0, s));
   HB_LAUNCH(kKernKsMac, count, launch_ks_mac(ctx_->dev(), n, KK, T, key, ACC, count, s));
   HB_LAUNCH(kKernNttInv, count * 2 * KK, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, ACC, count * 2 * KK, make_plan(1, mods), true, 0, s));
-  HB_LAUNCH(kKernKsModdown, count, launch_ks_moddown(ctx_->dev(), n, ACC, base, bstride, base_mask, out2, count, s));
+  HB_LAUNCH(kKernKsModdown, count, launch_ks_moddown(ctx_->dev(), n, ACC, base, bstride, base_mask, extra, out2, count, s));
   return kOk;
 }
 
-int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s) {
+// addend (optional): ciphertexts u64[count][2][K][N] added to the results inside the last kernel (a fused Add node)
+int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend) {
   const DevCtx& h = ctx_->host();
   if (h.KK < 2 || !rk) return kNoKey;
   if (h.logn > 15) return kUnsupported;
@@ -283,72 +283,30 @@ int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t coun
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     const u64* ct = ct3 + off * cs;
-    int rc = key_switch(ct + (size_t)2 * K * n, cs, rk, ct, cs, 3u, out2 + off * 2 * K * n, c, (u64*)sg.p, s);
+    int rc = key_switch(ct + (size_t)2 * K * n, cs, rk, ct, cs, 3u, out2 + off * 2 * K * n, c, (u64*)sg.p, s, addend ? addend + off * 2 * K * n : nullptr);
     if (rc) return rc;
   }
   return kOk;
 }
 
-int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s) {
+int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend) {
   const DevCtx& h = ctx_->host();
   if (h.KK < 2 || !rk) return kNoKey;
   const size_t cs = (size_t)3 * h.K * h.n, c2 = (size_t)2 * h.K * h.n;
   const size_t chunk = chunk_ops_;
-  // Independent chunks are issued round-robin on a few internal streams: the HBM-bound head / tail kernels of
-  // one chunk then overlap the VALU-bound middle kernels of another instead of alternating with them.
-  const size_t nchunks = (count + chunk - 1) / chunk;
-  const size_t ns = std::min<size_t>(nstreams_, nchunks);
-  if (ns <= 1) {
-    ScratchGuard sg(pool_, std::min(chunk, count) * cs * sizeof(u64), s);
-    if (!sg.p) return kOutOfMemory;
-    for (size_t off = 0; off < count; off += chunk) {
-      const size_t c = std::min(chunk, count - off);
-      int rc = multiply(a + off * c2, 2, b + off * c2, 2, (u64*)sg.p, c, s);
-      if (rc) return rc;
-      rc = relinearize((const u64*)sg.p, rk, out2 + off * c2, c, s);
-      if (rc) return rc;
-    }
-    return kOk;
-  }
-  if (int rc = ensure_streams(ns)) return rc;
-  HB_CHECK(hipEventRecord(fork_ev_, s));
-  std::vector<void*> tmp(ns, nullptr);
-  int rc = kOk;
-  for (size_t i = 0; i < ns && rc == kOk; i++) {
-    HB_CHECK(hipStreamWaitEvent(aux_[i], fork_ev_, 0));
-    tmp[i] = pool_.acquire(chunk * cs * sizeof(u64), aux_[i]);
-    if (!tmp[i]) rc = kOutOfMemory;
-  }
-  size_t idx = 0;
-  for (size_t off = 0; off < count && rc == kOk; off += chunk, idx++) {
+  ScratchGuard sg(pool_, std::min(chunk, count) * cs * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
-    hipStream_t st = aux_[idx % ns];
-    rc = multiply(a + off * c2, 2, b + off * c2, 2, (u64*)tmp[idx % ns], c, st);
-    if (rc == kOk) rc = relinearize((const u64*)tmp[idx % ns], rk, out2 + off * c2, c, st);
-  }
-  for (size_t i = 0; i < ns; i++) {
-    if (tmp[i]) pool_.release(tmp[i], aux_[i]);
-    (void)hipEventRecord(join_ev_[i], aux_[i]);
-    (void)hipStreamWaitEvent(s, join_ev_[i], 0);
-  }
-  return rc;
-}
-
-int Evaluator::ensure_streams(size_t n) {
-  std::lock_guard<std::mutex> g(stream_mu_);
-  if (!fork_ev_ && hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming) != hipSuccess) return kHipError;
-  while (aux_.size() < n) {
-    hipStream_t st = nullptr;
-    hipEvent_t ev = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return kHipError;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return kHipError;
-    aux_.push_back(st);
-    join_ev_.push_back(ev);
+    int rc = multiply(a + off * c2, 2, b + off * c2, 2, (u64*)sg.p, c, s);
+    if (rc) return rc;
+    rc = relinearize((const u64*)sg.p, rk, out2 + off * c2, c, s, addend ? addend + off * c2 : nullptr);
+    if (rc) return rc;
   }
   return kOk;
 }
 
-int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, size_t count, hipStream_t s) {
+int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, size_t count, hipStream_t s, const u64* addend) {
   const DevCtx& h = ctx_->host();
   const u32 n = h.n, K = h.K;
   if (!(elt & 1) || elt >= 2 * n) return kInvalidArg;
@@ -368,7 +326,7 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, 
     const size_t c = std::min(chunk, count - off);
     HB_LAUNCH(kKernGalois, c * 2, launch_galois(ctx_->dev(), n, ct2 + off * rot_words, rot, c * 2, ginv, s));
     // base = (sigma(c0), 0); target = sigma(c1)
-    int rc = key_switch(rot + (size_t)K * n, rot_words, key, rot, rot_words, 1u, out2 + off * rot_words, c, ks, s);
+    int rc = key_switch(rot + (size_t)K * n, rot_words, key, rot, rot_words, 1u, out2 + off * rot_words, c, ks, s, addend ? addend + off * rot_words : nullptr);
     if (rc) return rc;
   }
   return kOk;

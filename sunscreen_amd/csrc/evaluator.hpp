@@ -117,10 +117,11 @@ class Evaluator {
 
   // ---- SURVEY 8a rows a1-a5, batched ----
   int multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, size_t count, hipStream_t s);
-  int relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s);
-  int multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s);
+  // addend (optional, the three key-switching operations): ciphertexts u64[count][2][K][N] added to the results inside the last kernel
+  int relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
+  int multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
   // out2 = (sigma_g(c0), 0) + switch_key(sigma_g(c1), key)
-  int apply_galois(const u64* ct2, u32 galois_elt, const u64* key, u64* out2, size_t count, hipStream_t s);
+  int apply_galois(const u64* ct2, u32 galois_elt, const u64* key, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
   int add(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s);
   int sub(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s);
   int negate(const u64* a, u64* out, u32 size, size_t count, hipStream_t s);
@@ -153,14 +154,8 @@ class Evaluator {
 
  private:
   int key_switch(const u64* target, size_t tstride, const u64* key, const u64* base, size_t bstride, u32 base_mask, u64* out2,
-                 size_t count, u64* scratch, hipStream_t s);
+                 size_t count, u64* scratch, hipStream_t s, const u64* extra = nullptr);
   size_t ks_scratch_words() const;
-  int ensure_streams(size_t n);
-  std::mutex stream_mu_;
-  std::vector<hipStream_t> aux_;
-  std::vector<hipEvent_t> join_ev_;
-  hipEvent_t fork_ev_ = nullptr;
-  size_t nstreams_ = 1;  // >1: chunks round-robin on internal streams (measured: no gain on MI355X, kept for experiments)
   Context* ctx_;
   ScratchPool pool_;
   Profiler prof_;

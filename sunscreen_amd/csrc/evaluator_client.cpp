@@ -213,7 +213,7 @@ int Evaluator::encrypt(const u64* plain, size_t pstride, const u64* pk, u64 seed
     u64* out = ct2 + off * 2 * K * n;
     if (KK > 1) {
       // SEAL encrypts at the key level and divides-and-rounds by the special prime (mod_switch of the fresh encryption)
-      HC_CHECK(launch_ks_moddown(ctx_->dev(), n, c2, nullptr, 0, 0u, out, c, s));
+      HC_CHECK(launch_ks_moddown(ctx_->dev(), n, c2, nullptr, 0, 0u, nullptr, out, c, s));
     } else {
       HC_CHECK(hipMemcpyAsync(out, c2, c * 2 * (size_t)K * n * sizeof(u64), hipMemcpyDeviceToDevice, s));
     }

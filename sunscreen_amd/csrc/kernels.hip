@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kCoefThreads) void ks_mac_kernel(const DevCtx* __re
 // base: op stride bstride words, poly stride K*N; base_mask bit c = 0 means "treat base poly c as zero"
 __global__ __launch_bounds__(kCoefThreads) void ks_moddown_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ACC,
                                                                   const u64* __restrict__ base, size_t bstride, u32 base_mask,
-                                                                  u64* __restrict__ out) {
+                                                                  const u64* __restrict__ extra, u64* __restrict__ out) {
   const u32 n = ctx->n, K = ctx->K, KK = ctx->KK;
   const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
   const u32 c = blockIdx.y, op = blockIdx.z;
@@ -442,7 +442,8 @@ __global__ __launch_bounds__(kCoefThreads) void ks_moddown_kernel(const DevCtx* 
     tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
     u64 d = sub_mod(acc[(size_t)J * n + k], tk, mj.q);
     d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
-    const u64 b = ((base_mask >> c) & 1u) ? base[(size_t)op * bstride + ((size_t)c * K + J) * n + k] : 0;
+    u64 b = ((base_mask >> c) & 1u) ? base[(size_t)op * bstride + ((size_t)c * K + J) * n + k] : 0;
+    if (extra) b = add_mod(b, extra[(((size_t)op * 2 + c) * K + J) * n + k], mj.q);
     out[(((size_t)op * 2 + c) * K + J) * n + k] = add_mod(b, d, mj.q);
   }
 }
@@ -631,8 +632,9 @@ hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u
   return hipGetLastError();
 }
 
-hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, u64* out, size_t ops, hipStream_t s) {
-  ks_moddown_kernel<<<coef_grid(n, 2, (u32)ops), kCoefThreads, 0, s>>>(ctx, ACC, base, bstride, base_mask, out);
+hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out,
+                             size_t ops, hipStream_t s) {
+  ks_moddown_kernel<<<coef_grid(n, 2, (u32)ops), kCoefThreads, 0, s>>>(ctx, ACC, base, bstride, base_mask, extra, out);
   return hipGetLastError();
 }
 

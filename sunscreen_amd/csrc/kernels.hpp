@@ -27,7 +27,7 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
 hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
 hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops,
                          hipStream_t s);
-hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, u64* out2,
+hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
                           size_t ops, hipStream_t s);
 // split BEHZ multiply (2 x 2 -> 3), K <= 4
 hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
@@ -36,7 +36,8 @@ hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi,
                           const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s);
 hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, u32 kneed, const u64* D, u64* out, size_t ops,
                            hipStream_t s);
-hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, u64* out, size_t ops, hipStream_t s);
+hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out,
+                             size_t ops, hipStream_t s);
 hipError_t launch_galois(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t polys, u32 ginv, hipStream_t s);
 hipError_t launch_eltwise(const DevCtx* ctx, u32 n, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode, hipStream_t s);
 hipError_t launch_plain_addsub(const DevCtx* ctx, u32 n, u64* ct, size_t ctstride, const u64* plain, size_t pstride, size_t ops, int sub, hipStream_t s);

@@ -562,7 +562,7 @@ __device__ __forceinline__ void tail_inverse4(const ArithD& ar, double (&v)[4], 
 template <int L>
 __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                const double* __restrict__ ACC, const u64* __restrict__ base, size_t bstride,
-                                                               u32 base_mask, u64* __restrict__ out) {
+                                                               u32 base_mask, const u64* __restrict__ extra, u64* __restrict__ out) {
   constexpr u32 N = 1u << L, Q = N >> kTailLog;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 c = blockIdx.y, op = blockIdx.z;
@@ -598,7 +598,8 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
       u64 d = sub_mod(a, tk, mj.q);
       d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
       const size_t off = ((size_t)c * K + J) * N + t + (size_t)k * Q;
-      const u64 bv = ((base_mask >> c) & 1u) ? base[(size_t)op * bstride + off] : 0;
+      u64 bv = ((base_mask >> c) & 1u) ? base[(size_t)op * bstride + off] : 0;
+      if (extra) bv = add_mod(bv, extra[((size_t)op * 2) * K * N + off], mj.q);  // a ciphertext added to the result (fused Add node)
       out[((size_t)op * 2) * K * N + off] = add_mod(bv, d, mj.q);
     }
   }
@@ -1220,15 +1221,16 @@ hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, 
 }
 
 template <int L>
-static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, u64* out2, size_t ops,
-                            hipStream_t s) {
+static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra,
+                            u64* out2, size_t ops, hipStream_t s) {
   ks_tail_kernel<L><<<dim3((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base,
-                                                                                                   bstride, base_mask, out2);
+                                                                                                   bstride, base_mask, extra, out2);
   return hipGetLastError();
 }
-hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, u64* out2,
+// extra: optional ciphertexts u64[ops][2][K][N] added to the result
+hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
                           size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(ks_tail_t, ctx, twi, ACC, base, bstride, base_mask, out2, ops, s)
+  SPLIT_DISPATCH(ks_tail_t, ctx, twi, ACC, base, bstride, base_mask, extra, out2, ops, s)
 }
 
 template <int L>

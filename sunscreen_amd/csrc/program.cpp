@@ -454,6 +454,25 @@ int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t
     }
   }
 
+  // An Add one of whose operands comes from a key-switching node (Relinearize / rotation) that has no other user: the
+  // producer adds the other operand inside its last kernel -- when that operand already exists at that point of the
+  // topological order -- and the Add node then just adopts the result (no separate element-wise pass).
+  std::vector<int> add_user(nn, -1), folded(nn, -1);
+  for (int i = 0; i < nn; i++) {
+    if (nodes_[i].op != kOpAdd || nodes_[i].left == nodes_[i].right) continue;
+    for (int src : {nodes_[i].left, nodes_[i].right}) {
+      const OpKind k = nodes_[src].op;
+      if ((k == kOpRelinearize || k == kOpShiftLeft || k == kOpShiftRight || k == kOpSwapRows) && val[src].uses == 1) add_user[src] = i;
+    }
+  }
+  auto addend_for = [&](int producer) -> const u64* {
+    const int u = add_user[producer];
+    if (u < 0 || folded[u] >= 0) return nullptr;
+    const int other = nodes_[u].left == producer ? nodes_[u].right : nodes_[u].left;
+    const Value& o = val[other];
+    return (o.ct && o.size == 2) ? o.ct : nullptr;
+  };
+
   for (int id : order) {
     const Node& nd = nodes_[id];
     Value& v = val[id];
@@ -538,7 +557,9 @@ int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t
             pool.release(tmp, s);
             live.erase(std::remove(live.begin(), live.end(), (void*)tmp), live.end());
           } else {
-            rc = relin_key ? ev.multiply_relin(A.ct, B.ct, relin_key, out, batch, s) : (int)kNoKey;
+            const u64* addend = addend_for(id);
+            rc = relin_key ? ev.multiply_relin(A.ct, B.ct, relin_key, out, batch, s, addend) : (int)kNoKey;
+            if (addend && !rc) folded[add_user[id]] = id;
           }
           v.ct = out;
           v.owned = true;
@@ -551,7 +572,9 @@ int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t
         if (L->size == 2) {
           if (hipMemcpyAsync(out, L->ct, batch * ctx->ct_words(2) * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = kHipError;
         } else if (L->size == 3) {
-          rc = relin_key ? ev.relinearize(L->ct, relin_key, out, batch, s) : (int)kNoKey;
+          const u64* addend = addend_for(id);
+          rc = relin_key ? ev.relinearize(L->ct, relin_key, out, batch, s, addend) : (int)kNoKey;
+          if (addend && !rc) folded[add_user[id]] = id;
         } else {
           rc = kInvalidArg;
         }
@@ -561,6 +584,14 @@ int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t
       }
       case kOpAdd:
       case kOpSub: {
+        if (nd.op == kOpAdd && folded[id] >= 0) {  // the producer already added the other operand: adopt its buffer
+          Value& p = val[folded[id]];
+          v.ct = p.ct;
+          v.size = 2;
+          v.owned = p.owned;
+          p.owned = false;
+          break;
+        }
         if (!R->ct) return cleanup(kInvalidArg, "right operand is not a ciphertext");
         if (L->size != R->size) return cleanup(kInvalidArg, "add/sub of different ciphertext sizes is not supported in batched programs");
         v.size = L->size;
@@ -606,7 +637,18 @@ int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t
         v.size = 2;
         u64* out = alloc_ct(2);
         if (!out) return cleanup(kOutOfMemory, "out of device memory");
-        rc = rotate(L->ct, nd.op == kOpShiftLeft ? k : -k, out);
+        {
+          const int steps = nd.op == kOpShiftLeft ? k : -k;
+          const u32 elt = steps ? ev.galois_elt_from_step(steps) : 0;
+          const u64* key = elt ? galois_key(elt) : nullptr;
+          const u64* addend = key ? addend_for(id) : nullptr;  // single key switch: the Add can ride along
+          if (addend) {
+            rc = ev.apply_galois(L->ct, elt, key, out, batch, s, addend);
+            if (!rc) folded[add_user[id]] = id;
+          } else {
+            rc = rotate(L->ct, steps, out);
+          }
+        }
         v.ct = out;
         v.owned = true;
         break;
@@ -620,7 +662,11 @@ int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t
         v.size = 2;
         u64* out = alloc_ct(2);
         if (!out) return cleanup(kOutOfMemory, "out of device memory");
-        rc = ev.apply_galois(L->ct, elt, key, out, batch, s);
+        {
+          const u64* addend = addend_for(id);
+          rc = ev.apply_galois(L->ct, elt, key, out, batch, s, addend);
+          if (addend && !rc) folded[add_user[id]] = id;
+        }
         v.ct = out;
         v.owned = true;
         break;
