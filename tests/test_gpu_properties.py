@@ -235,3 +235,57 @@ def test_concurrent_host_threads_on_one_evaluator():
     for th in ts:
         th.join()
     assert not errors, errors
+
+
+def test_batches_beyond_the_grid_dimension_limit():
+    """Launch grids carry the batch in a 16-bit dimension: batches above 65535 items (and a chunk size set above it)
+    must be split correctly by every operation.  Checked against the same operation on slices around the chunk
+    boundaries, which in turn are covered by the oracle tests."""
+    import torch
+
+    from sunscreen_amd import Context, GaloisKeys, PublicKey, RelinearizationKeys, SecretKey
+    from sunscreen_amd.batch import BatchEvaluator
+
+    n = 4096
+    primes, t = O.bfv_default(n), O.plain_batching(n, 16)
+    o = O.Oracle(n, primes, t)
+    O.seed(77)
+    elt = o.galois_elt_from_step(1)
+    sk, pk, rk, gk = o.keygen(galois_elts=[elt])
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    ev.set_chunk_ops(1 << 20)
+    rkd, gkd = RelinearizationKeys.from_array(ctx, rk), GaloisKeys.from_arrays(ctx, gk)
+    skd, pkd = SecretKey.from_array(ctx, sk), PublicKey.from_array(ctx, pk)
+    B = 66000
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(5)
+    K = ctx.K
+    a = torch.empty((B, 2, K, n), dtype=torch.int64, device="cuda:0")
+    for i, q in enumerate(primes[:K]):
+        a[:, :, i, :] = torch.randint(0, q, (B, 2, n), generator=gen, device="cuda:0", dtype=torch.int64)
+    b = a.flip(0).contiguous()
+    pl = torch.randint(1, t, (B, n), generator=gen, device="cuda:0", dtype=torch.int64)
+    probes = [0, 1, 3275, 3276, 3277, 6552, 32767, 32768, 65534, 65535, 65536, B - 1]
+
+    def check(full, fn):
+        for i in probes:
+            assert torch.equal(full[i : i + 1], fn(i)), i
+
+    check(ev.add(a, b), lambda i: ev.add(a[i : i + 1].contiguous(), b[i : i + 1].contiguous()))
+    check(ev.negate(a), lambda i: ev.negate(a[i : i + 1].contiguous()))
+    check(ev.add_plain(a, pl), lambda i: ev.add_plain(a[i : i + 1].contiguous(), pl[i : i + 1].contiguous()))
+    check(ev.multiply_plain(a, pl), lambda i: ev.multiply_plain(a[i : i + 1].contiguous(), pl[i : i + 1].contiguous()))
+    m = ev.multiply(a, b)
+    check(m, lambda i: ev.multiply(a[i : i + 1].contiguous(), b[i : i + 1].contiguous()))
+    check(ev.relinearize(m, rkd), lambda i: ev.relinearize(m[i : i + 1].contiguous(), rkd))
+    del m
+    check(ev.multiply_relin(a, b, rkd), lambda i: ev.multiply_relin(a[i : i + 1].contiguous(), b[i : i + 1].contiguous(), rkd))
+    check(ev.rotate_rows(a, 1, gkd), lambda i: ev.rotate_rows(a[i : i + 1].contiguous(), 1, gkd))
+    check(ev.decrypt(a, skd), lambda i: ev.decrypt(a[i : i + 1].contiguous(), skd))
+    enc = ev.encode(pl % t)
+    check(enc, lambda i: ev.encode((pl[i : i + 1] % t).contiguous()))
+    assert torch.equal(ev.decode(enc), pl % t)
+    ct = ev.encrypt(enc, pkd, seed=9)
+    check(ct, lambda i: ev.encrypt(enc[i : i + 1].contiguous(), pkd, seed=9, first_op=i))
+    assert torch.equal(ev.decrypt(ct, skd), enc)
