@@ -17,6 +17,9 @@
 
 #include "devarith.hpp"
 #include "kernels.hpp"
+#ifndef NTT_PAIRS
+#define NTT_PAIRS 1
+#endif
 #ifndef NTT_DIRECT_LOAD
 #define NTT_DIRECT_LOAD 1
 #endif
@@ -272,10 +275,204 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
   }
 }
 
+// =====================================================================================
+// Paired transforms: one workgroup advances TWO polynomials of the same modulus pass by pass (as the middle kernels of
+// kernels_split.hip do): one barrier and one set of twiddle fetches per pass for both, two independent butterfly
+// streams per thread, both polynomials' loads in flight together.  2 * N words of LDS; used for N <= 4096, where two such workgroups fit a CU.
+// =====================================================================================
+template <class A, int LOGN, int PASS>
+__device__ __forceinline__ void fwd_passes2(const A& ar, typename A::V (&v)[2][kElemsPerThread], typename A::V* smem, u32 tid,
+                                            const typename A::Tw* tw, u32 reduce_mask) {
+  using Sh = NttShape<LOGN>;
+  constexpr int EPT = kElemsPerThread;
+  constexpr int R = Sh::radix(PASS), S0 = Sh::before(PASS), LOW = LOGN - S0 - R, G = EPT >> R;
+  if constexpr (PASS > 0) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) v[i][g * (1 << R) + k] = smem[i * Sh::N + lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    if ((reduce_mask >> PASS) & 1u) {
+#pragma unroll
+      for (int e = 0; e < EPT; e++) v[i][e] = ar.reduce(v[i][e]);
+    }
+    if ((reduce_mask >> (PASS + 16)) & 1u) {
+#pragma unroll
+      for (int e = 0; e < EPT; e++) v[i][e] = ar.reduce(v[i][e]);
+    }
+  }
+  fwd_pass_compute<A, LOGN, EPT, S0, R>(ar, v[0], tid, tw);
+  fwd_pass_compute<A, LOGN, EPT, S0, R>(ar, v[1], tid, tw);  // same twiddle addresses: the loads are shared
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) smem[i * Sh::N + lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[i][g * (1 << R) + k];
+  if constexpr (PASS + 1 < Sh::NPASS) fwd_passes2<A, LOGN, PASS + 1>(ar, v, smem, tid, tw, reduce_mask);
+}
+
+template <class A, int LOGN, int PASS>
+__device__ __forceinline__ void inv_passes2(const A& ar, typename A::V (&v)[2][kElemsPerThread], typename A::V* smem, u32 tid,
+                                            const typename A::Tw* tw, u32 reduce_mask) {
+  using Sh = NttShape<LOGN>;
+  constexpr int EPT = kElemsPerThread;
+  constexpr int FP = Sh::NPASS - 1 - PASS;
+  constexpr int R = Sh::radix(FP), LOW = LOGN - Sh::before(FP) - R, G = EPT >> R;
+  if constexpr (PASS > 0) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) v[i][g * (1 << R) + k] = smem[i * Sh::N + lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    if ((reduce_mask >> PASS) & 1u) {
+#pragma unroll
+      for (int e = 0; e < EPT; e++) v[i][e] = ar.reduce(v[i][e]);
+    }
+    if ((reduce_mask >> (PASS + 16)) & 1u) {
+#pragma unroll
+      for (int e = 0; e < EPT; e++) v[i][e] = ar.reduce(v[i][e]);
+    }
+  }
+  inv_pass_compute<A, LOGN, EPT, LOW, R>(ar, v[0], tid, tw);
+  inv_pass_compute<A, LOGN, EPT, LOW, R>(ar, v[1], tid, tw);
+  if constexpr (PASS + 1 < Sh::NPASS) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) smem[i * Sh::N + lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[i][g * (1 << R) + k];
+    inv_passes2<A, LOGN, PASS + 1>(ar, v, smem, tid, tw, reduce_mask);
+  }
+}
+
+template <class A, int LOGN>
+__device__ __forceinline__ void ntt_fwd2_body(const DevMod& dm, const typename A::Tw* tw, u64* x0, u64* x1, typename A::V* smem, u32 tid) {
+  using Sh = NttShape<LOGN>;
+  const A ar(dm);
+  constexpr int R0 = Sh::radix(0), LOW0 = LOGN - R0, G0 = kElemsPerThread >> R0;
+  typename A::V v[2][kElemsPerThread];
+#pragma unroll
+  for (int g = 0; g < G0; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R0); k++) {
+      const u32 e = elem_index<LOW0, R0>(tid + g * Sh::T, k);
+      v[0][g * (1 << R0) + k] = ar.from_u64(x0[e]);
+      v[1][g * (1 << R0) + k] = ar.from_u64(x1[e]);
+    }
+  fwd_passes2<A, LOGN, 0>(ar, v, smem, tid, tw, dm.fwd_reduce_mask);
+  __syncthreads();
+  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) {
+    x0[e] = ar.canonical(smem[lds_pos(e)]);
+    x1[e] = ar.canonical(smem[Sh::N + lds_pos(e)]);
+  }
+}
+
+template <class A, int LOGN>
+__device__ __forceinline__ void ntt_inv2_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Tw& sc, u64* x0, u64* x1,
+                                              typename A::V* smem, u32 tid) {
+  using Sh = NttShape<LOGN>;
+  const A ar(dm);
+  typename A::V v[2][kElemsPerThread];
+  constexpr int RF = Sh::radix(Sh::NPASS - 1), GF = kElemsPerThread >> RF;
+#pragma unroll
+  for (int g = 0; g < GF; g++) {
+    const ulonglong2* s0 = reinterpret_cast<const ulonglong2*>(x0 + ((size_t)(tid + g * Sh::T) << RF));
+    const ulonglong2* s1 = reinterpret_cast<const ulonglong2*>(x1 + ((size_t)(tid + g * Sh::T) << RF));
+#pragma unroll
+    for (int k = 0; k < (1 << RF); k += 2) {
+      const ulonglong2 a = s0[k >> 1], b = s1[k >> 1];
+      v[0][g * (1 << RF) + k] = ar.from_u64(a.x);
+      v[0][g * (1 << RF) + k + 1] = ar.from_u64(a.y);
+      v[1][g * (1 << RF) + k] = ar.from_u64(b.x);
+      v[1][g * (1 << RF) + k + 1] = ar.from_u64(b.y);
+    }
+  }
+  inv_passes2<A, LOGN, 0>(ar, v, smem, tid, tw, dm.inv_reduce_mask);
+  constexpr int R = Sh::radix(0), LOW = LOGN - R, G = kElemsPerThread >> R;
+#pragma unroll
+  for (int g = 0; g < G; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      const u32 e = elem_index<LOW, R>(tid + g * Sh::T, k);
+      x0[e] = ar.scale_canonical(v[0][g * (1 << R) + k], sc);
+      x1[e] = ar.scale_canonical(v[1][g * (1 << R) + k], sc);
+    }
+}
+
+// grid: polys / 2 workgroups; plan.div == 1 and polys % (2 * plan.period) == 0: workgroup w takes the polynomials
+// p0 = (w / period) * 2 * period + w % period and p0 + period, which share their modulus
+template <int LOGN, bool INVERSE>
+__global__ __launch_bounds__(NttShape<LOGN>::T, 2) void ntt_pair_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase, u64* data,
+                                                                        NttPlan plan, int scale_mode) {
+  using Sh = NttShape<LOGN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const u32 tid = threadIdx.x;
+  const u32 w = blockIdx.x;
+  const u32 p0 = (w / plan.period) * 2 * plan.period + w % plan.period, p1 = p0 + plan.period;
+  const u32 m = plan.mod[w % plan.period];
+  const DevMod& dm = ctx->mod[m];
+  u64* x0 = data + (size_t)p0 * Sh::N;
+  u64* x1 = data + (size_t)p1 * Sh::N;
+  const MulOp* tw = twbase + (size_t)m * Sh::N;
+  if (dm.use_f64) {
+    const MulOpD* twd = reinterpret_cast<const MulOpD*>(tw);
+    double* sm = reinterpret_cast<double*>(smem_raw);
+    if constexpr (INVERSE) {
+      MulOpD sc = dm.ninv_d;
+      if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q_d[m] : ctx->intt_scale_bsk_d[m - ctx->KK];
+      ntt_inv2_body<ArithD, LOGN>(dm, twd, sc, x0, x1, sm, tid);
+    } else {
+      ntt_fwd2_body<ArithD, LOGN>(dm, twd, x0, x1, sm, tid);
+    }
+  } else {
+    u64* sm = reinterpret_cast<u64*>(smem_raw);
+    if constexpr (INVERSE) {
+      MulOp sc = dm.ninv;
+      if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
+      ntt_inv2_body<ArithI, LOGN>(dm, tw, sc, x0, x1, sm, tid);
+    } else {
+      ntt_fwd2_body<ArithI, LOGN>(dm, tw, x0, x1, sm, tid);
+    }
+  }
+}
+
 template <int LOGN>
 static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
   using Sh = NttShape<LOGN>;
   const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
+#if NTT_PAIRS
+  if constexpr (LOGN <= 12) {  // measured: +5 % at N = 4096; at N = 8192 (128 KB of LDS, one workgroup per CU) 5 % slower
+    // as many polynomials as possible go two per workgroup; the remainder (< 2 * period) one per workgroup below
+    const size_t paired = plan.div == 1 ? polys / (2 * (size_t)plan.period) * (2 * (size_t)plan.period) : 0;
+    if (paired) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)ntt_pair_kernel<LOGN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
+        (void)hipFuncSetAttribute((const void*)ntt_pair_kernel<LOGN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
+        attr_done = true;
+      }
+      if (inverse)
+        ntt_pair_kernel<LOGN, true><<<dim3((unsigned)(paired / 2)), dim3(Sh::T), 2 * lds, s>>>(ctx, tw, data, plan, scale_mode);
+      else
+        ntt_pair_kernel<LOGN, false><<<dim3((unsigned)(paired / 2)), dim3(Sh::T), 2 * lds, s>>>(ctx, tw, data, plan, scale_mode);
+      if (paired == polys) return hipGetLastError();
+      data += paired * Sh::N;
+      polys -= paired;  // paired is a multiple of the period: the plan's modulus cycle continues unchanged
+    }
+  }
+#endif
   if (inverse) {
     static bool attr_done = false;
     if (!attr_done) {
