@@ -5,7 +5,12 @@ One "step" = one pass of the hot path over one batch: `--batch` (default 4096) i
 ciphertext pairs, n=8192, SEAL default 128-bit parameters (K=4 data primes + 1 special prime,
 t = batching(8192,17) = 114689) -- BASELINE.json configs[2], the configuration the metric is quoted
 on.  Inputs are resident in HBM before the timed region.  `--workload ntt` runs configs[1]
-(batched forward+inverse NTT, n=8192, 3 primes, 4096 polynomials) instead.
+(batched forward+inverse NTT, n=8192, 3 primes, 4096 polynomials) instead; chi_sq / dot_prod / pir / e2e run the
+reference's example programs and the client-side steps (secondary workloads, same JSON contract).
+
+The CPU oracle appears here in three roles only: client (it generates the keys and the few genuine encryptions the
+parity gate needs -- the library has no key generator), checker (parity gate, after the timed region) and
+`cpu_baseline`.  Nothing in the timed region touches it.
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank processes its own
 `--batch` items (weak scaling, no data-path collective); time = max over ranks.

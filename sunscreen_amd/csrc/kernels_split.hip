@@ -16,9 +16,12 @@
 // Intermediates between the three kernels are stored in the arithmetic policy's native lazy representation
 // (IEEE doubles holding exact integers for the FP64 path) -- they never leave this file.
 //
+// The middle kernels advance all polynomials of their (prime, block) together, pass by pass (mid_forward_multi):
+// one barrier and one set of twiddle fetches per pass, independent butterfly streams, all loads in flight at once.
+//
 // This file: key switching (SEAL Evaluator::switch_key_inplace; Evaluator_Relinearize / RotateRows /
 // RotateColumns, seal_fhe/src/bfv_evaluator.rs:148-244) for contexts whose key-level primes all take the
-// FP64 path.
+// FP64 path; the BEHZ multiply (Evaluator_Multiply) for up to 8 data primes; the two-kernel transforms of N = 32768.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -609,7 +612,8 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
 // BEHZ multiply (2 x 2 -> 3), split pipeline.  Replaces behz_extend -> ntt_fwd -> tensor -> ntt_inv ->
 // behz_floor_sk of the whole-polynomial path (SEAL bfv_multiply; Evaluator_Multiply,
 // seal_fhe/src/evaluator_base.rs:198-212).  Residue r < K uses prime q_r (FP64 path when its range plan
-// succeeded, integer path otherwise), residue K + j uses the 61-bit auxiliary prime Bsk_j (integer path).
+// succeeded, integer path otherwise), residue K + j uses the auxiliary prime Bsk_j: the library's own FP64-pipe base
+// when DevCtx::aux_f64 (AUXD instantiations, conversions in exact FP64), SEAL's 61-bit base on the integer path otherwise.
 // =================================================================================================
 
 __device__ __forceinline__ bool residue_is_f64(const DevMod& dm) { return dm.use_f64 && dm.split_ok; }
