@@ -163,6 +163,12 @@ long Evaluator_SubPlain(void *thisptr, void *encrypted, void *plain, void *desti
 long Evaluator_MultiplyPlain(void *thisptr, void *encrypted, void *plain, void *destination, void *pool);
 long Evaluator_RotateRows(void *thisptr, void *encrypted, int steps, void *galois_keys, void *destination, void *pool);
 long Evaluator_RotateColumns(void *thisptr, void *encrypted, void *galois_keys, void *destination, void *pool);
+/* mod_switch_to_next (seal_fhe/src/evaluator.rs:84-157): BFV ciphertexts are divided-and-rounded by the last data prime
+ * and move to the next level of the modulus-switching chain; every Evaluator_*, Decryptor_* and Ciphertext_Save/Load
+ * call accepts ciphertexts of any level (levels are created on first use; SEALContext_Create(expand_mod_chain = false)
+ * disables them).  Plaintexts of this path are never in NTT form, so the plaintext overload always fails as SEAL's does. */
+long Evaluator_ModSwitchToNext1(void *thisptr, void *encrypted, void *destination, void *pool);
+long Evaluator_ModSwitchToNext2(void *thisptr, void *plain, void *destination);
 
 /* ===================================================================================== */
 /* Part 2: hipbfv extensions                                                               */
@@ -181,6 +187,9 @@ long hipbfv_Context_Create(uint64_t poly_modulus_degree, const uint64_t *coeff_m
 long hipbfv_Context_Info(void *context, uint64_t *poly_modulus_degree, uint64_t *data_primes, uint64_t *key_primes,
                          uint64_t *plain_modulus);
 long hipbfv_Context_GetPrime(void *context, uint64_t index, uint64_t *value); /* key-level prime `index` */
+/* the context of the next level of the modulus-switching chain (one data prime fewer, same special prime): an owned
+ * handle for the batched API (Evaluator_Create on it, hipbfv_batch_* at that level) */
+long hipbfv_Context_NextLevel(void *context, void **next);
 /* The BEHZ auxiliary base Bsk = B u {m_sk} this context multiplies in (internal to Evaluator_Multiply; SEAL's
  * RNSTool keeps its own privately, native/src/seal/util/rns.h).  *fp64_base = 1 when the library chose its own
  * FP64-pipe primes (same size bound as SEAL's rule, bit-identical products), 0 when it uses SEAL's 61-bit primes.
@@ -239,6 +248,8 @@ long hipbfv_batch_multiply_plain(void *evaluator, const uint64_t *ct, uint64_t s
                                  uint64_t plain_stride, uint64_t *out, uint64_t count, void *stream);
 /* forward / inverse negacyclic NTT of u64[polys][N]; polynomial p uses key-level prime (p % nprimes) */
 long hipbfv_batch_ntt(void *evaluator, uint64_t *data, uint64_t polys, uint64_t nprimes, bool inverse, void *stream);
+/* ct u64[count][size][K][N] -> out u64[count][size][K-1][N] (the layout of hipbfv_Context_NextLevel's context) */
+long hipbfv_batch_mod_switch(void *evaluator, const uint64_t *ct, uint64_t size, uint64_t *out, uint64_t count, void *stream);
 /* The steps either side of the evaluator, batched on device buffers:
  * encode / decode: values u64[count][N] (int64 when is_signed) <-> plaintexts u64[count][N];
  * decrypt: ct u64[count][size][K][N] -> plaintexts u64[count][N] (zero padded);

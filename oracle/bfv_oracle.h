@@ -77,6 +77,7 @@ int ora_ntt_inverse_plain(const ora_ctx *c, uint64_t *x);
 #define ORA_E_TRANSPARENT (-2)
 #define ORA_E_NOKEY (-3)
 
+int ora_mod_switch_to_next(const ora_ctx *c, const uint64_t *ct, size_t s, uint64_t *out);
 int ora_add(const ora_ctx *c, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb, uint64_t *out);
 int ora_sub(const ora_ctx *c, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb, uint64_t *out);
 int ora_negate(const ora_ctx *c, const uint64_t *a, size_t sa, uint64_t *out);

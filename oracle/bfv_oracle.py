@@ -192,6 +192,17 @@ class Oracle:
         if rc != 0:
             raise RuntimeError({-1: "invalid argument", -2: "transparent ciphertext", -3: "missing key"}.get(rc, str(rc)))
 
+    def mod_switch_to_next(self, ct) -> np.ndarray:
+        """Evaluator::mod_switch_to_next (BFV): uint64[size][K-1][N] at the next level (an Oracle built from
+        key_primes[:K-1] + [special prime] continues from there)."""
+        ct = self._ct(ct)
+        out = np.zeros((ct.shape[0], self.K - 1, self.n), dtype=np.uint64)
+        self._chk(lib().ora_mod_switch_to_next(C.c_void_p(self._h), _p(ct), C.c_size_t(ct.shape[0]), _p(out)))
+        return out
+
+    def next_level(self) -> "Oracle":
+        return Oracle(self.n, self.key_primes[: self.K - 1] + self.key_primes[self.K :], self.t)
+
     def add(self, a, b, sub: bool = False) -> np.ndarray:
         a, b = self._ct(a), self._ct(b)
         out = np.zeros((max(a.shape[0], b.shape[0]), self.K, self.n), dtype=np.uint64)

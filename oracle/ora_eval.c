@@ -505,3 +505,29 @@ double ora_bench_ntt(const ora_ctx *c, uint64_t *x, size_t count, size_t nprimes
     }
     return now_s() - t0;
 }
+
+/* SEAL Evaluator::mod_switch_to_next for BFV (seal_fhe/src/evaluator.rs:84-157): every polynomial is divided-and-rounded by
+ * the LAST DATA prime (RNSTool::divide_and_round_q_last_inplace at the data level) and keeps the remaining K-1 residues.
+ * out: uint64[s][K-1][n]. */
+int ora_mod_switch_to_next(const ora_ctx *c, const uint64_t *ct, size_t s, uint64_t *out)
+{
+    const size_t n = c->n, K = c->K;
+    if (K < 2) return ORA_E_INVALIDARG;
+    const ora_mod *ml = &c->key_mod[K - 1];
+    const uint64_t half = ml->q >> 1;
+    for (size_t p = 0; p < s; p++) {
+        const uint64_t *x = ct + p * K * n;
+        for (size_t i = 0; i + 1 < K; i++) {
+            const ora_mod *m = &c->key_mod[i];
+            const uint64_t half_mod = ora_reduce64(half, m);
+            const uint64_t inv = ora_invmod(ora_reduce64(ml->q, m), m);
+            for (size_t k = 0; k < n; k++) {
+                uint64_t last = ora_addmod(x[(K - 1) * n + k], half, ml);
+                uint64_t tk = ora_submod(ora_reduce64(last, m), half_mod, m);
+                uint64_t d = ora_submod(x[i * n + k], tk, m);
+                out[(p * (K - 1) + i) * n + k] = ora_mulmod(d, inv, m);
+            }
+        }
+    }
+    return 0;
+}

@@ -124,6 +124,10 @@ _SIGNATURES = {
     "hipbfv_batch_sub_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
     "hipbfv_batch_multiply_plain": [vp, vp, u64, vp, u64, vp, u64, vp],
     "hipbfv_batch_ntt": [vp, vp, u64, u64, C.c_bool, vp],
+    "hipbfv_batch_mod_switch": [vp, vp, u64, vp, u64, vp],
+    "hipbfv_Context_NextLevel": [vp, vpp],
+    "Evaluator_ModSwitchToNext1": [vp, vp, vp, vp],
+    "Evaluator_ModSwitchToNext2": [vp, vp, vp],
     "hipbfv_batch_encode": [vp, vp, vp, u64, C.c_int, vp],
     "hipbfv_batch_plain_to_ntt": [vp, vp, u64, vp, u64, vp],
     "hipbfv_batch_ct_to_ntt": [vp, vp, u64, vp, u64, vp],

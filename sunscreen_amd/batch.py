@@ -187,6 +187,14 @@ class BatchEvaluator:
                                                 _ptr(out), count, _stream()))
         return out
 
+    def mod_switch(self, ct: torch.Tensor) -> torch.Tensor:
+        """mod_switch_to_next on a batch: int64[batch, size, K, N] -> int64[batch, size, K-1, N], the layout of
+        `self.ctx.next_level()` (build a BatchEvaluator on that context to continue there)."""
+        assert ct.dim() == 4 and ct.shape[2] == self.K and ct.shape[3] == self.n
+        out = torch.empty((ct.shape[0], ct.shape[1], self.K - 1, self.n), dtype=torch.int64, device=ct.device)
+        _check(_lib.load().hipbfv_batch_mod_switch(self._h, _ptr(ct), ct.shape[1], _ptr(out), ct.shape[0], _stream()))
+        return out
+
     # ---- plaintext-matrix x ciphertext-vector products (examples/pir) ----
     def plain_to_ntt(self, plain: torch.Tensor) -> torch.Tensor:
         """int64[..., N] plaintexts -> int64[..., K, N]: the transform-domain operand multiply_plain builds internally."""

@@ -162,9 +162,13 @@ struct CipherObj : Obj {
 struct KeysObj : Obj {
   std::shared_ptr<Context> ctx;
   std::map<u32, u64*> keys;  // index -> device key u64[K][2][K+1][N]
+  // keys re-packed for lower levels of the modulus-switching chain: (level context, index) -> u64[K'][2][K'+1][N]
+  std::map<std::pair<Context*, u32>, std::pair<u64*, size_t>> lower;
+  std::mutex mu;
   KeysObj() : Obj(kMagicKeys) {}
   ~KeysObj() override {
     for (auto& kv : keys) g_buffers.put(kv.second, ctx ? ctx->key_words() : 0);
+    for (auto& kv : lower) g_buffers.put(kv.second.first, kv.second.second);
   }
   const u64* find(u32 index) const {
     auto it = keys.find(index);
@@ -175,8 +179,34 @@ struct KeysObj : Obj {
 struct EvalObj : Obj {
   std::shared_ptr<Context> ctx;
   std::unique_ptr<Evaluator> ev;
+  // evaluators of the lower levels of the modulus-switching chain (SEAL's single Evaluator serves every level of
+  // its context; here every level has its own tables): created on first use
+  std::mutex mu;
+  std::map<Context*, std::unique_ptr<EvalObj>> lower;
   EvalObj() : Obj(kMagicEval) {}
 };
+
+// is `c` the context `top` or one of the (already created) levels below it?
+bool in_chain(const std::shared_ptr<Context>& top, const Context* c) {
+  for (std::shared_ptr<Context> p = top; p; p = p->peek_next())
+    if (p.get() == c) return true;
+  return false;
+}
+
+// the evaluator serving ciphertexts of level context `c` (nullptr if c does not belong to top's chain)
+EvalObj* level_eval(EvalObj* top, const std::shared_ptr<Context>& c) {
+  if (!top || !c) return nullptr;
+  if (top->ctx.get() == c.get()) return top;
+  if (!in_chain(top->ctx, c.get())) return nullptr;
+  std::lock_guard<std::mutex> g(top->mu);
+  auto& slot = top->lower[c.get()];
+  if (!slot) {
+    slot.reset(new EvalObj());
+    slot->ctx = c;
+    slot->ev.reset(new Evaluator(c.get()));
+  }
+  return slot.get();
+}
 
 // SecretKey: u64[KK][N] NTT form (SEAL SecretKey data); PublicKey: u64[2][KK][N] NTT form.  The device buffer is
 // shared with every Decryptor / Encryptor created from the handle.
@@ -198,7 +228,7 @@ struct EncoderObj : Obj {
 };
 struct DecryptorObj : Obj {
   std::shared_ptr<Context> ctx;
-  std::unique_ptr<Evaluator> ev;
+  EvalObj core;  // evaluators per level of the modulus-switching chain (ciphertexts of every level decrypt)
   std::shared_ptr<KeyBuffer> sk;
   DecryptorObj() : Obj(kMagicDecryptor) {}
 };
@@ -236,6 +266,34 @@ hipError_t copy_d2d(void* dst, const void* src, size_t bytes) {
   hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return e;
   return hipStreamSynchronize(s);
+}
+
+// The key-switching key `index` for the level e serves: the handle's own buffer at its own level, a re-packed copy
+// (digits J < K', residues {0..K'-1, special}) below it.  nullptr if absent or foreign.
+const u64* level_key(KeysObj* k, EvalObj* e, u32 index) {
+  if (!k || !k->ctx) return nullptr;
+  const u64* top = k->find(index);
+  if (!top) return nullptr;
+  if (k->ctx.get() == e->ctx.get()) return top;
+  if (!in_chain(k->ctx, e->ctx.get())) return nullptr;
+  std::lock_guard<std::mutex> g(k->mu);
+  auto it = k->lower.find({e->ctx.get(), index});
+  if (it != k->lower.end()) return it->second.first;
+  const size_t n = k->ctx->n(), KKt = k->ctx->KK(), Kl = e->ctx->K(), KKl = e->ctx->KK();
+  const size_t words = e->ctx->key_words();
+  u64* buf = g_buffers.get(words);
+  if (!buf) return nullptr;
+  for (size_t J = 0; J < Kl; J++)
+    for (size_t c = 0; c < 2; c++)
+      for (size_t I = 0; I < KKl; I++) {
+        const size_t It = I < Kl ? I : KKt - 1;  // the special prime is the last row at every level
+        if (copy_d2d(buf + ((J * 2 + c) * KKl + I) * n, top + ((J * 2 + c) * KKt + It) * n, n * sizeof(u64)) != hipSuccess) {
+          g_buffers.put(buf, words);
+          return nullptr;
+        }
+      }
+  k->lower[{e->ctx.get(), index}] = {buf, words};
+  return buf;
 }
 
 bool same_context(const CipherObj* a, const EvalObj* e) { return a->ctx && a->ctx.get() == e->ctx.get() && a->dev && a->size >= 2; }
@@ -475,11 +533,13 @@ static long make_context(u64 n, const std::vector<u64>& coeff, u64 plain, int se
 }
 
 long SEALContext_Create(void* params, bool expand_mod_chain, int sec_level, void** context) {
-  (void)expand_mod_chain;  // the evaluator path never mod-switches (sunscreen_fhe_program/src/operation.rs:12-94)
   ParamsObj* p = as<ParamsObj>(params, kMagicParams);
   if (!p || !context) return HIPBFV_E_POINTER;
   if (p->n > 0xFFFFFFFFull) return fail(HIPBFV_E_INVALIDARG, "invalid degree");
-  return make_context(p->n, p->coeff, p->plain, sec_level, context);
+  long hr = make_context(p->n, p->coeff, p->plain, sec_level, context);
+  // lower levels are created lazily on the first Evaluator_ModSwitchToNext; without the chain that call fails
+  if (hr == HIPBFV_S_OK) static_cast<ContextObj*>(*context)->ctx->set_chain_enabled(expand_mod_chain);
+  return hr;
 }
 
 long SEALContext_Destroy(void* h) {
@@ -819,6 +879,7 @@ long Evaluator_Negate(void* h, void* a, void* dst) {
   EvalObj* e = as<EvalObj>(h, kMagicEval);
   CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
   if (!e || !x || !d) return HIPBFV_E_POINTER;
+  if (EvalObj* le = level_eval(e, x->ctx)) e = le;
   if (!same_context(x, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
   hipStream_t s = thread_stream();
   u64* buf = g_buffers.get(x->words);
@@ -836,6 +897,7 @@ static long add_sub(void* h, void* a, void* b, void* dst, bool sub) {
   EvalObj* e = as<EvalObj>(h, kMagicEval);
   CipherObj *x = as<CipherObj>(a, kMagicCipher), *y = as<CipherObj>(b, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
   if (!e || !x || !y || !d) return HIPBFV_E_POINTER;
+  if (EvalObj* le = level_eval(e, x->ctx)) e = le;
   if (!same_context(x, e) || !same_context(y, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
   hipStream_t s = thread_stream();
   const u32 smax = std::max(x->size, y->size), smin = std::min(x->size, y->size);
@@ -888,6 +950,7 @@ long Evaluator_Multiply(void* h, void* a, void* b, void* dst, void* pool) {
   EvalObj* e = as<EvalObj>(h, kMagicEval);
   CipherObj *x = as<CipherObj>(a, kMagicCipher), *y = as<CipherObj>(b, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
   if (!e || !x || !y || !d) return HIPBFV_E_POINTER;
+  if (EvalObj* le = level_eval(e, x->ctx)) e = le;
   if (!same_context(x, e) || !same_context(y, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
   hipStream_t s = thread_stream();
   const u32 sd = x->size + y->size - 1;
@@ -910,6 +973,7 @@ long Evaluator_Relinearize(void* h, void* a, void* keys, void* dst, void* pool) 
   CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
   KeysObj* k = as<KeysObj>(keys, kMagicKeys);
   if (!e || !x || !d || !k) return HIPBFV_E_POINTER;
+  if (EvalObj* le = level_eval(e, x->ctx)) e = le;
   if (!same_context(x, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
   if (x->size == 2) {  // nothing to do: SEAL returns a copy
     if (d == x) return HIPBFV_S_OK;
@@ -924,12 +988,13 @@ long Evaluator_Relinearize(void* h, void* a, void* keys, void* dst, void* pool) 
   }
   // seal_fhe creates exactly one relinearization key (key_generator.rs:450-452): only size 3 -> 2
   if (x->size != 3) return fail(HIPBFV_E_INVALIDARG, "not enough relinearization keys");
-  if (k->ctx.get() != e->ctx.get() || !k->find(0)) return fail(HIPBFV_E_INVALIDARG, "relin_keys is not valid for encryption parameters");
+  const u64* rkey = level_key(k, e, 0);
+  if (!rkey) return fail(HIPBFV_E_INVALIDARG, "relin_keys is not valid for encryption parameters");
   hipStream_t s = thread_stream();
   const size_t words = e->ctx->ct_words(2);
   u64* buf = g_buffers.get(words);
   if (!buf) return from_status(kOutOfMemory);
-  int st = e->ev->relinearize(x->dev, k->find(0), buf, 1, s);
+  int st = e->ev->relinearize(x->dev, rkey, buf, 1, s);
   if (st) {
     g_buffers.put(buf, words);
     return from_status(st);
@@ -1024,6 +1089,7 @@ static long plain_op(void* h, void* a, void* plain, void* dst, int which) {
   CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
   PlainObj* p = as<PlainObj>(plain, kMagicPlain);
   if (!e || !x || !d || !p) return HIPBFV_E_POINTER;
+  if (EvalObj* le = level_eval(e, x->ctx)) e = le;
   if (!same_context(x, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
   u64* dplain = nullptr;
   size_t nonzero = 0, last = 0;
@@ -1064,7 +1130,7 @@ long Evaluator_MultiplyPlain(void* h, void* a, void* plain, void* dst, void* poo
 
 // one Galois automorphism + key switch on a handle (SEAL apply_galois_inplace)
 static long galois_handle(EvalObj* e, CipherObj* x, u32 elt, KeysObj* k, CipherObj* d) {
-  const u64* key = k->find((elt - 1) >> 1);
+  const u64* key = level_key(k, e, (elt - 1) >> 1);
   if (!key) return from_status(kNoKey);
   hipStream_t s = thread_stream();
   const size_t words = e->ctx->ct_words(2);
@@ -1108,10 +1174,11 @@ static long rotate_common(void* h, void* a, bool columns, int steps, void* keys,
   CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
   KeysObj* k = as<KeysObj>(keys, kMagicKeys);
   if (!e || !x || !d || !k) return HIPBFV_E_POINTER;
+  if (EvalObj* le = level_eval(e, x->ctx)) e = le;
   if (!same_context(x, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
   if (!e->ctx->batching()) return fail(HIPBFV_COR_E_INVALIDOPERATION, "encryption parameters do not support batching");
   if (x->size != 2) return fail(HIPBFV_E_INVALIDARG, "encrypted size must be 2");
-  if (k->ctx && k->ctx.get() != e->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "galois_keys is not valid for encryption parameters");
+  if (k->ctx && !in_chain(k->ctx, e->ctx.get())) return fail(HIPBFV_E_INVALIDARG, "galois_keys is not valid for encryption parameters");
   if (columns) return galois_handle(e, x, 2 * e->ctx->n() - 1, k, d);
   if (d != x) {  // work on a copy in the destination so that the NAF chain can run in place
     u64* buf = g_buffers.get(x->words);
@@ -1363,11 +1430,20 @@ long Ciphertext_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int6
   WireCiphertext ct;
   size_t used = 0;
   if (int rc = wire_unpack_ciphertext(inptr, size, &ct, &used)) return from_wire(rc);
-  uint8_t pid[32];
-  data_level_parms_id(*x->ctx, pid);
-  if (std::memcmp(pid, ct.parms_id, 32) != 0 || ct.is_ntt || ct.n != x->ctx->n() || ct.k != x->ctx->K() || ct.size < 2)
+  // the parms_id names the level of the modulus-switching chain the ciphertext lives at
+  std::shared_ptr<Context> lvl = x->ctx;
+  for (;;) {
+    uint8_t pid[32];
+    data_level_parms_id(*lvl, pid);
+    if (std::memcmp(pid, ct.parms_id, 32) == 0) break;
+    lvl = ct.k < lvl->K() ? lvl->next_level(nullptr) : nullptr;
+    if (!lvl) return fail(HIPBFV_E_INVALIDARG, "ciphertext data is invalid for the encryption parameters");
+  }
+  if (ct.is_ntt || ct.n != lvl->n() || ct.k != lvl->K() || ct.size < 2)
     return fail(HIPBFV_E_INVALIDARG, "ciphertext data is invalid for the encryption parameters");
-  long hr = hipbfv_Ciphertext_Assign(h, context, ct.size, reinterpret_cast<const uint64_t*>(ct.data.data()));
+  ContextObj level_handle;
+  level_handle.ctx = lvl;
+  long hr = hipbfv_Ciphertext_Assign(h, &level_handle, ct.size, reinterpret_cast<const uint64_t*>(ct.data.data()));
   if (hr != HIPBFV_S_OK) return hr;
   *in_bytes = (int64_t)used;
   return HIPBFV_S_OK;
@@ -1834,7 +1910,8 @@ long Decryptor_Create(void* context, void* secret_key, void** out) {
   if (!k->key || k->key->ctx.get() != x->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "secret key is not valid for encryption parameters");
   DecryptorObj* d = new DecryptorObj();
   d->ctx = x->ctx;
-  d->ev.reset(new Evaluator(x->ctx.get()));
+  d->core.ctx = x->ctx;
+  d->core.ev.reset(new Evaluator(x->ctx.get()));
   d->sk = k->key;
   *out = d;
   return HIPBFV_S_OK;
@@ -1850,15 +1927,16 @@ long Decryptor_Decrypt(void* h, void* encrypted, void* destination) {
   CipherObj* c = as<CipherObj>(encrypted, kMagicCipher);
   PlainObj* p = as<PlainObj>(destination, kMagicPlain);
   if (!d || !c || !p) return HIPBFV_E_POINTER;
-  if (!c->ctx || c->ctx.get() != d->ctx.get() || !c->dev || c->size < 2)
-    return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  EvalObj* le = c->ctx ? level_eval(&d->core, c->ctx) : nullptr;
+  if (!le || !c->dev || c->size < 2) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
   const size_t n = d->ctx->n();
   hipStream_t s = thread_stream();
   u64* dev = g_buffers.get(n);
   if (!dev) return from_status(kOutOfMemory);
   long hr = HIPBFV_S_OK;
   std::vector<u64> host(n);
-  if (int st = d->ev->decrypt(c->dev, c->size, d->sk->dev, dev, 1, s))
+  // the secret key's residues for a lower level are a prefix of its rows (the data primes come first)
+  if (int st = le->ev->decrypt(c->dev, c->size, d->sk->dev, dev, 1, s))
     hr = from_status(st);
   else if (hipMemcpyAsync(host.data(), dev, n * sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
     hr = from_status(kHipError);
@@ -1924,16 +2002,16 @@ long Decryptor_InvariantNoiseBudget(void* h, void* encrypted, int* budget) {
   DecryptorObj* d = as<DecryptorObj>(h, kMagicDecryptor);
   CipherObj* c = as<CipherObj>(encrypted, kMagicCipher);
   if (!d || !c || !budget) return HIPBFV_E_POINTER;
-  if (!c->ctx || c->ctx.get() != d->ctx.get() || !c->dev || c->size < 2)
-    return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
-  const Context& cx = *d->ctx;
+  EvalObj* le = c->ctx ? level_eval(&d->core, c->ctx) : nullptr;
+  if (!le || !c->dev || c->size < 2) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  const Context& cx = *le->ctx;
   const size_t n = cx.n(), K = cx.K();
   hipStream_t s = thread_stream();
   u64* dev = g_buffers.get(K * n);
   if (!dev) return from_status(kOutOfMemory);
   std::vector<u64> ph(K * n);
   long hr = HIPBFV_S_OK;
-  if (int st = d->ev->phase(c->dev, c->size, d->sk->dev, dev, 1, s))
+  if (int st = le->ev->phase(c->dev, c->size, d->sk->dev, dev, 1, s))
     hr = from_status(st);
   else if (hipMemcpyAsync(ph.data(), dev, ph.size() * sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
     hr = from_status(kHipError);
@@ -2111,6 +2189,59 @@ long hipbfv_batch_dot_plain_ntt(void* evaluator, const uint64_t* ctn, uint64_t c
   if (!ev || !ctn || !pntt || !out) return HIPBFV_E_POINTER;
   if (cols > 0xFFFFFFFFull || rows > 0xFFFFFFFFull) return fail(HIPBFV_E_INVALIDARG, "matrix too large");
   return from_status(ev->dot_plain_ntt((const u64*)ctn, (u32)cols, (const u64*)pntt, (u32)rows, (u64*)out, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------ modulus switching (evaluator_base.rs: mod_switch_to_next)
+long Evaluator_ModSwitchToNext1(void* h, void* encrypted, void* destination, void* pool) {
+  (void)pool;
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  CipherObj *x = as<CipherObj>(encrypted, kMagicCipher), *d = as<CipherObj>(destination, kMagicCipher);
+  if (!e || !x || !d) return HIPBFV_E_POINTER;
+  if (EvalObj* le = level_eval(e, x->ctx)) e = le;
+  if (!same_context(x, e)) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
+  std::string err;
+  std::shared_ptr<Context> next = e->ctx->next_level(&err);
+  if (!next) return fail(HIPBFV_E_INVALIDARG, err.empty() ? "end of modulus switching chain reached" : err.c_str());
+  hipStream_t s = thread_stream();
+  const size_t words = next->ct_words(x->size);
+  u64* buf = g_buffers.get(words);
+  if (!buf) return from_status(kOutOfMemory);
+  int st = e->ev->mod_switch_next(x->dev, x->size, buf, 1, s);
+  if (st) {
+    g_buffers.put(buf, words);
+    return from_status(st);
+  }
+  EvalObj* ne = level_eval(e, next);  // e may itself be a lower level: resolve from the level's own chain
+  if (!ne) {
+    g_buffers.put(buf, words);
+    return from_status(kHipError);
+  }
+  return finish_result(ne, d, x->size, buf, words, s, true);
+}
+
+long Evaluator_ModSwitchToNext2(void* h, void* plain, void* destination) {
+  // SEAL mod-switches only NTT-form plaintexts (CKKS / pre-transformed); BFV plaintexts of this path are never in NTT form
+  if (!as<EvalObj>(h, kMagicEval) || !as<PlainObj>(plain, kMagicPlain) || !as<PlainObj>(destination, kMagicPlain)) return HIPBFV_E_POINTER;
+  return fail(HIPBFV_E_INVALIDARG, "plain is not in NTT form");
+}
+
+long hipbfv_Context_NextLevel(void* context, void** next) {
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!x || !next) return HIPBFV_E_POINTER;
+  std::string err;
+  std::shared_ptr<Context> n = x->ctx->next_level(&err);
+  if (!n) return fail(HIPBFV_E_INVALIDARG, err.empty() ? "end of modulus switching chain reached" : err.c_str());
+  ContextObj* o = new ContextObj();
+  o->ctx = n;
+  *next = o;
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_batch_mod_switch(void* evaluator, const uint64_t* ct, uint64_t size, uint64_t* out, uint64_t count, void* stream) {
+  Evaluator* ev = eval_of(evaluator);
+  if (!ev || !ct || !out) return HIPBFV_E_POINTER;
+  if (size < 1) return fail(HIPBFV_E_INVALIDARG, "invalid ciphertext size");
+  return from_status(ev->mod_switch_next((const u64*)ct, (u32)size, (u64*)out, count, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -587,6 +587,18 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     }
   }
 
+  // ---- modulus switching to the next level: divide-and-round by the last data prime ----
+  if (K >= 2) {
+    const u64 ql = q[K - 1];
+    h.ms_half = ql >> 1;
+    for (u32 i = 0; i + 1 < K; i++) {
+      h.ms_half_mod_q[i] = h.ms_half % q[i];
+      u64 inv;
+      if (!invm(ql % q[i], q[i], &inv)) return fail("coefficient modulus primes are not distinct");
+      h.ms_inv_last_mod_q[i] = make_mulop(inv, q[i]);
+    }
+  }
+
   // ---- plaintext scaling ----
   {
     BigUint Qt = Q;
@@ -657,6 +669,23 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       return fail("hipMalloc failed");
   }
   return c.release();
+}
+
+std::shared_ptr<Context> Context::next_level(std::string* err) {
+  std::lock_guard<std::mutex> g(next_mu_);
+  if (next_) return next_;
+  if (host_.K < 2 || !chain_enabled_) {
+    if (err) *err = "end of modulus switching chain reached";
+    return nullptr;
+  }
+  std::vector<u64> primes(key_primes_.begin(), key_primes_.begin() + (host_.K - 1));
+  if (host_.KK > host_.K) primes.push_back(key_primes_.back());  // the special prime stays
+  Context* c = Context::create(host_.n, primes, host_.t, device_, err);
+  if (!c) return nullptr;
+  c->level_ = level_ + 1;
+  c->chain_enabled_ = chain_enabled_;
+  next_.reset(c);
+  return next_;
 }
 
 }  // namespace hipbfv

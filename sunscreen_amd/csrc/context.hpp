@@ -8,6 +8,8 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +40,15 @@ class Context {
   const DevCtx* dev() const { return dev_; }
   const std::vector<u64>& key_primes() const { return key_primes_; }
   bool batching() const { return batching_; }
+  // Modulus-switching chain (SEAL context_data->next_context_data()): the context of the next level drops the last
+  // data prime and keeps the special prime; created on first use; nullptr (and *err) at the end of the chain.
+  std::shared_ptr<Context> next_level(std::string* err);
+  std::shared_ptr<Context> peek_next() {  // the next level if it has been created already
+    std::lock_guard<std::mutex> g(next_mu_);
+    return next_;
+  }
+  int level() const { return level_; }
+  void set_chain_enabled(bool on) { chain_enabled_ = on; }  // SEALContext_Create(expand_mod_chain = false)  // 0 = the context the user created
   const u32* batch_index_map() const { return batch_map_; }  // device u32[n]: BatchEncoder matrix_reps_index_map
   size_t ct_words(size_t size) const { return size * (size_t)host_.K * host_.n; }
   size_t key_words() const { return (size_t)host_.K * 2 * host_.KK * host_.n; }
@@ -50,6 +61,10 @@ class Context {
   MulOp* tw_inv_ = nullptr;
   u32* batch_map_ = nullptr;
   int device_ = 0;
+  int level_ = 0;
+  bool chain_enabled_ = true;
+  std::mutex next_mu_;
+  std::shared_ptr<Context> next_;
   bool batching_ = false;
   std::vector<u64> key_primes_;
 };

@@ -127,6 +127,11 @@ struct DevCtx {
   MulOp neg_inv_q_mod_gamma;           // -(q^{-1}) mod gamma
   MulOp inv_gamma_mod_t;               // gamma^{-1} mod t
 
+  // ---- Evaluator_ModSwitchToNext: divide-and-round by the LAST DATA prime q_{K-1} (valid when K >= 2) ----
+  u64 ms_half;                         // q_{K-1} >> 1
+  u64 ms_half_mod_q[kMaxKey];          // (q_{K-1} >> 1) mod q_i, i < K-1
+  MulOp ms_inv_last_mod_q[kMaxKey];    // q_{K-1}^{-1} mod q_i, i < K-1
+
   // ---- plaintext lifting / scaling ----
   u64 q_div_t_mod_q[kMaxKey];          // floor(q/t) mod q_i
   u64 q_mod_t;                         // q mod t

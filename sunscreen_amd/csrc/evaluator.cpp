@@ -342,6 +342,19 @@ static int eltwise_chunks(Profiler& prof_, const DevCtx* dev, u32 n, u32 K, cons
   return kOk;
 }
 
+// out[op] (u64[count][size][K-1][N], the next level's layout) = mod_switch_to_next(ct[op]) : SEAL Evaluator::mod_switch_to_next
+// for BFV = divide-and-round every polynomial by the last data prime
+int Evaluator::mod_switch_next(const u64* ct, u32 size, u64* out, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.K < 2) return kInvalidArg;
+  const size_t polys = count * size;
+  for (size_t off = 0; off < polys; off += 65535) {
+    const size_t c = std::min<size_t>(65535, polys - off);
+    HB_CHECK(launch_mod_switch(ctx_->dev(), h.n, ct + off * (size_t)h.K * h.n, out + off * (size_t)(h.K - 1) * h.n, c, s));
+  }
+  return kOk;
+}
+
 int Evaluator::add(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s) {
   if (size < 2) return kInvalidArg;
   return eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 0, s);

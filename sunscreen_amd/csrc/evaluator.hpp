@@ -122,6 +122,7 @@ class Evaluator {
   int multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
   // out2 = (sigma_g(c0), 0) + switch_key(sigma_g(c1), key)
   int apply_galois(const u64* ct2, u32 galois_elt, const u64* key, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
+  int mod_switch_next(const u64* ct, u32 size, u64* out, size_t count, hipStream_t s);  // out has K-1 residues per polynomial
   int add(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s);
   int sub(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s);
   int negate(const u64* a, u64* out, u32 size, size_t count, hipStream_t s);

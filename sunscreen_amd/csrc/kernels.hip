@@ -668,6 +668,25 @@ __global__ __launch_bounds__(kCoefThreads) void ks_moddown_kernel(const DevCtx* 
   }
 }
 
+// ---- Evaluator_ModSwitchToNext (BFV): SEAL RNSTool::divide_and_round_q_last_inplace on every polynomial ----
+// in: u64[npoly][K][N] at this level; out: u64[npoly][K-1][N] at the next level
+__global__ __launch_bounds__(kCoefThreads) void mod_switch_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in, u64* __restrict__ out) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 poly = blockIdx.y;
+  if (k >= n) return;
+  const DevMod& ml = ctx->mod[K - 1];
+  const u64* x = in + (size_t)poly * K * n;
+  const u64 tl = add_mod(x[(size_t)(K - 1) * n + k], ctx->ms_half, ml.q);
+  for (u32 i = 0; i + 1 < K; i++) {
+    const DevMod& mi = ctx->mod[i];
+    u64 tk = ml.q > mi.q ? reduce64(tl, mi) : tl;
+    tk = sub_mod(tk, ctx->ms_half_mod_q[i], mi.q);
+    const u64 d = sub_mod(x[(size_t)i * n + k], tk, mi.q);
+    out[((size_t)poly * (K - 1) + i) * n + k] = mul_shoup(d, ctx->ms_inv_last_mod_q[i], mi.q);
+  }
+}
+
 // ---- Galois automorphism x -> x^g in coefficient form (gather form) ----
 // in/out: u64[npoly][K][N]; ginv = g^{-1} mod 2N
 __global__ __launch_bounds__(kCoefThreads) void galois_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in, u64* __restrict__ out, u32 ginv) {
@@ -855,6 +874,11 @@ hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u
 hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out,
                              size_t ops, hipStream_t s) {
   ks_moddown_kernel<<<coef_grid(n, 2, (u32)ops), kCoefThreads, 0, s>>>(ctx, ACC, base, bstride, base_mask, extra, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_mod_switch(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t polys, hipStream_t s) {
+  mod_switch_kernel<<<coef_grid(n, (u32)polys), kCoefThreads, 0, s>>>(ctx, in, out);
   return hipGetLastError();
 }
 

@@ -246,6 +246,15 @@ class Context:
     def get_handle(self):
         return self._h
 
+    def next_level(self) -> "Context":
+        """The next level of the modulus-switching chain (one data prime fewer, same special prime): where
+        mod_switch_to_next puts its result.  hipbfv extension for the batched API."""
+        c = Context.__new__(Context)
+        c._h = C.c_void_p()
+        _check(_lib.load().hipbfv_Context_NextLevel(self._h, C.byref(c._h)))
+        c._query()
+        return c
+
     def __del__(self):
         if getattr(self, "_h", None):
             _lib.load().SEALContext_Destroy(self._h)
@@ -568,6 +577,20 @@ class BFVEvaluator:
 
     def multiply_plain_inplace(self, a: Ciphertext, b: Plaintext) -> None:
         _check(_lib.load().Evaluator_MultiplyPlain(self._h, a._h, b._h, a._h, None))
+
+    # -- modulus switching (evaluator.rs:84-157)
+    def mod_switch_to_next(self, a: Ciphertext) -> Ciphertext:
+        out = Ciphertext()
+        _check(_lib.load().Evaluator_ModSwitchToNext1(self._h, a._h, out._h, None))
+        return out
+
+    def mod_switch_to_next_inplace(self, a: Ciphertext) -> None:
+        _check(_lib.load().Evaluator_ModSwitchToNext1(self._h, a._h, a._h, None))
+
+    def mod_switch_to_next_plaintext(self, p: "Plaintext") -> "Plaintext":
+        out = Plaintext()
+        _check(_lib.load().Evaluator_ModSwitchToNext2(self._h, p.get_handle(), out.get_handle()))
+        return out
 
     # -- key switching (bfv_evaluator.rs:143-247)
     def relinearize_inplace(self, a: Ciphertext, relin_keys: RelinearizationKeys) -> None:

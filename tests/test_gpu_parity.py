@@ -458,3 +458,90 @@ def test_largest_degree_n32768_two_kernel_ntt():
     assert (o.batch_decode(o.decrypt(r[0], sk)) == (va * vb) % t).all()
     g = to_host(ev.rotate_rows(to_device(a), 1, GaloisKeys.from_arrays(ctx, gk)))
     assert (g[0] == o.rotate_rows(a[0], 1, gk)).all()
+
+
+def test_modulus_switching_chain():
+    """Evaluator_ModSwitchToNext (seal_fhe/src/evaluator.rs:84-157): ciphertexts move down the chain, and every
+    operation, the Decryptor and the wire format accept them at their level.  Bit-exact against the oracle level by
+    level (the oracle's lower level is simply an Oracle over the shortened prime list)."""
+    from sunscreen_amd import (BFVEvaluator, Ciphertext, Context, Decryptor, GaloisKeys, HipBfvError, Plaintext, RelinearizationKeys,
+                               SecretKey)
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    n = 8192
+    primes, t = O.bfv_default(n), O.plain_batching(n, 17)
+    o0 = O.Oracle(n, primes, t)
+    O.seed(61)
+    elt = o0.galois_elt_from_step(3)
+    sk, pk, rk, gk = o0.keygen(galois_elts=[elt, 2 * n - 1])
+    ctx = Context.from_raw(n, primes, t)
+    be = BFVEvaluator(ctx)
+    rkd, gkd = RelinearizationKeys.from_array(ctx, rk), GaloisKeys.from_arrays(ctx, gk)
+    dec = Decryptor(ctx, SecretKey.from_array(ctx, sk))
+    rng = np.random.default_rng(2)
+    va, vb = rng.integers(0, 40, n).astype(np.uint64), rng.integers(0, 40, n).astype(np.uint64)
+    a0, b0 = o0.encrypt(pk, o0.batch_encode(va)), o0.encrypt(pk, o0.batch_encode(vb))
+    ha, hb = Ciphertext.from_array(ctx, a0), Ciphertext.from_array(ctx, b0)
+
+    def lower(o, keys, galois):  # oracle-side view of the next level: drop the last data prime everywhere
+        o2 = o.next_level()
+        rows = list(range(o2.K)) + [o.KK - 1]
+        k2 = np.ascontiguousarray(keys[: o2.K][:, :, rows, :])
+        g2 = {e: np.ascontiguousarray(g[: o2.K][:, :, rows, :]) for e, g in galois.items()}
+        return o2, k2, g2
+
+    o, cur_rk, cur_gk, cur_sk = o0, rk, gk, sk
+    ra, rb = a0, b0
+    for level in range(1, 4):  # K = 4 -> 3 -> 2 -> 1
+        ha, hb = be.mod_switch_to_next(ha), be.mod_switch_to_next(hb)
+        ra, rb = o.mod_switch_to_next(ra), o.mod_switch_to_next(rb)
+        o2, cur_rk, cur_gk = lower(o, cur_rk, cur_gk)
+        cur_sk = np.concatenate([cur_sk[: o2.K], cur_sk[o.K :]])
+        o = o2
+        assert ha.coeff_modulus_size() == o.K and (ha.to_array() == ra).all() and (hb.to_array() == rb).all(), level
+        # every operation at this level, against the oracle of this level
+        prod = be.multiply(ha, hb)
+        assert (prod.to_array() == o.multiply(ra, rb)).all(), level
+        rel = be.relinearize(prod, rkd)
+        assert (rel.to_array() == o.relinearize(o.multiply(ra, rb), cur_rk)).all(), level
+        assert (be.add(ha, hb).to_array() == o.add(ra, rb)).all()
+        assert (be.rotate_rows(ha, 3, gkd).to_array() == o.rotate_rows(ra, 3, cur_gk)).all(), level
+        assert (be.rotate_columns(ha, gkd).to_array() == o.rotate_columns(ra, cur_gk)).all(), level
+        pl = o.batch_encode(vb)
+        assert (be.multiply_plain(ha, Plaintext.from_coefficients([int(x) for x in pl])).to_array() == o.multiply_plain(ra, pl)).all()
+        # decryption and the noise budget at this level
+        got = dec.decrypt(rel)
+        coeffs = np.array([got.get_coefficient(k) for k in range(got.len())] + [0] * (n - got.len()), dtype=np.uint64)
+        ref_rel = o.relinearize(o.multiply(ra, rb), cur_rk)
+        assert (coeffs == o.decrypt(ref_rel, cur_sk)).all(), level
+        if o.noise_budget(ref_rel, cur_sk) > 0:  # the single 43-bit prime of the last level cannot hold a product
+            assert (o.batch_decode(coeffs) == (va * vb) % t).all(), level
+        assert dec.invariant_noise_budget(ha) == o.noise_budget(ra, cur_sk), level
+        # wire format: the parms_id names the level
+        back = Ciphertext.from_bytes(ctx, ha.as_bytes())
+        assert back.coeff_modulus_size() == o.K and (back.to_array() == ra).all()
+        with pytest.raises(HipBfvError):  # operands of different levels do not mix
+            be.add(ha, Ciphertext.from_array(ctx, a0))
+    with pytest.raises(HipBfvError) as ei:  # end of the chain
+        be.mod_switch_to_next(ha)
+    assert ei.value.kind == "InvalidArgument"
+    with pytest.raises(HipBfvError):  # BFV plaintexts are not in NTT form
+        be.mod_switch_to_next_plaintext(Plaintext.from_coefficients([1]))
+    # batched form: level contexts for the device-pointer API
+    ctx1 = ctx.next_level()
+    assert ctx1.K == 3 and ctx1.key_primes == primes[:3] + primes[-1:]
+    ev0, ev1 = BatchEvaluator(ctx), BatchEvaluator(ctx1)
+    batch = np.stack([a0, b0])
+    sw = ev0.mod_switch(to_device(batch))
+    assert (to_host(sw)[0] == o0.mod_switch_to_next(a0)).all()
+    o1, rk1, _ = lower(o0, rk, gk)
+    r1 = to_host(ev1.multiply_relin(sw[:1].contiguous(), sw[1:].contiguous(), RelinearizationKeys.from_array(ctx1, rk1)))
+    assert (r1[0] == o1.relinearize(o1.multiply(o0.mod_switch_to_next(a0), o0.mod_switch_to_next(b0)), rk1)).all()
+    # a context created without the chain refuses
+    from sunscreen_amd import BfvEncryptionParametersBuilder, CoefficientModulus, PlainModulus
+
+    params = (BfvEncryptionParametersBuilder().set_poly_modulus_degree(n).set_coefficient_modulus(CoefficientModulus.bfv_default(n))
+              .set_plain_modulus(PlainModulus.batching(n, 17)).build())
+    flat = Context(params, expand_mod_chain=False)
+    with pytest.raises(HipBfvError):
+        BFVEvaluator(flat).mod_switch_to_next(Ciphertext.from_array(flat, a0))
