@@ -108,7 +108,7 @@ long KSwitchKeys_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t com
 long KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 
 /* ---- SecretKey / PublicKey (seal_fhe/src/key_generator.rs:200-430): handles + SEAL 4.0 wire format.
- * Keys are produced by the client (KeyGenerator is not part of this library); data is key-level NTT form:
+ * Key data is key-level NTT form:
  * SecretKey u64[K+1][N], PublicKey u64[2][K+1][N]. ---- */
 long SecretKey_Create1(void **key);
 long SecretKey_Create2(void *copy, void **key);
@@ -122,6 +122,19 @@ long PublicKey_Destroy(void *thisptr);
 long PublicKey_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
 long PublicKey_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
 long PublicKey_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+
+/* ---- KeyGenerator (seal_fhe/src/key_generator.rs:20-200): keys are sampled and assembled on the device (Philox4x32-10;
+ * ternary secret, uniform a, rounded Gaussian errors; key-switching keys in SEAL's layout u64[K][2][K+1][N]).  Like
+ * SEAL's, the keys are not reproducible across implementations; they interoperate through the wire format.
+ * save_seed (seed-compressed serialisation) is accepted and ignored: handles always hold expanded keys. ---- */
+long KeyGenerator_Create1(void *context, void **key_generator);
+long KeyGenerator_Create2(void *context, void *secret_key, void **key_generator);
+long KeyGenerator_Destroy(void *thisptr);
+long KeyGenerator_SecretKey(void *thisptr, void **secret_key);
+long KeyGenerator_CreatePublicKey(void *thisptr, bool save_seed, void **public_key);
+long KeyGenerator_CreateRelinKeys(void *thisptr, bool save_seed, void **relin_keys);
+long KeyGenerator_CreateGaloisKeysFromElts(void *thisptr, uint64_t count, uint32_t *galois_elts, bool save_seed, void **galois_keys);
+long KeyGenerator_CreateGaloisKeysAll(void *thisptr, bool save_seed, void **galois_keys);
 
 /* ---- BatchEncoder (seal_fhe/src/encoder.rs:50-215): slot vectors <-> plaintexts, transforms over Z_t on the device ---- */
 long BatchEncoder_Create(void *context, void **encoder);
@@ -203,9 +216,15 @@ long hipbfv_Ciphertext_DevicePtr(void *cipher, uint64_t **device_ptr);
 long hipbfv_KSwitchKeys_AssignRelin(void *keys, void *context, const uint64_t *host_data);
 long hipbfv_KSwitchKeys_AssignGalois(void *keys, void *context, uint32_t galois_elt, const uint64_t *host_data);
 long hipbfv_KSwitchKeys_DevicePtr(void *keys, uint64_t index, uint64_t **device_ptr); /* index 0 = relin, (elt-1)/2 = galois */
+long hipbfv_KSwitchKeys_Read(void *keys, uint64_t index, uint64_t *host_out);          /* u64[K][2][K+1][N] */
+long hipbfv_KSwitchKeys_Has(void *keys, uint64_t index, bool *present);
+long hipbfv_SecretKey_Read(void *key, uint64_t *host_out);                              /* u64[K+1][N] */
+long hipbfv_PublicKey_Read(void *key, uint64_t *host_out);                              /* u64[2][K+1][N] */
 long hipbfv_SecretKey_Assign(void *key, void *context, const uint64_t *host_data);  /* u64[K+1][N], NTT form */
 long hipbfv_PublicKey_Assign(void *key, void *context, const uint64_t *host_data);  /* u64[2][K+1][N], NTT form */
 long hipbfv_Encryptor_SetSeed(void *encryptor, uint64_t seed);                      /* reproducible runs (tests) */
+long hipbfv_KeyGenerator_SetSeed(void *key_generator, uint64_t seed);               /* keys created afterwards */
+long hipbfv_KeyGenerator_CreateSeeded(void *context, uint64_t seed, void **key_generator); /* reproducible secret */
 
 /* Host-only helpers of the SEAL 4.0 wire format (no device access; used by the CPU tests against the
  * reference's binary fixtures): parms_id = BLAKE2b-256([scheme=1, n, primes..., t]); decode/encode one object. */

@@ -18,6 +18,7 @@ from .seal import (  # noqa: F401
     Encryptor,
     GaloisKeys,
     HipBfvError,
+    KeyGenerator,
     Modulus,
     PlainModulus,
     Plaintext,

@@ -144,6 +144,14 @@ _SIGNATURES = {
     "PublicKey_Create1": [vpp], "PublicKey_Create2": [vp, vpp], "PublicKey_Destroy": [vp],
     "PublicKey_SaveSize": [vp, C.c_uint8, i64p], "PublicKey_Save": [vp, C.c_char_p, u64, C.c_uint8, i64p],
     "PublicKey_Load": [vp, vp, C.c_char_p, u64, i64p],
+    "hipbfv_KSwitchKeys_Read": [vp, u64, u64p], "hipbfv_KSwitchKeys_Has": [vp, u64, C.POINTER(C.c_bool)],
+    "hipbfv_SecretKey_Read": [vp, u64p], "hipbfv_PublicKey_Read": [vp, u64p],
+    "KeyGenerator_Create1": [vp, vpp], "KeyGenerator_Create2": [vp, vp, vpp], "KeyGenerator_Destroy": [vp],
+    "KeyGenerator_SecretKey": [vp, vpp], "KeyGenerator_CreatePublicKey": [vp, C.c_bool, vpp],
+    "KeyGenerator_CreateRelinKeys": [vp, C.c_bool, vpp],
+    "KeyGenerator_CreateGaloisKeysFromElts": [vp, u64, C.POINTER(C.c_uint32), C.c_bool, vpp],
+    "KeyGenerator_CreateGaloisKeysAll": [vp, C.c_bool, vpp],
+    "hipbfv_KeyGenerator_SetSeed": [vp, u64], "hipbfv_KeyGenerator_CreateSeeded": [vp, u64, vpp],
     "BatchEncoder_Create": [vp, vpp], "BatchEncoder_Destroy": [vp],
     "BatchEncoder_Encode1": [vp, u64, u64p, vp], "BatchEncoder_Encode2": [vp, u64, C.POINTER(C.c_int64), vp],
     "BatchEncoder_Decode1": [vp, vp, u64p, u64p, vp], "BatchEncoder_Decode2": [vp, vp, u64p, C.POINTER(C.c_int64), vp],

@@ -63,6 +63,7 @@ enum Magic : uint32_t {
   kMagicEncoder = 0x42454E31,
   kMagicDecryptor = 0x44454331,
   kMagicEncryptor = 0x454E4331,
+  kMagicKeyGen = 0x4B47454E,
 };
 
 struct Obj {
@@ -240,6 +241,17 @@ struct EncryptorObj : Obj {
   std::mutex mu;
   u64 next_op = 0;  // Philox counter: every encryption of one Encryptor uses fresh randomness
   EncryptorObj() : Obj(kMagicEncryptor) {}
+};
+
+struct KeyGenObj : Obj {
+  std::shared_ptr<Context> ctx;
+  std::unique_ptr<Evaluator> ev;
+  std::shared_ptr<KeyBuffer> sk;        // NTT form, what SecretKey handles share
+  std::shared_ptr<KeyBuffer> sk_coeff;  // the ternary polynomial in coefficient form (Galois keys permute it)
+  u64 seed = 0;
+  std::mutex mu;
+  u64 next_stream = 1;  // every generated key draws from its own Philox stream
+  KeyGenObj() : Obj(kMagicKeyGen) {}
 };
 
 struct ProgramObj : Obj {
@@ -1741,6 +1753,30 @@ long PublicKey_Destroy(void* h) { return asym_destroy(kMagicPublicKey, h); }
 long hipbfv_SecretKey_Assign(void* h, void* context, const uint64_t* host_data) { return asym_assign(kMagicSecretKey, h, context, host_data, 1); }
 long hipbfv_PublicKey_Assign(void* h, void* context, const uint64_t* host_data) { return asym_assign(kMagicPublicKey, h, context, host_data, 2); }
 
+static long asym_read(Magic m, void* h, uint64_t* host_out) {
+  AsymKeyObj* k = as<AsymKeyObj>(h, m);
+  if (!k || !host_out) return HIPBFV_E_POINTER;
+  if (!k->key || !k->key->dev) return fail(HIPBFV_E_INVALIDARG, "key is empty");
+  if (hipMemcpy(host_out, k->key->dev, k->key->words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return from_status(kHipError);
+  return HIPBFV_S_OK;
+}
+long hipbfv_SecretKey_Read(void* h, uint64_t* host_out) { return asym_read(kMagicSecretKey, h, host_out); }
+long hipbfv_PublicKey_Read(void* h, uint64_t* host_out) { return asym_read(kMagicPublicKey, h, host_out); }
+long hipbfv_KSwitchKeys_Read(void* h, uint64_t index, uint64_t* host_out) {
+  KeysObj* k = as<KeysObj>(h, kMagicKeys);
+  if (!k || !host_out) return HIPBFV_E_POINTER;
+  const u64* dev = k->find((u32)index);
+  if (!dev) return fail(HIPBFV_E_INVALIDARG, "key not present");
+  if (hipMemcpy(host_out, dev, k->ctx->key_words() * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return from_status(kHipError);
+  return HIPBFV_S_OK;
+}
+long hipbfv_KSwitchKeys_Has(void* h, uint64_t index, bool* present) {
+  KeysObj* k = as<KeysObj>(h, kMagicKeys);
+  if (!k || !present) return HIPBFV_E_POINTER;
+  *present = k->find((u32)index) != nullptr;
+  return HIPBFV_S_OK;
+}
+
 // SecretKey is serialised as a Plaintext whose parms_id is the key level's (seal_fhe/tests/data/secret_key.bin)
 long SecretKey_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
   AsymKeyObj* k = as<AsymKeyObj>(h, kMagicSecretKey);
@@ -2242,6 +2278,166 @@ long hipbfv_batch_mod_switch(void* evaluator, const uint64_t* ct, uint64_t size,
   if (!ev || !ct || !out) return HIPBFV_E_POINTER;
   if (size < 1) return fail(HIPBFV_E_INVALIDARG, "invalid ciphertext size");
   return from_status(ev->mod_switch_next((const u64*)ct, (u32)size, (u64*)out, count, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------ KeyGenerator (seal_fhe/src/key_generator.rs:20-200)
+static u64 os_seed(const void* salt) {
+  FILE* f = std::fopen("/dev/urandom", "rb");
+  u64 sd = 0;
+  if (!f || std::fread(&sd, sizeof(sd), 1, f) != 1) sd = (u64)(uintptr_t)salt ^ 0x9E3779B97F4A7C15ull;
+  if (f) std::fclose(f);
+  return sd;
+}
+static std::shared_ptr<KeyBuffer> new_key_buffer(const std::shared_ptr<Context>& ctx, size_t words) {
+  auto b = std::make_shared<KeyBuffer>();
+  b->ctx = ctx;
+  b->words = words;
+  b->dev = g_buffers.get(words);
+  return b->dev ? b : nullptr;
+}
+static long keygen_new(void* context, AsymKeyObj* existing, void** out, const u64* fixed_seed = nullptr) {
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!x || !out) return HIPBFV_E_POINTER;
+  if (existing && (!existing->key || existing->key->ctx.get() != x->ctx.get()))
+    return fail(HIPBFV_E_INVALIDARG, "secret key is not valid for encryption parameters");
+  std::unique_ptr<KeyGenObj> g(new KeyGenObj());
+  g->ctx = x->ctx;
+  g->ev.reset(new Evaluator(x->ctx.get()));
+  g->seed = fixed_seed ? *fixed_seed : os_seed(g.get());
+  const size_t words = (size_t)x->ctx->KK() * x->ctx->n();
+  g->sk_coeff = new_key_buffer(x->ctx, words);
+  if (!g->sk_coeff) return from_status(kOutOfMemory);
+  hipStream_t s = thread_stream();
+  int st;
+  if (existing) {  // recover the ternary polynomial: the inverse transform of every residue row
+    g->sk = existing->key;
+    st = hipMemcpyAsync(g->sk_coeff->dev, g->sk->dev, words * sizeof(u64), hipMemcpyDeviceToDevice, s) == hipSuccess ? kOk : kHipError;
+    if (st == kOk) st = g->ev->ntt(g->sk_coeff->dev, x->ctx->KK(), x->ctx->KK(), true, s);
+  } else {
+    g->sk = new_key_buffer(x->ctx, words);
+    if (!g->sk) return from_status(kOutOfMemory);
+    st = g->ev->keygen_secret(g->seed, g->sk_coeff->dev, g->sk->dev, s);
+  }
+  if (st) return from_status(st);
+  if (long hr = sync_stream(s)) return hr;
+  *out = g.release();
+  return HIPBFV_S_OK;
+}
+long KeyGenerator_Create1(void* context, void** out) { return keygen_new(context, nullptr, out); }
+long hipbfv_KeyGenerator_CreateSeeded(void* context, uint64_t seed, void** out) { const u64 sd = seed; return keygen_new(context, nullptr, out, &sd); }
+long KeyGenerator_Create2(void* context, void* secret_key, void** out) {
+  AsymKeyObj* k = as<AsymKeyObj>(secret_key, kMagicSecretKey);
+  if (!k) return HIPBFV_E_POINTER;
+  return keygen_new(context, k, out);
+}
+long KeyGenerator_Destroy(void* h) {
+  KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
+  if (!g) return HIPBFV_E_POINTER;
+  delete g;
+  return HIPBFV_S_OK;
+}
+long hipbfv_KeyGenerator_SetSeed(void* h, uint64_t seed) {  // reproducible keys for tests; affects keys created afterwards
+  KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
+  if (!g) return HIPBFV_E_POINTER;
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->seed = seed;
+  g->next_stream = 1;
+  return HIPBFV_S_OK;
+}
+long KeyGenerator_SecretKey(void* h, void** secret_key) {
+  KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
+  if (!g || !secret_key) return HIPBFV_E_POINTER;
+  AsymKeyObj* k = new AsymKeyObj(kMagicSecretKey);
+  k->key = g->sk;
+  *secret_key = k;
+  return HIPBFV_S_OK;
+}
+static u64 take_stream(KeyGenObj* g, u64* seed) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  *seed = g->seed;
+  return g->next_stream++;
+}
+long KeyGenerator_CreatePublicKey(void* h, bool save_seed, void** public_key) {
+  (void)save_seed;  // seed-compressed keys are a serialisation option; the handle always holds the expanded key
+  KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
+  if (!g || !public_key) return HIPBFV_E_POINTER;
+  auto buf = new_key_buffer(g->ctx, (size_t)2 * g->ctx->KK() * g->ctx->n());
+  if (!buf) return from_status(kOutOfMemory);
+  hipStream_t s = thread_stream();
+  u64 seed;
+  const u64 stream = take_stream(g, &seed);
+  if (int st = g->ev->keygen_zero_encryptions(seed, stream, g->sk->dev, nullptr, buf->dev, 1, s)) return from_status(st);
+  if (long hr = sync_stream(s)) return hr;
+  AsymKeyObj* k = new AsymKeyObj(kMagicPublicKey);
+  k->key = buf;
+  *public_key = k;
+  return HIPBFV_S_OK;
+}
+static long keygen_kswitch_into(KeyGenObj* g, KeysObj* keys, u32 galois_elt) {
+  const size_t words = g->ctx->key_words();
+  u64* buf = g_buffers.get(words);
+  if (!buf) return from_status(kOutOfMemory);
+  hipStream_t s = thread_stream();
+  u64 seed;
+  const u64 stream = take_stream(g, &seed);
+  int st = g->ev->keygen_kswitch(seed, stream, g->sk_coeff->dev, g->sk->dev, galois_elt, buf, s);
+  long hr = st ? from_status(st) : sync_stream(s);
+  if (hr != HIPBFV_S_OK) {
+    g_buffers.put(buf, words);
+    return hr;
+  }
+  const u32 index = galois_elt ? (galois_elt - 1) >> 1 : 0;
+  auto it = keys->keys.find(index);
+  if (it != keys->keys.end()) g_buffers.put(it->second, words);
+  keys->keys[index] = buf;
+  return HIPBFV_S_OK;
+}
+long KeyGenerator_CreateRelinKeys(void* h, bool save_seed, void** relin_keys) {
+  (void)save_seed;
+  KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
+  if (!g || !relin_keys) return HIPBFV_E_POINTER;
+  if (g->ctx->KK() < 2) return fail(HIPBFV_COR_E_INVALIDOPERATION, "keyswitching is not supported by the context");
+  std::unique_ptr<KeysObj> k(new KeysObj());
+  k->ctx = g->ctx;
+  if (long hr = keygen_kswitch_into(g, k.get(), 0)) return hr;
+  *relin_keys = k.release();
+  return HIPBFV_S_OK;
+}
+long KeyGenerator_CreateGaloisKeysFromElts(void* h, uint64_t count, uint32_t* galois_elts, bool save_seed, void** galois_keys) {
+  (void)save_seed;
+  KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
+  if (!g || !galois_keys || (count && !galois_elts)) return HIPBFV_E_POINTER;
+  if (g->ctx->KK() < 2) return fail(HIPBFV_COR_E_INVALIDOPERATION, "keyswitching is not supported by the context");
+  if (!g->ctx->batching()) return fail(HIPBFV_COR_E_INVALIDOPERATION, "encryption parameters do not support batching");
+  std::unique_ptr<KeysObj> k(new KeysObj());
+  k->ctx = g->ctx;
+  for (uint64_t i = 0; i < count; i++) {
+    const u32 elt = galois_elts[i];
+    if (!(elt & 1) || elt >= 2 * g->ctx->n()) return fail(HIPBFV_E_INVALIDARG, "Galois element is not valid");
+    if (long hr = keygen_kswitch_into(g, k.get(), elt)) return hr;
+  }
+  *galois_keys = k.release();
+  return HIPBFV_S_OK;
+}
+// SEAL GaloisTool::get_elts_all: the column rotation 2N-1 and 3^(+-2^i) for every power-of-two row rotation
+long KeyGenerator_CreateGaloisKeysAll(void* h, bool save_seed, void** galois_keys) {
+  KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
+  if (!g || !galois_keys) return HIPBFV_E_POINTER;
+  const u64 m = 2 * (u64)g->ctx->n();
+  int logn = 0;
+  while ((1u << logn) < g->ctx->n()) logn++;
+  std::vector<uint32_t> elts;
+  elts.push_back((uint32_t)(m - 1));
+  u64 pos = 3, neg = 1;
+  for (int i = 0; i < 6; i++) neg = neg * (2 - 3 * neg);
+  neg &= m - 1;
+  for (int i = 0; i < logn - 1; i++) {
+    elts.push_back((uint32_t)pos);
+    pos = (pos * pos) & (m - 1);
+    elts.push_back((uint32_t)neg);
+    neg = (neg * neg) & (m - 1);
+  }
+  return KeyGenerator_CreateGaloisKeysFromElts(h, elts.size(), elts.data(), save_seed, galois_keys);
 }
 
 }  // extern "C"

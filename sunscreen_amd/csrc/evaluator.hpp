@@ -139,6 +139,9 @@ class Evaluator {
   int batch_encode(const u64* values, u64* plain, size_t count, bool is_signed, u32* bad_host, hipStream_t s);
   int batch_decode(const u64* plain, u64* values, size_t count, bool is_signed, hipStream_t s);
   int decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, size_t count, hipStream_t s);
+  int keygen_secret(u64 seed, u64* sk_coeff, u64* sk_ntt, hipStream_t s);
+  int keygen_zero_encryptions(u64 seed, u64 stream, const u64* sk_ntt, const u64* w, u64* key, u32 count, hipStream_t s);
+  int keygen_kswitch(u64 seed, u64 stream, const u64* sk_coeff, const u64* sk_ntt, u32 galois_elt, u64* key, hipStream_t s);
   int plain_to_ntt(const u64* plain, size_t pstride, u64* pntt, size_t count, hipStream_t s);
   int ct_to_ntt(const u64* ct, u32 size, u64* ctn, size_t count, hipStream_t s);
   int dot_plain_ntt(const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* out, hipStream_t s);

@@ -106,6 +106,54 @@ int Evaluator::decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, s
   return kOk;
 }
 
+// ---- KeyGenerator (seal_fhe/src/key_generator.rs:20-200; SEAL keygenerator.cpp) ----
+// sk_coeff / sk_ntt: u64[KK][N] -- the ternary secret in coefficient form (kept for the Galois keys) and its transform
+int Evaluator::keygen_secret(u64 seed, u64* sk_coeff, u64* sk_ntt, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.logn > 15) return kUnsupported;
+  HC_CHECK(launch_keygen_ternary(ctx_->dev(), h.n, seed, 0, sk_coeff, s));
+  HC_CHECK(hipMemcpyAsync(sk_ntt, sk_coeff, (size_t)h.KK * h.n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  HC_CHECK(launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, sk_ntt, h.KK, range_plan(h.KK), false, 0, s));
+  return kOk;
+}
+
+// `count` key-level encryptions of zero under sk_ntt, the z-th one carrying w (.) (q_sp mod q_z) on residue z when w is
+// given: count = 1, w = nullptr -> public key u64[2][KK][N]; count = K, w = s^2 or sigma_g(s) (NTT form) -> one
+// key-switching key u64[K][2][KK][N].  `stream` keys the randomness (distinct per key).
+int Evaluator::keygen_zero_encryptions(u64 seed, u64 stream, const u64* sk_ntt, const u64* w, u64* key, u32 count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.logn > 15) return kUnsupported;
+  const u32 n = h.n, KK = h.KK;
+  ScratchGuard sg(pool_, (size_t)count * 2 * KK * n * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* a = (u64*)sg.p;
+  u64* e = a + (size_t)count * KK * n;
+  HC_CHECK(launch_keygen_sample(ctx_->dev(), n, seed, stream << 8, a, e, count, s));
+  HC_CHECK(launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, e, (size_t)count * KK, range_plan(KK), false, 0, s));
+  HC_CHECK(launch_keygen_assemble(ctx_->dev(), n, KK, a, e, sk_ntt, w, key, count, s));
+  return kOk;
+}
+
+// relin: w = s^2; galois element g: w = NTT(sigma_g(s)).  key: u64[K][2][KK][N]
+int Evaluator::keygen_kswitch(u64 seed, u64 stream, const u64* sk_coeff, const u64* sk_ntt, u32 galois_elt, u64* key, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.KK < 2) return kNoKey;  // no special prime: SEAL refuses to create key-switching keys
+  const u32 n = h.n, KK = h.KK;
+  ScratchGuard sg(pool_, (size_t)KK * n * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* w = (u64*)sg.p;
+  if (galois_elt == 0) {
+    HC_CHECK(launch_keygen_square(ctx_->dev(), n, KK, sk_ntt, w, s));
+  } else {
+    if (!(galois_elt & 1) || galois_elt >= 2 * n) return kInvalidArg;
+    u64 inv = 1;
+    for (int i = 0; i < 6; i++) inv = inv * (2 - (u64)galois_elt * inv);
+    HC_CHECK(launch_keygen_galois(ctx_->dev(), n, KK, sk_coeff, w, (u32)(inv & (2 * n - 1)), s));
+    HC_CHECK(launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, w, KK, range_plan(KK), false, 0, s));
+  }
+  return keygen_zero_encryptions(seed, stream, sk_ntt, w, key, h.K, s);
+}
+
 // ---- plaintext-matrix x ciphertext-vector products (the first loop nest of examples/pir/src/main.rs:16-45) ----
 // pntt[op][K][N] = NTT(centred lift of plain[op]) -- what SEAL's multiply_plain computes internally for its plaintext
 // operand (including the monomial rule, kernels.hip plain_lift_kernel).  A static database is transformed once.

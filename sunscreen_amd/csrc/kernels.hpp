@@ -55,6 +55,12 @@ hipError_t launch_dot_secret(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u3
 hipError_t launch_decrypt_round(const DevCtx* ctx, u32 n, const u64* ct, u32 size, const u64* acc, u64* plain, size_t ops, hipStream_t s);
 hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, u64 seed, u64 op0, u64* u, u64* e, size_t ops, hipStream_t s);
 hipError_t launch_encrypt_dyadic(const DevCtx* ctx, u32 n, u32 KK, const u64* un, const u64* pk, u64* c, size_t ops, hipStream_t s);
+hipError_t launch_keygen_ternary(const DevCtx* ctx, u32 n, u64 seed, u64 stream, u64* s_out, hipStream_t s);
+hipError_t launch_keygen_sample(const DevCtx* ctx, u32 n, u64 seed, u64 stream0, u64* a, u64* e, size_t count, hipStream_t s);
+hipError_t launch_keygen_assemble(const DevCtx* ctx, u32 n, u32 KK, const u64* a, const u64* e, const u64* sk, const u64* w, u64* key, size_t count,
+                                  hipStream_t s);
+hipError_t launch_keygen_square(const DevCtx* ctx, u32 n, u32 KK, const u64* in, u64* out, hipStream_t s);
+hipError_t launch_keygen_galois(const DevCtx* ctx, u32 n, u32 KK, const u64* in, u64* out, u32 ginv, hipStream_t s);
 hipError_t launch_dot_plain(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* acc, hipStream_t s);
 hipError_t launch_add_key_level(const DevCtx* ctx, u32 n, u64* c, const u64* e, size_t residue_polys, hipStream_t s);
 

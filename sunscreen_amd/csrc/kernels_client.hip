@@ -179,6 +179,85 @@ __global__ __launch_bounds__(kClientThreads) void add_key_level_kernel(const Dev
   c[off] = add_mod(c[off], e[off], ctx->mod[res % KK].q);
 }
 
+// ---- KeyGenerator (seal_fhe/src/key_generator.rs:20-200) ----
+// s[i][x] = ternary secret polynomial (coefficient form) in every key-level residue
+__global__ __launch_bounds__(kClientThreads) void keygen_ternary_kernel(const DevCtx* __restrict__ ctx, u64 seed, u64 stream, u64* __restrict__ s) {
+  const u32 n = ctx->n, KK = ctx->KK;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  if (x >= n) return;
+  u32 r[4];
+  philox4x32(x, (u32)stream, (u32)(stream >> 32), 0x5Eu, (u32)seed, (u32)(seed >> 32), r);
+  const int tern = (int)(((u64)r[0] * 3u) >> 32) - 1;
+  for (u32 i = 0; i < KK; i++) s[(size_t)i * n + x] = small_to_residue(tern, ctx->mod[i].q);
+}
+
+// For `count` independent "encryptions of zero" at the key level (SEAL encrypt_zero_symmetric, NTT form):
+//   a[z][i][x] = uniform residue mod q_i (sampled directly in the transform domain),  e[z][i][x] = one rounded Gaussian
+//   per coefficient in every residue (coefficient form; the caller transforms it).
+__global__ __launch_bounds__(kClientThreads) void keygen_sample_kernel(const DevCtx* __restrict__ ctx, u64 seed, u64 stream0, u64* __restrict__ a,
+                                                                       u64* __restrict__ e) {
+  const u32 n = ctx->n, KK = ctx->KK;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 z = blockIdx.y;
+  if (x >= n) return;
+  const u64 stream = stream0 + z;
+  u32 g[4];
+  philox4x32(x, (u32)stream, (u32)(stream >> 32), 0xE0u, (u32)seed, (u32)(seed >> 32), g);
+  const int err = gauss_noise(g[0], g[1]);
+  for (u32 i = 0; i < KK; i++) {
+    const DevMod& dm = ctx->mod[i];
+    u32 r[4];
+    philox4x32(x, (u32)stream, (u32)(stream >> 32), 0xA0u + i, (u32)seed, (u32)(seed >> 32), r);
+    // 128 uniform bits reduced mod q_i: bias below 2^-66 (SEAL rejects instead; indistinguishable at this size)
+    const u128 wide = ((u128)(((u64)r[0] << 32) | r[1]) << 64) | (((u64)r[2] << 32) | r[3]);
+    a[((size_t)z * KK + i) * n + x] = reduce128(wide >> 1, dm);
+    e[((size_t)z * KK + i) * n + x] = small_to_residue(err, dm.q);
+  }
+}
+
+// key[z] = (c0, c1) with c1 = a, c0 = -(a (.) s + e) [+ w (.) factor on residue z, when w != nullptr]   (all NTT form)
+//   z = digit index of a key-switching key (factor = q_sp mod q_z, SEAL KeyGenerator::generate_one_kswitch_key) or 0 for a
+//   public key (w = nullptr).  key: u64[count][2][KK][N]
+__global__ __launch_bounds__(kClientThreads) void keygen_assemble_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ a,
+                                                                         const u64* __restrict__ e, const u64* __restrict__ s,
+                                                                         const u64* __restrict__ w, u64* __restrict__ key) {
+  const u32 n = ctx->n, KK = ctx->KK;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 i = blockIdx.y, z = blockIdx.z;
+  if (x >= n) return;
+  const DevMod& dm = ctx->mod[i];
+  const u64 av = a[((size_t)z * KK + i) * n + x];
+  u64 c0 = neg_mod(add_mod(mul_mod(av, s[(size_t)i * n + x], dm), e[((size_t)z * KK + i) * n + x], dm.q), dm.q);
+  if (w && i == z) {
+    const u64 factor = reduce64(ctx->mod[KK - 1].q, dm);
+    c0 = add_mod(c0, mul_mod(w[(size_t)i * n + x], factor, dm), dm.q);
+  }
+  key[(((size_t)z * 2 + 0) * KK + i) * n + x] = c0;
+  key[(((size_t)z * 2 + 1) * KK + i) * n + x] = av;
+}
+
+// out[i] = in[i] (.) in[i] per residue (s^2 in the transform domain), key level
+__global__ __launch_bounds__(kClientThreads) void keygen_square_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in, u64* __restrict__ out) {
+  const u32 n = ctx->n;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 i = blockIdx.y;
+  if (x >= n) return;
+  const u64 v = in[(size_t)i * n + x];
+  out[(size_t)i * n + x] = mul_mod(v, v, ctx->mod[i]);
+}
+
+// out[i][o] = +-in[i][o * g^{-1} mod 2N]: the Galois automorphism of a key-level polynomial in coefficient form
+__global__ __launch_bounds__(kClientThreads) void keygen_galois_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in, u64* __restrict__ out,
+                                                                       u32 ginv) {
+  const u32 n = ctx->n;
+  const u32 o = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 i = blockIdx.y;
+  if (o >= n) return;
+  const u32 kk = (u32)(((u64)o * ginv) & (2 * n - 1));
+  const u64 v = in[(size_t)i * n + (kk & (n - 1))];
+  out[(size_t)i * n + o] = kk >= n ? neg_mod(v, ctx->mod[i].q) : v;
+}
+
 // ---- plaintext-matrix x ciphertext-vector product in the transform domain (examples/pir/src/main.rs:16-45) ----
 // acc[row][p][i][x] = sum_j ctn[j][p][i][x] * pntt[row][j][i][x] mod q_i     (all NTT form, canonical residues)
 // One thread = one coefficient of one residue, RT consecutive rows and both ciphertext polynomials: every ciphertext
@@ -220,6 +299,27 @@ __global__ __launch_bounds__(kClientThreads) void dot_plain_kernel(const DevCtx*
 }
 
 // ---- launchers ----
+hipError_t launch_keygen_ternary(const DevCtx* ctx, u32 n, u64 seed, u64 stream, u64* s_out, hipStream_t s) {
+  keygen_ternary_kernel<<<cgrid(n, 1), kClientThreads, 0, s>>>(ctx, seed, stream, s_out);
+  return hipGetLastError();
+}
+hipError_t launch_keygen_sample(const DevCtx* ctx, u32 n, u64 seed, u64 stream0, u64* a, u64* e, size_t count, hipStream_t s) {
+  keygen_sample_kernel<<<cgrid(n, (u32)count), kClientThreads, 0, s>>>(ctx, seed, stream0, a, e);
+  return hipGetLastError();
+}
+hipError_t launch_keygen_assemble(const DevCtx* ctx, u32 n, u32 KK, const u64* a, const u64* e, const u64* sk, const u64* w, u64* key, size_t count,
+                                  hipStream_t s) {
+  keygen_assemble_kernel<<<cgrid(n, KK, (u32)count), kClientThreads, 0, s>>>(ctx, a, e, sk, w, key);
+  return hipGetLastError();
+}
+hipError_t launch_keygen_square(const DevCtx* ctx, u32 n, u32 KK, const u64* in, u64* out, hipStream_t s) {
+  keygen_square_kernel<<<cgrid(n, KK), kClientThreads, 0, s>>>(ctx, in, out);
+  return hipGetLastError();
+}
+hipError_t launch_keygen_galois(const DevCtx* ctx, u32 n, u32 KK, const u64* in, u64* out, u32 ginv, hipStream_t s) {
+  keygen_galois_kernel<<<cgrid(n, KK), kClientThreads, 0, s>>>(ctx, in, out, ginv);
+  return hipGetLastError();
+}
 hipError_t launch_dot_plain(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* acc, hipStream_t s) {
   constexpr int RT = 8;  // rows per thread: the query ciphertexts are re-read once per RT database rows (16: fewer, fatter
                          // workgroups -- measured slower)

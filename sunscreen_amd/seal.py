@@ -442,6 +442,21 @@ def _keys_from_bytes(cls, ctx: "Context", data: bytes):
     return k
 
 
+def _keys_to_array(self, ctx: "Context", index: int = 0) -> np.ndarray:
+    """hipbfv extension: one key-switching key, uint64[K][2][K+1][N]; index 0 = relin, (elt-1)/2 = Galois."""
+    out = np.empty((ctx.K, 2, ctx.KK, ctx.poly_modulus_degree), dtype=np.uint64)
+    _check(_lib.load().hipbfv_KSwitchKeys_Read(self._h, index, out.ctypes.data_as(_lib.u64p)))
+    return out
+
+
+def _keys_has(self, index: int) -> bool:
+    present = C.c_bool()
+    _check(_lib.load().hipbfv_KSwitchKeys_Has(self._h, index, C.byref(present)))
+    return present.value
+
+
+_KSwitchKeys.to_array = _keys_to_array
+_KSwitchKeys.has_key = _keys_has
 _KSwitchKeys.as_bytes = _keys_as_bytes
 _KSwitchKeys.from_bytes = classmethod(_keys_from_bytes)
 
@@ -619,8 +634,8 @@ class BFVEvaluator:
 
 # ---- the steps either side of the evaluator --------------------------------------------------
 class _AsymKey:
-    """SecretKey / PublicKey handles (seal_fhe/src/key_generator.rs:200-430).  Keys come from the client; the
-    library has no KeyGenerator."""
+    """SecretKey / PublicKey handles (seal_fhe/src/key_generator.rs:200-430): made by KeyGenerator, loaded from
+    SEAL's wire format, or assigned from raw residues."""
 
     _prefix = ""
     _polys = 1
@@ -640,6 +655,13 @@ class _AsymKey:
         assert arr.size == cls._polys * ctx.KK * ctx.poly_modulus_degree, arr.shape
         _check(getattr(_lib.load(), "hipbfv_" + cls._prefix + "_Assign")(k._h, ctx.get_handle(), arr.ctypes.data_as(_lib.u64p)))
         return k
+
+    def to_array(self, ctx: "Context") -> np.ndarray:
+        """hipbfv extension: the key-level NTT-form residues, uint64[(2,) K+1, N]."""
+        shape = (ctx.KK, ctx.poly_modulus_degree) if self._polys == 1 else (self._polys, ctx.KK, ctx.poly_modulus_degree)
+        out = np.empty(shape, dtype=np.uint64)
+        _check(getattr(_lib.load(), "hipbfv_" + self._prefix + "_Read")(self._h, out.ctypes.data_as(_lib.u64p)))
+        return out
 
     def as_bytes(self, compression: int = 2) -> bytes:
         L = _lib.load()
@@ -669,6 +691,67 @@ class SecretKey(_AsymKey):
 
 class PublicKey(_AsymKey):
     _prefix, _polys = "PublicKey", 2
+
+
+class KeyGenerator:
+    """seal_fhe/src/key_generator.rs:20-200.  Keys are sampled and assembled on the device."""
+
+    def __init__(self, ctx: "Context", secret_key: SecretKey | None = None, seed: int | None = None):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        L = _lib.load()
+        if secret_key is None:
+            if seed is not None:  # hipbfv extension: reproducible secret and keys (tests)
+                _check(L.hipbfv_KeyGenerator_CreateSeeded(ctx.get_handle(), seed, C.byref(self._h)))
+            else:
+                _check(L.KeyGenerator_Create1(ctx.get_handle(), C.byref(self._h)))
+        else:
+            _check(L.KeyGenerator_Create2(ctx.get_handle(), secret_key.get_handle(), C.byref(self._h)))
+            if seed is not None:
+                _check(L.hipbfv_KeyGenerator_SetSeed(self._h, seed))
+
+    @classmethod
+    def new_from_secret_key(cls, ctx: "Context", secret_key: SecretKey) -> "KeyGenerator":
+        return cls(ctx, secret_key)
+
+    def set_seed(self, seed: int) -> None:
+        """hipbfv extension: make the keys created afterwards reproducible (tests)."""
+        _check(_lib.load().hipbfv_KeyGenerator_SetSeed(self._h, seed))
+
+    def _adopt(self, cls):
+        k = cls.__new__(cls)
+        k._h = C.c_void_p()
+        return k
+
+    def secret_key(self) -> SecretKey:
+        k = self._adopt(SecretKey)
+        _check(_lib.load().KeyGenerator_SecretKey(self._h, C.byref(k._h)))
+        return k
+
+    def create_public_key(self) -> PublicKey:
+        k = self._adopt(PublicKey)
+        _check(_lib.load().KeyGenerator_CreatePublicKey(self._h, False, C.byref(k._h)))
+        return k
+
+    def create_relinearization_keys(self) -> RelinearizationKeys:
+        k = self._adopt(RelinearizationKeys)
+        _check(_lib.load().KeyGenerator_CreateRelinKeys(self._h, False, C.byref(k._h)))
+        return k
+
+    def create_galois_keys(self, galois_elts: Sequence[int] | None = None) -> GaloisKeys:
+        k = self._adopt(GaloisKeys)
+        L = _lib.load()
+        if galois_elts is None:
+            _check(L.KeyGenerator_CreateGaloisKeysAll(self._h, False, C.byref(k._h)))
+        else:
+            arr = (C.c_uint32 * len(galois_elts))(*[int(e) for e in galois_elts])
+            _check(L.KeyGenerator_CreateGaloisKeysFromElts(self._h, len(galois_elts), arr, False, C.byref(k._h)))
+        return k
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().KeyGenerator_Destroy(self._h)
+            self._h = None
 
 
 class BFVEncoder:

@@ -225,3 +225,168 @@ def test_key_handles_wire_format_roundtrip():
     bad[1, 5] = primes[1]
     with pytest.raises(HipBfvError):
         SecretKey.from_array(ctx, bad)
+
+
+# ---- KeyGenerator (seal_fhe/src/key_generator.rs:20-200): device-made keys judged by the oracle ----------------------
+def _centred(x, q):
+    x = x.astype(object)
+    return np.where(x > q // 2, x - q, x)
+
+
+def _dyadic(a, b, q):
+    return np.array((a.astype(object) * b.astype(object)) % q, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("name", ["default_8192_17", "default_4096_16", "seal_fhe_unit", "default_16384_17"])
+def test_key_generator_keys_are_valid_under_the_oracle(name):
+    from sunscreen_amd import Context, KeyGenerator
+
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    ctx = Context.from_raw(n, primes, t)
+    KK, K = len(primes), len(primes) - 1
+    kg = KeyGenerator(ctx, seed=77)
+    sk = kg.secret_key().to_array(ctx)
+    assert sk.shape == (KK, n)
+    # the secret is one ternary polynomial, present under every key prime
+    s_coeff = [_centred(o.ntt(i, sk[i], inverse=True), primes[i]) for i in range(KK)]
+    for i in range(1, KK):
+        assert (s_coeff[i] == s_coeff[0]).all()
+    assert set(np.unique(s_coeff[0]).tolist()) <= {-1, 0, 1}
+    frac = np.mean(s_coeff[0] != 0)
+    assert 0.6 < frac < 0.73, frac
+    # public key: pk0 + pk1*s = -e with e a clipped rounded Gaussian (sigma 3.2, |e| <= 19), one e for all residues
+    pk = kg.create_public_key().to_array(ctx)
+    errs = []
+    for i in range(KK):
+        q = primes[i]
+        v = (pk[0, i].astype(object) + _dyadic(pk[1, i], sk[i], q).astype(object)) % q
+        errs.append(_centred(o.ntt(i, np.array(v, dtype=np.uint64), inverse=True), q))
+    for i in range(1, KK):
+        assert (errs[i] == errs[0]).all()
+    e = errs[0].astype(np.float64)
+    assert np.abs(e).max() <= 19
+    assert 2.9 < e.std() < 3.5 and abs(e.mean()) < 0.25, (e.std(), e.mean())
+    # pk1 is uniform: the top bit of the range is hit about half the time
+    assert 0.45 < np.mean(pk[1, 0] > primes[0] // 2) < 0.55
+    # the oracle encrypts under the device public key and decrypts with the device secret key
+    O.seed(5)
+    osk, opk, ork, _ = o.keygen()
+    msg = np.arange(n, dtype=np.uint64) % t
+    ct = o.encrypt(pk, msg)
+    assert (o.decrypt(ct, sk) == msg).all()
+    assert o.noise_budget(ct, sk) >= o.noise_budget(o.encrypt(opk, msg), osk) - 2
+    if K < 1:
+        return
+    # relinearisation key: structure (digit z hides q_sp * s^2 on residue z only) and use
+    rk = kg.create_relinearization_keys()
+    rka = rk.to_array(ctx)
+    assert rka.shape == (K, 2, KK, n)
+    qsp = primes[-1]
+    for z in range(K):
+        for i in range(KK):
+            q = primes[i]
+            v = rka[z, 0, i].astype(object) + _dyadic(rka[z, 1, i], sk[i], q).astype(object)
+            if i == z:
+                v = v - (qsp % q) * _dyadic(sk[i], sk[i], q).astype(object)
+            err = _centred(o.ntt(i, np.array(v % q, dtype=np.uint64), inverse=True), q)
+            assert np.abs(err.astype(np.float64)).max() <= 19, (z, i)
+    a = o.encrypt(pk, msg)
+    prod3 = o.multiply(a, a)
+    want = o.decrypt(prod3, sk)
+    got = o.relinearize(prod3, rka)
+    assert got.shape[0] == 2 and (o.decrypt(got, sk) == want).all()
+    assert o.noise_budget(got, sk) >= o.noise_budget(prod3, sk) - 3
+    # Galois keys: SEAL's default set (column swap + every power-of-two row rotation, both directions)
+    logn = n.bit_length() - 1
+    gk = kg.create_galois_keys()
+    elts = sorted({2 * n - 1} | {pow(3, 1 << i, 2 * n) for i in range(logn - 1)} | {pow(3, -(1 << i), 2 * n) for i in range(logn - 1)})
+    present = [e for e in range(1, 2 * n, 2) if gk.has_key((e - 1) // 2)] if n <= 4096 else [e for e in elts if gk.has_key((e - 1) // 2)]
+    # 2(log n - 1) + 1 list entries in SEAL's get_elts_all; 3^(n/4) is its own inverse, so one fewer distinct keys
+    assert present == elts and len(elts) == 2 * (logn - 1)
+    if (t - 1) % (2 * n) == 0:
+        slots = np.arange(n, dtype=np.uint64) * 3 % t
+        cts = o.encrypt(pk, o.batch_encode(slots))
+        for step in (1, -2, n // 4):
+            elt = o.galois_elt_from_step(step)
+            gka = {elt: gk.to_array(ctx, (elt - 1) // 2)}
+            r = o.batch_decode(o.decrypt(o.rotate_rows(cts, step, gka), sk))
+            half = n // 2
+            want_rows = np.concatenate([np.roll(slots[:half], -step), np.roll(slots[half:], -step)])
+            assert (r == want_rows).all(), step
+        gka = {2 * n - 1: gk.to_array(ctx, n - 1)}
+        r = o.batch_decode(o.decrypt(o.rotate_columns(cts, gka), sk))
+        assert (r == np.concatenate([slots[n // 2 :], slots[: n // 2]])).all()
+
+
+def test_key_generator_from_existing_secret_and_reproducibility():
+    from sunscreen_amd import Context, GaloisKeys, KeyGenerator, PublicKey, RelinearizationKeys, SecretKey
+
+    name = "default_8192_17"
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    O.seed(9)
+    osk, opk, ork, _ = o.keygen()
+    ctx = Context.from_raw(n, primes, t)
+    kg = KeyGenerator.new_from_secret_key(ctx, SecretKey.from_array(ctx, osk))
+    assert (kg.secret_key().to_array(ctx) == osk).all()
+    pk = kg.create_public_key()
+    msg = np.arange(n, dtype=np.uint64) * 7 % t
+    ct = o.encrypt(pk.to_array(ctx), msg)
+    assert (o.decrypt(ct, osk) == msg).all()  # the ORACLE's secret key opens it
+    rk = kg.create_relinearization_keys()
+    p3 = o.multiply(ct, ct)
+    assert (o.decrypt(o.relinearize(p3, rk.to_array(ctx)), osk) == o.decrypt(p3, osk)).all()
+    elt = o.galois_elt_from_step(3)
+    gk = kg.create_galois_keys([elt])
+    assert gk.has_key((elt - 1) // 2) and not gk.has_key(n - 1)
+    rot = o.rotate_rows(ct, 3, {elt: gk.to_array(ctx, (elt - 1) // 2)})
+    assert (o.batch_decode(o.decrypt(rot, osk))[: n // 2] == np.roll(o.batch_decode(msg)[: n // 2], -3)).all()
+    # seeded generators repeat; successive keys from one generator differ; unseeded generators differ
+    a, b = KeyGenerator(ctx, seed=5), KeyGenerator(ctx, seed=5)
+    assert (a.secret_key().to_array(ctx) == b.secret_key().to_array(ctx)).all()
+    pa, pb = a.create_public_key().to_array(ctx), b.create_public_key().to_array(ctx)
+    assert (pa == pb).all()
+    assert not (a.create_public_key().to_array(ctx) == pa).all()
+    assert (a.create_relinearization_keys().to_array(ctx) == (b.create_public_key(), b.create_relinearization_keys())[1].to_array(ctx)).all()
+    c, d = KeyGenerator(ctx), KeyGenerator(ctx)
+    assert not (c.secret_key().to_array(ctx) == d.secret_key().to_array(ctx)).all()
+    # wire format round trip of device-made keys (SEAL 4.0 serialisation)
+    for cls, key in ((SecretKey, a.secret_key()), (PublicKey, a.create_public_key())):
+        back = cls.from_bytes(ctx, key.as_bytes())
+        assert (back.to_array(ctx) == key.to_array(ctx)).all()
+    rk2 = RelinearizationKeys.from_bytes(ctx, rk.as_bytes())
+    assert (rk2.to_array(ctx) == rk.to_array(ctx)).all()
+    gk2 = GaloisKeys.from_bytes(ctx, gk.as_bytes())
+    assert (gk2.to_array(ctx, (elt - 1) // 2) == gk.to_array(ctx, (elt - 1) // 2)).all()
+
+
+def test_device_only_round_trip_keygen_encrypt_evaluate_decrypt():
+    """The seal_fhe crate's own usage pattern (bfv_evaluator.rs tests): every object made by this library."""
+    from sunscreen_amd import BFVEncoder, BFVEvaluator, Context, Decryptor, Encryptor, HipBfvError, KeyGenerator
+
+    n, primes, t = params("seal_fhe_unit")
+    ctx = Context.from_raw(n, primes, t)
+    kg = KeyGenerator(ctx)
+    enc = Encryptor(ctx, kg.create_public_key())
+    dec = Decryptor(ctx, kg.secret_key())
+    rk, gk = kg.create_relinearization_keys(), kg.create_galois_keys()
+    be, ev = BFVEncoder(ctx), BFVEvaluator(ctx)
+    v = [int(x) for x in make_vec(n)]
+    a = enc.encrypt(be.encode_signed(v))
+    fresh = dec.invariant_noise_budget(a)
+    assert fresh > 20
+    sq = ev.relinearize(ev.multiply(a, a), rk)
+    assert be.decode_signed(dec.decrypt(sq)) == [((x * x + t // 2) % t) - t // 2 for x in v]
+    assert 0 < dec.invariant_noise_budget(sq) < fresh
+    r = be.decode_signed(dec.decrypt(ev.rotate_rows(a, -1, gk)))
+    half = n // 2
+    assert r[:half] == v[half - 1 : half] + v[: half - 1] and r[half:] == v[n - 1 :] + v[half : n - 1]
+    c = be.decode_signed(dec.decrypt(ev.rotate_columns(a, gk)))
+    assert c == v[half:] + v[:half]
+    # a generator for a context without a special prime cannot make key-switching keys
+    n2, primes2, t2 = params("default_2048_14")
+    assert len(primes2) == 1
+    with pytest.raises(HipBfvError) as ei:
+        KeyGenerator(Context.from_raw(n2, primes2, t2)).create_relinearization_keys()
+    assert ei.value.kind == "InternalError"  # COR_E_INVALIDOPERATION, as convert_seal_error maps it (error.rs:82-91)
