@@ -152,12 +152,50 @@ long Decryptor_Destroy(void *thisptr);
 long Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination);
 long Decryptor_InvariantNoiseBudget(void *thisptr, void *encrypted, int *invariant_noise_budget);
 
-/* ---- Encryptor, public-key mode (seal_fhe/src/encryptor_decryptor.rs:140-260).  The randomness is the library's
- * own (Philox4x32-10; ternary u, rounded Gaussian sigma 3.2 clipped at 19): ciphertexts are valid SEAL ciphertexts
- * but, like SEAL's, not reproducible across implementations.  secret_key may be NULL; symmetric mode is not exported. ---- */
+/* ---- Encryptor (seal_fhe/src/encryptor_decryptor.rs:140-600).  The randomness is the library's own (Philox4x32-10;
+ * ternary u, rounded Gaussian sigma 3.2 clipped at 19, uniform a): ciphertexts are valid SEAL ciphertexts but, like
+ * SEAL's, not reproducible across implementations.  public_key or secret_key may be NULL (with_public_key /
+ * with_secret_key / with_public_and_secret_key).  The *ReturnComponents* entry points are the Sunscreen fork's
+ * (encryptor_decryptor.rs:268-590): they also hand back the sampled u (1 polynomial), e (2; 1 in symmetric mode) as
+ * PolynomialArrays over the data primes and the scaling remainder r, such that over the data primes, exactly,
+ *   public key, disable_special_modulus: c0 = floor(q/t) m + r + pk0 u + e0,  c1 = pk1 u + e1
+ *   secret key:                          c0 = floor(q/t) m + r - (c1 s + e)
+ * (logproof/src/bfv_statement.rs:159-160).  The *SetSeed variants take the fork's [u64; 8] seed, folded into the
+ * Philox key: equal seeds give equal ciphertexts (not SEAL's bits: its PRNG is not restated).  save_seed is ignored. ---- */
 long Encryptor_Create(void *context, void *public_key, void *secret_key, void **encryptor);
 long Encryptor_Destroy(void *thisptr);
 long Encryptor_Encrypt(void *thisptr, void *plaintext, void *destination, void *pool);
+long Encryptor_EncryptReturnComponents(void *thisptr, void *plaintext, bool disable_special_modulus, void *destination,
+                                       void *u_destination, void *e_destination, void *r_destination, void *pool);
+long Encryptor_EncryptReturnComponentsSetSeed(void *thisptr, void *plaintext, bool disable_special_modulus, void *destination,
+                                              void *u_destination, void *e_destination, void *r_destination, void *seed, void *pool);
+long Encryptor_EncryptSymmetric(void *thisptr, void *plaintext, bool save_seed, void *destination, void *pool);
+long Encryptor_EncryptSymmetricReturnComponents(void *thisptr, void *plaintext, void *destination, void *e_destination,
+                                                void *r_destination, void *pool);
+long Encryptor_EncryptSymmetricReturnComponentsSetSeed(void *thisptr, void *plaintext, void *destination, void *e_destination,
+                                                       void *r_destination, void *seed, void *pool);
+
+/* ---- PolynomialArray, the Sunscreen fork's export type (seal_fhe/src/data_structures.rs:17-304): `PolySize`
+ * coefficient-form polynomials over the first `CoeffModulusSize` primes, exported either as RNS u64[poly][rns][coeff]
+ * or, after ToMultiprecision, as u64[poly][coeff][limb] (CRT-composed value in [0, q), little-endian limbs) -- the layout
+ * logproof/src/bfv_statement.rs:624-660 consumes.  Keys are converted out of NTT form and restricted to the data primes.
+ * The conversions run on the device.  Drop keeps residues 0..k-2 of every polynomial. ---- */
+long PolynomialArray_Create(void *pool, void **poly_array);
+long PolynomialArray_CreateFromCiphertext(void *pool, void *context, void *ciphertext, void **poly_array);
+long PolynomialArray_CreateFromPublicKey(void *pool, void *context, void *public_key, void **poly_array);
+long PolynomialArray_CreateFromSecretKey(void *pool, void *context, void *secret_key, void **poly_array);
+long PolynomialArray_Copy(void *copy, void **poly_array);
+long PolynomialArray_Destroy(void *thisptr);
+long PolynomialArray_IsReserved(void *thisptr, bool *is_reserved);
+long PolynomialArray_IsRns(void *thisptr, bool *is_rns);
+long PolynomialArray_ToRns(void *thisptr);
+long PolynomialArray_ToMultiprecision(void *thisptr);
+long PolynomialArray_PolySize(void *thisptr, uint64_t *size);
+long PolynomialArray_PolyModulusDegree(void *thisptr, uint64_t *size);
+long PolynomialArray_CoeffModulusSize(void *thisptr, uint64_t *size);
+long PolynomialArray_ExportSize(void *thisptr, uint64_t *size);
+long PolynomialArray_PerformExport(void *thisptr, uint64_t *data);
+long PolynomialArray_Drop(void *thisptr, void **poly_array);
 
 /* ---- Evaluator (seal_fhe/src/evaluator_base.rs:55-407, bfv_evaluator.rs:12-248) ---- */
 long Evaluator_Create(void *seal_context, void **evaluator);

@@ -22,6 +22,7 @@ from .seal import (  # noqa: F401
     Modulus,
     PlainModulus,
     Plaintext,
+    PolynomialArray,
     PublicKey,
     RelinearizationKeys,
     SecretKey,

@@ -159,6 +159,19 @@ _SIGNATURES = {
     "Decryptor_Create": [vp, vp, vpp], "Decryptor_Destroy": [vp], "Decryptor_Decrypt": [vp, vp, vp],
     "Decryptor_InvariantNoiseBudget": [vp, vp, C.POINTER(C.c_int)],
     "Encryptor_Create": [vp, vp, vp, vpp], "Encryptor_Destroy": [vp], "Encryptor_Encrypt": [vp, vp, vp, vp],
+    "Encryptor_EncryptReturnComponents": [vp, vp, C.c_bool, vp, vp, vp, vp, vp],
+    "Encryptor_EncryptReturnComponentsSetSeed": [vp, vp, C.c_bool, vp, vp, vp, vp, vp, vp],
+    "Encryptor_EncryptSymmetric": [vp, vp, C.c_bool, vp, vp],
+    "Encryptor_EncryptSymmetricReturnComponents": [vp, vp, vp, vp, vp, vp],
+    "Encryptor_EncryptSymmetricReturnComponentsSetSeed": [vp, vp, vp, vp, vp, vp, vp],
+    "PolynomialArray_Create": [vp, vpp], "PolynomialArray_CreateFromCiphertext": [vp, vp, vp, vpp],
+    "PolynomialArray_CreateFromPublicKey": [vp, vp, vp, vpp], "PolynomialArray_CreateFromSecretKey": [vp, vp, vp, vpp],
+    "PolynomialArray_Copy": [vp, vpp], "PolynomialArray_Destroy": [vp],
+    "PolynomialArray_IsReserved": [vp, C.POINTER(C.c_bool)], "PolynomialArray_IsRns": [vp, C.POINTER(C.c_bool)],
+    "PolynomialArray_ToRns": [vp], "PolynomialArray_ToMultiprecision": [vp],
+    "PolynomialArray_PolySize": [vp, u64p], "PolynomialArray_PolyModulusDegree": [vp, u64p],
+    "PolynomialArray_CoeffModulusSize": [vp, u64p], "PolynomialArray_ExportSize": [vp, u64p],
+    "PolynomialArray_PerformExport": [vp, u64p], "PolynomialArray_Drop": [vp, vpp],
     "hipbfv_set_chunk_ops": [vp, u64],
     "hipbfv_Program_Create": [vpp],
     "hipbfv_Program_Destroy": [vp],

@@ -64,6 +64,7 @@ enum Magic : uint32_t {
   kMagicDecryptor = 0x44454331,
   kMagicEncryptor = 0x454E4331,
   kMagicKeyGen = 0x4B47454E,
+  kMagicPolyArray = 0x504F4C59,
 };
 
 struct Obj {
@@ -237,6 +238,7 @@ struct EncryptorObj : Obj {
   std::shared_ptr<Context> ctx;
   std::unique_ptr<Evaluator> ev;
   std::shared_ptr<KeyBuffer> pk;
+  std::shared_ptr<KeyBuffer> sk;  // optional: symmetric encryption
   u64 seed = 0;
   std::mutex mu;
   u64 next_op = 0;  // Philox counter: every encryption of one Encryptor uses fresh randomness
@@ -252,6 +254,18 @@ struct KeyGenObj : Obj {
   std::mutex mu;
   u64 next_stream = 1;  // every generated key draws from its own Philox stream
   KeyGenObj() : Obj(kMagicKeyGen) {}
+};
+
+// The fork's PolynomialArray (seal_fhe/src/data_structures.rs:17-304): `polys` polynomials over the first `kc` primes of
+// the context, coefficient form, either RNS u64[polys][kc][N] or multiprecision u64[polys][N][kc] (little-endian limbs)
+struct PolyArrayObj : Obj {
+  std::shared_ptr<Context> ctx;
+  u32 polys = 0, kc = 0;
+  u64* dev = nullptr;
+  size_t words = 0;
+  bool rns = true, reserved = false;
+  PolyArrayObj() : Obj(kMagicPolyArray) {}
+  ~PolyArrayObj() override { g_buffers.put(dev, words); }
 };
 
 struct ProgramObj : Obj {
@@ -2098,14 +2112,18 @@ long Decryptor_InvariantNoiseBudget(void* h, void* encrypted, int* budget) {
 long Encryptor_Create(void* context, void* public_key, void* secret_key, void** out) {
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!x || !out) return HIPBFV_E_POINTER;
-  AsymKeyObj* pk = as<AsymKeyObj>(public_key, kMagicPublicKey);
-  (void)secret_key;  // symmetric encryption stays client-side (Encryptor_EncryptSymmetric is not exported)
-  if (!pk) return fail(HIPBFV_E_INVALIDARG, "a public key is required");
-  if (!pk->key || pk->key->ctx.get() != x->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "public key is not valid for encryption parameters");
+  // with_public_key / with_secret_key / with_public_and_secret_key (encryptor_decryptor.rs:140-200): either may be null
+  AsymKeyObj* pk = public_key ? as<AsymKeyObj>(public_key, kMagicPublicKey) : nullptr;
+  AsymKeyObj* sk = secret_key ? as<AsymKeyObj>(secret_key, kMagicSecretKey) : nullptr;
+  if ((public_key && !pk) || (secret_key && !sk)) return HIPBFV_E_POINTER;
+  if (!pk && !sk) return fail(HIPBFV_E_INVALIDARG, "a public key or a secret key is required");
+  if (pk && (!pk->key || pk->key->ctx.get() != x->ctx.get())) return fail(HIPBFV_E_INVALIDARG, "public key is not valid for encryption parameters");
+  if (sk && (!sk->key || sk->key->ctx.get() != x->ctx.get())) return fail(HIPBFV_E_INVALIDARG, "secret key is not valid for encryption parameters");
   EncryptorObj* e = new EncryptorObj();
   e->ctx = x->ctx;
   e->ev.reset(new Evaluator(x->ctx.get()));
-  e->pk = pk->key;
+  if (pk) e->pk = pk->key;
+  if (sk) e->sk = sk->key;
   // fresh seed per Encryptor from the OS (SEAL seeds its PRNG factory from std::random_device the same way)
   {
     FILE* f = std::fopen("/dev/urandom", "rb");
@@ -2137,6 +2155,7 @@ long Encryptor_Encrypt(void* h, void* plaintext, void* destination, void* pool) 
   PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
   CipherObj* c = as<CipherObj>(destination, kMagicCipher);
   if (!e || !p || !c) return HIPBFV_E_POINTER;
+  if (!e->pk) return fail(HIPBFV_COR_E_INVALIDOPERATION, "public key is not set");
   const size_t n = e->ctx->n(), words = e->ctx->ct_words(2);
   if (p->coeffs.size() > n) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
   for (u64 v : p->coeffs)
@@ -2278,6 +2297,346 @@ long hipbfv_batch_mod_switch(void* evaluator, const uint64_t* ct, uint64_t size,
   if (!ev || !ct || !out) return HIPBFV_E_POINTER;
   if (size < 1) return fail(HIPBFV_E_INVALIDARG, "invalid ciphertext size");
   return from_status(ev->mod_switch_next((const u64*)ct, (u32)size, (u64*)out, count, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------ PolynomialArray + encryption components (fork-only API)
+static long polyarray_fill(PolyArrayObj* a, const std::shared_ptr<Context>& ctx, u32 polys, u32 kc) {
+  if (a->reserved) return fail(HIPBFV_COR_E_INVALIDOPERATION, "polynomial array already holds data");
+  a->ctx = ctx;
+  a->polys = polys;
+  a->kc = kc;
+  a->words = (size_t)polys * kc * ctx->n();
+  a->dev = a->words ? g_buffers.get(a->words) : nullptr;
+  if (a->words && !a->dev) return from_status(kOutOfMemory);
+  a->rns = true;
+  a->reserved = true;
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_Create(void* pool, void** out) {
+  (void)pool;
+  if (!out) return HIPBFV_E_POINTER;
+  *out = new PolyArrayObj();
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_Destroy(void* h) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a) return HIPBFV_E_POINTER;
+  delete a;
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_CreateFromCiphertext(void* pool, void* context, void* ciphertext, void** out) {
+  (void)pool;
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  CipherObj* c = as<CipherObj>(ciphertext, kMagicCipher);
+  if (!x || !c || !out) return HIPBFV_E_POINTER;
+  std::shared_ptr<Context> ctx = c->ctx ? c->ctx : x->ctx;
+  if (ctx->n() != x->ctx->n()) return fail(HIPBFV_E_INVALIDARG, "ciphertext is not valid for encryption parameters");
+  std::unique_ptr<PolyArrayObj> a(new PolyArrayObj());
+  const u32 polys = c->dev ? c->size : 0;
+  if (long hr = polyarray_fill(a.get(), ctx, polys, ctx->K())) return hr;
+  if (a->words) {
+    hipStream_t s = thread_stream();
+    if (hipMemcpyAsync(a->dev, c->dev, a->words * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess) return from_status(kHipError);
+    if (long hr = sync_stream(s)) return hr;
+  }
+  *out = a.release();
+  return HIPBFV_S_OK;
+}
+static long polyarray_from_key(void* context, AsymKeyObj* k, u32 polys, void** out) {
+  ContextObj* x = as<ContextObj>(context, kMagicContext);
+  if (!x || !k || !out) return HIPBFV_E_POINTER;
+  if (!k->key || k->key->ctx.get() != x->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "key is not valid for encryption parameters");
+  std::unique_ptr<PolyArrayObj> a(new PolyArrayObj());
+  if (long hr = polyarray_fill(a.get(), x->ctx, polys, x->ctx->K())) return hr;
+  Evaluator ev(x->ctx.get());
+  hipStream_t s = thread_stream();
+  // keys live at the key level in NTT form; the array holds the data-level residues in coefficient form
+  if (int st = ev.key_to_coeff(k->key->dev, polys, a->dev, s)) return from_status(st);
+  if (long hr = sync_stream(s)) return hr;
+  *out = a.release();
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_CreateFromPublicKey(void* pool, void* context, void* public_key, void** out) {
+  (void)pool;
+  return polyarray_from_key(context, as<AsymKeyObj>(public_key, kMagicPublicKey), 2, out);
+}
+long PolynomialArray_CreateFromSecretKey(void* pool, void* context, void* secret_key, void** out) {
+  (void)pool;
+  return polyarray_from_key(context, as<AsymKeyObj>(secret_key, kMagicSecretKey), 1, out);
+}
+long PolynomialArray_Copy(void* h, void** out) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a || !out) return HIPBFV_E_POINTER;
+  std::unique_ptr<PolyArrayObj> b(new PolyArrayObj());
+  if (a->reserved) {
+    if (long hr = polyarray_fill(b.get(), a->ctx, a->polys, a->kc)) return hr;
+    b->rns = a->rns;
+    if (a->words) {
+      hipStream_t s = thread_stream();
+      if (hipMemcpyAsync(b->dev, a->dev, a->words * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess) return from_status(kHipError);
+      if (long hr = sync_stream(s)) return hr;
+    }
+  }
+  *out = b.release();
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_IsReserved(void* h, bool* result) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a || !result) return HIPBFV_E_POINTER;
+  *result = a->reserved;
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_IsRns(void* h, bool* result) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a || !result) return HIPBFV_E_POINTER;
+  *result = a->rns;
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_PolySize(void* h, uint64_t* result) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a || !result) return HIPBFV_E_POINTER;
+  *result = a->polys;
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_PolyModulusDegree(void* h, uint64_t* result) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a || !result) return HIPBFV_E_POINTER;
+  *result = a->ctx ? a->ctx->n() : 0;
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_CoeffModulusSize(void* h, uint64_t* result) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a || !result) return HIPBFV_E_POINTER;
+  *result = a->kc;
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_ExportSize(void* h, uint64_t* result) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a || !result) return HIPBFV_E_POINTER;
+  *result = a->words;
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_PerformExport(void* h, uint64_t* data) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a || (!data && a->words)) return HIPBFV_E_POINTER;
+  if (a->words && hipMemcpy(data, a->dev, a->words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return from_status(kHipError);
+  return HIPBFV_S_OK;
+}
+// CRT constants of the first kc primes: inv_punct[kc] | punct[kc][kc] | q[kc]
+static std::vector<u64> crt_constants(const Context& cx, u32 kc) {
+  std::vector<u64> c((size_t)kc + (size_t)kc * kc + kc, 0);
+  const DevCtx& h = cx.host();
+  for (u32 i = 0; i < kc; i++) {
+    Big punct(kc + 1);
+    punct.w[0] = 1;
+    u64 pm = 1;
+    for (u32 j = 0; j < kc; j++) {
+      if (j == i) continue;
+      Big next(kc + 1);
+      next.add_mul(punct, h.mod[j].q);
+      punct = next;
+      pm = mulmod64(pm, h.mod[j].q % h.mod[i].q, h.mod[i].q);
+    }
+    c[i] = invmod64(pm, h.mod[i].q);
+    for (u32 l = 0; l < kc; l++) c[kc + (size_t)i * kc + l] = punct.w[l];
+    if (i == 0) {
+      Big q(kc + 1);
+      q.add_mul(punct, h.mod[0].q);
+      for (u32 l = 0; l < kc; l++) c[kc + (size_t)kc * kc + l] = q.w[l];
+    }
+  }
+  return c;
+}
+static long polyarray_convert(PolyArrayObj* a, bool to_rns) {
+  if (!a->reserved || a->rns == to_rns || !a->words) {
+    if (a->reserved) a->rns = to_rns;
+    return HIPBFV_S_OK;
+  }
+  u64* out = g_buffers.get(a->words);
+  if (!out) return from_status(kOutOfMemory);
+  hipStream_t s = thread_stream();
+  long hr = HIPBFV_S_OK;
+  const u32 n = a->ctx->n();
+  if (to_rns) {
+    if (launch_crt_decompose(a->ctx->dev(), n, a->kc, a->dev, out, a->polys, s) != hipSuccess) hr = from_status(kHipError);
+  } else {
+    const std::vector<u64> consts = crt_constants(*a->ctx, a->kc);
+    u64* dc = g_buffers.get(consts.size());
+    if (!dc) {
+      g_buffers.put(out, a->words);
+      return from_status(kOutOfMemory);
+    }
+    if (hipMemcpyAsync(dc, consts.data(), consts.size() * sizeof(u64), hipMemcpyHostToDevice, s) != hipSuccess ||
+        launch_crt_compose(a->ctx->dev(), n, a->kc, dc, a->dev, out, a->polys, s) != hipSuccess)
+      hr = from_status(kHipError);
+    if (hr == HIPBFV_S_OK) hr = sync_stream(s);  // consts is a stack object: finish before it goes away
+    g_buffers.put(dc, consts.size());
+  }
+  if (hr == HIPBFV_S_OK) hr = sync_stream(s);
+  if (hr != HIPBFV_S_OK) {
+    g_buffers.put(out, a->words);
+    return hr;
+  }
+  g_buffers.put(a->dev, a->words);
+  a->dev = out;
+  a->rns = to_rns;
+  return HIPBFV_S_OK;
+}
+long PolynomialArray_ToRns(void* h) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a) return HIPBFV_E_POINTER;
+  return polyarray_convert(a, true);
+}
+long PolynomialArray_ToMultiprecision(void* h) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a) return HIPBFV_E_POINTER;
+  return polyarray_convert(a, false);
+}
+// Drop the last prime: the new array keeps residues 0..kc-2 of every polynomial (RNS form)
+long PolynomialArray_Drop(void* h, void** out) {
+  PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
+  if (!a || !out) return HIPBFV_E_POINTER;
+  if (!a->reserved || a->kc < 2) return fail(HIPBFV_E_INVALIDARG, "no modulus to drop");
+  const bool was_rns = a->rns;
+  if (long hr = polyarray_convert(a, true)) return hr;
+  std::unique_ptr<PolyArrayObj> b(new PolyArrayObj());
+  long hr = polyarray_fill(b.get(), a->ctx, a->polys, a->kc - 1);
+  if (hr == HIPBFV_S_OK && b->words) {
+    hipStream_t s = thread_stream();
+    const size_t row = (size_t)a->ctx->n() * sizeof(u64);
+    if (hipMemcpy2DAsync(b->dev, b->kc * row, a->dev, a->kc * row, b->kc * row, a->polys, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      hr = from_status(kHipError);
+    else
+      hr = sync_stream(s);
+  }
+  if (!was_rns) polyarray_convert(a, false);
+  if (hr != HIPBFV_S_OK) return hr;
+  *out = b.release();
+  return HIPBFV_S_OK;
+}
+
+// r_i = floor(((q mod t) * m_i + (t + 1)/2) / t): what SEAL's multiply_add_plain_with_scaling_variant adds on top of
+// floor(q/t) * m_i, so that c0 = floor(q/t)*m + r + ... exactly (logproof/src/bfv_statement.rs:159-160)
+static void scaling_remainder(const Context& cx, const std::vector<u64>& m, PlainObj* r) {
+  const u64 t = cx.t(), qt = cx.host().q_mod_t, half = (t + 1) >> 1;
+  r->coeffs.assign(cx.n(), 0);
+  for (size_t i = 0; i < m.size(); i++) r->coeffs[i] = (u64)(((unsigned __int128)qt * m[i] + half) / t);
+}
+static u64 fold_seed(const void* seed64bytes) {  // the fork passes [u64; 8]; folded into the Philox key
+  const u64* w = static_cast<const u64*>(seed64bytes);
+  u64 hsh = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < 8; i++) {
+    hsh ^= w[i] + 0x9E3779B97F4A7C15ull + (hsh << 6) + (hsh >> 2);
+    hsh *= 0xBF58476D1CE4E5B9ull;
+    hsh ^= hsh >> 31;
+  }
+  return hsh;
+}
+// shared body: symmetric (sk) or public-key encryption of one plaintext, optionally exporting u, e, r
+static long encrypt_one(EncryptorObj* e, PlainObj* p, CipherObj* c, bool symmetric, bool no_special, PolyArrayObj* u_dest, PolyArrayObj* e_dest,
+                        PlainObj* r_dest, const u64* fixed_seed) {
+  const Context& cx = *e->ctx;
+  const size_t n = cx.n(), words = cx.ct_words(2);
+  if (symmetric ? !e->sk : !e->pk) return fail(HIPBFV_COR_E_INVALIDOPERATION, symmetric ? "secret key is not set" : "public key is not set");
+  if (p->coeffs.size() > n) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
+  for (u64 v : p->coeffs)
+    if (v >= cx.t()) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
+  u64 op = 0, seed;
+  if (fixed_seed) {
+    seed = *fixed_seed;
+  } else {
+    std::lock_guard<std::mutex> g(e->mu);
+    op = e->next_op++;
+    seed = e->seed;
+  }
+  const u32 epolys = symmetric ? 1 : 2;
+  if (u_dest)
+    if (long hr = polyarray_fill(u_dest, e->ctx, 1, cx.K())) return hr;
+  if (e_dest)
+    if (long hr = polyarray_fill(e_dest, e->ctx, epolys, cx.K())) return hr;
+  std::vector<u64> coeffs(n, 0);
+  std::copy(p->coeffs.begin(), p->coeffs.end(), coeffs.begin());
+  hipStream_t s = thread_stream();
+  u64* pl = g_buffers.get(n);
+  u64* out = g_buffers.get(words);
+  if (!pl || !out) {
+    g_buffers.put(pl, n);
+    g_buffers.put(out, words);
+    return from_status(kOutOfMemory);
+  }
+  long hr = HIPBFV_S_OK;
+  int st = kOk;
+  if (hipMemcpyAsync(pl, coeffs.data(), n * sizeof(u64), hipMemcpyHostToDevice, s) != hipSuccess)
+    hr = from_status(kHipError);
+  else if (symmetric)
+    st = e->ev->encrypt_symmetric(pl, e->sk->dev, seed, op + 1, out, e_dest ? e_dest->dev : nullptr, s);
+  else
+    st = e->ev->encrypt_components(pl, e->pk->dev, seed, op, no_special, out, u_dest ? u_dest->dev : nullptr, e_dest ? e_dest->dev : nullptr, s);
+  if (hr == HIPBFV_S_OK) hr = st ? from_status(st) : sync_stream(s);
+  g_buffers.put(pl, n);
+  if (hr != HIPBFV_S_OK) {
+    g_buffers.put(out, words);
+    return hr;
+  }
+  c->adopt(e->ctx, 2, out, words);
+  if (r_dest) scaling_remainder(cx, p->coeffs, r_dest);
+  return HIPBFV_S_OK;
+}
+long Encryptor_EncryptReturnComponents(void* h, void* plaintext, bool disable_special_modulus, void* destination, void* u_destination,
+                                       void* e_destination, void* r_destination, void* pool) {
+  (void)pool;
+  EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
+  PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
+  CipherObj* c = as<CipherObj>(destination, kMagicCipher);
+  PolyArrayObj* ud = as<PolyArrayObj>(u_destination, kMagicPolyArray);
+  PolyArrayObj* ed = as<PolyArrayObj>(e_destination, kMagicPolyArray);
+  PlainObj* rd = as<PlainObj>(r_destination, kMagicPlain);
+  if (!e || !p || !c || !ud || !ed || !rd) return HIPBFV_E_POINTER;
+  return encrypt_one(e, p, c, false, disable_special_modulus, ud, ed, rd, nullptr);
+}
+long Encryptor_EncryptReturnComponentsSetSeed(void* h, void* plaintext, bool disable_special_modulus, void* destination, void* u_destination,
+                                              void* e_destination, void* r_destination, void* seed, void* pool) {
+  (void)pool;
+  EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
+  PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
+  CipherObj* c = as<CipherObj>(destination, kMagicCipher);
+  PolyArrayObj* ud = as<PolyArrayObj>(u_destination, kMagicPolyArray);
+  PolyArrayObj* ed = as<PolyArrayObj>(e_destination, kMagicPolyArray);
+  PlainObj* rd = as<PlainObj>(r_destination, kMagicPlain);
+  if (!e || !p || !c || !ud || !ed || !rd || !seed) return HIPBFV_E_POINTER;
+  const u64 sd = fold_seed(seed);
+  return encrypt_one(e, p, c, false, disable_special_modulus, ud, ed, rd, &sd);
+}
+long Encryptor_EncryptSymmetric(void* h, void* plaintext, bool save_seed, void* destination, void* pool) {
+  (void)pool;
+  (void)save_seed;  // seed-compressed ciphertexts are a serialisation option; the handle holds the expanded ciphertext
+  EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
+  PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
+  CipherObj* c = as<CipherObj>(destination, kMagicCipher);
+  if (!e || !p || !c) return HIPBFV_E_POINTER;
+  return encrypt_one(e, p, c, true, false, nullptr, nullptr, nullptr, nullptr);
+}
+long Encryptor_EncryptSymmetricReturnComponents(void* h, void* plaintext, void* destination, void* e_destination, void* r_destination, void* pool) {
+  (void)pool;
+  EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
+  PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
+  CipherObj* c = as<CipherObj>(destination, kMagicCipher);
+  PolyArrayObj* ed = as<PolyArrayObj>(e_destination, kMagicPolyArray);
+  PlainObj* rd = as<PlainObj>(r_destination, kMagicPlain);
+  if (!e || !p || !c || !ed || !rd) return HIPBFV_E_POINTER;
+  return encrypt_one(e, p, c, true, false, nullptr, ed, rd, nullptr);
+}
+long Encryptor_EncryptSymmetricReturnComponentsSetSeed(void* h, void* plaintext, void* destination, void* e_destination, void* r_destination,
+                                                       void* seed, void* pool) {
+  (void)pool;
+  EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
+  PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
+  CipherObj* c = as<CipherObj>(destination, kMagicCipher);
+  PolyArrayObj* ed = as<PolyArrayObj>(e_destination, kMagicPolyArray);
+  PlainObj* rd = as<PlainObj>(r_destination, kMagicPlain);
+  if (!e || !p || !c || !ed || !rd || !seed) return HIPBFV_E_POINTER;
+  const u64 sd = fold_seed(seed);
+  return encrypt_one(e, p, c, true, false, nullptr, ed, rd, &sd);
 }
 
 // ------------------------------------------------------------------ KeyGenerator (seal_fhe/src/key_generator.rs:20-200)

@@ -141,6 +141,12 @@ class Evaluator {
   int decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, size_t count, hipStream_t s);
   int keygen_secret(u64 seed, u64* sk_coeff, u64* sk_ntt, hipStream_t s);
   int keygen_zero_encryptions(u64 seed, u64 stream, const u64* sk_ntt, const u64* w, u64* key, u32 count, hipStream_t s);
+  // single encryptions that also return the sampled polynomials (fork-only API used by logproof), and secret-key encryption
+  int encrypt_components(const u64* plain, const u64* pk, u64 seed, u64 op, bool no_special, u64* ct2, u64* u_out, u64* e_out, hipStream_t s);
+  int encrypt_symmetric(const u64* plain, const u64* sk_ntt, u64 seed, u64 stream, u64* ct2, u64* e_out, hipStream_t s);
+  int key_to_coeff(const u64* key, u32 polys, u64* out, hipStream_t s);
+  int crt_compose(const u64* consts, u32 kc, const u64* in, u64* out, u32 polys, hipStream_t s);
+  int crt_decompose(u32 kc, const u64* in, u64* out, u32 polys, hipStream_t s);
   int keygen_kswitch(u64 seed, u64 stream, const u64* sk_coeff, const u64* sk_ntt, u32 galois_elt, u64* key, hipStream_t s);
   int plain_to_ntt(const u64* plain, size_t pstride, u64* pntt, size_t count, hipStream_t s);
   int ct_to_ntt(const u64* ct, u32 size, u64* ctn, size_t count, hipStream_t s);

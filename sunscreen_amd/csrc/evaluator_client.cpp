@@ -270,4 +270,86 @@ int Evaluator::encrypt(const u64* plain, size_t pstride, const u64* pk, u64 seed
   return add_plain(ct2, 2, plain, pstride, ct2, count, s);
 }
 
+// First K residue rows of each of `polys` key-level polynomials: src u64[polys][KK][N] -> dst u64[polys][K][N]
+static hipError_t take_data_rows(const DevCtx& h, const u64* src, u64* dst, u32 polys, hipStream_t s) {
+  const size_t row = (size_t)h.n * sizeof(u64);
+  return hipMemcpy2DAsync(dst, h.K * row, src, h.KK * row, h.K * row, polys, hipMemcpyDeviceToDevice, s);
+}
+
+// One public-key encryption that also hands back what was sampled (the fork's Encryptor_EncryptReturnComponents,
+// seal_fhe/src/encryptor_decryptor.rs:268-300): u_out u64[K][N] (ternary), e_out u64[2][K][N], coefficient-form data-level
+// residues.  no_special: compute (pk*u + e) on the data primes only, with no division by the special prime, so that
+// c0 = floor(q/t)*m + r + pk0*u + e0 and c1 = pk1*u + e1 hold EXACTLY (what logproof proves, bfv_statement.rs:159).
+int Evaluator::encrypt_components(const u64* plain, const u64* pk, u64 seed, u64 op, bool no_special, u64* ct2, u64* u_out, u64* e_out,
+                                  hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (!pk) return kInvalidArg;
+  if (h.logn > 15) return kUnsupported;
+  const u32 n = h.n, K = h.K, KK = h.KK;
+  ScratchGuard sg(pool_, 5 * (size_t)KK * n * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* u = (u64*)sg.p;
+  u64* e = u + (size_t)KK * n;
+  u64* c2 = e + 2 * (size_t)KK * n;
+  const NttPlan plan = range_plan(KK);
+  HC_CHECK(launch_encrypt_sample(ctx_->dev(), n, seed, op, u, e, 1, s));
+  if (u_out) HC_CHECK(take_data_rows(h, u, u_out, 1, s));
+  if (e_out) HC_CHECK(take_data_rows(h, e, e_out, 2, s));
+  HC_CHECK(launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, u, KK, plan, false, 0, s));
+  HC_CHECK(launch_encrypt_dyadic(ctx_->dev(), n, KK, u, pk, c2, 1, s));
+  HC_CHECK(launch_ntt(ctx_->dev(), h.tw_inv, h.logn, c2, 2 * KK, plan, true, 0, s));
+  HC_CHECK(launch_add_key_level(ctx_->dev(), n, c2, e, 2 * KK, s));
+  if (KK > 1 && !no_special) {
+    HC_CHECK(launch_ks_moddown(ctx_->dev(), n, c2, nullptr, 0, 0u, nullptr, ct2, 1, s));
+  } else {
+    HC_CHECK(take_data_rows(h, c2, ct2, 2, s));
+  }
+  return add_plain(ct2, 2, plain, 0, ct2, 1, s);
+}
+
+// Secret-key encryption (SEAL encrypt_zero_symmetric at the data level + scaled plaintext): c1 = a uniform,
+// c0 = floor(q/t)*m + r - (a*s + e).  e_out (optional): u64[K][N] coefficient-form residues of e.
+int Evaluator::encrypt_symmetric(const u64* plain, const u64* sk_ntt, u64 seed, u64 stream, u64* ct2, u64* e_out, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (!sk_ntt) return kInvalidArg;
+  if (h.logn > 15) return kUnsupported;
+  const u32 n = h.n, KK = h.KK;
+  ScratchGuard sg(pool_, 4 * (size_t)KK * n * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* a = (u64*)sg.p;
+  u64* e = a + (size_t)KK * n;
+  u64* c = e + (size_t)KK * n;
+  const NttPlan plan = range_plan(KK);
+  HC_CHECK(launch_keygen_sample(ctx_->dev(), n, seed, stream << 8, a, e, 1, s));
+  if (e_out) HC_CHECK(take_data_rows(h, e, e_out, 1, s));
+  HC_CHECK(launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, e, KK, plan, false, 0, s));
+  HC_CHECK(launch_keygen_assemble(ctx_->dev(), n, KK, a, e, sk_ntt, nullptr, c, 1, s));
+  HC_CHECK(launch_ntt(ctx_->dev(), h.tw_inv, h.logn, c, 2 * KK, plan, true, 0, s));
+  HC_CHECK(take_data_rows(h, c, ct2, 2, s));
+  return add_plain(ct2, 2, plain, 0, ct2, 1, s);
+}
+
+// Key-level NTT-form polynomials (public / secret key) as data-level coefficient-form residues: u64[polys][K][N]
+int Evaluator::key_to_coeff(const u64* key, u32 polys, u64* out, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.logn > 15) return kUnsupported;
+  const u32 n = h.n, KK = h.KK;
+  ScratchGuard sg(pool_, (size_t)polys * KK * n * sizeof(u64), s);
+  if (!sg.p) return kOutOfMemory;
+  u64* tmp = (u64*)sg.p;
+  HC_CHECK(hipMemcpyAsync(tmp, key, (size_t)polys * KK * n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  HC_CHECK(launch_ntt(ctx_->dev(), h.tw_inv, h.logn, tmp, (size_t)polys * KK, range_plan(KK), true, 0, s));
+  HC_CHECK(take_data_rows(h, tmp, out, polys, s));
+  return kOk;
+}
+
+int Evaluator::crt_compose(const u64* consts, u32 kc, const u64* in, u64* out, u32 polys, hipStream_t s) {
+  HC_CHECK(launch_crt_compose(ctx_->dev(), ctx_->host().n, kc, consts, in, out, polys, s));
+  return kOk;
+}
+int Evaluator::crt_decompose(u32 kc, const u64* in, u64* out, u32 polys, hipStream_t s) {
+  HC_CHECK(launch_crt_decompose(ctx_->dev(), ctx_->host().n, kc, in, out, polys, s));
+  return kOk;
+}
+
 }  // namespace hipbfv

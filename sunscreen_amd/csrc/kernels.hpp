@@ -62,6 +62,8 @@ hipError_t launch_keygen_assemble(const DevCtx* ctx, u32 n, u32 KK, const u64* a
 hipError_t launch_keygen_square(const DevCtx* ctx, u32 n, u32 KK, const u64* in, u64* out, hipStream_t s);
 hipError_t launch_keygen_galois(const DevCtx* ctx, u32 n, u32 KK, const u64* in, u64* out, u32 ginv, hipStream_t s);
 hipError_t launch_dot_plain(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* acc, hipStream_t s);
+hipError_t launch_crt_compose(const DevCtx* ctx, u32 n, u32 KC, const u64* consts, const u64* in, u64* out, u32 polys, hipStream_t s);
+hipError_t launch_crt_decompose(const DevCtx* ctx, u32 n, u32 KC, const u64* in, u64* out, u32 polys, hipStream_t s);
 hipError_t launch_add_key_level(const DevCtx* ctx, u32 n, u64* c, const u64* e, size_t residue_polys, hipStream_t s);
 
 }  // namespace hipbfv

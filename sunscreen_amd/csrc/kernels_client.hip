@@ -258,6 +258,75 @@ __global__ __launch_bounds__(kClientThreads) void keygen_galois_kernel(const Dev
   out[(size_t)i * n + o] = kk >= n ? neg_mod(v, ctx->mod[i].q) : v;
 }
 
+// ---- PolynomialArray (seal_fhe/src/data_structures.rs:130-304): RNS <-> multiprecision ("[poly][coeff][limb]") ----
+// consts: u64 inv_punct[KC] | punct[KC][KC] (little-endian limbs of q/q_i) | q[KC] (limbs of q)
+// x = sum_i [x_i * (q/q_i)^-1 mod q_i] * (q/q_i)  mod q, the canonical representative in [0, q)
+template <int KC>
+__global__ __launch_bounds__(kClientThreads) void crt_compose_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ consts,
+                                                                     const u64* __restrict__ in, u64* __restrict__ out) {
+  const u32 n = ctx->n;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 p = blockIdx.y;
+  if (x >= n) return;
+  const u64* inv_punct = consts;
+  const u64* punct = consts + KC;
+  const u64* qw = consts + KC + KC * KC;
+  u64 acc[KC + 1];
+#pragma unroll
+  for (int l = 0; l <= KC; l++) acc[l] = 0;
+#pragma unroll
+  for (int i = 0; i < KC; i++) {
+    const u64 y = mul_mod(in[((size_t)p * KC + i) * n + x], inv_punct[i], ctx->mod[i]);
+    u64 carry = 0;
+#pragma unroll
+    for (int l = 0; l < KC; l++) {
+      const u128 t = (u128)y * punct[i * KC + l] + acc[l] + carry;
+      acc[l] = (u64)t;
+      carry = (u64)(t >> 64);
+    }
+    acc[KC] += carry;
+  }
+  // acc < KC * q: at most KC - 1 subtractions
+  for (int round = 0; round < KC; round++) {
+    bool ge = acc[KC] != 0;
+    if (!ge) {
+      ge = true;  // equal counts as >= (x == q -> 0)
+#pragma unroll
+      for (int l = KC - 1; l >= 0; l--) {
+        if (acc[l] != qw[l]) {
+          ge = acc[l] > qw[l];
+          break;
+        }
+      }
+    }
+    if (!ge) break;
+    u64 borrow = 0;
+#pragma unroll
+    for (int l = 0; l < KC; l++) {
+      const u128 d = (u128)acc[l] - qw[l] - borrow;
+      acc[l] = (u64)d;
+      borrow = (u64)(d >> 64) & 1;
+    }
+    acc[KC] -= borrow;
+  }
+#pragma unroll
+  for (int l = 0; l < KC; l++) out[((size_t)p * n + x) * KC + l] = acc[l];
+}
+
+// out[p][i][x] = (multiprecision in[p][x][0..KC)) mod q_i, by Horner over the limbs
+__global__ __launch_bounds__(kClientThreads) void crt_decompose_kernel(const DevCtx* __restrict__ ctx, u32 KC, const u64* __restrict__ in,
+                                                                       u64* __restrict__ out) {
+  const u32 n = ctx->n;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 i = blockIdx.y, p = blockIdx.z;
+  if (x >= n) return;
+  const DevMod& dm = ctx->mod[i];
+  const u64* limbs = in + ((size_t)p * n + x) * KC;
+  u64 r = 0;
+  for (int l = (int)KC - 1; l >= 0; l--) r = reduce128(((u128)r << 64) | limbs[l], dm);
+  out[((size_t)p * KC + i) * n + x] = r;
+}
+
 // ---- plaintext-matrix x ciphertext-vector product in the transform domain (examples/pir/src/main.rs:16-45) ----
 // acc[row][p][i][x] = sum_j ctn[j][p][i][x] * pntt[row][j][i][x] mod q_i     (all NTT form, canonical residues)
 // One thread = one coefficient of one residue, RT consecutive rows and both ciphertext polynomials: every ciphertext
@@ -318,6 +387,26 @@ hipError_t launch_keygen_square(const DevCtx* ctx, u32 n, u32 KK, const u64* in,
 }
 hipError_t launch_keygen_galois(const DevCtx* ctx, u32 n, u32 KK, const u64* in, u64* out, u32 ginv, hipStream_t s) {
   keygen_galois_kernel<<<cgrid(n, KK), kClientThreads, 0, s>>>(ctx, in, out, ginv);
+  return hipGetLastError();
+}
+hipError_t launch_crt_compose(const DevCtx* ctx, u32 n, u32 KC, const u64* consts, const u64* in, u64* out, u32 polys, hipStream_t s) {
+  if (!polys) return hipSuccess;
+#define HB_CRT(K_)                                                                                 \
+  case K_:                                                                                         \
+    crt_compose_kernel<K_><<<cgrid(n, polys), kClientThreads, 0, s>>>(ctx, consts, in, out);       \
+    break;
+  switch (KC) {
+    HB_CRT(1) HB_CRT(2) HB_CRT(3) HB_CRT(4) HB_CRT(5) HB_CRT(6) HB_CRT(7) HB_CRT(8)
+    HB_CRT(9) HB_CRT(10) HB_CRT(11) HB_CRT(12) HB_CRT(13) HB_CRT(14) HB_CRT(15) HB_CRT(16)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef HB_CRT
+  return hipGetLastError();
+}
+hipError_t launch_crt_decompose(const DevCtx* ctx, u32 n, u32 KC, const u64* in, u64* out, u32 polys, hipStream_t s) {
+  if (!polys) return hipSuccess;
+  crt_decompose_kernel<<<cgrid(n, KC, polys), kClientThreads, 0, s>>>(ctx, KC, in, out);
   return hipGetLastError();
 }
 hipError_t launch_dot_plain(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* acc, hipStream_t s) {

@@ -823,20 +823,183 @@ class Decryptor:
             self._h = None
 
 
-class Encryptor:
-    """seal_fhe/src/encryptor_decryptor.rs:140-260, public-key mode (`Encryptor::with_public_key`)."""
+class PolynomialArray:
+    """seal_fhe/src/data_structures.rs:17-304 (the Sunscreen fork's export type, consumed by logproof)."""
 
-    def __init__(self, ctx: "Context", public_key: PublicKey, seed: int | None = None):
-        self._keep = (ctx, public_key)
+    def __init__(self):
         self._h = C.c_void_p()
-        _check(_lib.load().Encryptor_Create(ctx.get_handle(), public_key.get_handle(), None, C.byref(self._h)))
+        _check(_lib.load().PolynomialArray_Create(None, C.byref(self._h)))
+
+    @classmethod
+    def _adopt(cls, handle) -> "PolynomialArray":
+        a = cls.__new__(cls)
+        a._h = handle
+        return a
+
+    @classmethod
+    def new_from_ciphertext(cls, ctx: "Context", ciphertext: "Ciphertext") -> "PolynomialArray":
+        h = C.c_void_p()
+        _check(_lib.load().PolynomialArray_CreateFromCiphertext(None, ctx.get_handle(), ciphertext.get_handle(), C.byref(h)))
+        return cls._adopt(h)
+
+    @classmethod
+    def new_from_public_key(cls, ctx: "Context", public_key: PublicKey) -> "PolynomialArray":
+        h = C.c_void_p()
+        _check(_lib.load().PolynomialArray_CreateFromPublicKey(None, ctx.get_handle(), public_key.get_handle(), C.byref(h)))
+        return cls._adopt(h)
+
+    @classmethod
+    def new_from_secret_key(cls, ctx: "Context", secret_key: SecretKey) -> "PolynomialArray":
+        h = C.c_void_p()
+        _check(_lib.load().PolynomialArray_CreateFromSecretKey(None, ctx.get_handle(), secret_key.get_handle(), C.byref(h)))
+        return cls._adopt(h)
+
+    def get_handle(self):
+        return self._h
+
+    def clone(self) -> "PolynomialArray":
+        h = C.c_void_p()
+        _check(_lib.load().PolynomialArray_Copy(self._h, C.byref(h)))
+        return self._adopt(h)
+
+    def _flag(self, name: str) -> bool:
+        v = C.c_bool()
+        _check(getattr(_lib.load(), "PolynomialArray_" + name)(self._h, C.byref(v)))
+        return v.value
+
+    def _size(self, name: str) -> int:
+        v = C.c_uint64()
+        _check(getattr(_lib.load(), "PolynomialArray_" + name)(self._h, C.byref(v)))
+        return v.value
+
+    def is_reserved(self) -> bool:
+        return self._flag("IsReserved")
+
+    def is_rns(self) -> bool:
+        return self._flag("IsRns")
+
+    def is_multiprecision(self) -> bool:
+        return not self.is_rns()
+
+    def to_rns(self) -> None:
+        _check(_lib.load().PolynomialArray_ToRns(self._h))
+
+    def to_multiprecision(self) -> None:
+        _check(_lib.load().PolynomialArray_ToMultiprecision(self._h))
+
+    def num_polynomials(self) -> int:
+        return self._size("PolySize")
+
+    def poly_modulus_degree(self) -> int:
+        return self._size("PolyModulusDegree")
+
+    def coeff_modulus_size(self) -> int:
+        return self._size("CoeffModulusSize")
+
+    def as_u64s(self) -> np.ndarray:
+        out = np.empty(self._size("ExportSize"), dtype=np.uint64)
+        _check(_lib.load().PolynomialArray_PerformExport(self._h, out.ctypes.data_as(_lib.u64p)))
+        return out
+
+    def as_rns_u64s(self) -> np.ndarray:
+        """[poly][rns][coeff]; the array keeps its current format (data_structures.rs:226-243)."""
+        was_mp = self.is_reserved() and self.is_multiprecision()
+        if was_mp:
+            self.to_rns()
+        out = self.as_u64s()
+        if was_mp:
+            self.to_multiprecision()
+        return out
+
+    def as_multiprecision_u64s(self) -> np.ndarray:
+        """[poly][coeff][limb], least-significant limb first (data_structures.rs:198-224)."""
+        was_rns = self.is_reserved() and self.is_rns()
+        if was_rns:
+            self.to_multiprecision()
+        out = self.as_u64s()
+        if was_rns:
+            self.to_rns()
+        return out
+
+    def drop_modulus(self) -> "PolynomialArray":
+        if self.coeff_modulus_size() == 1:
+            raise ValueError("ModulusChainTooSmall")
+        h = C.c_void_p()
+        _check(_lib.load().PolynomialArray_Drop(self._h, C.byref(h)))
+        return self._adopt(h)
+
+    def __eq__(self, other):
+        return isinstance(other, PolynomialArray) and np.array_equal(self.as_rns_u64s(), other.as_rns_u64s())
+
+    __hash__ = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().PolynomialArray_Destroy(self._h)
+            self._h = None
+
+
+class Encryptor:
+    """seal_fhe/src/encryptor_decryptor.rs:140-600: public-key, secret-key or both (`with_public_key`,
+    `with_secret_key`, `with_public_and_secret_key`)."""
+
+    def __init__(self, ctx: "Context", public_key: PublicKey | None = None, seed: int | None = None, secret_key: SecretKey | None = None):
+        self._keep = (ctx, public_key, secret_key)
+        self._h = C.c_void_p()
+        _check(_lib.load().Encryptor_Create(ctx.get_handle(), public_key.get_handle() if public_key else None,
+                                            secret_key.get_handle() if secret_key else None, C.byref(self._h)))
         if seed is not None:
             _check(_lib.load().hipbfv_Encryptor_SetSeed(self._h, seed))
+
+    @classmethod
+    def with_public_and_secret_key(cls, ctx: "Context", public_key: PublicKey, secret_key: SecretKey) -> "Encryptor":
+        return cls(ctx, public_key, secret_key=secret_key)
+
+    @classmethod
+    def with_secret_key(cls, ctx: "Context", secret_key: SecretKey) -> "Encryptor":
+        return cls(ctx, None, secret_key=secret_key)
 
     def encrypt(self, plaintext: Plaintext) -> "Ciphertext":
         c = Ciphertext()
         _check(_lib.load().Encryptor_Encrypt(self._h, plaintext.get_handle(), c.get_handle(), None))
         return c
+
+    @staticmethod
+    def _seed_words(seed: Sequence[int]):
+        assert len(seed) == 8
+        return (C.c_uint64 * 8)(*[int(w) for w in seed])
+
+    def encrypt_return_components(self, plaintext: Plaintext, seed: Sequence[int] | None = None, disable_special_modulus: bool = True):
+        """-> (ciphertext, u, e, r); with `seed` ([u64; 8]) it is the fork's encrypt_return_components_deterministic."""
+        c, u, e, r = Ciphertext(), PolynomialArray(), PolynomialArray(), Plaintext()
+        L = _lib.load()
+        if seed is None:
+            _check(L.Encryptor_EncryptReturnComponents(self._h, plaintext.get_handle(), disable_special_modulus, c.get_handle(),
+                                                       u.get_handle(), e.get_handle(), r.get_handle(), None))
+        else:
+            _check(L.Encryptor_EncryptReturnComponentsSetSeed(self._h, plaintext.get_handle(), disable_special_modulus, c.get_handle(),
+                                                              u.get_handle(), e.get_handle(), r.get_handle(), self._seed_words(seed), None))
+        return c, u, e, r
+
+    def encrypt_deterministic(self, plaintext: Plaintext, seed: Sequence[int]) -> "Ciphertext":
+        return self.encrypt_return_components(plaintext, seed, disable_special_modulus=False)[0]
+
+    def encrypt_symmetric(self, plaintext: Plaintext) -> "Ciphertext":
+        c = Ciphertext()
+        _check(_lib.load().Encryptor_EncryptSymmetric(self._h, plaintext.get_handle(), False, c.get_handle(), None))
+        return c
+
+    def encrypt_symmetric_return_components(self, plaintext: Plaintext, seed: Sequence[int] | None = None):
+        """-> (ciphertext, e, r)."""
+        c, e, r = Ciphertext(), PolynomialArray(), Plaintext()
+        L = _lib.load()
+        if seed is None:
+            _check(L.Encryptor_EncryptSymmetricReturnComponents(self._h, plaintext.get_handle(), c.get_handle(), e.get_handle(),
+                                                                r.get_handle(), None))
+        else:
+            _check(L.Encryptor_EncryptSymmetricReturnComponentsSetSeed(self._h, plaintext.get_handle(), c.get_handle(), e.get_handle(),
+                                                                       r.get_handle(), self._seed_words(seed), None))
+        return c, e, r
 
     def __del__(self):
         if getattr(self, "_h", None):

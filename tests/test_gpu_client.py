@@ -390,3 +390,146 @@ def test_device_only_round_trip_keygen_encrypt_evaluate_decrypt():
     with pytest.raises(HipBfvError) as ei:
         KeyGenerator(Context.from_raw(n2, primes2, t2)).create_relinearization_keys()
     assert ei.value.kind == "InternalError"  # COR_E_INVALIDOPERATION, as convert_seal_error maps it (error.rs:82-91)
+
+
+# ---- the fork-only export path logproof consumes: PolynomialArray + encryption components -----------
+@pytest.mark.parametrize("name", ["seal_fhe_unit", "default_4096_16", "default_16384_17"])
+def test_polynomial_array_and_encryption_components(name):
+    """seal_fhe/src/data_structures.rs:330-534 (sizes, round trips, clone, drop) plus what logproof relies on
+    (bfv_statement.rs:159-160): the returned u, e, r satisfy the encryption equations EXACTLY over the data primes."""
+    from sunscreen_amd import (BFVEncoder, Ciphertext, Context, Decryptor, Encryptor, KeyGenerator, Plaintext, PolynomialArray)
+
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    K = len(primes) - 1
+    q = 1
+    for p in primes[:K]:
+        q *= p
+    ctx = Context.from_raw(n, primes, t)
+    kg = KeyGenerator(ctx, seed=3)
+    pk, sk = kg.create_public_key(), kg.secret_key()
+    enc = Encryptor.with_public_and_secret_key(ctx, pk, sk)
+    dec = Decryptor(ctx, sk)
+    be = BFVEncoder(ctx)
+    data = [i % t for i in range(n)]
+    plain = be.encode_unsigned(data)
+    m = np.array([plain.get_coefficient(i) for i in range(n)], dtype=object)
+
+    ct, u, e, r = enc.encrypt_return_components(plain)
+    assert be.decode_unsigned(dec.decrypt(ct)) == data
+    assert dec.invariant_noise_budget(ct) > 0
+    pa_pk = PolynomialArray.new_from_public_key(ctx, pk)
+    pa_sk = PolynomialArray.new_from_secret_key(ctx, sk)
+    pa_ct = PolynomialArray.new_from_ciphertext(ctx, ct)
+    for a, polys in ((pa_pk, 2), (pa_sk, 1), (pa_ct, 2), (u, 1), (e, 2)):
+        assert a.is_reserved() and a.is_rns()
+        assert (a.num_polynomials(), a.poly_modulus_degree(), a.coeff_modulus_size()) == (polys, n, K)
+        assert a.as_u64s().size == polys * n * K
+    assert r.len() == n
+    assert not PolynomialArray().is_reserved()
+    assert PolynomialArray.new_from_ciphertext(ctx, Ciphertext()).is_reserved()
+    # poly_array_u64_and_bytes_match: the array of a ciphertext is the ciphertext's data
+    assert (pa_ct.as_u64s() == ct.to_array().ravel()).all()
+    assert [ct.get_data(i) for i in (0, 1, n, 2 * K * n - 1)] == [int(pa_ct.as_u64s()[i]) for i in (0, 1, n, 2 * K * n - 1)]
+    # keys come out of NTT form, restricted to the data primes
+    skn = sk.to_array(ctx)
+    s_rns = pa_sk.as_rns_u64s().reshape(K, n)
+    for i in range(K):
+        assert (s_rns[i] == o.ntt(i, skn[i], inverse=True)).all()
+    pkn = pk.to_array(ctx)
+    p_rns = pa_pk.as_rns_u64s().reshape(2, K, n)
+    assert (p_rns[1, K - 1] == o.ntt(K - 1, pkn[1, K - 1], inverse=True)).all()
+    # multiprecision: [poly][coeff][limb], the CRT-composed value in [0, q); and back is the identity
+    before = pa_ct.as_u64s().copy()
+    mp = pa_ct.as_multiprecision_u64s().reshape(2, n, K)
+    assert pa_ct.is_rns() and (pa_ct.as_u64s() == before).all()
+    rns = before.reshape(2, K, n)
+    for p_ in range(2):
+        for x in (0, 1, n // 2, n - 1):
+            v = sum(int(mp[p_, x, l]) << (64 * l) for l in range(K))
+            assert v < q
+            assert [v % primes[i] for i in range(K)] == [int(rns[p_, i, x]) for i in range(K)]
+    pa_ct.to_multiprecision()
+    assert pa_ct.is_multiprecision() and (pa_ct.as_u64s() == mp.ravel()).all()
+    assert (pa_ct.as_rns_u64s() == before).all() and pa_ct.is_multiprecision()
+    pa_ct.to_rns()
+    assert (pa_ct.as_u64s() == before).all()
+    # small polynomials compose to small values or q - small
+    ump = u.as_multiprecision_u64s().reshape(n, K)
+    uv = [sum(int(ump[x, l]) << (64 * l) for l in range(K)) for x in range(64)]
+    assert set(uv) <= {0, 1, q - 1}
+
+    def centred(a, i):
+        return _centred(a, primes[i])
+
+    u_rns, e_rns = u.as_rns_u64s().reshape(K, n), e.as_rns_u64s().reshape(2, K, n)
+    assert set(np.unique(centred(u_rns[0], 0)).tolist()) <= {-1, 0, 1}
+    assert np.abs(centred(e_rns[0, 0], 0).astype(np.float64)).max() <= 19
+    for i in range(1, K):
+        assert (centred(u_rns[i], i) == centred(u_rns[0], 0)).all() and (centred(e_rns[1, i], i) == centred(e_rns[1, 0], 0)).all()
+    rv = np.array([r.get_coefficient(i) for i in range(n)], dtype=object)
+    assert (rv == ((q % t) * m + (t + 1) // 2) // t).all()
+    delta = q // t
+    c = ct.to_array()
+
+    def negacyclic(a_i, b_i, i):
+        prod = _dyadic(o.ntt(i, a_i), o.ntt(i, b_i), primes[i])
+        return o.ntt(i, prod, inverse=True).astype(object)
+
+    for i in range(K):
+        qi = primes[i]
+        want0 = (delta % qi * m + rv + negacyclic(p_rns[0, i], u_rns[i], i) + e_rns[0, i].astype(object)) % qi
+        want1 = (negacyclic(p_rns[1, i], u_rns[i], i) + e_rns[1, i].astype(object)) % qi
+        assert (c[0, i].astype(object) == want0).all() and (c[1, i].astype(object) == want1).all(), i
+
+    # secret-key mode: c0 = delta m + r - (c1 s + e)
+    cs, es, rs = enc.encrypt_symmetric_return_components(plain)
+    assert es.num_polynomials() == 1 and es.coeff_modulus_size() == K and rs.len() == n
+    assert be.decode_unsigned(dec.decrypt(cs)) == data
+    assert (np.array([rs.get_coefficient(i) for i in range(n)], dtype=object) == rv).all()
+    csa, es_rns = cs.to_array(), es.as_rns_u64s().reshape(K, n)
+    assert np.abs(centred(es_rns[0], 0).astype(np.float64)).max() <= 19
+    for i in range(K):
+        qi = primes[i]
+        want0 = (delta % qi * m + rv - negacyclic(csa[1, i], s_rns[i], i) - es_rns[i].astype(object)) % qi
+        assert (csa[0, i].astype(object) == want0).all(), i
+    c2 = enc.encrypt_symmetric(plain)
+    assert be.decode_unsigned(dec.decrypt(c2)) == data
+    assert dec.invariant_noise_budget(c2) >= dec.invariant_noise_budget(enc.encrypt(plain)) - 1  # symmetric noise is no larger
+    assert not (c2.to_array() == cs.to_array()).all()
+    only_sk = Encryptor.with_secret_key(ctx, sk)
+    assert be.decode_unsigned(dec.decrypt(only_sk.encrypt_symmetric(plain))) == data
+    from sunscreen_amd import HipBfvError
+
+    with pytest.raises(HipBfvError):
+        only_sk.encrypt(plain)
+    with pytest.raises(HipBfvError):
+        Encryptor(ctx, pk).encrypt_symmetric(plain)
+
+    # the "deterministic" feature: equal seeds, equal ciphertexts and components (encryptor_decryptor.rs:886-935)
+    z = [0] * 8
+    d1, d2 = enc.encrypt_deterministic(plain, z), enc.encrypt_deterministic(plain, z)
+    assert (d1.to_array() == d2.to_array()).all() and be.decode_unsigned(dec.decrypt(d1)) == data
+    assert not (enc.encrypt_deterministic(plain, [1] + [0] * 7).to_array() == d1.to_array()).all()
+    k1, k2 = enc.encrypt_return_components(plain, z), enc.encrypt_return_components(plain, z)
+    assert (k1[0].to_array() == k2[0].to_array()).all() and k1[1] == k2[1] and k1[2] == k2[2]
+    s1, s2 = enc.encrypt_symmetric_return_components(plain, z), enc.encrypt_symmetric_return_components(plain, z)
+    assert (s1[0].to_array() == s2[0].to_array()).all() and s1[1] == s2[1]
+    # clone / drop (data_structures.rs:497-533)
+    uc = u.clone()
+    assert uc == u and uc.get_handle().value != u.get_handle().value
+    if K > 1:
+        low = pa_pk.drop_modulus()
+        assert (low.num_polynomials(), low.poly_modulus_degree(), low.coeff_modulus_size()) == (2, n, K - 1)
+        assert (low.as_rns_u64s().reshape(2, K - 1, n) == p_rns[:, : K - 1]).all()
+        lmp = low.as_multiprecision_u64s().reshape(2, n, K - 1)
+        v = sum(int(lmp[1, 5, l]) << (64 * l) for l in range(K - 1))
+        assert [v % primes[i] for i in range(K - 1)] == [int(p_rns[1, i, 5]) for i in range(K - 1)]
+    # components of a lower level of the chain: the array follows the ciphertext's level
+    from sunscreen_amd import BFVEvaluator
+
+    if K > 1:
+        lower = BFVEvaluator(ctx).mod_switch_to_next(ct)
+        pl = PolynomialArray.new_from_ciphertext(ctx, lower)
+        assert pl.coeff_modulus_size() == K - 1 and (pl.as_u64s() == lower.to_array().ravel()).all()
+    assert isinstance(r, Plaintext)
