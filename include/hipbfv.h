@@ -151,6 +151,7 @@ long Decryptor_Create(void *context, void *secret_key, void **decryptor);
 long Decryptor_Destroy(void *thisptr);
 long Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination);
 long Decryptor_InvariantNoiseBudget(void *thisptr, void *encrypted, int *invariant_noise_budget);
+long Decryptor_InvariantNoise(void *thisptr, void *encrypted, double *invariant_noise); /* fork: encryptor_decryptor.rs:660-683 */
 
 /* ---- Encryptor (seal_fhe/src/encryptor_decryptor.rs:140-600).  The randomness is the library's own (Philox4x32-10;
  * ternary u, rounded Gaussian sigma 3.2 clipped at 19, uniform a): ciphertexts are valid SEAL ciphertexts but, like

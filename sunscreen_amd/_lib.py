@@ -157,7 +157,7 @@ _SIGNATURES = {
     "BatchEncoder_Decode1": [vp, vp, u64p, u64p, vp], "BatchEncoder_Decode2": [vp, vp, u64p, C.POINTER(C.c_int64), vp],
     "BatchEncoder_GetSlotCount": [vp, u64p],
     "Decryptor_Create": [vp, vp, vpp], "Decryptor_Destroy": [vp], "Decryptor_Decrypt": [vp, vp, vp],
-    "Decryptor_InvariantNoiseBudget": [vp, vp, C.POINTER(C.c_int)],
+    "Decryptor_InvariantNoiseBudget": [vp, vp, C.POINTER(C.c_int)], "Decryptor_InvariantNoise": [vp, vp, C.POINTER(C.c_double)],
     "Encryptor_Create": [vp, vp, vp, vpp], "Encryptor_Destroy": [vp], "Encryptor_Encrypt": [vp, vp, vp, vp],
     "Encryptor_EncryptReturnComponents": [vp, vp, C.c_bool, vp, vp, vp, vp, vp],
     "Encryptor_EncryptReturnComponentsSetSeed": [vp, vp, C.c_bool, vp, vp, vp, vp, vp, vp],

@@ -2048,10 +2048,11 @@ u64 invmod64(u64 a, u64 q) {  // q prime
 }
 }  // namespace
 
-long Decryptor_InvariantNoiseBudget(void* h, void* encrypted, int* budget) {
+// max_x |[t * ct(s)]_q|_x (centred) and q, as big integers: the quantity behind both noise measures
+static long invariant_noise_norm(void* h, void* encrypted, Big* worst_out, Big* q_out) {
   DecryptorObj* d = as<DecryptorObj>(h, kMagicDecryptor);
   CipherObj* c = as<CipherObj>(encrypted, kMagicCipher);
-  if (!d || !c || !budget) return HIPBFV_E_POINTER;
+  if (!d || !c) return HIPBFV_E_POINTER;
   EvalObj* le = c->ctx ? level_eval(&d->core, c->ctx) : nullptr;
   if (!le || !c->dev || c->size < 2) return fail(HIPBFV_E_INVALIDARG, "encrypted is not valid for encryption parameters");
   const Context& cx = *le->ctx;
@@ -2092,7 +2093,7 @@ long Decryptor_InvariantNoiseBudget(void* h, void* encrypted, int* budget) {
     }
     scale[i] = mulmod64(cx.t() % q[i], invmod64(pm, q[i]), q[i]);
   }
-  int worst = 0;
+  Big worst(len);
   for (size_t x = 0; x < n; x++) {
     Big v(len);
     for (size_t i = 0; i < K; i++) v.add_mul(punct[i], mulmod64(ph[i * n + x], scale[i], q[i]));
@@ -2102,9 +2103,31 @@ long Decryptor_InvariantNoiseBudget(void* h, void* encrypted, int* budget) {
       r.sub(v);
       v = r;
     }
-    worst = std::max(worst, v.bits());
+    if (v.cmp(worst) > 0) worst = v;
   }
-  *budget = std::max(0, Q.bits() - worst - 1);
+  *worst_out = worst;
+  *q_out = Q;
+  return HIPBFV_S_OK;
+}
+long Decryptor_InvariantNoiseBudget(void* h, void* encrypted, int* budget) {
+  if (!budget) return HIPBFV_E_POINTER;
+  Big worst(1), Q(1);
+  if (long hr = invariant_noise_norm(h, encrypted, &worst, &Q)) return hr;
+  *budget = std::max(0, Q.bits() - worst.bits() - 1);
+  return HIPBFV_S_OK;
+}
+// the fork's f64 variant (encryptor_decryptor.rs:660-683): the infinity norm of the invariant noise polynomial,
+// |[t * ct(s)]_q| / q; decryption is correct while it stays below 1/2
+long Decryptor_InvariantNoise(void* h, void* encrypted, double* invariant_noise) {
+  if (!invariant_noise) return HIPBFV_E_POINTER;
+  Big worst(1), Q(1);
+  if (long hr = invariant_noise_norm(h, encrypted, &worst, &Q)) return hr;
+  auto to_ld = [](const Big& b) {
+    long double v = 0;
+    for (size_t i = b.w.size(); i-- > 0;) v = v * 18446744073709551616.0L + (long double)b.w[i];
+    return v;
+  };
+  *invariant_noise = (double)(to_ld(worst) / to_ld(Q));
   return HIPBFV_S_OK;
 }
 

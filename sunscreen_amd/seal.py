@@ -817,6 +817,12 @@ class Decryptor:
         _check(_lib.load().Decryptor_InvariantNoiseBudget(self._h, ciphertext.get_handle(), C.byref(b)))
         return b.value
 
+    def invariant_noise(self, ciphertext: "Ciphertext") -> float:
+        """|[t * ct(s)]_q|_inf / q (encryptor_decryptor.rs:660-683); decryption is correct below 1/2."""
+        v = C.c_double()
+        _check(_lib.load().Decryptor_InvariantNoise(self._h, ciphertext.get_handle(), C.byref(v)))
+        return v.value
+
     def __del__(self):
         if getattr(self, "_h", None):
             _lib.load().Decryptor_Destroy(self._h)

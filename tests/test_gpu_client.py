@@ -379,6 +379,12 @@ def test_device_only_round_trip_keygen_encrypt_evaluate_decrypt():
     sq = ev.relinearize(ev.multiply(a, a), rk)
     assert be.decode_signed(dec.decrypt(sq)) == [((x * x + t // 2) % t) - t // 2 for x in v]
     assert 0 < dec.invariant_noise_budget(sq) < fresh
+    # the f64 noise measure (encryptor_decryptor.rs:660-683) tells the same story: budget ~ -log2(2 * noise)
+    import math
+
+    na, nsq = dec.invariant_noise(a), dec.invariant_noise(sq)
+    assert 0 < na < nsq < 0.5
+    assert abs(-math.log2(2 * na) - fresh) <= 1 and abs(-math.log2(2 * nsq) - dec.invariant_noise_budget(sq)) <= 1
     r = be.decode_signed(dec.decrypt(ev.rotate_rows(a, -1, gk)))
     half = n // 2
     assert r[:half] == v[half - 1 : half] + v[: half - 1] and r[half:] == v[n - 1 :] + v[half : n - 1]
