@@ -71,6 +71,7 @@ long SEALContext_Destroy(void *thisptr);
 
 /* ---- Plaintext (seal_fhe/src/plaintext_ciphertext.rs:36-300) ---- */
 long Plaintext_Create1(void *pool, void **plaintext);
+long Plaintext_Create4(char *hex_poly, void *pool, void **plaintext); /* "7FFx^3 + 1x^1 + 3", plaintext_ciphertext.rs:180-217 */
 long Plaintext_Create5(void *copy, void **plaintext);
 long Plaintext_Destroy(void *thisptr);
 long Plaintext_CoeffCount(void *thisptr, uint64_t *coeff_count);

@@ -49,7 +49,7 @@ _SIGNATURES = {
     "SEALContext_Create": [vp, C.c_bool, C.c_int, vpp],
     "SEALContext_Destroy": [vp],
     "Plaintext_Create1": [vp, vpp],
-    "Plaintext_Create5": [vp, vpp],
+    "Plaintext_Create5": [vp, vpp], "Plaintext_Create4": [C.c_char_p, vp, vpp],
     "Plaintext_Destroy": [vp],
     "Plaintext_CoeffCount": [vp, u64p],
     "Plaintext_CoeffAt": [vp, u64, u64p],

@@ -620,6 +620,59 @@ long Plaintext_Create1(void* pool, void** out) {
   return HIPBFV_S_OK;
 }
 
+// Plaintext from SEAL's polynomial string "7FFx^3 + 1x^1 + 3" (plaintext_ciphertext.rs:180-217): hexadecimal
+// coefficients, decimal exponents, strictly decreasing, terms separated by " + ", constant term without "x^"
+long Plaintext_Create4(char* hex_poly, void* pool, void** out) {
+  (void)pool;
+  if (!hex_poly || !out) return HIPBFV_E_POINTER;
+  std::vector<std::pair<u64, u64>> terms;  // (exponent, coefficient)
+  const char* p = hex_poly;
+  auto bad = [] { return fail(HIPBFV_E_INVALIDARG, "unable to parse hex_poly"); };
+  while (*p) {
+    u64 coeff = 0;
+    int digits = 0;
+    for (;; p++, digits++) {
+      int v;
+      if (*p >= '0' && *p <= '9') v = *p - '0';
+      else if (*p >= 'a' && *p <= 'f') v = *p - 'a' + 10;
+      else if (*p >= 'A' && *p <= 'F') v = *p - 'A' + 10;
+      else break;
+      if (coeff >> 60) return bad();
+      coeff = (coeff << 4) | (u64)v;
+    }
+    if (!digits) return bad();
+    u64 expo = 0;
+    if (*p == 'x') {
+      if (p[1] != '^') return bad();
+      p += 2;
+      int ed = 0;
+      for (; *p >= '0' && *p <= '9'; p++, ed++) {
+        if (expo > (1u << 20)) return bad();
+        expo = expo * 10 + (u64)(*p - '0');
+      }
+      if (!ed || !expo) return bad();
+    }
+    if (!terms.empty() && expo >= terms.back().first) return bad();
+    terms.emplace_back(expo, coeff);
+    if (!*p) break;
+    if (expo == 0 || std::strncmp(p, " + ", 3) != 0) return bad();
+    p += 3;
+    if (!*p) return bad();
+  }
+  PlainObj* n = new PlainObj();
+  if (!terms.empty()) {
+    // SEAL sizes the plaintext by its significant coefficients
+    size_t top = 0;
+    for (auto& t : terms)
+      if (t.second) top = std::max<size_t>(top, t.first + 1);
+    n->coeffs.assign(top, 0);
+    for (auto& t : terms)
+      if (t.second) n->coeffs[t.first] = t.second;
+  }
+  *out = n;
+  return HIPBFV_S_OK;
+}
+
 long Plaintext_Create5(void* copy, void** out) {
   PlainObj* p = as<PlainObj>(copy, kMagicPlain);
   if (!p || !out) return HIPBFV_E_POINTER;

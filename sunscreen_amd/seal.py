@@ -277,6 +277,14 @@ class Plaintext:
                 p.set_coefficient(i, int(c))
         return p
 
+    @classmethod
+    def from_hex_string(cls, hex_str: str) -> "Plaintext":
+        """SEAL's polynomial string, e.g. "1234x^2 + 4321" (plaintext_ciphertext.rs:180-217)."""
+        p = cls.__new__(cls)
+        p._h = C.c_void_p()
+        _check(_lib.load().Plaintext_Create4(hex_str.encode(), None, C.byref(p._h)))
+        return p
+
     def get_handle(self):
         return self._h
 

@@ -127,3 +127,21 @@ def test_plaintext_literal_decoding_is_host_only():
         with pytest.raises(HipBfvError) as ei:
             FheProgram().append_plaintext_literal(junk)
         assert ei.value.kind == "InvalidArgument"
+
+
+def test_plaintext_from_hex_string():
+    """plaintext_ciphertext.rs:524-531 (`plaintext_coefficients_in_increasing_order`) and the encoder's scalar path
+    (encoder.rs:236-245), plus the format rules listed at plaintext_ciphertext.rs:184-200."""
+    from sunscreen_amd import HipBfvError, Plaintext
+
+    p = Plaintext.from_hex_string("1234x^2 + 4321")
+    assert [p.get_coefficient(i) for i in range(3)] == [0x4321, 0, 0x1234] and p.len() == 3
+    assert Plaintext.from_hex_string("7FFx^3 + 1x^1 + 3").len() == 4
+    q = Plaintext.from_hex_string(format(0xDEADBEEF, "x"))
+    assert q.len() == 1 and q.get_coefficient(0) == 0xDEADBEEF
+    assert Plaintext.from_hex_string("0").len() == 0
+    assert Plaintext.from_hex_string("aBcx^10").get_coefficient(10) == 0xABC
+    assert Plaintext.from_hex_string("").len() == 0
+    for junk in ("x^2", "1x", "1x^", "1x^0", "1x^1 + 2x^1", "1x^1 + 2x^2", "3 + 1x^1", "1x^2+3", "1x^2 + ", "-1", "1 x^2", "12345678901234567x^1"):
+        with pytest.raises(HipBfvError):
+            Plaintext.from_hex_string(junk)
