@@ -145,3 +145,25 @@ def test_plaintext_from_hex_string():
     for junk in ("x^2", "1x", "1x^", "1x^0", "1x^1 + 2x^1", "1x^1 + 2x^2", "3 + 1x^1", "1x^2+3", "1x^2 + ", "-1", "1 x^2", "12345678901234567x^1"):
         with pytest.raises(HipBfvError):
             Plaintext.from_hex_string(junk)
+
+
+def test_every_ffi_symbol_the_reference_binds_is_exported():
+    """The drop-in claim, mechanically: each `bindgen::X(...)` the seal_fhe crate calls (list generated from the reference
+    by tests/golden/make_ffi_symbol_list.py) is declared in include/hipbfv.h with the same number of parameters and
+    exported by libhipbfv.so."""
+    from sunscreen_amd import _lib
+
+    lib = _lib.load()
+    wanted = [ln.split() for ln in open(os.path.join(ROOT, "tests", "golden", "seal_fhe_ffi_symbols.txt")).read().splitlines() if ln]
+    assert len(wanted) >= 120
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hipbfv.h")).read(), flags=re.S)
+    declared = {m.group(1): m.group(2) for m in re.finditer(r"^long\s+([A-Za-z_0-9]+)\s*\(([^;]*)\)\s*;", header, flags=re.M)}
+    problems = []
+    for name, argc in wanted:
+        if name not in declared or not hasattr(lib, name):
+            problems.append((name, "missing"))
+            continue
+        params = [a for a in declared[name].split(",") if a.strip() and a.strip() != "void"]
+        if len(params) != int(argc):
+            problems.append((name, f"{len(params)} parameters, the reference passes {argc}"))
+    assert not problems, problems
