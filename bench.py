@@ -302,6 +302,7 @@ def main():
         name, rec = dom
         # algorithmic bytes of one launch of that kernel
         S_, R_ = ctx_S(ctx), K + ctx_S(ctx)
+        bm, bk = (6 if getattr(ctx, "packed_mul", False) else 8), (6 if getattr(ctx, "packed_ks", False) else 8)
         per_unit = {
             # whole-polynomial path (kernels.hip)
             "ntt_fwd": 16 * n, "ntt_inv": 16 * n,                    # per residue polynomial: read + write
@@ -310,8 +311,10 @@ def main():
             "behz_floor_sk": 8 * n * (R_ + K),                       # per polynomial
             "ks_decompose": 8 * n * (K + KK * K), "ks_mac": 8 * n * (KK * K + 2 * KK), "ks_moddown": 8 * n * (2 * KK + 4 * K),
             # split path (kernels_split.hip); units: polynomials for mul_head / mul_tail, ops otherwise
-            "mul_head": 8 * n * (K + R_), "mul_mid": 8 * n * 7 * R_, "mul_tail": 8 * n * (R_ + K),
-            "ks_head": 8 * n * (K + KK * K), "ks_mid": 8 * n * (KK * K + 2 * KK), "ks_tail": 8 * n * (2 * KK + 4 * K),
+            # (intermediates travel as 6 bytes per value when the context packs them, 8 otherwise: bm / bk)
+            "mul_head": n * (8 * K + bm * R_), "mul_mid": bm * n * 7 * R_, "mul_tail": n * (bm * R_ + 8 * K),
+            "ks_head": n * (8 * K + bk * KK * K), "ks_mid": n * bk * (KK * K + 2 * KK),
+            "ks_tail": n * (bk * 2 * KK + 32 * K),
             "galois": 16 * n * K, "eltwise": 24 * n,                 # per polynomial / per residue polynomial (2 reads + 1 write)
         }.get(name, 16 * n)
         avg_ms = rec["ms"] / rec["launches"]

@@ -575,6 +575,20 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       h.mid_res_i[h.mid_ni++] = (unsigned char)r;
   }
 
+  {
+    bool ks = true, mul = h.aux_f64 != 0;
+    const u64 lim = 1ull << 48;
+    for (u32 i = 0; i < KK; i++) ks = ks && h.mod[i].use_f64 && h.mod[i].split_ok && h.mod[i].q < lim;
+    for (u32 r = 0; r < K + h.S; r++) {
+      const DevMod& dm = h.mod[r < K ? r : KK + (r - K)];
+      mul = mul && dm.use_f64 && dm.split_ok && dm.q < lim;
+    }
+    if (const char* env = std::getenv("HIPBFV_NO_PACK"))
+      if (env[0] == '1') ks = mul = false;
+    h.pack_ks = ks ? 1 : 0;
+    h.pack_mul = mul ? 1 : 0;
+  }
+
   // ---- key switching ----
   if (KK > 1) {
     const u64 qsp = key_primes[KK - 1];

@@ -92,7 +92,9 @@ struct DevCtx {
   // takes the FP64 split path, the auxiliary base is the library's own (context.cpp), and the head / tail
   // kernels run the BEHZ conversions in exact double arithmetic
   u32 aux_f64;
-  u32 pad3;
+  // 48-bit packed intermediates in the split pipelines (kernels_split.hip nat_load/nat_store): every modulus involved is an
+  // FP64-policy prime below 2^48.  pack_ks: the KK key primes; pack_mul: aux_f64 and the K data + S auxiliary primes.
+  unsigned char pack_ks, pack_mul, pad3[2];
   MulOpD ext_scale_d[kMaxKey];
   double q_to_bsk_d[kMaxBsk][kMaxKey];
   double q_mod_bsk_d[kMaxBsk];

@@ -285,7 +285,7 @@ int Evaluator::encrypt_components(const u64* plain, const u64* pk, u64 seed, u64
   const DevCtx& h = ctx_->host();
   if (!pk) return kInvalidArg;
   if (h.logn > 15) return kUnsupported;
-  const u32 n = h.n, K = h.K, KK = h.KK;
+  const u32 n = h.n, KK = h.KK;
   ScratchGuard sg(pool_, 5 * (size_t)KK * n * sizeof(u64), s);
   if (!sg.p) return kOutOfMemory;
   u64* u = (u64*)sg.p;

@@ -386,21 +386,59 @@ __device__ __forceinline__ void mid_inverse_multi(const A& ar, typename A::V (&v
 }
 
 constexpr int kHeadThreads = 256;
+#ifndef MID_FWD_PAIRS
+#define MID_FWD_PAIRS false
+#endif
 #ifndef MID_WAVES_D
 #define MID_WAVES_D 2
 #endif
 #ifndef MID_WAVES_I
 #define MID_WAVES_I 3
 #endif
+#ifndef KS_GROUP_MAX
+#define KS_GROUP_MAX 4  // digits transformed together in ks_mid (4 or 2): LDS = KS_GROUP_MAX * 16 KB per workgroup
+#endif
 #ifndef KS_MID_WAVES
 #define KS_MID_WAVES 2
 #endif
 
 // -------------------------------------------------------------------------------------------------
+// 48-bit packed storage of FP64-policy intermediates (PACK): every kernel of the split pipelines is HBM-bound or
+// close to it and its intermediates are integers below 2^47 in magnitude once reduced, so they travel as 6 bytes instead
+// of 8.  A residue polynomial keeps its 8N-byte region; the first 4N bytes hold the low words (u32 plane), the next
+// 2N bytes bits 32..47 (i16 plane) of the two's-complement value: both planes are read and written fully coalesced.
+// Packing/unpacking rides on the 2^52-magic conversion: r + 1.5*2^52 has mantissa 2^51 + r.
+// -------------------------------------------------------------------------------------------------
+constexpr double kPackMagic = 6755399441055744.0;  // 2^52 + 2^51
+
+template <bool PACK>
+__device__ __forceinline__ double nat_load(const double* __restrict__ region, u32 n, size_t idx) {
+  if constexpr (!PACK) {
+    return region[idx];
+  } else {
+    const u32 lo = reinterpret_cast<const u32*>(region)[idx];
+    const int hi = reinterpret_cast<const short*>(reinterpret_cast<const char*>(region) + 4 * (size_t)n)[idx];
+    const u32 hw = 0x43300000u | (((u32)hi & 0xFFFFFu) ^ 0x80000u);
+    return __hiloint2double((int)hw, (int)lo) - kPackMagic;
+  }
+}
+// PACK: v must be an integer with |v| < 2^47 (callers reduce first)
+template <bool PACK>
+__device__ __forceinline__ void nat_store(double* __restrict__ region, u32 n, size_t idx, double v) {
+  if constexpr (!PACK) {
+    region[idx] = v;
+  } else {
+    const double m = v + kPackMagic;
+    reinterpret_cast<u32*>(region)[idx] = (u32)__double2loint(m);
+    reinterpret_cast<short*>(reinterpret_cast<char*>(region) + 4 * (size_t)n)[idx] = (short)__double2hiint(m);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // key switch, head: T[op][I][J] = first three forward stages over q_I of (target_J mod q_I)
 // grid: (N/8/256, K, ops)
 // -------------------------------------------------------------------------------------------------
-template <int L>
+template <int L, bool PACK>
 __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                const u64* __restrict__ target, size_t tstride, double* __restrict__ T) {
   constexpr int NC = 1 << head_log(L);
@@ -425,9 +463,9 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
       v[k] = need_reduce ? ar.reduce(d) : d;
     }
     head_fwd(ar, v, tw);
-    double* dst = T + (((size_t)op * KK + I) * K + J) * N + t;
+    double* dst = T + (((size_t)op * KK + I) * K + J) * N;
 #pragma unroll
-    for (int k = 0; k < NC; k++) dst[(size_t)k * Q] = v[k];
+    for (int k = 0; k < NC; k++) nat_store<PACK>(dst, N, t + (size_t)k * Q, PACK ? ar.reduce(v[k]) : v[k]);
   }
 }
 
@@ -436,13 +474,13 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
 // key rows, run the block-local inverse stages of both accumulators.
 // grid: ops8 * KK * NBLK (slice-major per XCD, see the index computation)
 // -------------------------------------------------------------------------------------------------
-template <int L>
+template <int L, bool PACK>
 __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                        const MulOp* __restrict__ twi_base, const double* __restrict__ T,
                                                                        const u64* __restrict__ key, double* __restrict__ ACC, u32 ops) {
   using Sh = SplitShape<L>;
   using A = ArithD;
-  __shared__ double smem[4 * Sh::BLOCK];
+  __shared__ double smem[KS_GROUP_MAX * Sh::BLOCK];
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, KK = ctx->KK;
   const u32 b = blockIdx.x;
@@ -471,7 +509,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
 #pragma unroll
     for (int g = 0; g < First::G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+      for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = nat_load<PACK>(src, Sh::N, First::elem(tid, blk, g, k));
   };
   auto load_keys = [&](u32 J, ulonglong2(&ka)[kBlkEPT / 2], ulonglong2(&kc)[kBlkEPT / 2]) {
     const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
@@ -518,11 +556,9 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
   };
   u32 J = 0;
-  for (; J + 4 <= K; J += 4) group(J, std::integral_constant<int, 4>{});
-  if (J + 2 <= K) {
-    group(J, std::integral_constant<int, 2>{});
-    J += 2;
-  }
+  if constexpr (KS_GROUP_MAX >= 4)
+    for (; J + 4 <= K; J += 4) group(J, std::integral_constant<int, 4>{});
+  for (; J + 2 <= K; J += 2) group(J, std::integral_constant<int, 2>{});
   if (J < K) group(J, std::integral_constant<int, 1>{});
   reduce_all(ar, acc[0]);
   reduce_all(ar, acc[1]);
@@ -536,7 +572,8 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
 #pragma unroll
     for (int g = 0; g < Out::G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << RI); k++) dst[Out::elem(tid, blk, g, k)] = acc[c][g * (1 << RI) + k];
+      for (int k = 0; k < (1 << RI); k++)
+        nat_store<PACK>(dst, Sh::N, Out::elem(tid, blk, g, k), PACK ? ar.reduce(acc[c][g * (1 << RI) + k]) : acc[c][g * (1 << RI) + k]);
   }
 }
 
@@ -562,7 +599,7 @@ __device__ __forceinline__ void tail_inverse4(const ArithD& ar, double (&v)[4], 
   ar.inv(v[1], v[3], tw[1]);
 }
 
-template <int L>
+template <int L, bool PACK>
 __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                const double* __restrict__ ACC, const u64* __restrict__ base, size_t bstride,
                                                                u32 base_mask, const u64* __restrict__ extra, u64* __restrict__ out) {
@@ -570,7 +607,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 c = blockIdx.y, op = blockIdx.z;
   const u32 K = ctx->K, KK = ctx->KK;
-  const double* acc = ACC + ((size_t)op * 2 + c) * KK * N + t;
+  const double* acc = ACC + ((size_t)op * 2 + c) * KK * N;
   // special prime first
   u64 tl[4];
   {
@@ -579,7 +616,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK - 1) * N);
     double v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = acc[(size_t)(KK - 1) * N + (size_t)k * Q];
+    for (int k = 0; k < 4; k++) v[k] = nat_load<PACK>(acc + (size_t)(KK - 1) * N, N, t + (size_t)k * Q);
     tail_inverse4<L>(ar, v, tw, sp.split_inv_mask);
 #pragma unroll
     for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
@@ -591,7 +628,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)J * N);
     double v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = acc[(size_t)J * N + (size_t)k * Q];
+    for (int k = 0; k < 4; k++) v[k] = nat_load<PACK>(acc + (size_t)J * N, N, t + (size_t)k * Q);
     tail_inverse4<L>(ar, v, tw, mj.split_inv_mask);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -648,7 +685,7 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 // mul head: grid (N/8/256, 4 polys (a0,a1,b0,b1), ops); ext = [ops][4][K+S][N] in native representation
 // AUXD (DevCtx::aux_f64): every residue, auxiliary base included, takes the FP64 policy and the base extension
 // itself runs in FP64 (behz_extend_coeff_d).
-template <int L, int KMAX, bool AUXD>
+template <int L, int KMAX, bool AUXD, bool PACK>
 __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
                                                                 u64* __restrict__ ext) {
@@ -674,9 +711,9 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
 #pragma unroll
         for (int k = 0; k < NC; k++) v[k] = x[i][k];
         head_fwd(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)i * N));
-        double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
+        double* o = reinterpret_cast<double*>(dst - t + (size_t)i * N);
 #pragma unroll
-        for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
+        for (int k = 0; k < NC; k++) nat_store<PACK>(o, N, t + (size_t)k * Q, PACK ? ar.reduce(v[k]) : v[k]);
       }
     }
     // auxiliary base: extend all eight owned coefficients residue by residue (every conversion constant is
@@ -684,9 +721,9 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
     behz_extend_multi_d<KMAX, NC>(ctx, x, [&](u32 j, double(&ev)[NC]) {
       const ArithD ar(ctx->mod[KK + j]);
       head_fwd(ar, ev, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N));
-      double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
+      double* o = reinterpret_cast<double*>(dst - t + (size_t)(K + j) * N);
 #pragma unroll
-      for (int k = 0; k < NC; k++) o[(size_t)k * Q] = ev[k];
+      for (int k = 0; k < NC; k++) nat_store<PACK>(o, N, t + (size_t)k * Q, PACK ? ar.reduce(ev[k]) : ev[k]);
     });
     return;
   }
@@ -813,7 +850,7 @@ __device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A:
 
 // The same work with the four forward transforms (and then the three inverse ones) advanced together, pass by
 // pass (mid_forward_multi): smem = 4 regions of BLOCK elements, nothing is parked.
-template <class A, int L>
+template <class A, int L, bool PACK>
 __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi,
                                                      const typename A::V* ext_r, size_t poly_stride, typename A::V* D_r, size_t dpoly_stride,
                                                      typename A::V* smem, u32 tid, u32 blk) {
@@ -830,9 +867,22 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 #pragma unroll
     for (int g = 0; g < First::G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << RF0); k++) v[i][g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+      for (int k = 0; k < (1 << RF0); k++) {
+        if constexpr (PACK && std::is_same<A, ArithD>::value)
+          v[i][g * (1 << RF0) + k] = nat_load<true>(src, Sh::N, First::elem(tid, blk, g, k));
+        else
+          v[i][g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+      }
   }
-  mid_forward_multi<A, L, 4>(ar, v, smem, tid, blk, twf, dm.split_fwd_mask);
+  if constexpr (MID_FWD_PAIRS) {
+    // two pairs through 2 (of the 3) exchange regions: 48 KB of LDS per workgroup instead of 64 KB -> 3 workgroups per CU
+    using Pair = typename A::V[2][kBlkEPT];
+    mid_forward_multi<A, L, 2>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
+    __syncthreads();
+    mid_forward_multi<A, L, 2>(ar, *reinterpret_cast<Pair*>(&v[2]), smem, tid, blk, twf, dm.split_fwd_mask);
+  } else {
+    mid_forward_multi<A, L, 4>(ar, v, smem, tid, blk, twf, dm.split_fwd_mask);
+  }
   typename A::V d[3][kBlkEPT];
 #pragma unroll
   for (int e = 0; e < kBlkEPT; e++) {
@@ -848,20 +898,25 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 #pragma unroll
     for (int g = 0; g < Out::G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << RI); k++) dst[Out::elem(tid, blk, g, k)] = d[i][g * (1 << RI) + k];
+      for (int k = 0; k < (1 << RI); k++) {
+        if constexpr (PACK && std::is_same<A, ArithD>::value)
+          nat_store<true>(dst, Sh::N, Out::elem(tid, blk, g, k), ar.reduce(d[i][g * (1 << RI) + k]));
+        else
+          dst[Out::elem(tid, blk, g, k)] = d[i][g * (1 << RI) + k];
+      }
   }
 }
 
 // grid: ops * nres * NBLK workgroups of TPB threads; D = [ops][3][R][N] native representation.
 // Two instantiations (separate register allocations): FP64 residues (r in [0, K)) and integer residues.
 // POLICY_D selects which residues this launch handles: r0 = first residue, nres = number of residues.
-template <int L, bool POLICY_D>
+template <int L, bool POLICY_D, bool PACK>
 __global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D : MID_WAVES_I)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                            const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
                                                                            u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres) {
   using Sh = SplitShape<L>;
   constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
-  __shared__ u64 smem[(batched ? 4 : 1) * Sh::BLOCK];
+  __shared__ u64 smem[(batched ? (MID_FWD_PAIRS ? 3 : 4) : 1) * Sh::BLOCK];
   __shared__ u64 park[batched ? 1 : Sh::BLOCK];
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
@@ -877,11 +932,11 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D : MID
   const MulOp* twf = twf_base + (size_t)m * Sh::N;
   const MulOp* twi = twi_base + (size_t)m * Sh::N;
   if constexpr (batched && POLICY_D)
-    mul_mid_body_batched<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
+    mul_mid_body_batched<ArithD, L, PACK>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                                     reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                                     reinterpret_cast<double*>(smem), tid, blk);
   else if constexpr (batched)
-    mul_mid_body_batched<ArithI, L>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
+    mul_mid_body_batched<ArithI, L, false>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
   else if constexpr (POLICY_D)
     mul_mid_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                             reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
@@ -914,11 +969,12 @@ __device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V
 }
 
 // the same for the FP64 epilogue: reduced doubles out (|out| <= q/2)
-__device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const double* __restrict__ src, size_t Q, const MulOpD* __restrict__ tw,
-                                                  const MulOpD& sc, u32 mask, double (&out)[4]) {
+template <bool PACK>
+__device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const double* __restrict__ region, u32 n, u32 t, size_t Q,
+                                                  const MulOpD* __restrict__ tw, const MulOpD& sc, u32 mask, double (&out)[4]) {
   double v[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) v[k] = src[(size_t)k * Q];
+  for (int k = 0; k < 4; k++) v[k] = nat_load<PACK>(region, n, t + (size_t)k * Q);
   if ((mask >> 8) & 1u) {
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
@@ -936,7 +992,7 @@ __device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const double
 }
 
 // mul tail: grid (N/4/256, 3 polys, ops); out = [ops][3][K][N] canonical
-template <int L, int KMAX, bool AUXD>
+template <int L, int KMAX, bool AUXD, bool PACK>
 __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                 const u64* __restrict__ D, u64* __restrict__ out) {
   constexpr u32 N = 1u << L, Q = N >> kTailLog;
@@ -953,7 +1009,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
         const DevMod& dm = ctx->mod[i];
         const ArithD ar(dm);
         double r4[4];
-        tail_inv4_scale_d(ar, reinterpret_cast<const double*>(d + (size_t)i * N), Q, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
+        tail_inv4_scale_d<PACK>(ar, reinterpret_cast<const double*>(d - t + (size_t)i * N), N, t, Q, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
                           ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
 #pragma unroll
         for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
@@ -964,7 +1020,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
         ctx, yc,
         [&](u32 j, double(&xb)[4]) {
           const DevMod& dm = ctx->mod[KK + j];
-          tail_inv4_scale_d(ArithD(dm), reinterpret_cast<const double*>(d + (size_t)(K + j) * N), Q,
+          tail_inv4_scale_d<PACK>(ArithD(dm), reinterpret_cast<const double*>(d - t + (size_t)(K + j) * N), N, t, Q,
                             reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j], dm.split_inv_mask, xb);
         },
         res);
@@ -1201,89 +1257,116 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
   }
 
 template <int L>
-static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
-  ks_head_kernel<L><<<dim3(((1u << L) >> head_log(L)) / kHeadThreads, K, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twf, target, tstride,
-                                                                                                   reinterpret_cast<double*>(T));
+static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, bool pack, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
+  const dim3 grid(((1u << L) >> head_log(L)) / kHeadThreads, K, (unsigned)ops);
+  if (pack)
+    ks_head_kernel<L, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
+  else
+    ks_head_kernel<L, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
   return hipGetLastError();
 }
-hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(ks_head_t, ctx, twf, K, target, tstride, T, ops, s)
+// pack: DevCtx::pack_ks of the context behind `ctx` (48-bit packed intermediates, see nat_load)
+hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(ks_head_t, ctx, twf, pack, K, target, tstride, T, ops, s)
 }
 
 template <int L>
-static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops,
+static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops,
                            hipStream_t s) {
   using Sh = SplitShape<L>;
   const size_t ops8 = (ops + 7) / 8 * 8;
-  ks_mid_kernel<L><<<dim3((unsigned)(ops8 * KK * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key,
-                                                                               reinterpret_cast<double*>(ACC), (u32)ops);
+  const dim3 grid((unsigned)(ops8 * KK * Sh::NBLK));
+  if (pack)
+    ks_mid_kernel<L, true><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops);
+  else
+    ks_mid_kernel<L, false><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops);
   return hipGetLastError();
 }
-hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops,
-                         hipStream_t s) {
-  SPLIT_DISPATCH(ks_mid_t, ctx, twf, twi, KK, T, key, ACC, ops, s)
+hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, u32 KK, const u64* T, const u64* key, u64* ACC,
+                         size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(ks_mid_t, ctx, twf, twi, pack, KK, T, key, ACC, ops, s)
 }
 
 template <int L>
-static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra,
-                            u64* out2, size_t ops, hipStream_t s) {
-  ks_tail_kernel<L><<<dim3((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops), kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base,
-                                                                                                   bstride, base_mask, extra, out2);
+static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
+                            const u64* extra, u64* out2, size_t ops, hipStream_t s) {
+  const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
+  if (pack)
+    ks_tail_kernel<L, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
+  else
+    ks_tail_kernel<L, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
   return hipGetLastError();
 }
 // extra: optional ciphertexts u64[ops][2][K][N] added to the result
-hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
-                          size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(ks_tail_t, ctx, twi, ACC, base, bstride, base_mask, extra, out2, ops, s)
+hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
+                          const u64* extra, u64* out2, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(ks_tail_t, ctx, twi, pack, ACC, base, bstride, base_mask, extra, out2, ops, s)
 }
 
 template <int L>
-static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
-                             hipStream_t s) {
+static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
+                             size_t ops, hipStream_t s) {
   const dim3 grid(((1u << L) >> head_log(L)) / kHeadThreads, 4, (unsigned)ops);
-  if (kneed > 4)  // only the all-FP64 instantiation exists for 5..8 data primes (evaluator.cpp checks)
-    mul_head_kernel<L, 8, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
-  else if (aux_f64)
-    mul_head_kernel<L, 4, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
-  else
-    mul_head_kernel<L, 4, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+  if (kneed > 4) {  // only the all-FP64 instantiation exists for 5..8 data primes (evaluator.cpp checks)
+    if (pack)
+      mul_head_kernel<L, 8, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+    else
+      mul_head_kernel<L, 8, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+  } else if (aux_f64) {
+    if (pack)
+      mul_head_kernel<L, 4, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+    else
+      mul_head_kernel<L, 4, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+  } else {
+    mul_head_kernel<L, 4, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+  }
   return hipGetLastError();
 }
 // aux_f64: DevCtx::aux_f64 of the context behind `ctx` (selects the all-FP64 instantiation)
 // kneed: max(data primes, auxiliary primes - 2) -- selects the 4- or 8-prime instantiation
-hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
-                           hipStream_t s) {
-  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, kneed, a, b, ext, ops, s)
+// pack: DevCtx::pack_mul (only with aux_f64)
+hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
+                           size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack && aux_f64, kneed, a, b, ext, ops, s)
 }
 
 template <int L>
-static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, const unsigned char* res_d, u32 nd, const unsigned char* res_i,
-                            u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s) {
+static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
+                            const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s) {
   using Sh = SplitShape<L>;
-  if (nd) mul_mid_kernel<L, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
-  if (ni) mul_mid_kernel<L, false><<<dim3((unsigned)(ops * ni * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
+  if (nd && pack) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+  if (nd && !pack) mul_mid_kernel<L, true, false><<<dim3((unsigned)(ops * nd * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+  if (ni) mul_mid_kernel<L, false, false><<<dim3((unsigned)(ops * ni * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
   return hipGetLastError();
 }
 // res_d / res_i: device arrays listing the residue indices (0..R-1) handled by the FP64 / integer instantiation
-hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, const unsigned char* res_d, u32 nd,
+hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd,
                           const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mul_mid_t, ctx, twf, twi, res_d, nd, res_i, ni, ext, D, ops, s)
+  SPLIT_DISPATCH(mul_mid_t, ctx, twf, twi, pack && ni == 0, res_d, nd, res_i, ni, ext, D, ops, s)
 }
 
 template <int L>
-static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, u32 kneed, const u64* D, u64* out, size_t ops, hipStream_t s) {
+static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, bool pack, u32 kneed, const u64* D, u64* out, size_t ops,
+                             hipStream_t s) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, 3, (unsigned)ops);
-  if (kneed > 4)
-    mul_tail_kernel<L, 8, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
-  else if (aux_f64)
-    mul_tail_kernel<L, 4, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
-  else
-    mul_tail_kernel<L, 4, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+  if (kneed > 4) {
+    if (pack)
+      mul_tail_kernel<L, 8, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+    else
+      mul_tail_kernel<L, 8, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+  } else if (aux_f64) {
+    if (pack)
+      mul_tail_kernel<L, 4, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+    else
+      mul_tail_kernel<L, 4, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+  } else {
+    mul_tail_kernel<L, 4, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+  }
   return hipGetLastError();
 }
-hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, u32 kneed, const u64* D, u64* out, size_t ops,
+hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, bool pack, u32 kneed, const u64* D, u64* out, size_t ops,
                            hipStream_t s) {
-  SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, kneed, D, out, ops, s)
+  SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, pack && aux_f64, kneed, D, out, ops, s)
 }
 
 }  // namespace hipbfv

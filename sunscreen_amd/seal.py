@@ -241,7 +241,9 @@ class Context:
         buf = (C.c_uint64 * cnt.value)()
         _check(_lib.load().hipbfv_Context_AuxBase(self._h, C.byref(cnt), buf, cnt.value, C.byref(own)))
         self.aux_primes = list(buf)  # B..., m_sk (internal to multiply; see include/hipbfv.h)
-        self.aux_fp64 = bool(own.value)
+        self.aux_fp64 = bool(own.value & 1)
+        self.packed_mul = bool(own.value & 2)  # 48-bit packed intermediates in the split multiply / key switch
+        self.packed_ks = bool(own.value & 4)
 
     def get_handle(self):
         return self._h
