@@ -229,10 +229,13 @@ __device__ __forceinline__ void behz_extend_multi_d(const DevCtx* __restrict__ c
   }
 }
 
-// yc[i][k]: CANONICAL y_i of coefficient k (double); aux(j, xb): called once per auxiliary prime j, must fill
+// yc[i][k]: CANONICAL y_i of coefficient k (double); finish(j, raw, xb): called once per auxiliary prime j, must fill
 // xb[k] = x*t mod Bsk_j (any representative with |xb| < 2^52); out[i][k] = canonical u64 result mod q_i
-template <int KMAX, int NC, class Source>
-__device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__ ctx, const double (&yc)[KMAX][NC], Source&& aux,
+// Two-phase source: fetch(j, raw) only issues the loads of auxiliary residue j (raw words, no arithmetic on them);
+// finish(j, raw, xb) turns them into xb.  Residue j+1 is fetched before residue j is consumed, so two residues'
+// loads are in flight per thread (the tail kernels are latency-bound, not bandwidth-bound, at their occupancy).
+template <int KMAX, int NC, class Raw, class Fetch, class Finish>
+__device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__ ctx, const double (&yc)[KMAX][NC], Fetch&& fetch, Finish&& finish,
                                                       u64 (&out)[KMAX][NC]) {
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, nB = ctx->nB;
   double oacc[KMAX][NC], amsk[NC], flm[NC];
@@ -242,11 +245,17 @@ __device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__
   for (int i = 0; i < KMAX; i++)
 #pragma unroll
     for (int k = 0; k < NC; k++) oacc[i][k] = 0.0;
+  Raw cur[NC];
+  fetch(0u, cur);
 #pragma unroll 1
   for (u32 j = 0; j < S; j++) {
     const ArithD ar(ctx->mod[KK + j]);
+    Raw nxt[NC];
+    fetch(j + 1 < S ? j + 1 : j, nxt);  // the last round re-reads its own residue (cache hit) to keep the loop uniform
     double fl[NC];
-    aux(j, fl);
+    finish(j, cur, fl);
+#pragma unroll
+    for (int k = 0; k < NC; k++) cur[k] = nxt[k];
 #pragma unroll
     for (int k = 0; k < NC; k++) fl[k] = ar.reduce(fl[k]);
 #pragma unroll

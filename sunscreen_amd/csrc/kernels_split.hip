@@ -422,6 +422,36 @@ __device__ __forceinline__ double nat_load(const double* __restrict__ region, u3
     return __hiloint2double((int)hw, (int)lo) - kPackMagic;
   }
 }
+// the same in two steps, so that a caller can keep the loads of the NEXT item in flight while it works on this one
+template <bool PACK>
+struct NatRaw {
+  double d;
+};
+template <>
+struct NatRaw<true> {
+  u32 lo;
+  int hi;
+};
+template <bool PACK>
+__device__ __forceinline__ NatRaw<PACK> nat_fetch(const double* __restrict__ region, u32 n, size_t idx) {
+  NatRaw<PACK> r;
+  if constexpr (!PACK) {
+    r.d = region[idx];
+  } else {
+    r.lo = reinterpret_cast<const u32*>(region)[idx];
+    r.hi = reinterpret_cast<const short*>(reinterpret_cast<const char*>(region) + 4 * (size_t)n)[idx];
+  }
+  return r;
+}
+template <bool PACK>
+__device__ __forceinline__ double nat_unpack(const NatRaw<PACK>& r) {
+  if constexpr (!PACK) {
+    return r.d;
+  } else {
+    const u32 hw = 0x43300000u | (((u32)r.hi & 0xFFFFFu) ^ 0x80000u);
+    return __hiloint2double((int)hw, (int)r.lo) - kPackMagic;
+  }
+}
 // PACK: v must be an integer with |v| < 2^47 (callers reduce first)
 template <bool PACK>
 __device__ __forceinline__ void nat_store(double* __restrict__ region, u32 n, size_t idx, double v) {
@@ -970,11 +1000,11 @@ __device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V
 
 // the same for the FP64 epilogue: reduced doubles out (|out| <= q/2)
 template <bool PACK>
-__device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const double* __restrict__ region, u32 n, u32 t, size_t Q,
-                                                  const MulOpD* __restrict__ tw, const MulOpD& sc, u32 mask, double (&out)[4]) {
+__device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const NatRaw<PACK> (&raw)[4], const MulOpD* __restrict__ tw, const MulOpD& sc,
+                                                  u32 mask, double (&out)[4]) {
   double v[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) v[k] = nat_load<PACK>(region, n, t + (size_t)k * Q);
+  for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACK>(raw[k]);
   if ((mask >> 8) & 1u) {
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
@@ -1009,19 +1039,25 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
         const DevMod& dm = ctx->mod[i];
         const ArithD ar(dm);
         double r4[4];
-        tail_inv4_scale_d<PACK>(ar, reinterpret_cast<const double*>(d - t + (size_t)i * N), N, t, Q, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
-                          ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
+        NatRaw<PACK> raw[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK>(reinterpret_cast<const double*>(d - t + (size_t)i * N), N, t + (size_t)k * Q);
+        tail_inv4_scale_d<PACK>(ar, raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
 #pragma unroll
         for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
       }
     }
     u64 res[KMAX][4];
-    behz_floor_sk_multi_d<KMAX, 4>(
+    behz_floor_sk_multi_d<KMAX, 4, NatRaw<PACK>>(
         ctx, yc,
-        [&](u32 j, double(&xb)[4]) {
+        [&](u32 j, NatRaw<PACK>(&raw)[4]) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK>(reinterpret_cast<const double*>(d - t + (size_t)(K + j) * N), N, t + (size_t)k * Q);
+        },
+        [&](u32 j, const NatRaw<PACK>(&raw)[4], double(&xb)[4]) {
           const DevMod& dm = ctx->mod[KK + j];
-          tail_inv4_scale_d<PACK>(ArithD(dm), reinterpret_cast<const double*>(d - t + (size_t)(K + j) * N), N, t, Q,
-                            reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j], dm.split_inv_mask, xb);
+          tail_inv4_scale_d<PACK>(ArithD(dm), raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j],
+                                  dm.split_inv_mask, xb);
         },
         res);
 #pragma unroll
