@@ -386,11 +386,14 @@ __device__ __forceinline__ void mid_inverse_multi(const A& ar, typename A::V (&v
 }
 
 constexpr int kHeadThreads = 256;
+// mul_mid, FP64 instantiation: at N = 8192 the four forward transforms go through the exchange buffer as two pairs
+// (48 KB of LDS per workgroup instead of 64 KB: 3 workgroups = 12 waves per CU instead of 2 = 8; -5 % mul_mid).  At N = 4096
+// the regions are small anyway and the extra barriers cost 37 %; at N = 16384 one workgroup fills the CU either way.
 #ifndef MID_FWD_PAIRS
-#define MID_FWD_PAIRS false
+#define MID_FWD_PAIRS(L) ((L) == 13)
 #endif
 #ifndef MID_WAVES_D
-#define MID_WAVES_D 2
+#define MID_WAVES_D(L) ((L) == 13 ? 3 : 2)
 #endif
 #ifndef MID_WAVES_I
 #define MID_WAVES_I 3
@@ -904,7 +907,7 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
           v[i][g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
       }
   }
-  if constexpr (MID_FWD_PAIRS) {
+  if constexpr (MID_FWD_PAIRS(L) && std::is_same<A, ArithD>::value) {
     // two pairs through 2 (of the 3) exchange regions: 48 KB of LDS per workgroup instead of 64 KB -> 3 workgroups per CU
     using Pair = typename A::V[2][kBlkEPT];
     mid_forward_multi<A, L, 2>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
@@ -941,12 +944,12 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 // Two instantiations (separate register allocations): FP64 residues (r in [0, K)) and integer residues.
 // POLICY_D selects which residues this launch handles: r0 = first residue, nres = number of residues.
 template <int L, bool POLICY_D, bool PACK>
-__global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D : MID_WAVES_I)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+__global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D(L) : MID_WAVES_I)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                            const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
                                                                            u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres) {
   using Sh = SplitShape<L>;
   constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
-  __shared__ u64 smem[(batched ? (MID_FWD_PAIRS ? 3 : 4) : 1) * Sh::BLOCK];
+  __shared__ u64 smem[(batched ? (MID_FWD_PAIRS(L) && POLICY_D ? 3 : 4) : 1) * Sh::BLOCK];
   __shared__ u64 park[batched ? 1 : Sh::BLOCK];
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
