@@ -909,10 +909,23 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   }
   if constexpr (MID_FWD_PAIRS(L) && std::is_same<A, ArithD>::value) {
     // two pairs through 2 (of the 3) exchange regions: 48 KB of LDS per workgroup instead of 64 KB -> 3 workgroups per CU
+    // The pair that is not being transformed would sit in 32 registers; one of its two polynomials waits in the third
+    // exchange region instead (each thread parks and fetches its own values: no synchronisation), which keeps the kernel
+    // under the 168 registers of 3 waves per SIMD without scratch spills.
     using Pair = typename A::V[2][kBlkEPT];
+    typename A::V* park = smem + 2 * Sh::BLOCK + tid;
+#pragma unroll
+    for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB] = v[3][e];
     mid_forward_multi<A, L, 2>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
     __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kBlkEPT; e++) {
+      v[3][e] = park[e * Sh::TPB];
+      park[e * Sh::TPB] = v[0][e];
+    }
     mid_forward_multi<A, L, 2>(ar, *reinterpret_cast<Pair*>(&v[2]), smem, tid, blk, twf, dm.split_fwd_mask);
+#pragma unroll
+    for (int e = 0; e < kBlkEPT; e++) v[0][e] = park[e * Sh::TPB];
   } else {
     mid_forward_multi<A, L, 4>(ar, v, smem, tid, blk, twf, dm.split_fwd_mask);
   }
