@@ -398,11 +398,14 @@ constexpr int kHeadThreads = 256;
 #ifndef MID_WAVES_I
 #define MID_WAVES_I 3
 #endif
+// ks_mid: digits transformed together (4 or 2; LDS = that many exchange regions) and waves per SIMD the register
+// allocation aims at.  Pairs + 3 waves: -5.5 % at N = 8192, -11 % at N = 4096; at N = 16384 (32 KB regions, K = 8) groups
+// of four at 2 waves stay faster (+4 % the other way).
 #ifndef KS_GROUP_MAX
-#define KS_GROUP_MAX 4  // digits transformed together in ks_mid (4 or 2): LDS = KS_GROUP_MAX * 16 KB per workgroup
+#define KS_GROUP_MAX(L) ((L) <= 13 ? 2 : 4)
 #endif
 #ifndef KS_MID_WAVES
-#define KS_MID_WAVES 2
+#define KS_MID_WAVES(L) ((L) <= 13 ? 3 : 2)
 #endif
 
 // -------------------------------------------------------------------------------------------------
@@ -508,12 +511,12 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
 // grid: ops8 * KK * NBLK (slice-major per XCD, see the index computation)
 // -------------------------------------------------------------------------------------------------
 template <int L, bool PACK>
-__global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+__global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                        const MulOp* __restrict__ twi_base, const double* __restrict__ T,
                                                                        const u64* __restrict__ key, double* __restrict__ ACC, u32 ops) {
   using Sh = SplitShape<L>;
   using A = ArithD;
-  __shared__ double smem[KS_GROUP_MAX * Sh::BLOCK];
+  __shared__ double smem[KS_GROUP_MAX(L) * Sh::BLOCK];
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, KK = ctx->KK;
   const u32 b = blockIdx.x;
@@ -544,29 +547,28 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
 #pragma unroll
       for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = nat_load<PACK>(src, Sh::N, First::elem(tid, blk, g, k));
   };
-  auto load_keys = [&](u32 J, ulonglong2(&ka)[kBlkEPT / 2], ulonglong2(&kc)[kBlkEPT / 2]) {
+  // key rows of digit J for the group g of the last forward window (the elements this thread holds): 16-byte loads
+  auto mac = [&](u32 J, const double(&v)[kBlkEPT]) {
     const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
     const u64* k1 = key + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
 #pragma unroll
     for (int g = 0; g < Last::G; g++) {
       const u32 base = Last::elem(tid, blk, g, 0);
+      constexpr int W = 1 << RL;
+      ulonglong2 ka[W / 2], kc[W / 2];
 #pragma unroll
-      for (int k = 0; k < (1 << RL); k += 2) {
-        ka[(g * (1 << RL) + k) / 2] = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
-        kc[(g * (1 << RL) + k) / 2] = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
+      for (int k = 0; k < W; k += 2) {
+        ka[k / 2] = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
+        kc[k / 2] = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
       }
-    }
-  };
-  auto mac = [&](u32 J, const double(&v)[kBlkEPT]) {
-    ulonglong2 ka[kBlkEPT / 2], kc[kBlkEPT / 2];
-    load_keys(J, ka, kc);
 #pragma unroll
-    for (int h = 0; h < kBlkEPT / 2; h++) {
-      const int e = 2 * h;
-      acc[0][e] += ar.mul_var(v[e], ar.from_u64(ka[h].x));
-      acc[0][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(ka[h].y));
-      acc[1][e] += ar.mul_var(v[e], ar.from_u64(kc[h].x));
-      acc[1][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(kc[h].y));
+      for (int h = 0; h < W / 2; h++) {
+        const int e = g * W + 2 * h;
+        acc[0][e] += ar.mul_var(v[e], ar.from_u64(ka[h].x));
+        acc[0][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(ka[h].y));
+        acc[1][e] += ar.mul_var(v[e], ar.from_u64(kc[h].x));
+        acc[1][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(kc[h].y));
+      }
     }
     if ((J & 3u) == 3u) {
       reduce_all(ar, acc[0]);
@@ -589,7 +591,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES) void ks_mid_ker
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
   };
   u32 J = 0;
-  if constexpr (KS_GROUP_MAX >= 4)
+  if constexpr (KS_GROUP_MAX(L) >= 4)
     for (; J + 4 <= K; J += 4) group(J, std::integral_constant<int, 4>{});
   for (; J + 2 <= K; J += 2) group(J, std::integral_constant<int, 2>{});
   if (J < K) group(J, std::integral_constant<int, 1>{});
