@@ -244,30 +244,23 @@ int Evaluator::encrypt(const u64* plain, size_t pstride, const u64* pk, u64 seed
   const u32 n = h.n, K = h.K, KK = h.KK;
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / (2 * (size_t)KK)));
   const size_t cc = std::min(chunk, count);
-  // u[KK] + e[2][KK] + c[2][KK] residue polynomials per op
-  ScratchGuard sg(pool_, cc * 5 * (size_t)KK * n * sizeof(u64), s);
+  // u[KK] + c[2][KK] residue polynomials per op; the error polynomials are regenerated where they are consumed
+  ScratchGuard sg(pool_, cc * 3 * (size_t)KK * n * sizeof(u64), s);
   if (!sg.p) return kOutOfMemory;
   u64* u = (u64*)sg.p;
-  u64* e = u + cc * (size_t)KK * n;
-  u64* c2 = e + cc * 2 * (size_t)KK * n;
+  u64* c2 = u + cc * (size_t)KK * n;
   const NttPlan plan = range_plan(KK);
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
-    HC_CHECK(launch_encrypt_sample(ctx_->dev(), n, seed, first_op + off, u, e, c, s));
+    HC_CHECK(launch_encrypt_sample(ctx_->dev(), n, seed, first_op + off, u, nullptr, c, s));
     HB_LAUNCH_CLIENT(kKernNttFwd, c * KK, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, u, c * KK, plan, false, 0, s));
     HC_CHECK(launch_encrypt_dyadic(ctx_->dev(), n, KK, u, pk, c2, c, s));
     HB_LAUNCH_CLIENT(kKernNttInv, c * 2 * KK, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, c2, c * 2 * KK, plan, true, 0, s));
-    HC_CHECK(launch_add_key_level(ctx_->dev(), n, c2, e, c * 2 * KK, s));
-    u64* out = ct2 + off * 2 * K * n;
-    if (KK > 1) {
-      // SEAL encrypts at the key level and divides-and-rounds by the special prime (mod_switch of the fresh encryption)
-      HC_CHECK(launch_ks_moddown(ctx_->dev(), n, c2, nullptr, 0, 0u, nullptr, out, c, s));
-    } else {
-      HC_CHECK(hipMemcpyAsync(out, c2, c * 2 * (size_t)K * n * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    }
+    // + e, SEAL's divide-and-round by the special prime (the mod_switch of the fresh key-level encryption) and
+    // + round(q/t * m) with SEAL's rounding correction (multiply_add_plain_with_scaling_variant), in one pass
+    HC_CHECK(launch_encrypt_finish(ctx_->dev(), n, seed, first_op + off, c2, plain + off * pstride, pstride, ct2 + off * 2 * K * n, c, s));
   }
-  // + round(q/t * m) with SEAL's rounding correction (multiply_add_plain_with_scaling_variant) == add_plain
-  return add_plain(ct2, 2, plain, pstride, ct2, count, s);
+  return kOk;
 }
 
 // First K residue rows of each of `polys` key-level polynomials: src u64[polys][KK][N] -> dst u64[polys][K][N]

@@ -150,8 +150,53 @@ __global__ __launch_bounds__(kClientThreads) void encrypt_sample_kernel(const De
   for (u32 i = 0; i < KK; i++) {
     const u64 q = ctx->mod[i].q;
     u[((size_t)op * KK + i) * n + x] = small_to_residue(tern, q);
-    e[(((size_t)op * 2 + 0) * KK + i) * n + x] = small_to_residue(e0, q);
-    e[(((size_t)op * 2 + 1) * KK + i) * n + x] = small_to_residue(e1, q);
+    if (e) {  // nullptr: the caller regenerates the errors where it consumes them (encrypt_finish_kernel)
+      e[(((size_t)op * 2 + 0) * KK + i) * n + x] = small_to_residue(e0, q);
+      e[(((size_t)op * 2 + 1) * KK + i) * n + x] = small_to_residue(e1, q);
+    }
+  }
+}
+
+// The rest of a public-key encryption in one pass over the key-level product c2 = INTT(pk (.) NTT(u)), u64[op][2][KK][N]:
+// + e (regenerated from the same Philox counters as encrypt_sample_kernel, never stored), SEAL's divide-and-round by the
+// special prime (RNSTool::divide_and_round_q_last, as ks_moddown_kernel), and on polynomial 0 the scaled plaintext
+// floor(q/t) m + r (plain_addsub_kernel).  plain: u64[ops or 1][N]; out: u64[op][2][K][N].
+__global__ __launch_bounds__(kClientThreads) void encrypt_finish_kernel(const DevCtx* __restrict__ ctx, u64 seed, u64 op0, const u64* __restrict__ c2,
+                                                                        const u64* __restrict__ plain, size_t pstride, u64* __restrict__ out) {
+  const u32 n = ctx->n, K = ctx->K, KK = ctx->KK;
+  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
+  const u32 c = blockIdx.y, op = blockIdx.z;
+  if (x >= n) return;
+  const u64 gop = op0 + op;
+  u32 r[4];
+  int err;
+  philox4x32(x, (u32)gop, (u32)(gop >> 32), 0u, (u32)seed, (u32)(seed >> 32), r);
+  if (c == 0) {
+    err = gauss_noise(r[1], r[2]);
+  } else {
+    u32 w[4];
+    philox4x32(x, (u32)gop, (u32)(gop >> 32), 1u, (u32)seed, (u32)(seed >> 32), w);
+    err = gauss_noise(r[3], w[0]);
+  }
+  const u64* acc = c2 + ((size_t)op * 2 + c) * KK * n + x;
+  u64 fix = 0, m = 0;
+  if (c == 0) {
+    m = plain[(size_t)op * pstride + x];
+    fix = (u64)(((u128)m * ctx->q_mod_t + ctx->t_half_up) / ctx->t);
+  }
+  u64 tl = 0;
+  const DevMod& sp = ctx->mod[KK - 1];
+  if (KK > 1) tl = add_mod(add_mod(acc[(size_t)(KK - 1) * n], small_to_residue(err, sp.q), sp.q), ctx->qsp_half, sp.q);
+  for (u32 J = 0; J < K; J++) {
+    const DevMod& mj = ctx->mod[J];
+    u64 d = add_mod(acc[(size_t)J * n], small_to_residue(err, mj.q), mj.q);
+    if (KK > 1) {
+      u64 tk = sp.q > mj.q ? reduce64(tl, mj) : tl;
+      tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+      d = mul_shoup(sub_mod(d, tk, mj.q), ctx->inv_qsp_mod_q[J], mj.q);
+    }
+    if (c == 0) d = add_mod(d, reduce128((u128)m * ctx->q_div_t_mod_q[J] + fix, mj), mj.q);
+    out[(((size_t)op * 2 + c) * K + J) * n + x] = d;
   }
 }
 
@@ -434,6 +479,11 @@ hipError_t launch_decrypt_round(const DevCtx* ctx, u32 n, const u64* ct, u32 siz
 }
 hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, u64 seed, u64 op0, u64* u, u64* e, size_t ops, hipStream_t s) {
   encrypt_sample_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, seed, op0, u, e);
+  return hipGetLastError();
+}
+hipError_t launch_encrypt_finish(const DevCtx* ctx, u32 n, u64 seed, u64 op0, const u64* c2, const u64* plain, size_t pstride, u64* out, size_t ops,
+                                 hipStream_t s) {
+  encrypt_finish_kernel<<<cgrid(n, 2, (u32)ops), kClientThreads, 0, s>>>(ctx, seed, op0, c2, plain, pstride, out);
   return hipGetLastError();
 }
 hipError_t launch_encrypt_dyadic(const DevCtx* ctx, u32 n, u32 KK, const u64* un, const u64* pk, u64* c, size_t ops, hipStream_t s) {

@@ -521,6 +521,11 @@ def test_polynomial_array_and_encryption_components(name):
     assert (k1[0].to_array() == k2[0].to_array()).all() and k1[1] == k2[1] and k1[2] == k2[2]
     s1, s2 = enc.encrypt_symmetric_return_components(plain, z), enc.encrypt_symmetric_return_components(plain, z)
     assert (s1[0].to_array() == s2[0].to_array()).all() and s1[1] == s2[1]
+    # the fused encryption path (errors regenerated inside encrypt_finish_kernel) and the component-returning path
+    # (errors materialised) are the same function of (seed, counter): identical bits
+    fa = Encryptor(ctx, pk, seed=11).encrypt(plain)
+    fb = Encryptor(ctx, pk, seed=11).encrypt_return_components(plain, disable_special_modulus=False)[0]
+    assert (fa.to_array() == fb.to_array()).all()
     # clone / drop (data_structures.rs:497-533)
     uc = u.clone()
     assert uc == u and uc.get_handle().value != u.get_handle().value
