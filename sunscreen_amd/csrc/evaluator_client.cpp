@@ -254,8 +254,12 @@ int Evaluator::encrypt(const u64* plain, size_t pstride, const u64* pk, u64 seed
     const size_t c = std::min(chunk, count - off);
     HC_CHECK(launch_encrypt_sample(ctx_->dev(), n, seed, first_op + off, u, nullptr, c, s));
     HB_LAUNCH_CLIENT(kKernNttFwd, c * KK, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, u, c * KK, plan, false, 0, s));
-    HC_CHECK(launch_encrypt_dyadic(ctx_->dev(), n, KK, u, pk, c2, c, s));
-    HB_LAUNCH_CLIENT(kKernNttInv, c * 2 * KK, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, c2, c * 2 * KK, plan, true, 0, s));
+    if (h.logn <= 14) {  // pk (.) NTT(u) is formed while the inverse transform loads its input
+      HB_LAUNCH_CLIENT(kKernNttInv, c * 2 * KK, launch_ntt_inv_dyadic(ctx_->dev(), h.tw_inv, h.logn, u, pk, c2, KK, c, s));
+    } else {
+      HC_CHECK(launch_encrypt_dyadic(ctx_->dev(), n, KK, u, pk, c2, c, s));
+      HB_LAUNCH_CLIENT(kKernNttInv, c * 2 * KK, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, c2, c * 2 * KK, plan, true, 0, s));
+    }
     // + e, SEAL's divide-and-round by the special prime (the mod_switch of the fresh key-level encryption) and
     // + round(q/t * m) with SEAL's rounding correction (multiply_add_plain_with_scaling_variant), in one pass
     HC_CHECK(launch_encrypt_finish(ctx_->dev(), n, seed, first_op + off, c2, plain + off * pstride, pstride, ct2 + off * 2 * K * n, c, s));

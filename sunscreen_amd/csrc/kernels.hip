@@ -219,9 +219,12 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx
     ntt_fwd_body<ArithI, LOGN>(dm, tw, x, reinterpret_cast<u64*>(smem_raw), tid);
 }
 
+// mul_a / mul_b (both or neither): the transform's input is the pointwise product mul_a (.) mul_b mod q (canonical
+// operands) instead of x -- the dyadic multiply that precedes an inverse transform costs no pass of its own
 template <class A, int LOGN>
 __device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Tw& sc, u64* x,
-                                             typename A::V* smem, u32 tid) {
+                                             typename A::V* smem, u32 tid, const u64* __restrict__ mul_a = nullptr,
+                                             const u64* __restrict__ mul_b = nullptr) {
   using Sh = NttShape<LOGN>;
   const A ar(dm);
   typename A::V v[kElemsPerThread];
@@ -230,18 +233,28 @@ __device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A:
     constexpr int RF = Sh::radix(Sh::NPASS - 1), GF = kElemsPerThread >> RF;
 #pragma unroll
     for (int g = 0; g < GF; g++) {
-      const ulonglong2* src = reinterpret_cast<const ulonglong2*>(x + ((size_t)(tid + g * Sh::T) << RF));
+      const size_t at = (size_t)(tid + g * Sh::T) << RF;
+      const ulonglong2* src = reinterpret_cast<const ulonglong2*>((mul_b ? mul_a : x) + at);
 #pragma unroll
       for (int k = 0; k < (1 << RF); k += 2) {
         const ulonglong2 w = src[k >> 1];
         v[g * (1 << RF) + k] = ar.from_u64(w.x);
         v[g * (1 << RF) + k + 1] = ar.from_u64(w.y);
       }
+      if (mul_b) {
+        const ulonglong2* other = reinterpret_cast<const ulonglong2*>(mul_b + at);
+#pragma unroll
+        for (int k = 0; k < (1 << RF); k += 2) {
+          const ulonglong2 w = other[k >> 1];
+          v[g * (1 << RF) + k] = ar.mul_var(v[g * (1 << RF) + k], ar.from_u64(w.x));
+          v[g * (1 << RF) + k + 1] = ar.mul_var(v[g * (1 << RF) + k + 1], ar.from_u64(w.y));
+        }
+      }
     }
     InvPasses<A, LOGN, kElemsPerThread, 0, true>::run(ar, v, smem, tid, tw, dm.inv_reduce_mask);
   }
 #else
-  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) smem[lds_pos(e)] = ar.from_u64(x[e]);
+  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) smem[lds_pos(e)] = mul_b ? ar.mul_var(ar.from_u64(mul_a[e]), ar.from_u64(mul_b[e])) : ar.from_u64(x[e]);
   ntt_inv_from_lds<A, LOGN>(ar, v, smem, tid, tw, dm.inv_reduce_mask);
 #endif
   constexpr int R = Sh::radix(0);
@@ -273,6 +286,28 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
     if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
     ntt_inv_body<ArithI, LOGN>(dm, tw, sc, x, reinterpret_cast<u64*>(smem_raw), tid);
   }
+}
+
+// c[op][j][i] = INTT(a[op][i] (.) b[j][i]) for j = 0, 1 over the first `nmod` moduli: the key-level product pk * u of a
+// public-key encryption (a = NTT(u), b = the public key), one workgroup per output polynomial
+template <int LOGN>
+__global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_dyadic_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase,
+                                                                           const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ c,
+                                                                           u32 nmod) {
+  using Sh = NttShape<LOGN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const u32 tid = threadIdx.x;
+  const u32 poly = blockIdx.x;
+  const u32 m = poly % nmod, j = (poly / nmod) & 1u, op = poly / (2 * nmod);
+  const DevMod& dm = ctx->mod[m];
+  u64* x = c + (size_t)poly * Sh::N;
+  const u64* pa = a + ((size_t)op * nmod + m) * Sh::N;
+  const u64* pb = b + ((size_t)j * nmod + m) * Sh::N;
+  const MulOp* tw = twbase + (size_t)m * Sh::N;
+  if (dm.use_f64)
+    ntt_inv_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), dm.ninv_d, x, reinterpret_cast<double*>(smem_raw), tid, pa, pb);
+  else
+    ntt_inv_body<ArithI, LOGN>(dm, tw, dm.ninv, x, reinterpret_cast<u64*>(smem_raw), tid, pa, pb);
 }
 
 // =====================================================================================
@@ -489,6 +524,31 @@ static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, si
     ntt_fwd_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan);
   }
   return hipGetLastError();
+}
+
+template <int LOGN>
+static hipError_t launch_ntt_inv_dyadic_t(const DevCtx* ctx, const MulOp* tw, const u64* a, const u64* b, u64* c, u32 nmod, size_t ops, hipStream_t s) {
+  using Sh = NttShape<LOGN>;
+  const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)ntt_inv_dyadic_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  ntt_inv_dyadic_kernel<LOGN><<<dim3((unsigned)(ops * 2 * nmod)), dim3(Sh::T), lds, s>>>(ctx, tw, a, b, c, nmod);
+  return hipGetLastError();
+}
+// c u64[ops][2][nmod][N] = INTT(a[op][i] (.) b[j][i]); a u64[ops][nmod][N], b u64[2][nmod][N] (N <= 16384)
+hipError_t launch_ntt_inv_dyadic(const DevCtx* ctx, const MulOp* tw_inv, u32 logn, const u64* a, const u64* b, u64* c, u32 nmod, size_t ops, hipStream_t s) {
+  if (ops == 0) return hipSuccess;
+  switch (logn) {
+    case 10: return launch_ntt_inv_dyadic_t<10>(ctx, tw_inv, a, b, c, nmod, ops, s);
+    case 11: return launch_ntt_inv_dyadic_t<11>(ctx, tw_inv, a, b, c, nmod, ops, s);
+    case 12: return launch_ntt_inv_dyadic_t<12>(ctx, tw_inv, a, b, c, nmod, ops, s);
+    case 13: return launch_ntt_inv_dyadic_t<13>(ctx, tw_inv, a, b, c, nmod, ops, s);
+    case 14: return launch_ntt_inv_dyadic_t<14>(ctx, tw_inv, a, b, c, nmod, ops, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_ntt(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
