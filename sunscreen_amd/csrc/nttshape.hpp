@@ -37,14 +37,24 @@ static_assert(HIPBFV_HEAD_LOG_14 == 2 || HIPBFV_HEAD_LOG_14 == 3, "head depth at
 constexpr int head_log(int logn) { return logn == 14 ? HIPBFV_HEAD_LOG_14 : 3; }
 constexpr int kHeadLogMax = 3;
 constexpr int kTailLog = 2;
-constexpr int kBlkEPT = 8;
-constexpr int split_fwd_passes(int logn) { return (logn - head_log(logn) + 2) / 3; }
-constexpr int split_inv_passes(int logn) { return (logn - kTailLog + 2) / 3; }
+// Elements per middle-kernel thread: 8 (radix <= 8 passes).  4 (radix <= 4 passes, twice the threads, about half the
+// registers, ~40 % more passes) is a build-time experiment (-DHIPBFV_BLK_EPT=4), see DESIGN.md 5.5.
+#ifndef HIPBFV_BLK_EPT
+#define HIPBFV_BLK_EPT 8
+#endif
+constexpr int kBlkEPT = HIPBFV_BLK_EPT;
+static_assert(kBlkEPT == 8 || kBlkEPT == 4, "middle kernels hold 8 or 4 elements per thread");
+constexpr int split_fwd_passes(int logn) { return kBlkEPT == 4 ? (logn - head_log(logn) + 1) / 2 : (logn - head_log(logn) + 2) / 3; }
+constexpr int split_inv_passes(int logn) { return kBlkEPT == 4 ? (logn - kTailLog + 1) / 2 : (logn - kTailLog + 2) / 3; }
 constexpr int split_fwd_radix(int logn, int p) {
+  // 4 per thread: radix 4 throughout, an odd stage count starts with one radix-2 pass
+  if (kBlkEPT == 4) return (((logn - head_log(logn)) & 1) && p == 0) ? 1 : 2;
   // remaining stages: 9 -> 3,3,3 ; 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3
   return logn - head_log(logn) == 10 ? (p < 2 ? 3 : 2) : logn - head_log(logn) == 11 ? (p == 0 ? 2 : 3) : 3;
 }
 constexpr int split_inv_radix(int logn, int p) {
+  // 4 per thread: radix 4 throughout, an odd stage count ends with one radix-2 pass
+  if (kBlkEPT == 4) return (((logn - kTailLog) & 1) && p == split_inv_passes(logn) - 1) ? 1 : 2;
   // logn-2 stages, first radix == last forward radix: 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3 ; 13 -> 3,3,3,2,2
   return logn - kTailLog == 10 ? (p < 2 ? 3 : 2) : logn - kTailLog == 11 ? (p == 0 ? 2 : 3) : logn - kTailLog == 13 ? (p < 3 ? 3 : 2) : 3;
 }
