@@ -617,6 +617,9 @@ class BFVEvaluator:
         _check(_lib.load().Evaluator_ModSwitchToNext2(self._h, p.get_handle(), out.get_handle()))
         return out
 
+    def mod_switch_to_next_inplace_plaintext(self, p: "Plaintext") -> None:
+        _check(_lib.load().Evaluator_ModSwitchToNext2(self._h, p.get_handle(), p.get_handle()))
+
     # -- key switching (bfv_evaluator.rs:143-247)
     def relinearize_inplace(self, a: Ciphertext, relin_keys: RelinearizationKeys) -> None:
         _check(_lib.load().Evaluator_Relinearize(self._h, a._h, relin_keys._h, a._h, None))
