@@ -99,8 +99,12 @@ int Evaluator::decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, s
     HC_CHECK(hipMemcpy2DAsync(ctn, per * n * sizeof(u64), ct + off * cs + (size_t)K * n, cs * sizeof(u64), per * n * sizeof(u64), c,
                               hipMemcpyDeviceToDevice, s));
     HB_LAUNCH_CLIENT(kKernNttFwd, c * per, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, ctn, c * per, plan, false, 0, s));
-    HC_CHECK(launch_dot_secret(ctx_->dev(), n, K, ctn, size, sk_ntt, acc, c, s));
-    HB_LAUNCH_CLIENT(kKernNttInv, c * K, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, acc, c * K, plan, true, 0, s));
+    if (size == 2 && h.logn <= 14) {  // c1 (.) s is formed while the inverse transform loads its input
+      HB_LAUNCH_CLIENT(kKernNttInv, c * K, launch_ntt_inv_dyadic(ctx_->dev(), h.tw_inv, h.logn, ctn, sk_ntt, acc, K, 1, h.KK, c, s));
+    } else {
+      HC_CHECK(launch_dot_secret(ctx_->dev(), n, K, ctn, size, sk_ntt, acc, c, s));
+      HB_LAUNCH_CLIENT(kKernNttInv, c * K, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, acc, c * K, plan, true, 0, s));
+    }
     HC_CHECK(launch_decrypt_round(ctx_->dev(), n, ct + off * cs, size, acc, plain + off * n, c, s));
   }
   return kOk;
@@ -255,7 +259,7 @@ int Evaluator::encrypt(const u64* plain, size_t pstride, const u64* pk, u64 seed
     HC_CHECK(launch_encrypt_sample(ctx_->dev(), n, seed, first_op + off, u, nullptr, c, s));
     HB_LAUNCH_CLIENT(kKernNttFwd, c * KK, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, u, c * KK, plan, false, 0, s));
     if (h.logn <= 14) {  // pk (.) NTT(u) is formed while the inverse transform loads its input
-      HB_LAUNCH_CLIENT(kKernNttInv, c * 2 * KK, launch_ntt_inv_dyadic(ctx_->dev(), h.tw_inv, h.logn, u, pk, c2, KK, c, s));
+      HB_LAUNCH_CLIENT(kKernNttInv, c * 2 * KK, launch_ntt_inv_dyadic(ctx_->dev(), h.tw_inv, h.logn, u, pk, c2, KK, 2, KK, c, s));
     } else {
       HC_CHECK(launch_encrypt_dyadic(ctx_->dev(), n, KK, u, pk, c2, c, s));
       HB_LAUNCH_CLIENT(kKernNttInv, c * 2 * KK, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, c2, c * 2 * KK, plan, true, 0, s));

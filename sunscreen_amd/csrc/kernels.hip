@@ -288,21 +288,22 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
   }
 }
 
-// c[op][j][i] = INTT(a[op][i] (.) b[j][i]) for j = 0, 1 over the first `nmod` moduli: the key-level product pk * u of a
-// public-key encryption (a = NTT(u), b = the public key), one workgroup per output polynomial
+// c[op][j][i] = INTT(a[op][i] (.) b[j][i]) for j < nb over the first `nmod` moduli, one workgroup per output polynomial:
+// the key-level product pk * u of a public-key encryption (a = NTT(u), b = the public key, nb = 2) and the c1 * s of a
+// decryption (a = NTT(c1), b = the secret key, nb = 1)
 template <int LOGN>
 __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_dyadic_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase,
                                                                            const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ c,
-                                                                           u32 nmod) {
+                                                                           u32 nmod, u32 nb, u32 bstride) {
   using Sh = NttShape<LOGN>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const u32 tid = threadIdx.x;
   const u32 poly = blockIdx.x;
-  const u32 m = poly % nmod, j = (poly / nmod) & 1u, op = poly / (2 * nmod);
+  const u32 m = poly % nmod, j = (poly / nmod) % nb, op = poly / (nb * nmod);
   const DevMod& dm = ctx->mod[m];
   u64* x = c + (size_t)poly * Sh::N;
   const u64* pa = a + ((size_t)op * nmod + m) * Sh::N;
-  const u64* pb = b + ((size_t)j * nmod + m) * Sh::N;
+  const u64* pb = b + ((size_t)j * bstride + m) * Sh::N;  // b: u64[nb][bstride][N] (bstride >= nmod rows per polynomial)
   const MulOp* tw = twbase + (size_t)m * Sh::N;
   if (dm.use_f64)
     ntt_inv_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), dm.ninv_d, x, reinterpret_cast<double*>(smem_raw), tid, pa, pb);
@@ -527,7 +528,8 @@ static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, si
 }
 
 template <int LOGN>
-static hipError_t launch_ntt_inv_dyadic_t(const DevCtx* ctx, const MulOp* tw, const u64* a, const u64* b, u64* c, u32 nmod, size_t ops, hipStream_t s) {
+static hipError_t launch_ntt_inv_dyadic_t(const DevCtx* ctx, const MulOp* tw, const u64* a, const u64* b, u64* c, u32 nmod, u32 nb, u32 bstride,
+                                          size_t ops, hipStream_t s) {
   using Sh = NttShape<LOGN>;
   const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
   static bool attr_done = false;
@@ -535,18 +537,19 @@ static hipError_t launch_ntt_inv_dyadic_t(const DevCtx* ctx, const MulOp* tw, co
     (void)hipFuncSetAttribute((const void*)ntt_inv_dyadic_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  ntt_inv_dyadic_kernel<LOGN><<<dim3((unsigned)(ops * 2 * nmod)), dim3(Sh::T), lds, s>>>(ctx, tw, a, b, c, nmod);
+  ntt_inv_dyadic_kernel<LOGN><<<dim3((unsigned)(ops * nb * nmod)), dim3(Sh::T), lds, s>>>(ctx, tw, a, b, c, nmod, nb, bstride);
   return hipGetLastError();
 }
-// c u64[ops][2][nmod][N] = INTT(a[op][i] (.) b[j][i]); a u64[ops][nmod][N], b u64[2][nmod][N] (N <= 16384)
-hipError_t launch_ntt_inv_dyadic(const DevCtx* ctx, const MulOp* tw_inv, u32 logn, const u64* a, const u64* b, u64* c, u32 nmod, size_t ops, hipStream_t s) {
+// c u64[ops][nb][nmod][N] = INTT(a[op][i] (.) b[j][i]); a u64[ops][nmod][N], b u64[nb][bstride][N] (N <= 16384)
+hipError_t launch_ntt_inv_dyadic(const DevCtx* ctx, const MulOp* tw_inv, u32 logn, const u64* a, const u64* b, u64* c, u32 nmod, u32 nb, u32 bstride,
+                                 size_t ops, hipStream_t s) {
   if (ops == 0) return hipSuccess;
   switch (logn) {
-    case 10: return launch_ntt_inv_dyadic_t<10>(ctx, tw_inv, a, b, c, nmod, ops, s);
-    case 11: return launch_ntt_inv_dyadic_t<11>(ctx, tw_inv, a, b, c, nmod, ops, s);
-    case 12: return launch_ntt_inv_dyadic_t<12>(ctx, tw_inv, a, b, c, nmod, ops, s);
-    case 13: return launch_ntt_inv_dyadic_t<13>(ctx, tw_inv, a, b, c, nmod, ops, s);
-    case 14: return launch_ntt_inv_dyadic_t<14>(ctx, tw_inv, a, b, c, nmod, ops, s);
+    case 10: return launch_ntt_inv_dyadic_t<10>(ctx, tw_inv, a, b, c, nmod, nb, bstride, ops, s);
+    case 11: return launch_ntt_inv_dyadic_t<11>(ctx, tw_inv, a, b, c, nmod, nb, bstride, ops, s);
+    case 12: return launch_ntt_inv_dyadic_t<12>(ctx, tw_inv, a, b, c, nmod, nb, bstride, ops, s);
+    case 13: return launch_ntt_inv_dyadic_t<13>(ctx, tw_inv, a, b, c, nmod, nb, bstride, ops, s);
+    case 14: return launch_ntt_inv_dyadic_t<14>(ctx, tw_inv, a, b, c, nmod, nb, bstride, ops, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -54,7 +54,8 @@ hipError_t launch_batch_gather(const DevCtx* ctx, u32 n, const u32* map, const u
 hipError_t launch_dot_secret(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 size, const u64* sk, u64* acc, size_t ops, hipStream_t s);
 hipError_t launch_decrypt_round(const DevCtx* ctx, u32 n, const u64* ct, u32 size, const u64* acc, u64* plain, size_t ops, hipStream_t s);
 hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, u64 seed, u64 op0, u64* u, u64* e, size_t ops, hipStream_t s);
-hipError_t launch_ntt_inv_dyadic(const DevCtx* ctx, const MulOp* tw_inv, u32 logn, const u64* a, const u64* b, u64* c, u32 nmod, size_t ops, hipStream_t s);
+hipError_t launch_ntt_inv_dyadic(const DevCtx* ctx, const MulOp* tw_inv, u32 logn, const u64* a, const u64* b, u64* c, u32 nmod, u32 nb, u32 bstride,
+                                 size_t ops, hipStream_t s);
 hipError_t launch_encrypt_finish(const DevCtx* ctx, u32 n, u64 seed, u64 op0, const u64* c2, const u64* plain, size_t pstride, u64* out, size_t ops,
                                  hipStream_t s);
 hipError_t launch_encrypt_dyadic(const DevCtx* ctx, u32 n, u32 KK, const u64* un, const u64* pk, u64* c, size_t ops, hipStream_t s);
