@@ -43,6 +43,8 @@ def parse():
                          "(examples/chi_sq, examples/dot_prod) through the batch graph executor (SURVEY 8d configs 4 / 5b); "
                          "e2e = encode + encrypt both operands, multiply + relinearize, decrypt + decode, all on the device; "
                          "pir = examples/pir lookup over a (--batch x --batch) plaintext database held in transform form (SURVEY 8d config 5a)")
+    ap.add_argument("--coeff-bits", default="", help="comma-separated prime sizes (CoeffModulus::create, last = special prime) instead of the "
+                    "SEAL default set for --n, e.g. 54,54,54,56 for the 3 x 54-bit n=8192 variant BASELINE.json mentions")
     ap.add_argument("--chunk", type=int, default=0, help="override the executor's chunk size (ops per launch group)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="ops in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -77,7 +79,8 @@ def main():
     from oracle import bfv_oracle as O
 
     n = args.n
-    primes = O.bfv_default(n)
+    primes = O.coeff_modulus_create(n, [int(b) for b in args.coeff_bits.split(",")]) if args.coeff_bits else O.bfv_default(n)
+    pset = ("CoeffModulus::create(" + args.coeff_bits + ")") if args.coeff_bits else "SEAL default 128-bit"
     t = O.plain_batching(n, 17)
     ctx = Context.from_raw(n, primes, t)
     ev = BatchEvaluator(ctx)
@@ -121,7 +124,7 @@ def main():
         unit_bytes = 48 * K * n  # read 2 ciphertexts, write 1 (compulsory HBM traffic per op)
         units_per_step = B
         metric, unit = "bfv_mul_relin_ops_per_sec", "ops/s"
-        workload = f"BFV ct*ct multiply+relinearize, n={n}, K={K}+1 SEAL default 128-bit primes, t={t}, batch={B} pairs/GPU"
+        workload = f"BFV ct*ct multiply+relinearize, n={n}, K={K}+1 {pset} primes, t={t}, batch={B} pairs/GPU"
     elif args.workload == "e2e":
         from sunscreen_amd import PublicKey, SecretKey
 
@@ -229,7 +232,7 @@ def main():
         unit_bytes = 16 * n  # one single-residue transform: read + write
         units_per_step = 2 * B * nprimes
         metric, unit = "ntt_single_residue_transforms_per_sec", "NTT/s"
-        workload = f"batched forward+inverse negacyclic NTT, n={n}, {nprimes} primes, batch={B} polys/GPU"
+        workload = f"batched forward+inverse negacyclic NTT, n={n}, {nprimes} primes ({pset}), batch={B} polys/GPU"
 
     def barrier():
         if world > 1:
