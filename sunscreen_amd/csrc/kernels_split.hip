@@ -178,7 +178,7 @@ __device__ __forceinline__ void reduce_all(const A& ar, typename A::V (&v)[kBlkE
 #define MID_BATCHED_D true
 #endif
 #ifndef MID_BATCHED_I
-#define MID_BATCHED_I false
+#define MID_BATCHED_I true
 #endif
 #ifndef TW_PIPE_D
 #define TW_PIPE_D 1
