@@ -4,6 +4,8 @@ Every test calls libhipbfv.so (sunscreen_amd/lib) -- never the oracle -- for the
 uses the oracle only as the checker.  Sizes are kept where the oracle finishes in seconds; full
 BASELINE sizes are covered by size-independent properties in test_gpu_properties.py.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -372,6 +374,12 @@ def test_multiply_edge_parameter_sets(n, bits, tbits):
             RelinearizationKeys.from_array(ctx, np.zeros((1, 2, 1, n), dtype=np.uint64))
 
 
+# These two tests assert the DEFAULT base choice; the switches that turn it off make them moot (the rest of the suite is
+# meaningful -- and green -- under every switch, which is how the variants are exercised wholesale)
+_own_base_off = os.environ.get("HIPBFV_SEAL_AUX") == "1" or os.environ.get("HIPBFV_NO_F64") == "1"
+
+
+@pytest.mark.skipif(_own_base_off, reason="the own auxiliary base is switched off by the environment")
 def test_auxiliary_base_choice_and_bound():
     """The BEHZ auxiliary base is internal to multiply.  FP64-capable data primes -> the library's own base of
     primes below 2^48 whose product covers the same bound SEAL sizes its base for (2^(32 + bits(t) + bits(q)));
@@ -396,6 +404,7 @@ def test_auxiliary_base_choice_and_bound():
     assert not ctx2.aux_fp64 and ctx2.aux_primes == [int(p) for p in o2.bsk]
 
 
+@pytest.mark.skipif(_own_base_off, reason="the own auxiliary base is switched off by the environment")
 @pytest.mark.parametrize("n,tbits", [(8192, 40), (8192, 50), (4096, 30), (16384, 45)])
 def test_multiply_large_plain_modulus_own_base(n, tbits):
     """Large plain moduli push the integers that pass through the auxiliary base towards its size bound
