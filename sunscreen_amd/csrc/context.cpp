@@ -1,5 +1,6 @@
 // sunscreen_amd/csrc/context.cpp -- see context.hpp.
 #include "context.hpp"
+#include "griddot.hpp"
 #include "nttshape.hpp"
 
 #include <hip/hip_runtime.h>
@@ -564,6 +565,18 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       h.B_to_msk_d[j] = (double)h.B_to_msk[j];
     }
     h.inv_B_mod_msk_d = make_mulop_d(h.inv_B_mod_msk.w, m_sk);
+    // Exact sums for the q -> Bsk conversions of the head and tail kernels (griddot.hpp): every term is a residue mod
+    // some q_i times a constant below the target Bsk_j; the extension has K + 1 terms (the r_mtilde correction, whose
+    // factors are smaller still), the floor K.  One grid serves every target; sums are reduced by the Bsk primes.
+    long double qmax = 0, bmax = 0, bmin = 1e30L;
+    for (u32 i = 0; i < K; i++) qmax = std::max(qmax, (long double)q[i]);
+    for (u64 p : Bsk) bmax = std::max(bmax, (long double)p), bmin = std::min(bmin, (long double)p);
+    double magic = 0;
+    const bool ok = plan_grid_dot(qmax, bmax, K + 1, bmin, bmax, &magic);
+    h.conv_grid = ok ? 1u : 0u;
+    h.conv_magic = ok ? magic : 0.0;
+    if (const char* env = std::getenv("HIPBFV_NO_GRID"))
+      if (env[0] == '1') h.conv_grid = 0;
   }
 
   h.mid_nd = h.mid_ni = 0;

@@ -106,6 +106,11 @@ struct DevCtx {
   double B_to_msk_d[kMaxBsk];
   MulOpD inv_B_mod_msk_d;
   double B_mod_q_d[kMaxKey];
+  // exact base-conversion sums (griddot.hpp): 1.5 * 2^(52+g), valid when conv_grid != 0 (context.cpp proves the bounds
+  // for this context's moduli; otherwise the head / tail kernels reduce every product of a sum on its own)
+  double conv_magic;
+  u32 conv_grid;
+  u32 pad4;
 
   // split multiply: residue indices (0..K+S-1) handled by the FP64 / integer middle kernel
   unsigned char mid_res_d[kMaxMod];

@@ -244,6 +244,7 @@ class Context:
         self.aux_fp64 = bool(own.value & 1)
         self.packed_mul = bool(own.value & 2)  # 48-bit packed intermediates in the split multiply / key switch
         self.packed_ks = bool(own.value & 4)
+        self.conv_grid = bool(own.value & 8)  # base-conversion sums formed exactly and reduced once (griddot.hpp)
 
     def get_handle(self):
         return self._h
