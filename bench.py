@@ -326,10 +326,19 @@ def main():
         # measured HBM bytes per launch from the committed PMC profile of this workload (FETCH_SIZE x2 + WRITE_SIZE,
         # collected in separate rocprofv3 --pmc passes: tools/gpu_round_report.sh, tools/pmc_traffic.py)
         traffic = None
+        valu = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
             if name in pmc and n == 8192:
                 traffic = int(pmc[name]["hbm_bytes_per_unit"] * rec["units"] / rec["launches"])
+                if "valu_issue_frac" in pmc[name]:
+                    # SURVEY 8(d) asks for the VALU bound beside the HBM one: this path is FP64-issue-bound before it is
+                    # HBM-bound.  Measured in the same committed PMC passes: SQ_INSTS_VALU x 4 cycles per wave64
+                    # instruction / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); not re-measured live (PMC needs rocprofv3).
+                    valu = {"bound": "valu_issue", "kernel": name, "frac": pmc[name]["valu_issue_frac"],
+                            "wave_insts_per_launch": int(pmc[name]["valu_wave_insts_per_dispatch"]),
+                            "shader_cycles_per_launch": int(pmc[name]["shader_cycles_per_dispatch"]),
+                            "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes)"}
         except Exception:
             traffic = None
         roofline = {
@@ -364,6 +373,7 @@ def main():
         "config": {"workload": workload, "batch_per_gpu": B, "poly_modulus_degree": n, "coeff_modulus_primes": KK,
                    "plain_modulus": t, "parallelism": f"batch-sharded x{world}", "chunk_ops": args.chunk or "auto"},
         "roofline": roofline,
+        "valu": valu if dom else None,
         "whole_op_hbm": {"algorithmic_bytes_per_unit": unit_bytes, "achieved_GBps_per_gpu": round(op_rate_gbs, 1),
                          "frac_of_peak": round(op_rate_gbs / HBM_PEAK_GBS, 4)},
         "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},

@@ -136,6 +136,7 @@ long KeyGenerator_CreatePublicKey(void *thisptr, bool save_seed, void **public_k
 long KeyGenerator_CreateRelinKeys(void *thisptr, bool save_seed, void **relin_keys);
 long KeyGenerator_CreateGaloisKeysFromElts(void *thisptr, uint64_t count, uint32_t *galois_elts, bool save_seed, void **galois_keys);
 long KeyGenerator_CreateGaloisKeysAll(void *thisptr, bool save_seed, void **galois_keys);
+long KeyGenerator_CreateGaloisKeysFromSteps(void *thisptr, uint64_t count, int *steps, bool save_seed, void **galois_keys); /* SEAL keygenerator.h; not bound by seal_fhe */
 
 /* ---- BatchEncoder (seal_fhe/src/encoder.rs:50-215): slot vectors <-> plaintexts, transforms over Z_t on the device ---- */
 long BatchEncoder_Create(void *context, void **encoder);

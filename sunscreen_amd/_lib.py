@@ -151,6 +151,7 @@ _SIGNATURES = {
     "KeyGenerator_CreateRelinKeys": [vp, C.c_bool, vpp],
     "KeyGenerator_CreateGaloisKeysFromElts": [vp, u64, C.POINTER(C.c_uint32), C.c_bool, vpp],
     "KeyGenerator_CreateGaloisKeysAll": [vp, C.c_bool, vpp],
+    "KeyGenerator_CreateGaloisKeysFromSteps": [vp, u64, C.POINTER(C.c_int), C.c_bool, vpp],
     "hipbfv_KeyGenerator_SetSeed": [vp, u64], "hipbfv_KeyGenerator_CreateSeeded": [vp, u64, vpp],
     "BatchEncoder_Create": [vp, vpp], "BatchEncoder_Destroy": [vp],
     "BatchEncoder_Encode1": [vp, u64, u64p, vp], "BatchEncoder_Encode2": [vp, u64, C.POINTER(C.c_int64), vp],

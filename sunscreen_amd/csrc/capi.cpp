@@ -2854,6 +2854,19 @@ long KeyGenerator_CreateGaloisKeysFromElts(void* h, uint64_t count, uint32_t* ga
   *galois_keys = k.release();
   return HIPBFV_S_OK;
 }
+// SEAL KeyGenerator::create_galois_keys(steps): one key per rotation step, GaloisTool::get_elts_from_steps (step 0 = the
+// column rotation).  The seal_fhe crate does not call it; exported so that the whole KeyGenerator_* family links.
+long KeyGenerator_CreateGaloisKeysFromSteps(void* h, uint64_t count, int* steps, bool save_seed, void** galois_keys) {
+  KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
+  if (!g || !galois_keys || (count && !steps)) return HIPBFV_E_POINTER;
+  std::vector<uint32_t> elts;
+  for (uint64_t i = 0; i < count; i++) {
+    const u32 elt = g->ev->galois_elt_from_step(steps[i]);
+    if (!elt) return fail(HIPBFV_E_INVALIDARG, "step count too large");
+    elts.push_back(elt);
+  }
+  return KeyGenerator_CreateGaloisKeysFromElts(h, elts.size(), elts.data(), save_seed, galois_keys);
+}
 // SEAL GaloisTool::get_elts_all: the column rotation 2N-1 and 3^(+-2^i) for every power-of-two row rotation
 long KeyGenerator_CreateGaloisKeysAll(void* h, bool save_seed, void** galois_keys) {
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);

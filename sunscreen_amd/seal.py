@@ -752,10 +752,15 @@ class KeyGenerator:
         _check(_lib.load().KeyGenerator_CreateRelinKeys(self._h, False, C.byref(k._h)))
         return k
 
-    def create_galois_keys(self, galois_elts: Sequence[int] | None = None) -> GaloisKeys:
+    def create_galois_keys(self, galois_elts: Sequence[int] | None = None, steps: Sequence[int] | None = None) -> GaloisKeys:
+        """All keys (SEAL create_galois_keys()), the keys of the given Galois elements, or -- `steps` -- of the given
+        rotation steps (SEAL create_galois_keys(steps); step 0 = the column rotation)."""
         k = self._adopt(GaloisKeys)
         L = _lib.load()
-        if galois_elts is None:
+        if steps is not None:
+            arr = (C.c_int * len(steps))(*[int(e) for e in steps])
+            _check(L.KeyGenerator_CreateGaloisKeysFromSteps(self._h, len(steps), arr, False, C.byref(k._h)))
+        elif galois_elts is None:
             _check(L.KeyGenerator_CreateGaloisKeysAll(self._h, False, C.byref(k._h)))
         else:
             arr = (C.c_uint32 * len(galois_elts))(*[int(e) for e in galois_elts])

@@ -342,6 +342,17 @@ def test_key_generator_from_existing_secret_and_reproducibility():
     assert gk.has_key((elt - 1) // 2) and not gk.has_key(n - 1)
     rot = o.rotate_rows(ct, 3, {elt: gk.to_array(ctx, (elt - 1) // 2)})
     assert (o.batch_decode(o.decrypt(rot, osk))[: n // 2] == np.roll(o.batch_decode(msg)[: n // 2], -3)).all()
+    # keys by rotation step (SEAL create_galois_keys(steps)): step 0 is the column rotation, too large a step is refused
+    gs = kg.create_galois_keys(steps=[3, -2, 0])
+    for st in (3, -2, 0):
+        e = o.galois_elt_from_step(st) if st else 2 * n - 1
+        assert gs.has_key((e - 1) // 2)
+    assert not gs.has_key((o.galois_elt_from_step(1) - 1) // 2)
+    e2 = o.galois_elt_from_step(-2)
+    rot = o.rotate_rows(ct, -2, {e2: gs.to_array(ctx, (e2 - 1) // 2)})
+    assert (o.batch_decode(o.decrypt(rot, osk))[: n // 2] == np.roll(o.batch_decode(msg)[: n // 2], 2)).all()
+    with pytest.raises(Exception):
+        kg.create_galois_keys(steps=[n // 2])
     # seeded generators repeat; successive keys from one generator differ; unseeded generators differ
     a, b = KeyGenerator(ctx, seed=5), KeyGenerator(ctx, seed=5)
     assert (a.secret_key().to_array(ctx) == b.secret_key().to_array(ctx)).all()
