@@ -199,6 +199,53 @@ np.save(sys.argv[1], np.concatenate([r.cpu().numpy().ravel(), m.cpu().numpy().ra
         assert (r[9 + i].astype(np.uint64) == o.relinearize(om, rk)).all(), i
 
 
+@pytest.mark.parametrize("name", ["default_4096_16", "default_8192_17", "default_16384_17", "seal_fhe_unit"])
+def test_grid_base_conversion_sums_give_the_same_bits(name):
+    """The multiply's q -> Bsk sums are formed exactly on an FP64 grid and reduced once (griddot.hpp) or, with
+    HIPBFV_NO_GRID=1, reduced term by term: every degree's head / tail instantiation (4 and 8 primes) must produce the same
+    product in both forms, on random operands and at the edges of the bounds, and the edge cases must equal the oracle."""
+    import tempfile
+
+    script = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from tests.bfv_helpers import params
+from tests.test_gpu_properties import _extreme_rows
+from sunscreen_amd import Context
+from sunscreen_amd.batch import BatchEvaluator
+n, primes, t = params(sys.argv[2])
+ctx = Context.from_raw(n, primes, t); ev = BatchEvaluator(ctx)
+gen = torch.Generator(device="cuda:0"); gen.manual_seed(23)
+a = torch.empty((5, 2, ctx.K, n), dtype=torch.int64, device="cuda:0"); b = torch.empty_like(a)
+for i, q in enumerate(primes[:ctx.K]):
+    a[:, :, i, :] = torch.randint(0, q, (5, 2, n), generator=gen, device="cuda:0", dtype=torch.int64)
+    b[:, :, i, :] = torch.randint(0, q, (5, 2, n), generator=gen, device="cuda:0", dtype=torch.int64)
+xa, xb = _extreme_rows(primes, ctx.K, n)
+a = torch.cat([a, torch.from_numpy(xa).cuda()]); b = torch.cat([b, torch.from_numpy(xb).cuda()])
+m = ev.multiply(a, b)
+torch.cuda.synchronize()
+np.save(sys.argv[1], np.concatenate([m.cpu().numpy().ravel(), np.array([int(ctx.conv_grid)], dtype=np.int64)]))
+""" % ROOT
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("grid", {}), ("per_term", {"HIPBFV_NO_GRID": "1"})):
+            path = os.path.join(td, tag + ".npy")
+            subprocess.check_call([sys.executable, "-c", script, path, name], env=dict(os.environ, **env))
+            outs.append(np.load(path))
+    assert outs[1][-1] == 0, "HIPBFV_NO_GRID=1 must select the per-term form"
+    switched_off = any(os.environ.get(k) == "1" for k in ("HIPBFV_NO_GRID", "HIPBFV_SEAL_AUX", "HIPBFV_NO_F64"))
+    if name.startswith("default_") and not switched_off:  # (seal_fhe_unit has 50-bit primes: the plan may refuse them)
+        assert outs[0][-1] == 1, "the default parameter sets are within the grid plan's bounds"
+    assert (outs[0][:-1] == outs[1][:-1]).all()
+    n, primes, t = params(name)
+    o = oracle_for(name)
+    K = len(primes) - 1
+    xa, xb = _extreme_rows(primes, K, n)
+    m = outs[0][:-1].reshape(5 + len(xa), 3, K, n)
+    for i in range(len(xa)):
+        assert (m[5 + i].astype(np.uint64) == o.multiply(xa[i].astype(np.uint64), xb[i].astype(np.uint64))).all(), i
+
+
 def test_concurrent_host_threads_on_one_evaluator():
     """sunscreen_runtime/src/run.rs:415-469 calls one evaluator from a rayon pool: handle-level calls must be
     thread-safe (one non-blocking HIP stream per host thread, no shared mutable scratch)."""
