@@ -8,12 +8,6 @@
 
 namespace hipbfv {
 
-// Coefficients whose q -> Bsk sums are formed together in the head kernel (it owns 8 per thread at N <= 8192; all 8 at
-// once cost 22 more VGPRs and one wave per SIMD).
-#ifndef GRID_EXT_GROUP
-#define GRID_EXT_GROUP 4
-#endif
-
 // fastbconv_m_tilde + sm_mrq for one coefficient: x[i] = residue mod q_i  ->  out[j] = residue mod Bsk_j
 // (Evaluator_Multiply steps 1-2, seal_fhe/src/evaluator_base.rs:198-212 -> SEAL bfv_multiply).
 template <int KMAX>
@@ -190,9 +184,7 @@ __device__ __forceinline__ void behz_floor_sk_coeff_d(const DevCtx* __restrict__
 
 // x[i][k]: canonical residue of coefficient k mod q_i (double); ext(j, out): called once per auxiliary prime j with
 // out[k] = representative of the extended value mod Bsk_j, |out[k]| < Bsk_j
-// GRID (DevCtx::conv_grid): the sums over the source residues are formed exactly on the grid of DevCtx::conv_magic and
-// reduced once (griddot.hpp) instead of term by term -- the same residues, so the same canonical results.
-template <int KMAX, int NC, bool GRID, class Sink>
+template <int KMAX, int NC, class Sink>
 __device__ __forceinline__ void behz_extend_multi_d(const DevCtx* __restrict__ ctx, double (&x)[KMAX][NC], Sink&& ext) {
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK;
   u32 rm[NC];
@@ -221,39 +213,14 @@ __device__ __forceinline__ void behz_extend_multi_d(const DevCtx* __restrict__ c
     const ArithD ar(ctx->mod[KK + j]);
     double acc[NC];
     const double qmb = ctx->q_mod_bsk_d[j];
-    if constexpr (GRID) {
-      // coefficients in groups of GRID_EXT_GROUP: each sum carries two accumulators while it is being formed
-      const double magic = ctx->conv_magic;
-      constexpr int GN = NC < GRID_EXT_GROUP ? NC : GRID_EXT_GROUP;
 #pragma unroll
-      for (int k0 = 0; k0 < NC; k0 += GN) {
-        double hi[GN], lo[GN];
+    for (int k = 0; k < NC; k++) acc[k] = ar.mul_var(rc[k], qmb);
 #pragma unroll
-        for (int k = 0; k < GN; k++) {
-          const GridDot g(magic, rc[k0 + k], qmb);
-          hi[k] = g.acc, lo[k] = g.err;
-        }
+    for (int i = 0; i < KMAX; i++) {
+      if ((u32)i < K) {
+        const double c = ctx->q_to_bsk_d[j][i];
 #pragma unroll
-        for (int i = 0; i < KMAX; i++) {
-          if ((u32)i < K) {
-            const double c = ctx->q_to_bsk_d[j][i];
-#pragma unroll
-            for (int k = 0; k < GN; k++) grid_dot_add(hi[k], lo[k], x[i][k0 + k], c);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < GN; k++) acc[k0 + k] = ar.reduce(hi[k] - magic) + lo[k];
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NC; k++) acc[k] = ar.mul_var(rc[k], qmb);
-#pragma unroll
-      for (int i = 0; i < KMAX; i++) {
-        if ((u32)i < K) {
-          const double c = ctx->q_to_bsk_d[j][i];
-#pragma unroll
-          for (int k = 0; k < NC; k++) acc[k] += ar.mul_var(x[i][k], c);
-        }
+        for (int k = 0; k < NC; k++) acc[k] += ar.mul_var(x[i][k], c);
       }
     }
     const MulOpD inv = ctx->inv_mtilde_mod_bsk_d[j];
@@ -268,9 +235,13 @@ __device__ __forceinline__ void behz_extend_multi_d(const DevCtx* __restrict__ c
 // Two-phase source: fetch(j, raw) only issues the loads of auxiliary residue j (raw words, no arithmetic on them);
 // finish(j, raw, xb) turns them into xb.  Residue j+1 is fetched before residue j is consumed, so two residues'
 // loads are in flight per thread (the tail kernels are latency-bound, not bandwidth-bound, at their occupancy).
-// GRID: as in behz_extend_multi_d, for the q -> Bsk sums (they live inside one trip of the loop over auxiliary primes).
-// The Shenoy-Kumaresan sums grow across the trips: in grid form each needs a second loop-carried accumulator, and the
-// register copies that come with it cancel the saving (ISA count), so they keep the per-term reduction.
+// GRID (DevCtx::conv_grid, used by the 8-prime instantiation): the q -> Bsk sums of the floor are formed exactly on the
+// grid of DevCtx::conv_magic and reduced once (griddot.hpp) instead of term by term -- the same residues, so the same
+// canonical results.  Measured (interleaved A/B on one box): mul_tail -8.5 % at K = 8 (n = 16384), +1.4 % at K = 4, where a
+// sum has too few terms to repay its fixed cost; the same form in the head's extension costs registers (one wave per
+// SIMD) for no gain at K = 4 and +8 % at K = 8 (the head is HBM-bound), so the head keeps the per-term reduction.  The
+// Shenoy-Kumaresan sums grow across the trips of the loop: in grid form each needs a second loop-carried accumulator and
+// the register copies that come with it cancel the saving (ISA count).
 template <int KMAX, int NC, bool GRID, class Raw, class Fetch, class Finish>
 __device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__ ctx, const double (&yc)[KMAX][NC], Fetch&& fetch, Finish&& finish,
                                                       u64 (&out)[KMAX][NC]) {

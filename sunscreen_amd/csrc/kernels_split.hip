@@ -720,8 +720,7 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 // mul head: grid (N/8/256, 4 polys (a0,a1,b0,b1), ops); ext = [ops][4][K+S][N] in native representation
 // AUXD (DevCtx::aux_f64): every residue, auxiliary base included, takes the FP64 policy and the base extension
 // itself runs in FP64 (behz_extend_coeff_d).
-// GRID (DevCtx::conv_grid, AUXD only): base-conversion sums formed exactly and reduced once (griddot.hpp).
-template <int L, int KMAX, bool AUXD, bool PACK, bool GRID>
+template <int L, int KMAX, bool AUXD, bool PACK>
 __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
                                                                 u64* __restrict__ ext) {
@@ -754,7 +753,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
     }
     // auxiliary base: extend all eight owned coefficients residue by residue (every conversion constant is
     // fetched once), and run the head stages of each auxiliary residue as soon as it is complete
-    behz_extend_multi_d<KMAX, NC, GRID>(ctx, x, [&](u32 j, double(&ev)[NC]) {
+    behz_extend_multi_d<KMAX, NC>(ctx, x, [&](u32 j, double(&ev)[NC]) {
       const ArithD ar(ctx->mod[KK + j]);
       head_fwd(ar, ev, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N));
       double* o = reinterpret_cast<double*>(dst - t + (size_t)(K + j) * N);
@@ -1041,6 +1040,7 @@ __device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const NatRaw
 }
 
 // mul tail: grid (N/4/256, 3 polys, ops); out = [ops][3][K][N] canonical
+// GRID (DevCtx::conv_grid, 8-prime all-FP64 instantiation only): floor sums formed exactly and reduced once (griddot.hpp)
 template <int L, int KMAX, bool AUXD, bool PACK, bool GRID>
 __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                 const u64* __restrict__ D, u64* __restrict__ out) {
@@ -1359,43 +1359,30 @@ hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pa
 }
 
 template <int L>
-static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, bool pack, bool conv_grid, u32 kneed, const u64* a, const u64* b, u64* ext,
+static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
                              size_t ops, hipStream_t s) {
   const dim3 grid(((1u << L) >> head_log(L)) / kHeadThreads, 4, (unsigned)ops);
   if (kneed > 4) {  // only the all-FP64 instantiation exists for 5..8 data primes (evaluator.cpp checks)
     if (pack)
-      if (conv_grid)
-        mul_head_kernel<L, 8, true, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
-      else
-        mul_head_kernel<L, 8, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 8, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
     else
-      if (conv_grid)
-        mul_head_kernel<L, 8, true, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
-      else
-        mul_head_kernel<L, 8, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 8, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   } else if (aux_f64) {
     if (pack)
-      if (conv_grid)
-        mul_head_kernel<L, 4, true, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
-      else
-        mul_head_kernel<L, 4, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 4, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
     else
-      if (conv_grid)
-        mul_head_kernel<L, 4, true, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
-      else
-        mul_head_kernel<L, 4, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 4, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   } else {
-    mul_head_kernel<L, 4, false, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+    mul_head_kernel<L, 4, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   }
   return hipGetLastError();
 }
 // aux_f64: DevCtx::aux_f64 of the context behind `ctx` (selects the all-FP64 instantiation)
 // kneed: max(data primes, auxiliary primes - 2) -- selects the 4- or 8-prime instantiation
 // pack: DevCtx::pack_mul (only with aux_f64)
-// conv_grid: DevCtx::conv_grid (only with aux_f64)
-hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, bool pack, bool conv_grid, u32 kneed, const u64* a, const u64* b,
-                           u64* ext, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack && aux_f64, conv_grid && aux_f64, kneed, a, b, ext, ops, s)
+hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
+                           size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack && aux_f64, kneed, a, b, ext, ops, s)
 }
 
 template <int L>
@@ -1430,20 +1417,15 @@ static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, 
         mul_tail_kernel<L, 8, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
   } else if (aux_f64) {
     if (pack)
-      if (conv_grid)
-        mul_tail_kernel<L, 4, true, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
-      else
-        mul_tail_kernel<L, 4, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+      mul_tail_kernel<L, 4, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
     else
-      if (conv_grid)
-        mul_tail_kernel<L, 4, true, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
-      else
-        mul_tail_kernel<L, 4, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+      mul_tail_kernel<L, 4, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
   } else {
     mul_tail_kernel<L, 4, false, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
   }
   return hipGetLastError();
 }
+// conv_grid: DevCtx::conv_grid (takes effect in the 8-prime instantiation, kneed > 4)
 hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, bool pack, bool conv_grid, u32 kneed, const u64* D, u64* out,
                            size_t ops, hipStream_t s) {
   SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, pack && aux_f64, conv_grid && aux_f64, kneed, D, out, ops, s)
