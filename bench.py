@@ -329,7 +329,7 @@ def main():
         valu = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-            if name in pmc and n == 8192:
+            if name in pmc and n == 8192 and args.workload == "mulrelin" and not args.coeff_bits:  # the workload the PMC passes profiled
                 traffic = int(pmc[name]["hbm_bytes_per_unit"] * rec["units"] / rec["launches"])
                 if "valu_issue_frac" in pmc[name]:
                     # SURVEY 8(d) asks for the VALU bound beside the HBM one: this path is FP64-issue-bound before it is
