@@ -246,6 +246,41 @@ np.save(sys.argv[1], np.concatenate([m.cpu().numpy().ravel(), np.array([int(ctx.
         assert (m[5 + i].astype(np.uint64) == o.multiply(xa[i].astype(np.uint64), xb[i].astype(np.uint64))).all(), i
 
 
+@pytest.mark.parametrize(
+    "n,bits",
+    [
+        (4096, [36, 36, 36, 36, 36, 37]),          # K = 5: the 8-prime instantiation with small primes (a coarse grid suffices)
+        (4096, [44] * 8 + [45]),                    # K = 8, n = 8192-sized primes
+        (8192, [47] * 6 + [48]),                    # K = 6 close to the plan's limit
+        (4096, [49] * 6 + [50]),                    # K = 6 with the widest FP64-policy primes
+        (16384, [48, 48, 48, 49, 49, 49, 49, 49, 49]),  # the n = 16384 default sizes
+    ],
+)
+def test_multiply_around_the_grid_plan_limit(n, bits):
+    """The 8-prime head / tail instantiation (5..8 data primes) across prime sizes up to plan_grid_dot()'s bounds: the product
+    equals the oracle's (SEAL's 61-bit base, integer arithmetic) on random operands and at the edges, whichever form the
+    context's plan selected."""
+    import torch
+
+    from sunscreen_amd import Context
+    from sunscreen_amd.batch import BatchEvaluator
+
+    primes = O.coeff_modulus_create(n, bits)
+    t = O.plain_batching(n, 17)
+    o = O.Oracle(n, primes, t)
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    K = len(primes) - 1
+    rng = np.random.default_rng(n + sum(bits))
+    a = np.stack([rng.integers(0, q, (2, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2).astype(np.int64)
+    b = np.stack([rng.integers(0, q, (2, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2).astype(np.int64)
+    xa, xb = _extreme_rows(primes, K, n)
+    a, b = np.concatenate([a, xa]), np.concatenate([b, xb])
+    m = ev.multiply(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy().astype(np.uint64)
+    for i in range(len(a)):
+        assert (m[i] == o.multiply(a[i].astype(np.uint64), b[i].astype(np.uint64))).all(), (i, ctx.aux_fp64, ctx.conv_grid)
+
+
 def test_concurrent_host_threads_on_one_evaluator():
     """sunscreen_runtime/src/run.rs:415-469 calls one evaluator from a rayon pool: handle-level calls must be
     thread-safe (one non-blocking HIP stream per host thread, no shared mutable scratch)."""
