@@ -45,6 +45,5 @@ timeout 300 python bench.py --coeff-bits 54,54,54,56 --steps 5 --warmup 2 2>/dev
 timeout 300 python bench.py --workload e2e --batch 2048 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_e2e_n8192.json
 timeout 300 python bench.py --workload chi_sq --n 16384 --batch 256 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_chi_sq_n16384.json
 timeout 300 python bench.py --workload dot_prod --n 16384 --batch 256 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_dot_prod_n16384.json
-timeout 300 python bench.py --workload pir --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_pir_n8192.json
 HIPBFV_NO_GRID=1 timeout 600 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_no_grid.log 2>&1; tail -1 $OUT/pytest_gpu_no_grid.log
 ls $OUT; du -sh $OUT
