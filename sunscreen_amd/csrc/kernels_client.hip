@@ -376,6 +376,9 @@ __global__ __launch_bounds__(kClientThreads) void crt_decompose_kernel(const Dev
 // acc[row][p][i][x] = sum_j ctn[j][p][i][x] * pntt[row][j][i][x] mod q_i     (all NTT form, canonical residues)
 // One thread = one coefficient of one residue, RT consecutive rows and both ciphertext polynomials: every ciphertext
 // word is read once per RT rows, the plaintext matrix (the database) streams through exactly once.
+#ifndef PIR_NT
+#define PIR_NT 1
+#endif
 template <int RT>
 __global__ __launch_bounds__(kClientThreads) void dot_plain_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 cols,
                                                                    const u64* __restrict__ pntt, u32 rows, u64* __restrict__ acc) {
@@ -393,7 +396,11 @@ __global__ __launch_bounds__(kClientThreads) void dot_plain_kernel(const DevCtx*
 #pragma unroll
     for (int r = 0; r < RT; r++) {
       if (r0 + r < rows) {
+#if PIR_NT
+        const u64 pv = __builtin_nontemporal_load(&pntt[(((size_t)(r0 + r) * cols + j) * K + i) * n + x]);  // the database streams through once
+#else
         const u64 pv = pntt[(((size_t)(r0 + r) * cols + j) * K + i) * n + x];
+#endif
         a0[r] += (u128)c0 * pv;
         a1[r] += (u128)c1 * pv;
       }
