@@ -1,0 +1,53 @@
+"""The committed benchmark evidence keeps the driver's contract: one JSON object per line with the metric BASELINE.json
+names, a `roofline` object for the dominant kernel, a `cpu_baseline` object for the oracle, and -- for the headline
+workload -- PMC-derived traffic and VALU issue occupancy that agree with profiles/pmc_traffic.json (tools/pmc_traffic.py)."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lines():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v2*_bench_*.json")))
+    assert files, "no committed bench lines"
+    return [(os.path.basename(f), json.load(open(f))) for f in files]
+
+
+def test_bench_lines_follow_the_contract():
+    for name, d in _lines():
+        for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                         ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str)):
+            assert isinstance(d[key], typ), (name, key)
+        assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["data"] == "synthetic" and d["dtype"] == "u64", name
+        assert "workload" in d["config"] and "model" not in d["config"], name
+        r = d["roofline"]
+        assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s"), name
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3, name
+        c = d["cpu_baseline"]
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"], name
+        assert "bit-exact" in d["parity"] or "==" in d["parity"] or "decrypts" in d["parity"] or "decoded" in d["parity"], name
+
+
+def test_headline_line_carries_the_measured_traffic_and_valu_occupancy():
+    d = dict(_lines())["r01_v22_bench_mulrelin_n8192.json"]
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+    k = d["roofline"]["kernel"]
+    per_launch = pmc[k]["hbm_bytes_per_unit"] * pmc[k]["units_per_dispatch"]
+    assert abs(d["roofline"]["traffic"] - per_launch) / per_launch < 0.01
+    # measured traffic within a few per cent of the algorithmic bytes: no wasted re-reads
+    assert 0.95 < d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"] < 1.10
+    assert d["valu"]["kernel"] == k and abs(d["valu"]["frac"] - pmc[k]["valu_issue_frac"]) < 1e-6
+    assert 0.0 < d["valu"]["frac"] < 1.0
+
+
+def test_pmc_traffic_tool_reproduces_the_committed_file(tmp_path):
+    p = os.path.join(ROOT, "profiles", "r01_v22_mulrelin_n8192_")
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    units = tmp_path / "units.json"
+    units.write_text(json.dumps({k: v["units_per_dispatch"] for k, v in committed["kernels"].items()}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), p + "pmc_fetch.txt", p + "pmc_write.txt", str(units),
+                          p + "pmc_inst.txt"], capture_output=True, text=True, check=True).stdout
+    assert json.loads(out) == committed
