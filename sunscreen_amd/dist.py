@@ -77,3 +77,31 @@ def gather_results(local: torch.Tensor, total: int) -> torch.Tensor | None:
         lo, hi = shard_range(total, r, world)
         out.append(parts[r][: hi - lo])
     return torch.cat(out, dim=0)
+
+
+def broadcast_bytes(data: bytes | None, src: int = 0, device: str | torch.device = "cpu") -> bytes:
+    """One-time replication of a serialised object (keys are broadcast from their owner, 2.6 MB ... 486 MB):
+    rank `src` passes the bytes, every other rank passes None; all ranks return the same bytes.  Two collectives (length,
+    payload); over RCCL the payload travels as one uint8 tensor on `device`."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        assert data is not None
+        return data
+    rank = dist.get_rank()
+    n = torch.tensor([len(data) if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    if rank == src:
+        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
+    else:
+        buf = torch.empty((int(n.item()),), dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src=src)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def replicate_keys(ctx, key, cls, src: int = 0, device: str | torch.device = "cpu"):
+    """The key owner (rank `src`) holds `key` (a sunscreen_amd.seal RelinearizationKeys / GaloisKeys / PublicKey object);
+    every rank returns a device-resident copy, made from the SEAL wire format (uncompressed: the bytes cross xGMI once,
+    zstd would cost more host time than the transfer).  Evaluation then needs no further communication."""
+    blob = broadcast_bytes(key.as_bytes(compression=0) if (not dist.is_initialized() or dist.get_rank() == src) else None, src, device)
+    if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_rank() != src:
+        return cls.from_bytes(ctx, blob)
+    return key

@@ -51,6 +51,10 @@ def test_two_rank_gloo_timing_and_gather(tmp_path):
             elapsed = D.timed_steps(step, steps=3, warmup=1)
             assert len(calls) == 4
             assert elapsed >= 0.06 - 1e-3, elapsed
+            # one-time key replication: the owner's serialised bytes reach every rank unchanged
+            blob = bytes(range(256)) * 1000 + b"tail"
+            got = D.broadcast_bytes(blob if rank == 1 else None, src=1)
+            assert got == blob
             full = D.gather_results(local, total)
             assert full.shape == (total, 2, 3)
             assert [int(full[i, 0, 0]) for i in range(total)] == [i * 10 for i in range(total)]
