@@ -565,9 +565,10 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       h.B_to_msk_d[j] = (double)h.B_to_msk[j];
     }
     h.inv_B_mod_msk_d = make_mulop_d(h.inv_B_mod_msk.w, m_sk);
-    // Exact sums for the q -> Bsk conversions of the head and tail kernels (griddot.hpp): every term is a residue mod
-    // some q_i times a constant below the target Bsk_j; the extension has K + 1 terms (the r_mtilde correction, whose
-    // factors are smaller still), the floor K.  One grid serves every target; sums are reduced by the Bsk primes.
+    // Exact sums for the q -> Bsk conversion of the multiply's floor (griddot.hpp; used by the 8-prime tail kernel, where
+    // it pays): every term is a residue mod some q_i times a constant below the target Bsk_j, K terms per sum (the plan
+    // allows K + 1, the length of the extension's sum with its r_mtilde term).  One grid serves every target; the sums
+    // are reduced by the Bsk primes.
     long double qmax = 0, bmax = 0, bmin = 1e30L;
     for (u32 i = 0; i < K; i++) qmax = std::max(qmax, (long double)q[i]);
     for (u64 p : Bsk) bmax = std::max(bmax, (long double)p), bmin = std::min(bmin, (long double)p);

@@ -12,8 +12,8 @@
 //
 // So  sum = (acc - M) + err  exactly, with H = acc - M a multiple of 2^g: one quotient estimate reduces H
 // (H - rint(H/p)*p is a small integer, exact in one fma), and err is added on top.  4 DP instructions per term + 5 per
-// sum instead of 7 per term.  plan_grid_dot() (host) picks g for a context and proves the bounds; contexts that fail
-// keep the per-term reduction.
+// sum instead of 7 per term: it pays from about 8 terms (the floor of the 8-prime multiply, behzcore.hpp; measured there).
+// plan_grid_dot() (host) picks g for a context and proves the bounds; contexts that fail keep the per-term reduction.
 #pragma once
 #include <cmath>
 
