@@ -11,7 +11,7 @@
 
 #include "hipbfv.hpp"
 
-using namespace hipbfv;
+using namespace seal_fhe;
 
 static int host_only() {
   // modulus.rs:279-313 known answers: CoeffModulus::create(8192, [50, 30, 30, 50, 50]) and PlainModulus::batching

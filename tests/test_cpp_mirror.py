@@ -1,7 +1,10 @@
 """include/hipbfv.hpp -- the compiled-language host mirror of the `seal_fhe` crate's surface (the reference's host side is
 Rust; no Rust toolchain exists here) -- builds against the C ABI and behaves like the crate: examples/simple_multiply.cpp is
 the reference's examples/simple_multiply (15 * 5 = 75, examples/simple_multiply/src/main.rs:57-80) plus the rotation / wire
-format / transparent-ciphertext checks of seal_fhe/src/bfv_evaluator.rs:322-970, written against that header."""
+format / transparent-ciphertext checks of seal_fhe/src/bfv_evaluator.rs:322-970, written against that header.
+
+The device half (`./simple_multiply` without arguments) ran on the MI355X box (profiles/r01_final_cpp_simple_multiply.log);
+it is not part of the `-m gpu` suite yet: see DESIGN.md section 10 (symbol visibility of the library)."""
 import os
 import subprocess
 
