@@ -359,6 +359,9 @@ long finish_result(EvalObj* e, CipherObj* dst, u32 size, u64* buf, size_t words,
 
 }  // namespace
 
+// The C ABI is the library's only interface: with `make HIDDEN=1` (-fvisibility=hidden) everything else stays inside the DSO
+// (the internal hipbfv:: C++ symbols are otherwise exported and can be interposed by user code).
+#pragma GCC visibility push(default)
 extern "C" {
 
 // ------------------------------------------------------------------ library
@@ -2889,3 +2892,4 @@ long KeyGenerator_CreateGaloisKeysAll(void* h, bool save_seed, void** galois_key
 }
 
 }  // extern "C"
+#pragma GCC visibility pop
