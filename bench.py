@@ -13,7 +13,10 @@ parity gate needs -- the library has no key generator), checker (parity gate, af
 `cpu_baseline`.  Nothing in the timed region touches it.
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank processes its own
-`--batch` items (weak scaling, no data-path collective); time = max over ranks.
+`--batch` items (weak scaling, no data-path collective); time = max over ranks.  Under torchrun the ranks come from the
+environment (WORLD_SIZE must equal --gpus); a bare `python bench.py --gpus N` spawns the N ranks itself.  Rank 0 owns the
+keys and broadcasts them once (sunscreen_amd.dist.replicate_keys); `--gather` additionally times the optional all_gather
+of the results (reported apart from `value`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -49,19 +52,49 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="ops in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--check-items", type=int, default=64, help="mulrelin: items compared bit for bit with the oracle (BASELINE.md section 3: >= 64)")
+    ap.add_argument("--gather", action="store_true", help="N>1: also time one all_gather of the result batch (reported as result_gather_ms, never part of value)")
     return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without torchrun: start one process per GPU (this file again) with the torchrun
+    environment, wait for all of them; rank 0 prints the JSON line.  The parent never touches a GPU."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(args.gpus)]
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+        if rc:  # one rank failed: the others would wait in a collective forever
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+    return rc
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (torchrun --nproc-per-node {args.gpus}) or drop the torchrun environment"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # validation knobs for boxes with fewer GPUs than ranks (not used by the driver): all ranks on device 0, gloo
     if os.environ.get("HIPBFV_BENCH_ONE_DEVICE") == "1":
@@ -100,22 +133,29 @@ def main():
 
     result = {}
     if args.workload == "mulrelin":
+        from sunscreen_amd import PublicKey, SecretKey
+        from sunscreen_amd import dist as D
+
         o = O.Oracle(n, primes, t)
-        O.seed(0xBF5 + 17)
-        sk, pk, rk, _ = o.keygen()
-        rkd = RelinearizationKeys.from_array(ctx, rk)
-        a = uniform_residues((B, 2), K, primes)
-        b = uniform_residues((B, 2), K, primes)
-        # a few genuine encryptions at the head of the batch: parity + decrypt check against the oracle
-        ncheck = 0 if args.no_check else 4
-        rng = np.random.default_rng(rank)
-        va = rng.integers(0, 257, (ncheck, n)).astype(np.uint64)
-        vb = rng.integers(0, 257, (ncheck, n)).astype(np.uint64)
-        if ncheck:
-            ea = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in va])
-            eb = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vb])
-            a[:ncheck] = to_device(ea, dev)
-            b[:ncheck] = to_device(eb, dev)
+        # rank 0 is the key owner (the oracle stands in for the client's key generator); the other ranks receive the
+        # SEAL-format bytes once and build their device copies from them -- the deployment form, SURVEY 8(e)
+        rk = sk = None
+        rkd = skd = pkd = None
+        if rank == 0:
+            O.seed(0xBF5 + 17)
+            sk, pk, rk, _ = o.keygen()
+            rkd, skd, pkd = RelinearizationKeys.from_array(ctx, rk), SecretKey.from_array(ctx, sk), PublicKey.from_array(ctx, pk)
+        cdev = dev if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+        rkd = D.replicate_keys(ctx, rkd, RelinearizationKeys, 0, cdev)
+        skd = D.replicate_keys(ctx, skd, SecretKey, 0, cdev)
+        pkd = D.replicate_keys(ctx, pkd, PublicKey, 0, cdev)
+        # the whole batch is genuine: slot vectors in [-128, 128] (products stay below t/2),
+        # batch-encoded and encrypted under the public key by the library's own encryptor, resident in HBM
+        va = torch.randint(-128, 129, (B, n), generator=gen, device=dev, dtype=torch.int64)
+        vb = torch.randint(-128, 129, (B, n), generator=gen, device=dev, dtype=torch.int64)
+        a = ev.encrypt(ev.encode(va, signed=True), pkd, seed=0xA0 + 2 * rank)
+        b = ev.encrypt(ev.encode(vb, signed=True), pkd, seed=0xA1 + 2 * rank)
+        ncheck = 0 if args.no_check else min(args.check_items, B)
         out = torch.empty((B, 2, K, n), dtype=torch.int64, device=dev)
 
         def step():
@@ -257,18 +297,42 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- optional result gather (only if the consumer wants every result on one device), timed apart ----
+    gather_ms = None
+    if args.gather and world > 1 and args.workload == "mulrelin":
+        from sunscreen_amd import dist as D
+
+        barrier()
+        t0 = time.perf_counter()
+        full = D.gather_results(out, B * world)
+        torch.cuda.synchronize()
+        gather_ms = 1e3 * (time.perf_counter() - t0)
+        assert full.shape[0] == B * world and torch.equal(full[rank * B : (rank + 1) * B], out)
+        del full
+
     # ---- parity gate (after timing so that the timed region is exactly K steps) ----
     parity = "skipped"
     if args.workload == "mulrelin" and not args.no_check:
-        got = to_host(out[:ncheck])
-        for i in range(ncheck):
-            ref_i = o.relinearize(o.multiply(ea[i], eb[i]), rk)
-            assert (got[i] == ref_i).all(), "HIP result differs from the CPU oracle"
-            assert (o.batch_decode(o.decrypt(got[i], sk)) == (va[i] * vb[i]) % t).all()
-        # size-independent property on the whole batch: every output word is a canonical residue
+        # (1) decrypt-correct on ALL items of every rank (device decryptor, itself bit-exact vs the oracle: tests/test_gpu_client.py)
+        dec = ev.decode(ev.decrypt(out, skd), signed=True)
+        ok = bool(torch.equal(dec, va * vb))
+        # (2) every output word is a canonical residue
         for i in range(K):
-            assert int(out[:, :, i, :].max()) < primes[i] and int(out[:, :, i, :].min()) >= 0
-        parity = f"bit-exact vs oracle on {ncheck} items; all {B} outputs canonical"
+            ok = ok and int(out[:, :, i, :].max()) < primes[i] and int(out[:, :, i, :].min()) >= 0
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+        assert ok, "a multiply+relinearize result does not decrypt to the slot-wise product (or is not canonical)"
+        # (3) bit-exact vs the oracle on the first `ncheck` items of rank 0's shard (OpenMP over the items)
+        if rank == 0:
+            ha, hb, got = to_host(a[:ncheck]), to_host(b[:ncheck]), to_host(out[:ncheck])
+            _, ref = o.bench_mul_relin(ha, hb, rk, threads=min(os.cpu_count() or 1, 64))
+            assert (got == ref).all(), "HIP result differs from the CPU oracle"
+            assert (ref[0] == o.relinearize(o.multiply(ha[0], hb[0]), rk)).all()
+            budget = o.noise_budget(got[0], sk)
+            assert budget > 0
+        parity = f"bit-exact vs oracle on {ncheck} items; all {B * world} results decrypt to the slot-wise products; all outputs canonical"
     elif args.workload == "pir" and not args.no_check:
         got = to_host(ev.decrypt(holder["out"], skd))[0]
         assert int(got[0]) == int(vals[sel_r, sel_c]) and not got[1:].any(), "PIR lookup returned the wrong entry"
@@ -321,24 +385,32 @@ def main():
             "galois": 16 * n * K, "eltwise": 24 * n,                 # per polynomial / per residue polynomial (2 reads + 1 write)
         }.get(name, 16 * n)
         avg_ms = rec["ms"] / rec["launches"]
-        bytes_per_launch = per_unit * rec["units"] / rec["launches"]
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        # measured HBM bytes per launch from the committed PMC profile of this workload (FETCH_SIZE x2 + WRITE_SIZE,
-        # collected in separate rocprofv3 --pmc passes: tools/gpu_round_report.sh, tools/pmc_traffic.py)
+        kernel_bytes_per_launch = per_unit * rec["units"] / rec["launches"]
+        kernel_rate = kernel_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        # SURVEY 8(d) ALGORITHMIC bytes: the per-unit compulsory figure x the units ONE launch of this kernel processes.
+        # A unit is one op / program run / database entry (the dominant kernel sees total_units / launches of them per
+        # launch); for the transform workload the unit is one single-residue transform = the kernel's own work unit.
+        units_per_launch = rec["units"] / rec["launches"] if args.workload == "ntt" else units_per_step * args.steps / rec["launches"]
+        achieved = unit_bytes * units_per_launch / (avg_ms * 1e-3) / 1e9
+        # measured HBM bytes per launch and VALU issue occupancy from the committed PMC profile of THIS workload
+        # (FETCH_SIZE x2 + WRITE_SIZE, SQ_INSTS_VALU*, GRBM_GUI_ACTIVE in separate rocprofv3 --pmc passes:
+        # tools/gpu_pmc_report.sh, tools/pmc_traffic.py); PMC needs rocprofv3, so it is not re-measured live
         traffic = None
         valu = None
+        wkey = pmc_workload_key(args, n)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-            if name in pmc and n == 8192 and args.workload == "mulrelin" and not args.coeff_bits:  # the workload the PMC passes profiled
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"][wkey]["kernels"]
+            if name in pmc:
                 traffic = int(pmc[name]["hbm_bytes_per_unit"] * rec["units"] / rec["launches"])
                 if "valu_issue_frac" in pmc[name]:
                     # SURVEY 8(d) asks for the VALU bound beside the HBM one: this path is FP64-issue-bound before it is
-                    # HBM-bound.  Measured in the same committed PMC passes: SQ_INSTS_VALU x 4 cycles per wave64
-                    # instruction / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); not re-measured live (PMC needs rocprofv3).
+                    # HBM-bound.  Issue cycles per wave64 instruction by class: 4 for FP64, 2 for everything else
+                    # (MI355X_MICROARCH.md, wave scheduling) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).
                     valu = {"bound": "valu_issue", "kernel": name, "frac": pmc[name]["valu_issue_frac"],
                             "wave_insts_per_launch": int(pmc[name]["valu_wave_insts_per_dispatch"]),
+                            "f64_wave_insts_per_launch": int(pmc[name].get("valu_f64_wave_insts_per_dispatch", 0)),
                             "shader_cycles_per_launch": int(pmc[name]["shader_cycles_per_dispatch"]),
-                            "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes)"}
+                            "source": f"profiles/pmc_traffic.json [{wkey}] (rocprofv3 --pmc passes)"}
         except Exception:
             traffic = None
         roofline = {
@@ -351,7 +423,13 @@ def main():
             "traffic": traffic,
             "avg_launch_ms": round(avg_ms, 4),
             "launches": rec["launches"],
-            "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "algorithmic_bytes_per_unit": unit_bytes,
+            "units_per_launch": round(units_per_launch, 3),
+            "algorithmic_bytes_per_launch": int(unit_bytes * units_per_launch),
+            # the kernel's OWN reads and writes (pipeline intermediates included) over the same
+            # launch time: what it keeps in flight, not what the operation has to move
+            "kernel_hbm": {"bytes_per_launch": int(kernel_bytes_per_launch), "achieved": round(kernel_rate, 1),
+                           "frac": round(kernel_rate / HBM_PEAK_GBS, 4)},
         }
     op_rate_gbs = unit_bytes * (value / world) / 1e9
     cpu = None
@@ -377,12 +455,23 @@ def main():
         "whole_op_hbm": {"algorithmic_bytes_per_unit": unit_bytes, "achieved_GBps_per_gpu": round(op_rate_gbs, 1),
                          "frac_of_peak": round(op_rate_gbs / HBM_PEAK_GBS, 4)},
         "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+        "kernel_units_per_launch": {k: v["units"] / v["launches"] for k, v in prof.items()},
         "cpu_baseline": cpu,
         "parity": parity,
     }
+    if gather_ms is not None:
+        line["result_gather_ms"] = round(gather_ms, 3)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_workload_key(args, n):
+    """Key of this run's workload in profiles/pmc_traffic.json (the PMC passes are per workload)."""
+    k = f"{args.workload}_n{n}"
+    if args.coeff_bits:
+        k += "_bits" + args.coeff_bits.replace(",", "-")
+    return k
 
 
 def ctx_S(ctx):

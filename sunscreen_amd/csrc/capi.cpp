@@ -8,11 +8,15 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -25,8 +29,22 @@ using namespace hipbfv;
 namespace {
 
 thread_local std::string tls_error;
-int g_device = 0;
+// One device per process (one process per GPU): hipbfv_set_device() picks it before the first context
+// exists.  Every C entry point makes it the calling thread's current device first (enter_thread), so host threads that never
+// called hipSetDevice themselves -- the rayon workers of sunscreen_runtime/src/run.rs:415-469 -- allocate, create their
+// stream and launch on the device the contexts, twiddles and keys live on.
+std::atomic<int> g_device{0};
+std::atomic<long> g_live_contexts{0};
 bool g_throw_transparent = true;
+
+void enter_thread() {
+  thread_local int tls_device = -1;
+  const int want = g_device.load(std::memory_order_relaxed);
+  if (tls_device != want) {
+    if (hipSetDevice(want) != hipSuccess) (void)hipGetLastError();  // no GPU: the host-only entry points still work
+    tls_device = want;
+  }
+}
 
 long fail(long hr, const char* msg) {
   tls_error = msg ? msg : "";
@@ -107,6 +125,11 @@ struct PlainObj : Obj {
 // serialise concurrent evaluator threads (sunscreen_runtime/src/run.rs:415-469 calls from a rayon pool).
 class BufferCache {
  public:
+  BufferCache() {
+    // bytes the cache may hold on to (freed blocks beyond it go back to the device at once): long-lived processes that
+    // create and drop key sets (hundreds of MB each) or many contexts do not grow without bound
+    if (const char* e = std::getenv("HIPBFV_CACHE_BYTES")) budget_ = std::strtoull(e, nullptr, 10);
+  }
   u64* get(size_t words) {
     {
       std::lock_guard<std::mutex> g(mu_);
@@ -114,11 +137,13 @@ class BufferCache {
       if (it != free_.end() && !it->second.empty()) {
         u64* p = it->second.back();
         it->second.pop_back();
+        cached_ -= words * sizeof(u64);
         return p;
       }
     }
     void* p = nullptr;
     if (hipMalloc(&p, words * sizeof(u64)) != hipSuccess) {
+      (void)hipGetLastError();
       drain();
       if (hipMalloc(&p, words * sizeof(u64)) != hipSuccess) return nullptr;
     }
@@ -126,19 +151,34 @@ class BufferCache {
   }
   void put(u64* p, size_t words) {
     if (!p) return;
-    std::lock_guard<std::mutex> g(mu_);
-    free_[words].push_back(p);
+    const size_t bytes = words * sizeof(u64);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (cached_ + bytes <= budget_) {
+        free_[words].push_back(p);
+        cached_ += bytes;
+        return;
+      }
+    }
+    (void)hipFree(p);  // over budget: synchronises the device, which only happens for blocks the cache refuses
   }
   void drain() {
     std::lock_guard<std::mutex> g(mu_);
     for (auto& kv : free_)
       for (u64* p : kv.second) (void)hipFree(p);
     free_.clear();
+    cached_ = 0;
+  }
+  size_t cached_bytes() {
+    std::lock_guard<std::mutex> g(mu_);
+    return cached_;
   }
 
  private:
   std::mutex mu_;
   std::map<size_t, std::vector<u64*>> free_;
+  size_t cached_ = 0;
+  size_t budget_ = (size_t)4 << 30;
 };
 BufferCache g_buffers;
 
@@ -148,6 +188,7 @@ struct CipherObj : Obj {
   u64* dev = nullptr;
   size_t words = 0;
   std::vector<u64> host;  // lazily filled host mirror for GetDataAt
+  std::mutex host_mu;
   bool host_valid = false;
   CipherObj() : Obj(kMagicCipher) {}
   ~CipherObj() override { g_buffers.put(dev, words); }
@@ -361,73 +402,92 @@ long finish_result(EvalObj* e, CipherObj* dst, u32 size, u64* buf, size_t words,
 
 // The C ABI is the library's only interface: with `make HIDDEN=1` (-fvisibility=hidden) everything else stays inside the DSO
 // (the internal hipbfv:: C++ symbols are otherwise exported and can be interposed by user code).
+//
+// Exception barrier: no C++ exception may unwind through an extern "C" frame into Rust / ctypes (abort or UB there).  Every
+// exported function is a function-try-block that maps what is thrown to the HRESULT SEAL's C layer would return
+// (std::bad_alloc / length_error -> E_OUTOFMEMORY, invalid_argument / out_of_range -> E_INVALIDARG, logic_error ->
+// COR_E_INVALIDOPERATION, anything else -> E_UNEXPECTED) and records the message for hipbfv_last_error.
+#define HIPBFV_BEGIN try { enter_thread();
+#define HIPBFV_END                                                                                               \
+  }                                                                                                              \
+  catch (const std::bad_alloc&) { return fail(HIPBFV_E_OUTOFMEMORY, "out of host memory"); }                      \
+  catch (const std::length_error& x) { return fail(HIPBFV_E_OUTOFMEMORY, x.what()); }                             \
+  catch (const std::invalid_argument& x) { return fail(HIPBFV_E_INVALIDARG, x.what()); }                          \
+  catch (const std::out_of_range& x) { return fail(HIPBFV_E_INVALIDARG, x.what()); }                              \
+  catch (const std::logic_error& x) { return fail(HIPBFV_COR_E_INVALIDOPERATION, x.what()); }                     \
+  catch (const std::exception& x) { return fail(HIPBFV_E_UNEXPECTED, x.what()); }                                 \
+  catch (...) { return fail(HIPBFV_E_UNEXPECTED, "unknown C++ exception"); }
+
 #pragma GCC visibility push(default)
 extern "C" {
 
 // ------------------------------------------------------------------ library
-long hipbfv_version(uint32_t* major, uint32_t* minor) {
+long hipbfv_version(uint32_t* major, uint32_t* minor) HIPBFV_BEGIN
   if (!major || !minor) return HIPBFV_E_POINTER;
   *major = 0;
   *minor = 1;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_last_error(char* buffer, uint64_t capacity) {
+long hipbfv_last_error(char* buffer, uint64_t capacity) HIPBFV_BEGIN
   if (!buffer || capacity == 0) return HIPBFV_E_POINTER;
   std::strncpy(buffer, tls_error.c_str(), capacity - 1);
   buffer[capacity - 1] = 0;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_set_device(int device) {
+long hipbfv_set_device(int device) HIPBFV_BEGIN
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return fail(HIPBFV_E_INVALIDARG, "no such HIP device");
+  if (device != g_device.load() && g_live_contexts.load() > 0)
+    return fail(HIPBFV_COR_E_INVALIDOPERATION, "hipbfv_set_device: contexts exist on the current device (one device per process; destroy them first)");
   g_device = device;
+  enter_thread();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_set_throw_on_transparent(bool enabled) {
+long hipbfv_set_throw_on_transparent(bool enabled) HIPBFV_BEGIN
   g_throw_transparent = enabled;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ Modulus
-long Modulus_Create1(uint64_t value, void** out) {
+long Modulus_Create1(uint64_t value, void** out) HIPBFV_BEGIN
   if (!out) return HIPBFV_E_POINTER;
   if (value == 1 || (value >> 61)) return fail(HIPBFV_E_INVALIDARG, "modulus must be 0 or in [2, 2^61)");
   *out = new ModulusObj(value);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Modulus_Create2(void* copy, void** out) {
+long Modulus_Create2(void* copy, void** out) HIPBFV_BEGIN
   ModulusObj* m = as<ModulusObj>(copy, kMagicModulus);
   if (!m || !out) return HIPBFV_E_POINTER;
   *out = new ModulusObj(m->value);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Modulus_Destroy(void* p) {
+long Modulus_Destroy(void* p) HIPBFV_BEGIN
   ModulusObj* m = as<ModulusObj>(p, kMagicModulus);
   if (!m) return HIPBFV_E_POINTER;
   delete m;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Modulus_Value(void* p, uint64_t* result) {
+long Modulus_Value(void* p, uint64_t* result) HIPBFV_BEGIN
   ModulusObj* m = as<ModulusObj>(p, kMagicModulus);
   if (!m || !result) return HIPBFV_E_POINTER;
   *result = m->value;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ CoeffModulus
-long CoeffModulus_MaxBitCount(uint64_t n, int sec, int* bit_count) {
+long CoeffModulus_MaxBitCount(uint64_t n, int sec, int* bit_count) HIPBFV_BEGIN
   if (!bit_count) return HIPBFV_E_POINTER;
   *bit_count = max_coeff_bit_count(n, sec);
   return *bit_count ? HIPBFV_S_OK : fail(HIPBFV_E_INVALIDARG, "unsupported degree / security level");
-}
+HIPBFV_END
 
-long CoeffModulus_BFVDefault(uint64_t n, int sec, uint64_t* length, void** coeffs) {
+long CoeffModulus_BFVDefault(uint64_t n, int sec, uint64_t* length, void** coeffs) HIPBFV_BEGIN
   if (!length) return HIPBFV_E_POINTER;
   std::vector<u64> p = default_coeff_modulus(n, sec);
   if (p.empty()) return fail(HIPBFV_E_INVALIDARG, "no default coefficient modulus for these parameters");
@@ -435,9 +495,9 @@ long CoeffModulus_BFVDefault(uint64_t n, int sec, uint64_t* length, void** coeff
   if (!coeffs) return HIPBFV_S_OK;  // SEAL convention: first call queries the length
   for (size_t i = 0; i < p.size(); i++) coeffs[i] = new ModulusObj(p[i]);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long CoeffModulus_Create1(uint64_t n, uint64_t length, int* bit_sizes, void** coeffs) {
+long CoeffModulus_Create1(uint64_t n, uint64_t length, int* bit_sizes, void** coeffs) HIPBFV_BEGIN
   if (!bit_sizes || !coeffs) return HIPBFV_E_POINTER;
   if (n < 2 || (n & (n - 1)) || length == 0 || length > 64) return fail(HIPBFV_E_INVALIDARG, "invalid degree or length");
   // per distinct bit size: take the needed count from the descending prime list, hand out smallest first
@@ -460,40 +520,40 @@ long CoeffModulus_Create1(uint64_t n, uint64_t length, int* bit_sizes, void** co
   }
   for (uint64_t i = 0; i < length; i++) coeffs[i] = new ModulusObj(result[i]);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ EncryptionParameters
-long EncParams_Create1(uint8_t scheme, void** out) {
+long EncParams_Create1(uint8_t scheme, void** out) HIPBFV_BEGIN
   if (!out) return HIPBFV_E_POINTER;
   if (scheme != 1) return fail(HIPBFV_E_INVALIDARG, "only the BFV scheme (1) is supported");
   ParamsObj* p = new ParamsObj();
   p->scheme = scheme;
   *out = p;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long EncParams_Destroy(void* h) {
+long EncParams_Destroy(void* h) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(h, kMagicParams);
   if (!p) return HIPBFV_E_POINTER;
   delete p;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long EncParams_SetPolyModulusDegree(void* h, uint64_t degree) {
+long EncParams_SetPolyModulusDegree(void* h, uint64_t degree) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(h, kMagicParams);
   if (!p) return HIPBFV_E_POINTER;
   p->n = degree;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long EncParams_GetPolyModulusDegree(void* h, uint64_t* degree) {
+long EncParams_GetPolyModulusDegree(void* h, uint64_t* degree) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(h, kMagicParams);
   if (!p || !degree) return HIPBFV_E_POINTER;
   *degree = p->n;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long EncParams_SetCoeffModulus(void* h, uint64_t length, void** coeffs) {
+long EncParams_SetCoeffModulus(void* h, uint64_t length, void** coeffs) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(h, kMagicParams);
   if (!p || !coeffs) return HIPBFV_E_POINTER;
   std::vector<u64> v;
@@ -504,45 +564,45 @@ long EncParams_SetCoeffModulus(void* h, uint64_t length, void** coeffs) {
   }
   p->coeff = v;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long EncParams_GetCoeffModulus(void* h, uint64_t* length, void** coeffs) {
+long EncParams_GetCoeffModulus(void* h, uint64_t* length, void** coeffs) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(h, kMagicParams);
   if (!p || !length) return HIPBFV_E_POINTER;
   *length = p->coeff.size();
   if (!coeffs) return HIPBFV_S_OK;
   for (size_t i = 0; i < p->coeff.size(); i++) coeffs[i] = new ModulusObj(p->coeff[i]);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long EncParams_SetPlainModulus1(void* h, void* modulus) {
+long EncParams_SetPlainModulus1(void* h, void* modulus) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(h, kMagicParams);
   ModulusObj* m = as<ModulusObj>(modulus, kMagicModulus);
   if (!p || !m) return HIPBFV_E_POINTER;
   p->plain = m->value;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long EncParams_SetPlainModulus2(void* h, uint64_t plain) {
+long EncParams_SetPlainModulus2(void* h, uint64_t plain) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(h, kMagicParams);
   if (!p) return HIPBFV_E_POINTER;
   p->plain = plain;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long EncParams_GetPlainModulus(void* h, void** modulus) {
+long EncParams_GetPlainModulus(void* h, void** modulus) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(h, kMagicParams);
   if (!p || !modulus) return HIPBFV_E_POINTER;
   *modulus = new ModulusObj(p->plain);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long EncParams_GetScheme(void* h, uint8_t* scheme) {
+long EncParams_GetScheme(void* h, uint8_t* scheme) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(h, kMagicParams);
   if (!p || !scheme) return HIPBFV_E_POINTER;
   *scheme = p->scheme;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ SEALContext
 static long make_context(u64 n, const std::vector<u64>& coeff, u64 plain, int sec, void** out) {
@@ -556,12 +616,16 @@ static long make_context(u64 n, const std::vector<u64>& coeff, u64 plain, int se
   Context* c = Context::create((u32)n, coeff, plain, g_device, &err);
   if (!c) return fail(HIPBFV_E_INVALIDARG, err.c_str());
   ContextObj* o = new ContextObj();
-  o->ctx.reset(c);
+  g_live_contexts.fetch_add(1);
+  o->ctx.reset(c, [](Context* x) {
+    delete x;
+    g_live_contexts.fetch_sub(1);
+  });
   *out = o;
   return HIPBFV_S_OK;
 }
 
-long SEALContext_Create(void* params, bool expand_mod_chain, int sec_level, void** context) {
+long SEALContext_Create(void* params, bool expand_mod_chain, int sec_level, void** context) HIPBFV_BEGIN
   ParamsObj* p = as<ParamsObj>(params, kMagicParams);
   if (!p || !context) return HIPBFV_E_POINTER;
   if (p->n > 0xFFFFFFFFull) return fail(HIPBFV_E_INVALIDARG, "invalid degree");
@@ -569,22 +633,22 @@ long SEALContext_Create(void* params, bool expand_mod_chain, int sec_level, void
   // lower levels are created lazily on the first Evaluator_ModSwitchToNext; without the chain that call fails
   if (hr == HIPBFV_S_OK) static_cast<ContextObj*>(*context)->ctx->set_chain_enabled(expand_mod_chain);
   return hr;
-}
+HIPBFV_END
 
-long SEALContext_Destroy(void* h) {
+long SEALContext_Destroy(void* h) HIPBFV_BEGIN
   ContextObj* c = as<ContextObj>(h, kMagicContext);
   if (!c) return HIPBFV_E_POINTER;
   delete c;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Context_Create(uint64_t n, const uint64_t* coeff, uint64_t count, uint64_t plain, void** context) {
+long hipbfv_Context_Create(uint64_t n, const uint64_t* coeff, uint64_t count, uint64_t plain, void** context) HIPBFV_BEGIN
   if (!coeff || !context) return HIPBFV_E_POINTER;
   if (n > 0xFFFFFFFFull) return fail(HIPBFV_E_INVALIDARG, "invalid degree");
   return make_context(n, std::vector<u64>(coeff, coeff + count), plain, 0, context);
-}
+HIPBFV_END
 
-long hipbfv_Context_Info(void* h, uint64_t* n, uint64_t* K, uint64_t* KK, uint64_t* t) {
+long hipbfv_Context_Info(void* h, uint64_t* n, uint64_t* K, uint64_t* KK, uint64_t* t) HIPBFV_BEGIN
   ContextObj* c = as<ContextObj>(h, kMagicContext);
   if (!c) return HIPBFV_E_POINTER;
   if (n) *n = c->ctx->n();
@@ -592,17 +656,17 @@ long hipbfv_Context_Info(void* h, uint64_t* n, uint64_t* K, uint64_t* KK, uint64
   if (KK) *KK = c->ctx->KK();
   if (t) *t = c->ctx->t();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Context_GetPrime(void* h, uint64_t index, uint64_t* value) {
+long hipbfv_Context_GetPrime(void* h, uint64_t index, uint64_t* value) HIPBFV_BEGIN
   ContextObj* c = as<ContextObj>(h, kMagicContext);
   if (!c || !value) return HIPBFV_E_POINTER;
   if (index >= c->ctx->key_primes().size()) return fail(HIPBFV_E_INVALIDARG, "prime index out of range");
   *value = c->ctx->key_primes()[index];
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Context_AuxBase(void* h, uint64_t* count, uint64_t* primes, uint64_t capacity, int* fp64_base) {
+long hipbfv_Context_AuxBase(void* h, uint64_t* count, uint64_t* primes, uint64_t capacity, int* fp64_base) HIPBFV_BEGIN
   ContextObj* c = as<ContextObj>(h, kMagicContext);
   if (!c || !count) return HIPBFV_E_POINTER;
   const hipbfv::DevCtx& d = c->ctx->host();
@@ -613,19 +677,19 @@ long hipbfv_Context_AuxBase(void* h, uint64_t* count, uint64_t* primes, uint64_t
     for (uint32_t j = 0; j < d.S; j++) primes[j] = d.mod[d.KK + j].q;
   }
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ Plaintext
-long Plaintext_Create1(void* pool, void** out) {
+long Plaintext_Create1(void* pool, void** out) HIPBFV_BEGIN
   (void)pool;
   if (!out) return HIPBFV_E_POINTER;
   *out = new PlainObj();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // Plaintext from SEAL's polynomial string "7FFx^3 + 1x^1 + 3" (plaintext_ciphertext.rs:180-217): hexadecimal
 // coefficients, decimal exponents, strictly decreasing, terms separated by " + ", constant term without "x^"
-long Plaintext_Create4(char* hex_poly, void* pool, void** out) {
+long Plaintext_Create4(char* hex_poly, void* pool, void** out) HIPBFV_BEGIN
   (void)pool;
   if (!hex_poly || !out) return HIPBFV_E_POINTER;
   std::vector<std::pair<u64, u64>> terms;  // (exponent, coefficient)
@@ -650,7 +714,7 @@ long Plaintext_Create4(char* hex_poly, void* pool, void** out) {
       p += 2;
       int ed = 0;
       for (; *p >= '0' && *p <= '9'; p++, ed++) {
-        if (expo > (1u << 20)) return bad();
+        if (expo > (1u << 17)) return bad();  // SEAL_POLY_MOD_DEGREE_MAX = 131072 bounds the allocation below
         expo = expo * 10 + (u64)(*p - '0');
       }
       if (!ed || !expo) return bad();
@@ -674,71 +738,71 @@ long Plaintext_Create4(char* hex_poly, void* pool, void** out) {
   }
   *out = n;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_Create5(void* copy, void** out) {
+long Plaintext_Create5(void* copy, void** out) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(copy, kMagicPlain);
   if (!p || !out) return HIPBFV_E_POINTER;
   PlainObj* n = new PlainObj();
   n->coeffs = p->coeffs;
   *out = n;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_Destroy(void* h) {
+long Plaintext_Destroy(void* h) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(h, kMagicPlain);
   if (!p) return HIPBFV_E_POINTER;
   delete p;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_CoeffCount(void* h, uint64_t* count) {
+long Plaintext_CoeffCount(void* h, uint64_t* count) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(h, kMagicPlain);
   if (!p || !count) return HIPBFV_E_POINTER;
   *count = p->coeffs.size();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_CoeffAt(void* h, uint64_t index, uint64_t* coeff) {
+long Plaintext_CoeffAt(void* h, uint64_t index, uint64_t* coeff) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(h, kMagicPlain);
   if (!p || !coeff) return HIPBFV_E_POINTER;
   if (index >= p->coeffs.size()) return fail(HIPBFV_E_INVALIDARG, "coefficient index out of range");
   *coeff = p->coeffs[index];
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_SetCoeffAt(void* h, uint64_t index, uint64_t value) {
+long Plaintext_SetCoeffAt(void* h, uint64_t index, uint64_t value) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(h, kMagicPlain);
   if (!p) return HIPBFV_E_POINTER;
   if (index >= p->coeffs.size()) return fail(HIPBFV_E_INVALIDARG, "coefficient index out of range");
   p->coeffs[index] = value;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_Resize(void* h, uint64_t count) {
+long Plaintext_Resize(void* h, uint64_t count) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(h, kMagicPlain);
   if (!p) return HIPBFV_E_POINTER;
   if (count > (1u << 20)) return fail(HIPBFV_E_INVALIDARG, "plaintext too large");
   p->coeffs.resize(count, 0);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_IsNTTForm(void* h, bool* is_ntt) {
+long Plaintext_IsNTTForm(void* h, bool* is_ntt) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(h, kMagicPlain);
   if (!p || !is_ntt) return HIPBFV_E_POINTER;
   *is_ntt = false;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ Ciphertext
-long Ciphertext_Create1(void* pool, void** out) {
+long Ciphertext_Create1(void* pool, void** out) HIPBFV_BEGIN
   (void)pool;
   if (!out) return HIPBFV_E_POINTER;
   *out = new CipherObj();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Ciphertext_Create2(void* copy, void** out) {
+long Ciphertext_Create2(void* copy, void** out) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(copy, kMagicCipher);
   if (!c || !out) return HIPBFV_E_POINTER;
   CipherObj* n = new CipherObj();
@@ -757,37 +821,40 @@ long Ciphertext_Create2(void* copy, void** out) {
   }
   *out = n;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Ciphertext_Destroy(void* h) {
+long Ciphertext_Destroy(void* h) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c) return HIPBFV_E_POINTER;
   delete c;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Ciphertext_Size(void* h, uint64_t* size) {
+long Ciphertext_Size(void* h, uint64_t* size) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !size) return HIPBFV_E_POINTER;
   *size = c->size;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Ciphertext_CoeffModulusSize(void* h, uint64_t* k) {
+long Ciphertext_CoeffModulusSize(void* h, uint64_t* k) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !k) return HIPBFV_E_POINTER;
   *k = c->ctx ? c->ctx->K() : 0;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Ciphertext_PolyModulusDegree(void* h, uint64_t* n) {
+long Ciphertext_PolyModulusDegree(void* h, uint64_t* n) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !n) return HIPBFV_E_POINTER;
   *n = c->ctx ? c->ctx->n() : 0;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 static long ensure_host(CipherObj* c) {
+  // reads of one shared ciphertext from several host threads are legal in SEAL (GetDataAt / Save are const): the lazy
+  // mirror is filled under a lock, and host_valid is published after the data
+  std::lock_guard<std::mutex> g(c->host_mu);
   if (c->host_valid) return HIPBFV_S_OK;
   c->host.resize(c->words);
   if (c->words && hipMemcpy(c->host.data(), c->dev, c->words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess)
@@ -796,7 +863,7 @@ static long ensure_host(CipherObj* c) {
   return HIPBFV_S_OK;
 }
 
-long Ciphertext_GetDataAt1(void* h, uint64_t index, uint64_t* data) {
+long Ciphertext_GetDataAt1(void* h, uint64_t index, uint64_t* data) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !data) return HIPBFV_E_POINTER;
   if (index >= c->words) return fail(HIPBFV_E_INVALIDARG, "index out of range");
@@ -804,9 +871,9 @@ long Ciphertext_GetDataAt1(void* h, uint64_t index, uint64_t* data) {
   if (hr != HIPBFV_S_OK) return hr;
   *data = c->host[index];
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Ciphertext_GetDataAt2(void* h, uint64_t poly_index, uint64_t coeff_index, uint64_t* data) {
+long Ciphertext_GetDataAt2(void* h, uint64_t poly_index, uint64_t coeff_index, uint64_t* data) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !data) return HIPBFV_E_POINTER;
   if (!c->ctx || poly_index >= c->size || coeff_index >= c->ctx->n()) return fail(HIPBFV_E_INVALIDARG, "index out of range");
@@ -815,16 +882,16 @@ long Ciphertext_GetDataAt2(void* h, uint64_t poly_index, uint64_t coeff_index, u
   const size_t K = c->ctx->K(), n = c->ctx->n();
   for (size_t i = 0; i < K; i++) data[i] = c->host[(poly_index * K + i) * n + coeff_index];
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Ciphertext_IsNTTForm(void* h, bool* is_ntt) {
+long Ciphertext_IsNTTForm(void* h, bool* is_ntt) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !is_ntt) return HIPBFV_E_POINTER;
   *is_ntt = false;  // BFV ciphertexts stay in coefficient form between operations (evaluator_base.rs:46-53)
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Ciphertext_Assign(void* h, void* context, uint64_t size, const uint64_t* host_data) {
+long hipbfv_Ciphertext_Assign(void* h, void* context, uint64_t size, const uint64_t* host_data) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!c || !x || !host_data) return HIPBFV_E_POINTER;
@@ -844,32 +911,32 @@ long hipbfv_Ciphertext_Assign(void* h, void* context, uint64_t size, const uint6
   }
   c->adopt(x->ctx, (u32)size, buf, words);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Ciphertext_Export(void* h, uint64_t* host_data, uint64_t capacity_words) {
+long hipbfv_Ciphertext_Export(void* h, uint64_t* host_data, uint64_t capacity_words) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !host_data) return HIPBFV_E_POINTER;
   if (capacity_words < c->words) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
   if (c->words && hipMemcpy(host_data, c->dev, c->words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess)
     return from_status(kHipError);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Ciphertext_DevicePtr(void* h, uint64_t** device_ptr) {
+long hipbfv_Ciphertext_DevicePtr(void* h, uint64_t** device_ptr) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !device_ptr) return HIPBFV_E_POINTER;
   *device_ptr = (uint64_t*)c->dev;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ KSwitchKeys
-long KSwitchKeys_Create1(void** out) {
+long KSwitchKeys_Create1(void** out) HIPBFV_BEGIN
   if (!out) return HIPBFV_E_POINTER;
   *out = new KeysObj();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long KSwitchKeys_Create2(void* copy, void** out) {
+long KSwitchKeys_Create2(void* copy, void** out) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(copy, kMagicKeys);
   if (!k || !out) return HIPBFV_E_POINTER;
   KeysObj* n = new KeysObj();
@@ -885,14 +952,14 @@ long KSwitchKeys_Create2(void* copy, void** out) {
   }
   *out = n;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long KSwitchKeys_Destroy(void* h) {
+long KSwitchKeys_Destroy(void* h) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(h, kMagicKeys);
   if (!k) return HIPBFV_E_POINTER;
   delete k;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 static long assign_key(KeysObj* k, ContextObj* x, u32 index, const uint64_t* host_data) {
   if (x->ctx->KK() < 2) return fail(HIPBFV_E_INVALIDARG, "these parameters do not support key switching");
@@ -917,30 +984,30 @@ static long assign_key(KeysObj* k, ContextObj* x, u32 index, const uint64_t* hos
   return HIPBFV_S_OK;
 }
 
-long hipbfv_KSwitchKeys_AssignRelin(void* h, void* context, const uint64_t* host_data) {
+long hipbfv_KSwitchKeys_AssignRelin(void* h, void* context, const uint64_t* host_data) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(h, kMagicKeys);
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!k || !x || !host_data) return HIPBFV_E_POINTER;
   return assign_key(k, x, 0, host_data);
-}
+HIPBFV_END
 
-long hipbfv_KSwitchKeys_AssignGalois(void* h, void* context, uint32_t elt, const uint64_t* host_data) {
+long hipbfv_KSwitchKeys_AssignGalois(void* h, void* context, uint32_t elt, const uint64_t* host_data) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(h, kMagicKeys);
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!k || !x || !host_data) return HIPBFV_E_POINTER;
   if (!(elt & 1) || elt >= 2 * x->ctx->n()) return fail(HIPBFV_E_INVALIDARG, "invalid Galois element");
   return assign_key(k, x, (elt - 1) >> 1, host_data);
-}
+HIPBFV_END
 
-long hipbfv_KSwitchKeys_DevicePtr(void* h, uint64_t index, uint64_t** device_ptr) {
+long hipbfv_KSwitchKeys_DevicePtr(void* h, uint64_t index, uint64_t** device_ptr) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(h, kMagicKeys);
   if (!k || !device_ptr) return HIPBFV_E_POINTER;
   *device_ptr = (uint64_t*)k->find((u32)index);
   return *device_ptr ? HIPBFV_S_OK : fail(HIPBFV_E_INVALIDARG, "key not present");
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ Evaluator (handle level, synchronous)
-long Evaluator_Create(void* context, void** out) {
+long Evaluator_Create(void* context, void** out) HIPBFV_BEGIN
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!x || !out) return HIPBFV_E_POINTER;
   EvalObj* e = new EvalObj();
@@ -948,16 +1015,16 @@ long Evaluator_Create(void* context, void** out) {
   e->ev.reset(new Evaluator(x->ctx.get()));
   *out = e;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Evaluator_Destroy(void* h) {
+long Evaluator_Destroy(void* h) HIPBFV_BEGIN
   EvalObj* e = as<EvalObj>(h, kMagicEval);
   if (!e) return HIPBFV_E_POINTER;
   delete e;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Evaluator_Negate(void* h, void* a, void* dst) {
+long Evaluator_Negate(void* h, void* a, void* dst) HIPBFV_BEGIN
   EvalObj* e = as<EvalObj>(h, kMagicEval);
   CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
   if (!e || !x || !d) return HIPBFV_E_POINTER;
@@ -972,7 +1039,7 @@ long Evaluator_Negate(void* h, void* a, void* dst) {
     return from_status(st);
   }
   return finish_result(e, d, x->size, buf, x->words, s, false);
-}
+HIPBFV_END
 
 // add/sub with SEAL's size rule: the result has max(size) polynomials; extra ones are copied (negated for sub)
 static long add_sub(void* h, void* a, void* b, void* dst, bool sub) {
@@ -1001,10 +1068,10 @@ static long add_sub(void* h, void* a, void* b, void* dst, bool sub) {
   return finish_result(e, d, smax, buf, words, s, true);
 }
 
-long Evaluator_Add(void* h, void* a, void* b, void* dst) { return add_sub(h, a, b, dst, false); }
-long Evaluator_Sub(void* h, void* a, void* b, void* dst) { return add_sub(h, a, b, dst, true); }
+long Evaluator_Add(void* h, void* a, void* b, void* dst) HIPBFV_BEGIN return add_sub(h, a, b, dst, false); HIPBFV_END
+long Evaluator_Sub(void* h, void* a, void* b, void* dst) HIPBFV_BEGIN return add_sub(h, a, b, dst, true); HIPBFV_END
 
-long Evaluator_AddMany(void* h, uint64_t count, void** cts, void* dst) {
+long Evaluator_AddMany(void* h, uint64_t count, void** cts, void* dst) HIPBFV_BEGIN
   if (!cts) return HIPBFV_E_POINTER;
   if (count == 0) return fail(HIPBFV_E_INVALIDARG, "encrypteds cannot be empty");
   void* acc = nullptr;
@@ -1025,9 +1092,9 @@ long Evaluator_AddMany(void* h, uint64_t count, void** cts, void* dst) {
   }
   Ciphertext_Destroy(acc);
   return hr;
-}
+HIPBFV_END
 
-long Evaluator_Multiply(void* h, void* a, void* b, void* dst, void* pool) {
+long Evaluator_Multiply(void* h, void* a, void* b, void* dst, void* pool) HIPBFV_BEGIN
   (void)pool;
   EvalObj* e = as<EvalObj>(h, kMagicEval);
   CipherObj *x = as<CipherObj>(a, kMagicCipher), *y = as<CipherObj>(b, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
@@ -1045,11 +1112,11 @@ long Evaluator_Multiply(void* h, void* a, void* b, void* dst, void* pool) {
     return from_status(st);
   }
   return finish_result(e, d, sd, buf, words, s, true);
-}
+HIPBFV_END
 
-long Evaluator_Square(void* h, void* a, void* dst, void* pool) { return Evaluator_Multiply(h, a, a, dst, pool); }
+long Evaluator_Square(void* h, void* a, void* dst, void* pool) HIPBFV_BEGIN return Evaluator_Multiply(h, a, a, dst, pool); HIPBFV_END
 
-long Evaluator_Relinearize(void* h, void* a, void* keys, void* dst, void* pool) {
+long Evaluator_Relinearize(void* h, void* a, void* keys, void* dst, void* pool) HIPBFV_BEGIN
   (void)pool;
   EvalObj* e = as<EvalObj>(h, kMagicEval);
   CipherObj *x = as<CipherObj>(a, kMagicCipher), *d = as<CipherObj>(dst, kMagicCipher);
@@ -1082,10 +1149,10 @@ long Evaluator_Relinearize(void* h, void* a, void* keys, void* dst, void* pool) 
     return from_status(st);
   }
   return finish_result(e, d, 2, buf, words, s, true);
-}
+HIPBFV_END
 
 // SEAL Evaluator::multiply_many: pairwise products with relinearisation, results appended to the work list
-long Evaluator_MultiplyMany(void* h, uint64_t count, void** cts, void* keys, void* dst, void* pool) {
+long Evaluator_MultiplyMany(void* h, uint64_t count, void** cts, void* keys, void* dst, void* pool) HIPBFV_BEGIN
   if (!cts) return HIPBFV_E_POINTER;
   if (count == 0) return fail(HIPBFV_E_INVALIDARG, "encrypteds vector must not be empty");
   CipherObj* d = as<CipherObj>(dst, kMagicCipher);
@@ -1133,14 +1200,14 @@ long Evaluator_MultiplyMany(void* h, uint64_t count, void** cts, void* keys, voi
   }
   cleanup();
   return hr;
-}
+HIPBFV_END
 
-long Evaluator_Exponentiate(void* h, void* a, uint64_t exponent, void* keys, void* dst, void* pool) {
+long Evaluator_Exponentiate(void* h, void* a, uint64_t exponent, void* keys, void* dst, void* pool) HIPBFV_BEGIN
   if (exponent == 0) return fail(HIPBFV_E_INVALIDARG, "exponent cannot be 0");
   if (exponent > 4096) return fail(HIPBFV_E_INVALIDARG, "exponent too large");
   std::vector<void*> v((size_t)exponent, a);
   return Evaluator_MultiplyMany(h, exponent, v.data(), keys, dst, pool);
-}
+HIPBFV_END
 
 static long plain_to_device(EvalObj* e, PlainObj* p, u64** out, size_t* nonzero, size_t* last_nonzero) {
   const size_t n = e->ctx->n();
@@ -1203,12 +1270,12 @@ static long plain_op(void* h, void* a, void* plain, void* dst, int which) {
   return hr;
 }
 
-long Evaluator_AddPlain(void* h, void* a, void* plain, void* dst) { return plain_op(h, a, plain, dst, 0); }
-long Evaluator_SubPlain(void* h, void* a, void* plain, void* dst) { return plain_op(h, a, plain, dst, 1); }
-long Evaluator_MultiplyPlain(void* h, void* a, void* plain, void* dst, void* pool) {
+long Evaluator_AddPlain(void* h, void* a, void* plain, void* dst) HIPBFV_BEGIN return plain_op(h, a, plain, dst, 0); HIPBFV_END
+long Evaluator_SubPlain(void* h, void* a, void* plain, void* dst) HIPBFV_BEGIN return plain_op(h, a, plain, dst, 1); HIPBFV_END
+long Evaluator_MultiplyPlain(void* h, void* a, void* plain, void* dst, void* pool) HIPBFV_BEGIN
   (void)pool;
   return plain_op(h, a, plain, dst, 2);
-}
+HIPBFV_END
 
 // one Galois automorphism + key switch on a handle (SEAL apply_galois_inplace)
 static long galois_handle(EvalObj* e, CipherObj* x, u32 elt, KeysObj* k, CipherObj* d) {
@@ -1274,15 +1341,15 @@ static long rotate_common(void* h, void* a, bool columns, int steps, void* keys,
   return rotate_internal(e, d, steps, k, d);
 }
 
-long Evaluator_RotateRows(void* h, void* a, int steps, void* keys, void* dst, void* pool) {
+long Evaluator_RotateRows(void* h, void* a, int steps, void* keys, void* dst, void* pool) HIPBFV_BEGIN
   (void)pool;
   return rotate_common(h, a, false, steps, keys, dst);
-}
+HIPBFV_END
 
-long Evaluator_RotateColumns(void* h, void* a, void* keys, void* dst, void* pool) {
+long Evaluator_RotateColumns(void* h, void* a, void* keys, void* dst, void* pool) HIPBFV_BEGIN
   (void)pool;
   return rotate_common(h, a, true, 0, keys, dst);
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ batched device-pointer API
 #define EVAL_OR_RETURN(h)                      \
@@ -1295,36 +1362,36 @@ static const u64* key_or_null(void* keys, EvalObj* e, u32 index) {
   return k->find(index);
 }
 
-long hipbfv_batch_multiply(void* h, const uint64_t* a, uint64_t sa, const uint64_t* b, uint64_t sb, uint64_t* out, uint64_t count, void* stream) {
+long hipbfv_batch_multiply(void* h, const uint64_t* a, uint64_t sa, const uint64_t* b, uint64_t sb, uint64_t* out, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!a || !b || !out) return HIPBFV_E_POINTER;
   return from_status(e->ev->multiply((const u64*)a, (u32)sa, (const u64*)b, (u32)sb, (u64*)out, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
-long hipbfv_batch_relinearize(void* h, const uint64_t* ct3, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+long hipbfv_batch_relinearize(void* h, const uint64_t* ct3, void* keys, uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!ct3 || !out2) return HIPBFV_E_POINTER;
   const u64* rk = key_or_null(keys, e, 0);
   if (!rk) return from_status(kNoKey);
   return from_status(e->ev->relinearize((const u64*)ct3, rk, (u64*)out2, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
-long hipbfv_batch_multiply_relin(void* h, const uint64_t* a, const uint64_t* b, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+long hipbfv_batch_multiply_relin(void* h, const uint64_t* a, const uint64_t* b, void* keys, uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!a || !b || !out2) return HIPBFV_E_POINTER;
   const u64* rk = key_or_null(keys, e, 0);
   if (!rk) return from_status(kNoKey);
   return from_status(e->ev->multiply_relin((const u64*)a, (const u64*)b, rk, (u64*)out2, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
-long hipbfv_batch_apply_galois(void* h, const uint64_t* ct2, uint32_t elt, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+long hipbfv_batch_apply_galois(void* h, const uint64_t* ct2, uint32_t elt, void* keys, uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!ct2 || !out2) return HIPBFV_E_POINTER;
   if (!(elt & 1) || elt >= 2 * e->ctx->n()) return from_status(kInvalidArg);
   const u64* key = key_or_null(keys, e, (elt - 1) >> 1);
   if (!key) return from_status(kNoKey);
   return from_status(e->ev->apply_galois((const u64*)ct2, elt, key, (u64*)out2, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
 // all items rotate by the same step (each Galois key is streamed once per batch); NAF chain like SEAL
 static long batch_rotate_internal(EvalObj* e, const u64* in, int steps, void* keys, u64* out, uint64_t count, hipStream_t s) {
@@ -1352,7 +1419,7 @@ static long batch_rotate_internal(EvalObj* e, const u64* in, int steps, void* ke
   return HIPBFV_S_OK;
 }
 
-long hipbfv_batch_rotate_rows(void* h, const uint64_t* ct2, int steps, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+long hipbfv_batch_rotate_rows(void* h, const uint64_t* ct2, int steps, void* keys, uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!ct2 || !out2) return HIPBFV_E_POINTER;
   if (!e->ctx->batching()) return fail(HIPBFV_COR_E_INVALIDOPERATION, "encryption parameters do not support batching");
@@ -1364,57 +1431,68 @@ long hipbfv_batch_rotate_rows(void* h, const uint64_t* ct2, int steps, void* key
     return HIPBFV_S_OK;
   }
   return batch_rotate_internal(e, (const u64*)ct2, steps, keys, (u64*)out2, count, s);
-}
+HIPBFV_END
 
-long hipbfv_batch_rotate_columns(void* h, const uint64_t* ct2, void* keys, uint64_t* out2, uint64_t count, void* stream) {
+long hipbfv_batch_rotate_columns(void* h, const uint64_t* ct2, void* keys, uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!e->ctx->batching()) return fail(HIPBFV_COR_E_INVALIDOPERATION, "encryption parameters do not support batching");
   return hipbfv_batch_apply_galois(h, ct2, 2 * e->ctx->n() - 1, keys, out2, count, stream);
-}
+HIPBFV_END
 
-long hipbfv_batch_add(void* h, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t size, uint64_t count, void* stream) {
+long hipbfv_batch_add(void* h, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t size, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!a || !b || !out) return HIPBFV_E_POINTER;
   return from_status(e->ev->add((const u64*)a, (const u64*)b, (u64*)out, (u32)size, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
-long hipbfv_batch_sub(void* h, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t size, uint64_t count, void* stream) {
+long hipbfv_batch_sub(void* h, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t size, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!a || !b || !out) return HIPBFV_E_POINTER;
   return from_status(e->ev->sub((const u64*)a, (const u64*)b, (u64*)out, (u32)size, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
-long hipbfv_batch_negate(void* h, const uint64_t* a, uint64_t* out, uint64_t size, uint64_t count, void* stream) {
+long hipbfv_batch_negate(void* h, const uint64_t* a, uint64_t* out, uint64_t size, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!a || !out) return HIPBFV_E_POINTER;
   return from_status(e->ev->negate((const u64*)a, (u64*)out, (u32)size, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
-long hipbfv_batch_add_plain(void* h, const uint64_t* ct, uint64_t size, const uint64_t* plain, uint64_t pstride, uint64_t* out, uint64_t count, void* stream) {
+long hipbfv_batch_add_plain(void* h, const uint64_t* ct, uint64_t size, const uint64_t* plain, uint64_t pstride, uint64_t* out, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!ct || !plain || !out) return HIPBFV_E_POINTER;
   return from_status(e->ev->add_plain((const u64*)ct, (u32)size, (const u64*)plain, pstride, (u64*)out, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
-long hipbfv_batch_sub_plain(void* h, const uint64_t* ct, uint64_t size, const uint64_t* plain, uint64_t pstride, uint64_t* out, uint64_t count, void* stream) {
+long hipbfv_batch_sub_plain(void* h, const uint64_t* ct, uint64_t size, const uint64_t* plain, uint64_t pstride, uint64_t* out, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!ct || !plain || !out) return HIPBFV_E_POINTER;
   return from_status(e->ev->sub_plain((const u64*)ct, (u32)size, (const u64*)plain, pstride, (u64*)out, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
-long hipbfv_batch_multiply_plain(void* h, const uint64_t* ct, uint64_t size, const uint64_t* plain, uint64_t pstride, uint64_t* out, uint64_t count, void* stream) {
+long hipbfv_batch_multiply_plain(void* h, const uint64_t* ct, uint64_t size, const uint64_t* plain, uint64_t pstride, uint64_t* out, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!ct || !plain || !out) return HIPBFV_E_POINTER;
   return from_status(e->ev->multiply_plain((const u64*)ct, (u32)size, (const u64*)plain, pstride, (u64*)out, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
-long hipbfv_batch_ntt(void* h, uint64_t* data, uint64_t polys, uint64_t nprimes, bool inverse, void* stream) {
+long hipbfv_batch_ntt(void* h, uint64_t* data, uint64_t polys, uint64_t nprimes, bool inverse, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!data) return HIPBFV_E_POINTER;
   return from_status(e->ev->ntt((u64*)data, polys, (u32)nprimes, inverse, (hipStream_t)stream));
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ SEAL 4.0 wire format (wire.cpp)
+// Ceilings on a decompressed object body for a given context (the bytes are untrusted: a small zstd frame may declare any
+// content size).  SEAL_CIPHERTEXT_SIZE_MAX = 16 polynomials; a key-switching key set holds at most one key per odd Galois
+// element actually stored -- 8 * log2(N) keys is four times SEAL's default set.
+static size_t max_ct_body(const Context& c) { return 4096 + (size_t)16 * c.n() * c.KK() * 8; }
+static size_t max_plain_body(const Context& c) { return 4096 + (size_t)c.n() * c.KK() * 8; }
+static size_t max_keys_body(const Context& c) {
+  size_t lg = 0;
+  while (((size_t)1 << lg) < c.n()) lg++;
+  return 4096 + 8 * (size_t)c.n() + 8 * lg * c.K() * (512 + (size_t)2 * c.KK() * c.n() * 8);
+}
+
 static long from_wire(int rc) {
   switch (rc) {
     case kWireOk: return HIPBFV_S_OK;
@@ -1427,18 +1505,18 @@ static long from_wire(int rc) {
 static void data_level_parms_id(const Context& c, uint8_t out[32]) { seal_parms_id(c.n(), c.key_primes().data(), c.K(), c.t(), out); }
 static void key_level_parms_id(const Context& c, uint8_t out[32]) { seal_parms_id(c.n(), c.key_primes().data(), c.KK(), c.t(), out); }
 
-long hipbfv_wire_parms_id(uint64_t n, const uint64_t* primes, uint64_t count, uint64_t plain_modulus, uint8_t* out32) {
+long hipbfv_wire_parms_id(uint64_t n, const uint64_t* primes, uint64_t count, uint64_t plain_modulus, uint8_t* out32) HIPBFV_BEGIN
   if (!primes || !out32) return HIPBFV_E_POINTER;
   seal_parms_id(n, reinterpret_cast<const unsigned long long*>(primes), count, plain_modulus, out32);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 long hipbfv_wire_decode_ciphertext(const uint8_t* in, uint64_t in_size, uint8_t* parms_id32, bool* is_ntt, uint64_t* size, uint64_t* n,
-                                   uint64_t* k, uint64_t* data, uint64_t capacity_words, int64_t* in_bytes) {
+                                   uint64_t* k, uint64_t* data, uint64_t capacity_words, int64_t* in_bytes) HIPBFV_BEGIN
   if (!in) return HIPBFV_E_POINTER;
   WireCiphertext ct;
   size_t used = 0;
-  if (int rc = wire_unpack_ciphertext(in, in_size, &ct, &used)) return from_wire(rc);
+  if (int rc = wire_unpack_ciphertext(in, in_size, &ct, &used, data ? 4096 + (size_t)capacity_words * 8 : 0)) return from_wire(rc);
   if (parms_id32) std::memcpy(parms_id32, ct.parms_id, 32);
   if (is_ntt) *is_ntt = ct.is_ntt;
   if (size) *size = ct.size;
@@ -1450,10 +1528,10 @@ long hipbfv_wire_decode_ciphertext(const uint8_t* in, uint64_t in_size, uint8_t*
     std::memcpy(data, ct.data.data(), ct.data.size() * 8);
   }
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 long hipbfv_wire_encode_ciphertext(const uint8_t* parms_id32, bool is_ntt, uint64_t size, uint64_t n, uint64_t k, const uint64_t* data,
-                                   uint8_t compr_mode, uint8_t* out, uint64_t capacity, int64_t* out_bytes) {
+                                   uint8_t compr_mode, uint8_t* out, uint64_t capacity, int64_t* out_bytes) HIPBFV_BEGIN
   if (!parms_id32 || !data || !out_bytes) return HIPBFV_E_POINTER;
   std::vector<uint8_t> buf;
   if (int rc = wire_pack_ciphertext(parms_id32, is_ntt, size, n, k, reinterpret_cast<const unsigned long long*>(data), compr_mode, &buf)) return from_wire(rc);
@@ -1462,14 +1540,14 @@ long hipbfv_wire_encode_ciphertext(const uint8_t* parms_id32, bool is_ntt, uint6
   if (capacity < buf.size()) return fail(HIPBFV_E_INVALIDARG, "buffer too small");
   std::memcpy(out, buf.data(), buf.size());
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 long hipbfv_wire_decode_plaintext(const uint8_t* in, uint64_t in_size, uint8_t* parms_id32, uint64_t* coeff_count, uint64_t* coeffs,
-                                  uint64_t capacity_words, int64_t* in_bytes) {
+                                  uint64_t capacity_words, int64_t* in_bytes) HIPBFV_BEGIN
   if (!in) return HIPBFV_E_POINTER;
   WirePlaintext pt;
   size_t used = 0;
-  if (int rc = wire_unpack_plaintext(in, in_size, &pt, &used)) return from_wire(rc);
+  if (int rc = wire_unpack_plaintext(in, in_size, &pt, &used, coeffs ? 4096 + (size_t)capacity_words * 8 : 0)) return from_wire(rc);
   if (parms_id32) std::memcpy(parms_id32, pt.parms_id, 32);
   if (coeff_count) *coeff_count = pt.coeffs.size();
   if (in_bytes) *in_bytes = (int64_t)used;
@@ -1478,18 +1556,18 @@ long hipbfv_wire_decode_plaintext(const uint8_t* in, uint64_t in_size, uint8_t* 
     std::memcpy(coeffs, pt.coeffs.data(), pt.coeffs.size() * 8);
   }
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // upper bound of the serialised size, like SEAL's save_size()
-long Ciphertext_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+long Ciphertext_SaveSize(void* h, uint8_t compr_mode, int64_t* result) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !result) return HIPBFV_E_POINTER;
   const size_t raw = 16 + 32 + 1 + 8 * 5 + 16 + 8 + c->words * 8;
   *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Ciphertext_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+long Ciphertext_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   if (!c || !outptr || !out_bytes) return HIPBFV_E_POINTER;
   if (!c->ctx || !c->dev) return fail(HIPBFV_E_INVALIDARG, "ciphertext is empty");
@@ -1503,15 +1581,15 @@ long Ciphertext_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode
   std::memcpy(outptr, buf.data(), buf.size());
   *out_bytes = (int64_t)buf.size();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Ciphertext_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+long Ciphertext_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) HIPBFV_BEGIN
   CipherObj* c = as<CipherObj>(h, kMagicCipher);
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!c || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
   WireCiphertext ct;
   size_t used = 0;
-  if (int rc = wire_unpack_ciphertext(inptr, size, &ct, &used)) return from_wire(rc);
+  if (int rc = wire_unpack_ciphertext(inptr, size, &ct, &used, max_ct_body(*x->ctx))) return from_wire(rc);
   // the parms_id names the level of the modulus-switching chain the ciphertext lives at
   std::shared_ptr<Context> lvl = x->ctx;
   for (;;) {
@@ -1529,17 +1607,17 @@ long Ciphertext_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int6
   if (hr != HIPBFV_S_OK) return hr;
   *in_bytes = (int64_t)used;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+long Plaintext_SaveSize(void* h, uint8_t compr_mode, int64_t* result) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(h, kMagicPlain);
   if (!p || !result) return HIPBFV_E_POINTER;
   const size_t raw = 16 + 32 + 16 + 16 + 8 + p->coeffs.size() * 8;
   *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+long Plaintext_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(h, kMagicPlain);
   if (!p || !outptr || !out_bytes) return HIPBFV_E_POINTER;
   const uint8_t zero[32] = {0};  // BFV plaintexts in coefficient form carry parms_id_zero
@@ -1549,15 +1627,15 @@ long Plaintext_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode,
   std::memcpy(outptr, buf.data(), buf.size());
   *out_bytes = (int64_t)buf.size();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long Plaintext_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+long Plaintext_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) HIPBFV_BEGIN
   PlainObj* p = as<PlainObj>(h, kMagicPlain);
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!p || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
   WirePlaintext pt;
   size_t used = 0;
-  if (int rc = wire_unpack_plaintext(inptr, size, &pt, &used)) return from_wire(rc);
+  if (int rc = wire_unpack_plaintext(inptr, size, &pt, &used, max_plain_body(*x->ctx))) return from_wire(rc);
   const uint8_t zero[32] = {0};
   if (std::memcmp(pt.parms_id, zero, 32) != 0) return fail(HIPBFV_E_INVALIDARG, "NTT-form plaintexts are not used by BFV evaluation");
   if (pt.coeffs.size() > x->ctx->n()) return fail(HIPBFV_E_INVALIDARG, "plaintext data is invalid for the encryption parameters");
@@ -1566,7 +1644,7 @@ long Plaintext_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64
   p->coeffs = pt.coeffs;
   *in_bytes = (int64_t)used;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 static long keys_to_host(KeysObj* k, std::vector<std::vector<u64>>* host, std::vector<std::vector<const u64*>>* ptrs) {
   const size_t KK = k->ctx->KK(), K = k->ctx->K(), n = k->ctx->n();
@@ -1582,7 +1660,7 @@ static long keys_to_host(KeysObj* k, std::vector<std::vector<u64>>* host, std::v
   return HIPBFV_S_OK;
 }
 
-long KSwitchKeys_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+long KSwitchKeys_SaveSize(void* h, uint8_t compr_mode, int64_t* result) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(h, kMagicKeys);
   if (!k || !result) return HIPBFV_E_POINTER;
   size_t raw = 16 + 32 + 8;
@@ -1594,9 +1672,9 @@ long KSwitchKeys_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
   }
   *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long KSwitchKeys_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+long KSwitchKeys_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(h, kMagicKeys);
   if (!k || !outptr || !out_bytes) return HIPBFV_E_POINTER;
   if (!k->ctx) return fail(HIPBFV_E_INVALIDARG, "keys are empty");
@@ -1613,15 +1691,15 @@ long KSwitchKeys_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mod
   std::memcpy(outptr, buf.data(), buf.size());
   *out_bytes = (int64_t)buf.size();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long KSwitchKeys_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+long KSwitchKeys_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(h, kMagicKeys);
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!k || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
   WireKSwitchKeys ks;
   size_t used = 0;
-  if (int rc = wire_unpack_kswitch(inptr, size, &ks, &used)) return from_wire(rc);
+  if (int rc = wire_unpack_kswitch(inptr, size, &ks, &used, max_keys_body(*x->ctx), x->ctx->n())) return from_wire(rc);
   uint8_t pid[32];
   key_level_parms_id(*x->ctx, pid);
   if (std::memcmp(pid, ks.parms_id, 32) != 0) return fail(HIPBFV_E_INVALIDARG, "keys are invalid for the encryption parameters");
@@ -1641,32 +1719,32 @@ long KSwitchKeys_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int
   }
   *in_bytes = (int64_t)used;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ program graphs (batch executor)
-long hipbfv_Program_Create(void** out) {
+long hipbfv_Program_Create(void** out) HIPBFV_BEGIN
   if (!out) return HIPBFV_E_POINTER;
   *out = new ProgramObj();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Program_Destroy(void* h) {
+long hipbfv_Program_Destroy(void* h) HIPBFV_BEGIN
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   if (!p) return HIPBFV_E_POINTER;
   delete p;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Program_AddNode(void* h, uint32_t op, uint64_t arg, uint32_t* node_id) {
+long hipbfv_Program_AddNode(void* h, uint32_t op, uint64_t arg, uint32_t* node_id) HIPBFV_BEGIN
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   if (!p || !node_id) return HIPBFV_E_POINTER;
   if (op >= (uint32_t)kOpCount || op == (uint32_t)kOpLiteralPlaintext)
     return fail(HIPBFV_E_INVALIDARG, "unknown operation kind (plaintext literals: hipbfv_Program_AddPlaintextLiteral)");
   *node_id = (uint32_t)p->prog.add_node((OpKind)op, arg);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Program_AddPlaintextLiteral(void* h, const uint8_t* bytes, uint64_t length, uint32_t* node_id) {
+long hipbfv_Program_AddPlaintextLiteral(void* h, const uint8_t* bytes, uint64_t length, uint32_t* node_id) HIPBFV_BEGIN
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   if (!p || !bytes || !node_id) return HIPBFV_E_POINTER;
   std::string err;
@@ -1674,34 +1752,34 @@ long hipbfv_Program_AddPlaintextLiteral(void* h, const uint8_t* bytes, uint64_t 
   if (id < 0) return fail(HIPBFV_E_INVALIDARG, err.c_str());
   *node_id = (uint32_t)id;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Program_AddEdge(void* h, uint32_t src, uint32_t dst, uint32_t kind) {
+long hipbfv_Program_AddEdge(void* h, uint32_t src, uint32_t dst, uint32_t kind) HIPBFV_BEGIN
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   if (!p) return HIPBFV_E_POINTER;
   if (kind > 2 || p->prog.add_edge((int)src, (int)dst, (EdgeKind)kind) != kOk) return fail(HIPBFV_E_INVALIDARG, "invalid edge");
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Program_LoadJson(void* h, const char* json, uint64_t length) {
+long hipbfv_Program_LoadJson(void* h, const char* json, uint64_t length) HIPBFV_BEGIN
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   if (!p || !json) return HIPBFV_E_POINTER;
   std::string err;
   if (p->prog.load_json(json, length, &err) != kOk) return fail(HIPBFV_E_INVALIDARG, err.c_str());
   if (p->prog.validate(&err) != kOk) return fail(HIPBFV_E_INVALIDARG, err.c_str());
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_Program_NumOutputs(void* h, uint64_t* count) {
+long hipbfv_Program_NumOutputs(void* h, uint64_t* count) HIPBFV_BEGIN
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   if (!p || !count) return HIPBFV_E_POINTER;
   *count = p->prog.num_outputs();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t* input_kinds,
                         const uint64_t* const* input_ptrs, const uint64_t* input_strides, void* relin_keys, void* galois_keys,
-                        uint64_t num_outputs, uint64_t* const* outputs, void* stream) {
+                        uint64_t num_outputs, uint64_t* const* outputs, void* stream) HIPBFV_BEGIN
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
   if (!p || !e || (num_inputs && (!input_kinds || !input_ptrs || !input_strides)) || (num_outputs && !outputs)) return HIPBFV_E_POINTER;
@@ -1722,29 +1800,29 @@ long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_i
     return hr;
   }
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_profile_enable(void* h, bool enabled) {
+long hipbfv_profile_enable(void* h, bool enabled) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   e->ev->profiler().collect();
   e->ev->profiler().enabled = enabled;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_profile_reset(void* h) {
+long hipbfv_profile_reset(void* h) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   e->ev->profiler().reset();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_profile_kernel_count(uint32_t* count) {
+long hipbfv_profile_kernel_count(uint32_t* count) HIPBFV_BEGIN
   if (!count) return HIPBFV_E_POINTER;
   *count = kKernCount;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 long hipbfv_profile_read(void* h, uint32_t kernel_id, char* name, uint64_t name_capacity, double* total_ms, uint64_t* launches,
-                         uint64_t* units) {
+                         uint64_t* units) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (kernel_id >= (uint32_t)kKernCount) return fail(HIPBFV_E_INVALIDARG, "kernel id out of range");
   Profiler& p = e->ev->profiler();
@@ -1757,13 +1835,13 @@ long hipbfv_profile_read(void* h, uint32_t kernel_id, char* name, uint64_t name_
   if (launches) *launches = p.launches[kernel_id];
   if (units) *units = p.units[kernel_id];
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_set_chunk_ops(void* h, uint64_t chunk) {
+long hipbfv_set_chunk_ops(void* h, uint64_t chunk) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   e->ev->set_chunk_ops(chunk);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ SecretKey / PublicKey (seal_fhe/src/key_generator.rs:200-430)
 static long asym_create(uint32_t magic, void** out) {
@@ -1814,14 +1892,14 @@ static long asym_to_host(AsymKeyObj* k, std::vector<u64>* host) {
   return HIPBFV_S_OK;
 }
 
-long SecretKey_Create1(void** out) { return asym_create(kMagicSecretKey, out); }
-long SecretKey_Create2(void* copy, void** out) { return asym_copy(kMagicSecretKey, copy, out); }
-long SecretKey_Destroy(void* h) { return asym_destroy(kMagicSecretKey, h); }
-long PublicKey_Create1(void** out) { return asym_create(kMagicPublicKey, out); }
-long PublicKey_Create2(void* copy, void** out) { return asym_copy(kMagicPublicKey, copy, out); }
-long PublicKey_Destroy(void* h) { return asym_destroy(kMagicPublicKey, h); }
-long hipbfv_SecretKey_Assign(void* h, void* context, const uint64_t* host_data) { return asym_assign(kMagicSecretKey, h, context, host_data, 1); }
-long hipbfv_PublicKey_Assign(void* h, void* context, const uint64_t* host_data) { return asym_assign(kMagicPublicKey, h, context, host_data, 2); }
+long SecretKey_Create1(void** out) HIPBFV_BEGIN return asym_create(kMagicSecretKey, out); HIPBFV_END
+long SecretKey_Create2(void* copy, void** out) HIPBFV_BEGIN return asym_copy(kMagicSecretKey, copy, out); HIPBFV_END
+long SecretKey_Destroy(void* h) HIPBFV_BEGIN return asym_destroy(kMagicSecretKey, h); HIPBFV_END
+long PublicKey_Create1(void** out) HIPBFV_BEGIN return asym_create(kMagicPublicKey, out); HIPBFV_END
+long PublicKey_Create2(void* copy, void** out) HIPBFV_BEGIN return asym_copy(kMagicPublicKey, copy, out); HIPBFV_END
+long PublicKey_Destroy(void* h) HIPBFV_BEGIN return asym_destroy(kMagicPublicKey, h); HIPBFV_END
+long hipbfv_SecretKey_Assign(void* h, void* context, const uint64_t* host_data) HIPBFV_BEGIN return asym_assign(kMagicSecretKey, h, context, host_data, 1); HIPBFV_END
+long hipbfv_PublicKey_Assign(void* h, void* context, const uint64_t* host_data) HIPBFV_BEGIN return asym_assign(kMagicPublicKey, h, context, host_data, 2); HIPBFV_END
 
 static long asym_read(Magic m, void* h, uint64_t* host_out) {
   AsymKeyObj* k = as<AsymKeyObj>(h, m);
@@ -1830,32 +1908,32 @@ static long asym_read(Magic m, void* h, uint64_t* host_out) {
   if (hipMemcpy(host_out, k->key->dev, k->key->words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return from_status(kHipError);
   return HIPBFV_S_OK;
 }
-long hipbfv_SecretKey_Read(void* h, uint64_t* host_out) { return asym_read(kMagicSecretKey, h, host_out); }
-long hipbfv_PublicKey_Read(void* h, uint64_t* host_out) { return asym_read(kMagicPublicKey, h, host_out); }
-long hipbfv_KSwitchKeys_Read(void* h, uint64_t index, uint64_t* host_out) {
+long hipbfv_SecretKey_Read(void* h, uint64_t* host_out) HIPBFV_BEGIN return asym_read(kMagicSecretKey, h, host_out); HIPBFV_END
+long hipbfv_PublicKey_Read(void* h, uint64_t* host_out) HIPBFV_BEGIN return asym_read(kMagicPublicKey, h, host_out); HIPBFV_END
+long hipbfv_KSwitchKeys_Read(void* h, uint64_t index, uint64_t* host_out) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(h, kMagicKeys);
   if (!k || !host_out) return HIPBFV_E_POINTER;
   const u64* dev = k->find((u32)index);
   if (!dev) return fail(HIPBFV_E_INVALIDARG, "key not present");
   if (hipMemcpy(host_out, dev, k->ctx->key_words() * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return from_status(kHipError);
   return HIPBFV_S_OK;
-}
-long hipbfv_KSwitchKeys_Has(void* h, uint64_t index, bool* present) {
+HIPBFV_END
+long hipbfv_KSwitchKeys_Has(void* h, uint64_t index, bool* present) HIPBFV_BEGIN
   KeysObj* k = as<KeysObj>(h, kMagicKeys);
   if (!k || !present) return HIPBFV_E_POINTER;
   *present = k->find((u32)index) != nullptr;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // SecretKey is serialised as a Plaintext whose parms_id is the key level's (seal_fhe/tests/data/secret_key.bin)
-long SecretKey_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+long SecretKey_SaveSize(void* h, uint8_t compr_mode, int64_t* result) HIPBFV_BEGIN
   AsymKeyObj* k = as<AsymKeyObj>(h, kMagicSecretKey);
   if (!k || !result) return HIPBFV_E_POINTER;
   const size_t raw = 16 + 32 + 16 + 16 + 8 + (k->key ? k->key->words : 0) * 8;
   *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
   return HIPBFV_S_OK;
-}
-long SecretKey_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+HIPBFV_END
+long SecretKey_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) HIPBFV_BEGIN
   AsymKeyObj* k = as<AsymKeyObj>(h, kMagicSecretKey);
   if (!k || !outptr || !out_bytes) return HIPBFV_E_POINTER;
   std::vector<u64> host;
@@ -1868,13 +1946,13 @@ long SecretKey_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode,
   std::memcpy(outptr, buf.data(), buf.size());
   *out_bytes = (int64_t)buf.size();
   return HIPBFV_S_OK;
-}
-long SecretKey_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+HIPBFV_END
+long SecretKey_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) HIPBFV_BEGIN
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!as<AsymKeyObj>(h, kMagicSecretKey) || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
   WirePlaintext pt;
   size_t used = 0;
-  if (int rc = wire_unpack_plaintext(inptr, size, &pt, &used)) return from_wire(rc);
+  if (int rc = wire_unpack_plaintext(inptr, size, &pt, &used, max_plain_body(*x->ctx))) return from_wire(rc);
   uint8_t pid[32];
   key_level_parms_id(*x->ctx, pid);
   if (std::memcmp(pid, pt.parms_id, 32) != 0 || pt.coeffs.size() != (size_t)x->ctx->KK() * x->ctx->n())
@@ -1882,17 +1960,17 @@ long SecretKey_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64
   long hr = asym_assign(kMagicSecretKey, h, context, reinterpret_cast<const uint64_t*>(pt.coeffs.data()), 1);
   if (hr == HIPBFV_S_OK) *in_bytes = (int64_t)used;
   return hr;
-}
+HIPBFV_END
 
 // PublicKey is serialised as a size-2 NTT-form Ciphertext at the key level (seal_fhe/tests/data/public_key.bin)
-long PublicKey_SaveSize(void* h, uint8_t compr_mode, int64_t* result) {
+long PublicKey_SaveSize(void* h, uint8_t compr_mode, int64_t* result) HIPBFV_BEGIN
   AsymKeyObj* k = as<AsymKeyObj>(h, kMagicPublicKey);
   if (!k || !result) return HIPBFV_E_POINTER;
   const size_t raw = 16 + 32 + 1 + 8 * 5 + 16 + 8 + (k->key ? k->key->words : 0) * 8;
   *result = (int64_t)(compr_mode ? raw + raw / 128 + 512 : raw);
   return HIPBFV_S_OK;
-}
-long PublicKey_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) {
+HIPBFV_END
+long PublicKey_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode, int64_t* out_bytes) HIPBFV_BEGIN
   AsymKeyObj* k = as<AsymKeyObj>(h, kMagicPublicKey);
   if (!k || !outptr || !out_bytes) return HIPBFV_E_POINTER;
   std::vector<u64> host;
@@ -1907,13 +1985,13 @@ long PublicKey_Save(void* h, uint8_t* outptr, uint64_t size, uint8_t compr_mode,
   std::memcpy(outptr, buf.data(), buf.size());
   *out_bytes = (int64_t)buf.size();
   return HIPBFV_S_OK;
-}
-long PublicKey_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) {
+HIPBFV_END
+long PublicKey_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64_t* in_bytes) HIPBFV_BEGIN
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!as<AsymKeyObj>(h, kMagicPublicKey) || !x || !inptr || !in_bytes) return HIPBFV_E_POINTER;
   WireCiphertext ct;
   size_t used = 0;
-  if (int rc = wire_unpack_ciphertext(inptr, size, &ct, &used)) return from_wire(rc);
+  if (int rc = wire_unpack_ciphertext(inptr, size, &ct, &used, max_ct_body(*x->ctx))) return from_wire(rc);
   uint8_t pid[32];
   key_level_parms_id(*x->ctx, pid);
   if (std::memcmp(pid, ct.parms_id, 32) != 0 || !ct.is_ntt || ct.size != 2 || ct.n != x->ctx->n() || ct.k != x->ctx->KK())
@@ -1921,10 +1999,10 @@ long PublicKey_Load(void* h, void* context, uint8_t* inptr, uint64_t size, int64
   long hr = asym_assign(kMagicPublicKey, h, context, reinterpret_cast<const uint64_t*>(ct.data.data()), 2);
   if (hr == HIPBFV_S_OK) *in_bytes = (int64_t)used;
   return hr;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ BatchEncoder (seal_fhe/src/encoder.rs:50-215)
-long BatchEncoder_Create(void* context, void** out) {
+long BatchEncoder_Create(void* context, void** out) HIPBFV_BEGIN
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!x || !out) return HIPBFV_E_POINTER;
   if (!x->ctx->batching()) return fail(HIPBFV_E_INVALIDARG, "encryption parameters are not valid for batching");
@@ -1933,19 +2011,19 @@ long BatchEncoder_Create(void* context, void** out) {
   e->ev.reset(new Evaluator(x->ctx.get()));
   *out = e;
   return HIPBFV_S_OK;
-}
-long BatchEncoder_Destroy(void* h) {
+HIPBFV_END
+long BatchEncoder_Destroy(void* h) HIPBFV_BEGIN
   EncoderObj* e = as<EncoderObj>(h, kMagicEncoder);
   if (!e) return HIPBFV_E_POINTER;
   delete e;
   return HIPBFV_S_OK;
-}
-long BatchEncoder_GetSlotCount(void* h, uint64_t* count) {
+HIPBFV_END
+long BatchEncoder_GetSlotCount(void* h, uint64_t* count) HIPBFV_BEGIN
   EncoderObj* e = as<EncoderObj>(h, kMagicEncoder);
   if (!e || !count) return HIPBFV_E_POINTER;
   *count = e->ctx->n();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 static long encode_common(void* h, uint64_t count, const uint64_t* values, void* plain, bool is_signed) {
   EncoderObj* e = as<EncoderObj>(h, kMagicEncoder);
   PlainObj* p = as<PlainObj>(plain, kMagicPlain);
@@ -1972,10 +2050,10 @@ static long encode_common(void* h, uint64_t count, const uint64_t* values, void*
   g_buffers.put(dev, 2 * n);
   return hr;
 }
-long BatchEncoder_Encode1(void* h, uint64_t count, uint64_t* values, void* plain) { return encode_common(h, count, values, plain, false); }
-long BatchEncoder_Encode2(void* h, uint64_t count, int64_t* values, void* plain) {
+long BatchEncoder_Encode1(void* h, uint64_t count, uint64_t* values, void* plain) HIPBFV_BEGIN return encode_common(h, count, values, plain, false); HIPBFV_END
+long BatchEncoder_Encode2(void* h, uint64_t count, int64_t* values, void* plain) HIPBFV_BEGIN
   return encode_common(h, count, reinterpret_cast<const uint64_t*>(values), plain, true);
-}
+HIPBFV_END
 static long decode_common(void* h, void* plain, uint64_t* count, uint64_t* values, bool is_signed) {
   EncoderObj* e = as<EncoderObj>(h, kMagicEncoder);
   PlainObj* p = as<PlainObj>(plain, kMagicPlain);
@@ -1999,17 +2077,17 @@ static long decode_common(void* h, void* plain, uint64_t* count, uint64_t* value
   g_buffers.put(dev, 2 * n);
   return hr;
 }
-long BatchEncoder_Decode1(void* h, void* plain, uint64_t* count, uint64_t* values, void* pool) {
+long BatchEncoder_Decode1(void* h, void* plain, uint64_t* count, uint64_t* values, void* pool) HIPBFV_BEGIN
   (void)pool;
   return decode_common(h, plain, count, values, false);
-}
-long BatchEncoder_Decode2(void* h, void* plain, uint64_t* count, int64_t* values, void* pool) {
+HIPBFV_END
+long BatchEncoder_Decode2(void* h, void* plain, uint64_t* count, int64_t* values, void* pool) HIPBFV_BEGIN
   (void)pool;
   return decode_common(h, plain, count, reinterpret_cast<uint64_t*>(values), true);
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ Decryptor (seal_fhe/src/encryptor_decryptor.rs:596-690)
-long Decryptor_Create(void* context, void* secret_key, void** out) {
+long Decryptor_Create(void* context, void* secret_key, void** out) HIPBFV_BEGIN
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   AsymKeyObj* k = as<AsymKeyObj>(secret_key, kMagicSecretKey);
   if (!x || !k || !out) return HIPBFV_E_POINTER;
@@ -2021,14 +2099,14 @@ long Decryptor_Create(void* context, void* secret_key, void** out) {
   d->sk = k->key;
   *out = d;
   return HIPBFV_S_OK;
-}
-long Decryptor_Destroy(void* h) {
+HIPBFV_END
+long Decryptor_Destroy(void* h) HIPBFV_BEGIN
   DecryptorObj* d = as<DecryptorObj>(h, kMagicDecryptor);
   if (!d) return HIPBFV_E_POINTER;
   delete d;
   return HIPBFV_S_OK;
-}
-long Decryptor_Decrypt(void* h, void* encrypted, void* destination) {
+HIPBFV_END
+long Decryptor_Decrypt(void* h, void* encrypted, void* destination) HIPBFV_BEGIN
   DecryptorObj* d = as<DecryptorObj>(h, kMagicDecryptor);
   CipherObj* c = as<CipherObj>(encrypted, kMagicCipher);
   PlainObj* p = as<PlainObj>(destination, kMagicPlain);
@@ -2054,7 +2132,7 @@ long Decryptor_Decrypt(void* h, void* encrypted, void* destination) {
   host.resize(len);
   p->coeffs.swap(host);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // Decryptor::invariant_noise_budget (encryptor_decryptor.rs:640-660): bits(q) - bits(|t * phase mod q| centred, max over
 // coefficients) - 1, floored at 0.  The phase comes from the device; the multi-word arithmetic (one CRT composition
@@ -2165,16 +2243,16 @@ static long invariant_noise_norm(void* h, void* encrypted, Big* worst_out, Big* 
   *q_out = Q;
   return HIPBFV_S_OK;
 }
-long Decryptor_InvariantNoiseBudget(void* h, void* encrypted, int* budget) {
+long Decryptor_InvariantNoiseBudget(void* h, void* encrypted, int* budget) HIPBFV_BEGIN
   if (!budget) return HIPBFV_E_POINTER;
   Big worst(1), Q(1);
   if (long hr = invariant_noise_norm(h, encrypted, &worst, &Q)) return hr;
   *budget = std::max(0, Q.bits() - worst.bits() - 1);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 // the fork's f64 variant (encryptor_decryptor.rs:660-683): the infinity norm of the invariant noise polynomial,
 // |[t * ct(s)]_q| / q; decryption is correct while it stays below 1/2
-long Decryptor_InvariantNoise(void* h, void* encrypted, double* invariant_noise) {
+long Decryptor_InvariantNoise(void* h, void* encrypted, double* invariant_noise) HIPBFV_BEGIN
   if (!invariant_noise) return HIPBFV_E_POINTER;
   Big worst(1), Q(1);
   if (long hr = invariant_noise_norm(h, encrypted, &worst, &Q)) return hr;
@@ -2185,10 +2263,10 @@ long Decryptor_InvariantNoise(void* h, void* encrypted, double* invariant_noise)
   };
   *invariant_noise = (double)(to_ld(worst) / to_ld(Q));
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ Encryptor, public-key mode (encryptor_decryptor.rs:140-260)
-long Encryptor_Create(void* context, void* public_key, void* secret_key, void** out) {
+long Encryptor_Create(void* context, void* public_key, void* secret_key, void** out) HIPBFV_BEGIN
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!x || !out) return HIPBFV_E_POINTER;
   // with_public_key / with_secret_key / with_public_and_secret_key (encryptor_decryptor.rs:140-200): either may be null
@@ -2213,22 +2291,22 @@ long Encryptor_Create(void* context, void* public_key, void* secret_key, void** 
   }
   *out = e;
   return HIPBFV_S_OK;
-}
-long Encryptor_Destroy(void* h) {
+HIPBFV_END
+long Encryptor_Destroy(void* h) HIPBFV_BEGIN
   EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
   if (!e) return HIPBFV_E_POINTER;
   delete e;
   return HIPBFV_S_OK;
-}
-long hipbfv_Encryptor_SetSeed(void* h, uint64_t seed) {
+HIPBFV_END
+long hipbfv_Encryptor_SetSeed(void* h, uint64_t seed) HIPBFV_BEGIN
   EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
   if (!e) return HIPBFV_E_POINTER;
   std::lock_guard<std::mutex> g(e->mu);
   e->seed = seed;
   e->next_op = 0;
   return HIPBFV_S_OK;
-}
-long Encryptor_Encrypt(void* h, void* plaintext, void* destination, void* pool) {
+HIPBFV_END
+long Encryptor_Encrypt(void* h, void* plaintext, void* destination, void* pool) HIPBFV_BEGIN
   (void)pool;
   EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
   PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
@@ -2269,64 +2347,64 @@ long Encryptor_Encrypt(void* h, void* plaintext, void* destination, void* pool) 
   }
   c->adopt(e->ctx, 2, out, words);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ batched device-pointer forms
 static Evaluator* eval_of(void* evaluator) {
   EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
   return e ? e->ev.get() : nullptr;
 }
-long hipbfv_batch_encode(void* evaluator, const uint64_t* values, uint64_t* plain, uint64_t count, int is_signed, void* stream) {
+long hipbfv_batch_encode(void* evaluator, const uint64_t* values, uint64_t* plain, uint64_t count, int is_signed, void* stream) HIPBFV_BEGIN
   Evaluator* ev = eval_of(evaluator);
   if (!ev || !values || !plain) return HIPBFV_E_POINTER;
   u32 bad = 0;
   if (int st = ev->batch_encode((const u64*)values, (u64*)plain, count, is_signed != 0, &bad, (hipStream_t)stream)) return from_status(st);
   if (bad) return fail(HIPBFV_E_INVALIDARG, "input value is larger than plain_modulus");
   return HIPBFV_S_OK;
-}
-long hipbfv_batch_decode(void* evaluator, const uint64_t* plain, uint64_t* values, uint64_t count, int is_signed, void* stream) {
+HIPBFV_END
+long hipbfv_batch_decode(void* evaluator, const uint64_t* plain, uint64_t* values, uint64_t count, int is_signed, void* stream) HIPBFV_BEGIN
   Evaluator* ev = eval_of(evaluator);
   if (!ev || !values || !plain) return HIPBFV_E_POINTER;
   return from_status(ev->batch_decode((const u64*)plain, (u64*)values, count, is_signed != 0, (hipStream_t)stream));
-}
-long hipbfv_batch_decrypt(void* evaluator, const uint64_t* ct, uint32_t size, void* secret_key, uint64_t* plain, uint64_t count, void* stream) {
+HIPBFV_END
+long hipbfv_batch_decrypt(void* evaluator, const uint64_t* ct, uint32_t size, void* secret_key, uint64_t* plain, uint64_t count, void* stream) HIPBFV_BEGIN
   EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
   AsymKeyObj* k = as<AsymKeyObj>(secret_key, kMagicSecretKey);
   if (!e || !k || !ct || !plain) return HIPBFV_E_POINTER;
   if (!k->key || k->key->ctx.get() != e->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "secret key is not valid for encryption parameters");
   return from_status(e->ev->decrypt((const u64*)ct, size, k->key->dev, (u64*)plain, count, (hipStream_t)stream));
-}
+HIPBFV_END
 long hipbfv_batch_encrypt(void* evaluator, const uint64_t* plain, uint64_t plain_stride, void* public_key, uint64_t seed, uint64_t first_op,
-                          uint64_t* ct, uint64_t count, void* stream) {
+                          uint64_t* ct, uint64_t count, void* stream) HIPBFV_BEGIN
   EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
   AsymKeyObj* k = as<AsymKeyObj>(public_key, kMagicPublicKey);
   if (!e || !k || !ct || !plain) return HIPBFV_E_POINTER;
   if (!k->key || k->key->ctx.get() != e->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "public key is not valid for encryption parameters");
   return from_status(e->ev->encrypt((const u64*)plain, plain_stride, k->key->dev, seed, first_op, (u64*)ct, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ plaintext-matrix x ciphertext-vector (PIR, examples/pir)
-long hipbfv_batch_plain_to_ntt(void* evaluator, const uint64_t* plain, uint64_t plain_stride, uint64_t* pntt, uint64_t count, void* stream) {
+long hipbfv_batch_plain_to_ntt(void* evaluator, const uint64_t* plain, uint64_t plain_stride, uint64_t* pntt, uint64_t count, void* stream) HIPBFV_BEGIN
   Evaluator* ev = eval_of(evaluator);
   if (!ev || !plain || !pntt) return HIPBFV_E_POINTER;
   return from_status(ev->plain_to_ntt((const u64*)plain, plain_stride, (u64*)pntt, count, (hipStream_t)stream));
-}
-long hipbfv_batch_ct_to_ntt(void* evaluator, const uint64_t* ct, uint64_t size, uint64_t* ctn, uint64_t count, void* stream) {
+HIPBFV_END
+long hipbfv_batch_ct_to_ntt(void* evaluator, const uint64_t* ct, uint64_t size, uint64_t* ctn, uint64_t count, void* stream) HIPBFV_BEGIN
   Evaluator* ev = eval_of(evaluator);
   if (!ev || !ct || !ctn) return HIPBFV_E_POINTER;
   if (size < 1) return fail(HIPBFV_E_INVALIDARG, "invalid ciphertext size");
   return from_status(ev->ct_to_ntt((const u64*)ct, (u32)size, (u64*)ctn, count, (hipStream_t)stream));
-}
+HIPBFV_END
 long hipbfv_batch_dot_plain_ntt(void* evaluator, const uint64_t* ctn, uint64_t cols, const uint64_t* pntt, uint64_t rows, uint64_t* out,
-                                void* stream) {
+                                void* stream) HIPBFV_BEGIN
   Evaluator* ev = eval_of(evaluator);
   if (!ev || !ctn || !pntt || !out) return HIPBFV_E_POINTER;
   if (cols > 0xFFFFFFFFull || rows > 0xFFFFFFFFull) return fail(HIPBFV_E_INVALIDARG, "matrix too large");
   return from_status(ev->dot_plain_ntt((const u64*)ctn, (u32)cols, (const u64*)pntt, (u32)rows, (u64*)out, (hipStream_t)stream));
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ modulus switching (evaluator_base.rs: mod_switch_to_next)
-long Evaluator_ModSwitchToNext1(void* h, void* encrypted, void* destination, void* pool) {
+long Evaluator_ModSwitchToNext1(void* h, void* encrypted, void* destination, void* pool) HIPBFV_BEGIN
   (void)pool;
   EvalObj* e = as<EvalObj>(h, kMagicEval);
   CipherObj *x = as<CipherObj>(encrypted, kMagicCipher), *d = as<CipherObj>(destination, kMagicCipher);
@@ -2351,15 +2429,15 @@ long Evaluator_ModSwitchToNext1(void* h, void* encrypted, void* destination, voi
     return from_status(kHipError);
   }
   return finish_result(ne, d, x->size, buf, words, s, true);
-}
+HIPBFV_END
 
-long Evaluator_ModSwitchToNext2(void* h, void* plain, void* destination) {
+long Evaluator_ModSwitchToNext2(void* h, void* plain, void* destination) HIPBFV_BEGIN
   // SEAL mod-switches only NTT-form plaintexts (CKKS / pre-transformed); BFV plaintexts of this path are never in NTT form
   if (!as<EvalObj>(h, kMagicEval) || !as<PlainObj>(plain, kMagicPlain) || !as<PlainObj>(destination, kMagicPlain)) return HIPBFV_E_POINTER;
   return fail(HIPBFV_E_INVALIDARG, "plain is not in NTT form");
-}
+HIPBFV_END
 
-long hipbfv_Context_NextLevel(void* context, void** next) {
+long hipbfv_Context_NextLevel(void* context, void** next) HIPBFV_BEGIN
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!x || !next) return HIPBFV_E_POINTER;
   std::string err;
@@ -2369,14 +2447,14 @@ long hipbfv_Context_NextLevel(void* context, void** next) {
   o->ctx = n;
   *next = o;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
-long hipbfv_batch_mod_switch(void* evaluator, const uint64_t* ct, uint64_t size, uint64_t* out, uint64_t count, void* stream) {
+long hipbfv_batch_mod_switch(void* evaluator, const uint64_t* ct, uint64_t size, uint64_t* out, uint64_t count, void* stream) HIPBFV_BEGIN
   Evaluator* ev = eval_of(evaluator);
   if (!ev || !ct || !out) return HIPBFV_E_POINTER;
   if (size < 1) return fail(HIPBFV_E_INVALIDARG, "invalid ciphertext size");
   return from_status(ev->mod_switch_next((const u64*)ct, (u32)size, (u64*)out, count, (hipStream_t)stream));
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ PolynomialArray + encryption components (fork-only API)
 static long polyarray_fill(PolyArrayObj* a, const std::shared_ptr<Context>& ctx, u32 polys, u32 kc) {
@@ -2391,19 +2469,19 @@ static long polyarray_fill(PolyArrayObj* a, const std::shared_ptr<Context>& ctx,
   a->reserved = true;
   return HIPBFV_S_OK;
 }
-long PolynomialArray_Create(void* pool, void** out) {
+long PolynomialArray_Create(void* pool, void** out) HIPBFV_BEGIN
   (void)pool;
   if (!out) return HIPBFV_E_POINTER;
   *out = new PolyArrayObj();
   return HIPBFV_S_OK;
-}
-long PolynomialArray_Destroy(void* h) {
+HIPBFV_END
+long PolynomialArray_Destroy(void* h) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a) return HIPBFV_E_POINTER;
   delete a;
   return HIPBFV_S_OK;
-}
-long PolynomialArray_CreateFromCiphertext(void* pool, void* context, void* ciphertext, void** out) {
+HIPBFV_END
+long PolynomialArray_CreateFromCiphertext(void* pool, void* context, void* ciphertext, void** out) HIPBFV_BEGIN
   (void)pool;
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   CipherObj* c = as<CipherObj>(ciphertext, kMagicCipher);
@@ -2420,7 +2498,7 @@ long PolynomialArray_CreateFromCiphertext(void* pool, void* context, void* ciphe
   }
   *out = a.release();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 static long polyarray_from_key(void* context, AsymKeyObj* k, u32 polys, void** out) {
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!x || !k || !out) return HIPBFV_E_POINTER;
@@ -2435,15 +2513,15 @@ static long polyarray_from_key(void* context, AsymKeyObj* k, u32 polys, void** o
   *out = a.release();
   return HIPBFV_S_OK;
 }
-long PolynomialArray_CreateFromPublicKey(void* pool, void* context, void* public_key, void** out) {
+long PolynomialArray_CreateFromPublicKey(void* pool, void* context, void* public_key, void** out) HIPBFV_BEGIN
   (void)pool;
   return polyarray_from_key(context, as<AsymKeyObj>(public_key, kMagicPublicKey), 2, out);
-}
-long PolynomialArray_CreateFromSecretKey(void* pool, void* context, void* secret_key, void** out) {
+HIPBFV_END
+long PolynomialArray_CreateFromSecretKey(void* pool, void* context, void* secret_key, void** out) HIPBFV_BEGIN
   (void)pool;
   return polyarray_from_key(context, as<AsymKeyObj>(secret_key, kMagicSecretKey), 1, out);
-}
-long PolynomialArray_Copy(void* h, void** out) {
+HIPBFV_END
+long PolynomialArray_Copy(void* h, void** out) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a || !out) return HIPBFV_E_POINTER;
   std::unique_ptr<PolyArrayObj> b(new PolyArrayObj());
@@ -2458,49 +2536,49 @@ long PolynomialArray_Copy(void* h, void** out) {
   }
   *out = b.release();
   return HIPBFV_S_OK;
-}
-long PolynomialArray_IsReserved(void* h, bool* result) {
+HIPBFV_END
+long PolynomialArray_IsReserved(void* h, bool* result) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a || !result) return HIPBFV_E_POINTER;
   *result = a->reserved;
   return HIPBFV_S_OK;
-}
-long PolynomialArray_IsRns(void* h, bool* result) {
+HIPBFV_END
+long PolynomialArray_IsRns(void* h, bool* result) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a || !result) return HIPBFV_E_POINTER;
   *result = a->rns;
   return HIPBFV_S_OK;
-}
-long PolynomialArray_PolySize(void* h, uint64_t* result) {
+HIPBFV_END
+long PolynomialArray_PolySize(void* h, uint64_t* result) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a || !result) return HIPBFV_E_POINTER;
   *result = a->polys;
   return HIPBFV_S_OK;
-}
-long PolynomialArray_PolyModulusDegree(void* h, uint64_t* result) {
+HIPBFV_END
+long PolynomialArray_PolyModulusDegree(void* h, uint64_t* result) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a || !result) return HIPBFV_E_POINTER;
   *result = a->ctx ? a->ctx->n() : 0;
   return HIPBFV_S_OK;
-}
-long PolynomialArray_CoeffModulusSize(void* h, uint64_t* result) {
+HIPBFV_END
+long PolynomialArray_CoeffModulusSize(void* h, uint64_t* result) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a || !result) return HIPBFV_E_POINTER;
   *result = a->kc;
   return HIPBFV_S_OK;
-}
-long PolynomialArray_ExportSize(void* h, uint64_t* result) {
+HIPBFV_END
+long PolynomialArray_ExportSize(void* h, uint64_t* result) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a || !result) return HIPBFV_E_POINTER;
   *result = a->words;
   return HIPBFV_S_OK;
-}
-long PolynomialArray_PerformExport(void* h, uint64_t* data) {
+HIPBFV_END
+long PolynomialArray_PerformExport(void* h, uint64_t* data) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a || (!data && a->words)) return HIPBFV_E_POINTER;
   if (a->words && hipMemcpy(data, a->dev, a->words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return from_status(kHipError);
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 // CRT constants of the first kc primes: inv_punct[kc] | punct[kc][kc] | q[kc]
 static std::vector<u64> crt_constants(const Context& cx, u32 kc) {
   std::vector<u64> c((size_t)kc + (size_t)kc * kc + kc, 0);
@@ -2561,18 +2639,18 @@ static long polyarray_convert(PolyArrayObj* a, bool to_rns) {
   a->rns = to_rns;
   return HIPBFV_S_OK;
 }
-long PolynomialArray_ToRns(void* h) {
+long PolynomialArray_ToRns(void* h) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a) return HIPBFV_E_POINTER;
   return polyarray_convert(a, true);
-}
-long PolynomialArray_ToMultiprecision(void* h) {
+HIPBFV_END
+long PolynomialArray_ToMultiprecision(void* h) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a) return HIPBFV_E_POINTER;
   return polyarray_convert(a, false);
-}
+HIPBFV_END
 // Drop the last prime: the new array keeps residues 0..kc-2 of every polynomial (RNS form)
-long PolynomialArray_Drop(void* h, void** out) {
+long PolynomialArray_Drop(void* h, void** out) HIPBFV_BEGIN
   PolyArrayObj* a = as<PolyArrayObj>(h, kMagicPolyArray);
   if (!a || !out) return HIPBFV_E_POINTER;
   if (!a->reserved || a->kc < 2) return fail(HIPBFV_E_INVALIDARG, "no modulus to drop");
@@ -2592,7 +2670,7 @@ long PolynomialArray_Drop(void* h, void** out) {
   if (hr != HIPBFV_S_OK) return hr;
   *out = b.release();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 
 // r_i = floor(((q mod t) * m_i + (t + 1)/2) / t): what SEAL's multiply_add_plain_with_scaling_variant adds on top of
 // floor(q/t) * m_i, so that c0 = floor(q/t)*m + r + ... exactly (logproof/src/bfv_statement.rs:159-160)
@@ -2662,7 +2740,7 @@ static long encrypt_one(EncryptorObj* e, PlainObj* p, CipherObj* c, bool symmetr
   return HIPBFV_S_OK;
 }
 long Encryptor_EncryptReturnComponents(void* h, void* plaintext, bool disable_special_modulus, void* destination, void* u_destination,
-                                       void* e_destination, void* r_destination, void* pool) {
+                                       void* e_destination, void* r_destination, void* pool) HIPBFV_BEGIN
   (void)pool;
   EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
   PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
@@ -2672,9 +2750,9 @@ long Encryptor_EncryptReturnComponents(void* h, void* plaintext, bool disable_sp
   PlainObj* rd = as<PlainObj>(r_destination, kMagicPlain);
   if (!e || !p || !c || !ud || !ed || !rd) return HIPBFV_E_POINTER;
   return encrypt_one(e, p, c, false, disable_special_modulus, ud, ed, rd, nullptr);
-}
+HIPBFV_END
 long Encryptor_EncryptReturnComponentsSetSeed(void* h, void* plaintext, bool disable_special_modulus, void* destination, void* u_destination,
-                                              void* e_destination, void* r_destination, void* seed, void* pool) {
+                                              void* e_destination, void* r_destination, void* seed, void* pool) HIPBFV_BEGIN
   (void)pool;
   EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
   PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
@@ -2685,8 +2763,8 @@ long Encryptor_EncryptReturnComponentsSetSeed(void* h, void* plaintext, bool dis
   if (!e || !p || !c || !ud || !ed || !rd || !seed) return HIPBFV_E_POINTER;
   const u64 sd = fold_seed(seed);
   return encrypt_one(e, p, c, false, disable_special_modulus, ud, ed, rd, &sd);
-}
-long Encryptor_EncryptSymmetric(void* h, void* plaintext, bool save_seed, void* destination, void* pool) {
+HIPBFV_END
+long Encryptor_EncryptSymmetric(void* h, void* plaintext, bool save_seed, void* destination, void* pool) HIPBFV_BEGIN
   (void)pool;
   (void)save_seed;  // seed-compressed ciphertexts are a serialisation option; the handle holds the expanded ciphertext
   EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
@@ -2694,8 +2772,8 @@ long Encryptor_EncryptSymmetric(void* h, void* plaintext, bool save_seed, void* 
   CipherObj* c = as<CipherObj>(destination, kMagicCipher);
   if (!e || !p || !c) return HIPBFV_E_POINTER;
   return encrypt_one(e, p, c, true, false, nullptr, nullptr, nullptr, nullptr);
-}
-long Encryptor_EncryptSymmetricReturnComponents(void* h, void* plaintext, void* destination, void* e_destination, void* r_destination, void* pool) {
+HIPBFV_END
+long Encryptor_EncryptSymmetricReturnComponents(void* h, void* plaintext, void* destination, void* e_destination, void* r_destination, void* pool) HIPBFV_BEGIN
   (void)pool;
   EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
   PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
@@ -2704,9 +2782,9 @@ long Encryptor_EncryptSymmetricReturnComponents(void* h, void* plaintext, void* 
   PlainObj* rd = as<PlainObj>(r_destination, kMagicPlain);
   if (!e || !p || !c || !ed || !rd) return HIPBFV_E_POINTER;
   return encrypt_one(e, p, c, true, false, nullptr, ed, rd, nullptr);
-}
+HIPBFV_END
 long Encryptor_EncryptSymmetricReturnComponentsSetSeed(void* h, void* plaintext, void* destination, void* e_destination, void* r_destination,
-                                                       void* seed, void* pool) {
+                                                       void* seed, void* pool) HIPBFV_BEGIN
   (void)pool;
   EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
   PlainObj* p = as<PlainObj>(plaintext, kMagicPlain);
@@ -2716,7 +2794,7 @@ long Encryptor_EncryptSymmetricReturnComponentsSetSeed(void* h, void* plaintext,
   if (!e || !p || !c || !ed || !rd || !seed) return HIPBFV_E_POINTER;
   const u64 sd = fold_seed(seed);
   return encrypt_one(e, p, c, true, false, nullptr, ed, rd, &sd);
-}
+HIPBFV_END
 
 // ------------------------------------------------------------------ KeyGenerator (seal_fhe/src/key_generator.rs:20-200)
 static u64 os_seed(const void* salt) {
@@ -2761,19 +2839,19 @@ static long keygen_new(void* context, AsymKeyObj* existing, void** out, const u6
   *out = g.release();
   return HIPBFV_S_OK;
 }
-long KeyGenerator_Create1(void* context, void** out) { return keygen_new(context, nullptr, out); }
-long hipbfv_KeyGenerator_CreateSeeded(void* context, uint64_t seed, void** out) { const u64 sd = seed; return keygen_new(context, nullptr, out, &sd); }
-long KeyGenerator_Create2(void* context, void* secret_key, void** out) {
+long KeyGenerator_Create1(void* context, void** out) HIPBFV_BEGIN return keygen_new(context, nullptr, out); HIPBFV_END
+long hipbfv_KeyGenerator_CreateSeeded(void* context, uint64_t seed, void** out) HIPBFV_BEGIN const u64 sd = seed; return keygen_new(context, nullptr, out, &sd); HIPBFV_END
+long KeyGenerator_Create2(void* context, void* secret_key, void** out) HIPBFV_BEGIN
   AsymKeyObj* k = as<AsymKeyObj>(secret_key, kMagicSecretKey);
   if (!k) return HIPBFV_E_POINTER;
   return keygen_new(context, k, out);
-}
-long KeyGenerator_Destroy(void* h) {
+HIPBFV_END
+long KeyGenerator_Destroy(void* h) HIPBFV_BEGIN
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g) return HIPBFV_E_POINTER;
   delete g;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 long hipbfv_KeyGenerator_SetSeed(void* h, uint64_t seed) {  // reproducible keys for tests; affects keys created afterwards
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g) return HIPBFV_E_POINTER;
@@ -2782,20 +2860,20 @@ long hipbfv_KeyGenerator_SetSeed(void* h, uint64_t seed) {  // reproducible keys
   g->next_stream = 1;
   return HIPBFV_S_OK;
 }
-long KeyGenerator_SecretKey(void* h, void** secret_key) {
+long KeyGenerator_SecretKey(void* h, void** secret_key) HIPBFV_BEGIN
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g || !secret_key) return HIPBFV_E_POINTER;
   AsymKeyObj* k = new AsymKeyObj(kMagicSecretKey);
   k->key = g->sk;
   *secret_key = k;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 static u64 take_stream(KeyGenObj* g, u64* seed) {
   std::lock_guard<std::mutex> lk(g->mu);
   *seed = g->seed;
   return g->next_stream++;
 }
-long KeyGenerator_CreatePublicKey(void* h, bool save_seed, void** public_key) {
+long KeyGenerator_CreatePublicKey(void* h, bool save_seed, void** public_key) HIPBFV_BEGIN
   (void)save_seed;  // seed-compressed keys are a serialisation option; the handle always holds the expanded key
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g || !public_key) return HIPBFV_E_POINTER;
@@ -2810,7 +2888,7 @@ long KeyGenerator_CreatePublicKey(void* h, bool save_seed, void** public_key) {
   k->key = buf;
   *public_key = k;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 static long keygen_kswitch_into(KeyGenObj* g, KeysObj* keys, u32 galois_elt) {
   const size_t words = g->ctx->key_words();
   u64* buf = g_buffers.get(words);
@@ -2830,7 +2908,7 @@ static long keygen_kswitch_into(KeyGenObj* g, KeysObj* keys, u32 galois_elt) {
   keys->keys[index] = buf;
   return HIPBFV_S_OK;
 }
-long KeyGenerator_CreateRelinKeys(void* h, bool save_seed, void** relin_keys) {
+long KeyGenerator_CreateRelinKeys(void* h, bool save_seed, void** relin_keys) HIPBFV_BEGIN
   (void)save_seed;
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g || !relin_keys) return HIPBFV_E_POINTER;
@@ -2840,8 +2918,8 @@ long KeyGenerator_CreateRelinKeys(void* h, bool save_seed, void** relin_keys) {
   if (long hr = keygen_kswitch_into(g, k.get(), 0)) return hr;
   *relin_keys = k.release();
   return HIPBFV_S_OK;
-}
-long KeyGenerator_CreateGaloisKeysFromElts(void* h, uint64_t count, uint32_t* galois_elts, bool save_seed, void** galois_keys) {
+HIPBFV_END
+long KeyGenerator_CreateGaloisKeysFromElts(void* h, uint64_t count, uint32_t* galois_elts, bool save_seed, void** galois_keys) HIPBFV_BEGIN
   (void)save_seed;
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g || !galois_keys || (count && !galois_elts)) return HIPBFV_E_POINTER;
@@ -2856,10 +2934,10 @@ long KeyGenerator_CreateGaloisKeysFromElts(void* h, uint64_t count, uint32_t* ga
   }
   *galois_keys = k.release();
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 // SEAL KeyGenerator::create_galois_keys(steps): one key per rotation step, GaloisTool::get_elts_from_steps (step 0 = the
 // column rotation).  The seal_fhe crate does not call it; exported so that the whole KeyGenerator_* family links.
-long KeyGenerator_CreateGaloisKeysFromSteps(void* h, uint64_t count, int* steps, bool save_seed, void** galois_keys) {
+long KeyGenerator_CreateGaloisKeysFromSteps(void* h, uint64_t count, int* steps, bool save_seed, void** galois_keys) HIPBFV_BEGIN
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g || !galois_keys || (count && !steps)) return HIPBFV_E_POINTER;
   std::vector<uint32_t> elts;
@@ -2869,9 +2947,9 @@ long KeyGenerator_CreateGaloisKeysFromSteps(void* h, uint64_t count, int* steps,
     elts.push_back(elt);
   }
   return KeyGenerator_CreateGaloisKeysFromElts(h, elts.size(), elts.data(), save_seed, galois_keys);
-}
+HIPBFV_END
 // SEAL GaloisTool::get_elts_all: the column rotation 2N-1 and 3^(+-2^i) for every power-of-two row rotation
-long KeyGenerator_CreateGaloisKeysAll(void* h, bool save_seed, void** galois_keys) {
+long KeyGenerator_CreateGaloisKeysAll(void* h, bool save_seed, void** galois_keys) HIPBFV_BEGIN
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g || !galois_keys) return HIPBFV_E_POINTER;
   const u64 m = 2 * (u64)g->ctx->n();
@@ -2889,7 +2967,7 @@ long KeyGenerator_CreateGaloisKeysAll(void* h, bool save_seed, void** galois_key
     neg = (neg * neg) & (m - 1);
   }
   return KeyGenerator_CreateGaloisKeysFromElts(h, elts.size(), elts.data(), save_seed, galois_keys);
-}
+HIPBFV_END
 
 }  // extern "C"
 #pragma GCC visibility pop

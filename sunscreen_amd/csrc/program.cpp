@@ -42,6 +42,8 @@ struct JParser {
   const char* p;
   const char* end;
   bool ok = true;
+  int depth = 0;
+  static constexpr int kMaxDepth = 64;  // serde's FheProgram JSON nests 5 deep; the parser recurses, so untrusted input is bounded
   void ws() {
     while (p < end && std::isspace((unsigned char)*p)) p++;
   }
@@ -54,6 +56,17 @@ struct JParser {
     return false;
   }
   JValue parse() {
+    JValue v;
+    if (++depth > kMaxDepth) {
+      ok = false;
+      --depth;
+      return v;
+    }
+    v = parse_value();
+    --depth;
+    return v;
+  }
+  JValue parse_value() {
     JValue v;
     ws();
     if (p >= end) {
@@ -133,15 +146,21 @@ struct JParser {
     } else if (lit("null")) {
       v.kind = JValue::kNull;
     } else {
+      // the buffer is (pointer, length), not NUL-terminated: copy the number token before handing it to strtod/strtoull
+      char tok[64];
+      size_t len = 0;
+      while (p + len < end && len + 1 < sizeof(tok) && (std::isdigit((unsigned char)p[len]) || std::strchr("+-.eE", p[len]))) len++;
+      std::memcpy(tok, p, len);
+      tok[len] = 0;
       char* e = nullptr;
       v.kind = JValue::kNum;
-      v.num = std::strtod(p, &e);
-      if (e == p) {
+      v.num = std::strtod(tok, &e);
+      if (e == tok) {
         ok = false;
         return v;
       }
-      if (*p != '-') v.unum = std::strtoull(p, nullptr, 10);
-      p = e;
+      if (tok[0] != '-') v.unum = std::strtoull(tok, nullptr, 10);
+      p += e - tok;
     }
     return v;
   }

@@ -219,7 +219,10 @@ int finish(const std::vector<uint8_t>& body, int compr, std::vector<uint8_t>* ou
 }
 
 // strip the outer header, decompress: body bytes + number of input bytes consumed
-int open_object(const uint8_t* in, size_t size, std::vector<uint8_t>* body, size_t* consumed) {
+// `max_body` bounds the decompressed size by what the caller's context can legally hold (a tiny zstd frame may declare
+// gigabytes: the bytes are untrusted); 0 = the format-wide ceiling
+int open_object(const uint8_t* in, size_t size, std::vector<uint8_t>* body, size_t* consumed, size_t max_body) {
+  if (!max_body) max_body = (size_t)1 << 32;
   Reader r{in, in + size};
   unsigned long long total = 0;
   const int compr = r.header(&total);
@@ -235,7 +238,7 @@ int open_object(const uint8_t* in, size_t size, std::vector<uint8_t>* body, size
   Zstd& z = zstd();
   if (!z.ok()) return kWireNoZstd;
   unsigned long long raw = z.frameContentSize(payload, plen);
-  if (raw == ~0ull || raw == ~0ull - 1 || raw > (1ull << 34)) return kWireIo;
+  if (raw == ~0ull || raw == ~0ull - 1 || raw > max_body) return kWireIo;
   body->resize(raw);
   const size_t got = z.decompress(body->data(), body->size(), payload, plen);
   if (z.isError(got) || got != raw) return kWireIo;
@@ -260,9 +263,9 @@ int wire_pack_ciphertext(const uint8_t parms_id[32], bool is_ntt, unsigned long 
   return finish(body, compr, out);
 }
 
-int wire_unpack_ciphertext(const uint8_t* in, size_t in_size, WireCiphertext* ct, size_t* consumed) {
+int wire_unpack_ciphertext(const uint8_t* in, size_t in_size, WireCiphertext* ct, size_t* consumed, size_t max_body) {
   std::vector<uint8_t> body;
-  if (int rc = open_object(in, in_size, &body, consumed)) return rc;
+  if (int rc = open_object(in, in_size, &body, consumed, max_body)) return rc;
   Reader r{body.data(), body.data() + body.size()};
   r.raw(ct->parms_id, 32);
   ct->is_ntt = r.u8() != 0;
@@ -286,9 +289,9 @@ int wire_pack_plaintext(const uint8_t parms_id[32], const unsigned long long* co
   return finish(body, compr, out);
 }
 
-int wire_unpack_plaintext(const uint8_t* in, size_t in_size, WirePlaintext* pt, size_t* consumed) {
+int wire_unpack_plaintext(const uint8_t* in, size_t in_size, WirePlaintext* pt, size_t* consumed, size_t max_body) {
   std::vector<uint8_t> body;
-  if (int rc = open_object(in, in_size, &body, consumed)) return rc;
+  if (int rc = open_object(in, in_size, &body, consumed, max_body)) return rc;
   Reader r{body.data(), body.data() + body.size()};
   r.raw(pt->parms_id, 32);
   const unsigned long long count = r.u64();
@@ -314,13 +317,14 @@ int wire_pack_kswitch(const uint8_t parms_id[32], unsigned long long n, unsigned
   return finish(body, compr, out);
 }
 
-int wire_unpack_kswitch(const uint8_t* in, size_t in_size, WireKSwitchKeys* ks, size_t* consumed) {
+int wire_unpack_kswitch(const uint8_t* in, size_t in_size, WireKSwitchKeys* ks, size_t* consumed, size_t max_body, size_t max_index) {
   std::vector<uint8_t> body;
-  if (int rc = open_object(in, in_size, &body, consumed)) return rc;
+  if (int rc = open_object(in, in_size, &body, consumed, max_body)) return rc;
   Reader r{body.data(), body.data() + body.size()};
   r.raw(ks->parms_id, 32);
   const unsigned long long dim1 = r.u64();
-  if (!r.ok || dim1 > (1u << 20)) return kWireIo;
+  // an index is (galois_elt - 1) / 2 < N: the context bounds it; every entry costs at least its 8-byte length word
+  if (!r.ok || dim1 > (max_index ? max_index : (1u << 17)) || dim1 > body.size() / 8) return kWireIo;
   ks->keys.resize(dim1);
   for (unsigned long long i = 0; i < dim1; i++) {
     const unsigned long long dim2 = r.u64();

@@ -34,12 +34,14 @@ bool wire_zstd_available();
 
 int wire_pack_ciphertext(const uint8_t parms_id[32], bool is_ntt, unsigned long long size, unsigned long long n, unsigned long long k, const unsigned long long* data, int compr,
                          std::vector<uint8_t>* out);
-int wire_unpack_ciphertext(const uint8_t* in, size_t in_size, WireCiphertext* ct, size_t* consumed);
+// max_body: ceiling on the (decompressed) object body in bytes, 0 = format-wide default; callers with a context pass what
+// that context can legally hold
+int wire_unpack_ciphertext(const uint8_t* in, size_t in_size, WireCiphertext* ct, size_t* consumed, size_t max_body = 0);
 int wire_pack_plaintext(const uint8_t parms_id[32], const unsigned long long* coeffs, unsigned long long count, int compr, std::vector<uint8_t>* out);
-int wire_unpack_plaintext(const uint8_t* in, size_t in_size, WirePlaintext* pt, size_t* consumed);
+int wire_unpack_plaintext(const uint8_t* in, size_t in_size, WirePlaintext* pt, size_t* consumed, size_t max_body = 0);
 // keys[index] = list over the decomposition index J of pointers to u64[2][kk][n]; an empty list = key absent
 int wire_pack_kswitch(const uint8_t parms_id[32], unsigned long long n, unsigned long long kk, const std::vector<std::vector<const unsigned long long*>>& keys, int compr,
                       std::vector<uint8_t>* out);
-int wire_unpack_kswitch(const uint8_t* in, size_t in_size, WireKSwitchKeys* ks, size_t* consumed);
+int wire_unpack_kswitch(const uint8_t* in, size_t in_size, WireKSwitchKeys* ks, size_t* consumed, size_t max_body = 0, size_t max_index = 0);
 
 }  // namespace hipbfv

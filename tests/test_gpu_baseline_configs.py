@@ -1,0 +1,236 @@
+"""BASELINE.json configurations at their stated parameters, HIP (through the C ABI) vs the CPU oracle bit for bit.
+
+What the other GPU test files run at reduced degree runs here on exactly the parameter sets BASELINE.json / SURVEY 8(d)
+name (VERDICT r01 rows g1, g2 and the config-3 gate):
+
+  * config 3 gate     : n=8192, SEAL default K=4+1, t=batching(8192,17): >= 64 genuine encryptions bit-exact and
+                        decrypt-correct
+  * north-star literal: n=8192, CoeffModulus::create(8192,[54,54,54,56]) -- "3 x 54-bit RNS primes"
+  * config 4          : examples/chi_sq `chi_sq_optimized_impl` (examples/chi_sq/src/main.rs:59-88) at n=16384, K=8+1,
+                        t=batching(16384,17)=65537, incl. the example's (2,7,9) -> 529/242/275/1250 (main.rs:236-238)
+  * config 5b         : examples/dot_prod (examples/dot_prod/src/main.rs:38-75) at n=16384 with its 13 power-of-two
+                        rotation keys + the column key
+  * config 5a         : examples/pir matrix-vector product + lookup (examples/pir/src/main.rs:16-45) at n=16384
+
+The oracle runs one item per host thread (its C calls release the GIL), so every test stays within seconds.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from oracle import bfv_oracle as O
+from oracle.program_interp import run_program
+
+pytestmark = pytest.mark.gpu
+
+THREADS = min(os.cpu_count() or 1, 64)
+
+
+def _pmap(fn, items):
+    with ThreadPoolExecutor(THREADS) as ex:
+        return list(ex.map(fn, items))
+
+
+def _signed(t, v):
+    v = v.astype(np.int64)
+    return np.where(v > t // 2, v - t, v)
+
+
+def _setup(n, primes, t, galois=None, seed=21):
+    from sunscreen_amd import Context, GaloisKeys, RelinearizationKeys
+    from sunscreen_amd.batch import BatchEvaluator
+
+    o = O.Oracle(n, primes, t)
+    O.seed(seed)
+    sk, pk, rk, gk = o.keygen(galois_elts=galois)
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    rkd = RelinearizationKeys.from_array(ctx, rk)
+    gkd = GaloisKeys.from_arrays(ctx, gk) if gk else None
+    return o, sk, pk, rk, gk, ctx, ev, rkd, gkd
+
+
+def _encrypt_slots(o, pk, vals):
+    # encryption draws from the oracle's one seeded generator: keep it sequential so the inputs are reproducible
+    return np.stack([o.encrypt(pk, o.batch_encode(v.astype(np.uint64) % o.t)) for v in vals])
+
+
+def test_config3_gate_64_genuine_encryptions_bit_exact_and_decrypt_correct():
+    from sunscreen_amd.batch import to_device, to_host
+
+    n, t = 8192, O.plain_batching(8192, 17)
+    assert t == 114689  # seal_fhe/src/modulus.rs:296-313 known answer
+    o, sk, pk, rk, gk, ctx, ev, rkd, gkd = _setup(n, O.bfv_default(n), t)
+    count = 64
+    rng = np.random.default_rng(3)
+    # slot vectors x_i = (seed + i) mod 257 - 128 (products stay below t/2)
+    va = np.stack([(rng.integers(0, 1 << 30) + np.arange(n)) % 257 - 128 for _ in range(count)])
+    vb = np.stack([(rng.integers(0, 1 << 30) + 3 * np.arange(n)) % 257 - 128 for _ in range(count)])
+    a, b = _encrypt_slots(o, pk, va), _encrypt_slots(o, pk, vb)
+    got = to_host(ev.multiply_relin(to_device(a), to_device(b), rkd))
+    _, ref = o.bench_mul_relin(a, b, rk, threads=THREADS)  # the oracle's multiply + relinearize, OpenMP over the items
+    assert (got == ref).all()
+    spot = o.relinearize(o.multiply(a[5], b[5]), rk)
+    assert (ref[5] == spot).all()  # the batched oracle leg is the node-by-node oracle
+    dec = _pmap(lambda i: _signed(t, o.batch_decode(o.decrypt(got[i], sk))), range(count))
+    for i in range(count):
+        assert (dec[i] == va[i] * vb[i]).all(), i
+    assert o.noise_budget(got[0], sk) > 0
+
+
+def test_north_star_literal_3x54bit_primes_mul_relin_and_rotate():
+    from sunscreen_amd.batch import to_device, to_host
+
+    n = 8192
+    primes = O.coeff_modulus_create(n, [54, 54, 54, 56])
+    assert primes[:3] == [0x3FFFFFFFE7C001, 0x3FFFFFFFEB8001, 0x3FFFFFFFEF8001]  # SURVEY 8(d) config 2 [PROBED]
+    t = O.plain_batching(n, 17)
+    o = O.Oracle(n, primes, t)
+    elts = [o.galois_elt_from_step(1), o.galois_elt_from_step(-3), 2 * n - 1]
+    o, sk, pk, rk, gk, ctx, ev, rkd, gkd = _setup(n, primes, t, galois=elts)
+    assert ctx.K == 3 and ctx.KK == 4
+    count = 8
+    rng = np.random.default_rng(54)
+    va = rng.integers(-128, 129, (count, n))
+    vb = rng.integers(-128, 129, (count, n))
+    a, b = _encrypt_slots(o, pk, va), _encrypt_slots(o, pk, vb)
+    da, db = to_device(a), to_device(b)
+    m = to_host(ev.multiply(da, db))
+    fused = to_host(ev.multiply_relin(da, db, rkd))
+    relin = to_host(ev.relinearize(to_device(m), rkd))
+    om = _pmap(lambda i: o.multiply(a[i], b[i]), range(count))
+    orl = _pmap(lambda i: o.relinearize(om[i], rk), range(count))
+    for i in range(count):
+        assert (m[i] == om[i]).all(), i
+        assert (relin[i] == orl[i]).all(), i
+        assert (fused[i] == orl[i]).all(), i
+        assert (_signed(t, o.batch_decode(o.decrypt(fused[i], sk))) == va[i] * vb[i]).all()
+    # key switching under the same primes: rotations (a3)
+    r1 = to_host(ev.rotate_rows(da, 1, gkd))
+    r3 = to_host(ev.rotate_rows(da, -3, gkd))
+    rc = to_host(ev.rotate_columns(da, gkd))
+    for i in range(2):
+        assert (r1[i] == o.rotate_rows(a[i], 1, gk)).all()
+        assert (r3[i] == o.rotate_rows(a[i], -3, gk)).all()
+        assert (rc[i] == o.rotate_columns(a[i], gk)).all()
+    # extreme operands (every residue q_i - 1 / 0): the integer-policy pipelines' lazy ranges
+    ext = np.zeros((2, 2, 3, n), dtype=np.uint64)
+    for k in range(3):
+        ext[0, :, k, :] = primes[k] - 1
+        ext[1, 0, k, ::2] = primes[k] - 1
+    got = to_host(ev.multiply_relin(to_device(ext), to_device(ext[::-1].copy()), rkd))
+    for i in range(2):
+        assert (got[i] == o.relinearize(o.multiply(ext[i], ext[1 - i]), rk)).all()
+
+
+def test_config4_chi_sq_at_n16384():
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.workloads import chi_sq_optimized
+
+    n = 16384
+    t = O.plain_batching(n, 17)
+    assert t == 65537
+    primes = O.bfv_default(n)
+    assert len(primes) == 9
+    o, sk, pk, rk, gk, ctx, ev, rkd, gkd = _setup(n, primes, t)
+    prog = chi_sq_optimized()
+    batch = 4
+    rng = np.random.default_rng(4)
+    vals = rng.integers(0, 7, (3, batch, n))
+    vals[:, 0, :] = np.array([2, 7, 9])[:, None]  # examples/chi_sq/src/main.rs:236-238
+    cts = [_encrypt_slots(o, pk, vals[a]) for a in range(3)]
+    outs = [to_host(x) for x in prog.run(ev, [to_device(c) for c in cts], rkd)]
+    refs = _pmap(lambda i: run_program(o, prog.nodes, prog.edges, [c[i] for c in cts], rk), range(batch))
+    for i in range(batch):
+        n0, n1, n2 = (vals[a, i].astype(np.int64) for a in range(3))
+        x, y = 2 * n0 + n1, 2 * n2 + n1
+        expect = [(4 * n0 * n2 - n1 * n1) ** 2, 2 * x * x, x * y, 2 * y * y]
+        for k in range(4):
+            assert (outs[k][i] == refs[i][k]).all(), (i, k)
+            assert (_signed(t, o.batch_decode(o.decrypt(outs[k][i], sk))) == expect[k]).all(), (i, k)
+    d0 = [int(_signed(t, o.batch_decode(o.decrypt(outs[k][0], sk)))[0]) for k in range(4)]
+    assert d0 == [529, 242, 275, 1250]
+
+
+def test_config5b_dot_product_at_n16384_with_its_rotation_key_set():
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.workloads import dot_product
+
+    n = 16384
+    t = O.plain_batching(n, 17)
+    primes = O.bfv_default(n)
+    lanes = n // 2
+    o = O.Oracle(n, primes, t)
+    elts = sorted({o.galois_elt_from_step(1 << i) for i in range(lanes.bit_length() - 1)} | {2 * n - 1})
+    assert len(elts) == 14  # 13 power-of-two row rotations + the column swap
+    o, sk, pk, rk, gk, ctx, ev, rkd, gkd = _setup(n, primes, t, galois=elts)
+    prog = dot_product(lanes)
+    batch = 2
+    rng = np.random.default_rng(5)
+    va = rng.integers(0, 2, (batch, n))
+    vb = rng.integers(0, 3, (batch, n))
+    ca, cb = _encrypt_slots(o, pk, va), _encrypt_slots(o, pk, vb)
+    (out,) = prog.run(ev, [to_device(ca), to_device(cb)], rkd, gkd)
+    out = to_host(out)
+    refs = _pmap(lambda i: run_program(o, prog.nodes, prog.edges, [ca[i], cb[i]], rk, gk)[0], range(batch))
+    for i in range(batch):
+        assert (out[i] == refs[i]).all(), i
+        dot = int((va[i] * vb[i]).sum()) % t
+        assert (o.batch_decode(o.decrypt(out[i], sk)) == dot).all()
+
+
+def test_config5a_pir_matrix_vector_product_and_lookup_at_n16384():
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.workloads import pir_lookup
+
+    n = 16384
+    t = O.plain_batching(n, 17)
+    primes = O.bfv_default(n)
+    o, sk, pk, rk, gk, ctx, ev, rkd, gkd = _setup(n, primes, t)
+    rows, cols = 4, 18  # 18 columns: crosses the lazy accumulation's 16-term reduction point
+    rng = np.random.default_rng(6)
+    db = rng.integers(1, t, (rows, cols, n), dtype=np.uint64)
+    db[0, 0, 1:] = 0
+    db[0, 0, 0] = t - 1  # monomial with an upper-half coefficient
+    db[1, 2, 9:] = 0     # short plaintext
+    colq = _encrypt_slots(o, pk, rng.integers(0, 5, (cols, n)))
+    got = to_host(ev.dot_plain_ntt(ev.ct_to_ntt(to_device(colq)), ev.plain_to_ntt(to_device(db))))
+
+    def row_ref(i):
+        acc = o.multiply_plain(colq[0], db[i, 0])
+        for j in range(1, cols):
+            acc = o.add(acc, o.multiply_plain(colq[j], db[i, j]))
+        return acc
+
+    refs = _pmap(row_ref, range(rows))
+    for i in range(rows):
+        assert (got[i] == refs[i]).all(), i
+
+    # the whole lookup with one-hot queries, scalar encoding as in the example (value in coefficient 0)
+    def scalar(v):
+        p = np.zeros(n, dtype=np.uint64)
+        p[0] = v % t
+        return p
+
+    vals = rng.integers(1, 1000, (rows, cols))
+    dbs = np.stack([np.stack([scalar(int(vals[i, j])) for j in range(cols)]) for i in range(rows)])
+    sel_r, sel_c = 2, 13
+    cq = np.stack([o.encrypt(pk, scalar(1 if j == sel_c else 0)) for j in range(cols)])
+    rq = np.stack([o.encrypt(pk, scalar(1 if i == sel_r else 0)) for i in range(rows)])
+    out = to_host(pir_lookup(ev, to_device(cq), to_device(rq), ev.plain_to_ntt(to_device(dbs)), rkd))
+    assert out.shape == (1, 2, o.K, n)
+    assert int(o.decrypt(out[0], sk)[0]) == int(vals[sel_r, sel_c])
+
+    def term(i):
+        col = o.multiply_plain(cq[0], dbs[i, 0])
+        for j in range(1, cols):
+            col = o.add(col, o.multiply_plain(cq[j], dbs[i, j]))
+        return o.relinearize(o.multiply(col, rq[i]), rk)
+
+    terms = _pmap(term, range(rows))
+    acc = terms[0]
+    for x in terms[1:]:
+        acc = o.add(acc, x)
+    assert (out[0] == acc).all()

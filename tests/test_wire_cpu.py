@@ -108,3 +108,47 @@ def test_malformed_objects_are_rejected():
     good = encode_ct(b"\x01" * 32, False, 2, 1024, 3, data, 0)
     assert L.hipbfv_wire_decode_ciphertext(good[:-8], len(good) - 8, None, None, None, None, None, None, 0, C.byref(used)) != 0
     assert L.hipbfv_wire_decode_ciphertext(good, len(good), None, None, None, None, None, None, 0, C.byref(used)) == 0
+
+
+def test_untrusted_bytes_cannot_drive_allocations_or_unwind_through_the_c_abi():
+    """a tiny zstd frame may declare gigabytes of content; a huge element count may sit in a header.  The
+    decoders cap what they allocate by what the caller can hold and every exported function is an exception barrier:
+    such inputs come back as an HRESULT, never as a C++ exception crossing extern "C" (which would abort the process)."""
+    import ctypes.util
+
+    L = _lib.load()
+    used = C.c_int64()
+    z = C.CDLL(ctypes.util.find_library("zstd") or "libzstd.so.1")
+    z.ZSTD_compressBound.restype = C.c_size_t
+    z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    raw = bytes(1 << 26)  # 64 MiB of zeros -> a frame of a few KB
+    dst = C.create_string_buffer(z.ZSTD_compressBound(len(raw)))
+    got = z.ZSTD_compress(dst, len(dst), raw, len(raw), 3)
+    frame = dst.raw[:got]
+    assert len(frame) < 1 << 16
+    bomb = bytes([0x5E, 0xA1, 16, 4, 0, 2, 0, 0]) + struct.pack("<Q", 16 + len(frame)) + frame
+    small = np.zeros(1024, dtype=np.uint64)
+    pid = C.create_string_buffer(32)
+    ntt, size, n, k = C.c_bool(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    # with a destination buffer the decoder refuses to inflate beyond what that buffer could hold
+    hr = L.hipbfv_wire_decode_ciphertext(bomb, len(bomb), pid, C.byref(ntt), C.byref(size), C.byref(n), C.byref(k),
+                                         small.ctypes.data_as(_lib.u64p), small.size, C.byref(used))
+    assert hr == 0x80131620 - (1 << 32) or hr == 0x80131620  # COR_E_IO
+    # an element count far beyond the bytes present
+    body = b"\x01" * 32 + b"\x00" + struct.pack("<QQQdQ", 2, 1 << 19, 60, 1.0, 1)
+    body += bytes([0x5E, 0xA1, 16, 4, 0, 0, 0, 0]) + struct.pack("<QQ", 24, 1 << 40)
+    obj = bytes([0x5E, 0xA1, 16, 4, 0, 0, 0, 0]) + struct.pack("<Q", 16 + len(body)) + body
+    assert L.hipbfv_wire_decode_ciphertext(obj, len(obj), None, None, None, None, None, None, 0, C.byref(used)) != 0
+    # JSON: nesting beyond the parser's depth limit, and a number that ends exactly at the end of an unterminated buffer
+    prog = C.c_void_p()
+    assert L.hipbfv_Program_Create(C.byref(prog)) == 0
+    deep = b"[" * 200000
+    assert L.hipbfv_Program_LoadJson(prog, deep, len(deep)) != 0
+    tail = b'{"graph": {"nodes": [], "edges": [], "x": 12345'
+    buf = (C.c_char * len(tail)).from_buffer_copy(tail)  # no NUL after the digits
+    assert L.hipbfv_Program_LoadJson(prog, C.cast(buf, C.c_char_p), len(tail)) != 0
+    assert L.hipbfv_Program_Destroy(prog) == 0
+    # hex polynomial with an absurd exponent: refused before anything is sized by it
+    out = C.c_void_p()
+    assert L.Plaintext_Create4(b"1x^99999999999", None, C.byref(out)) != 0

@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3 FETCH_SIZE / WRITE_SIZE summaries (tools/rocprof_summary.py --pmc output) plus the
-kernel-trace stats into profiles/pmc_traffic.json: measured HBM bytes per work unit for each kernel.
+"""Turn rocprofv3 PMC summaries (tools/rocprof_summary.py --pmc output) into an entry of profiles/pmc_traffic.json:
+measured HBM bytes per work unit and VALU issue occupancy of each kernel of ONE workload.
 
-FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B);
-WRITE_SIZE is used as reported (it matched the known byte count of the NTT kernels to 6 %).
-usage: tools/pmc_traffic.py <pmc_fetch.txt> <pmc_write.txt> <units.json> [<pmc_inst.txt>] > profiles/pmc_traffic.json
-units.json maps kernel short name -> average work units per dispatch (from a bench line's profiler output).
+usage: tools/pmc_traffic.py <workload-key> <pmc_fetch.txt> <pmc_write.txt> <units.json> [<pmc_inst.txt>] [--into profiles/pmc_traffic.json]
 
-With the SQ_INSTS_VALU pass (pmc_inst.txt) and the GRBM_GUI_ACTIVE column of the fetch pass, each kernel also gets its
-VALU issue occupancy: wave-instructions x 4 cycles (a wave64 instruction occupies its SIMD's 16 lanes for 4 cycles; the
-FP64 fma/mul/add/rndne the kernels are made of issue at that full rate) / (1024 SIMDs x shader cycles of the dispatch).
-GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (GUI_ACTIVE / 8 / wall time = the 1.9-2.0 GHz the part sustains under
-this load, MI355X_MICROARCH.md "DVFS give-back").
+  workload-key   bench.py's pmc_workload_key(): e.g. mulrelin_n8192, mulrelin_n16384, ntt_n8192, mulrelin_n8192_bits54-54-54-56
+  units.json     kernel short name -> average work units per dispatch (from the bench line's profiler output)
+
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B); WRITE_SIZE is used
+as reported (it matched the known byte count of the NTT kernels to 6 %).
+
+VALU issue occupancy = issue cycles / (1024 SIMDs x shader cycles of the dispatch).  Shader cycles = GRBM_GUI_ACTIVE / 8
+(reported summed over the 8 XCDs; GUI_ACTIVE / 8 / wall time = the 1.9-2.0 GHz the part sustains under this load).  Issue
+cycles per wave64 instruction by class (MI355X_MICROARCH.md "Wave scheduling": a SIMD-32 issues a 32-bit VALU instruction
+over 2 cycles; FP64 runs at half that rate): 4 for FP64, 2 for everything else.  FP64 instructions = SQ_INSTS_VALU_{ADD,MUL,
+FMA,TRANS}_F64 when the instruction-class pass collected them; v_rndne_f64 / v_cvt are in none of those classes, so
+`valu_issue_frac` (the unclassified remainder priced at 2 cycles) is a lower bound and `valu_issue_frac_upper` prices the
+remainder at 4.  Without class counters (older passes) every instruction is priced at 4 and the entry says so.
+--into merges the entry into an existing multi-workload file (and refreshes the top-level "kernels" alias of the headline
+workload mulrelin_n8192) and writes it back; otherwise the single entry is printed.
 """
 import json
 import re
 import sys
+
+SOURCE = ("rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE / WRITE_SIZE / SQ_INSTS_VALU* (separate passes, tools/gpu_pmc_report.sh); "
+          "FETCH_SIZE x2 on gfx950")
+F64 = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")
+OTHER = ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT")
 
 
 def parse(path, counter):
@@ -25,6 +37,9 @@ def parse(path, counter):
         if m:
             cur = m.group(1)
             continue
+        if not line.startswith(" "):
+            cur = None
+            continue
         m = re.match(r"^\s+(\S+)\s+([0-9.]+)", line)
         if m and cur and m.group(1) == counter:
             # template variants of one kernel (e.g. mul_mid<..,true/false>) are one profiler record in bench.py: sum them
@@ -33,12 +48,12 @@ def parse(path, counter):
     return out
 
 
-def main():
-    fetch = parse(sys.argv[1], "FETCH_SIZE")
-    write = parse(sys.argv[2], "WRITE_SIZE")
-    units = json.load(open(sys.argv[3]))
-    valu = parse(sys.argv[4], "SQ_INSTS_VALU") if len(sys.argv) > 4 else {}
-    gui = parse(sys.argv[1], "GRBM_GUI_ACTIVE")
+def entry(fetch_p, write_p, units, inst_p):
+    fetch = parse(fetch_p, "FETCH_SIZE")
+    write = parse(write_p, "WRITE_SIZE")
+    gui = parse(fetch_p, "GRBM_GUI_ACTIVE")
+    valu = parse(inst_p, "SQ_INSTS_VALU") if inst_p else {}
+    classes = {c: parse(inst_p, c) for c in F64 + OTHER} if inst_p else {}
     res = {}
     for k in fetch:
         if k not in units or k not in write:
@@ -55,8 +70,46 @@ def main():
             cycles = gui[k] / 8.0
             res[k]["valu_wave_insts_per_dispatch"] = valu[k]
             res[k]["shader_cycles_per_dispatch"] = cycles
-            res[k]["valu_issue_frac"] = round(valu[k] * 4.0 / (1024.0 * cycles), 4)
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 on gfx950; SQ_INSTS_VALU and GRBM_GUI_ACTIVE for the VALU issue occupancy", "kernels": res}, sys.stdout, indent=1)
+            have_classes = any(k in classes[c] for c in F64)
+            if have_classes:
+                f64 = sum(classes[c].get(k, 0.0) for c in F64)
+                other = sum(classes[c].get(k, 0.0) for c in OTHER)
+                rest = max(0.0, valu[k] - f64 - other)  # v_rndne_f64, moves, bit ops, compares ...
+                res[k]["valu_f64_wave_insts_per_dispatch"] = f64
+                res[k]["valu_int_cvt_wave_insts_per_dispatch"] = other
+                res[k]["valu_unclassified_wave_insts_per_dispatch"] = rest
+                res[k]["valu_issue_frac"] = round((4.0 * f64 + 2.0 * (other + rest)) / (1024.0 * cycles), 4)
+                res[k]["valu_issue_frac_upper"] = round((4.0 * (f64 + rest) + 2.0 * other) / (1024.0 * cycles), 4)
+                res[k]["valu_pricing"] = "4 cycles per FP64 wave64 instruction, 2 per other"
+            else:
+                res[k]["valu_issue_frac"] = round(valu[k] * 4.0 / (1024.0 * cycles), 4)
+                res[k]["valu_pricing"] = "4 cycles per wave64 instruction (no class counters in this pass: upper bound)"
+    return {"kernels": res}
+
+
+def main():
+    argv = sys.argv[1:]
+    into = None
+    if "--into" in argv:
+        i = argv.index("--into")
+        into = argv[i + 1]
+        del argv[i : i + 2]
+    key, fetch_p, write_p, units_p = argv[:4]
+    inst_p = argv[4] if len(argv) > 4 else None
+    e = entry(fetch_p, write_p, json.load(open(units_p)), inst_p)
+    if not into:
+        json.dump(e, sys.stdout, indent=1)
+        return
+    try:
+        doc = json.load(open(into))
+    except Exception:
+        doc = {}
+    doc.setdefault("workloads", {})
+    doc["source"] = SOURCE
+    doc["workloads"][key] = e
+    if "mulrelin_n8192" in doc["workloads"]:
+        doc["kernels"] = doc["workloads"]["mulrelin_n8192"]["kernels"]  # alias: the headline workload
+    json.dump(doc, open(into, "w"), indent=1)
 
 
 if __name__ == "__main__":
