@@ -344,10 +344,18 @@ long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
  * LoadJson accepts the serde JSON form of `FheProgram` (petgraph StableGraph).
  * Run executes the graph over `batch` independent input sets: input i is a device pointer to
  * u64[batch][2][K][N] (kind 0) or to plaintexts u64[batch][N] / one shared u64[N] (kind 1, stride N / 0);
- * one output buffer u64[batch][2][K][N] per OutputCiphertext node, in node order. Asynchronous on `stream`.
- * The batched entry points (hipbfv_batch_*, Program_Run) do not scan results for transparent ciphertexts (that needs a
- * device-to-host round trip per operation); the handle-level Evaluator_* functions do, as SEAL built with
- * SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT does. */
+ * one output buffer u64[batch][2][K][N] per OutputCiphertext node, in node order.
+ *
+ * Transparent results (SEAL built with SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT, seal_fhe/build.rs:46-66: `runtime.run` fails
+ * on `a * 0`, sunscreen/tests/features.rs:8-34).  The handle-level Evaluator_* functions check their one result before
+ * they return.  The batched paths check on the device: every operation records, in a status word, the smallest batch
+ * index whose result is transparent.  Program_Run owns such a word per run, reads it once at exit (one stream
+ * synchronisation per run) and returns COR_E_INVALIDOPERATION -- hipbfv_last_error names the input set.  The
+ * hipbfv_batch_* operations stay asynchronous on `stream` and record into their evaluator's word; hipbfv_batch_status
+ * synchronises `stream`, reads and resets it: COR_E_INVALIDOPERATION + the first transparent item (of any operation since
+ * the previous call), S_OK + ~0 otherwise.  hipbfv_set_batch_transparent_check(evaluator, false) switches the recording
+ * off for one evaluator; hipbfv_set_throw_on_transparent(false) for the whole library (the crate's
+ * `transparent-ciphertexts` feature). */
 long hipbfv_Program_Create(void **program);
 long hipbfv_Program_Destroy(void *program);
 long hipbfv_Program_AddNode(void *program, uint32_t op, uint64_t arg, uint32_t *node_id);
@@ -358,6 +366,8 @@ long hipbfv_Program_AddNode(void *program, uint32_t op, uint64_t arg, uint32_t *
 long hipbfv_Program_AddPlaintextLiteral(void *program, const uint8_t *bytes, uint64_t length, uint32_t *node_id);
 long hipbfv_Program_AddEdge(void *program, uint32_t src, uint32_t dst, uint32_t kind);
 long hipbfv_Program_LoadJson(void *program, const char *json, uint64_t length);
+long hipbfv_batch_status(void *evaluator, uint64_t *first_transparent_item, void *stream);
+long hipbfv_set_batch_transparent_check(void *evaluator, bool enabled);
 long hipbfv_Program_NumOutputs(void *program, uint64_t *count);
 long hipbfv_Program_Run(void *program, void *evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t *input_kinds,
                         const uint64_t *const *input_ptrs, const uint64_t *input_strides, void *relin_keys,

@@ -187,8 +187,14 @@ class Oracle:
         assert a.ndim == 3 and a.shape[1] == self.K and a.shape[2] == self.n, a.shape
         return a
 
-    @staticmethod
-    def _chk(rc: int):
+    # SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (seal_fhe/build.rs:46-66).  The C functions finish their result before they
+    # report it transparent, so tests that push degenerate operands through the arithmetic (all-zero polynomials at the
+    # edges of the BEHZ bounds) may switch the exception off and still read the bits.
+    throw_on_transparent = True
+
+    def _chk(self, rc: int):
+        if rc == -2 and not self.throw_on_transparent:
+            return
         if rc != 0:
             raise RuntimeError({-1: "invalid argument", -2: "transparent ciphertext", -3: "missing key"}.get(rc, str(rc)))
 

@@ -24,6 +24,19 @@ static uint64_t *poly_alloc(size_t words)
 
 /* ------------------------------------------------------------------ add / sub / negate */
 
+/* SEAL is built by seal_fhe with SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (seal_fhe/build.rs:46-66): every Evaluator operation
+ * ends with `if (result.is_transparent()) throw logic_error("result ciphertext is transparent")` [RECALLED: SEAL 4.0
+ * evaluator.cpp -- negate, add, sub, multiply, square, relinearize_internal, mod_switch_*_to_next, add_plain, sub_plain,
+ * multiply_plain, apply_galois]; Ciphertext::is_transparent = all polynomials from index 1 on are zero.  Pinned by
+ * sunscreen/tests/features.rs:8-34 (`a * 0` fails without the transparent-ciphertexts feature). */
+static int is_transparent(const ora_ctx *c, const uint64_t *ct, size_t s)
+{
+    const size_t K = c->K, n = c->n;
+    for (size_t k = K * n; k < s * K * n; k++)
+        if (ct[k]) return 0;
+    return 1;
+}
+
 static int addsub(const ora_ctx *c, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb, uint64_t *out, int sub)
 {
     if (sa < 2 || sb < 2) return ORA_E_INVALIDARG;
@@ -50,12 +63,16 @@ static int addsub(const ora_ctx *c, const uint64_t *a, size_t sa, const uint64_t
 
 int ora_add(const ora_ctx *c, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb, uint64_t *out)
 {
-    return addsub(c, a, sa, b, sb, out, 0);
+    int rc = addsub(c, a, sa, b, sb, out, 0);
+    if (!rc && is_transparent(c, out, sa > sb ? sa : sb)) return ORA_E_TRANSPARENT;
+    return rc;
 }
 
 int ora_sub(const ora_ctx *c, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb, uint64_t *out)
 {
-    return addsub(c, a, sa, b, sb, out, 1);
+    int rc = addsub(c, a, sa, b, sb, out, 1);
+    if (!rc && is_transparent(c, out, sa > sb ? sa : sb)) return ORA_E_TRANSPARENT;
+    return rc;
 }
 
 int ora_negate(const ora_ctx *c, const uint64_t *a, size_t sa, uint64_t *out)
@@ -65,7 +82,7 @@ int ora_negate(const ora_ctx *c, const uint64_t *a, size_t sa, uint64_t *out)
     for (size_t p = 0; p < sa; p++)
         for (size_t i = 0; i < K; i++)
             for (size_t k = 0; k < n; k++) out[(p * K + i) * n + k] = ora_negmod(a[(p * K + i) * n + k], &c->key_mod[i]);
-    return 0;
+    return is_transparent(c, out, sa) ? ORA_E_TRANSPARENT : 0;
 }
 
 /* ------------------------------------------------------------------ BEHZ pieces (SEAL util/rns.cpp) */
@@ -187,7 +204,7 @@ int ora_multiply(const ora_ctx *c, const uint64_t *a, size_t sa, const uint64_t 
     free(ea);
     free(eb);
     free(ed);
-    return 0;
+    return is_transparent(c, out, sd) ? ORA_E_TRANSPARENT : 0;
 }
 
 /* ------------------------------------------------------------------ key switching */
@@ -256,6 +273,7 @@ int ora_relinearize(const ora_ctx *c, const uint64_t *ct3, const uint64_t *rk, u
     memmove(out2, ct3, 2 * K * n * sizeof(uint64_t));
     int rc = ora_switch_key(c, out2, target, rk);
     free(target);
+    if (!rc && is_transparent(c, out2, 2)) return ORA_E_TRANSPARENT;
     return rc;
 }
 
@@ -310,6 +328,7 @@ int ora_apply_galois(const ora_ctx *c, const uint64_t *ct2, uint32_t elt, const 
     memcpy(out2, res, 2 * K * n * sizeof(uint64_t));
     free(res);
     free(target);
+    if (!rc && is_transparent(c, out2, 2)) return ORA_E_TRANSPARENT;
     return rc;
 }
 
@@ -379,21 +398,18 @@ static int plain_addsub(const ora_ctx *c, const uint64_t *ct, size_t s, const ui
 
 int ora_add_plain(const ora_ctx *c, const uint64_t *ct, size_t s, const uint64_t *plain, size_t pc, uint64_t *out)
 {
-    return plain_addsub(c, ct, s, plain, pc, out, 0);
+    int rc = plain_addsub(c, ct, s, plain, pc, out, 0);
+    if (!rc && is_transparent(c, out, s)) return ORA_E_TRANSPARENT;
+    return rc;
 }
 
 int ora_sub_plain(const ora_ctx *c, const uint64_t *ct, size_t s, const uint64_t *plain, size_t pc, uint64_t *out)
 {
-    return plain_addsub(c, ct, s, plain, pc, out, 1);
+    int rc = plain_addsub(c, ct, s, plain, pc, out, 1);
+    if (!rc && is_transparent(c, out, s)) return ORA_E_TRANSPARENT;
+    return rc;
 }
 
-static int is_transparent(const ora_ctx *c, const uint64_t *ct, size_t s)
-{
-    const size_t K = c->K, n = c->n;
-    for (size_t k = K * n; k < s * K * n; k++)
-        if (ct[k]) return 0;
-    return 1;
-}
 
 /* Lift one plaintext coefficient (mod t) to q_i: values >= (t+1)/2 represent negatives, i.e. c - t.
  * With SEAL's fast plain lift (t < every q_i) this is c + (q_i - t); otherwise SEAL adds the
@@ -529,5 +545,7 @@ int ora_mod_switch_to_next(const ora_ctx *c, const uint64_t *ct, size_t s, uint6
             }
         }
     }
-    return 0;
+    for (size_t k = (K - 1) * n; k < s * (K - 1) * n; k++)
+        if (out[k]) return 0;
+    return ORA_E_TRANSPARENT; /* is_transparent() at the next level's K - 1 residues */
 }

@@ -42,6 +42,17 @@ class BatchEvaluator:
         self._h = self._ev.get_handle()
         self.n, self.K, self.KK = ctx.poly_modulus_degree, ctx.K, ctx.KK
 
+    def check(self) -> None:
+        """Raise HipBfvError (COR_E_INVALIDOPERATION, as the reference's runtime does: sunscreen/tests/features.rs:8-34) if
+        any batched operation since the last call produced a transparent ciphertext; synchronises the current stream.
+        The operations themselves stay asynchronous: call this where the reference would have seen the error -- at the
+        latest before results leave the device."""
+        first = C.c_uint64()
+        _check(_lib.load().hipbfv_batch_status(self._h, C.byref(first), _stream()))
+
+    def set_transparent_check(self, enabled: bool) -> None:
+        _check(_lib.load().hipbfv_set_batch_transparent_check(self._h, enabled))
+
     def set_chunk_ops(self, chunk: int) -> None:
         _check(_lib.load().hipbfv_set_chunk_ops(self._h, chunk))
 

@@ -226,6 +226,7 @@ struct EvalObj : Obj {
   // its context; here every level has its own tables): created on first use
   std::mutex mu;
   std::map<Context*, std::unique_ptr<EvalObj>> lower;
+  bool batch_watch = true;  // hipbfv_batch_*: record transparent results in the evaluator's status word
   EvalObj() : Obj(kMagicEval) {}
 };
 
@@ -1352,9 +1353,12 @@ long Evaluator_RotateColumns(void* h, void* a, void* keys, void* dst, void* pool
 HIPBFV_END
 
 // ------------------------------------------------------------------ batched device-pointer API
+// every hipbfv_batch_* call watches its results for transparent ciphertexts (asynchronously, in the evaluator's status
+// word): hipbfv_batch_status reads and resets it
 #define EVAL_OR_RETURN(h)                      \
   EvalObj* e = as<EvalObj>(h, kMagicEval);     \
-  if (!e) return HIPBFV_E_POINTER;
+  if (!e) return HIPBFV_E_POINTER;             \
+  WatchScope watch_scope_(e->batch_watch && g_throw_transparent ? e->ev->batch_status() : nullptr);
 
 static const u64* key_or_null(void* keys, EvalObj* e, u32 index) {
   KeysObj* k = as<KeysObj>(keys, kMagicKeys);
@@ -1793,12 +1797,57 @@ long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_i
     if (k->ctx.get() == e->ctx.get())
       for (auto& kv : k->keys) gk[kv.first] = kv.second;
   std::string err;
-  int st = p->prog.run(*e->ev, batch, ins.data(), ins.size(), rk, gk, (u64* const*)outputs, num_outputs, (hipStream_t)stream, &err);
+  // the reference's runtime.run fails when any node's result is transparent (SEAL built with throw-on-transparent,
+  // seal_fhe/build.rs:46-66; sunscreen/tests/features.rs:8-34; error collapse run.rs:78-82): every node's results are
+  // watched in a status word owned by this run and read once at exit
+  hipStream_t s = (hipStream_t)stream;
+  u32* status = g_throw_transparent ? (u32*)e->ev->scratch().acquire(256, s) : nullptr;
+  if (g_throw_transparent && (!status || hipMemsetAsync(status, 0xFF, sizeof(u32), s) != hipSuccess)) {
+    if (status) e->ev->scratch().release(status, s);
+    return from_status(kOutOfMemory);
+  }
+  int st;
+  {
+    WatchScope watch(status);
+    st = p->prog.run(*e->ev, batch, ins.data(), ins.size(), rk, gk, (u64* const*)outputs, num_outputs, s, &err);
+  }
+  u32 first_bad = 0xFFFFFFFFu;
+  if (status) {
+    const int st2 = e->ev->take_status(status, &first_bad, s);
+    e->ev->scratch().release(status, s);
+    if (st == kOk) st = st2;
+  }
   if (st != kOk) {
     long hr = from_status(st);
     if (!err.empty()) tls_error = err;
     return hr;
   }
+  if (first_bad != 0xFFFFFFFFu) {
+    char msg[128];
+    snprintf(msg, sizeof(msg), "result ciphertext is transparent (input set %u of the batch)", first_bad);
+    return fail(HIPBFV_COR_E_INVALIDOPERATION, msg);
+  }
+  return HIPBFV_S_OK;
+HIPBFV_END
+
+long hipbfv_batch_status(void* h, uint64_t* first_transparent_item, void* stream) HIPBFV_BEGIN
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  if (!e) return HIPBFV_E_POINTER;
+  u32 first_bad = 0xFFFFFFFFu;
+  if (int st = e->ev->take_status(e->ev->batch_status(), &first_bad, (hipStream_t)stream)) return from_status(st);
+  if (first_transparent_item) *first_transparent_item = first_bad == 0xFFFFFFFFu ? ~0ull : first_bad;
+  if (first_bad != 0xFFFFFFFFu) {
+    char msg[128];
+    snprintf(msg, sizeof(msg), "result ciphertext is transparent (batch item %u)", first_bad);
+    return fail(HIPBFV_COR_E_INVALIDOPERATION, msg);
+  }
+  return HIPBFV_S_OK;
+HIPBFV_END
+
+long hipbfv_set_batch_transparent_check(void* h, bool enabled) HIPBFV_BEGIN
+  EvalObj* e = as<EvalObj>(h, kMagicEval);
+  if (!e) return HIPBFV_E_POINTER;
+  e->batch_watch = enabled;
   return HIPBFV_S_OK;
 HIPBFV_END
 
@@ -2169,8 +2218,8 @@ struct Big {
     return 0;
   }
 };
-u64 mulmod64(u64 a, u64 b, u64 q) { return (u64)((unsigned __int128)a * b % q); }
-u64 invmod64(u64 a, u64 q) {  // q prime
+static u64 mulmod64(u64 a, u64 b, u64 q) { return (u64)((unsigned __int128)a * b % q); }
+static u64 invmod64(u64 a, u64 q) {  // q prime
   u64 r = 1, e = q - 2;
   a %= q;
   while (e) {
@@ -2450,8 +2499,9 @@ long hipbfv_Context_NextLevel(void* context, void** next) HIPBFV_BEGIN
 HIPBFV_END
 
 long hipbfv_batch_mod_switch(void* evaluator, const uint64_t* ct, uint64_t size, uint64_t* out, uint64_t count, void* stream) HIPBFV_BEGIN
-  Evaluator* ev = eval_of(evaluator);
-  if (!ev || !ct || !out) return HIPBFV_E_POINTER;
+  EVAL_OR_RETURN(evaluator);
+  Evaluator* ev = e->ev.get();
+  if (!ct || !out) return HIPBFV_E_POINTER;
   if (size < 1) return fail(HIPBFV_E_INVALIDARG, "invalid ciphertext size");
   return from_status(ev->mod_switch_next((const u64*)ct, (u32)size, (u64*)out, count, (hipStream_t)stream));
 HIPBFV_END

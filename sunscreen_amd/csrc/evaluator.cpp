@@ -175,6 +175,42 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 1024));
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS")) split_ks_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_MUL")) split_mul_ = env[0] != '1';
+  if (hipMalloc((void**)&status_dev_, 256) == hipSuccess)
+    (void)hipMemset(status_dev_, 0xFF, 256);
+  else {
+    status_dev_ = nullptr;
+    (void)hipGetLastError();
+  }
+}
+
+namespace {
+thread_local u32* tls_watch = nullptr;
+}
+WatchScope::WatchScope(u32* status_dev) : prev(tls_watch) { tls_watch = status_dev; }
+WatchScope::~WatchScope() { tls_watch = prev; }
+
+Evaluator::~Evaluator() {
+  if (status_dev_) (void)hipFree(status_dev_);
+}
+
+int Evaluator::note_result(const u64* ct, u32 size, u32 residues, size_t count, hipStream_t s) {
+  u32* status = tls_watch;
+  if (!status || size < 2 || !count) return kOk;
+  const size_t poly = (size_t)residues * ctx_->n();
+  for (size_t off = 0; off < count; off += (size_t)1 << 30) {
+    const size_t c = std::min<size_t>((size_t)1 << 30, count - off);
+    HB_CHECK(launch_transparent_watch(ct + off * size * poly, size * poly, poly, (u32)off, status, c, s));
+  }
+  return kOk;
+}
+
+int Evaluator::take_status(u32* status_dev, u32* first_bad, hipStream_t s) {
+  if (!status_dev) return kOutOfMemory;
+  *first_bad = 0xFFFFFFFFu;
+  HB_CHECK(hipMemcpyAsync(first_bad, status_dev, sizeof(u32), hipMemcpyDeviceToHost, s));
+  HB_CHECK(hipMemsetAsync(status_dev, 0xFF, sizeof(u32), s));
+  HB_CHECK(hipStreamSynchronize(s));
+  return kOk;
 }
 
 u32 Evaluator::galois_elt_from_step(int step) const {
@@ -203,7 +239,7 @@ int Evaluator::ntt(u64* data, size_t polys, u32 nprimes, bool inverse, hipStream
   return kOk;
 }
 
-int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, size_t count, hipStream_t s) {
+int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, size_t count, hipStream_t s, bool watch) {
   const DevCtx& h = ctx_->host();
   if (sa < 2 || sb < 2 || sa + sb > 16) return kInvalidArg;
   if (h.logn > 15) return kUnsupported;
@@ -236,7 +272,7 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
     HB_LAUNCH(kKernNttInv, c * sd * R, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, D, c * sd * R, plan, true, 1, s));
     HB_LAUNCH(kKernBehzFloorSk, c * sd, launch_behz_floor_sk(ctx_->dev(), n, kneed, D, out + off * sd * K * n, c * sd, s));
   }
-  return kOk;
+  return watch ? note_result(out, sd, K, count, s) : (int)kOk;
 }
 
 size_t Evaluator::ks_scratch_words() const {
@@ -271,7 +307,7 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
 }
 
 // addend (optional): ciphertexts u64[count][2][K][N] added to the results inside the last kernel (a fused Add node)
-int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend) {
+int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend, bool watch) {
   const DevCtx& h = ctx_->host();
   if (h.KK < 2 || !rk) return kNoKey;
   if (h.logn > 15) return kUnsupported;
@@ -286,7 +322,7 @@ int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t coun
     int rc = key_switch(ct + (size_t)2 * K * n, cs, rk, ct, cs, 3u, out2 + off * 2 * K * n, c, (u64*)sg.p, s, addend ? addend + off * 2 * K * n : nullptr);
     if (rc) return rc;
   }
-  return kOk;
+  return watch ? note_result(out2, 2, K, count, s) : (int)kOk;
 }
 
 int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend) {
@@ -298,12 +334,12 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
   if (!sg.p) return kOutOfMemory;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
-    int rc = multiply(a + off * c2, 2, b + off * c2, 2, (u64*)sg.p, c, s);
+    int rc = multiply(a + off * c2, 2, b + off * c2, 2, (u64*)sg.p, c, s, false);
     if (rc) return rc;
-    rc = relinearize((const u64*)sg.p, rk, out2 + off * c2, c, s, addend ? addend + off * c2 : nullptr);
+    rc = relinearize((const u64*)sg.p, rk, out2 + off * c2, c, s, addend ? addend + off * c2 : nullptr, false);
     if (rc) return rc;
   }
-  return kOk;
+  return note_result(out2, 2, h.K, count, s);
 }
 
 int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, size_t count, hipStream_t s, const u64* addend) {
@@ -329,7 +365,7 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, 
     int rc = key_switch(rot + (size_t)K * n, rot_words, key, rot, rot_words, 1u, out2 + off * rot_words, c, ks, s, addend ? addend + off * rot_words : nullptr);
     if (rc) return rc;
   }
-  return kOk;
+  return note_result(out2, 2, K, count, s);
 }
 
 static int eltwise_chunks(Profiler& prof_, const DevCtx* dev, u32 n, u32 K, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode,
@@ -352,22 +388,25 @@ int Evaluator::mod_switch_next(const u64* ct, u32 size, u64* out, size_t count, 
     const size_t c = std::min<size_t>(65535, polys - off);
     HB_CHECK(launch_mod_switch(ctx_->dev(), h.n, ct + off * (size_t)h.K * h.n, out + off * (size_t)(h.K - 1) * h.n, c, s));
   }
-  return kOk;
+  return note_result(out, size, h.K - 1, count, s);
 }
 
 int Evaluator::add(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s) {
   if (size < 2) return kInvalidArg;
-  return eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 0, s);
+  if (int rc = eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 0, s)) return rc;
+  return note_result(out, size, ctx_->K(), count, s);
 }
 
 int Evaluator::sub(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s) {
   if (size < 2) return kInvalidArg;
-  return eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 1, s);
+  if (int rc = eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, b, out, count * size * ctx_->K(), 1, s)) return rc;
+  return note_result(out, size, ctx_->K(), count, s);
 }
 
 int Evaluator::negate(const u64* a, u64* out, u32 size, size_t count, hipStream_t s) {
   if (size < 1) return kInvalidArg;
-  return eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, nullptr, out, count * size * ctx_->K(), 2, s);
+  if (int rc = eltwise_chunks(prof_, ctx_->dev(), ctx_->n(), ctx_->K(), a, nullptr, out, count * size * ctx_->K(), 2, s)) return rc;
+  return note_result(out, size, ctx_->K(), count, s);
 }
 
 static int plain_addsub(Context* ctx, const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, int sub, hipStream_t s) {
@@ -382,11 +421,13 @@ static int plain_addsub(Context* ctx, const u64* ct, u32 size, const u64* plain,
 }
 
 int Evaluator::add_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s) {
-  return plain_addsub(ctx_, ct, size, plain, pstride, out, count, 0, s);
+  if (int rc = plain_addsub(ctx_, ct, size, plain, pstride, out, count, 0, s)) return rc;
+  return note_result(out, size, ctx_->K(), count, s);
 }
 
 int Evaluator::sub_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s) {
-  return plain_addsub(ctx_, ct, size, plain, pstride, out, count, 1, s);
+  if (int rc = plain_addsub(ctx_, ct, size, plain, pstride, out, count, 1, s)) return rc;
+  return note_result(out, size, ctx_->K(), count, s);
 }
 
 int Evaluator::multiply_plain(const u64* ct, u32 size, const u64* plain, size_t pstride, u64* out, size_t count, hipStream_t s) {
@@ -420,7 +461,7 @@ int Evaluator::multiply_plain(const u64* ct, u32 size, const u64* plain, size_t 
     HB_CHECK(launch_dyadic_plain(ctx_->dev(), n, K, x, size, pl, shared ? 0 : (size_t)K * n, c, s));
     HB_LAUNCH(kKernNttInv, c * size * K, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, x, c * size * K, plan, true, 0, s));
   }
-  return kOk;
+  return note_result(out, size, K, count, s);
 }
 
 int Evaluator::multiply_plain_mono(const u64* ct, u32 size, u64 coeff, u32 exponent, u64* out, size_t count, hipStream_t s) {
@@ -457,7 +498,7 @@ int Evaluator::multiply_plain_mono(const u64* ct, u32 size, u64 coeff, u32 expon
     const size_t cnt = std::min(step, total - off);
     HB_CHECK(launch_mono_mul(ctx_->dev(), n, src + off * n, out + off * n, cnt, d_rns, exponent, s));
   }
-  return kOk;
+  return note_result(out, size, K, count, s);
 }
 
 int Evaluator::nonzero_tail(const u64* ct, u32 size, u32* flags, size_t count, hipStream_t s) {

@@ -108,17 +108,34 @@ struct ScratchGuard {
   ScratchGuard& operator=(const ScratchGuard&) = delete;
 };
 
+// Transparent-result watch of the batched path.  While a WatchScope is alive on the calling thread, every Evaluator
+// operation that produces ciphertexts records, in the device word it was given, the smallest batch index whose result is
+// transparent (all polynomials but the first are zero; 0xFFFFFFFF = none): the reference's SEAL build throws on such a
+// result (seal_fhe/build.rs:46-66, sunscreen/tests/features.rs:8-34).  The handle-level C entry points do their own
+// per-call check and never open a scope.
+struct WatchScope {
+  explicit WatchScope(u32* status_dev);
+  ~WatchScope();
+  u32* prev;
+};
+
 class Evaluator {
  public:
   explicit Evaluator(Context* ctx);
+  ~Evaluator();
+  // the evaluator's own status word for hipbfv_batch_* callers (nullptr if the allocation failed); read-and-reset:
+  // *first_bad = smallest transparent item since the last call, 0xFFFFFFFF if none.  Synchronises `s`.
+  u32* batch_status() const { return status_dev_; }
+  int take_status(u32* status_dev, u32* first_bad, hipStream_t s);
+  int note_result(const u64* ct, u32 size, u32 residues, size_t count, hipStream_t s);
   Profiler& profiler() { return prof_; }
   ScratchPool& scratch() { return pool_; }
   Context* ctx() const { return ctx_; }
 
   // ---- SURVEY 8a rows a1-a5, batched ----
-  int multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, size_t count, hipStream_t s);
+  int multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, size_t count, hipStream_t s, bool watch = true);
   // addend (optional, the three key-switching operations): ciphertexts u64[count][2][K][N] added to the results inside the last kernel
-  int relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
+  int relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr, bool watch = true);
   int multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
   // out2 = (sigma_g(c0), 0) + switch_key(sigma_g(c1), key)
   int apply_galois(const u64* ct2, u32 galois_elt, const u64* key, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
@@ -167,6 +184,7 @@ class Evaluator {
                  size_t count, u64* scratch, hipStream_t s, const u64* extra = nullptr);
   size_t ks_scratch_words() const;
   Context* ctx_;
+  u32* status_dev_ = nullptr;
   ScratchPool pool_;
   Profiler prof_;
   size_t chunk_ops_;

@@ -911,6 +911,23 @@ __global__ __launch_bounds__(kCoefThreads) void nonzero_tail_kernel(const u64* _
   if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&flags[op], 1u);
 }
 
+// Transparent-result watch of the batched path (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT, seal_fhe/build.rs:46-66): one
+// workgroup per ciphertext; *status = min(*status, first_item + op) for every op whose polynomials 1.. are all zero.
+// A genuine ciphertext has a non-zero word among the first kCoefThreads of c1, so the common case reads 2 KB per item
+// and leaves after one round; only an (almost) all-zero tail is scanned in full.
+__global__ __launch_bounds__(kCoefThreads) void transparent_watch_kernel(const u64* __restrict__ ct, size_t words_per_ct, size_t skip_words,
+                                                                         u32 first_item, u32* __restrict__ status) {
+  const u32 op = blockIdx.x;
+  const u64* p = ct + (size_t)op * words_per_ct + skip_words;
+  const size_t len = words_per_ct - skip_words;
+  for (size_t base = 0; base < len; base += kCoefThreads) {
+    const size_t i = base + threadIdx.x;
+    const bool nz = i < len && p[i] != 0;
+    if (__syncthreads_or(nz)) return;
+  }
+  if (threadIdx.x == 0) atomicMin(status, first_item + op);
+}
+
 // =====================================================================================
 // host launchers
 // =====================================================================================
@@ -1008,6 +1025,11 @@ hipError_t launch_mono_mul(const DevCtx* ctx, u32 n, const u64* in, u64* out, si
 
 hipError_t launch_nonzero_tail(const u64* ct, size_t words_per_ct, size_t skip_words, u32* flags, size_t ops, hipStream_t s) {
   nonzero_tail_kernel<<<dim3(64, (u32)ops), kCoefThreads, 0, s>>>(ct, words_per_ct, skip_words, flags);
+  return hipGetLastError();
+}
+
+hipError_t launch_transparent_watch(const u64* ct, size_t words_per_ct, size_t skip_words, u32 first_item, u32* status, size_t ops, hipStream_t s) {
+  transparent_watch_kernel<<<dim3((u32)ops), kCoefThreads, 0, s>>>(ct, words_per_ct, skip_words, first_item, status);
   return hipGetLastError();
 }
 

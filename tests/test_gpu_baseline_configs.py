@@ -54,7 +54,7 @@ def _setup(n, primes, t, galois=None, seed=21):
 
 def _encrypt_slots(o, pk, vals):
     # encryption draws from the oracle's one seeded generator: keep it sequential so the inputs are reproducible
-    return np.stack([o.encrypt(pk, o.batch_encode(v.astype(np.uint64) % o.t)) for v in vals])
+    return np.stack([o.encrypt(pk, o.batch_encode((v.astype(np.int64) % o.t).astype(np.uint64))) for v in vals])
 
 
 def test_config3_gate_64_genuine_encryptions_bit_exact_and_decrypt_correct():

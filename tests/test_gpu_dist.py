@@ -40,7 +40,7 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_them():
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert d1["n_gpus"] == 1
     # weak scaling: two ranks did twice the work of one (on one shared device the rate does not double; the count does)
-    assert abs(d["value"] * d["ms_per_step"] / (d1["value"] * d1["ms_per_step"]) - 2.0) < 1e-6
+    assert abs(d["value"] * d["ms_per_step"] / (d1["value"] * d1["ms_per_step"]) - 2.0) < 0.05  # ms_per_step is rounded to 1 us
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

@@ -234,3 +234,73 @@ def test_program_errors():
     cyc.append_output_ciphertext(n2)
     with pytest.raises(HipBfvError):
         cyc.run(ev, [ct], rkd)
+
+
+def test_transparent_results_fail_the_run_like_the_reference():
+    """sunscreen/tests/features.rs:8-34: without the `transparent-ciphertexts` feature `runtime.run` of `a * 0` is an
+    error (SEAL is built with SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT, seal_fhe/build.rs:46-66; run.rs:78-82 collapses it
+    into a SealError).  The batch executor watches every node's results on the device and fails the run, naming the
+    first offending input set; the asynchronous hipbfv_batch_* operations record the same thing for BatchEvaluator.check."""
+    from sunscreen_amd import HipBfvError, Plaintext, _lib
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.program import FheProgram, encode_plaintext_literal
+
+    name = "default_4096_16"
+    n, primes, t = params(name)
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx(name)
+    rng = np.random.default_rng(21)
+    batch = 5
+    vals = rng.integers(0, 50, (batch, o.n)).astype(np.uint64)
+    ca = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vals])
+    da = to_device(ca)
+
+    # a * 0 with the zero as a plaintext literal, exactly the features.rs program
+    zero = encode_plaintext_literal(n, primes, t, Plaintext.from_coefficients([0]).as_bytes())
+    p = FheProgram()
+    a = p.append_input_ciphertext(0)
+    p.append_output_ciphertext(p.append_multiply_plaintext(a, p.append_plaintext_literal(zero)))
+    with pytest.raises(HipBfvError, match="transparent") as ei:
+        p.run(ev, [da], rkd)
+    assert ei.value.hresult & 0xFFFFFFFF == 0x80131509  # COR_E_INVALIDOPERATION (seal_fhe/src/lib.rs:28-34)
+
+    # x - x in the middle of a graph whose OUTPUT is not transparent: the reference fails at the Sub node
+    q = FheProgram()
+    x = q.append_input_ciphertext(0)
+    y = q.append_input_ciphertext(1)
+    q.append_output_ciphertext(q.append_add(q.append_sub(x, x), y))
+    with pytest.raises(HipBfvError, match="transparent"):
+        q.run(ev, [da, da], rkd)
+    with pytest.raises(RuntimeError, match="transparent"):
+        run_program(o, q.nodes, q.edges, [ca[0], ca[0]], rk)
+
+    # only ONE input set of the batch is degenerate (per-item plaintexts, item 3 is zero): the error names it
+    r = FheProgram()
+    x = r.append_input_ciphertext(0)
+    r.append_output_ciphertext(r.append_multiply_plaintext(x, r.append_input_plaintext(1)))
+    plains = rng.integers(1, t, (batch, o.n)).astype(np.uint64)
+    (ok,) = r.run(ev, [da, to_device(plains)], rkd)
+    assert (to_host(ok)[1] == o.multiply_plain(ca[1], plains[1])).all()
+    plains[3] = 0
+    with pytest.raises(HipBfvError, match="input set 3"):
+        r.run(ev, [da, to_device(plains)], rkd)
+
+    # the asynchronous batch operations: nothing is raised by the operation itself, check() reports and resets
+    ev.check()
+    ev.sub(da, da)
+    ev.add(da, da)
+    with pytest.raises(HipBfvError, match="transparent"):
+        ev.check()
+    ev.check()  # reset by the previous read
+    ev.multiply_relin(da, da, rkd)
+    ev.check()
+    # the crate's `transparent-ciphertexts` feature = SEAL built without the throw: nothing is watched
+    ev.set_transparent_check(False)
+    ev.sub(da, da)
+    ev.check()
+    ev.set_transparent_check(True)
+    assert _lib.load().hipbfv_set_throw_on_transparent(False) == 0
+    try:
+        (outz,) = q.run(ev, [da, da], rkd)
+        assert (to_host(outz) == ca).all()  # (x - x) + y == y
+    finally:
+        assert _lib.load().hipbfv_set_throw_on_transparent(True) == 0

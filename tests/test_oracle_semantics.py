@@ -109,6 +109,17 @@ def test_multiply_plain_monomial_and_zero(unit):
     # zero plaintext -> transparent ciphertext -> error (sunscreen/tests/features.rs:8-34)
     with pytest.raises(RuntimeError, match="transparent"):
         o.multiply_plain(ca, np.zeros(1, dtype=np.uint64))
+    # every Evaluator operation carries the same check in a SEAL built with SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT
+    # (seal_fhe/build.rs:46-66): x - x, and anything computed from a transparent operand alone
+    with pytest.raises(RuntimeError, match="transparent"):
+        o.sub(ca, ca)
+    zero_ct = np.zeros_like(ca)
+    zero_ct[0] = ca[0]  # (c0, 0): transparent
+    for op in (lambda: o.negate(zero_ct), lambda: o.add(zero_ct, zero_ct), lambda: o.multiply(zero_ct, zero_ct),
+               lambda: o.add_plain(zero_ct, np.ones(1, dtype=np.uint64))):
+        with pytest.raises(RuntimeError, match="transparent"):
+            op()
+    assert (o.add(zero_ct, ca)[1] == ca[1]).all()  # a transparent OPERAND is fine as long as the result is not
 
 
 def test_rotate_rows_and_columns(unit):
