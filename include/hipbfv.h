@@ -315,14 +315,21 @@ long hipbfv_batch_mod_switch(void *evaluator, const uint64_t *ct, uint64_t size,
 /* The steps either side of the evaluator, batched on device buffers:
  * encode / decode: values u64[count][N] (int64 when is_signed) <-> plaintexts u64[count][N];
  * decrypt: ct u64[count][size][K][N] -> plaintexts u64[count][N] (zero padded);
- * encrypt: plaintexts u64[count][N] (plain_stride = N) or one shared (0) -> ct u64[count][2][K][N]; item i uses the
- * Philox counter first_op + i under `seed` (distinct (seed, op) pairs give independent randomness).
+ * encrypt: plaintexts u64[count][N] (plain_stride = N) or one shared (0) -> ct u64[count][2][K][N]; item i draws its
+ * randomness from the ChaCha20 blocks at position first_op + i under the seed (distinct (seed, op) pairs give independent
+ * randomness; the generator is described in sunscreen_amd/csrc/rng.hpp).  hipbfv_batch_encrypt_seeded takes the 512-bit
+ * seed SEAL's prng_seed_type carries (64 bytes; NULL = 512 fresh bits from getrandom(2), failing with E_UNEXPECTED if
+ * the OS has none) and is the production entry point.  hipbfv_batch_encrypt with its 64-bit `seed` is TEST ONLY
+ * (reproducible batches for the parity tests: 2^64 candidates can be searched), like hipbfv_Encryptor_SetSeed,
+ * hipbfv_KeyGenerator_SetSeed and hipbfv_KeyGenerator_CreateSeeded.
  * encode synchronises the stream (it reports out-of-range values); the others are asynchronous. */
 long hipbfv_batch_encode(void *evaluator, const uint64_t *values, uint64_t *plain, uint64_t count, int is_signed, void *stream);
 long hipbfv_batch_decode(void *evaluator, const uint64_t *plain, uint64_t *values, uint64_t count, int is_signed, void *stream);
 long hipbfv_batch_decrypt(void *evaluator, const uint64_t *ct, uint32_t size, void *secret_key, uint64_t *plain, uint64_t count, void *stream);
 long hipbfv_batch_encrypt(void *evaluator, const uint64_t *plain, uint64_t plain_stride, void *public_key, uint64_t seed, uint64_t first_op,
                           uint64_t *ct, uint64_t count, void *stream);
+long hipbfv_batch_encrypt_seeded(void *evaluator, const uint64_t *plain, uint64_t plain_stride, void *public_key, const uint8_t *seed64,
+                                 uint64_t first_op, uint64_t *ct, uint64_t count, void *stream);
 /* Plaintext-matrix x ciphertext-vector products in the transform domain -- the first loop nest of examples/pir
  * (examples/pir/src/main.rs:16-45: col[i] = sum_j database[i][j] * col_query[j]).  plain_to_ntt transforms plaintexts
  * the way Evaluator_MultiplyPlain does internally (a static database is transformed once); ct_to_ntt transforms every

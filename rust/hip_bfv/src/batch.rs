@@ -1,0 +1,113 @@
+//! The GPU batch executor seam: one graph node over `count` independent ciphertexts per call.
+//!
+//! `sunscreen_runtime/src/run.rs:160-341` issues one FFI call (and at least one allocation) per node per ciphertext.
+//! Here a ciphertext batch is a device buffer `u64[count][size][K][N]` that never leaves HBM between nodes; operations
+//! are asynchronous on the caller's HIP stream.  Transparent results (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT,
+//! `sunscreen/tests/features.rs:8-34`) are recorded on the device and surface at [`BatchEvaluator::check`] /
+//! [`Program::run`], which is where this path synchronises.
+use std::ffi::c_void;
+use std::ptr::null_mut;
+
+use crate::{bindgen, check, BFVEvaluator, GaloisKeys, RelinearizationKeys, Result};
+
+/// A borrowed device buffer of `count` ciphertexts of `size` polynomials (memory is owned by the caller's allocator:
+/// hipMalloc, a torch tensor, ...).
+#[derive(Clone, Copy)]
+pub struct DeviceBatch {
+    pub ptr: *mut u64,
+    pub size: u64,
+    pub count: u64,
+}
+
+pub struct BatchEvaluator<'e> {
+    eval: &'e BFVEvaluator,
+    stream: *mut c_void,
+}
+
+impl<'e> BatchEvaluator<'e> {
+    /// `stream`: a `hipStream_t` (null = the default stream).
+    pub fn new(eval: &'e BFVEvaluator, stream: *mut c_void) -> Self {
+        Self { eval, stream }
+    }
+    fn h(&self) -> *mut c_void {
+        self.eval.get_handle()
+    }
+
+    pub fn multiply_relin(&self, a: DeviceBatch, b: DeviceBatch, rk: &RelinearizationKeys, out: DeviceBatch) -> Result<()> {
+        check(unsafe { bindgen::hipbfv_batch_multiply_relin(self.h(), a.ptr, b.ptr, rk.get_handle(), out.ptr, a.count, self.stream) })
+    }
+    pub fn multiply(&self, a: DeviceBatch, b: DeviceBatch, out: DeviceBatch) -> Result<()> {
+        check(unsafe { bindgen::hipbfv_batch_multiply(self.h(), a.ptr, a.size, b.ptr, b.size, out.ptr, a.count, self.stream) })
+    }
+    pub fn relinearize(&self, ct3: DeviceBatch, rk: &RelinearizationKeys, out: DeviceBatch) -> Result<()> {
+        check(unsafe { bindgen::hipbfv_batch_relinearize(self.h(), ct3.ptr, rk.get_handle(), out.ptr, ct3.count, self.stream) })
+    }
+    pub fn rotate_rows(&self, a: DeviceBatch, steps: i32, gk: &GaloisKeys, out: DeviceBatch) -> Result<()> {
+        check(unsafe { bindgen::hipbfv_batch_rotate_rows(self.h(), a.ptr, steps, gk.get_handle(), out.ptr, a.count, self.stream) })
+    }
+    pub fn rotate_columns(&self, a: DeviceBatch, gk: &GaloisKeys, out: DeviceBatch) -> Result<()> {
+        check(unsafe { bindgen::hipbfv_batch_rotate_columns(self.h(), a.ptr, gk.get_handle(), out.ptr, a.count, self.stream) })
+    }
+    pub fn add(&self, a: DeviceBatch, b: DeviceBatch, out: DeviceBatch) -> Result<()> {
+        check(unsafe { bindgen::hipbfv_batch_add(self.h(), a.ptr, b.ptr, out.ptr, a.size, a.count, self.stream) })
+    }
+    pub fn sub(&self, a: DeviceBatch, b: DeviceBatch, out: DeviceBatch) -> Result<()> {
+        check(unsafe { bindgen::hipbfv_batch_sub(self.h(), a.ptr, b.ptr, out.ptr, a.size, a.count, self.stream) })
+    }
+    pub fn negate(&self, a: DeviceBatch, out: DeviceBatch) -> Result<()> {
+        check(unsafe { bindgen::hipbfv_batch_negate(self.h(), a.ptr, out.ptr, a.size, a.count, self.stream) })
+    }
+    /// Synchronise the stream; `Err(InternalError(COR_E_INVALIDOPERATION, ..))` if any operation since the last call
+    /// produced a transparent ciphertext.
+    pub fn check(&self) -> Result<()> {
+        let mut first = 0u64;
+        check(unsafe { bindgen::hipbfv_batch_status(self.h(), &mut first, self.stream) })
+    }
+}
+
+/// A compiled `FheProgram` graph (serde JSON of `sunscreen_fhe_program::FheProgram`, or built node by node) executed over
+/// a batch of independent input sets: the replacement of `run_program_unchecked` (`run.rs:100-357`).
+pub struct Program {
+    handle: *mut c_void,
+}
+unsafe impl Sync for Program {}
+unsafe impl Send for Program {}
+
+pub enum Input {
+    Ciphertexts(*const u64),
+    /// per-item plaintexts `u64[batch][N]` (stride N) or one shared `u64[N]` (stride 0)
+    Plaintexts { ptr: *const u64, stride: u64 },
+}
+
+impl Program {
+    pub fn from_json(json: &str) -> Result<Self> {
+        let mut handle = null_mut();
+        check(unsafe { bindgen::hipbfv_Program_Create(&mut handle) })?;
+        let p = Self { handle };
+        check(unsafe { bindgen::hipbfv_Program_LoadJson(p.handle, json.as_ptr() as *const _, json.len() as u64) })?;
+        Ok(p)
+    }
+
+    /// One output buffer `u64[batch][2][K][N]` per `OutputCiphertext` node, in node order.
+    pub fn run(
+        &self, eval: &BFVEvaluator, batch: u64, inputs: &[Input], rk: Option<&RelinearizationKeys>, gk: Option<&GaloisKeys>,
+        outputs: &[*mut u64], stream: *mut c_void,
+    ) -> Result<()> {
+        let kinds: Vec<u32> = inputs.iter().map(|i| matches!(i, Input::Plaintexts { .. }) as u32).collect();
+        let ptrs: Vec<*const u64> = inputs.iter().map(|i| match i { Input::Ciphertexts(p) => *p, Input::Plaintexts { ptr, .. } => *ptr }).collect();
+        let strides: Vec<u64> = inputs.iter().map(|i| match i { Input::Ciphertexts(_) => 0, Input::Plaintexts { stride, .. } => *stride }).collect();
+        check(unsafe {
+            bindgen::hipbfv_Program_Run(
+                self.handle, eval.get_handle(), batch, inputs.len() as u64, kinds.as_ptr(), ptrs.as_ptr(), strides.as_ptr(),
+                rk.map_or(null_mut(), |k| k.get_handle()), gk.map_or(null_mut(), |k| k.get_handle()),
+                outputs.len() as u64, outputs.as_ptr(), stream,
+            )
+        })
+    }
+}
+
+impl Drop for Program {
+    fn drop(&mut self) {
+        check(unsafe { bindgen::hipbfv_Program_Destroy(self.handle) }).expect("hipbfv_Program_Destroy");
+    }
+}

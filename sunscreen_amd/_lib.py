@@ -135,6 +135,7 @@ _SIGNATURES = {
     "hipbfv_batch_decode": [vp, vp, vp, u64, C.c_int, vp],
     "hipbfv_batch_decrypt": [vp, vp, C.c_uint32, vp, vp, u64, vp],
     "hipbfv_batch_encrypt": [vp, vp, u64, vp, u64, u64, vp, u64, vp],
+    "hipbfv_batch_encrypt_seeded": [vp, vp, u64, vp, C.c_char_p, u64, vp, u64, vp],
     "hipbfv_SecretKey_Assign": [vp, vp, u64p],
     "hipbfv_PublicKey_Assign": [vp, vp, u64p],
     "hipbfv_Encryptor_SetSeed": [vp, u64],

@@ -189,13 +189,20 @@ class BatchEvaluator:
         _check(_lib.load().hipbfv_batch_decrypt(self._h, _ptr(ct), ct.shape[1], secret_key.get_handle(), _ptr(out), ct.shape[0], _stream()))
         return out
 
-    def encrypt(self, plain: torch.Tensor, public_key, seed: int, first_op: int = 0) -> torch.Tensor:
-        """int64[batch, N] (or one shared int64[N]) plaintexts -> fresh encryptions int64[batch', 2, K, N]."""
+    def encrypt(self, plain: torch.Tensor, public_key, seed: int | bytes | None = None, first_op: int = 0) -> torch.Tensor:
+        """int64[batch, N] (or one shared int64[N]) plaintexts -> fresh encryptions int64[batch', 2, K, N].
+        seed: None = 512 fresh bits from the OS (production); 64 bytes = SEAL's prng_seed_type; an int = the TEST-ONLY
+        64-bit seed (reproducible batches)."""
         shared = plain.dim() == 1
         count = 1 if shared else plain.shape[0]
         out = torch.empty((count, 2, self.K, self.n), dtype=torch.int64, device=plain.device)
-        _check(_lib.load().hipbfv_batch_encrypt(self._h, _ptr(plain), 0 if shared else self.n, public_key.get_handle(), seed, first_op,
-                                                _ptr(out), count, _stream()))
+        if isinstance(seed, int):
+            _check(_lib.load().hipbfv_batch_encrypt(self._h, _ptr(plain), 0 if shared else self.n, public_key.get_handle(), seed, first_op,
+                                                    _ptr(out), count, _stream()))
+        else:
+            assert seed is None or len(seed) == 64
+            _check(_lib.load().hipbfv_batch_encrypt_seeded(self._h, _ptr(plain), 0 if shared else self.n, public_key.get_handle(), seed, first_op,
+                                                           _ptr(out), count, _stream()))
         return out
 
     def mod_switch(self, ct: torch.Tensor) -> torch.Tensor:

@@ -7,6 +7,9 @@
 #include "../../include/hipbfv.h"
 
 #include <hip/hip_runtime.h>
+#include <sys/random.h>
+
+#include <cerrno>
 
 #include <atomic>
 #include <cstdio>
@@ -281,9 +284,9 @@ struct EncryptorObj : Obj {
   std::unique_ptr<Evaluator> ev;
   std::shared_ptr<KeyBuffer> pk;
   std::shared_ptr<KeyBuffer> sk;  // optional: symmetric encryption
-  u64 seed = 0;
+  RngSeed seed{};  // 512 bits of OS entropy per Encryptor (rng.hpp); hipbfv_Encryptor_SetSeed replaces it for tests
   std::mutex mu;
-  u64 next_op = 0;  // Philox counter: every encryption of one Encryptor uses fresh randomness
+  u64 next_op = 0;  // block counter: every encryption of one Encryptor uses fresh randomness
   EncryptorObj() : Obj(kMagicEncryptor) {}
 };
 
@@ -292,9 +295,9 @@ struct KeyGenObj : Obj {
   std::unique_ptr<Evaluator> ev;
   std::shared_ptr<KeyBuffer> sk;        // NTT form, what SecretKey handles share
   std::shared_ptr<KeyBuffer> sk_coeff;  // the ternary polynomial in coefficient form (Galois keys permute it)
-  u64 seed = 0;
+  RngSeed seed{};  // 512 bits of OS entropy per KeyGenerator (rng.hpp)
   std::mutex mu;
-  u64 next_stream = 1;  // every generated key draws from its own Philox stream
+  u64 next_stream = 1;  // every generated key draws from its own stream (block-input word)
   KeyGenObj() : Obj(kMagicKeyGen) {}
 };
 
@@ -314,6 +317,24 @@ struct ProgramObj : Obj {
   Program prog;
   ProgramObj() : Obj(kMagicProgram) {}
 };
+
+// 512 bits from the kernel's CSPRNG (getrandom(2)); keys are never derived from anything weaker: no entropy -> the
+// operation fails (E_UNEXPECTED), there is no fallback seed
+bool os_seed(RngSeed* out) {
+  uint8_t raw[64];
+  size_t got = 0;
+  while (got < sizeof(raw)) {
+    const ssize_t r = getrandom(raw + got, sizeof(raw) - got, 0);
+    if (r < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    got += (size_t)r;
+  }
+  *out = rng_seed_from_512(raw);
+  std::memset(raw, 0, sizeof(raw));
+  return true;
+}
 
 // one non-blocking stream per host thread: concurrent handle-level calls do not serialise on the null stream
 hipStream_t thread_stream() {
@@ -2330,13 +2351,10 @@ long Encryptor_Create(void* context, void* public_key, void* secret_key, void** 
   e->ev.reset(new Evaluator(x->ctx.get()));
   if (pk) e->pk = pk->key;
   if (sk) e->sk = sk->key;
-  // fresh seed per Encryptor from the OS (SEAL seeds its PRNG factory from std::random_device the same way)
-  {
-    FILE* f = std::fopen("/dev/urandom", "rb");
-    u64 sd = 0;
-    if (!f || std::fread(&sd, sizeof(sd), 1, f) != 1) sd = (u64)(uintptr_t)e ^ 0x9E3779B97F4A7C15ull;
-    if (f) std::fclose(f);
-    e->seed = sd;
+  // fresh 512-bit seed per Encryptor from the OS (SEAL seeds its PRNG factory from the OS the same way)
+  if (!os_seed(&e->seed)) {
+    delete e;
+    return fail(HIPBFV_E_UNEXPECTED, "no entropy available from the operating system (getrandom failed)");
   }
   *out = e;
   return HIPBFV_S_OK;
@@ -2351,7 +2369,7 @@ long hipbfv_Encryptor_SetSeed(void* h, uint64_t seed) HIPBFV_BEGIN
   EncryptorObj* e = as<EncryptorObj>(h, kMagicEncryptor);
   if (!e) return HIPBFV_E_POINTER;
   std::lock_guard<std::mutex> g(e->mu);
-  e->seed = seed;
+  e->seed = rng_seed_from_u64_for_tests(seed);  // TEST ONLY: 64 bits of entropy (reproducible ciphertexts for parity tests)
   e->next_op = 0;
   return HIPBFV_S_OK;
 HIPBFV_END
@@ -2366,7 +2384,8 @@ long Encryptor_Encrypt(void* h, void* plaintext, void* destination, void* pool) 
   if (p->coeffs.size() > n) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
   for (u64 v : p->coeffs)
     if (v >= e->ctx->t()) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
-  u64 op, seed;
+  u64 op;
+  RngSeed seed;
   {
     std::lock_guard<std::mutex> g(e->mu);
     op = e->next_op++;
@@ -2429,6 +2448,20 @@ long hipbfv_batch_encrypt(void* evaluator, const uint64_t* plain, uint64_t plain
   AsymKeyObj* k = as<AsymKeyObj>(public_key, kMagicPublicKey);
   if (!e || !k || !ct || !plain) return HIPBFV_E_POINTER;
   if (!k->key || k->key->ctx.get() != e->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "public key is not valid for encryption parameters");
+  // TEST ONLY: a 64-bit seed (reproducible batches for the parity tests); production callers use hipbfv_batch_encrypt_seeded
+  return from_status(e->ev->encrypt((const u64*)plain, plain_stride, k->key->dev, rng_seed_from_u64_for_tests(seed), first_op, (u64*)ct, count, (hipStream_t)stream));
+HIPBFV_END
+long hipbfv_batch_encrypt_seeded(void* evaluator, const uint64_t* plain, uint64_t plain_stride, void* public_key, const uint8_t* seed64, uint64_t first_op,
+                                 uint64_t* ct, uint64_t count, void* stream) HIPBFV_BEGIN
+  EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
+  AsymKeyObj* k = as<AsymKeyObj>(public_key, kMagicPublicKey);
+  if (!e || !k || !ct || !plain) return HIPBFV_E_POINTER;
+  if (!k->key || k->key->ctx.get() != e->ctx.get()) return fail(HIPBFV_E_INVALIDARG, "public key is not valid for encryption parameters");
+  RngSeed seed;
+  if (seed64)
+    seed = rng_seed_from_512(seed64);
+  else if (!os_seed(&seed))
+    return fail(HIPBFV_E_UNEXPECTED, "no entropy available from the operating system (getrandom failed)");
   return from_status(e->ev->encrypt((const u64*)plain, plain_stride, k->key->dev, seed, first_op, (u64*)ct, count, (hipStream_t)stream));
 HIPBFV_END
 
@@ -2729,26 +2762,17 @@ static void scaling_remainder(const Context& cx, const std::vector<u64>& m, Plai
   r->coeffs.assign(cx.n(), 0);
   for (size_t i = 0; i < m.size(); i++) r->coeffs[i] = (u64)(((unsigned __int128)qt * m[i] + half) / t);
 }
-static u64 fold_seed(const void* seed64bytes) {  // the fork passes [u64; 8]; folded into the Philox key
-  const u64* w = static_cast<const u64*>(seed64bytes);
-  u64 hsh = 0x9E3779B97F4A7C15ull;
-  for (int i = 0; i < 8; i++) {
-    hsh ^= w[i] + 0x9E3779B97F4A7C15ull + (hsh << 6) + (hsh >> 2);
-    hsh *= 0xBF58476D1CE4E5B9ull;
-    hsh ^= hsh >> 31;
-  }
-  return hsh;
-}
 // shared body: symmetric (sk) or public-key encryption of one plaintext, optionally exporting u, e, r
 static long encrypt_one(EncryptorObj* e, PlainObj* p, CipherObj* c, bool symmetric, bool no_special, PolyArrayObj* u_dest, PolyArrayObj* e_dest,
-                        PlainObj* r_dest, const u64* fixed_seed) {
+                        PlainObj* r_dest, const RngSeed* fixed_seed) {
   const Context& cx = *e->ctx;
   const size_t n = cx.n(), words = cx.ct_words(2);
   if (symmetric ? !e->sk : !e->pk) return fail(HIPBFV_COR_E_INVALIDOPERATION, symmetric ? "secret key is not set" : "public key is not set");
   if (p->coeffs.size() > n) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
   for (u64 v : p->coeffs)
     if (v >= cx.t()) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
-  u64 op = 0, seed;
+  u64 op = 0;
+  RngSeed seed;
   if (fixed_seed) {
     seed = *fixed_seed;
   } else {
@@ -2811,7 +2835,7 @@ long Encryptor_EncryptReturnComponentsSetSeed(void* h, void* plaintext, bool dis
   PolyArrayObj* ed = as<PolyArrayObj>(e_destination, kMagicPolyArray);
   PlainObj* rd = as<PlainObj>(r_destination, kMagicPlain);
   if (!e || !p || !c || !ud || !ed || !rd || !seed) return HIPBFV_E_POINTER;
-  const u64 sd = fold_seed(seed);
+  const RngSeed sd = rng_seed_from_512(seed);  // the fork passes [u64; 8]: all 512 bits key the generator
   return encrypt_one(e, p, c, false, disable_special_modulus, ud, ed, rd, &sd);
 HIPBFV_END
 long Encryptor_EncryptSymmetric(void* h, void* plaintext, bool save_seed, void* destination, void* pool) HIPBFV_BEGIN
@@ -2842,18 +2866,11 @@ long Encryptor_EncryptSymmetricReturnComponentsSetSeed(void* h, void* plaintext,
   PolyArrayObj* ed = as<PolyArrayObj>(e_destination, kMagicPolyArray);
   PlainObj* rd = as<PlainObj>(r_destination, kMagicPlain);
   if (!e || !p || !c || !ed || !rd || !seed) return HIPBFV_E_POINTER;
-  const u64 sd = fold_seed(seed);
+  const RngSeed sd = rng_seed_from_512(seed);  // the fork passes [u64; 8]: all 512 bits key the generator
   return encrypt_one(e, p, c, true, false, nullptr, ed, rd, &sd);
 HIPBFV_END
 
 // ------------------------------------------------------------------ KeyGenerator (seal_fhe/src/key_generator.rs:20-200)
-static u64 os_seed(const void* salt) {
-  FILE* f = std::fopen("/dev/urandom", "rb");
-  u64 sd = 0;
-  if (!f || std::fread(&sd, sizeof(sd), 1, f) != 1) sd = (u64)(uintptr_t)salt ^ 0x9E3779B97F4A7C15ull;
-  if (f) std::fclose(f);
-  return sd;
-}
 static std::shared_ptr<KeyBuffer> new_key_buffer(const std::shared_ptr<Context>& ctx, size_t words) {
   auto b = std::make_shared<KeyBuffer>();
   b->ctx = ctx;
@@ -2861,7 +2878,7 @@ static std::shared_ptr<KeyBuffer> new_key_buffer(const std::shared_ptr<Context>&
   b->dev = g_buffers.get(words);
   return b->dev ? b : nullptr;
 }
-static long keygen_new(void* context, AsymKeyObj* existing, void** out, const u64* fixed_seed = nullptr) {
+static long keygen_new(void* context, AsymKeyObj* existing, void** out, const RngSeed* fixed_seed = nullptr) {
   ContextObj* x = as<ContextObj>(context, kMagicContext);
   if (!x || !out) return HIPBFV_E_POINTER;
   if (existing && (!existing->key || existing->key->ctx.get() != x->ctx.get()))
@@ -2869,7 +2886,10 @@ static long keygen_new(void* context, AsymKeyObj* existing, void** out, const u6
   std::unique_ptr<KeyGenObj> g(new KeyGenObj());
   g->ctx = x->ctx;
   g->ev.reset(new Evaluator(x->ctx.get()));
-  g->seed = fixed_seed ? *fixed_seed : os_seed(g.get());
+  if (fixed_seed)
+    g->seed = *fixed_seed;
+  else if (!os_seed(&g->seed))
+    return fail(HIPBFV_E_UNEXPECTED, "no entropy available from the operating system (getrandom failed)");
   const size_t words = (size_t)x->ctx->KK() * x->ctx->n();
   g->sk_coeff = new_key_buffer(x->ctx, words);
   if (!g->sk_coeff) return from_status(kOutOfMemory);
@@ -2890,7 +2910,10 @@ static long keygen_new(void* context, AsymKeyObj* existing, void** out, const u6
   return HIPBFV_S_OK;
 }
 long KeyGenerator_Create1(void* context, void** out) HIPBFV_BEGIN return keygen_new(context, nullptr, out); HIPBFV_END
-long hipbfv_KeyGenerator_CreateSeeded(void* context, uint64_t seed, void** out) HIPBFV_BEGIN const u64 sd = seed; return keygen_new(context, nullptr, out, &sd); HIPBFV_END
+long hipbfv_KeyGenerator_CreateSeeded(void* context, uint64_t seed, void** out) HIPBFV_BEGIN
+  const RngSeed sd = rng_seed_from_u64_for_tests(seed);  // TEST ONLY: 64 bits of entropy
+  return keygen_new(context, nullptr, out, &sd);
+HIPBFV_END
 long KeyGenerator_Create2(void* context, void* secret_key, void** out) HIPBFV_BEGIN
   AsymKeyObj* k = as<AsymKeyObj>(secret_key, kMagicSecretKey);
   if (!k) return HIPBFV_E_POINTER;
@@ -2902,14 +2925,14 @@ long KeyGenerator_Destroy(void* h) HIPBFV_BEGIN
   delete g;
   return HIPBFV_S_OK;
 HIPBFV_END
-long hipbfv_KeyGenerator_SetSeed(void* h, uint64_t seed) {  // reproducible keys for tests; affects keys created afterwards
+long hipbfv_KeyGenerator_SetSeed(void* h, uint64_t seed) HIPBFV_BEGIN  // TEST ONLY (64 bits of entropy): reproducible keys; affects keys created afterwards
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g) return HIPBFV_E_POINTER;
   std::lock_guard<std::mutex> lk(g->mu);
-  g->seed = seed;
+  g->seed = rng_seed_from_u64_for_tests(seed);
   g->next_stream = 1;
   return HIPBFV_S_OK;
-}
+HIPBFV_END
 long KeyGenerator_SecretKey(void* h, void** secret_key) HIPBFV_BEGIN
   KeyGenObj* g = as<KeyGenObj>(h, kMagicKeyGen);
   if (!g || !secret_key) return HIPBFV_E_POINTER;
@@ -2918,7 +2941,7 @@ long KeyGenerator_SecretKey(void* h, void** secret_key) HIPBFV_BEGIN
   *secret_key = k;
   return HIPBFV_S_OK;
 HIPBFV_END
-static u64 take_stream(KeyGenObj* g, u64* seed) {
+static u64 take_stream(KeyGenObj* g, RngSeed* seed) {
   std::lock_guard<std::mutex> lk(g->mu);
   *seed = g->seed;
   return g->next_stream++;
@@ -2930,7 +2953,7 @@ long KeyGenerator_CreatePublicKey(void* h, bool save_seed, void** public_key) HI
   auto buf = new_key_buffer(g->ctx, (size_t)2 * g->ctx->KK() * g->ctx->n());
   if (!buf) return from_status(kOutOfMemory);
   hipStream_t s = thread_stream();
-  u64 seed;
+  RngSeed seed;
   const u64 stream = take_stream(g, &seed);
   if (int st = g->ev->keygen_zero_encryptions(seed, stream, g->sk->dev, nullptr, buf->dev, 1, s)) return from_status(st);
   if (long hr = sync_stream(s)) return hr;
@@ -2944,7 +2967,7 @@ static long keygen_kswitch_into(KeyGenObj* g, KeysObj* keys, u32 galois_elt) {
   u64* buf = g_buffers.get(words);
   if (!buf) return from_status(kOutOfMemory);
   hipStream_t s = thread_stream();
-  u64 seed;
+  RngSeed seed;
   const u64 stream = take_stream(g, &seed);
   int st = g->ev->keygen_kswitch(seed, stream, g->sk_coeff->dev, g->sk->dev, galois_elt, buf, s);
   long hr = st ? from_status(st) : sync_stream(s);

@@ -156,20 +156,20 @@ class Evaluator {
   int batch_encode(const u64* values, u64* plain, size_t count, bool is_signed, u32* bad_host, hipStream_t s);
   int batch_decode(const u64* plain, u64* values, size_t count, bool is_signed, hipStream_t s);
   int decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, size_t count, hipStream_t s);
-  int keygen_secret(u64 seed, u64* sk_coeff, u64* sk_ntt, hipStream_t s);
-  int keygen_zero_encryptions(u64 seed, u64 stream, const u64* sk_ntt, const u64* w, u64* key, u32 count, hipStream_t s);
+  int keygen_secret(const RngSeed& seed, u64* sk_coeff, u64* sk_ntt, hipStream_t s);
+  int keygen_zero_encryptions(const RngSeed& seed, u64 stream, const u64* sk_ntt, const u64* w, u64* key, u32 count, hipStream_t s);
   // single encryptions that also return the sampled polynomials (fork-only API used by logproof), and secret-key encryption
-  int encrypt_components(const u64* plain, const u64* pk, u64 seed, u64 op, bool no_special, u64* ct2, u64* u_out, u64* e_out, hipStream_t s);
-  int encrypt_symmetric(const u64* plain, const u64* sk_ntt, u64 seed, u64 stream, u64* ct2, u64* e_out, hipStream_t s);
+  int encrypt_components(const u64* plain, const u64* pk, const RngSeed& seed, u64 op, bool no_special, u64* ct2, u64* u_out, u64* e_out, hipStream_t s);
+  int encrypt_symmetric(const u64* plain, const u64* sk_ntt, const RngSeed& seed, u64 stream, u64* ct2, u64* e_out, hipStream_t s);
   int key_to_coeff(const u64* key, u32 polys, u64* out, hipStream_t s);
   int crt_compose(const u64* consts, u32 kc, const u64* in, u64* out, u32 polys, hipStream_t s);
   int crt_decompose(u32 kc, const u64* in, u64* out, u32 polys, hipStream_t s);
-  int keygen_kswitch(u64 seed, u64 stream, const u64* sk_coeff, const u64* sk_ntt, u32 galois_elt, u64* key, hipStream_t s);
+  int keygen_kswitch(const RngSeed& seed, u64 stream, const u64* sk_coeff, const u64* sk_ntt, u32 galois_elt, u64* key, hipStream_t s);
   int plain_to_ntt(const u64* plain, size_t pstride, u64* pntt, size_t count, hipStream_t s);
   int ct_to_ntt(const u64* ct, u32 size, u64* ctn, size_t count, hipStream_t s);
   int dot_plain_ntt(const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* out, hipStream_t s);
   int phase(const u64* ct, u32 size, const u64* sk_ntt, u64* out, size_t count, hipStream_t s);
-  int encrypt(const u64* plain, size_t pstride, const u64* pk, u64 seed, u64 first_op, u64* ct2, size_t count, hipStream_t s);
+  int encrypt(const u64* plain, size_t pstride, const u64* pk, const RngSeed& seed, u64 first_op, u64* ct2, size_t count, hipStream_t s);
 
   // ---- NTT entry points (BASELINE config 2) ----
   // data: u64[polys][N]; polynomial p uses key-level prime (p % nprimes)

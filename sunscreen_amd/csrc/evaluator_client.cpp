@@ -112,7 +112,7 @@ int Evaluator::decrypt(const u64* ct, u32 size, const u64* sk_ntt, u64* plain, s
 
 // ---- KeyGenerator (seal_fhe/src/key_generator.rs:20-200; SEAL keygenerator.cpp) ----
 // sk_coeff / sk_ntt: u64[KK][N] -- the ternary secret in coefficient form (kept for the Galois keys) and its transform
-int Evaluator::keygen_secret(u64 seed, u64* sk_coeff, u64* sk_ntt, hipStream_t s) {
+int Evaluator::keygen_secret(const RngSeed& seed, u64* sk_coeff, u64* sk_ntt, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (h.logn > 15) return kUnsupported;
   HC_CHECK(launch_keygen_ternary(ctx_->dev(), h.n, seed, 0, sk_coeff, s));
@@ -124,7 +124,7 @@ int Evaluator::keygen_secret(u64 seed, u64* sk_coeff, u64* sk_ntt, hipStream_t s
 // `count` key-level encryptions of zero under sk_ntt, the z-th one carrying w (.) (q_sp mod q_z) on residue z when w is
 // given: count = 1, w = nullptr -> public key u64[2][KK][N]; count = K, w = s^2 or sigma_g(s) (NTT form) -> one
 // key-switching key u64[K][2][KK][N].  `stream` keys the randomness (distinct per key).
-int Evaluator::keygen_zero_encryptions(u64 seed, u64 stream, const u64* sk_ntt, const u64* w, u64* key, u32 count, hipStream_t s) {
+int Evaluator::keygen_zero_encryptions(const RngSeed& seed, u64 stream, const u64* sk_ntt, const u64* w, u64* key, u32 count, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (h.logn > 15) return kUnsupported;
   const u32 n = h.n, KK = h.KK;
@@ -139,7 +139,7 @@ int Evaluator::keygen_zero_encryptions(u64 seed, u64 stream, const u64* sk_ntt, 
 }
 
 // relin: w = s^2; galois element g: w = NTT(sigma_g(s)).  key: u64[K][2][KK][N]
-int Evaluator::keygen_kswitch(u64 seed, u64 stream, const u64* sk_coeff, const u64* sk_ntt, u32 galois_elt, u64* key, hipStream_t s) {
+int Evaluator::keygen_kswitch(const RngSeed& seed, u64 stream, const u64* sk_coeff, const u64* sk_ntt, u32 galois_elt, u64* key, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (h.KK < 2) return kNoKey;  // no special prime: SEAL refuses to create key-switching keys
   const u32 n = h.n, KK = h.KK;
@@ -239,9 +239,9 @@ int Evaluator::phase(const u64* ct, u32 size, const u64* sk_ntt, u64* out, size_
 }
 
 // ct2[op] = Encryptor_Encrypt(plain[op]) under the public key pk: u64[2][KK][N] (NTT form, key level).
-// Randomness: Philox4x32-10 keyed by `seed`, counter = (coefficient, first_op + op): reproducible and independent of
+// Randomness: ChaCha20 blocks keyed by `seed.secret` (rng.hpp), counter = (coefficient, first_op + op): reproducible and independent of
 // the chunking.  plain: u64[count][N] (pstride = N) or one shared plaintext (pstride = 0).
-int Evaluator::encrypt(const u64* plain, size_t pstride, const u64* pk, u64 seed, u64 first_op, u64* ct2, size_t count, hipStream_t s) {
+int Evaluator::encrypt(const u64* plain, size_t pstride, const u64* pk, const RngSeed& seed, u64 first_op, u64* ct2, size_t count, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (!pk) return kInvalidArg;
   if (h.logn > 15) return kUnsupported;
@@ -281,7 +281,7 @@ static hipError_t take_data_rows(const DevCtx& h, const u64* src, u64* dst, u32 
 // seal_fhe/src/encryptor_decryptor.rs:268-300): u_out u64[K][N] (ternary), e_out u64[2][K][N], coefficient-form data-level
 // residues.  no_special: compute (pk*u + e) on the data primes only, with no division by the special prime, so that
 // c0 = floor(q/t)*m + r + pk0*u + e0 and c1 = pk1*u + e1 hold EXACTLY (what logproof proves, bfv_statement.rs:159).
-int Evaluator::encrypt_components(const u64* plain, const u64* pk, u64 seed, u64 op, bool no_special, u64* ct2, u64* u_out, u64* e_out,
+int Evaluator::encrypt_components(const u64* plain, const u64* pk, const RngSeed& seed, u64 op, bool no_special, u64* ct2, u64* u_out, u64* e_out,
                                   hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (!pk) return kInvalidArg;
@@ -310,7 +310,7 @@ int Evaluator::encrypt_components(const u64* plain, const u64* pk, u64 seed, u64
 
 // Secret-key encryption (SEAL encrypt_zero_symmetric at the data level + scaled plaintext): c1 = a uniform,
 // c0 = floor(q/t)*m + r - (a*s + e).  e_out (optional): u64[K][N] coefficient-form residues of e.
-int Evaluator::encrypt_symmetric(const u64* plain, const u64* sk_ntt, u64 seed, u64 stream, u64* ct2, u64* e_out, hipStream_t s) {
+int Evaluator::encrypt_symmetric(const u64* plain, const u64* sk_ntt, const RngSeed& seed, u64 stream, u64* ct2, u64* e_out, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (!sk_ntt) return kInvalidArg;
   if (h.logn > 15) return kUnsupported;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "devctx.hpp"
+#include "rng.hpp"
 
 namespace hipbfv {
 
@@ -54,14 +55,14 @@ hipError_t launch_batch_scatter(const DevCtx* ctx, u32 n, const u32* map, const 
 hipError_t launch_batch_gather(const DevCtx* ctx, u32 n, const u32* map, const u64* tmp, u64* values, size_t ops, int is_signed, hipStream_t s);
 hipError_t launch_dot_secret(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 size, const u64* sk, u64* acc, size_t ops, hipStream_t s);
 hipError_t launch_decrypt_round(const DevCtx* ctx, u32 n, const u64* ct, u32 size, const u64* acc, u64* plain, size_t ops, hipStream_t s);
-hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, u64 seed, u64 op0, u64* u, u64* e, size_t ops, hipStream_t s);
+hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 op0, u64* u, u64* e, size_t ops, hipStream_t s);
 hipError_t launch_ntt_inv_dyadic(const DevCtx* ctx, const MulOp* tw_inv, u32 logn, const u64* a, const u64* b, u64* c, u32 nmod, u32 nb, u32 bstride,
                                  size_t ops, hipStream_t s);
-hipError_t launch_encrypt_finish(const DevCtx* ctx, u32 n, u64 seed, u64 op0, const u64* c2, const u64* plain, size_t pstride, u64* out, size_t ops,
+hipError_t launch_encrypt_finish(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 op0, const u64* c2, const u64* plain, size_t pstride, u64* out, size_t ops,
                                  hipStream_t s);
 hipError_t launch_encrypt_dyadic(const DevCtx* ctx, u32 n, u32 KK, const u64* un, const u64* pk, u64* c, size_t ops, hipStream_t s);
-hipError_t launch_keygen_ternary(const DevCtx* ctx, u32 n, u64 seed, u64 stream, u64* s_out, hipStream_t s);
-hipError_t launch_keygen_sample(const DevCtx* ctx, u32 n, u64 seed, u64 stream0, u64* a, u64* e, size_t count, hipStream_t s);
+hipError_t launch_keygen_ternary(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 stream, u64* s_out, hipStream_t s);
+hipError_t launch_keygen_sample(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 stream0, u64* a, u64* e, size_t count, hipStream_t s);
 hipError_t launch_keygen_assemble(const DevCtx* ctx, u32 n, u32 KK, const u64* a, const u64* e, const u64* sk, const u64* w, u64* key, size_t count,
                                   hipStream_t s);
 hipError_t launch_keygen_square(const DevCtx* ctx, u32 n, u32 KK, const u64* in, u64* out, hipStream_t s);

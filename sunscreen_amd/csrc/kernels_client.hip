@@ -109,19 +109,8 @@ __global__ __launch_bounds__(kClientThreads) void decrypt_round_kernel(const Dev
 }
 
 // ---- Encryptor ----
-// Philox4x32-10 (Salmon et al., SC'11): counter = (coefficient, op, stream, 0), key = seed
-__device__ __forceinline__ void philox4x32(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 (&out)[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    const u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;
-    const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n1 = (u32)p1, n2 = (u32)(p0 >> 32) ^ c3 ^ k1, n3 = (u32)p0;
-    c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
-}
-
+// Randomness: ChaCha20 as a counter-based PRF (rng.hpp): 16 words = block(key, (coefficient, op_lo, op_hi, domain)).
+// Secret material (u, e, ternary secrets) is generated under RngSeed::secret, published uniform polynomials under ::pub.
 // rounded Gaussian, sigma = 3.2, clipped to |x| <= 19 (the reference builds SEAL with SEAL_USE_GAUSSIAN_NOISE=ON,
 // seal_fhe/build.rs:50; the sampler is pinned statistically only -- SURVEY 8f row 3)
 __device__ __forceinline__ int gauss_noise(u32 a, u32 b) {
@@ -135,18 +124,17 @@ __device__ __forceinline__ int gauss_noise(u32 a, u32 b) {
 __device__ __forceinline__ u64 small_to_residue(int v, u64 q) { return v < 0 ? q - (u64)(-v) : (u64)v; }
 
 // u[op][KK][N] = ternary polynomial in every key-level residue; e[op][2][KK][N] = the two error polynomials
-__global__ __launch_bounds__(kClientThreads) void encrypt_sample_kernel(const DevCtx* __restrict__ ctx, u64 seed, u64 op0, u64* __restrict__ u,
+__global__ __launch_bounds__(kClientThreads) void encrypt_sample_kernel(const DevCtx* __restrict__ ctx, RngKey key, u64 op0, u64* __restrict__ u,
                                                                         u64* __restrict__ e) {
   const u32 n = ctx->n, KK = ctx->KK;
   const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
   const u32 op = blockIdx.y;
   if (x >= n) return;
   const u64 gop = op0 + op;
-  u32 r[4], w[4];
-  philox4x32(x, (u32)gop, (u32)(gop >> 32), 0u, (u32)seed, (u32)(seed >> 32), r);
-  philox4x32(x, (u32)gop, (u32)(gop >> 32), 1u, (u32)seed, (u32)(seed >> 32), w);
+  u32 r[5];
+  chacha20_block<5>(key, x, (u32)gop, (u32)(gop >> 32), 0u, r);
   const int tern = (int)(((u64)r[0] * 3u) >> 32) - 1;
-  const int e0 = gauss_noise(r[1], r[2]), e1 = gauss_noise(r[3], w[0]);
+  const int e0 = gauss_noise(r[1], r[2]), e1 = gauss_noise(r[3], r[4]);
   for (u32 i = 0; i < KK; i++) {
     const u64 q = ctx->mod[i].q;
     u[((size_t)op * KK + i) * n + x] = small_to_residue(tern, q);
@@ -158,26 +146,19 @@ __global__ __launch_bounds__(kClientThreads) void encrypt_sample_kernel(const De
 }
 
 // The rest of a public-key encryption in one pass over the key-level product c2 = INTT(pk (.) NTT(u)), u64[op][2][KK][N]:
-// + e (regenerated from the same Philox counters as encrypt_sample_kernel, never stored), SEAL's divide-and-round by the
+// + e (regenerated from the same ChaCha block as encrypt_sample_kernel, never stored), SEAL's divide-and-round by the
 // special prime (RNSTool::divide_and_round_q_last, as ks_moddown_kernel), and on polynomial 0 the scaled plaintext
 // floor(q/t) m + r (plain_addsub_kernel).  plain: u64[ops or 1][N]; out: u64[op][2][K][N].
-__global__ __launch_bounds__(kClientThreads) void encrypt_finish_kernel(const DevCtx* __restrict__ ctx, u64 seed, u64 op0, const u64* __restrict__ c2,
+__global__ __launch_bounds__(kClientThreads) void encrypt_finish_kernel(const DevCtx* __restrict__ ctx, RngKey key, u64 op0, const u64* __restrict__ c2,
                                                                         const u64* __restrict__ plain, size_t pstride, u64* __restrict__ out) {
   const u32 n = ctx->n, K = ctx->K, KK = ctx->KK;
   const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
   const u32 c = blockIdx.y, op = blockIdx.z;
   if (x >= n) return;
   const u64 gop = op0 + op;
-  u32 r[4];
-  int err;
-  philox4x32(x, (u32)gop, (u32)(gop >> 32), 0u, (u32)seed, (u32)(seed >> 32), r);
-  if (c == 0) {
-    err = gauss_noise(r[1], r[2]);
-  } else {
-    u32 w[4];
-    philox4x32(x, (u32)gop, (u32)(gop >> 32), 1u, (u32)seed, (u32)(seed >> 32), w);
-    err = gauss_noise(r[3], w[0]);
-  }
+  u32 r[5];
+  chacha20_block<5>(key, x, (u32)gop, (u32)(gop >> 32), 0u, r);
+  const int err = c == 0 ? gauss_noise(r[1], r[2]) : gauss_noise(r[3], r[4]);
   const u64* acc = c2 + ((size_t)op * 2 + c) * KK * n + x;
   u64 fix = 0, m = 0;
   if (c == 0) {
@@ -226,12 +207,12 @@ __global__ __launch_bounds__(kClientThreads) void add_key_level_kernel(const Dev
 
 // ---- KeyGenerator (seal_fhe/src/key_generator.rs:20-200) ----
 // s[i][x] = ternary secret polynomial (coefficient form) in every key-level residue
-__global__ __launch_bounds__(kClientThreads) void keygen_ternary_kernel(const DevCtx* __restrict__ ctx, u64 seed, u64 stream, u64* __restrict__ s) {
+__global__ __launch_bounds__(kClientThreads) void keygen_ternary_kernel(const DevCtx* __restrict__ ctx, RngKey key, u64 stream, u64* __restrict__ s) {
   const u32 n = ctx->n, KK = ctx->KK;
   const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
   if (x >= n) return;
-  u32 r[4];
-  philox4x32(x, (u32)stream, (u32)(stream >> 32), 0x5Eu, (u32)seed, (u32)(seed >> 32), r);
+  u32 r[1];
+  chacha20_block<1>(key, x, (u32)stream, (u32)(stream >> 32), 0x5Eu, r);
   const int tern = (int)(((u64)r[0] * 3u) >> 32) - 1;
   for (u32 i = 0; i < KK; i++) s[(size_t)i * n + x] = small_to_residue(tern, ctx->mod[i].q);
 }
@@ -239,20 +220,22 @@ __global__ __launch_bounds__(kClientThreads) void keygen_ternary_kernel(const De
 // For `count` independent "encryptions of zero" at the key level (SEAL encrypt_zero_symmetric, NTT form):
 //   a[z][i][x] = uniform residue mod q_i (sampled directly in the transform domain),  e[z][i][x] = one rounded Gaussian
 //   per coefficient in every residue (coefficient form; the caller transforms it).
-__global__ __launch_bounds__(kClientThreads) void keygen_sample_kernel(const DevCtx* __restrict__ ctx, u64 seed, u64 stream0, u64* __restrict__ a,
+__global__ __launch_bounds__(kClientThreads) void keygen_sample_kernel(const DevCtx* __restrict__ ctx, RngSeed seed, u64 stream0, u64* __restrict__ a,
                                                                        u64* __restrict__ e) {
   const u32 n = ctx->n, KK = ctx->KK;
   const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
   const u32 z = blockIdx.y;
   if (x >= n) return;
   const u64 stream = stream0 + z;
-  u32 g[4];
-  philox4x32(x, (u32)stream, (u32)(stream >> 32), 0xE0u, (u32)seed, (u32)(seed >> 32), g);
+  u32 g[2];
+  chacha20_block<2>(seed.secret, x, (u32)stream, (u32)(stream >> 32), 0xE0u, g);  // the error is secret
   const int err = gauss_noise(g[0], g[1]);
+  u32 blk[16];
   for (u32 i = 0; i < KK; i++) {
     const DevMod& dm = ctx->mod[i];
-    u32 r[4];
-    philox4x32(x, (u32)stream, (u32)(stream >> 32), 0xA0u + i, (u32)seed, (u32)(seed >> 32), r);
+    // the uniform polynomial is published: its own key; one block serves four residues (4 words each)
+    if ((i & 3) == 0) chacha20_block<16>(seed.pub, x, (u32)stream, (u32)(stream >> 32), 0xA0u + (i >> 2), blk);
+    const u32* r = blk + 4 * (i & 3);
     // 128 uniform bits reduced mod q_i: bias below 2^-66 (SEAL rejects instead; indistinguishable at this size)
     const u128 wide = ((u128)(((u64)r[0] << 32) | r[1]) << 64) | (((u64)r[2] << 32) | r[3]);
     a[((size_t)z * KK + i) * n + x] = reduce128(wide >> 1, dm);
@@ -420,11 +403,11 @@ __global__ __launch_bounds__(kClientThreads) void dot_plain_kernel(const DevCtx*
 }
 
 // ---- launchers ----
-hipError_t launch_keygen_ternary(const DevCtx* ctx, u32 n, u64 seed, u64 stream, u64* s_out, hipStream_t s) {
-  keygen_ternary_kernel<<<cgrid(n, 1), kClientThreads, 0, s>>>(ctx, seed, stream, s_out);
+hipError_t launch_keygen_ternary(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 stream, u64* s_out, hipStream_t s) {
+  keygen_ternary_kernel<<<cgrid(n, 1), kClientThreads, 0, s>>>(ctx, seed.secret, stream, s_out);
   return hipGetLastError();
 }
-hipError_t launch_keygen_sample(const DevCtx* ctx, u32 n, u64 seed, u64 stream0, u64* a, u64* e, size_t count, hipStream_t s) {
+hipError_t launch_keygen_sample(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 stream0, u64* a, u64* e, size_t count, hipStream_t s) {
   keygen_sample_kernel<<<cgrid(n, (u32)count), kClientThreads, 0, s>>>(ctx, seed, stream0, a, e);
   return hipGetLastError();
 }
@@ -484,13 +467,13 @@ hipError_t launch_decrypt_round(const DevCtx* ctx, u32 n, const u64* ct, u32 siz
   decrypt_round_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, ct, size, acc, plain);
   return hipGetLastError();
 }
-hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, u64 seed, u64 op0, u64* u, u64* e, size_t ops, hipStream_t s) {
-  encrypt_sample_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, seed, op0, u, e);
+hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 op0, u64* u, u64* e, size_t ops, hipStream_t s) {
+  encrypt_sample_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, seed.secret, op0, u, e);
   return hipGetLastError();
 }
-hipError_t launch_encrypt_finish(const DevCtx* ctx, u32 n, u64 seed, u64 op0, const u64* c2, const u64* plain, size_t pstride, u64* out, size_t ops,
+hipError_t launch_encrypt_finish(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 op0, const u64* c2, const u64* plain, size_t pstride, u64* out, size_t ops,
                                  hipStream_t s) {
-  encrypt_finish_kernel<<<cgrid(n, 2, (u32)ops), kClientThreads, 0, s>>>(ctx, seed, op0, c2, plain, pstride, out);
+  encrypt_finish_kernel<<<cgrid(n, 2, (u32)ops), kClientThreads, 0, s>>>(ctx, seed.secret, op0, c2, plain, pstride, out);
   return hipGetLastError();
 }
 hipError_t launch_encrypt_dyadic(const DevCtx* ctx, u32 n, u32 KK, const u64* un, const u64* pk, u64* c, size_t ops, hipStream_t s) {
