@@ -589,6 +589,21 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       h.mid_res_i[h.mid_ni++] = (unsigned char)r;
   }
 
+  // key switching: a key prime takes the FP64 policy when its split range plan exists, the integer policy when its
+  // twiddle tables are Shoup pairs (use_f64 == 0); an FP64-table prime WITHOUT a split plan has neither form
+  h.ks_nd = h.ks_ni = 0;
+  h.ks_split_ok = 1;
+  for (u32 i = 0; i < KK; i++) {
+    if (h.mod[i].use_f64 && h.mod[i].split_ok)
+      h.ks_res_d[h.ks_nd++] = (unsigned char)i;
+    else if (!h.mod[i].use_f64)
+      h.ks_res_i[h.ks_ni++] = (unsigned char)i;
+    else
+      h.ks_split_ok = 0;
+  }
+  if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS_INT"))  // integer-policy primes through the whole-polynomial key switch (A/B, tests)
+    if (env[0] == '1' && h.ks_ni) h.ks_split_ok = 0;
+
   {
     // N = 4096: the multiply's middle kernel loses more on the doubled load count than its head gains (measured -1.4 %)
     bool ks = true, mul = h.aux_f64 != 0 && h.logn >= 13;

@@ -116,6 +116,11 @@ struct DevCtx {
   unsigned char mid_res_d[kMaxMod];
   unsigned char mid_res_i[kMaxMod];
   u32 mid_nd, mid_ni;
+  // split key switch: key-prime indices (0..KK-1) handled by the FP64 / integer middle kernel; ks_split_ok: every key prime
+  // has a policy the split kernels implement (FP64 with a split range plan, or integer with Shoup twiddle tables)
+  unsigned char ks_res_d[kMaxKey + 3];
+  unsigned char ks_res_i[kMaxKey + 3];
+  u32 ks_nd, ks_ni, ks_split_ok, pad5;
 
   // ---- key switching (special prime = mod[KK-1]) ----
   u64 qsp_half;                        // q_sp >> 1

@@ -289,13 +289,14 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
   u64* ACC = scratch + count * (size_t)KK * K * n;
   std::vector<u32> mods;
   for (u32 i = 0; i < KK; i++) mods.push_back(i);
-  bool split_ok = split_ks_ && h.logn >= 12 && h.logn <= 14;
-  for (u32 i = 0; i < KK; i++) split_ok = split_ok && h.mod[i].split_ok;
+  const bool split_ok = split_ks_ && h.logn >= 12 && h.logn <= 14 && h.ks_split_ok;
   if (split_ok) {
-    // head / middle / tail split transforms (kernels_split.hip): 3 launches, no whole-polynomial NTT round trips
-    HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, K, target, tstride, T, count, s));
-    HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, KK, T, key, ACC, count, s));
-    HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, h.pack_ks != 0, ACC, base, bstride, base_mask, extra, out2, count, s));
+    // head / middle / tail split transforms (kernels_split.hip): 3 launches (4 when FP64- and integer-policy key primes are
+    // mixed: one middle kernel per policy), no whole-polynomial NTT round trips
+    const bool mixed = h.ks_ni != 0;
+    HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, mixed, K, target, tstride, T, count, s));
+    HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, key, ACC, count, s));
+    HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, h.pack_ks != 0, mixed, ACC, base, bstride, base_mask, extra, out2, count, s));
     return kOk;
   }
   HB_LAUNCH(kKernKsDecompose, count, launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));

@@ -25,10 +25,10 @@ hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u
 hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse,
                             int scale_mode, hipStream_t s);
 // split (head / middle / tail) key switch, kernels_split.hip
-hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
-hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops,
-                         hipStream_t s);
-hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
+hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
+hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd, const unsigned char* res_i, u32 ni,
+                         const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s);
+hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
                           size_t ops, hipStream_t s);
 // split BEHZ multiply (2 x 2 -> 3), K <= 4
 hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,

@@ -497,11 +497,18 @@ __device__ __forceinline__ void nat_store(double* __restrict__ region, u32 n, si
   }
 }
 
+__device__ __forceinline__ bool residue_is_f64(const DevMod& dm) { return dm.use_f64 && dm.split_ok; }
+template <class A, int NC>
+__device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], const typename A::Tw* __restrict__ tw);
+
 // -------------------------------------------------------------------------------------------------
 // key switch, head: T[op][I][J] = first three forward stages over q_I of (target_J mod q_I)
 // grid: (N/8/256, K, ops)
+// MIXED: some key primes take the integer policy (user primes >= 2^50, e.g. CoeffModulus::create(8192,[54,54,54,56])):
+// their rows of T hold lazy u64 values in [0, 4q) instead of doubles; the policy is a property of the residue I, so the
+// branch is wave-uniform.  MIXED = false is the all-FP64 kernel (every SEAL default parameter set).
 // -------------------------------------------------------------------------------------------------
-template <int L, bool PACK>
+template <int L, bool PACK, bool MIXED>
 __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                const u64* __restrict__ target, size_t tstride, double* __restrict__ T) {
   constexpr int NC = 1 << head_log(L);
@@ -516,14 +523,34 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
   const u64 qJ = ctx->mod[J].q;
   for (u32 I = 0; I < KK; I++) {
     const DevMod& dm = ctx->mod[I];
+    if constexpr (MIXED) {
+      if (!residue_is_f64(dm)) {
+        const ArithI ai(dm);
+        const bool shrink = qJ > dm.q;
+        u64 w[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) w[k] = shrink ? reduce64(x[k], dm) : x[k];
+        head_fwd(ai, w, twf_base + (size_t)I * N);
+        u64* dsti = reinterpret_cast<u64*>(T) + (((size_t)op * KK + I) * K + J) * N;
+#pragma unroll
+        for (int k = 0; k < NC; k++) dsti[t + (size_t)k * Q] = w[k];
+        continue;
+      }
+    }
     const ArithD ar(dm);
     const MulOpD* tw = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * N);
     const bool need_reduce = qJ > dm.q;
     double v[NC];
 #pragma unroll
     for (int k = 0; k < NC; k++) {
-      const double d = ar.from_u64(x[k]);
-      v[k] = need_reduce ? ar.reduce(d) : d;
+      if constexpr (MIXED) {
+        // the digit may come from an integer-policy prime (up to 61 bits): from_u64 is exact below 2^52 only, so bring it
+        // under q_I with integer arithmetic first
+        v[k] = ar.from_u64(need_reduce ? reduce64(x[k], dm) : x[k]);
+      } else {
+        const double d = ar.from_u64(x[k]);
+        v[k] = need_reduce ? ar.reduce(d) : d;
+      }
     }
     head_fwd(ar, v, tw);
     double* dst = T + (((size_t)op * KK + I) * K + J) * N;
@@ -537,10 +564,13 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
 // key rows, run the block-local inverse stages of both accumulators.
 // grid: ops8 * KK * NBLK (slice-major per XCD, see the index computation)
 // -------------------------------------------------------------------------------------------------
+// residues / nres: the key-prime indices this launch handles (DevCtx::ks_res_d: the FP64-policy ones, all of them for the
+// SEAL default sets; the integer-policy ones go through ks_mid_int_kernel below)
 template <int L, bool PACK>
 __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                        const MulOp* __restrict__ twi_base, const double* __restrict__ T,
-                                                                       const u64* __restrict__ key, double* __restrict__ ACC, u32 ops) {
+                                                                       const u64* __restrict__ key, double* __restrict__ ACC, u32 ops,
+                                                                       const unsigned char* __restrict__ residues, u32 nres) {
   using Sh = SplitShape<L>;
   using A = ArithD;
   __shared__ double smem[KS_GROUP_MAX(L) * Sh::BLOCK];
@@ -554,7 +584,8 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
   const u32 op = (slot % per) * 8u + xcd;
   const u32 ib = slot / per;
   const u32 blk = ib % Sh::NBLK;
-  const u32 I = ib / Sh::NBLK;
+  const u32 I = __builtin_amdgcn_readfirstlane((u32)residues[ib / Sh::NBLK]);  // a byte load lands in a VGPR: make it scalar again
+  (void)nres;
   if (op >= ops) return;
   const DevMod& dm = ctx->mod[I];
   const A ar(dm);
@@ -639,13 +670,119 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
   }
 }
 
+
+// The same for integer-policy key primes (Harvey butterflies on lazy u64 values, Shoup twiddles): the digit rows arrive as
+// u64 in [0, 4q) from the head's integer branch; the products with the key rows are summed in 128 bits and reduced once per
+// four digits (4 * 4q * q < 2^126 for q < 2^61); the accumulators leave as lazy u64 in [0, 2q).
+#ifndef KS_MID_INT_GROUP
+#define KS_MID_INT_GROUP 2
+#endif
+template <int L>
+__global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+                                                                             const MulOp* __restrict__ twi_base, const u64* __restrict__ T,
+                                                                             const u64* __restrict__ key, u64* __restrict__ ACC, u32 ops,
+                                                                             const unsigned char* __restrict__ residues, u32 nres) {
+  using Sh = SplitShape<L>;
+  using A = ArithI;
+  __shared__ u64 smem[KS_MID_INT_GROUP * Sh::BLOCK];
+  const u32 tid = threadIdx.x;
+  const u32 K = ctx->K, KK = ctx->KK;
+  const u32 b = blockIdx.x;
+  const u32 xcd = b & 7u, slot = b >> 3;
+  const u32 per = (ops + 7u) >> 3;
+  const u32 op = (slot % per) * 8u + xcd;
+  const u32 ib = slot / per;
+  const u32 blk = ib % Sh::NBLK;
+  const u32 I = __builtin_amdgcn_readfirstlane((u32)residues[ib / Sh::NBLK]);  // a byte load lands in a VGPR: make it scalar again
+  (void)nres;
+  if (op >= ops) return;
+  const DevMod& dm = ctx->mod[I];
+  const A ar(dm);
+  const MulOp* twf = twf_base + (size_t)I * Sh::N;
+  const MulOp* twi = twi_base + (size_t)I * Sh::N;
+  constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
+  using First = BlkPass<A, L, LOWF0, RF0>;
+  constexpr int RL = split_fwd_radix(L, Sh::NPF - 1);
+  using Last = BlkPass<A, L, 0, RL>;
+  u128 wide[2][kBlkEPT];
+#pragma unroll
+  for (int e = 0; e < kBlkEPT; e++) wide[0][e] = 0, wide[1][e] = 0;
+  auto load_src = [&](u32 J, u64(&dst)[kBlkEPT]) {
+    const u64* src = T + (((size_t)op * KK + I) * K + J) * Sh::N;
+#pragma unroll
+    for (int g = 0; g < First::G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = nt_ld<NtSites<L>::ks_mid_ld>(src + First::elem(tid, blk, g, k));
+  };
+  auto mac = [&](u32 J, const u64(&v)[kBlkEPT]) {
+    const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
+    const u64* k1 = key + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
+#pragma unroll
+    for (int g = 0; g < Last::G; g++) {
+      const u32 base = Last::elem(tid, blk, g, 0);
+      constexpr int W = 1 << RL;
+#pragma unroll
+      for (int k = 0; k < W; k += 2) {
+        const ulonglong2 ka = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
+        const ulonglong2 kc = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
+        const int e = g * W + k;
+        wide[0][e] += (u128)v[e] * ka.x;
+        wide[0][e + 1] += (u128)v[e + 1] * ka.y;
+        wide[1][e] += (u128)v[e] * kc.x;
+        wide[1][e + 1] += (u128)v[e + 1] * kc.y;
+      }
+    }
+    if ((J & 3u) == 3u) {
+#pragma unroll
+      for (int e = 0; e < kBlkEPT; e++) wide[0][e] = reduce128(wide[0][e], dm), wide[1][e] = reduce128(wide[1][e], dm);
+    }
+  };
+  auto group = [&](u32 J0, auto np_tag) {
+    constexpr int NP = decltype(np_tag)::value;
+    u64 v[NP][kBlkEPT];
+#pragma unroll
+    for (int i = 0; i < NP; i++) load_src(J0 + i, v[i]);
+    if (J0 > 0) __syncthreads();
+    const MulOp* twf_j = twf;
+    asm volatile("" : "+s"(twf_j));
+    mid_forward_multi<A, L, NP>(ar, v, smem, tid, blk, twf_j, 0u);
+#pragma unroll
+    for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
+  };
+  u32 J = 0;
+  if constexpr (KS_MID_INT_GROUP >= 2)
+    for (; J + 2 <= K; J += 2) group(J, std::integral_constant<int, 2>{});
+  for (; J < K; J++) group(J, std::integral_constant<int, 1>{});
+  u64 acc[2][kBlkEPT];
+#pragma unroll
+  for (int e = 0; e < kBlkEPT; e++) acc[0][e] = reduce128(wide[0][e], dm), acc[1][e] = reduce128(wide[1][e], dm);
+  constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
+  using Out = BlkPass<A, L, LOWI, RI>;
+  __syncthreads();
+  if constexpr (KS_MID_INT_GROUP >= 2) {
+    mid_inverse_multi<A, L, 2>(ar, acc, smem, tid, blk, twi, 0u);
+  } else {
+    mid_inverse<A, L, 0>(ar, acc[0], smem, tid, blk, twi, 0u);
+    __syncthreads();
+    mid_inverse<A, L, 0>(ar, acc[1], smem, tid, blk, twi, 0u);
+  }
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    u64* dst = ACC + (((size_t)op * 2 + c) * KK + I) * Sh::N;
+#pragma unroll
+    for (int g = 0; g < Out::G; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << RI); k++) nt_st<NtSites<L>::ks_mid_st>(dst + Out::elem(tid, blk, g, k), acc[c][g * (1 << RI) + k]);
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // key switch, tail: last two inverse stages + n^{-1} on the coefficients {t + k*N/4}, then SEAL's mod-down
 // by the special prime with rounding, added to the base ciphertext.
 // grid: (N/4/256, 2, ops)
 // -------------------------------------------------------------------------------------------------
-template <int L>
-__device__ __forceinline__ void tail_inverse4(const ArithD& ar, double (&v)[4], const MulOpD* __restrict__ tw, u32 mask) {
+template <int L, class A = ArithD>
+__device__ __forceinline__ void tail_inverse4(const A& ar, typename A::V (&v)[4], const typename A::Tw* __restrict__ tw, u32 mask) {
   if ((mask >> 8) & 1u) {
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
@@ -661,7 +798,8 @@ __device__ __forceinline__ void tail_inverse4(const ArithD& ar, double (&v)[4], 
   ar.inv(v[1], v[3], tw[1]);
 }
 
-template <int L, bool PACK>
+// MIXED: rows of ACC that belong to integer-policy key primes hold lazy u64 values in [0, 2q) (ks_mid_int_kernel)
+template <int L, bool PACK, bool MIXED>
 __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                const double* __restrict__ ACC, const u64* __restrict__ base, size_t bstride,
                                                                u32 base_mask, const u64* __restrict__ extra, u64* __restrict__ out) {
@@ -672,7 +810,22 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
   const double* acc = ACC + ((size_t)op * 2 + c) * KK * N;
   // special prime first
   u64 tl[4];
-  {
+  bool sp_done = false;
+  if constexpr (MIXED) {
+    const DevMod& sp = ctx->mod[KK - 1];
+    if (!residue_is_f64(sp)) {
+      const ArithI ai(sp);
+      const u64* src = reinterpret_cast<const u64*>(acc) + (size_t)(KK - 1) * N + t;
+      u64 w[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) w[k] = src[(size_t)k * Q];
+      tail_inverse4<L, ArithI>(ai, w, twi_base + (size_t)(KK - 1) * N, 0u);
+#pragma unroll
+      for (int k = 0; k < 4; k++) tl[k] = add_mod(ai.scale_canonical(w[k], sp.ninv), ctx->qsp_half, sp.q);
+      sp_done = true;
+    }
+  }
+  if (!sp_done) {
     const DevMod& sp = ctx->mod[KK - 1];
     const ArithD ar(sp);
     const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK - 1) * N);
@@ -686,15 +839,34 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
   const u64 qsp = ctx->mod[KK - 1].q;
   for (u32 J = 0; J < K; J++) {
     const DevMod& mj = ctx->mod[J];
-    const ArithD ar(mj);
-    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)J * N);
-    double v[4];
+    u64 av[4];
+    bool done = false;
+    if constexpr (MIXED) {
+      if (!residue_is_f64(mj)) {
+        const ArithI ai(mj);
+        const u64* src = reinterpret_cast<const u64*>(acc) + (size_t)J * N + t;
+        u64 w[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, t + (size_t)k * Q);
-    tail_inverse4<L>(ar, v, tw, mj.split_inv_mask);
+        for (int k = 0; k < 4; k++) w[k] = src[(size_t)k * Q];
+        tail_inverse4<L, ArithI>(ai, w, twi_base + (size_t)J * N, 0u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) av[k] = ai.scale_canonical(w[k], mj.ninv);
+        done = true;
+      }
+    }
+    if (!done) {
+      const ArithD ar(mj);
+      const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)J * N);
+      double v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, t + (size_t)k * Q);
+      tail_inverse4<L>(ar, v, tw, mj.split_inv_mask);
+#pragma unroll
+      for (int k = 0; k < 4; k++) av[k] = ar.scale_canonical(v[k], mj.ninv_d);
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
+      const u64 a = av[k];
       u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
       tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
       u64 d = sub_mod(a, tk, mj.q);
@@ -714,8 +886,6 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
 // succeeded, integer path otherwise), residue K + j uses the auxiliary prime Bsk_j: the library's own FP64-pipe base
 // when DevCtx::aux_f64 (AUXD instantiations, conversions in exact FP64), SEAL's 61-bit base on the integer path otherwise.
 // =================================================================================================
-
-__device__ __forceinline__ bool residue_is_f64(const DevMod& dm) { return dm.use_f64 && dm.split_ok; }
 
 // A pointer the compiler can prove wave-uniform (scalar loads stay possible) but cannot hoist loads through:
 // used to keep twiddle loads inside the transform that consumes them.
@@ -1339,50 +1509,61 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
   }
 
 template <int L>
-static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, bool pack, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
+static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
   const dim3 grid(((1u << L) >> head_log(L)) / kHeadThreads, K, (unsigned)ops);
-  if (pack)
-    ks_head_kernel<L, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
+  if (mixed)
+    ks_head_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
+  else if (pack)
+    ks_head_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
   else
-    ks_head_kernel<L, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
+    ks_head_kernel<L, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
   return hipGetLastError();
 }
-// pack: DevCtx::pack_ks of the context behind `ctx` (48-bit packed intermediates, see nat_load)
-hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(ks_head_t, ctx, twf, pack, K, target, tstride, T, ops, s)
+// pack: DevCtx::pack_ks of the context behind `ctx` (48-bit packed intermediates, see nat_load); mixed: DevCtx::ks_ni != 0
+hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(ks_head_t, ctx, twf, pack, mixed, K, target, tstride, T, ops, s)
 }
 
+// res_d / nd, res_i / ni: device lists (inside the DevCtx) of the key primes that take the FP64 / the integer policy
 template <int L>
-static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops,
-                           hipStream_t s) {
+static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
+                           const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s) {
   using Sh = SplitShape<L>;
   const size_t ops8 = (ops + 7) / 8 * 8;
-  const dim3 grid((unsigned)(ops8 * KK * Sh::NBLK));
-  if (pack)
-    ks_mid_kernel<L, true><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops);
-  else
-    ks_mid_kernel<L, false><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops);
+  if (nd) {
+    const dim3 grid((unsigned)(ops8 * nd * Sh::NBLK));
+    if (pack)
+      ks_mid_kernel<L, true><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd);
+    else
+      ks_mid_kernel<L, false><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd);
+  }
+  if (ni) {
+    const dim3 grid((unsigned)(ops8 * ni * Sh::NBLK));
+    ks_mid_int_kernel<L><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, T, key, ACC, (u32)ops, res_i, ni);
+  }
   return hipGetLastError();
 }
-hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, u32 KK, const u64* T, const u64* key, u64* ACC,
-                         size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(ks_mid_t, ctx, twf, twi, pack, KK, T, key, ACC, ops, s)
+hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd,
+                         const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(ks_mid_t, ctx, twf, twi, pack, res_d, nd, res_i, ni, T, key, ACC, ops, s)
 }
 
 template <int L>
-static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
+static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
                             const u64* extra, u64* out2, size_t ops, hipStream_t s) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
-  if (pack)
-    ks_tail_kernel<L, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
+  if (mixed)
+    ks_tail_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
+  else if (pack)
+    ks_tail_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
   else
-    ks_tail_kernel<L, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
+    ks_tail_kernel<L, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
   return hipGetLastError();
 }
 // extra: optional ciphertexts u64[ops][2][K][N] added to the result
-hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
+hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
                           const u64* extra, u64* out2, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(ks_tail_t, ctx, twi, pack, ACC, base, bstride, base_mask, extra, out2, ops, s)
+  SPLIT_DISPATCH(ks_tail_t, ctx, twi, pack, mixed, ACC, base, bstride, base_mask, extra, out2, ops, s)
 }
 
 template <int L>
