@@ -175,6 +175,7 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 1024));
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS")) split_ks_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_MUL")) split_mul_ = env[0] != '1';
+  if (const char* env = std::getenv("HIPBFV_NO_FUSED_TAIL")) fuse_mulrelin_ = env[0] != '1';
   if (hipMalloc((void**)&status_dev_, 256) == hipSuccess)
     (void)hipMemset(status_dev_, 0xFF, 256);
   else {
@@ -329,7 +330,36 @@ int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t coun
 int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend) {
   const DevCtx& h = ctx_->host();
   if (h.KK < 2 || !rk) return kNoKey;
-  const size_t cs = (size_t)3 * h.K * h.n, c2 = (size_t)2 * h.K * h.n;
+  const u32 n = h.n, K = h.K, KK = h.KK, S = h.S, R = K + S;
+  const size_t cs = (size_t)3 * K * n, c2 = (size_t)2 * K * n;
+  const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
+  // Fused pipeline (all-FP64 contexts: every SEAL default set up to N = 16384): six launches; the product's c0 and c1 are
+  // formed inside the last one (mulrelin_tail_kernel) and only c2 -- the key-switch target -- is written by mul_tail.
+  const bool fused = fuse_mulrelin_ && split_mul_ && split_ks_ && h.aux_f64 && h.ks_split_ok && h.ks_ni == 0 && kneed <= 8 && h.logn >= 12 && h.logn <= 14;
+  if (fused) {
+    const size_t ext_words = (size_t)4 * R * n, d_words = (size_t)3 * R * n, t_words = (size_t)KK * K * n, acc_words = (size_t)2 * KK * n, c2_words = (size_t)K * n;
+    const size_t per_op = ext_words + d_words + t_words + acc_words + c2_words;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>({chunk_ops_, (size_t)65535 / (R * 4), (size_t)65535 / ((size_t)KK * K)}));
+    ScratchGuard sg(pool_, std::min(chunk, count) * per_op * sizeof(u64), s);
+    if (!sg.p) return kOutOfMemory;
+    const size_t cc = std::min(chunk, count);
+    u64* ext = (u64*)sg.p;
+    u64* D = ext + cc * ext_words;
+    u64* T = D + cc * d_words;
+    u64* ACC = T + cc * t_words;
+    u64* C2 = ACC + cc * acc_words;
+    for (size_t off = 0; off < count; off += chunk) {
+      const size_t c = std::min(chunk, count - off);
+      HB_LAUNCH(kKernMulHead, c * 4, launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, h.pack_mul != 0, kneed, a + off * c2, b + off * c2, ext, c, s));
+      HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_mul != 0, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s));
+      HB_LAUNCH(kKernMulTail, c, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, true, h.pack_mul != 0, h.conv_grid != 0, kneed, D, C2, c, s, 2, 1));
+      HB_LAUNCH(kKernKsHead, c, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, false, K, C2, c2_words, T, c, s));
+      HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, rk, ACC, c, s));
+      HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail(ctx_->dev(), h.tw_inv, h.logn, h.pack_mul != 0, h.conv_grid != 0, h.pack_ks != 0, kneed, D, ACC,
+                                                    addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s));
+    }
+    return note_result(out2, 2, K, count, s);
+  }
   const size_t chunk = chunk_ops_;
   ScratchGuard sg(pool_, std::min(chunk, count) * cs * sizeof(u64), s);
   if (!sg.p) return kOutOfMemory;

@@ -59,6 +59,42 @@ __device__ __forceinline__ void ntt_st(T* p, T v) {
 // pass are bank-conflict free).
 // =====================================================================================
 
+// ---- which LDS exchanges need a workgroup barrier ----
+// Virtual thread vt = tid + g*T handles, in the pass over the index window [LOW, LOW+R), the elements
+// (vt >> LOW) << (LOW+R) | k << LOW | (vt & (2^LOW - 1)).  The lane bits of vt (0..5), k and g range over everything inside
+// one wavefront; only the WAVE-ID bits of vt (6 .. log2 T - 1) tie a wavefront to a part of the polynomial: bit b lands at
+// element bit b + R when b >= LOW, else at b.  When two consecutive passes send every wave-id bit to the same element
+// bit, a wavefront reads back in the second pass exactly the elements it wrote in the first: the exchange between them is
+// private to the wavefront, whose LDS accesses execute in order -- no s_barrier.  At N = 8192 (windows 9..12, 6..8, 3..5,
+// 0..2) only the first exchange of a forward transform (the last of an inverse one) couples wavefronts: 1 workgroup
+// barrier per transform instead of 4, and after it the eight wavefronts of a workgroup run their 2 x 512-coefficient
+// blocks independently, so their load / compute / store phases stagger instead of meeting at every pass.
+#ifndef NTT_WAVE_PRIVATE
+#define NTT_WAVE_PRIVATE 1
+#endif
+constexpr int wave_bit_target(int b, int low, int r) { return b >= low ? b + r : b; }
+// pa, pb: forward pass numbers of the two passes an exchange connects
+constexpr bool exchange_is_wave_private(int logn, int ept, int pa, int pb) {
+  if (!NTT_WAVE_PRIVATE) return false;
+  const int logt = logn - ilog2(ept);
+  const int ra = ntt_pass_radix(logn, pa, ept), rb = ntt_pass_radix(logn, pb, ept);
+  const int lowa = logn - ntt_stages_before(logn, pa, ept) - ra, lowb = logn - ntt_stages_before(logn, pb, ept) - rb;
+  for (int b = 6; b < logt; b++)
+    if (wave_bit_target(b, lowa, ra) != wave_bit_target(b, lowb, rb)) return false;
+  return true;
+}
+template <bool PRIVATE>
+__device__ __forceinline__ void exchange_sync() {
+  if constexpr (PRIVATE) {
+    // same wavefront, LDS operations are issued and executed in order: only the compiler must not move them across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 // ---- forward (Cooley-Tukey, gap shrinking) ----
 template <class A, int LOGN, int EPT, int S0, int R>
 __device__ __forceinline__ void fwd_pass_compute(const A& ar, typename A::V (&v)[EPT], u32 tid,
@@ -98,8 +134,8 @@ struct FwdPasses {
     constexpr int S0 = Sh::before(PASS);
     constexpr int LOW = LOGN - S0 - R;
     constexpr int G = EPT >> R;
-    if (PASS > 0) {
-      __syncthreads();
+    if constexpr (PASS > 0) {
+      exchange_sync<exchange_is_wave_private(LOGN, EPT, PASS - 1, PASS)>();
 #pragma unroll
       for (int g = 0; g < G; g++)
 #pragma unroll
@@ -139,7 +175,18 @@ __device__ __forceinline__ void ntt_fwd_to_lds(const A& ar, const u64* __restric
 #pragma unroll
     for (int k = 0; k < (1 << R0); k++) v[g * (1 << R0) + k] = ar.from_u64(ntt_ld<(NTT_NT_FWD & 1) != 0>(src + elem_index<LOW0, R0>(tid + g * Sh::T, k)));
   FwdPasses<A, LOGN, EPT, 0>::run(ar, v, smem, tid, tw, reduce_mask);
-  __syncthreads();
+}
+
+// After a forward transform whose last pass left its results in LDS: element j (0 .. EPT-1) of the set THIS wavefront wrote
+// there, enumerated so that the 64 lanes are 64 consecutive coefficients (512 contiguous bytes per wave instruction).  The
+// last pass has LOW = 0: wave-id bit b sits at element bit b + R, i.e. the wave id occupies [6 + R, log2 T + R).
+template <int LOGN, int EPT>
+__device__ __forceinline__ u32 own_element_after_fwd(u32 tid, u32 j) {
+  using Sh = NttShape<LOGN, EPT>;
+  constexpr int R = Sh::radix(Sh::NPASS - 1);
+  constexpr int LOGT = LOGN - ilog2(EPT);
+  const u32 lane = tid & 63u, wave = tid >> 6;
+  return lane | ((j & ((1u << R) - 1u)) << 6) | (wave << (6 + R)) | ((j >> R) << (LOGT + R));
 }
 
 // ---- inverse (Gentleman-Sande, gap growing) ----
@@ -179,7 +226,11 @@ struct InvPasses {
     constexpr int R = Sh::radix(FP);
     constexpr int LOW = LOGN - Sh::before(FP) - R;
     constexpr int G = EPT >> R;
-    __syncthreads();
+    if constexpr (PASS == 0) {
+      if constexpr (!FROM_REGS) __syncthreads();  // the caller filled LDS cooperatively
+    } else {
+      exchange_sync<exchange_is_wave_private(LOGN, EPT, FP + 1, FP)>();
+    }
     if constexpr (!(FROM_REGS && PASS == 0)) {
 #pragma unroll
       for (int g = 0; g < G; g++)
@@ -222,7 +273,18 @@ __device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A:
   // (storing the last pass's 2^R-element runs straight from registers was measured 15 % slower than this staged,
   // fully coalesced store; the mirror-image direct LOAD in ntt_inv_body is 25 % faster than staging)
   ntt_fwd_to_lds<A, LOGN>(ar, x, smem, tid, tw, dm.fwd_reduce_mask);
-  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) ntt_st<(NTT_NT_FWD & 2) != 0>(x + e, ar.canonical(smem[lds_pos(e)]));
+  if constexpr (NTT_WAVE_PRIVATE && Sh::T >= 64) {
+    // every wavefront stores the coefficients its own last pass produced: no barrier before the store either
+    exchange_sync<true>();
+#pragma unroll
+    for (u32 j = 0; j < (u32)kElemsPerThread; j++) {
+      const u32 e = own_element_after_fwd<LOGN, kElemsPerThread>(tid, j);
+      ntt_st<(NTT_NT_FWD & 2) != 0>(x + e, ar.canonical(smem[lds_pos(e)]));
+    }
+  } else {
+    __syncthreads();
+    for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) ntt_st<(NTT_NT_FWD & 2) != 0>(x + e, ar.canonical(smem[lds_pos(e)]));
+  }
 }
 
 template <int LOGN>

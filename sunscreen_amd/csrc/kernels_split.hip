@@ -1238,44 +1238,58 @@ __device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const NatRaw
 
 // mul tail: grid (N/4/256, 3 polys, ops); out = [ops][3][K][N] canonical
 // GRID (DevCtx::conv_grid, 8-prime all-FP64 instantiation only): floor sums formed exactly and reduced once (griddot.hpp)
-template <int L, int KMAX, bool AUXD, bool PACK, bool GRID>
-__global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
-                                                                const u64* __restrict__ D, u64* __restrict__ out) {
+// All-FP64 tail of the BEHZ multiply for the 4 coefficients {t + k*N/4} of ONE output polynomial: last two inverse stages of
+// every residue, scaling, fast_floor + Shenoy-Kumaresan conversion (behz_floor_sk_multi_d): canonical data residues in res.
+// d: the polynomial's R residue rows in D, already offset by t.
+template <int L, int KMAX, bool PACK, bool GRID>
+__device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base, const u64* __restrict__ d, u32 t,
+                                                   u64 (&res)[KMAX][4]) {
   constexpr u32 N = 1u << L, Q = N >> kTailLog;
-  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
-  const u32 poly = blockIdx.y, op = blockIdx.z;
-  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
-  const u64* d = D + ((size_t)op * 3 + poly) * R * N + t;
-  u64* o = out + ((size_t)op * 3 + poly) * K * N + t;
-  if constexpr (AUXD) {
+  const u32 K = ctx->K, KK = ctx->KK;
     double yc[KMAX][4];
 #pragma unroll
-    for (int i = 0; i < KMAX; i++) {
-      if ((u32)i < K) {
-        const DevMod& dm = ctx->mod[i];
-        const ArithD ar(dm);
-        double r4[4];
-        NatRaw<PACK> raw[4];
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const DevMod& dm = ctx->mod[i];
+      const ArithD ar(dm);
+      double r4[4];
+      NatRaw<PACK> raw[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d - t + (size_t)i * N), N, t + (size_t)k * Q);
-        tail_inv4_scale_d<PACK>(ar, raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
+      for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d - t + (size_t)i * N), N, t + (size_t)k * Q);
+      tail_inv4_scale_d<PACK>(ar, raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
 #pragma unroll
-        for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
-      }
+      for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
     }
-    u64 res[KMAX][4];
-    behz_floor_sk_multi_d<KMAX, 4, GRID, NatRaw<PACK>>(
-        ctx, yc,
-        [&](u32 j, NatRaw<PACK>(&raw)[4]) {
+  }
+  behz_floor_sk_multi_d<KMAX, 4, GRID, NatRaw<PACK>>(
+      ctx, yc,
+      [&](u32 j, NatRaw<PACK>(&raw)[4]) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d - t + (size_t)(K + j) * N), N, t + (size_t)k * Q);
-        },
-        [&](u32 j, const NatRaw<PACK>(&raw)[4], double(&xb)[4]) {
-          const DevMod& dm = ctx->mod[KK + j];
-          tail_inv4_scale_d<PACK>(ArithD(dm), raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j],
-                                  dm.split_inv_mask, xb);
-        },
-        res);
+        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d - t + (size_t)(K + j) * N), N, t + (size_t)k * Q);
+      },
+      [&](u32 j, const NatRaw<PACK>(&raw)[4], double(&xb)[4]) {
+        const DevMod& dm = ctx->mod[KK + j];
+        tail_inv4_scale_d<PACK>(ArithD(dm), raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j],
+                                dm.split_inv_mask, xb);
+      },
+      res);
+}
+
+template <int L, int KMAX, bool AUXD, bool PACK, bool GRID>
+// poly0 / out_polys: the launch covers product polynomials poly0 .. poly0 + gridDim.y - 1 and writes them to
+// out[op][out_polys][K][N] (3 polynomials from 0 for a stand-alone multiply; only c2, compactly, in the fused
+// multiply + relinearize, whose last kernel forms c0 and c1 itself: mulrelin_tail_kernel)
+__global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+                                                                const u64* __restrict__ D, u64* __restrict__ out, u32 poly0, u32 out_polys) {
+  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 poly = blockIdx.y + poly0, op = blockIdx.z;
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
+  const u64* d = D + ((size_t)op * 3 + poly) * R * N + t;
+  u64* o = out + ((size_t)op * out_polys + (poly - poly0)) * K * N + t;
+  if constexpr (AUXD) {
+    u64 res[KMAX][4];
+    mul_tail_compute_d<L, KMAX, PACK, GRID>(ctx, twi_base, d, t, res);
 #pragma unroll
     for (int i = 0; i < KMAX; i++)
       if ((u32)i < K) {
@@ -1328,6 +1342,61 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
       for (int i = 0; i < KMAX; i++) y[kk][i] = y[kk + 1][i];
 #pragma unroll
       for (int j = 0; j < KMAX + 2; j++) xb[kk][j] = xb[kk + 1][j];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// multiply + relinearize, last kernel: ks_tail whose base ciphertext (c0, c1 of the product) is computed in place from the
+// multiply's intermediates D instead of being read back: c0 and c1 never travel through HBM (1 MB of the 12 MB a mul+relin
+// moves at N = 8192).  Thread t of polynomial c owns the same coefficients {t + k*N/4} in both halves.  All-FP64 contexts
+// only (the SEAL default parameter sets).  grid: (N/4/256, 2, ops)
+// -------------------------------------------------------------------------------------------------
+template <int L, int KMAX, bool PACKM, bool GRID, bool PACKK>
+__global__ __launch_bounds__(kHeadThreads) void mulrelin_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+                                                                     const u64* __restrict__ D, const double* __restrict__ ACC,
+                                                                     const u64* __restrict__ extra, u64* __restrict__ out) {
+  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 c = blockIdx.y, op = blockIdx.z;
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
+  u64 basev[KMAX][4];
+  mul_tail_compute_d<L, KMAX, PACKM, GRID>(ctx, twi_base, D + ((size_t)op * 3 + c) * R * N + t, t, basev);
+  const double* acc = ACC + ((size_t)op * 2 + c) * KK * N;
+  u64 tl[4];
+  {
+    const DevMod& sp = ctx->mod[KK - 1];
+    const ArithD ar(sp);
+    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK - 1) * N);
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = nat_load<PACKK, NtSites<L>::tail_ld>(acc + (size_t)(KK - 1) * N, N, t + (size_t)k * Q);
+    tail_inverse4<L>(ar, v, tw, sp.split_inv_mask);
+#pragma unroll
+    for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
+  }
+  const u64 qsp = ctx->mod[KK - 1].q;
+#pragma unroll
+  for (int J = 0; J < KMAX; J++) {
+    if ((u32)J >= K) break;
+    const DevMod& mj = ctx->mod[J];
+    const ArithD ar(mj);
+    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)J * N);
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = nat_load<PACKK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, t + (size_t)k * Q);
+    tail_inverse4<L>(ar, v, tw, mj.split_inv_mask);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
+      u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
+      tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+      u64 dd = sub_mod(a, tk, mj.q);
+      dd = mul_shoup(dd, ctx->inv_qsp_mod_q[J], mj.q);
+      const size_t off = ((size_t)c * K + J) * N + t + (size_t)k * Q;
+      u64 bv = basev[J][k];
+      if (extra) bv = add_mod(bv, extra[((size_t)op * 2) * K * N + off], mj.q);
+      out[((size_t)op * 2) * K * N + off] = add_mod(bv, dd, mj.q);
     }
   }
 }
@@ -1610,33 +1679,56 @@ hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi,
 
 template <int L>
 static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, bool pack, bool conv_grid, u32 kneed, const u64* D, u64* out, size_t ops,
-                             hipStream_t s) {
-  const dim3 grid((1u << L) / 4 / kHeadThreads, 3, (unsigned)ops);
+                             u32 poly0, u32 npolys, hipStream_t s) {
+  const dim3 grid((1u << L) / 4 / kHeadThreads, npolys, (unsigned)ops);
   if (kneed > 4) {
     if (pack)
       if (conv_grid)
-        mul_tail_kernel<L, 8, true, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+        mul_tail_kernel<L, 8, true, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
       else
-        mul_tail_kernel<L, 8, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+        mul_tail_kernel<L, 8, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
     else
       if (conv_grid)
-        mul_tail_kernel<L, 8, true, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+        mul_tail_kernel<L, 8, true, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
       else
-        mul_tail_kernel<L, 8, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+        mul_tail_kernel<L, 8, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
   } else if (aux_f64) {
     if (pack)
-      mul_tail_kernel<L, 4, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+      mul_tail_kernel<L, 4, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
     else
-      mul_tail_kernel<L, 4, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+      mul_tail_kernel<L, 4, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
   } else {
-    mul_tail_kernel<L, 4, false, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out);
+    mul_tail_kernel<L, 4, false, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
   }
   return hipGetLastError();
 }
 // conv_grid: DevCtx::conv_grid (takes effect in the 8-prime instantiation, kneed > 4)
+// poly0, npolys: which product polynomials to finish (0, 3 = all; 2, 1 = only c2, written compactly as out[op][K][N])
 hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, bool pack, bool conv_grid, u32 kneed, const u64* D, u64* out,
-                           size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, pack && aux_f64, conv_grid && aux_f64, kneed, D, out, ops, s)
+                           size_t ops, hipStream_t s, u32 poly0, u32 npolys) {
+  SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, pack && aux_f64, conv_grid && aux_f64, kneed, D, out, ops, poly0, npolys, s)
+}
+
+template <int L>
+static hipError_t mulrelin_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D, const u64* ACC,
+                                  const u64* extra, u64* out2, size_t ops, hipStream_t s) {
+  const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
+  const double* acc = reinterpret_cast<const double*>(ACC);
+#define MRT(KM, PM, GR, PK) mulrelin_tail_kernel<L, KM, PM, GR, PK><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, acc, extra, out2)
+  if (kneed > 4) {
+    if (pack_mul) { if (conv_grid) { if (pack_ks) MRT(8, true, true, true); else MRT(8, true, true, false); } else { if (pack_ks) MRT(8, true, false, true); else MRT(8, true, false, false); } }
+    else { if (conv_grid) { if (pack_ks) MRT(8, false, true, true); else MRT(8, false, true, false); } else { if (pack_ks) MRT(8, false, false, true); else MRT(8, false, false, false); } }
+  } else {
+    if (pack_mul) { if (pack_ks) MRT(4, true, false, true); else MRT(4, true, false, false); }
+    else { if (pack_ks) MRT(4, false, false, true); else MRT(4, false, false, false); }
+  }
+#undef MRT
+  return hipGetLastError();
+}
+// the last kernel of the fused multiply + relinearize of all-FP64 contexts (DevCtx::aux_f64, every key prime FP64-policy)
+hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
+                                const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mulrelin_tail_t, ctx, twi, pack_mul, conv_grid, pack_ks, kneed, D, ACC, extra, out2, ops, s)
 }
 
 }  // namespace hipbfv

@@ -18,9 +18,9 @@
 #include <cstring>
 
 #if defined(__HIPCC__)
-#define HIPBFV_HD __host__ __device__ __forceinline__
+#define HIPBFV_RNG_HD __host__ __device__ __forceinline__
 #else
-#define HIPBFV_HD inline
+#define HIPBFV_RNG_HD inline
 #endif
 
 namespace hipbfv {
@@ -34,7 +34,7 @@ struct RngSeed {
   RngKey pub;
 };
 
-HIPBFV_HD uint32_t rng_rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+HIPBFV_RNG_HD uint32_t rng_rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
 
 #define HIPBFV_QR(a, b, c, d) \
   a += b; d ^= a; d = rng_rotl(d, 16); \
@@ -44,7 +44,7 @@ HIPBFV_HD uint32_t rng_rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c
 
 // out[0..NOUT) = the first NOUT words of the ChaCha20 block (20 rounds + feed-forward) for `key` at input (i0,i1,i2,i3)
 template <int NOUT>
-HIPBFV_HD void chacha20_block(const RngKey& key, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3, uint32_t (&out)[NOUT]) {
+HIPBFV_RNG_HD void chacha20_block(const RngKey& key, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3, uint32_t (&out)[NOUT]) {
   static_assert(NOUT >= 1 && NOUT <= 16, "a block has 16 words");
   const uint32_t s0 = 0x61707865u, s1 = 0x3320646eu, s2 = 0x79622d32u, s3 = 0x6b206574u;  // "expand 32-byte k"
   uint32_t x0 = s0, x1 = s1, x2 = s2, x3 = s3;
