@@ -176,6 +176,7 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS")) split_ks_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_MUL")) split_mul_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_TAIL")) fuse_mulrelin_ = env[0] != '1';
+  if (const char* env = std::getenv("HIPBFV_NO_FUSED_HEAD")) fuse_head_ = env[0] != '1';
   if (hipMalloc((void**)&status_dev_, 256) == hipSuccess)
     (void)hipMemset(status_dev_, 0xFF, 256);
   else {
@@ -352,8 +353,12 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
       const size_t c = std::min(chunk, count - off);
       HB_LAUNCH(kKernMulHead, c * 4, launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, h.pack_mul != 0, kneed, a + off * c2, b + off * c2, ext, c, s));
       HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_mul != 0, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s));
-      HB_LAUNCH(kKernMulTail, c, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, true, h.pack_mul != 0, h.conv_grid != 0, kneed, D, C2, c, s, 2, 1));
-      HB_LAUNCH(kKernKsHead, c, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, false, K, C2, c2_words, T, c, s));
+      if (fuse_head_) {
+        HB_LAUNCH(kKernKsHead, c, launch_mulrelin_head(ctx_->dev(), h.tw_inv, h.tw_fwd, h.logn, h.pack_mul != 0, h.conv_grid != 0, h.pack_ks != 0, kneed, D, T, c, s));
+      } else {
+        HB_LAUNCH(kKernMulTail, c, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, true, h.pack_mul != 0, h.conv_grid != 0, kneed, D, C2, c, s, 2, 1));
+        HB_LAUNCH(kKernKsHead, c, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, false, K, C2, c2_words, T, c, s));
+      }
       HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, rk, ACC, c, s));
       HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail(ctx_->dev(), h.tw_inv, h.logn, h.pack_mul != 0, h.conv_grid != 0, h.pack_ks != 0, kneed, D, ACC,
                                                     addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s));

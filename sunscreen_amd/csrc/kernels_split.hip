@@ -1401,6 +1401,57 @@ __global__ __launch_bounds__(kHeadThreads) void mulrelin_tail_kernel(const DevCt
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// multiply + relinearize, fourth kernel: the tail of the multiply for c2 (the key-switch target) and the head of the key
+// switch in one pass -- c2 never travels through HBM either.  A key-switch head thread owns the NC = 2^head_log coefficients
+// {t + k*N/NC}; those are NC/4 of the multiply tail's groups {t' + k*N/4} (t' = t + h*N/NC), computed one after the other
+// into x[J][k]; then, per digit J and key prime I, the conversion and the first forward stages exactly as ks_head_kernel.
+// All-FP64 contexts only.  grid: (N/NC/256, 1, ops)
+// -------------------------------------------------------------------------------------------------
+template <int L, int KMAX, bool PACKM, bool GRID, bool PACKK>
+__global__ __launch_bounds__(kHeadThreads) void mulrelin_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+                                                                     const MulOp* __restrict__ twf_base, const u64* __restrict__ D,
+                                                                     double* __restrict__ T) {
+  constexpr int NC = 1 << head_log(L);
+  constexpr int GROUPS = NC / 4;
+  constexpr u32 N = 1u << L, Q = N / NC;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 op = blockIdx.z;
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
+  u64 x[KMAX][NC];
+#pragma unroll
+  for (int h = 0; h < GROUPS; h++) {
+    const u32 tt = t + (u32)h * Q;
+    u64 res[KMAX][4];
+    mul_tail_compute_d<L, KMAX, PACKM, GRID>(ctx, twi_base, D + ((size_t)op * 3 + 2) * R * N + tt, tt, res);
+#pragma unroll
+    for (int J = 0; J < KMAX; J++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[J][GROUPS * k + h] = res[J][k];
+  }
+#pragma unroll
+  for (int J = 0; J < KMAX; J++) {
+    if ((u32)J >= K) break;
+    const u64 qJ = ctx->mod[J].q;
+    for (u32 I = 0; I < KK; I++) {
+      const DevMod& dm = ctx->mod[I];
+      const ArithD ar(dm);
+      const MulOpD* tw = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * N);
+      const bool need_reduce = qJ > dm.q;
+      double v[NC];
+#pragma unroll
+      for (int k = 0; k < NC; k++) {
+        const double d = ar.from_u64(x[J][k]);
+        v[k] = need_reduce ? ar.reduce(d) : d;
+      }
+      head_fwd(ar, v, tw);
+      double* dst = T + (((size_t)op * KK + I) * K + J) * N;
+#pragma unroll
+      for (int k = 0; k < NC; k++) nat_store<PACKK, NtSites<L>::ks_head_st>(dst, N, t + (size_t)k * Q, PACKK ? ar.reduce(v[k]) : v[k]);
+    }
+  }
+}
+
 // =================================================================================================
 // Stand-alone two-kernel transforms for N = 32768, whose 256 KB residue polynomials do not fit one CU's LDS:
 // forward = head stages (streaming) + block-local rest; inverse = block-local stages + tail stages (streaming).
@@ -1725,6 +1776,28 @@ static hipError_t mulrelin_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack
 #undef MRT
   return hipGetLastError();
 }
+template <int L>
+static hipError_t mulrelin_head_t(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
+                                  u64* T, size_t ops, hipStream_t s) {
+  const dim3 grid(((1u << L) >> head_log(L)) / kHeadThreads, 1, (unsigned)ops);
+  double* t = reinterpret_cast<double*>(T);
+#define MRH(KM, PM, GR, PK) mulrelin_head_kernel<L, KM, PM, GR, PK><<<grid, kHeadThreads, 0, s>>>(ctx, twi, twf, D, t)
+  if (kneed > 4) {
+    if (pack_mul) { if (conv_grid) { if (pack_ks) MRH(8, true, true, true); else MRH(8, true, true, false); } else { if (pack_ks) MRH(8, true, false, true); else MRH(8, true, false, false); } }
+    else { if (conv_grid) { if (pack_ks) MRH(8, false, true, true); else MRH(8, false, true, false); } else { if (pack_ks) MRH(8, false, false, true); else MRH(8, false, false, false); } }
+  } else {
+    if (pack_mul) { if (pack_ks) MRH(4, true, false, true); else MRH(4, true, false, false); }
+    else { if (pack_ks) MRH(4, false, false, true); else MRH(4, false, false, false); }
+  }
+#undef MRH
+  return hipGetLastError();
+}
+// multiply tail of c2 + key-switch head in one kernel (all-FP64 contexts)
+hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed,
+                                const u64* D, u64* T, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mulrelin_head_t, ctx, twi, twf, pack_mul, conv_grid, pack_ks, kneed, D, T, ops, s)
+}
+
 // the last kernel of the fused multiply + relinearize of all-FP64 contexts (DevCtx::aux_f64, every key prime FP64-policy)
 hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
                                 const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s) {

@@ -166,6 +166,7 @@ np.save(sys.argv[1], np.concatenate([r.cpu().numpy().ravel(), m.cpu().numpy().ra
     variants = (
         ("split", {}),
         ("split_unfused_tail", {"HIPBFV_NO_FUSED_TAIL": "1"}),  # multiply then relinearize through a c0/c1/c2 buffer instead of mulrelin_tail
+        ("split_unfused_head", {"HIPBFV_NO_FUSED_HEAD": "1"}),  # c2 through HBM between mul_tail and ks_head instead of mulrelin_head
         ("split_unpacked", {"HIPBFV_NO_PACK": "1"}),  # 8-byte instead of 48-bit packed intermediates
         ("split_no_grid", {"HIPBFV_NO_GRID": "1"}),  # base-conversion sums reduced term by term instead of once (griddot.hpp)
         ("whole", {"HIPBFV_NO_SPLIT_MUL": "1", "HIPBFV_NO_SPLIT_KS": "1"}),
