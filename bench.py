@@ -383,6 +383,7 @@ def main():
             "ks_head": n * (8 * K + bk * KK * K), "ks_mid": n * bk * (KK * K + 2 * KK),
             "ks_tail": n * (bk * 2 * KK + 32 * K),
             "galois": 16 * n * K, "eltwise": 24 * n,                 # per polynomial / per residue polynomial (2 reads + 1 write)
+            "plain": 8 * K * n,                                      # dot_plain_ntt, per database entry: its K transform-domain residues
         }.get(name, 16 * n)
         avg_ms = rec["ms"] / rec["launches"]
         kernel_bytes_per_launch = per_unit * rec["units"] / rec["launches"]

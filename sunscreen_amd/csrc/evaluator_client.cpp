@@ -207,7 +207,7 @@ int Evaluator::dot_plain_ntt(const u64* ctn, u32 cols, const u64* pntt, u32 rows
   for (u32 off = 0; off < rows; off += step) {
     const u32 c = std::min(step, rows - off);
     u64* o = out + (size_t)off * 2 * K * n;
-    HC_CHECK(launch_dot_plain(ctx_->dev(), n, K, ctn, cols, pntt + (size_t)off * cols * K * n, c, o, s));
+    HB_LAUNCH_CLIENT(kKernPlain, (size_t)c * cols, launch_dot_plain(ctx_->dev(), n, K, ctn, cols, pntt + (size_t)off * cols * K * n, c, o, s));
     HB_LAUNCH_CLIENT(kKernNttInv, (size_t)c * 2 * K, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, o, (size_t)c * 2 * K, plan, true, 0, s));
   }
   return kOk;

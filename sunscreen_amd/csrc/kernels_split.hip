@@ -497,6 +497,47 @@ __device__ __forceinline__ void nat_store(double* __restrict__ region, u32 n, si
   }
 }
 
+// Packed stores of the NC values a head thread owns (indices t + k*Q), two values per store instruction.  Stored one by one, a
+// packed value costs a 4-byte and a 2-byte store per lane -- the narrowest accesses of the whole pipeline.  Neighbouring
+// lanes own neighbouring coefficients, so a pair of lanes (2i, 2i+1) exchanges halves across the wavefront (one DPP quad_perm
+// swap each for the low words and the high halves): the even lane then stores BOTH lanes' low words of value k as one 8-byte
+// word and both high halves as one 4-byte word, the odd lane does the same for value k+1 -- every lane active, half the
+// store instructions, 8- and 4-byte accesses instead of 4- and 2-byte ones.  The memory image is unchanged.
+#ifndef PACK_PAIR_STORES
+#define PACK_PAIR_STORES 0  // measured (interleaved A/B, r02): mul_head +0.8 %, ks_head +2 % SLOWER with the pair stores: store width is not what limits the head kernels
+#endif
+__device__ __forceinline__ u32 swap_adjacent_lanes(u32 v) {
+  return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+template <bool PACK, bool NT, int NC>
+__device__ __forceinline__ void nat_store_owned(double* __restrict__ region, u32 n, u32 t, size_t Q, const double (&v)[NC]) {
+  if constexpr (PACK && PACK_PAIR_STORES && !NT && (NC % 2 == 0)) {
+    typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+    const bool odd = (t & 1u) != 0;
+    const u32 te = t & ~1u;
+    u32* lo_plane = reinterpret_cast<u32*>(region);
+    short* hi_plane = reinterpret_cast<short*>(reinterpret_cast<char*>(region) + 4 * (size_t)n);
+#pragma unroll
+    for (int k = 0; k < NC; k += 2) {
+      const double ma = v[k] + kPackMagic, mb = v[k + 1] + kPackMagic;
+      const u32 loa = (u32)__double2loint(ma), lob = (u32)__double2loint(mb);
+      const u32 hia = (u32)__double2hiint(ma) & 0xFFFFu, hib = (u32)__double2hiint(mb) & 0xFFFFu;
+      const u32 rlo = swap_adjacent_lanes(odd ? loa : lob);  // even lane receives the odd lane's A, odd lane the even lane's B
+      const u32 rhi = swap_adjacent_lanes(odd ? hia : hib);
+      u32x2_t w;
+      w.x = odd ? rlo : loa;
+      w.y = odd ? lob : rlo;
+      const u32 h = odd ? (rhi | (hib << 16)) : (hia | (rhi << 16));
+      const size_t idx = te + (size_t)(odd ? k + 1 : k) * Q;
+      *reinterpret_cast<u32x2_t*>(lo_plane + idx) = w;
+      *reinterpret_cast<u32*>(hi_plane + idx) = h;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NC; k++) nat_store<PACK, NT>(region, n, t + (size_t)k * Q, v[k]);
+  }
+}
+
 __device__ __forceinline__ bool residue_is_f64(const DevMod& dm) { return dm.use_f64 && dm.split_ok; }
 template <class A, int NC>
 __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], const typename A::Tw* __restrict__ tw);
@@ -554,8 +595,11 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
     }
     head_fwd(ar, v, tw);
     double* dst = T + (((size_t)op * KK + I) * K + J) * N;
+    if constexpr (PACK) {
 #pragma unroll
-    for (int k = 0; k < NC; k++) nat_store<PACK, NtSites<L>::ks_head_st>(dst, N, t + (size_t)k * Q, PACK ? ar.reduce(v[k]) : v[k]);
+      for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
+    }
+    nat_store_owned<PACK, NtSites<L>::ks_head_st, NC>(dst, N, t, Q, v);
   }
 }
 
@@ -944,8 +988,11 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
         for (int k = 0; k < NC; k++) v[k] = x[i][k];
         head_fwd(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)i * N));
         double* o = reinterpret_cast<double*>(dst - t + (size_t)i * N);
+        if constexpr (PACK) {
 #pragma unroll
-        for (int k = 0; k < NC; k++) nat_store<PACK, NtSites<L>::head_st>(o, N, t + (size_t)k * Q, PACK ? ar.reduce(v[k]) : v[k]);
+          for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
+        }
+        nat_store_owned<PACK, NtSites<L>::head_st, NC>(o, N, t, Q, v);
       }
     }
     // auxiliary base: extend all eight owned coefficients residue by residue (every conversion constant is
@@ -954,8 +1001,11 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
       const ArithD ar(ctx->mod[KK + j]);
       head_fwd(ar, ev, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N));
       double* o = reinterpret_cast<double*>(dst - t + (size_t)(K + j) * N);
+      if constexpr (PACK) {
 #pragma unroll
-      for (int k = 0; k < NC; k++) nat_store<PACK, NtSites<L>::head_st>(o, N, t + (size_t)k * Q, PACK ? ar.reduce(ev[k]) : ev[k]);
+        for (int k = 0; k < NC; k++) ev[k] = ar.reduce(ev[k]);
+      }
+      nat_store_owned<PACK, NtSites<L>::head_st, NC>(o, N, t, Q, ev);
     });
     return;
   }
@@ -1446,8 +1496,11 @@ __global__ __launch_bounds__(kHeadThreads) void mulrelin_head_kernel(const DevCt
       }
       head_fwd(ar, v, tw);
       double* dst = T + (((size_t)op * KK + I) * K + J) * N;
+      if constexpr (PACKK) {
 #pragma unroll
-      for (int k = 0; k < NC; k++) nat_store<PACKK, NtSites<L>::ks_head_st>(dst, N, t + (size_t)k * Q, PACKK ? ar.reduce(v[k]) : v[k]);
+        for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
+      }
+      nat_store_owned<PACKK, NtSites<L>::ks_head_st, NC>(dst, N, t, Q, v);
     }
   }
 }

@@ -6,9 +6,9 @@ TAG=$1; shift
 ROOT=$(cd $(dirname $0)/.. && pwd)
 make -s -C $ROOT/sunscreen_amd/csrc
 mkdir -p $ROOT/sunscreen_amd/lib/variants $ROOT/build/variants
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 "$@" -c $ROOT/sunscreen_amd/csrc/kernels_split.hip -o $ROOT/build/variants/split_$TAG.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden --offload-arch=gfx950 "$@" -c $ROOT/sunscreen_amd/csrc/kernels_split.hip -o $ROOT/build/variants/split_$TAG.o
 # context.cpp plans the FP64 reduce masks for the same pass structure (nttshape.hpp): it must see the same macros
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 "$@" -x hip -c $ROOT/sunscreen_amd/csrc/context.cpp -o $ROOT/build/variants/context_$TAG.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden --offload-arch=gfx950 "$@" -x hip -c $ROOT/sunscreen_amd/csrc/context.cpp -o $ROOT/build/variants/context_$TAG.o
 OBJS=$(ls $ROOT/build/hipbfv_*.o | grep -v "kernels_split\|hipbfv_context")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/sunscreen_amd/lib/variants/libhipbfv_$TAG.so $OBJS $ROOT/build/variants/split_$TAG.o $ROOT/build/variants/context_$TAG.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$ROOT/sunscreen_amd/csrc/exports.map -o $ROOT/sunscreen_amd/lib/variants/libhipbfv_$TAG.so $OBJS $ROOT/build/variants/split_$TAG.o $ROOT/build/variants/context_$TAG.o -ldl
 echo built $TAG

@@ -13,8 +13,9 @@ as reported (it matched the known byte count of the NTT kernels to 6 %).
 VALU issue occupancy = issue cycles / (1024 SIMDs x shader cycles of the dispatch).  Shader cycles = GRBM_GUI_ACTIVE / 8
 (reported summed over the 8 XCDs; GUI_ACTIVE / 8 / wall time = the 1.9-2.0 GHz the part sustains under this load).  Issue
 cycles per wave64 instruction by class (MI355X_MICROARCH.md "Wave scheduling": a SIMD-32 issues a 32-bit VALU instruction
-over 2 cycles; FP64 runs at half that rate): 4 for FP64, 2 for everything else.  FP64 instructions = SQ_INSTS_VALU_{ADD,MUL,
-FMA,TRANS}_F64 when the instruction-class pass collected them; v_rndne_f64 / v_cvt are in none of those classes, so
+over 2 cycles; FP64 runs at half that rate): 4 for FP64 and 64-bit integer multiplies, 2 for everything else.  FP64
+instructions = SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, 64-bit integer = SQ_INSTS_VALU_INT64, when the instruction-class pass
+collected them; v_rndne_f64 / v_cvt are in none of those classes, so
 `valu_issue_frac` (the unclassified remainder priced at 2 cycles) is a lower bound and `valu_issue_frac_upper` prices the
 remainder at 4.  Without class counters (older passes) every instruction is priced at 4 and the entry says so.
 --into merges the entry into an existing multi-workload file (and refreshes the top-level "kernels" alias of the headline
@@ -27,7 +28,15 @@ import sys
 SOURCE = ("rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE / WRITE_SIZE / SQ_INSTS_VALU* (separate passes, tools/gpu_pmc_report.sh); "
           "FETCH_SIZE x2 on gfx950")
 F64 = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")
-OTHER = ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT")
+# 64-bit integer multiplies (v_mad_u64_u32, the Harvey / Barrett arithmetic of the integer policy) issue at the FP64 rate too
+# (measured 50 lane-ops/clk/CU against 59-61 for v_fma_f64: profiles/r01_microbench_instruction_rates.txt)
+SLOW = ("SQ_INSTS_VALU_INT64",)
+OTHER = ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT")
+
+
+# rocprof kernel name -> the profiler record bench.py reports it under (the fused multiply+relinearize kernels run in the
+# key-switch head / tail slots of the pipeline)
+ALIAS = {"mulrelin_head": "ks_head", "mulrelin_tail": "ks_tail", "ks_mid_int": "ks_mid"}
 
 
 def parse(path, counter):
@@ -43,7 +52,7 @@ def parse(path, counter):
         m = re.match(r"^\s+(\S+)\s+([0-9.]+)", line)
         if m and cur and m.group(1) == counter:
             # template variants of one kernel (e.g. mul_mid<..,true/false>) are one profiler record in bench.py: sum them
-            key = cur.replace("_kernel", "")
+            key = ALIAS.get(cur.replace("_kernel", ""), cur.replace("_kernel", ""))
             out[key] = out.get(key, 0.0) + float(m.group(2))
     return out
 
@@ -53,7 +62,7 @@ def entry(fetch_p, write_p, units, inst_p):
     write = parse(write_p, "WRITE_SIZE")
     gui = parse(fetch_p, "GRBM_GUI_ACTIVE")
     valu = parse(inst_p, "SQ_INSTS_VALU") if inst_p else {}
-    classes = {c: parse(inst_p, c) for c in F64 + OTHER} if inst_p else {}
+    classes = {c: parse(inst_p, c) for c in F64 + SLOW + OTHER} if inst_p else {}
     res = {}
     for k in fetch:
         if k not in units or k not in write:
@@ -72,7 +81,7 @@ def entry(fetch_p, write_p, units, inst_p):
             res[k]["shader_cycles_per_dispatch"] = cycles
             have_classes = any(k in classes[c] for c in F64)
             if have_classes:
-                f64 = sum(classes[c].get(k, 0.0) for c in F64)
+                f64 = sum(classes[c].get(k, 0.0) for c in F64 + SLOW)
                 other = sum(classes[c].get(k, 0.0) for c in OTHER)
                 rest = max(0.0, valu[k] - f64 - other)  # v_rndne_f64, moves, bit ops, compares ...
                 res[k]["valu_f64_wave_insts_per_dispatch"] = f64
@@ -80,7 +89,7 @@ def entry(fetch_p, write_p, units, inst_p):
                 res[k]["valu_unclassified_wave_insts_per_dispatch"] = rest
                 res[k]["valu_issue_frac"] = round((4.0 * f64 + 2.0 * (other + rest)) / (1024.0 * cycles), 4)
                 res[k]["valu_issue_frac_upper"] = round((4.0 * (f64 + rest) + 2.0 * other) / (1024.0 * cycles), 4)
-                res[k]["valu_pricing"] = "4 cycles per FP64 wave64 instruction, 2 per other"
+                res[k]["valu_pricing"] = "4 cycles per FP64 / INT64 wave64 instruction, 2 per other; unclassified (v_rndne_f64, moves, logic) at 2 (frac) or 4 (upper)"
             else:
                 res[k]["valu_issue_frac"] = round(valu[k] * 4.0 / (1024.0 * cycles), 4)
                 res[k]["valu_pricing"] = "4 cycles per wave64 instruction (no class counters in this pass: upper bound)"
