@@ -10,7 +10,7 @@ reference's example programs and the client-side steps (secondary workloads, sam
 
 The CPU oracle appears here in three roles only: client (it generates the keys and the few genuine encryptions the
 parity gate needs -- the library has no key generator), checker (parity gate, after the timed region) and
-`cpu_baseline`.  Nothing in the timed region touches it.
+`cpu_baseline` (all host cores, OpenMP over the batch).  Nothing in the timed region touches it.
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank processes its own
 `--batch` items (weak scaling, no data-path collective); time = max over ranks.  Under torchrun the ranks come from the
@@ -484,14 +484,14 @@ def cpu_baseline(args, O, n, primes, t):
     """The CPU oracle (a port of SEAL's algorithms, NOT SEAL itself -- SEAL's source is absent from the
     reference tree) timed on this host on a bounded sample of the same workload."""
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = min(cores, 256)  # all host cores (SURVEY 8d); the sample scales with them so that every thread gets several items
     o = O.Oracle(n, primes, t)
     rng = np.random.default_rng(1)
     K = o.K
     if args.workload == "mulrelin":
         O.seed(99)
         sk, pk, rk, _ = o.keygen()
-        sample = args.cpu_sample or max(threads * 8, 64)
+        sample = args.cpu_sample or max(threads * (8 if n <= 8192 else 4), 64)
         a = np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)]) for _ in range(2 * sample)]).reshape(sample, 2, K, n)
         b = a[::-1].copy()
         secs1, _ = o.bench_mul_relin(a[: max(8, sample // threads)], b[: max(8, sample // threads)], rk, threads=1)

@@ -166,6 +166,32 @@ struct BlkPass {
   }
 };
 
+// Which exchanges of a middle kernel need a workgroup barrier: the same argument as in kernels.hip (exchange_is_wave_private).
+// Virtual thread vt = blk*(BLOCK >> R) + tid + g*TPB; the wave-id bits of tid (6 .. log2 TPB - 1) land at element bit b + R when
+// b >= LOW, else at b.  Two consecutive passes that agree on this for every wave-id bit exchange data inside a wavefront only.
+// At N = 8192 that holds for the last forward exchange (windows 2..3 -> 0..1) and for the inverse exchange 2..4 -> 5..7.
+#ifndef MID_WAVE_PRIVATE
+#define MID_WAVE_PRIVATE 1
+#endif
+template <int L>
+constexpr bool blk_exchange_private(int lowa, int ra, int lowb, int rb) {
+  if (!MID_WAVE_PRIVATE) return false;
+  constexpr int logt = SplitShape<L>::LB - ilog2(kBlkEPT);
+  for (int b = 6; b < logt; b++)
+    if ((b >= lowa ? b + ra : b) != (b >= lowb ? b + rb : b)) return false;
+  return true;
+}
+template <bool PRIVATE>
+__device__ __forceinline__ void blk_exchange_sync() {
+  if constexpr (PRIVATE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 template <class A>
 __device__ __forceinline__ void reduce_all(const A& ar, typename A::V (&v)[kBlkEPT]) {
 #pragma unroll
@@ -206,7 +232,7 @@ __device__ __forceinline__ void mid_forward_p(const A& ar, typename A::V (&v)[kB
   using Next = BlkPass<A, L, split_fwd_low(L, PN), split_fwd_radix(L, PN)>;
   typename A::Tw wn[kBlkEPT - 1];
   if constexpr (P > 0) {
-    __syncthreads();
+    blk_exchange_sync<blk_exchange_private<L>(split_fwd_low(L, P > 0 ? P - 1 : 0), split_fwd_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
     Pass::load_lds(v, smem, tid, blk);
   }
   if constexpr (more && TwPipe<A>::value == 2) Next::load_tw_fwd(wn, tid, blk, tw);
@@ -231,7 +257,7 @@ __device__ __forceinline__ void mid_inverse_p(const A& ar, typename A::V (&v)[kB
   using Next = BlkPass<A, L, split_inv_low(L, PN), split_inv_radix(L, PN)>;
   typename A::Tw wn[kBlkEPT - 1];
   if constexpr (P > 0) {
-    __syncthreads();
+    blk_exchange_sync<blk_exchange_private<L>(split_inv_low(L, P > 0 ? P - 1 : 0), split_inv_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
     Pass::load_lds(v, smem, tid, blk);
   }
   if constexpr (more && TwPipe<A>::value == 2) Next::load_tw_inv(wn, tid, blk, tw);
@@ -319,7 +345,7 @@ __device__ __forceinline__ void mid_forward_multi_p(const A& ar, typename A::V (
   using Next = BlkPass<A, L, split_fwd_low(L, PN), split_fwd_radix(L, PN)>;
   typename A::Tw wn[kBlkEPT - 1];
   if constexpr (P > 0) {
-    __syncthreads();
+    blk_exchange_sync<blk_exchange_private<L>(split_fwd_low(L, P > 0 ? P - 1 : 0), split_fwd_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::load_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
   }
@@ -358,7 +384,7 @@ __device__ __forceinline__ void mid_inverse_multi_p(const A& ar, typename A::V (
   using Next = BlkPass<A, L, split_inv_low(L, PN), split_inv_radix(L, PN)>;
   typename A::Tw wn[kBlkEPT - 1];
   if constexpr (P > 0) {
-    __syncthreads();
+    blk_exchange_sync<blk_exchange_private<L>(split_inv_low(L, P > 0 ? P - 1 : 0), split_inv_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::load_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
   }
