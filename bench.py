@@ -492,6 +492,7 @@ def cpu_baseline(args, O, n, primes, t):
         O.seed(99)
         sk, pk, rk, _ = o.keygen()
         sample = args.cpu_sample or max(threads * (8 if n <= 8192 else 4), 64)
+        sample = max(64, min(sample, (6 << 30) // (3 * 2 * K * n * 8)))  # operands + results of the sample stay below 6 GB of host memory
         a = np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)]) for _ in range(2 * sample)]).reshape(sample, 2, K, n)
         b = a[::-1].copy()
         secs1, _ = o.bench_mul_relin(a[: max(8, sample // threads)], b[: max(8, sample // threads)], rk, threads=1)
