@@ -338,9 +338,11 @@ bool os_seed(RngSeed* out) {
 
 // one non-blocking stream per host thread: concurrent handle-level calls do not serialise on the null stream
 hipStream_t thread_stream() {
-  thread_local hipStream_t s = nullptr;
-  if (!s) (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-  return s;
+  // a stream belongs to the device that was current when it was created: cache one per (thread, device)
+  thread_local hipStream_t streams[16] = {};
+  const int dev = g_device.load(std::memory_order_relaxed) & 15;
+  if (!streams[dev]) (void)hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking);
+  return streams[dev];
 }
 
 long sync_stream(hipStream_t s) {
@@ -463,6 +465,7 @@ long hipbfv_set_device(int device) HIPBFV_BEGIN
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return fail(HIPBFV_E_INVALIDARG, "no such HIP device");
   if (device != g_device.load() && g_live_contexts.load() > 0)
     return fail(HIPBFV_COR_E_INVALIDOPERATION, "hipbfv_set_device: contexts exist on the current device (one device per process; destroy them first)");
+  if (device != g_device.load()) g_buffers.drain();  // cached blocks belong to the device they were allocated on
   g_device = device;
   enter_thread();
   return HIPBFV_S_OK;

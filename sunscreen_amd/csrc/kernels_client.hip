@@ -153,31 +153,31 @@ __global__ __launch_bounds__(kClientThreads) void encrypt_finish_kernel(const De
                                                                         const u64* __restrict__ plain, size_t pstride, u64* __restrict__ out) {
   const u32 n = ctx->n, K = ctx->K, KK = ctx->KK;
   const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
-  const u32 c = blockIdx.y, op = blockIdx.z;
+  const u32 op = blockIdx.y;
   if (x >= n) return;
   const u64 gop = op0 + op;
   u32 r[5];
-  chacha20_block<5>(key, x, (u32)gop, (u32)(gop >> 32), 0u, r);
-  const int err = c == 0 ? gauss_noise(r[1], r[2]) : gauss_noise(r[3], r[4]);
-  const u64* acc = c2 + ((size_t)op * 2 + c) * KK * n + x;
-  u64 fix = 0, m = 0;
-  if (c == 0) {
-    m = plain[(size_t)op * pstride + x];
-    fix = (u64)(((u128)m * ctx->q_mod_t + ctx->t_half_up) / ctx->t);
-  }
-  u64 tl = 0;
+  chacha20_block<5>(key, x, (u32)gop, (u32)(gop >> 32), 0u, r);  // one block serves both polynomials' errors
+  const u64 m = plain[(size_t)op * pstride + x];
+  const u64 fix = (u64)(((u128)m * ctx->q_mod_t + ctx->t_half_up) / ctx->t);
   const DevMod& sp = ctx->mod[KK - 1];
-  if (KK > 1) tl = add_mod(add_mod(acc[(size_t)(KK - 1) * n], small_to_residue(err, sp.q), sp.q), ctx->qsp_half, sp.q);
-  for (u32 J = 0; J < K; J++) {
-    const DevMod& mj = ctx->mod[J];
-    u64 d = add_mod(acc[(size_t)J * n], small_to_residue(err, mj.q), mj.q);
-    if (KK > 1) {
-      u64 tk = sp.q > mj.q ? reduce64(tl, mj) : tl;
-      tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
-      d = mul_shoup(sub_mod(d, tk, mj.q), ctx->inv_qsp_mod_q[J], mj.q);
+#pragma unroll
+  for (u32 c = 0; c < 2; c++) {
+    const int err = c == 0 ? gauss_noise(r[1], r[2]) : gauss_noise(r[3], r[4]);
+    const u64* acc = c2 + ((size_t)op * 2 + c) * KK * n + x;
+    u64 tl = 0;
+    if (KK > 1) tl = add_mod(add_mod(acc[(size_t)(KK - 1) * n], small_to_residue(err, sp.q), sp.q), ctx->qsp_half, sp.q);
+    for (u32 J = 0; J < K; J++) {
+      const DevMod& mj = ctx->mod[J];
+      u64 d = add_mod(acc[(size_t)J * n], small_to_residue(err, mj.q), mj.q);
+      if (KK > 1) {
+        u64 tk = sp.q > mj.q ? reduce64(tl, mj) : tl;
+        tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+        d = mul_shoup(sub_mod(d, tk, mj.q), ctx->inv_qsp_mod_q[J], mj.q);
+      }
+      if (c == 0) d = add_mod(d, reduce128((u128)m * ctx->q_div_t_mod_q[J] + fix, mj), mj.q);
+      out[(((size_t)op * 2 + c) * K + J) * n + x] = d;
     }
-    if (c == 0) d = add_mod(d, reduce128((u128)m * ctx->q_div_t_mod_q[J] + fix, mj), mj.q);
-    out[(((size_t)op * 2 + c) * K + J) * n + x] = d;
   }
 }
 
@@ -473,7 +473,7 @@ hipError_t launch_encrypt_sample(const DevCtx* ctx, u32 n, const RngSeed& seed, 
 }
 hipError_t launch_encrypt_finish(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 op0, const u64* c2, const u64* plain, size_t pstride, u64* out, size_t ops,
                                  hipStream_t s) {
-  encrypt_finish_kernel<<<cgrid(n, 2, (u32)ops), kClientThreads, 0, s>>>(ctx, seed.secret, op0, c2, plain, pstride, out);
+  encrypt_finish_kernel<<<cgrid(n, (u32)ops), kClientThreads, 0, s>>>(ctx, seed.secret, op0, c2, plain, pstride, out);
   return hipGetLastError();
 }
 hipError_t launch_encrypt_dyadic(const DevCtx* ctx, u32 n, u32 KK, const u64* un, const u64* pk, u64* c, size_t ops, hipStream_t s) {
