@@ -393,20 +393,22 @@ bool same_context(const CipherObj* a, const EvalObj* e) { return a->ctx && a->ct
 long finish_result(EvalObj* e, CipherObj* dst, u32 size, u64* buf, size_t words, hipStream_t s, bool check_transparent) {
   u32 flag = 1;
   if (check_transparent && g_throw_transparent) {
-    u32* dflag = (u32*)g_buffers.get(1);
-    if (!dflag) {
+    // one word of pinned, device-addressable host memory per host thread: the check kernel writes its verdict there
+    thread_local u32* host_flag = nullptr;
+    if (!host_flag && hipHostMalloc((void**)&host_flag, 64, hipHostMallocMapped) != hipSuccess) {
+      host_flag = nullptr;
+      (void)hipGetLastError();
       g_buffers.put(buf, words);
       return from_status(kOutOfMemory);
     }
-    (void)hipMemsetAsync(dflag, 0, sizeof(u32), s);
-    int st = e->ev->nonzero_tail(buf, size, dflag, 1, s);
-    if (st == kOk && hipMemcpyAsync(&flag, dflag, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) st = kHipError;
-    long hr = st == kOk ? sync_stream(s) : from_status(st);
-    g_buffers.put((u64*)dflag, 1);
+    *host_flag = 1u;
+    const size_t poly = (size_t)e->ctx->K() * e->ctx->n();
+    long hr = launch_transparent_flag(buf, (size_t)size * poly, poly, host_flag, s) == hipSuccess ? sync_stream(s) : from_status(kHipError);
     if (hr != HIPBFV_S_OK) {
       g_buffers.put(buf, words);
       return hr;
     }
+    flag = *(volatile u32*)host_flag;
   } else {
     long hr = sync_stream(s);
     if (hr != HIPBFV_S_OK) {

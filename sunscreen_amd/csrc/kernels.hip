@@ -990,6 +990,21 @@ __global__ __launch_bounds__(kCoefThreads) void transparent_watch_kernel(const u
   if (threadIdx.x == 0) atomicMin(status, first_item + op);
 }
 
+// The handle-level form of the same check: ONE ciphertext, the verdict (1 = not transparent) written straight into a word of
+// pinned host memory the device can address -- the caller only has to synchronise its stream, no memset, no copy back.
+__global__ __launch_bounds__(kCoefThreads) void transparent_flag_kernel(const u64* __restrict__ ct, size_t words, size_t skip_words,
+                                                                       volatile u32* __restrict__ host_flag) {
+  for (size_t base = skip_words; base < words; base += kCoefThreads) {
+    const size_t i = base + threadIdx.x;
+    const bool nz = i < words && ct[i] != 0;
+    if (__syncthreads_or(nz)) {
+      if (threadIdx.x == 0) *host_flag = 1u;
+      return;
+    }
+  }
+  if (threadIdx.x == 0) *host_flag = 0u;
+}
+
 // =====================================================================================
 // host launchers
 // =====================================================================================
@@ -1087,6 +1102,11 @@ hipError_t launch_mono_mul(const DevCtx* ctx, u32 n, const u64* in, u64* out, si
 
 hipError_t launch_nonzero_tail(const u64* ct, size_t words_per_ct, size_t skip_words, u32* flags, size_t ops, hipStream_t s) {
   nonzero_tail_kernel<<<dim3(64, (u32)ops), kCoefThreads, 0, s>>>(ct, words_per_ct, skip_words, flags);
+  return hipGetLastError();
+}
+
+hipError_t launch_transparent_flag(const u64* ct, size_t words, size_t skip_words, u32* host_flag, hipStream_t s) {
+  transparent_flag_kernel<<<dim3(1), kCoefThreads, 0, s>>>(ct, words, skip_words, host_flag);
   return hipGetLastError();
 }
 
