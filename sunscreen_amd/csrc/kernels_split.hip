@@ -39,12 +39,16 @@ __device__ __forceinline__ u32 blk_pos(u32 e) {
   return e ^ m;
 }
 
-template <int L>
+// EPT: elements per middle-kernel thread (8).  At N = 16384 a block is 4096 coefficients, and 512-thread workgroups with four
+// 32 KB exchange regions leave room for ONE workgroup per CU -- nothing overlaps its load and store phases (an N = 8192 middle
+// kernel padded down to one workgroup per CU runs 1.7x slower: -DMID_LDS_PAD).  The machinery is parametrised on EPT so that 16
+// elements per thread (256-thread workgroups, two of them resident) could be tried there: see MID_EPT_14.
+template <int L, int EPT = kBlkEPT>
 struct SplitShape {
   static constexpr int N = 1 << L;
   static constexpr int LB = L - kTailLog;
   static constexpr int BLOCK = 1 << LB;           // coefficients per middle workgroup
-  static constexpr int TPB = BLOCK / kBlkEPT;     // threads per middle workgroup
+  static constexpr int TPB = BLOCK / EPT;         // threads per middle workgroup
   static constexpr int NBLK = 1 << kTailLog;      // blocks per polynomial
   static constexpr int NPF = split_fwd_passes(L);
   static constexpr int NPI = split_inv_passes(L);
@@ -56,26 +60,26 @@ struct SplitShape {
 
 // One pass of a middle kernel over the index window [LOW, LOW+R).  `blk` is the block index inside the
 // polynomial; virtual threads are numbered globally so that twiddle indices are those of the full transform.
-template <class A, int L, int LOW, int R>
+template <class A, int L, int LOW, int R, int EPT = kBlkEPT>
 struct BlkPass {
-  using Sh = SplitShape<L>;
-  static constexpr int G = kBlkEPT >> R;
+  using Sh = SplitShape<L, EPT>;
+  static constexpr int G = EPT >> R;
   static __device__ __forceinline__ u32 vt(u32 tid, u32 blk, int g) { return blk * (u32)(Sh::BLOCK >> R) + tid + (u32)g * Sh::TPB; }
   static __device__ __forceinline__ u32 elem(u32 tid, u32 blk, int g, int k) { return elem_index<LOW, R>(vt(tid, blk, g), (u32)k); }
-  static __device__ __forceinline__ void load_lds(typename A::V (&v)[kBlkEPT], const typename A::V* smem, u32 tid, u32 blk) {
+  static __device__ __forceinline__ void load_lds(typename A::V (&v)[EPT], const typename A::V* smem, u32 tid, u32 blk) {
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[blk_pos(elem(tid, blk, g, k) & (Sh::BLOCK - 1))];
   }
-  static __device__ __forceinline__ void store_lds(const typename A::V (&v)[kBlkEPT], typename A::V* smem, u32 tid, u32 blk) {
+  static __device__ __forceinline__ void store_lds(const typename A::V (&v)[EPT], typename A::V* smem, u32 tid, u32 blk) {
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) smem[blk_pos(elem(tid, blk, g, k) & (Sh::BLOCK - 1))] = v[g * (1 << R) + k];
   }
   // forward stages S0..S0+R-1, S0 = L - LOW - R
-  static __device__ __forceinline__ void fwd(const A& ar, typename A::V (&v)[kBlkEPT], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
+  static __device__ __forceinline__ void fwd(const A& ar, typename A::V (&v)[EPT], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
     constexpr int S0 = L - LOW - R;
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -96,7 +100,7 @@ struct BlkPass {
   // The same stages with the twiddles fetched separately (load_tw_*) so that the fetch can be issued a pass ahead
   // of its use: w[g*NW + slot], forward slot of (stage j, c) = 2^j - 1 + c, inverse slot = 2^R - 2^(R-j) + c.
   static constexpr int NW = (1 << R) - 1;
-  static __device__ __forceinline__ void load_tw_fwd(typename A::Tw (&w)[kBlkEPT - 1], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
+  static __device__ __forceinline__ void load_tw_fwd(typename A::Tw (&w)[EPT - 1], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
     constexpr int S0 = L - LOW - R;
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -108,7 +112,7 @@ struct BlkPass {
         for (int c = 0; c < (1 << j); c++) w[g * NW + (1 << j) - 1 + c] = tw[(1u << (S0 + j)) + ((hi << j) | (u32)c)];
     }
   }
-  static __device__ __forceinline__ void fwd_tw(const A& ar, typename A::V (&v)[kBlkEPT], const typename A::Tw (&w)[kBlkEPT - 1]) {
+  static __device__ __forceinline__ void fwd_tw(const A& ar, typename A::V (&v)[EPT], const typename A::Tw (&w)[EPT - 1]) {
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
@@ -121,7 +125,7 @@ struct BlkPass {
         }
       }
   }
-  static __device__ __forceinline__ void load_tw_inv(typename A::Tw (&w)[kBlkEPT - 1], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
+  static __device__ __forceinline__ void load_tw_inv(typename A::Tw (&w)[EPT - 1], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
 #pragma unroll
     for (int g = 0; g < G; g++) {
       u32 hi = vt(tid, blk, g) >> LOW;
@@ -133,7 +137,7 @@ struct BlkPass {
           w[g * NW + (1 << R) - (1 << (R - j)) + c] = tw[(1u << (L - 1 - LOW - j)) + ((hi << (R - 1 - j)) | (u32)c)];
     }
   }
-  static __device__ __forceinline__ void inv_tw(const A& ar, typename A::V (&v)[kBlkEPT], const typename A::Tw (&w)[kBlkEPT - 1]) {
+  static __device__ __forceinline__ void inv_tw(const A& ar, typename A::V (&v)[EPT], const typename A::Tw (&w)[EPT - 1]) {
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
@@ -147,7 +151,7 @@ struct BlkPass {
       }
   }
   // inverse stages with global gaps 2^LOW .. 2^(LOW+R-1)
-  static __device__ __forceinline__ void inv(const A& ar, typename A::V (&v)[kBlkEPT], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
+  static __device__ __forceinline__ void inv(const A& ar, typename A::V (&v)[EPT], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {
 #pragma unroll
     for (int g = 0; g < G; g++) {
       u32 hi = vt(tid, blk, g) >> LOW;
@@ -173,10 +177,10 @@ struct BlkPass {
 #ifndef MID_WAVE_PRIVATE
 #define MID_WAVE_PRIVATE 1
 #endif
-template <int L>
+template <int L, int EPT = kBlkEPT>
 constexpr bool blk_exchange_private(int lowa, int ra, int lowb, int rb) {
   if (!MID_WAVE_PRIVATE) return false;
-  constexpr int logt = SplitShape<L>::LB - ilog2(kBlkEPT);
+  constexpr int logt = SplitShape<L, EPT>::LB - ilog2(EPT);
   for (int b = 6; b < logt; b++)
     if ((b >= lowa ? b + ra : b) != (b >= lowb ? b + rb : b)) return false;
   return true;
@@ -192,10 +196,10 @@ __device__ __forceinline__ void blk_exchange_sync() {
   }
 }
 
-template <class A>
-__device__ __forceinline__ void reduce_all(const A& ar, typename A::V (&v)[kBlkEPT]) {
+template <class A, int EPT>
+__device__ __forceinline__ void reduce_all(const A& ar, typename A::V (&v)[EPT]) {
 #pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) v[e] = ar.reduce(v[e]);
+  for (int e = 0; e < EPT; e++) v[e] = ar.reduce(v[e]);
 }
 
 // TW_PIPE_D / TW_PIPE_I (FP64 / integer policy): 0 = every pass fetches its twiddles when it needs them; 1 = the next pass's twiddles are fetched
@@ -333,19 +337,19 @@ __device__ __forceinline__ void mid_inverse(const A& ar, typename A::V (&v)[kBlk
 // of twiddle fetches per pass serves all NP polynomials, their butterflies are independent instruction streams
 // the scheduler can interleave, and the NP global loads / stores are in flight together.  smem: NP regions of
 // BLOCK elements.
-template <class A, int L, int P, int NP>
-__device__ __forceinline__ void mid_forward_multi_p(const A& ar, typename A::V (&v)[NP][kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
-                                                    const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[kBlkEPT - 1]) {
-  using Sh = SplitShape<L>;
+template <class A, int L, int P, int NP, int EPT = kBlkEPT>
+__device__ __forceinline__ void mid_forward_multi_p(const A& ar, typename A::V (&v)[NP][EPT], typename A::V* smem, u32 tid, u32 blk,
+                                                    const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[EPT - 1]) {
+  using Sh = SplitShape<L, EPT>;
   constexpr int R = split_fwd_radix(L, P);
   constexpr int LOW = split_fwd_low(L, P);
-  using Pass = BlkPass<A, L, LOW, R>;
+  using Pass = BlkPass<A, L, LOW, R, EPT>;
   constexpr bool more = P + 1 < Sh::NPF;
   constexpr int PN = more ? P + 1 : P;
-  using Next = BlkPass<A, L, split_fwd_low(L, PN), split_fwd_radix(L, PN)>;
-  typename A::Tw wn[kBlkEPT - 1];
+  using Next = BlkPass<A, L, split_fwd_low(L, PN), split_fwd_radix(L, PN), EPT>;
+  typename A::Tw wn[EPT - 1];
   if constexpr (P > 0) {
-    blk_exchange_sync<blk_exchange_private<L>(split_fwd_low(L, P > 0 ? P - 1 : 0), split_fwd_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
+    blk_exchange_sync<blk_exchange_private<L, EPT>(split_fwd_low(L, P > 0 ? P - 1 : 0), split_fwd_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::load_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
   }
@@ -360,31 +364,31 @@ __device__ __forceinline__ void mid_forward_multi_p(const A& ar, typename A::V (
     Next::load_tw_fwd(wn, tid, blk, tw);
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::store_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
-    mid_forward_multi_p<A, L, PN, NP>(ar, v, smem, tid, blk, tw, mask, wn);
+    mid_forward_multi_p<A, L, PN, NP, EPT>(ar, v, smem, tid, blk, tw, mask, wn);
   }
 }
-template <class A, int L, int NP>
-__device__ __forceinline__ void mid_forward_multi(const A& ar, typename A::V (&v)[NP][kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+template <class A, int L, int NP, int EPT = kBlkEPT>
+__device__ __forceinline__ void mid_forward_multi(const A& ar, typename A::V (&v)[NP][EPT], typename A::V* smem, u32 tid, u32 blk,
                                                   const typename A::Tw* tw, u32 mask) {
-  using Pass = BlkPass<A, L, split_fwd_low(L, 0), split_fwd_radix(L, 0)>;
-  typename A::Tw w[kBlkEPT - 1];
+  using Pass = BlkPass<A, L, split_fwd_low(L, 0), split_fwd_radix(L, 0), EPT>;
+  typename A::Tw w[EPT - 1];
   Pass::load_tw_fwd(w, tid, blk, tw);
-  mid_forward_multi_p<A, L, 0, NP>(ar, v, smem, tid, blk, tw, mask, w);
+  mid_forward_multi_p<A, L, 0, NP, EPT>(ar, v, smem, tid, blk, tw, mask, w);
 }
 
-template <class A, int L, int P, int NP>
-__device__ __forceinline__ void mid_inverse_multi_p(const A& ar, typename A::V (&v)[NP][kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
-                                                    const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[kBlkEPT - 1]) {
-  using Sh = SplitShape<L>;
+template <class A, int L, int P, int NP, int EPT = kBlkEPT>
+__device__ __forceinline__ void mid_inverse_multi_p(const A& ar, typename A::V (&v)[NP][EPT], typename A::V* smem, u32 tid, u32 blk,
+                                                    const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[EPT - 1]) {
+  using Sh = SplitShape<L, EPT>;
   constexpr int R = split_inv_radix(L, P);
   constexpr int LOW = split_inv_low(L, P);
-  using Pass = BlkPass<A, L, LOW, R>;
+  using Pass = BlkPass<A, L, LOW, R, EPT>;
   constexpr bool more = P + 1 < Sh::NPI;
   constexpr int PN = more ? P + 1 : P;
-  using Next = BlkPass<A, L, split_inv_low(L, PN), split_inv_radix(L, PN)>;
-  typename A::Tw wn[kBlkEPT - 1];
+  using Next = BlkPass<A, L, split_inv_low(L, PN), split_inv_radix(L, PN), EPT>;
+  typename A::Tw wn[EPT - 1];
   if constexpr (P > 0) {
-    blk_exchange_sync<blk_exchange_private<L>(split_inv_low(L, P > 0 ? P - 1 : 0), split_inv_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
+    blk_exchange_sync<blk_exchange_private<L, EPT>(split_inv_low(L, P > 0 ? P - 1 : 0), split_inv_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::load_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
   }
@@ -399,16 +403,16 @@ __device__ __forceinline__ void mid_inverse_multi_p(const A& ar, typename A::V (
     Next::load_tw_inv(wn, tid, blk, tw);
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::store_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
-    mid_inverse_multi_p<A, L, PN, NP>(ar, v, smem, tid, blk, tw, mask, wn);
+    mid_inverse_multi_p<A, L, PN, NP, EPT>(ar, v, smem, tid, blk, tw, mask, wn);
   }
 }
-template <class A, int L, int NP>
-__device__ __forceinline__ void mid_inverse_multi(const A& ar, typename A::V (&v)[NP][kBlkEPT], typename A::V* smem, u32 tid, u32 blk,
+template <class A, int L, int NP, int EPT = kBlkEPT>
+__device__ __forceinline__ void mid_inverse_multi(const A& ar, typename A::V (&v)[NP][EPT], typename A::V* smem, u32 tid, u32 blk,
                                                   const typename A::Tw* tw, u32 mask) {
-  using Pass = BlkPass<A, L, split_inv_low(L, 0), split_inv_radix(L, 0)>;
-  typename A::Tw w[kBlkEPT - 1];
+  using Pass = BlkPass<A, L, split_inv_low(L, 0), split_inv_radix(L, 0), EPT>;
+  typename A::Tw w[EPT - 1];
   Pass::load_tw_inv(w, tid, blk, tw);
-  mid_inverse_multi_p<A, L, 0, NP>(ar, v, smem, tid, blk, tw, mask, w);
+  mid_inverse_multi_p<A, L, 0, NP, EPT>(ar, v, smem, tid, blk, tw, mask, w);
 }
 
 constexpr int kHeadThreads = 256;
@@ -1158,19 +1162,21 @@ __device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A:
 
 // The same work with the four forward transforms (and then the three inverse ones) advanced together, pass by
 // pass (mid_forward_multi): smem = 4 regions of BLOCK elements, nothing is parked.
-template <class A, int L, bool PACK>
+// MODE 0: the four forward transforms together (4 exchange regions); 1: two pairs, one polynomial of the waiting pair parked in
+// a third region (3 regions, N = 8192); 2: two pairs with nothing parked and the inverse transforms as a pair + one (2 regions:
+// the 16-elements-per-thread geometry of N = 16384, where two such workgroups share a CU)
+template <class A, int L, bool PACK, int EPT = kBlkEPT, int MODE = ((MID_FWD_PAIRS(L) && std::is_same<A, ArithD>::value) ? 1 : 0)>
 __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi,
                                                      const typename A::V* ext_r, size_t poly_stride, typename A::V* D_r, size_t dpoly_stride,
                                                      typename A::V* smem, u32 tid, u32 blk) {
-  using Sh = SplitShape<L>;
+  using Sh = SplitShape<L, EPT>;
   const A ar(dm);
   constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
-  using First = BlkPass<A, L, LOWF0, RF0>;
+  using First = BlkPass<A, L, LOWF0, RF0, EPT>;
   constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
-  using Out = BlkPass<A, L, LOWI, RI>;
-  typename A::V v[4][kBlkEPT];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
+  using Out = BlkPass<A, L, LOWI, RI, EPT>;
+  typename A::V v[4][EPT];
+  auto load_poly = [&](int i) {
     const typename A::V* src = ext_r + (size_t)i * poly_stride;
 #pragma unroll
     for (int g = 0; g < First::G; g++)
@@ -1181,38 +1187,59 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
         else
           v[i][g * (1 << RF0) + k] = nt_ld<NtSites<L>::mul_mid_ld>(src + First::elem(tid, blk, g, k));
       }
+  };
+  // MODE 2 loads the second pair only after the first pair's transform: at 16 elements per thread the four operands are 128
+  // registers, and holding all of them through the first transform spills (the other resident workgroup covers the latency)
+  load_poly(0);
+  load_poly(1);
+  if constexpr (MODE != 2) {
+    load_poly(2);
+    load_poly(3);
   }
-  if constexpr (MID_FWD_PAIRS(L) && std::is_same<A, ArithD>::value) {
+  using Pair = typename A::V[2][EPT];
+  if constexpr (MODE == 1) {
     // two pairs through 2 (of the 3) exchange regions: 48 KB of LDS per workgroup instead of 64 KB -> 3 workgroups per CU
     // The pair that is not being transformed would sit in 32 registers; one of its two polynomials waits in the third
     // exchange region instead (each thread parks and fetches its own values: no synchronisation), which keeps the kernel
     // under the 168 registers of 3 waves per SIMD without scratch spills.
-    using Pair = typename A::V[2][kBlkEPT];
     typename A::V* park = smem + 2 * Sh::BLOCK + tid;
 #pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB] = v[3][e];
-    mid_forward_multi<A, L, 2>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
+    for (int e = 0; e < EPT; e++) park[e * Sh::TPB] = v[3][e];
+    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) {
+    for (int e = 0; e < EPT; e++) {
       v[3][e] = park[e * Sh::TPB];
       park[e * Sh::TPB] = v[0][e];
     }
-    mid_forward_multi<A, L, 2>(ar, *reinterpret_cast<Pair*>(&v[2]), smem, tid, blk, twf, dm.split_fwd_mask);
+    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[2]), smem, tid, blk, twf, dm.split_fwd_mask);
 #pragma unroll
-    for (int e = 0; e < kBlkEPT; e++) v[0][e] = park[e * Sh::TPB];
+    for (int e = 0; e < EPT; e++) v[0][e] = park[e * Sh::TPB];
+  } else if constexpr (MODE == 2) {
+    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
+    load_poly(2);
+    load_poly(3);
+    __syncthreads();  // the first pair's last pass may still be reading the exchange buffer
+    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[2]), smem, tid, blk, twf, dm.split_fwd_mask);
   } else {
-    mid_forward_multi<A, L, 4>(ar, v, smem, tid, blk, twf, dm.split_fwd_mask);
+    mid_forward_multi<A, L, 4, EPT>(ar, v, smem, tid, blk, twf, dm.split_fwd_mask);
   }
-  typename A::V d[3][kBlkEPT];
+  typename A::V d[3][EPT];
 #pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) {
+  for (int e = 0; e < EPT; e++) {
     d[0][e] = ar.mul_var(v[0][e], v[2][e]);
     d[1][e] = ar.mul_add(v[0][e], v[3][e], ar.mul_var(v[1][e], v[2][e]));
     d[2][e] = ar.mul_var(v[1][e], v[3][e]);
   }
   __syncthreads();  // the last forward pass may still be reading the exchange buffer
-  mid_inverse_multi<A, L, 3>(ar, d, smem, tid, blk, twi, dm.split_inv_mask);
+  if constexpr (MODE == 2) {
+    using One = typename A::V[1][EPT];
+    mid_inverse_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&d[0]), smem, tid, blk, twi, dm.split_inv_mask);
+    __syncthreads();
+    mid_inverse_multi<A, L, 1, EPT>(ar, *reinterpret_cast<One*>(&d[2]), smem, tid, blk, twi, dm.split_inv_mask);
+  } else {
+    mid_inverse_multi<A, L, 3, EPT>(ar, d, smem, tid, blk, twi, dm.split_inv_mask);
+  }
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     typename A::V* dst = D_r + (size_t)i * dpoly_stride;
@@ -1231,14 +1258,36 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 // grid: ops * nres * NBLK workgroups of TPB threads; D = [ops][3][R][N] native representation.
 // Two instantiations (separate register allocations): FP64 residues (r in [0, K)) and integer residues.
 // POLICY_D selects which residues this launch handles: r0 = first residue, nres = number of residues.
+// Elements per thread of the FP64 middle kernels at N = 16384.  16 (256-thread workgroups, two exchange regions, two workgroups
+// per CU instead of one) was built and measured in round 2: the four operands of the tensor product are 128 registers, the 14
+// vector twiddles of a pass and of the prefetched next pass another 112, the kernel spills 860 bytes per lane and mul_mid takes
+// 16.5 ms instead of 6.4 (bit-exact, `-DMID_EPT_14=16`).  8 stays.
+#ifndef MID_EPT_14
+#define MID_EPT_14 8
+#endif
+constexpr int mid_ept_d(int logn) { return logn == 14 ? MID_EPT_14 : kBlkEPT; }
+template <int L, bool POLICY_D>
+struct MulMidGeom {
+  static constexpr int EPT = POLICY_D ? mid_ept_d(L) : kBlkEPT;
+  static constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
+  static constexpr int MODE = !POLICY_D ? 0 : EPT > kBlkEPT ? 2 : MID_FWD_PAIRS(L) ? 1 : 0;
+  static constexpr int REGIONS = !batched ? 1 : MODE == 2 ? 2 : MODE == 1 ? 3 : 4;
+  static constexpr int TPB = SplitShape<L, EPT>::TPB;
+  static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : EPT > kBlkEPT ? 2 : MID_WAVES_D(L);
+};
 template <int L, bool POLICY_D, bool PACK>
-__global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D(L) : MID_WAVES_I)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+__global__ __launch_bounds__((MulMidGeom<L, POLICY_D>::TPB), (MulMidGeom<L, POLICY_D>::WAVES)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                            const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
                                                                            u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres) {
-  using Sh = SplitShape<L>;
-  constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
-  __shared__ u64 smem[(batched ? (MID_FWD_PAIRS(L) && POLICY_D ? 3 : 4) : 1) * Sh::BLOCK];
+  using Geo = MulMidGeom<L, POLICY_D>;
+  using Sh = SplitShape<L, Geo::EPT>;
+  constexpr bool batched = Geo::batched;
+  __shared__ u64 smem[Geo::REGIONS * Sh::BLOCK];
   __shared__ u64 park[batched ? 1 : Sh::BLOCK];
+#ifdef MID_LDS_PAD  // occupancy experiment: extra LDS per workgroup lowers the number of resident workgroups per CU
+  __shared__ u64 lds_pad[L == 13 ? MID_LDS_PAD / 8 : 64];
+  if (ext == nullptr) lds_pad[threadIdx.x] = 1, D[0] = lds_pad[(threadIdx.x + 1) & 63];
+#endif
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   const u32 b = blockIdx.x;
@@ -1253,11 +1302,11 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), (POLICY_D ? MID_WAVES_D(L) : 
   const MulOp* twf = twf_base + (size_t)m * Sh::N;
   const MulOp* twi = twi_base + (size_t)m * Sh::N;
   if constexpr (batched && POLICY_D)
-    mul_mid_body_batched<ArithD, L, PACK>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
+    mul_mid_body_batched<ArithD, L, PACK, Geo::EPT, Geo::MODE>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                                     reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                                     reinterpret_cast<double*>(smem), tid, blk);
   else if constexpr (batched)
-    mul_mid_body_batched<ArithI, L, false>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
+    mul_mid_body_batched<ArithI, L, false, kBlkEPT, 0>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
   else if constexpr (POLICY_D)
     mul_mid_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                             reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
@@ -1796,9 +1845,10 @@ template <int L>
 static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
                             const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s) {
   using Sh = SplitShape<L>;
-  if (nd && pack) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
-  if (nd && !pack) mul_mid_kernel<L, true, false><<<dim3((unsigned)(ops * nd * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
-  if (ni) mul_mid_kernel<L, false, false><<<dim3((unsigned)(ops * ni * Sh::NBLK)), Sh::TPB, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
+  constexpr unsigned TD = MulMidGeom<L, true>::TPB, TI = MulMidGeom<L, false>::TPB;
+  if (nd && pack) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+  if (nd && !pack) mul_mid_kernel<L, true, false><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+  if (ni) mul_mid_kernel<L, false, false><<<dim3((unsigned)(ops * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
   return hipGetLastError();
 }
 // res_d / res_i: device arrays listing the residue indices (0..R-1) handled by the FP64 / integer instantiation
