@@ -215,7 +215,7 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
     if (M * (double)q * (double)q * M > 4.0e31) return false;
     *fwd_mask = mask;
   }
-  {  // inverse: middle passes from products / accumulators (|x| <= 2.5 q), then kTailLog stages in the tail
+  {  // inverse: middle passes from products / accumulators (|x| <= 2.5 q), then tail_log(logn) stages in the tail
     double M = 2.5;
     u32 mask = 0;
     auto run = [&](double m, int r, bool* ok) {
@@ -230,7 +230,7 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
     };
     for (int p = 0; p <= split_inv_passes(logn); p++) {
       const bool tail = p == split_inv_passes(logn);
-      const int r = tail ? kTailLog : split_inv_radix(logn, p);
+      const int r = tail ? tail_log(logn) : split_inv_radix(logn, p);
       bool ok;
       double m = run(M, r, &ok);
       if (!ok) {

@@ -1,7 +1,7 @@
 // sunscreen_amd/csrc/kernels_split.hip -- "head / middle / tail" split-transform kernels.
 //
-// A negacyclic NTT of N = 2^L points is L radix-2 stages.  The first head_log(L) stages (gaps >= N/8; N/4 at L = 14) and the
-// last kTailLog stages of the inverse (gaps >= N/4) are the only ones that couple distant coefficients;
+// A negacyclic NTT of N = 2^L points is L radix-2 stages.  The first head_log(L) stages (gaps >= N/8) and the
+// last tail_log(L) stages of the inverse (gaps >= N/4; N/8 at L = 14, nttshape.hpp) are the only ones that couple distant coefficients;
 // all stages in between act inside contiguous blocks of N/4 coefficients.  So instead of one LDS-resident
 // whole-polynomial transform per residue (kernels.hip), the pipeline is cut at those two places:
 //
@@ -46,10 +46,10 @@ __device__ __forceinline__ u32 blk_pos(u32 e) {
 template <int L, int EPT = kBlkEPT>
 struct SplitShape {
   static constexpr int N = 1 << L;
-  static constexpr int LB = L - kTailLog;
+  static constexpr int LB = L - tail_log(L);
   static constexpr int BLOCK = 1 << LB;           // coefficients per middle workgroup
   static constexpr int TPB = BLOCK / EPT;         // threads per middle workgroup
-  static constexpr int NBLK = 1 << kTailLog;      // blocks per polynomial
+  static constexpr int NBLK = 1 << tail_log(L);   // blocks per polynomial
   static constexpr int NPF = split_fwd_passes(L);
   static constexpr int NPI = split_inv_passes(L);
   // the pointwise work (tensor product / key multiply-accumulate) happens on the register layout the last forward pass
@@ -527,6 +527,145 @@ __device__ __forceinline__ void nat_store(double* __restrict__ region, u32 n, si
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Who owns which coefficients in the head / tail kernels (EdgeGeom).
+// Plain degrees: a head thread t owns the NC = 2^head_log coefficients {t + k*N/NC}, a tail thread the 4 coefficients
+// {t + k*N/4}.  Lane-split degrees (N = 16384): the 8 coefficients {p + k*N/8} belong to the lane PAIR (l, l + 32) of one
+// wavefront -- so that each half-wave still touches 32 consecutive coefficients per access -- and each lane holds 4 of them,
+// in one of two arrangements (s = 0 for lanes 0..31, 1 for lanes 32..63):
+//   natural : lane s holds k = 4s + j                    -- the side facing the middle kernels (head output, tail input)
+//   split   : lane s holds k = (j & 1) | (j >> 1) << 2 | s << 1, i.e. {0,1,4,5} / {2,3,6,7}  -- the coefficient-wise side
+// The stage with gap N/2 (pairs k, k+4) is local in the split arrangement, the stages with gaps N/4 and N/8 in the natural
+// one; between them the two lanes trade two values each with v_permlane32_swap, the wavefront-level half exchange of gfx950:
+// one instruction per dword, no LDS, no selects (head_fwd_owned / tail_inv_owned).
+// -------------------------------------------------------------------------------------------------
+template <int L>
+struct EdgeGeom {
+  static constexpr bool SPLIT = lane_split(L);
+  static constexpr u32 N = 1u << L;
+  static constexpr int HEAD_NC = SPLIT ? 4 : (1 << head_log(L));  // coefficients a head thread owns
+  static constexpr u32 HEAD_THREADS = SPLIT ? N / 4 : (N >> head_log(L));  // head threads per polynomial
+  static constexpr u32 QH = SPLIT ? N / 8 : N / (u32)HEAD_NC;              // distance between the set's coefficients
+  static constexpr u32 QT = SPLIT ? N / 8 : N / 4;
+  static __device__ __forceinline__ u32 half(u32 t) { return (t >> 5) & 1u; }
+  static __device__ __forceinline__ u32 base(u32 t) { return SPLIT ? (((t >> 6) << 5) | (t & 31u)) : t; }
+  static __device__ __forceinline__ u32 k_natural(u32 t, int j) { return SPLIT ? (u32)j + 4u * half(t) : (u32)j; }
+  static __device__ __forceinline__ u32 k_split(u32 t, int j) { return SPLIT ? (((u32)j & 1u) | (((u32)j >> 1) << 2) | (half(t) << 1)) : (u32)j; }
+  // coefficient index of owned slot j
+  static __device__ __forceinline__ u32 head_in(u32 t, int j) { return base(t) + k_split(t, j) * QH; }
+  static __device__ __forceinline__ u32 head_out(u32 t, int j) { return base(t) + k_natural(t, j) * QH; }
+  static __device__ __forceinline__ u32 tail_in(u32 t, int j) { return base(t) + k_natural(t, j) * QT; }
+  static __device__ __forceinline__ u32 tail_out(u32 t, int j) { return base(t) + k_split(t, j) * QT; }
+};
+
+__device__ __forceinline__ u32 swap_adjacent_lanes(u32 v) {
+  return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+// lower half-wave's `lo_side` <-> upper half-wave's `hi_side` (v_permlane32_swap: lanes 32..63 of vdst swap with lanes 0..31 of src)
+__device__ __forceinline__ void half_wave_swap(u32& hi_side, u32& lo_side) {
+  const auto r = __builtin_amdgcn_permlane32_swap(hi_side, lo_side, false, false);
+  hi_side = r[0];
+  lo_side = r[1];
+}
+__device__ __forceinline__ void half_wave_swap(double& hi_side, double& lo_side) {
+  u32 hl = (u32)__double2loint(hi_side), hh = (u32)__double2hiint(hi_side), ll = (u32)__double2loint(lo_side), lh = (u32)__double2hiint(lo_side);
+  half_wave_swap(hl, ll);
+  half_wave_swap(hh, lh);
+  hi_side = __hiloint2double((int)hh, (int)hl);
+  lo_side = __hiloint2double((int)lh, (int)ll);
+}
+__device__ __forceinline__ void half_wave_swap(u64& hi_side, u64& lo_side) {
+  u32 hl = (u32)hi_side, hh = (u32)(hi_side >> 32), ll = (u32)lo_side, lh = (u32)(lo_side >> 32);
+  half_wave_swap(hl, ll);
+  half_wave_swap(hh, lh);
+  hi_side = ((u64)hh << 32) | hl;
+  lo_side = ((u64)lh << 32) | ll;
+}
+// natural <-> split: the lower lane gives its slots 2,3 and takes the upper lane's slots 0,1 (the map is its own inverse)
+template <class V>
+__device__ __forceinline__ void lane_pair_exchange(V (&v)[4]) {
+  half_wave_swap(v[0], v[2]);
+  half_wave_swap(v[1], v[3]);
+}
+
+template <class A, int NC>
+__device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], const typename A::Tw* __restrict__ tw);
+
+// The twiddle of a lane-split stage depends on the half-wave only.  Loading tw[i + s] would be a VECTOR load (two distinct
+// addresses per wavefront) in the middle of the dependency chain; both candidates are wave-uniform, so they come through the
+// scalar cache and the lane picks one (4 v_cndmask per twiddle).
+// (pinning the candidates in SGPRs keeps the compiler from turning select(load a, load b) into one divergent load)
+__device__ __forceinline__ u64 pin_scalar(u64 v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+__device__ __forceinline__ MulOpD pick_tw(const MulOpD& a, const MulOpD& b, bool upper) {
+  const u64 aw = pin_scalar((u64)__double_as_longlong(a.w)), aq = pin_scalar((u64)__double_as_longlong(a.wq));
+  const u64 bw = pin_scalar((u64)__double_as_longlong(b.w)), bq = pin_scalar((u64)__double_as_longlong(b.wq));
+  MulOpD r;
+  r.w = __longlong_as_double((long long)(upper ? bw : aw));
+  r.wq = __longlong_as_double((long long)(upper ? bq : aq));
+  return r;
+}
+__device__ __forceinline__ MulOp pick_tw(const MulOp& a, const MulOp& b, bool upper) {
+  const u64 aw = pin_scalar(a.w), aq = pin_scalar(a.wq), bw = pin_scalar(b.w), bq = pin_scalar(b.wq);
+  MulOp r;
+  r.w = upper ? bw : aw;
+  r.wq = upper ? bq : aq;
+  return r;
+}
+
+// the head's forward stages on the coefficients thread t owns: in = coefficient-wise side, out = middle-kernel side
+template <class A, int L>
+__device__ __forceinline__ void head_fwd_owned(const A& ar, typename A::V (&v)[EdgeGeom<L>::HEAD_NC], const typename A::Tw* __restrict__ tw, u32 t) {
+  if constexpr (!EdgeGeom<L>::SPLIT) {
+    head_fwd(ar, v, tw);
+  } else {
+    const bool upper = EdgeGeom<L>::half(t) != 0;
+    // gap N/2 (pairs k, k+4) in the split arrangement: slots (0,2), (1,3); twiddle index 1
+    ar.fwd(v[0], v[2], tw[1]);
+    ar.fwd(v[1], v[3], tw[1]);
+    lane_pair_exchange(v);
+    // gap N/4 (pairs k, k+2) in the natural arrangement: slots (0,2), (1,3); twiddle 2 + (k >> 2) = 2 + s
+    const typename A::Tw w1 = pick_tw(tw[2], tw[3], upper);
+    ar.fwd(v[0], v[2], w1);
+    ar.fwd(v[1], v[3], w1);
+    // gap N/8 (pairs k, k+1): slots (0,1), (2,3); twiddle 4 + (k >> 1) = 4 + 2s + slot/2
+    ar.fwd(v[0], v[1], pick_tw(tw[4], tw[6], upper));
+    ar.fwd(v[2], v[3], pick_tw(tw[5], tw[7], upper));
+  }
+}
+
+template <int L, class A>
+__device__ __forceinline__ void tail_inverse4(const A& ar, typename A::V (&v)[4], const typename A::Tw* __restrict__ tw, u32 mask);
+
+// the tail's inverse stages on the 4 values thread t holds: in = middle-kernel side, out = coefficient-wise side
+template <class A, int L>
+__device__ __forceinline__ void tail_inv_owned(const A& ar, typename A::V (&v)[4], const typename A::Tw* __restrict__ tw, u32 mask, u32 t) {
+  if constexpr (!EdgeGeom<L>::SPLIT) {
+    tail_inverse4<L, A>(ar, v, tw, mask);
+  } else {
+    const bool upper = EdgeGeom<L>::half(t) != 0;
+    if ((mask >> 8) & 1u) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
+    }
+    if ((mask >> 24) & 1u) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
+    }
+    // window [L-3, L): gap N/8 (pairs k, k+1), twiddle 4 + (k >> 1); gap N/4 (k, k+2), twiddle 2 + (k >> 2); gap N/2, twiddle 1
+    ar.inv(v[0], v[1], pick_tw(tw[4], tw[6], upper));
+    ar.inv(v[2], v[3], pick_tw(tw[5], tw[7], upper));
+    const typename A::Tw w1 = pick_tw(tw[2], tw[3], upper);
+    ar.inv(v[0], v[2], w1);
+    ar.inv(v[1], v[3], w1);
+    lane_pair_exchange(v);
+    ar.inv(v[0], v[2], tw[1]);
+    ar.inv(v[1], v[3], tw[1]);
+  }
+}
+
 // Packed stores of the NC values a head thread owns (indices t + k*Q), two values per store instruction.  Stored one by one, a
 // packed value costs a 4-byte and a 2-byte store per lane -- the narrowest accesses of the whole pipeline.  Neighbouring
 // lanes own neighbouring coefficients, so a pair of lanes (2i, 2i+1) exchanges halves across the wavefront (one DPP quad_perm
@@ -536,9 +675,10 @@ __device__ __forceinline__ void nat_store(double* __restrict__ region, u32 n, si
 #ifndef PACK_PAIR_STORES
 #define PACK_PAIR_STORES 0  // measured (interleaved A/B, r02): mul_head +0.8 %, ks_head +2 % SLOWER with the pair stores: store width is not what limits the head kernels
 #endif
-__device__ __forceinline__ u32 swap_adjacent_lanes(u32 v) {
-  return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-}
+// the NC head outputs of thread t to their places facing the middle kernels (EdgeGeom::head_out)
+template <int L, bool PACK, bool NT>
+__device__ __forceinline__ void nat_store_head(double* __restrict__ region, u32 t, const double (&v)[EdgeGeom<L>::HEAD_NC]);
+
 template <bool PACK, bool NT, int NC>
 __device__ __forceinline__ void nat_store_owned(double* __restrict__ region, u32 n, u32 t, size_t Q, const double (&v)[NC]) {
   if constexpr (PACK && PACK_PAIR_STORES && !NT && (NC % 2 == 0)) {
@@ -567,6 +707,16 @@ __device__ __forceinline__ void nat_store_owned(double* __restrict__ region, u32
     for (int k = 0; k < NC; k++) nat_store<PACK, NT>(region, n, t + (size_t)k * Q, v[k]);
   }
 }
+template <int L, bool PACK, bool NT>
+__device__ __forceinline__ void nat_store_head(double* __restrict__ region, u32 t, const double (&v)[EdgeGeom<L>::HEAD_NC]) {
+  using G = EdgeGeom<L>;
+  if constexpr (!G::SPLIT) {
+    nat_store_owned<PACK, NT, G::HEAD_NC>(region, G::N, t, G::QH, v);
+  } else {
+#pragma unroll
+    for (int k = 0; k < G::HEAD_NC; k++) nat_store<PACK, NT>(region, G::N, G::head_out(t, k), v[k]);
+  }
+}
 
 __device__ __forceinline__ bool residue_is_f64(const DevMod& dm) { return dm.use_f64 && dm.split_ok; }
 template <class A, int NC>
@@ -582,15 +732,16 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 template <int L, bool PACK, bool MIXED>
 __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                const u64* __restrict__ target, size_t tstride, double* __restrict__ T) {
-  constexpr int NC = 1 << head_log(L);
-  constexpr u32 N = 1u << L, Q = N / NC;
+  using G = EdgeGeom<L>;
+  constexpr int NC = G::HEAD_NC;
+  constexpr u32 N = 1u << L;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 J = blockIdx.y, op = blockIdx.z;
   const u32 K = ctx->K, KK = ctx->KK;
-  const u64* src = target + (size_t)op * tstride + (size_t)J * N + t;
+  const u64* src = target + (size_t)op * tstride + (size_t)J * N;
   u64 x[NC];
 #pragma unroll
-  for (int k = 0; k < NC; k++) x[k] = src[(size_t)k * Q];
+  for (int k = 0; k < NC; k++) x[k] = src[G::head_in(t, k)];
   const u64 qJ = ctx->mod[J].q;
   for (u32 I = 0; I < KK; I++) {
     const DevMod& dm = ctx->mod[I];
@@ -601,10 +752,10 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
         u64 w[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) w[k] = shrink ? reduce64(x[k], dm) : x[k];
-        head_fwd(ai, w, twf_base + (size_t)I * N);
+        head_fwd_owned<ArithI, L>(ai, w, twf_base + (size_t)I * N, t);
         u64* dsti = reinterpret_cast<u64*>(T) + (((size_t)op * KK + I) * K + J) * N;
 #pragma unroll
-        for (int k = 0; k < NC; k++) dsti[t + (size_t)k * Q] = w[k];
+        for (int k = 0; k < NC; k++) dsti[G::head_out(t, k)] = w[k];
         continue;
       }
     }
@@ -623,13 +774,13 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
         v[k] = need_reduce ? ar.reduce(d) : d;
       }
     }
-    head_fwd(ar, v, tw);
+    head_fwd_owned<ArithD, L>(ar, v, tw, t);
     double* dst = T + (((size_t)op * KK + I) * K + J) * N;
     if constexpr (PACK) {
 #pragma unroll
       for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
     }
-    nat_store_owned<PACK, NtSites<L>::ks_head_st, NC>(dst, N, t, Q, v);
+    nat_store_head<L, PACK, NtSites<L>::ks_head_st>(dst, t, v);
   }
 }
 
@@ -877,7 +1028,8 @@ template <int L, bool PACK, bool MIXED>
 __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                const double* __restrict__ ACC, const u64* __restrict__ base, size_t bstride,
                                                                u32 base_mask, const u64* __restrict__ extra, u64* __restrict__ out) {
-  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  using G = EdgeGeom<L>;
+  constexpr u32 N = 1u << L;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 c = blockIdx.y, op = blockIdx.z;
   const u32 K = ctx->K, KK = ctx->KK;
@@ -889,11 +1041,11 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     const DevMod& sp = ctx->mod[KK - 1];
     if (!residue_is_f64(sp)) {
       const ArithI ai(sp);
-      const u64* src = reinterpret_cast<const u64*>(acc) + (size_t)(KK - 1) * N + t;
+      const u64* src = reinterpret_cast<const u64*>(acc) + (size_t)(KK - 1) * N;
       u64 w[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) w[k] = src[(size_t)k * Q];
-      tail_inverse4<L, ArithI>(ai, w, twi_base + (size_t)(KK - 1) * N, 0u);
+      for (int k = 0; k < 4; k++) w[k] = src[G::tail_in(t, k)];
+      tail_inv_owned<ArithI, L>(ai, w, twi_base + (size_t)(KK - 1) * N, 0u, t);
 #pragma unroll
       for (int k = 0; k < 4; k++) tl[k] = add_mod(ai.scale_canonical(w[k], sp.ninv), ctx->qsp_half, sp.q);
       sp_done = true;
@@ -905,8 +1057,8 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK - 1) * N);
     double v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)(KK - 1) * N, N, t + (size_t)k * Q);
-    tail_inverse4<L>(ar, v, tw, sp.split_inv_mask);
+    for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)(KK - 1) * N, N, G::tail_in(t, k));
+    tail_inv_owned<ArithD, L>(ar, v, tw, sp.split_inv_mask, t);
 #pragma unroll
     for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
   }
@@ -918,11 +1070,11 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     if constexpr (MIXED) {
       if (!residue_is_f64(mj)) {
         const ArithI ai(mj);
-        const u64* src = reinterpret_cast<const u64*>(acc) + (size_t)J * N + t;
+        const u64* src = reinterpret_cast<const u64*>(acc) + (size_t)J * N;
         u64 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) w[k] = src[(size_t)k * Q];
-        tail_inverse4<L, ArithI>(ai, w, twi_base + (size_t)J * N, 0u);
+        for (int k = 0; k < 4; k++) w[k] = src[G::tail_in(t, k)];
+        tail_inv_owned<ArithI, L>(ai, w, twi_base + (size_t)J * N, 0u, t);
 #pragma unroll
         for (int k = 0; k < 4; k++) av[k] = ai.scale_canonical(w[k], mj.ninv);
         done = true;
@@ -933,8 +1085,8 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
       const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)J * N);
       double v[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, t + (size_t)k * Q);
-      tail_inverse4<L>(ar, v, tw, mj.split_inv_mask);
+      for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, G::tail_in(t, k));
+      tail_inv_owned<ArithD, L>(ar, v, tw, mj.split_inv_mask, t);
 #pragma unroll
       for (int k = 0; k < 4; k++) av[k] = ar.scale_canonical(v[k], mj.ninv_d);
     }
@@ -945,7 +1097,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
       tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
       u64 d = sub_mod(a, tk, mj.q);
       d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
-      const size_t off = ((size_t)c * K + J) * N + t + (size_t)k * Q;
+      const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
       u64 bv = ((base_mask >> c) & 1u) ? base[(size_t)op * bstride + off] : 0;
       if (extra) bv = add_mod(bv, extra[((size_t)op * 2) * K * N + off], mj.q);  // a ciphertext added to the result (fused Add node)
       out[((size_t)op * 2) * K * N + off] = add_mod(bv, d, mj.q);
@@ -995,19 +1147,21 @@ template <int L, int KMAX, bool AUXD, bool PACK>
 __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
                                                                 u64* __restrict__ ext) {
-  constexpr int NC = 1 << head_log(L);
-  constexpr u32 N = 1u << L, Q = N / NC;
+  using G = EdgeGeom<L>;
+  constexpr int NC = G::HEAD_NC;
+  constexpr u32 N = 1u << L;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 poly = blockIdx.y, op = blockIdx.z;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
-  const u64* src = (poly < 2 ? in0 + ((size_t)op * 2 + poly) * K * N : in1 + ((size_t)op * 2 + (poly - 2)) * K * N) + t;
-  u64* dst = ext + ((size_t)op * 4 + poly) * R * N + t;
+  // src / dst: the polynomial's rows; owned coefficients sit at G::head_in(t, k) (inputs) / G::head_out(t, k) (outputs)
+  const u64* src = (poly < 2 ? in0 + ((size_t)op * 2 + poly) * K * N : in1 + ((size_t)op * 2 + (poly - 2)) * K * N);
+  u64* dst = ext + ((size_t)op * 4 + poly) * R * N;
   if constexpr (AUXD) {
     double x[KMAX][NC];
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
 #pragma unroll
-      for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? ArithD::from_u64(src[(size_t)i * N + (size_t)k * Q]) : 0.0;
+      for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? ArithD::from_u64(src[(size_t)i * N + G::head_in(t, k)]) : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
@@ -1016,26 +1170,26 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
         double v[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) v[k] = x[i][k];
-        head_fwd(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)i * N));
-        double* o = reinterpret_cast<double*>(dst - t + (size_t)i * N);
+        head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)i * N), t);
+        double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
         if constexpr (PACK) {
 #pragma unroll
           for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
         }
-        nat_store_owned<PACK, NtSites<L>::head_st, NC>(o, N, t, Q, v);
+        nat_store_head<L, PACK, NtSites<L>::head_st>(o, t, v);
       }
     }
     // auxiliary base: extend all eight owned coefficients residue by residue (every conversion constant is
     // fetched once), and run the head stages of each auxiliary residue as soon as it is complete
     behz_extend_multi_d<KMAX, NC>(ctx, x, [&](u32 j, double(&ev)[NC]) {
       const ArithD ar(ctx->mod[KK + j]);
-      head_fwd(ar, ev, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N));
-      double* o = reinterpret_cast<double*>(dst - t + (size_t)(K + j) * N);
+      head_fwd_owned<ArithD, L>(ar, ev, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N), t);
+      double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
       if constexpr (PACK) {
 #pragma unroll
         for (int k = 0; k < NC; k++) ev[k] = ar.reduce(ev[k]);
       }
-      nat_store_owned<PACK, NtSites<L>::head_st, NC>(o, N, t, Q, ev);
+      nat_store_head<L, PACK, NtSites<L>::head_st>(o, t, ev);
     });
     return;
   }
@@ -1043,7 +1197,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
 #pragma unroll
-    for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? src[(size_t)i * N + (size_t)k * Q] : 0;
+    for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? src[(size_t)i * N + G::head_in(t, k)] : 0;
   }
   // q residues: just the three head stages
 #pragma unroll
@@ -1056,19 +1210,19 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
         double v[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) v[k] = ar.from_u64(x[i][k]);
-        head_fwd(ar, v, reinterpret_cast<const MulOpD*>(tw));
+        head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const MulOpD*>(tw), t);
         double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
 #pragma unroll
-        for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
+        for (int k = 0; k < NC; k++) o[G::head_out(t, k)] = v[k];
       } else {
         const ArithI ar(dm);
         u64 v[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) v[k] = x[i][k];
-        head_fwd(ar, v, tw);
+        head_fwd_owned<ArithI, L>(ar, v, tw, t);
         u64* o = dst + (size_t)i * N;
 #pragma unroll
-        for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
+        for (int k = 0; k < NC; k++) o[G::head_out(t, k)] = v[k];
       }
     }
   }
@@ -1093,10 +1247,10 @@ __global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __
       u64 v[NC];
 #pragma unroll
       for (int k = 0; k < NC; k++) v[k] = ev[j][k];
-      head_fwd(ar, v, twf_base + (size_t)(KK + j) * N);
+      head_fwd_owned<ArithI, L>(ar, v, twf_base + (size_t)(KK + j) * N, t);
       u64* o = dst + (size_t)(K + j) * N;
 #pragma unroll
-      for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
+      for (int k = 0; k < NC; k++) o[G::head_out(t, k)] = v[k];
     }
   }
 }
@@ -1315,48 +1469,27 @@ __global__ __launch_bounds__((MulMidGeom<L, POLICY_D>::TPB), (MulMidGeom<L, POLI
     mul_mid_body<ArithI, L>(dm, twf, twi, ext_r, ps, D_r, ps, smem, park, tid, blk);
 }
 
-// last two inverse stages + BEHZ scaling on {t + k*N/4}: canonical residues out
-template <class A>
-__device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V* __restrict__ src, size_t Q, const typename A::Tw* __restrict__ tw,
+// the tail's inverse stages + BEHZ scaling on the 4 coefficients thread t owns (EdgeGeom): canonical residues out
+// src: the residue row (not offset by t)
+template <class A, int L>
+__device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V* __restrict__ src, u32 t, const typename A::Tw* __restrict__ tw,
                                                 const typename A::Tw& sc, u32 mask, u64 (&out)[4]) {
   typename A::V v[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) v[k] = src[(size_t)k * Q];
-  if ((mask >> 8) & 1u) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
-  }
-  if ((mask >> 24) & 1u) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
-  }
-  ar.inv(v[0], v[1], tw[2]);
-  ar.inv(v[2], v[3], tw[3]);
-  ar.inv(v[0], v[2], tw[1]);
-  ar.inv(v[1], v[3], tw[1]);
+  for (int k = 0; k < 4; k++) v[k] = src[EdgeGeom<L>::tail_in(t, k)];
+  tail_inv_owned<A, L>(ar, v, tw, mask, t);
 #pragma unroll
   for (int k = 0; k < 4; k++) out[k] = ar.scale_canonical(v[k], sc);
 }
 
 // the same for the FP64 epilogue: reduced doubles out (|out| <= q/2)
-template <bool PACK>
+template <int L, bool PACK>
 __device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const NatRaw<PACK> (&raw)[4], const MulOpD* __restrict__ tw, const MulOpD& sc,
-                                                  u32 mask, double (&out)[4]) {
+                                                  u32 mask, u32 t, double (&out)[4]) {
   double v[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACK>(raw[k]);
-  if ((mask >> 8) & 1u) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
-  }
-  if ((mask >> 24) & 1u) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = ar.reduce(v[k]);
-  }
-  ar.inv(v[0], v[1], tw[2]);
-  ar.inv(v[2], v[3], tw[3]);
-  ar.inv(v[0], v[2], tw[1]);
-  ar.inv(v[1], v[3], tw[1]);
+  tail_inv_owned<ArithD, L>(ar, v, tw, mask, t);
 #pragma unroll
   for (int k = 0; k < 4; k++) out[k] = ar.reduce(ar.mul_const(v[k], sc));
 }
@@ -1365,11 +1498,12 @@ __device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const NatRaw
 // GRID (DevCtx::conv_grid, 8-prime all-FP64 instantiation only): floor sums formed exactly and reduced once (griddot.hpp)
 // All-FP64 tail of the BEHZ multiply for the 4 coefficients {t + k*N/4} of ONE output polynomial: last two inverse stages of
 // every residue, scaling, fast_floor + Shenoy-Kumaresan conversion (behz_floor_sk_multi_d): canonical data residues in res.
-// d: the polynomial's R residue rows in D, already offset by t.
+// d: the polynomial's R residue rows in D (not offset by t); thread t owns the coefficients EdgeGeom<L>::tail_out(t, k).
 template <int L, int KMAX, bool PACK, bool GRID>
 __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base, const u64* __restrict__ d, u32 t,
                                                    u64 (&res)[KMAX][4]) {
-  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  using G = EdgeGeom<L>;
+  constexpr u32 N = 1u << L;
   const u32 K = ctx->K, KK = ctx->KK;
     double yc[KMAX][4];
 #pragma unroll
@@ -1380,8 +1514,8 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
       double r4[4];
       NatRaw<PACK> raw[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d - t + (size_t)i * N), N, t + (size_t)k * Q);
-      tail_inv4_scale_d<PACK>(ar, raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
+      for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d + (size_t)i * N), N, G::tail_in(t, k));
+      tail_inv4_scale_d<L, PACK>(ar, raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
 #pragma unroll
       for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
     }
@@ -1390,12 +1524,12 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
       ctx, yc,
       [&](u32 j, NatRaw<PACK>(&raw)[4]) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d - t + (size_t)(K + j) * N), N, t + (size_t)k * Q);
+        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d + (size_t)(K + j) * N), N, G::tail_in(t, k));
       },
       [&](u32 j, const NatRaw<PACK>(&raw)[4], double(&xb)[4]) {
         const DevMod& dm = ctx->mod[KK + j];
-        tail_inv4_scale_d<PACK>(ArithD(dm), raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j],
-                                dm.split_inv_mask, xb);
+        tail_inv4_scale_d<L, PACK>(ArithD(dm), raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j],
+                                   dm.split_inv_mask, t, xb);
       },
       res);
 }
@@ -1406,12 +1540,13 @@ template <int L, int KMAX, bool AUXD, bool PACK, bool GRID>
 // multiply + relinearize, whose last kernel forms c0 and c1 itself: mulrelin_tail_kernel)
 __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                 const u64* __restrict__ D, u64* __restrict__ out, u32 poly0, u32 out_polys) {
-  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  using G = EdgeGeom<L>;
+  constexpr u32 N = 1u << L;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 poly = blockIdx.y + poly0, op = blockIdx.z;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
-  const u64* d = D + ((size_t)op * 3 + poly) * R * N + t;
-  u64* o = out + ((size_t)op * out_polys + (poly - poly0)) * K * N + t;
+  const u64* d = D + ((size_t)op * 3 + poly) * R * N;
+  u64* o = out + ((size_t)op * out_polys + (poly - poly0)) * K * N;
   if constexpr (AUXD) {
     u64 res[KMAX][4];
     mul_tail_compute_d<L, KMAX, PACK, GRID>(ctx, twi_base, d, t, res);
@@ -1419,7 +1554,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
     for (int i = 0; i < KMAX; i++)
       if ((u32)i < K) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) o[(size_t)i * N + (size_t)k * Q] = res[i][k];
+        for (int k = 0; k < 4; k++) o[(size_t)i * N + G::tail_out(t, k)] = res[i][k];
       }
     return;
   }
@@ -1431,11 +1566,11 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
       u64 r4[4];
       if (residue_is_f64(dm)) {
         const ArithD ar(dm);
-        tail_inv4_scale(ar, reinterpret_cast<const double*>(d + (size_t)i * N), Q, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
-                        ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
+        tail_inv4_scale<ArithD, L>(ar, reinterpret_cast<const double*>(d + (size_t)i * N), t, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
+                                   ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
       } else {
         const ArithI ar(dm);
-        tail_inv4_scale(ar, d + (size_t)i * N, Q, twi_base + (size_t)i * N, ctx->intt_scale_q[i], 0u, r4);
+        tail_inv4_scale<ArithI, L>(ar, d + (size_t)i * N, t, twi_base + (size_t)i * N, ctx->intt_scale_q[i], 0u, r4);
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) y[k][i] = r4[k];
@@ -1447,7 +1582,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
       const DevMod& dm = ctx->mod[KK + j];
       const ArithI ar(dm);
       u64 r4[4];
-      tail_inv4_scale(ar, d + (size_t)(K + j) * N, Q, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], 0u, r4);
+      tail_inv4_scale<ArithI, L>(ar, d + (size_t)(K + j) * N, t, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], 0u, r4);
 #pragma unroll
       for (int k = 0; k < 4; k++) xb[k][j] = r4[k];
     }
@@ -1460,7 +1595,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
     behz_floor_sk_coeff<KMAX>(ctx, y[0], xb[0], r);
 #pragma unroll
     for (int i = 0; i < KMAX; i++)
-      if ((u32)i < K) o[(size_t)i * N + (size_t)k * Q] = r[i];
+      if ((u32)i < K) o[(size_t)i * N + G::tail_out(t, k)] = r[i];
 #pragma unroll
     for (int kk = 0; kk < 3; kk++) {
 #pragma unroll
@@ -1481,12 +1616,13 @@ template <int L, int KMAX, bool PACKM, bool GRID, bool PACKK>
 __global__ __launch_bounds__(kHeadThreads) void mulrelin_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                      const u64* __restrict__ D, const double* __restrict__ ACC,
                                                                      const u64* __restrict__ extra, u64* __restrict__ out) {
-  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  using G = EdgeGeom<L>;
+  constexpr u32 N = 1u << L;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 c = blockIdx.y, op = blockIdx.z;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   u64 basev[KMAX][4];
-  mul_tail_compute_d<L, KMAX, PACKM, GRID>(ctx, twi_base, D + ((size_t)op * 3 + c) * R * N + t, t, basev);
+  mul_tail_compute_d<L, KMAX, PACKM, GRID>(ctx, twi_base, D + ((size_t)op * 3 + c) * R * N, t, basev);
   const double* acc = ACC + ((size_t)op * 2 + c) * KK * N;
   u64 tl[4];
   {
@@ -1495,8 +1631,8 @@ __global__ __launch_bounds__(kHeadThreads) void mulrelin_tail_kernel(const DevCt
     const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK - 1) * N);
     double v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = nat_load<PACKK, NtSites<L>::tail_ld>(acc + (size_t)(KK - 1) * N, N, t + (size_t)k * Q);
-    tail_inverse4<L>(ar, v, tw, sp.split_inv_mask);
+    for (int k = 0; k < 4; k++) v[k] = nat_load<PACKK, NtSites<L>::tail_ld>(acc + (size_t)(KK - 1) * N, N, G::tail_in(t, k));
+    tail_inv_owned<ArithD, L>(ar, v, tw, sp.split_inv_mask, t);
 #pragma unroll
     for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
   }
@@ -1509,8 +1645,8 @@ __global__ __launch_bounds__(kHeadThreads) void mulrelin_tail_kernel(const DevCt
     const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)J * N);
     double v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = nat_load<PACKK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, t + (size_t)k * Q);
-    tail_inverse4<L>(ar, v, tw, mj.split_inv_mask);
+    for (int k = 0; k < 4; k++) v[k] = nat_load<PACKK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, G::tail_in(t, k));
+    tail_inv_owned<ArithD, L>(ar, v, tw, mj.split_inv_mask, t);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
@@ -1518,7 +1654,7 @@ __global__ __launch_bounds__(kHeadThreads) void mulrelin_tail_kernel(const DevCt
       tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
       u64 dd = sub_mod(a, tk, mj.q);
       dd = mul_shoup(dd, ctx->inv_qsp_mod_q[J], mj.q);
-      const size_t off = ((size_t)c * K + J) * N + t + (size_t)k * Q;
+      const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
       u64 bv = basev[J][k];
       if (extra) bv = add_mod(bv, extra[((size_t)op * 2) * K * N + off], mj.q);
       out[((size_t)op * 2) * K * N + off] = add_mod(bv, dd, mj.q);
@@ -1537,18 +1673,21 @@ template <int L, int KMAX, bool PACKM, bool GRID, bool PACKK>
 __global__ __launch_bounds__(kHeadThreads) void mulrelin_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                      const MulOp* __restrict__ twf_base, const u64* __restrict__ D,
                                                                      double* __restrict__ T) {
-  constexpr int NC = 1 << head_log(L);
+  using G = EdgeGeom<L>;
+  constexpr int NC = G::HEAD_NC;
+  // plain degrees: the head's NC = 8 coefficients {t + k*N/8} are two of the tail's groups {t' + k*N/4}, t' = t + h*N/8;
+  // lane-split degrees: a lane owns the same 4 coefficients in the tail (its output side) and in the head (its input side)
   constexpr int GROUPS = NC / 4;
-  constexpr u32 N = 1u << L, Q = N / NC;
+  constexpr u32 N = 1u << L;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 op = blockIdx.z;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   u64 x[KMAX][NC];
 #pragma unroll
   for (int h = 0; h < GROUPS; h++) {
-    const u32 tt = t + (u32)h * Q;
+    const u32 tt = t + (u32)h * (N / 8);
     u64 res[KMAX][4];
-    mul_tail_compute_d<L, KMAX, PACKM, GRID>(ctx, twi_base, D + ((size_t)op * 3 + 2) * R * N + tt, tt, res);
+    mul_tail_compute_d<L, KMAX, PACKM, GRID>(ctx, twi_base, D + ((size_t)op * 3 + 2) * R * N, tt, res);
 #pragma unroll
     for (int J = 0; J < KMAX; J++)
 #pragma unroll
@@ -1569,13 +1708,13 @@ __global__ __launch_bounds__(kHeadThreads) void mulrelin_head_kernel(const DevCt
         const double d = ar.from_u64(x[J][k]);
         v[k] = need_reduce ? ar.reduce(d) : d;
       }
-      head_fwd(ar, v, tw);
+      head_fwd_owned<ArithD, L>(ar, v, tw, t);
       double* dst = T + (((size_t)op * KK + I) * K + J) * N;
       if constexpr (PACKK) {
 #pragma unroll
         for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
       }
-      nat_store_owned<PACKK, NtSites<L>::ks_head_st, NC>(dst, N, t, Q, v);
+      nat_store_head<L, PACKK, NtSites<L>::ks_head_st>(dst, t, v);
     }
   }
 }
@@ -1698,26 +1837,27 @@ __global__ __launch_bounds__((SplitShape<L>::TPB)) void ntt_midinv_kernel(const 
 template <int L>
 __global__ __launch_bounds__(kHeadThreads) void ntt_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base, u64* data,
                                                                 NttPlan plan, int scale_mode) {
-  constexpr u32 N = 1u << L, Q = N >> kTailLog;
+  using G = EdgeGeom<L>;
+  constexpr u32 N = 1u << L;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
   const u32 poly = blockIdx.y;
   const u32 m = plan_mod_split(plan, poly);
   const DevMod& dm = ctx->mod[m];
-  u64* x = data + (size_t)poly * N + t;
+  u64* x = data + (size_t)poly * N;
   const MulOp* tw = twi_base + (size_t)m * N;
   u64 o[4];
   if (residue_is_f64(dm)) {
     const ArithD ar(dm);
     const MulOpD sc = scale_mode == 1 ? (m < ctx->KK ? ctx->intt_scale_q_d[m] : ctx->intt_scale_bsk_d[m - ctx->KK]) : dm.ninv_d;
-    tail_inv4_scale(ar, reinterpret_cast<const double*>(x), Q, reinterpret_cast<const MulOpD*>(tw), sc, dm.split_inv_mask, o);
+    tail_inv4_scale<ArithD, L>(ar, reinterpret_cast<const double*>(x), t, reinterpret_cast<const MulOpD*>(tw), sc, dm.split_inv_mask, o);
   } else {
     const ArithI ar(dm);
     MulOp sc = dm.ninv;
     if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
-    tail_inv4_scale(ar, x, Q, tw, sc, 0u, o);
+    tail_inv4_scale<ArithI, L>(ar, x, t, tw, sc, 0u, o);
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) x[(size_t)k * Q] = o[k];
+  for (int k = 0; k < 4; k++) x[G::tail_out(t, k)] = o[k];
 }
 
 template <int L>
@@ -1758,7 +1898,7 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
 
 template <int L>
 static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
-  const dim3 grid(((1u << L) >> head_log(L)) / kHeadThreads, K, (unsigned)ops);
+  const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, K, (unsigned)ops);
   if (mixed)
     ks_head_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
   else if (pack)
@@ -1817,7 +1957,7 @@ hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pa
 template <int L>
 static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
                              size_t ops, hipStream_t s) {
-  const dim3 grid(((1u << L) >> head_log(L)) / kHeadThreads, 4, (unsigned)ops);
+  const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, 4, (unsigned)ops);
   if (kneed > 4) {  // only the all-FP64 instantiation exists for 5..8 data primes (evaluator.cpp checks)
     if (pack)
       mul_head_kernel<L, 8, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
@@ -1908,7 +2048,7 @@ static hipError_t mulrelin_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack
 template <int L>
 static hipError_t mulrelin_head_t(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
                                   u64* T, size_t ops, hipStream_t s) {
-  const dim3 grid(((1u << L) >> head_log(L)) / kHeadThreads, 1, (unsigned)ops);
+  const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, 1, (unsigned)ops);
   double* t = reinterpret_cast<double*>(T);
 #define MRH(KM, PM, GR, PK) mulrelin_head_kernel<L, KM, PM, GR, PK><<<grid, kHeadThreads, 0, s>>>(ctx, twi, twf, D, t)
   if (kneed > 4) {

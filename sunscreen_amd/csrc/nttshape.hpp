@@ -24,19 +24,28 @@ constexpr int ntt_stages_before(int logn, int p, int ept = kElemsPerThread) {
 // the last kTailLog inverse stages (gaps >= N/4) by the coefficient-parallel consumer kernel; everything
 // in between is local to contiguous blocks of N/4 coefficients and runs in one "middle" kernel per block
 // with 8 elements per thread.  Pass radices of the middle kernel:
-// Head depth per degree: 3 stages (8 coefficients per head thread) except at N = 16384, where 2 stages (4 coefficients)
-// halve the head kernels' register footprint at K = 8 and the middle kernel absorbs the extra stage without an extra pass
-// (12 stages = 3,3,3,3 instead of 11 = 2,3,3,3).
-#ifndef HIPBFV_HEAD_LOG_14
-#define HIPBFV_HEAD_LOG_14 2
+// Head / tail depth per degree.  N <= 8192: the head does 3 forward stages (a head thread owns the 8 coefficients
+// {t + k*N/8}), the tail the last 2 inverse stages ({t + k*N/4}), the middle kernels work on blocks of N/4 coefficients.
+// N = 16384 (HIPBFV_GEOM14):
+//   4 (default) = blocks of N/4 = 4096 coefficients, head 2 stages, tail 2 stages; one 128 KB-LDS middle workgroup per CU.
+//   8           = the block size of N = 8192 (N/8 = 2048 coefficients, 16 KB per transform in flight, two to three middle
+//                 workgroups per CU): head AND tail each take 3 stages, and because 8 coefficients per thread are too many
+//                 registers at 8 data primes, a PAIR of lanes (l, l + 32) shares each set of 8 (4 each; one of the three
+//                 stages sits between two halves that trade two values through v_permlane32_swap: lane_split, EdgeGeom).
+//     Measured in round 2 (interleaved A/B, n = 16384, K = 8+1, per 1024 ops): the middle kernels gain what the occupancy
+//     experiment predicted -- mul_mid 6.39 -> 5.28 ms, ks_mid 5.59 -> 5.01 -- but the head / tail kernels, which run at 2
+//     waves per SIMD there, pay more for their third stage and the exchange than that: mul_head 2.71 -> 3.48, fused ks_head
+//     2.45 -> 3.16, fused ks_tail 3.30 -> 4.02: 49.6 K -> 48.4 K mul+relin/s.  Bit-exact (the GPU suite runs the geom-8 build
+//     as a variant library, tests/test_gpu_properties.py); 4 stays the default.
+#ifndef HIPBFV_GEOM14
+#define HIPBFV_GEOM14 4
 #endif
-// Depth 2 is not selectable at N = 8192: its forward sequence would end with a radix-8 pass while the inverse starts
-// with a radix-4 one, and the pointwise work happens in the layout both must share (checked in SplitShape) -- and
-// mul_head is already at the copy rate there.
-static_assert(HIPBFV_HEAD_LOG_14 == 2 || HIPBFV_HEAD_LOG_14 == 3, "head depth at N = 16384 is 2 or 3");
-constexpr int head_log(int logn) { return logn == 14 ? HIPBFV_HEAD_LOG_14 : 3; }
+static_assert(HIPBFV_GEOM14 == 8 || HIPBFV_GEOM14 == 4, "N = 16384 middle blocks are N/8 or N/4 coefficients");
+constexpr bool lane_split(int logn) { return logn == 14 && HIPBFV_GEOM14 == 8; }
+constexpr int head_log(int logn) { return logn == 14 ? (HIPBFV_GEOM14 == 8 ? 3 : 2) : 3; }
+constexpr int tail_log(int logn) { return lane_split(logn) ? 3 : 2; }
 constexpr int kHeadLogMax = 3;
-constexpr int kTailLog = 2;
+constexpr int kTailLog = 2;  // degrees without lane splitting
 // Elements per middle-kernel thread: 8 (radix <= 8 passes).  4 (radix <= 4 passes, twice the threads, about half the
 // registers, ~40 % more passes) is a build-time experiment (-DHIPBFV_BLK_EPT=4), see DESIGN.md 5.5.
 #ifndef HIPBFV_BLK_EPT
@@ -45,18 +54,18 @@ constexpr int kTailLog = 2;
 constexpr int kBlkEPT = HIPBFV_BLK_EPT;
 static_assert(kBlkEPT == 8 || kBlkEPT == 4, "middle kernels hold 8 or 4 elements per thread");
 constexpr int split_fwd_passes(int logn) { return kBlkEPT == 4 ? (logn - head_log(logn) + 1) / 2 : (logn - head_log(logn) + 2) / 3; }
-constexpr int split_inv_passes(int logn) { return kBlkEPT == 4 ? (logn - kTailLog + 1) / 2 : (logn - kTailLog + 2) / 3; }
+constexpr int split_inv_passes(int logn) { return kBlkEPT == 4 ? (logn - tail_log(logn) + 1) / 2 : (logn - tail_log(logn) + 2) / 3; }
 constexpr int split_fwd_radix(int logn, int p) {
   // 4 per thread: radix 4 throughout, an odd stage count starts with one radix-2 pass
   if (kBlkEPT == 4) return (((logn - head_log(logn)) & 1) && p == 0) ? 1 : 2;
-  // remaining stages: 9 -> 3,3,3 ; 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3
-  return logn - head_log(logn) == 10 ? (p < 2 ? 3 : 2) : logn - head_log(logn) == 11 ? (p == 0 ? 2 : 3) : 3;
+  // remaining stages: 9 -> 3,3,3 ; 10 -> 3,3,2,2 ; 11 -> 3,3,3,2 (the inverse of 11 stages starts with a radix-4 pass) ; 12 -> 3,3,3,3
+  return logn - head_log(logn) == 10 ? (p < 2 ? 3 : 2) : logn - head_log(logn) == 11 ? (p < 3 ? 3 : 2) : 3;
 }
 constexpr int split_inv_radix(int logn, int p) {
   // 4 per thread: radix 4 throughout, an odd stage count ends with one radix-2 pass
-  if (kBlkEPT == 4) return (((logn - kTailLog) & 1) && p == split_inv_passes(logn) - 1) ? 1 : 2;
-  // logn-2 stages, first radix == last forward radix: 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3 ; 13 -> 3,3,3,2,2
-  return logn - kTailLog == 10 ? (p < 2 ? 3 : 2) : logn - kTailLog == 11 ? (p == 0 ? 2 : 3) : logn - kTailLog == 13 ? (p < 3 ? 3 : 2) : 3;
+  if (kBlkEPT == 4) return (((logn - tail_log(logn)) & 1) && p == split_inv_passes(logn) - 1) ? 1 : 2;
+  // logn - tail stages, first radix == last forward radix: 10 -> 3,3,2,2 ; 11 -> 2,3,3,3 ; 12 -> 3,3,3,3 ; 13 -> 3,3,3,2,2
+  return logn - tail_log(logn) == 10 ? (p < 2 ? 3 : 2) : logn - tail_log(logn) == 11 ? (p == 0 ? 2 : 3) : logn - tail_log(logn) == 13 ? (p < 3 ? 3 : 2) : 3;
 }
 constexpr int split_fwd_low(int logn, int p) {  // lowest index bit of the window of forward middle pass p
   int s = head_log(logn);

@@ -379,3 +379,62 @@ def test_batches_beyond_the_grid_dimension_limit():
     ct = ev.encrypt(enc, pkd, seed=9)
     check(ct, lambda i: ev.encrypt(enc[i : i + 1].contiguous(), pkd, seed=9, first_op=i))
     assert torch.equal(ev.decrypt(ct, skd), enc)
+
+
+def test_lane_split_geometry_build_gives_the_same_bits_at_n16384():
+    """The N = 16384 pipelines exist in two geometries (sunscreen_amd/csrc/nttshape.hpp, HIPBFV_GEOM14): the default (blocks of
+    N/4) and the lane-split one (blocks of N/8; pairs of lanes share eight coefficients and trade two values per residue with
+    v_permlane32_swap inside the head's and the tail's three stages), built as sunscreen_amd/lib/variants/libhipbfv_geom8.so
+    by `make variants`.  Same inputs through both libraries in separate processes: multiply, the fused multiply+relinearize,
+    relinearize and a rotation must agree word for word, and with the oracle."""
+    lib = os.path.join(ROOT, "sunscreen_amd", "lib", "variants", "libhipbfv_geom8.so")
+    assert os.path.exists(lib), "build the variant library first: make -C sunscreen_amd/csrc variants (build() does)"
+    script = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from tests.bfv_helpers import params
+from sunscreen_amd import Context, RelinearizationKeys, GaloisKeys
+from sunscreen_amd.batch import BatchEvaluator
+from oracle import bfv_oracle as O
+n, primes, t = params("default_16384_17")
+o = O.Oracle(n, primes, t); O.seed(14); sk, pk, rk, gk = o.keygen(galois_elts=[3])
+ctx = Context.from_raw(n, primes, t); ev = BatchEvaluator(ctx)
+gen = torch.Generator(device="cuda:0"); gen.manual_seed(14)
+a = torch.empty((5, 2, ctx.K, n), dtype=torch.int64, device="cuda:0"); b = torch.empty_like(a)
+for i, q in enumerate(primes[:ctx.K]):
+    a[:, :, i, :] = torch.randint(0, q, (5, 2, n), generator=gen, device="cuda:0", dtype=torch.int64)
+    b[:, :, i, :] = torch.randint(0, q, (5, 2, n), generator=gen, device="cuda:0", dtype=torch.int64)
+    a[4, :, i, :] = q - 1          # every residue at its maximum
+    b[4, :, i, ::2] = 0
+rkd = RelinearizationKeys.from_array(ctx, rk)
+r = ev.multiply_relin(a, b, rkd)
+m = ev.multiply(a, b)
+r2 = ev.relinearize(m, rkd)
+g = ev.apply_galois(a, 3, GaloisKeys.from_arrays(ctx, gk))
+torch.cuda.synchronize()
+assert torch.equal(r, r2)
+np.save(sys.argv[1], np.concatenate([x.cpu().numpy().ravel() for x in (a, b, r, m, g)]))
+""" % ROOT
+    import tempfile
+
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("default", {}), ("geom8", {"HIPBFV_LIB": lib})):
+            path = os.path.join(td, tag + ".npy")
+            subprocess.check_call([sys.executable, "-c", script, path], env=dict(os.environ, **env))
+            outs.append(np.load(path))
+    assert (outs[0] == outs[1]).all()
+    from tests.bfv_helpers import params
+
+    n, primes, t = params("default_16384_17")
+    K = len(primes) - 1
+    o = O.Oracle(n, primes, t)
+    o.throw_on_transparent = False
+    O.seed(14)
+    sk, pk, rk, gk = o.keygen(galois_elts=[3])
+    w = 5 * 2 * K * n
+    a = outs[1][:w].reshape(5, 2, K, n).astype(np.uint64)
+    b = outs[1][w : 2 * w].reshape(5, 2, K, n).astype(np.uint64)
+    r = outs[1][2 * w : 3 * w].reshape(5, 2, K, n).astype(np.uint64)
+    for i in (0, 4):
+        assert (r[i] == o.relinearize(o.multiply(a[i], b[i]), rk)).all(), i
