@@ -497,11 +497,19 @@ def cpu_baseline(args, O, n, primes, t):
         b = a[::-1].copy()
         secs1, _ = o.bench_mul_relin(a[: max(8, sample // threads)], b[: max(8, sample // threads)], rk, threads=1)
         one = max(8, sample // threads) / secs1
-        secs, _ = o.bench_mul_relin(a, b, rk, threads=threads)
-        return {"value": round(sample / secs, 2), "unit": "ops/s", "cores": threads, "kind": "port",
-                "sample": f"{sample} mul+relin ops (same parameters) with OpenMP over the batch on {threads} threads; "
-                          f"single-thread rate {one:.2f} ops/s on {max(8, sample // threads)} ops",
+        # OpenMP over the batch on every host core AND on 64 threads: the 256-CPU boxes run this memory-bound kernel faster
+        # on a quarter of their hardware threads (measured 840 vs 1700 ops/s); the better of the two is the baseline
+        trials = {}
+        for th in sorted({threads, min(threads, 64)}):
+            secs, _ = o.bench_mul_relin(a, b, rk, threads=th)
+            trials[th] = sample / secs
+        best = max(trials, key=trials.get)
+        return {"value": round(trials[best], 2), "unit": "ops/s", "cores": best, "kind": "port",
+                "sample": f"{sample} mul+relin ops (same parameters) with OpenMP over the batch; threads -> ops/s: "
+                          + ", ".join(f"{th} -> {v:.0f}" for th, v in sorted(trials.items()))
+                          + f"; single-thread rate {one:.2f} ops/s on {max(8, sample // threads)} ops",
                 "single_thread_value": round(one, 2), "host_cpus": cores}
+    threads = min(threads, 64)  # the secondary workloads keep the thread count round 1 measured them with
     if args.workload == "pir":
         from concurrent.futures import ThreadPoolExecutor
 
