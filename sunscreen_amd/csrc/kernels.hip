@@ -72,6 +72,9 @@ __device__ __forceinline__ void ntt_st(T* p, T v) {
 #ifndef NTT_WAVE_PRIVATE
 #define NTT_WAVE_PRIVATE 1
 #endif
+#ifndef NTT_WIDE_STORE
+#define NTT_WIDE_STORE 0
+#endif
 constexpr int wave_bit_target(int b, int low, int r) { return b >= low ? b + r : b; }
 // pa, pb: forward pass numbers of the two passes an exchange connects
 constexpr bool exchange_is_wave_private(int logn, int ept, int pa, int pb) {
@@ -134,12 +137,13 @@ struct FwdPasses {
     constexpr int S0 = Sh::before(PASS);
     constexpr int LOW = LOGN - S0 - R;
     constexpr int G = EPT >> R;
+    const u32 P = pass_pos_base<LOW, R>(tid);
     if constexpr (PASS > 0) {
       exchange_sync<exchange_is_wave_private(LOGN, EPT, PASS - 1, PASS)>();
 #pragma unroll
       for (int g = 0; g < G; g++)
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
+        for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[pass_pos<LOW, R, Sh::T>(P, tid, g, k)];
     }
     if ((reduce_mask >> PASS) & 1u) {
 #pragma unroll
@@ -154,7 +158,7 @@ struct FwdPasses {
 #pragma unroll
       for (int g = 0; g < G; g++)
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[g * (1 << R) + k];
+        for (int k = 0; k < (1 << R); k++) smem[pass_pos<LOW, R, Sh::T>(P, tid, g, k)] = v[g * (1 << R) + k];
     }
     if constexpr (PASS + 1 < Sh::NPASS) FwdPasses<A, LOGN, EPT, PASS + 1, KEEP_REGS>::run(ar, v, smem, tid, tw, reduce_mask);
   }
@@ -226,6 +230,7 @@ struct InvPasses {
     constexpr int R = Sh::radix(FP);
     constexpr int LOW = LOGN - Sh::before(FP) - R;
     constexpr int G = EPT >> R;
+    const u32 P = pass_pos_base<LOW, R>(tid);
     if constexpr (PASS == 0) {
       if constexpr (!FROM_REGS) __syncthreads();  // the caller filled LDS cooperatively
     } else {
@@ -235,7 +240,7 @@ struct InvPasses {
 #pragma unroll
       for (int g = 0; g < G; g++)
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))];
+        for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[pass_pos<LOW, R, Sh::T>(P, tid, g, k)];
     }
     if ((reduce_mask >> PASS) & 1u) {
 #pragma unroll
@@ -250,7 +255,7 @@ struct InvPasses {
 #pragma unroll
       for (int g = 0; g < G; g++)
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) smem[lds_pos(elem_index<LOW, R>(tid + g * Sh::T, k))] = v[g * (1 << R) + k];
+        for (int k = 0; k < (1 << R); k++) smem[pass_pos<LOW, R, Sh::T>(P, tid, g, k)] = v[g * (1 << R) + k];
       InvPasses<A, LOGN, EPT, PASS + 1, FROM_REGS>::run(ar, v, smem, tid, tw, reduce_mask);
     }
   }
@@ -276,11 +281,31 @@ __device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A:
   if constexpr (NTT_WAVE_PRIVATE && Sh::T >= 64) {
     // every wavefront stores the coefficients its own last pass produced: no barrier before the store either
     exchange_sync<true>();
+#if NTT_WIDE_STORE
+    // 16-byte stores: the wavefront's j-th and (j+1)-th runs of 64 coefficients are adjacent (j bit 0 is element bit 6), so a
+    // lane takes two neighbouring coefficients of the 128 and the wavefront writes 1 KB contiguous per instruction
 #pragma unroll
-    for (u32 j = 0; j < (u32)kElemsPerThread; j++) {
-      const u32 e = own_element_after_fwd<LOGN, kElemsPerThread>(tid, j);
-      ntt_st<(NTT_NT_FWD & 2) != 0>(x + e, ar.canonical(smem[lds_pos(e)]));
+    for (u32 j = 0; j < (u32)kElemsPerThread; j += 2) {
+      typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+      const u32 e = own_element_after_fwd<LOGN, kElemsPerThread>(tid & ~63u, j) + 2u * (tid & 63u);
+      u64x2_t w;
+      w.x = ar.canonical(smem[lds_pos(e)]);
+      w.y = ar.canonical(smem[lds_pos(e + 1)]);
+      ntt_st<(NTT_NT_FWD & 2) != 0>(reinterpret_cast<u64x2_t*>(x + e), w);
     }
+#else
+    {
+      // per-thread and compile-time parts of the position, as in pass_pos
+      const u32 e0 = own_element_after_fwd<LOGN, kElemsPerThread>(tid, 0), P = lds_pos(e0);
+      u64* const x0 = x + e0;
+#pragma unroll
+      for (u32 j = 0; j < (u32)kElemsPerThread; j++) {
+        const u32 C = own_element_after_fwd<LOGN, kElemsPerThread>(0, j), X = lds_pos(C);
+        const u32 pos = NTT_SPLIT_LDS_ADDR ? (P ^ (X & 31u)) + (X & ~31u) : lds_pos(e0 | C);
+        ntt_st<(NTT_NT_FWD & 2) != 0>(x0 + C, ar.canonical(smem[pos]));
+      }
+    }
+#endif
   } else {
     __syncthreads();
     for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) ntt_st<(NTT_NT_FWD & 2) != 0>(x + e, ar.canonical(smem[lds_pos(e)]));

@@ -66,17 +66,29 @@ struct BlkPass {
   static constexpr int G = EPT >> R;
   static __device__ __forceinline__ u32 vt(u32 tid, u32 blk, int g) { return blk * (u32)(Sh::BLOCK >> R) + tid + (u32)g * Sh::TPB; }
   static __device__ __forceinline__ u32 elem(u32 tid, u32 blk, int g, int k) { return elem_index<LOW, R>(vt(tid, blk, g), (u32)k); }
+  // position inside the block's LDS image: per-thread part ^ / + compile-time parts (nttcore.hpp pass_pos: the DS
+  // instructions take the constant part as their immediate offset)
+  static __device__ __forceinline__ u32 pos(u32 tid, u32 blk, int g, int k) {
+#if NTT_SPLIT_LDS_ADDR
+    static_assert((Sh::TPB & (Sh::TPB - 1)) == 0, "tid and g*TPB must occupy disjoint bits");
+    const u32 P = blk_pos(elem_index<LOW, R>(tid, 0));
+    const u32 X = blk_pos(elem_index<LOW, R>((u32)g * Sh::TPB, (u32)k));
+    return (P ^ (X & 31u)) + (X & ~31u);
+#else
+    return blk_pos(elem(tid, blk, g, k) & (Sh::BLOCK - 1));
+#endif
+  }
   static __device__ __forceinline__ void load_lds(typename A::V (&v)[EPT], const typename A::V* smem, u32 tid, u32 blk) {
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[blk_pos(elem(tid, blk, g, k) & (Sh::BLOCK - 1))];
+      for (int k = 0; k < (1 << R); k++) v[g * (1 << R) + k] = smem[pos(tid, blk, g, k)];
   }
   static __device__ __forceinline__ void store_lds(const typename A::V (&v)[EPT], typename A::V* smem, u32 tid, u32 blk) {
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << R); k++) smem[blk_pos(elem(tid, blk, g, k) & (Sh::BLOCK - 1))] = v[g * (1 << R) + k];
+      for (int k = 0; k < (1 << R); k++) smem[pos(tid, blk, g, k)] = v[g * (1 << R) + k];
   }
   // forward stages S0..S0+R-1, S0 = L - LOW - R
   static __device__ __forceinline__ void fwd(const A& ar, typename A::V (&v)[EPT], u32 tid, u32 blk, const typename A::Tw* __restrict__ tw) {

@@ -37,6 +37,29 @@ __device__ __forceinline__ u32 elem_index(u32 vt, u32 k) {
   return (hi << (LOW + R)) | (k << LOW) | lo;
 }
 
+// LDS position of element (virtual thread tid + g*T, k) of a pass over [LOW, LOW+R), written as a per-thread part and
+// compile-time parts.  With tid < T and T a power of two the element is e0 | C, e0 = elem_index(tid, 0) and
+// C = elem_index(g*T, k) on disjoint bits; the swizzle is linear over GF(2), so lds_pos(e0 | C) = lds_pos(e0) ^ lds_pos(C).
+// P = lds_pos(e0) is zero wherever C has bits at positions >= 5 (the swizzle only changes bits 0..4), so those bits of
+// lds_pos(C) are an ADDITION -- which the DS instructions take as their immediate offset -- and only its low five bits
+// need an XOR: one v_xor per DISTINCT low part per pass instead of or + xor + shift-add per access (NTT_SPLIT_LDS_ADDR=0
+// is the A/B build).
+#ifndef NTT_SPLIT_LDS_ADDR
+#define NTT_SPLIT_LDS_ADDR 1
+#endif
+template <int LOW, int R, int T>
+__device__ __forceinline__ u32 pass_pos(u32 P, u32 tid, int g, int k) {
+#if NTT_SPLIT_LDS_ADDR
+  static_assert((T & (T - 1)) == 0, "tid and g*T must occupy disjoint bits");
+  const u32 X = lds_pos(elem_index<LOW, R>((u32)(g * T), (u32)k));  // a constant once the g, k loops are unrolled
+  return (P ^ (X & 31u)) + (X & ~31u);
+#else
+  return lds_pos(elem_index<LOW, R>(tid + (u32)(g * T), (u32)k));
+#endif
+}
+template <int LOW, int R>
+__device__ __forceinline__ u32 pass_pos_base(u32 tid) { return lds_pos(elem_index<LOW, R>(tid, 0)); }
+
 // ---- arithmetic policies -------------------------------------------------------------
 // ArithI: 64-bit integers, Harvey lazy butterflies with Shoup twiddles (any prime < 2^62).
 struct ArithI {
