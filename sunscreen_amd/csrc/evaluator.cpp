@@ -396,7 +396,7 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, 
   u64* ks = rot + chunk * rot_words;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
-    HB_LAUNCH(kKernGalois, c * 2, launch_galois(ctx_->dev(), n, ct2 + off * rot_words, rot, c * 2, ginv, s));
+    HB_LAUNCH(kKernGalois, c * 2, launch_galois(ctx_->dev(), n, K, ct2 + off * rot_words, rot, c * 2, ginv, s));
     // base = (sigma(c0), 0); target = sigma(c1)
     int rc = key_switch(rot + (size_t)K * n, rot_words, key, rot, rot_words, 1u, out2 + off * rot_words, c, ks, s, addend ? addend + off * rot_words : nullptr);
     if (rc) return rc;

@@ -14,6 +14,9 @@
 // wavefront's 64 lanes touch 512 contiguous bytes (coefficient-parallel kernels) or one
 // workgroup owns one residue polynomial (NTT kernels, staged through LDS).
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "devarith.hpp"
 #include "kernels.hpp"
@@ -595,6 +598,19 @@ __global__ __launch_bounds__(NttShape<LOGN>::T, 2) void ntt_pair_kernel(const De
   }
 }
 
+// Kernels that take more than 64 KB of dynamic LDS need the attribute raised once per (device, kernel): the attribute
+// belongs to the device's copy of the code object, and a process may move to another device between contexts
+// (hipbfv_set_device), so a per-process flag is not enough.
+static void allow_dynamic_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.insert(std::make_pair(dev, kernel)).second)
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 template <int LOGN>
 static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
   using Sh = NttShape<LOGN>;
@@ -604,12 +620,8 @@ static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, si
     // as many polynomials as possible go two per workgroup; the remainder (< 2 * period) one per workgroup below
     const size_t paired = plan.div == 1 ? polys / (2 * (size_t)plan.period) * (2 * (size_t)plan.period) : 0;
     if (paired) {
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)ntt_pair_kernel<LOGN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
-        (void)hipFuncSetAttribute((const void*)ntt_pair_kernel<LOGN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
-        attr_done = true;
-      }
+      allow_dynamic_lds((const void*)ntt_pair_kernel<LOGN, true>, 2 * lds);
+      allow_dynamic_lds((const void*)ntt_pair_kernel<LOGN, false>, 2 * lds);
       if (inverse)
         ntt_pair_kernel<LOGN, true><<<dim3((unsigned)(paired / 2)), dim3(Sh::T), 2 * lds, s>>>(ctx, tw, data, plan, scale_mode);
       else
@@ -621,18 +633,10 @@ static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, si
   }
 #endif
   if (inverse) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
-    }
+    allow_dynamic_lds((const void*)ntt_inv_kernel<LOGN>, lds);
     ntt_inv_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan, scale_mode);
   } else {
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
-    }
+    allow_dynamic_lds((const void*)ntt_fwd_kernel<LOGN>, lds);
     ntt_fwd_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan);
   }
   return hipGetLastError();
@@ -643,11 +647,7 @@ static hipError_t launch_ntt_inv_dyadic_t(const DevCtx* ctx, const MulOp* tw, co
                                           size_t ops, hipStream_t s) {
   using Sh = NttShape<LOGN>;
   const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)ntt_inv_dyadic_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  allow_dynamic_lds((const void*)ntt_inv_dyadic_kernel<LOGN>, lds);
   ntt_inv_dyadic_kernel<LOGN><<<dim3((unsigned)(ops * nb * nmod)), dim3(Sh::T), lds, s>>>(ctx, tw, a, b, c, nmod, nb, bstride);
   return hipGetLastError();
 }
@@ -877,24 +877,66 @@ __global__ __launch_bounds__(kCoefThreads) void galois_kernel(const DevCtx* __re
   }
 }
 
+// The same permutation with the whole residue polynomial staged in LDS (N <= 16384): global loads and stores are 16 bytes
+// per lane and fully coalesced, the gather happens in LDS.  Even- and odd-indexed coefficients live in separate halves
+// (position (s >> 1) + (s & 1) * N/2): a lane's two outputs 2j, 2j+1 come from sources 2j*ginv (even) and 2j*ginv + ginv
+// (odd), so across the lanes of a wavefront each of the two LDS reads walks one half with the odd stride ginv --
+// conflict-free -- and the staging writes are contiguous in each half.
+#ifndef GALOIS_LDS
+#define GALOIS_LDS 1
+#endif
+constexpr int kGaloisThreads = 1024;
+template <int LOGN>
+__global__ __launch_bounds__(kGaloisThreads) void galois_lds_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in, u64* __restrict__ out, u32 ginv) {
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  constexpr u32 N = 1u << LOGN, H = N / 2;
+  __shared__ u64 smem[N];
+  const u32 tid = threadIdx.x;
+  const size_t row = blockIdx.x;  // residue polynomial: u64[npoly * K][N]
+  const u64 q = ctx->mod[row % ctx->K].q;
+  const u64x2_t* src = reinterpret_cast<const u64x2_t*>(in + row * N);
+  u64x2_t* dst = reinterpret_cast<u64x2_t*>(out + row * N);
+#pragma unroll
+  for (u32 j = tid; j < H; j += kGaloisThreads) {
+    const u64x2_t w = __builtin_nontemporal_load(src + j);
+    smem[j] = w.x;
+    smem[H + j] = w.y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 j = tid; j < H; j += kGaloisThreads) {
+    const u32 s0 = (2u * j * ginv) & (2u * N - 1u);  // even
+    const u32 s1 = (s0 + ginv) & (2u * N - 1u);       // odd
+    const u64 v0 = smem[(s0 & (N - 1u)) >> 1], v1 = smem[H + ((s1 & (N - 1u)) >> 1)];
+    u64x2_t r;
+    r.x = s0 >= N ? neg_mod(v0, q) : v0;
+    r.y = s1 >= N ? neg_mod(v1, q) : v1;
+    dst[j] = r;
+  }
+}
+
 // ---- element-wise ciphertext ops ----
-// mode 0: a+b, 1: a-b, 2: -a.  polys laid out u64[npoly][K][N]
+// mode 0: a+b, 1: a-b, 2: -a.  polys laid out u64[npoly][K][N]; two adjacent coefficients per thread (16-byte accesses)
 __global__ __launch_bounds__(kCoefThreads) void eltwise_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ a, const u64* __restrict__ b,
                                                                u64* __restrict__ out, int mode) {
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
   const u32 n = ctx->n, K = ctx->K;
-  const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
+  const u32 k = 2u * (blockIdx.x * kCoefThreads + threadIdx.x);
   const u32 res = blockIdx.y;  // global residue-poly index
   if (k >= n) return;
   const u64 q = ctx->mod[res % K].q;
   const size_t off = (size_t)res * n + k;
-  u64 r;
-  if (mode == 0)
-    r = add_mod(a[off], b[off], q);
-  else if (mode == 1)
-    r = sub_mod(a[off], b[off], q);
-  else
-    r = neg_mod(a[off], q);
-  out[off] = r;
+  const u64x2_t x = *reinterpret_cast<const u64x2_t*>(a + off);
+  u64x2_t r;
+  if (mode == 2) {
+    r.x = neg_mod(x.x, q);
+    r.y = neg_mod(x.y, q);
+  } else {
+    const u64x2_t y = *reinterpret_cast<const u64x2_t*>(b + off);
+    r.x = mode == 0 ? add_mod(x.x, y.x, q) : sub_mod(x.x, y.x, q);
+    r.y = mode == 0 ? add_mod(x.y, y.y, q) : sub_mod(x.y, y.y, q);
+  }
+  *reinterpret_cast<u64x2_t*>(out + off) = r;
 }
 
 // c0 +/-= round(q/t * m)  (SEAL multiply_add_plain_with_scaling_variant); ct u64[ops][size][K][N]
@@ -1088,14 +1130,23 @@ hipError_t launch_mod_switch(const DevCtx* ctx, u32 n, const u64* in, u64* out, 
   return hipGetLastError();
 }
 
-hipError_t launch_galois(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t polys, u32 ginv, hipStream_t s) {
+hipError_t launch_galois(const DevCtx* ctx, u32 n, u32 K, const u64* in, u64* out, size_t polys, u32 ginv, hipStream_t s) {
+#if GALOIS_LDS
+  // polys * K residue polynomials, one workgroup each (the host reads K from its own copy of the context: see the caller)
+  switch (n) {
+    case 4096: galois_lds_kernel<12><<<dim3((unsigned)(polys * K)), kGaloisThreads, 0, s>>>(ctx, in, out, ginv); return hipGetLastError();
+    case 8192: galois_lds_kernel<13><<<dim3((unsigned)(polys * K)), kGaloisThreads, 0, s>>>(ctx, in, out, ginv); return hipGetLastError();
+    case 16384: galois_lds_kernel<14><<<dim3((unsigned)(polys * K)), kGaloisThreads, 0, s>>>(ctx, in, out, ginv); return hipGetLastError();
+    default: break;
+  }
+#endif
   galois_kernel<<<coef_grid(n, (u32)polys), kCoefThreads, 0, s>>>(ctx, in, out, ginv);
   return hipGetLastError();
 }
 
 hipError_t launch_eltwise(const DevCtx* ctx, u32 n, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode, hipStream_t s) {
   // caller guarantees residue_polys <= 65535 and that `a` starts at a residue index that is a multiple of K
-  eltwise_kernel<<<coef_grid(n, (u32)residue_polys), kCoefThreads, 0, s>>>(ctx, a, b, out, mode);
+  eltwise_kernel<<<coef_grid(n / 2, (u32)residue_polys), kCoefThreads, 0, s>>>(ctx, a, b, out, mode);
   return hipGetLastError();
 }
 

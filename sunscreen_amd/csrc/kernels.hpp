@@ -44,7 +44,7 @@ hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, b
 hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out,
                              size_t ops, hipStream_t s);
 hipError_t launch_mod_switch(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t polys, hipStream_t s);
-hipError_t launch_galois(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t polys, u32 ginv, hipStream_t s);
+hipError_t launch_galois(const DevCtx* ctx, u32 n, u32 K, const u64* in, u64* out, size_t polys, u32 ginv, hipStream_t s);
 hipError_t launch_eltwise(const DevCtx* ctx, u32 n, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode, hipStream_t s);
 hipError_t launch_plain_addsub(const DevCtx* ctx, u32 n, u64* ct, size_t ctstride, const u64* plain, size_t pstride, size_t ops, int sub, hipStream_t s);
 hipError_t launch_plain_lift(const DevCtx* ctx, u32 n, const u64* plain, size_t pstride, u64* out, size_t ops, u32* nonzero, hipStream_t s);
