@@ -1528,6 +1528,8 @@ static long from_wire(int rc) {
     case kWireOk: return HIPBFV_S_OK;
     case kWireBadArg: return fail(HIPBFV_E_INVALIDARG, "unsupported compression mode");
     case kWireNoZstd: return fail(HIPBFV_COR_E_IO, "libzstd.so.1 is not available: only compr_mode 0 (none) can be used");
+    case kWireSeeded:
+      return fail(HIPBFV_COR_E_IO, "seed-compressed (compact) SEAL object: expanding SEAL's PRNG stream is not supported, save the object without save_seed");
     default: return fail(HIPBFV_COR_E_IO, "malformed or truncated SEAL object");
   }
 }

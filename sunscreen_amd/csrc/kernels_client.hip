@@ -418,6 +418,9 @@ __global__ __launch_bounds__(kClientThreads) void dot_plain2_kernel(const DevCtx
   u128 a0[RT][2], a1[RT][2];
 #pragma unroll
   for (int r = 0; r < RT; r++) a0[r][0] = a0[r][1] = a1[r][0] = a1[r][1] = 0;
+#ifdef PIR_UNROLL
+#pragma unroll PIR_UNROLL
+#endif
   for (u32 j = 0; j < cols; j++) {
     const u64x2_t c0 = *reinterpret_cast<const u64x2_t*>(&ctn[(((size_t)j * 2 + 0) * K + i) * n + x]);
     const u64x2_t c1 = *reinterpret_cast<const u64x2_t*>(&ctn[(((size_t)j * 2 + 1) * K + i) * n + x]);

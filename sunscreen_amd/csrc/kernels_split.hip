@@ -1436,10 +1436,18 @@ template <int L, bool POLICY_D>
 struct MulMidGeom {
   static constexpr int EPT = POLICY_D ? mid_ept_d(L) : kBlkEPT;
   static constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
+#ifdef MID_MODE_14  // experiment hook: exchange-region scheme of the FP64 middle kernel at N = 16384 (with MID_WAVES_14)
+  static constexpr int MODE = !POLICY_D ? 0 : (L == 14 ? MID_MODE_14 : EPT > kBlkEPT ? 2 : MID_FWD_PAIRS(L) ? 1 : 0);
+#else
   static constexpr int MODE = !POLICY_D ? 0 : EPT > kBlkEPT ? 2 : MID_FWD_PAIRS(L) ? 1 : 0;
+#endif
   static constexpr int REGIONS = !batched ? 1 : MODE == 2 ? 2 : MODE == 1 ? 3 : 4;
   static constexpr int TPB = SplitShape<L, EPT>::TPB;
+#ifdef MID_WAVES_14
+  static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : L == 14 ? MID_WAVES_14 : MID_WAVES_D(L);
+#else
   static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : EPT > kBlkEPT ? 2 : MID_WAVES_D(L);
+#endif
 };
 template <int L, bool POLICY_D, bool PACK>
 __global__ __launch_bounds__((MulMidGeom<L, POLICY_D>::TPB), (MulMidGeom<L, POLICY_D>::WAVES)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,

@@ -275,7 +275,10 @@ int wire_unpack_ciphertext(const uint8_t* in, size_t in_size, WireCiphertext* ct
   ct->scale = r.f64();
   ct->correction = r.u64();
   if (!r.ok || ct->size > 64 || ct->n > (1u << 20) || ct->k > 64) return kWireIo;
-  if (!r.dynarray(&ct->data, (size_t)1 << 28) || ct->data.size() != ct->size * ct->n * ct->k) return kWireIo;
+  if (!r.dynarray(&ct->data, (size_t)1 << 28)) return kWireIo;
+  // Ciphertext::save_members with a seed marker: half the data, then a UniformRandomGeneratorInfo object (header, u8 type, 64-byte seed)
+  if (ct->size == 2 && ct->data.size() == ct->n * ct->k && (size_t)(r.end - r.p) >= 16 + 1 + 64) return kWireSeeded;
+  if (ct->data.size() != ct->size * ct->n * ct->k) return kWireIo;
   return kWireOk;
 }
 

@@ -152,3 +152,27 @@ def test_untrusted_bytes_cannot_drive_allocations_or_unwind_through_the_c_abi():
     # hex polynomial with an absurd exponent: refused before anything is sized by it
     out = C.c_void_p()
     assert L.Plaintext_Create4(b"1x^99999999999", None, C.byref(out)) != 0
+
+
+def test_seed_compressed_objects_are_refused_with_their_own_message():
+    """A SEAL client may save keys / symmetric ciphertexts with save_seed: Ciphertext::save_members then writes the first
+    polynomial only, followed by a UniformRandomGeneratorInfo object (header, prng type, 64-byte seed)
+    (/root/reference/seal_fhe/src/key_generator.rs:89-158 create_compact_*).  Expanding that seed needs SEAL's own PRNG stream,
+    which nothing here can be pinned against: the decoder says so instead of failing as "malformed"."""
+    L = _lib.load()
+    used = C.c_int64()
+    n, k = 1024, 2
+    hdr = lambda total: bytes([0x5E, 0xA1, 16, 4, 0, 0, 0, 0]) + struct.pack("<Q", total)
+    half = np.arange(n * k, dtype=np.uint64).tobytes()
+    dyn = hdr(16 + 8 + len(half)) + struct.pack("<Q", n * k) + half
+    info = hdr(16 + 1 + 64) + bytes([1]) + bytes(64)  # blake2xb, all-zero seed
+    body = b"\x07" * 32 + b"\x01" + struct.pack("<QQQdQ", 2, n, k, 1.0, 1) + dyn + info
+    obj = hdr(16 + len(body)) + body
+    hr = L.hipbfv_wire_decode_ciphertext(obj, len(obj), None, None, None, None, None, None, 0, C.byref(used))
+    assert hr & 0xFFFFFFFF == 0x80131620
+    msg = _lib.last_error()
+    assert "seed-compressed" in msg
+    # the same bytes without the trailing seed object are just a truncated ciphertext
+    obj2 = hdr(16 + len(body) - len(info)) + body[: -len(info)]
+    assert L.hipbfv_wire_decode_ciphertext(obj2, len(obj2), None, None, None, None, None, None, 0, C.byref(used)) != 0
+    assert "seed-compressed" not in _lib.last_error()
