@@ -2,6 +2,8 @@
 default sets, every evaluator operation compared bit for bit with the oracle.  Exercises the code-path selection
 (integer vs FP64 policy per modulus, own vs SEAL auxiliary base, split vs whole-polynomial pipelines, 4- / 8- / 16-prime
 kernel instantiations, fast vs generic plain lift)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,9 +13,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _configs():
-    rng = np.random.default_rng(20260925)
+    # HIPBFV_FUZZ_SEED / HIPBFV_FUZZ_COUNT: extended campaigns (profiles/r02_v2_fuzz_campaign.txt); the defaults are the suite's
+    rng = np.random.default_rng(int(os.environ.get("HIPBFV_FUZZ_SEED", "20260925")))
     out = []
-    for _ in range(40):
+    for _ in range(int(os.environ.get("HIPBFV_FUZZ_COUNT", "40"))):
         n = int(rng.choice([1024, 2048, 4096, 8192, 16384, 32768]))
         kk = int(rng.integers(1, 10)) if n < 32768 else int(rng.integers(2, 5))
         style = rng.integers(0, 3)
