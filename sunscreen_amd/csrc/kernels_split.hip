@@ -216,6 +216,9 @@ __device__ __forceinline__ void reduce_all(const A& ar, typename A::V (&v)[EPT])
 
 // TW_PIPE_D / TW_PIPE_I (FP64 / integer policy): 0 = every pass fetches its twiddles when it needs them; 1 = the next pass's twiddles are fetched
 // before the LDS exchange that precedes it; 2 = before the current pass's butterflies (needs both sets live).
+#ifndef MUL_SQUARE  // squaring specialisation of the multiply's head and middle kernels (0: x * x runs as a general product)
+#define MUL_SQUARE 1
+#endif
 #ifndef MID_BATCHED_D
 #define MID_BATCHED_D true
 #endif
@@ -1331,7 +1334,10 @@ __device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A:
 // MODE 0: the four forward transforms together (4 exchange regions); 1: two pairs, one polynomial of the waiting pair parked in
 // a third region (3 regions, N = 8192); 2: two pairs with nothing parked and the inverse transforms as a pair + one (2 regions:
 // the 16-elements-per-thread geometry of N = 16384, where two such workgroups share a CU)
-template <class A, int L, bool PACK, int EPT = kBlkEPT, int MODE = ((MID_FWD_PAIRS(L) && std::is_same<A, ArithD>::value) ? 1 : 0)>
+// SQUARE: both operands are the same ciphertext (Evaluator_Square, a program's x * x): only its two polynomials were extended
+// (ext polys 0, 1), two forward transforms instead of four, d = (a0^2, a0 a1 + a0 a1, a1^2) -- the sums SEAL's bfv_multiply
+// forms for equal operands, so the bits are those of multiply(x, x)
+template <class A, int L, bool PACK, int EPT = kBlkEPT, int MODE = ((MID_FWD_PAIRS(L) && std::is_same<A, ArithD>::value) ? 1 : 0), bool SQUARE = false>
 __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi,
                                                      const typename A::V* ext_r, size_t poly_stride, typename A::V* D_r, size_t dpoly_stride,
                                                      typename A::V* smem, u32 tid, u32 blk) {
@@ -1358,12 +1364,14 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   // registers, and holding all of them through the first transform spills (the other resident workgroup covers the latency)
   load_poly(0);
   load_poly(1);
-  if constexpr (MODE != 2) {
+  if constexpr (MODE != 2 && !SQUARE) {
     load_poly(2);
     load_poly(3);
   }
   using Pair = typename A::V[2][EPT];
-  if constexpr (MODE == 1) {
+  if constexpr (SQUARE) {
+    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
+  } else if constexpr (MODE == 1) {
     // two pairs through 2 (of the 3) exchange regions: 48 KB of LDS per workgroup instead of 64 KB -> 3 workgroups per CU
     // The pair that is not being transformed would sit in 32 registers; one of its two polynomials waits in the third
     // exchange region instead (each thread parks and fetches its own values: no synchronisation), which keeps the kernel
@@ -1393,9 +1401,15 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   typename A::V d[3][EPT];
 #pragma unroll
   for (int e = 0; e < EPT; e++) {
-    d[0][e] = ar.mul_var(v[0][e], v[2][e]);
-    d[1][e] = ar.mul_add(v[0][e], v[3][e], ar.mul_var(v[1][e], v[2][e]));
-    d[2][e] = ar.mul_var(v[1][e], v[3][e]);
+    if constexpr (SQUARE) {
+      d[0][e] = ar.mul_var(v[0][e], v[0][e]);
+      d[1][e] = ar.mul_add(v[0][e], v[1][e], ar.mul_var(v[1][e], v[0][e]));
+      d[2][e] = ar.mul_var(v[1][e], v[1][e]);
+    } else {
+      d[0][e] = ar.mul_var(v[0][e], v[2][e]);
+      d[1][e] = ar.mul_add(v[0][e], v[3][e], ar.mul_var(v[1][e], v[2][e]));
+      d[2][e] = ar.mul_var(v[1][e], v[3][e]);
+    }
   }
   __syncthreads();  // the last forward pass may still be reading the exchange buffer
   if constexpr (MODE == 2) {
@@ -1449,7 +1463,7 @@ struct MulMidGeom {
   static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : EPT > kBlkEPT ? 2 : MID_WAVES_D(L);
 #endif
 };
-template <int L, bool POLICY_D, bool PACK>
+template <int L, bool POLICY_D, bool PACK, bool SQUARE = false>
 __global__ __launch_bounds__((MulMidGeom<L, POLICY_D>::TPB), (MulMidGeom<L, POLICY_D>::WAVES)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                            const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
                                                                            u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres) {
@@ -1475,12 +1489,13 @@ __global__ __launch_bounds__((MulMidGeom<L, POLICY_D>::TPB), (MulMidGeom<L, POLI
   const size_t ps = (size_t)R * Sh::N;
   const MulOp* twf = twf_base + (size_t)m * Sh::N;
   const MulOp* twi = twi_base + (size_t)m * Sh::N;
+  static_assert(batched || !SQUARE, "the squaring specialisation exists in the pass-batched bodies only");
   if constexpr (batched && POLICY_D)
-    mul_mid_body_batched<ArithD, L, PACK, Geo::EPT, Geo::MODE>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
+    mul_mid_body_batched<ArithD, L, PACK, Geo::EPT, Geo::MODE, SQUARE>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                                     reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                                     reinterpret_cast<double*>(smem), tid, blk);
   else if constexpr (batched)
-    mul_mid_body_batched<ArithI, L, false, kBlkEPT, 0>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
+    mul_mid_body_batched<ArithI, L, false, kBlkEPT, 0, SQUARE>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
   else if constexpr (POLICY_D)
     mul_mid_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
                             reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
@@ -1976,8 +1991,8 @@ hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pa
 
 template <int L>
 static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
-                             size_t ops, hipStream_t s) {
-  const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, 4, (unsigned)ops);
+                             size_t ops, u32 npolys, hipStream_t s) {
+  const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, npolys, (unsigned)ops);
   if (kneed > 4) {  // only the all-FP64 instantiation exists for 5..8 data primes (evaluator.cpp checks)
     if (pack)
       mul_head_kernel<L, 8, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
@@ -1996,25 +2011,35 @@ static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, 
 // aux_f64: DevCtx::aux_f64 of the context behind `ctx` (selects the all-FP64 instantiation)
 // kneed: max(data primes, auxiliary primes - 2) -- selects the 4- or 8-prime instantiation
 // pack: DevCtx::pack_mul (only with aux_f64)
+// npolys: 4 = (a0, a1, b0, b1); 2 = the first operand only (squaring: ext polys 2, 3 stay unwritten and unread)
 hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
-                           size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack && aux_f64, kneed, a, b, ext, ops, s)
+                           size_t ops, hipStream_t s, u32 npolys) {
+  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack && aux_f64, kneed, a, b, ext, ops, npolys, s)
 }
 
 template <int L>
 static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
-                            const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s) {
+                            const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, bool square, hipStream_t s) {
   using Sh = SplitShape<L>;
   constexpr unsigned TD = MulMidGeom<L, true>::TPB, TI = MulMidGeom<L, false>::TPB;
+#if MUL_SQUARE
+  if (square) {
+    if (nd && pack) mul_mid_kernel<L, true, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+    if (nd && !pack) mul_mid_kernel<L, true, false, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+    if (ni) mul_mid_kernel<L, false, false, true><<<dim3((unsigned)(ops * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
+    return hipGetLastError();
+  }
+#endif
   if (nd && pack) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
   if (nd && !pack) mul_mid_kernel<L, true, false><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
   if (ni) mul_mid_kernel<L, false, false><<<dim3((unsigned)(ops * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
   return hipGetLastError();
 }
 // res_d / res_i: device arrays listing the residue indices (0..R-1) handled by the FP64 / integer instantiation
+// square: the operands are one ciphertext -- ext holds polys 0, 1 only (launch_mul_head with npolys = 2)
 hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd,
-                          const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mul_mid_t, ctx, twf, twi, pack && ni == 0, res_d, nd, res_i, ni, ext, D, ops, s)
+                          const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s, bool square) {
+  SPLIT_DISPATCH(mul_mid_t, ctx, twf, twi, pack && ni == 0, res_d, nd, res_i, ni, ext, D, ops, square, s)
 }
 
 template <int L>

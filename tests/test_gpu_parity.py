@@ -111,6 +111,13 @@ def test_multiply_relinearize_bit_exact(name):
         assert (fused[i] == orl).all(), (name, i)
         if o.t % (2 * o.n) == 1:
             assert (o.batch_decode(o.decrypt(fused[i], sk)) == (va[i] * vb[i]) % o.t).all()
+    # x * x: one operand twice selects the squaring specialisation (two forward transforms, ext polys 0 and 1 only);
+    # SEAL's Evaluator::square computes the same sums (seal_fhe/src/evaluator.rs square / square_inplace)
+    sq = to_host(ev.multiply(da, da))
+    sqr = to_host(ev.multiply_relin(db, db, rkd))
+    for i in range(count):
+        assert (sq[i] == o.multiply(a[i], a[i])).all(), (name, i)
+        assert (sqr[i] == o.relinearize(o.multiply(b[i], b[i]), rk)).all(), (name, i)
 
 
 def test_multiply_general_sizes_and_chunking():

@@ -158,8 +158,11 @@ a = torch.cat([a, torch.from_numpy(xa).cuda()]); b = torch.cat([b, torch.from_nu
 r = ev.multiply_relin(a, b, RelinearizationKeys.from_array(ctx, rk))
 m = ev.multiply(a, b)
 g = ev.apply_galois(a, 3, GaloisKeys.from_arrays(ctx, gk))
+ev.set_transparent_check(False)  # the extreme rows include all-zero operands; x * x of those is what is compared
+sq = ev.multiply(a, a)            # one operand twice: the squaring specialisation of the split kernels
+sqr = ev.multiply_relin(b, b, RelinearizationKeys.from_array(ctx, rk))
 torch.cuda.synchronize()
-np.save(sys.argv[1], np.concatenate([r.cpu().numpy().ravel(), m.cpu().numpy().ravel(), g.cpu().numpy().ravel()]))
+np.save(sys.argv[1], np.concatenate([x.cpu().numpy().ravel() for x in (r, m, g, sq, sqr)]))
 """ % ROOT
     import tempfile
 
@@ -167,6 +170,7 @@ np.save(sys.argv[1], np.concatenate([r.cpu().numpy().ravel(), m.cpu().numpy().ra
         ("split", {}),
         ("split_unfused_tail", {"HIPBFV_NO_FUSED_TAIL": "1"}),  # multiply then relinearize through a c0/c1/c2 buffer instead of mulrelin_tail
         ("split_unfused_head", {"HIPBFV_NO_FUSED_HEAD": "1"}),  # c2 through HBM between mul_tail and ks_head instead of mulrelin_head
+        ("split_no_square", {"HIPBFV_NO_SQUARE": "1"}),  # x * x as a general product (four forward transforms instead of two)
         ("split_unpacked", {"HIPBFV_NO_PACK": "1"}),  # 8-byte instead of 48-bit packed intermediates
         ("split_no_grid", {"HIPBFV_NO_GRID": "1"}),  # base-conversion sums reduced term by term instead of once (griddot.hpp)
         ("whole", {"HIPBFV_NO_SPLIT_MUL": "1", "HIPBFV_NO_SPLIT_KS": "1"}),
@@ -200,6 +204,16 @@ np.save(sys.argv[1], np.concatenate([r.cpu().numpy().ravel(), m.cpu().numpy().ra
         om = o.multiply(xa[i].astype(np.uint64), xb[i].astype(np.uint64))
         assert (m[9 + i].astype(np.uint64) == om).all(), i
         assert (r[9 + i].astype(np.uint64) == o.relinearize(om, rk)).all(), i
+    # the squares against the oracle's multiply(x, x): two random items and every extreme row
+    g_words = count * 2 * K * n
+    sq0 = count * 5 * K * n + g_words
+    sq = outs[0][sq0 : sq0 + count * 3 * K * n].reshape(count, 3, K, n).astype(np.uint64)
+    sqr = outs[0][sq0 + count * 3 * K * n :].reshape(count, 2, K, n).astype(np.uint64)
+    assert sqr.size == count * 2 * K * n
+    for i in range(len(xa)):
+        assert (sq[9 + i] == o.multiply(xa[i].astype(np.uint64), xa[i].astype(np.uint64))).all(), i
+        xs = xb[i].astype(np.uint64)
+        assert (sqr[9 + i] == o.relinearize(o.multiply(xs, xs), rk)).all(), i
 
 
 @pytest.mark.parametrize("name", ["default_4096_16", "default_8192_17", "default_16384_17", "seal_fhe_unit"])
