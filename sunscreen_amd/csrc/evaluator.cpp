@@ -178,6 +178,7 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_TAIL")) fuse_mulrelin_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_HEAD")) fuse_head_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SQUARE")) square_ = env[0] != '1';
+  if (const char* env = std::getenv("HIPBFV_NO_FUSED_PLAIN")) fused_plain_ = env[0] != '1';
   if (hipMalloc((void**)&status_dev_, 256) == hipSuccess)
     (void)hipMemset(status_dev_, 0xFF, 256);
   else {
@@ -489,12 +490,20 @@ int Evaluator::multiply_plain(const u64* ct, u32 size, const u64* plain, size_t 
     HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain, 0, pl, 1, nonzero, s));
     HB_LAUNCH(kKernNttFwd, K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, pl, K, plan, false, 0, s));
   }
-  if (out != ct) HB_CHECK(hipMemcpyAsync(out, ct, count * cs * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  const bool fused = fused_plain_ && h.logn >= 10 && h.logn <= 14;
+  bool any_d = false, any_i = false;
+  for (u32 i = 0; i < K; i++) (h.mod[i].use_f64 ? any_d : any_i) = true;
+  if (out != ct && !fused) HB_CHECK(hipMemcpyAsync(out, ct, count * cs * sizeof(u64), hipMemcpyDeviceToDevice, s));
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     if (!shared) {
       HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain + off * pstride, pstride, pl, c, nonzero, s));
       HB_LAUNCH(kKernNttFwd, c * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, pl, c * K, plan, false, 0, s));
+    }
+    if (fused) {
+      // transform -> product -> inverse transform of every residue polynomial in one kernel: the ciphertext crosses HBM twice
+      HB_LAUNCH(kKernPlain, c, launch_ct_plain(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, K, any_d, any_i, pl, shared ? 0 : (size_t)K * n, ct + off * cs, out + off * cs, size, c, s));
+      continue;
     }
     u64* x = out + off * cs;
     HB_LAUNCH(kKernNttFwd, c * size * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, x, c * size * K, plan, false, 0, s));

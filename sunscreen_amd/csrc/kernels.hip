@@ -651,6 +651,120 @@ static hipError_t launch_ntt_inv_dyadic_t(const DevCtx* ctx, const MulOp* tw, co
   ntt_inv_dyadic_kernel<LOGN><<<dim3((unsigned)(ops * nb * nmod)), dim3(Sh::T), lds, s>>>(ctx, tw, a, b, c, nmod, nb, bstride);
   return hipGetLastError();
 }
+// =====================================================================================
+// Ciphertext x plaintext (Evaluator_MultiplyPlain, seal_fhe/src/bfv_evaluator.rs multiply_plain; SEAL
+// multiply_plain_normal): the plaintext is lifted and transformed once (plain_lift_kernel + ntt_fwd_kernel, K residue
+// polynomials); then ONE kernel per chunk takes every residue polynomial of the ciphertext through transform -> product
+// with the plaintext's transform (read from global memory at the point of use, in the register layout the last forward
+// pass leaves) -> inverse transform -> n^-1 scale -> store.  The ciphertext crosses HBM twice (in, out) instead of six
+// times (transform in place, dyadic product in place, inverse in place), and no copy precedes an out-of-place call.
+// (Holding the plaintext's transform in registers across the polynomials of one workgroup was tried first: with two
+// transforms' worth of live values the kernel needs > 128 registers at N = 16384 -- 536 bytes of scratch -- and the
+// loop-invariant twiddle / address hoisting has to be fought; one polynomial per workgroup needs neither.)
+// =====================================================================================
+#ifndef CT_PLAIN_FUSED
+#define CT_PLAIN_FUSED 1
+#endif
+template <class A, int LOGN>
+__device__ __forceinline__ void ct_plain_body(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi, const typename A::Tw& ninv,
+                                              const u64* __restrict__ pn, const u64* x, u64* y, typename A::V* smem, u32 tid) {
+  using Sh = NttShape<LOGN>;
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  constexpr int EPT = kElemsPerThread;
+  constexpr int R0 = Sh::radix(0), LOW0 = LOGN - R0, G0 = EPT >> R0;
+  const A ar(dm);
+  typename A::V v[EPT];
+#pragma unroll
+  for (int g = 0; g < G0; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R0); k++) v[g * (1 << R0) + k] = ar.from_u64(x[elem_index<LOW0, R0>(tid + g * Sh::T, k)]);
+  FwdPasses<A, LOGN, EPT, 0, true>::run(ar, v, smem, tid, twf, dm.fwd_reduce_mask);
+  // the last forward pass leaves element ((tid + g*T) << RF) | k in v[g * 2^RF + k]: runs of 2^RF consecutive coefficients
+  constexpr int RF = Sh::radix(Sh::NPASS - 1), GF = EPT >> RF;
+  static_assert(RF >= 1, "pairs of consecutive coefficients");
+  // fence: the inverse transform's twiddle loads and the plaintext loads must not be scheduled up into the forward transform
+  // (the two transforms' live values together do not fit 128 registers: 140 at N = 8192, scratch at N = 16384)
+  const typename A::Tw* twi_c = opaque_uniform(twi);
+  const u64* pn_c = opaque_uniform(pn);
+#pragma unroll
+  for (int g = 0; g < GF; g++) {
+    const u64x2_t* src = reinterpret_cast<const u64x2_t*>(pn_c + ((size_t)(tid + g * Sh::T) << RF));
+#pragma unroll
+    for (int k = 0; k < (1 << RF); k += 2) {
+      const u64x2_t w = src[k >> 1];
+      v[g * (1 << RF) + k] = ar.mul_var(v[g * (1 << RF) + k], ar.from_u64(w.x));
+      v[g * (1 << RF) + k + 1] = ar.mul_var(v[g * (1 << RF) + k + 1], ar.from_u64(w.y));
+    }
+  }
+  __syncthreads();  // slower wavefronts may still be reading LDS in the forward transform's last pass
+  InvPasses<A, LOGN, EPT, 0, true>::run(ar, v, smem, tid, twi_c, dm.inv_reduce_mask);
+#pragma unroll
+  for (int g = 0; g < G0; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R0); k++) y[elem_index<LOW0, R0>(tid + g * Sh::T, k)] = ar.scale_canonical(v[g * (1 << R0) + k], ninv);
+}
+
+// grid: ops * size * K workgroups; pn = the plaintexts' transforms u64[ops or 1][K][N] (pnstride = 0: one for every op)
+// POLICY_D: one instantiation per arithmetic policy (the integer body needs 152 registers, the FP64 one 126 = two
+// workgroups per CU at N = 8192); a workgroup whose residue has the other policy leaves at once
+template <int LOGN, bool POLICY_D>
+__global__ __launch_bounds__(NttShape<LOGN>::T) void ct_plain_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+                                                                     const MulOp* __restrict__ twi_base, const u64* __restrict__ pn, size_t pnstride,
+                                                                     const u64* in, u64* out, u32 size) {
+  using Sh = NttShape<LOGN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const u32 tid = threadIdx.x;
+  const u32 K = ctx->K;
+  const u32 row = blockIdx.x;  // (op * size + c) * K + i
+  const u32 i = row % K, op = row / (K * size);
+  const DevMod& dm = ctx->mod[i];
+  if ((dm.use_f64 != 0) != POLICY_D) return;
+  const u64* x = in + (size_t)row * Sh::N;
+  u64* y = out + (size_t)row * Sh::N;
+  const u64* p = pn + (size_t)op * pnstride + (size_t)i * Sh::N;
+  const MulOp* twf = twf_base + (size_t)i * Sh::N;
+  const MulOp* twi = twi_base + (size_t)i * Sh::N;
+  if constexpr (POLICY_D)
+    ct_plain_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi), dm.ninv_d, p, x, y,
+                                reinterpret_cast<double*>(smem_raw), tid);
+  else
+    ct_plain_body<ArithI, LOGN>(dm, twf, twi, dm.ninv, p, x, y, reinterpret_cast<u64*>(smem_raw), tid);
+}
+
+template <int LOGN>
+static hipError_t launch_ct_plain_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 K, bool any_d, bool any_i, const u64* pn, size_t pnstride,
+                                    const u64* in, u64* out, u32 size, size_t ops, hipStream_t s) {
+  using Sh = NttShape<LOGN>;
+  const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
+  if (any_d) {
+    allow_dynamic_lds((const void*)ct_plain_kernel<LOGN, true>, lds);
+    ct_plain_kernel<LOGN, true><<<dim3((unsigned)(ops * size * K)), dim3(Sh::T), lds, s>>>(ctx, twf, twi, pn, pnstride, in, out, size);
+  }
+  if (any_i) {
+    allow_dynamic_lds((const void*)ct_plain_kernel<LOGN, false>, lds);
+    ct_plain_kernel<LOGN, false><<<dim3((unsigned)(ops * size * K)), dim3(Sh::T), lds, s>>>(ctx, twf, twi, pn, pnstride, in, out, size);
+  }
+  return hipGetLastError();
+}
+// out u64[ops][size][K][N] = INTT(NTT(in) (.) pn); pn u64[ops or 1][K][N] = the lifted plaintexts' transforms; out may be in.
+// any_d / any_i: whether any of the K data primes takes the FP64 / the integer policy (DevMod::use_f64 on the host's copy).
+// hipErrorNotSupported: no instantiation for this degree (the caller falls back to the separate kernels).
+hipError_t launch_ct_plain(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 K, bool any_d, bool any_i, const u64* pn, size_t pnstride,
+                           const u64* in, u64* out, u32 size, size_t ops, hipStream_t s) {
+  if (ops == 0) return hipSuccess;
+#if CT_PLAIN_FUSED
+  switch (logn) {
+    case 10: return launch_ct_plain_t<10>(ctx, twf, twi, K, any_d, any_i, pn, pnstride, in, out, size, ops, s);
+    case 11: return launch_ct_plain_t<11>(ctx, twf, twi, K, any_d, any_i, pn, pnstride, in, out, size, ops, s);
+    case 12: return launch_ct_plain_t<12>(ctx, twf, twi, K, any_d, any_i, pn, pnstride, in, out, size, ops, s);
+    case 13: return launch_ct_plain_t<13>(ctx, twf, twi, K, any_d, any_i, pn, pnstride, in, out, size, ops, s);
+    case 14: return launch_ct_plain_t<14>(ctx, twf, twi, K, any_d, any_i, pn, pnstride, in, out, size, ops, s);
+    default: break;
+  }
+#endif
+  return hipErrorNotSupported;
+}
+
 // c u64[ops][nb][nmod][N] = INTT(a[op][i] (.) b[j][i]); a u64[ops][nmod][N], b u64[nb][bstride][N] (N <= 16384)
 hipError_t launch_ntt_inv_dyadic(const DevCtx* ctx, const MulOp* tw_inv, u32 logn, const u64* a, const u64* b, u64* c, u32 nmod, u32 nb, u32 bstride,
                                  size_t ops, hipStream_t s) {

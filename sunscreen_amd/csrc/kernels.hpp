@@ -48,6 +48,8 @@ hipError_t launch_galois(const DevCtx* ctx, u32 n, u32 K, const u64* in, u64* ou
 hipError_t launch_eltwise(const DevCtx* ctx, u32 n, const u64* a, const u64* b, u64* out, size_t residue_polys, int mode, hipStream_t s);
 hipError_t launch_plain_addsub(const DevCtx* ctx, u32 n, u64* ct, size_t ctstride, const u64* plain, size_t pstride, size_t ops, int sub, hipStream_t s);
 hipError_t launch_plain_lift(const DevCtx* ctx, u32 n, const u64* plain, size_t pstride, u64* out, size_t ops, u32* nonzero, hipStream_t s);
+hipError_t launch_ct_plain(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 K, bool any_d, bool any_i, const u64* pn, size_t pnstride,
+                           const u64* in, u64* out, u32 size, size_t ops, hipStream_t s);
 hipError_t launch_dyadic_plain(const DevCtx* ctx, u32 n, u32 K, u64* x, u32 size, const u64* pl, size_t plstride, size_t ops, hipStream_t s);
 hipError_t launch_mono_mul(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t residue_polys, const u64* coeff_rns, u32 e, hipStream_t s);
 hipError_t launch_transparent_flag(const u64* ct, size_t words, size_t skip_words, u32* host_flag, hipStream_t s);

@@ -1128,16 +1128,6 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
 // when DevCtx::aux_f64 (AUXD instantiations, conversions in exact FP64), SEAL's 61-bit base on the integer path otherwise.
 // =================================================================================================
 
-// A pointer the compiler can prove wave-uniform (scalar loads stay possible) but cannot hoist loads through:
-// used to keep twiddle loads inside the transform that consumes them.
-template <class T>
-__device__ __forceinline__ const T* opaque_uniform(const T* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
-  unsigned long long r = ((unsigned long long)hi << 32) | lo;
-  asm volatile("" : "+s"(r));
-  return reinterpret_cast<const T*>(r);
-}
 
 // the first HL = log2(NC) forward stages on the NC values {t + k*N/NC}; native (lazy) representation out
 template <class A, int NC>

@@ -60,6 +60,17 @@ __device__ __forceinline__ u32 pass_pos(u32 P, u32 tid, int g, int k) {
 template <int LOW, int R>
 __device__ __forceinline__ u32 pass_pos_base(u32 tid) { return lds_pos(elem_index<LOW, R>(tid, 0)); }
 
+// A pointer the compiler can prove wave-uniform (scalar loads stay possible) but cannot hoist loads through:
+// used to keep twiddle loads inside the transform that consumes them.
+template <class T>
+__device__ __forceinline__ const T* opaque_uniform(const T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  unsigned long long r = ((unsigned long long)hi << 32) | lo;
+  asm volatile("" : "+s"(r));
+  return reinterpret_cast<const T*>(r);
+}
+
 // ---- arithmetic policies -------------------------------------------------------------
 // ArithI: 64-bit integers, Harvey lazy butterflies with Shoup twiddles (any prime < 2^62).
 struct ArithI {

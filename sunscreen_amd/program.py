@@ -46,9 +46,12 @@ class FheProgram:
         self.nodes: list[tuple[str, int]] = []
         self.edges: list[tuple[int, int, str]] = []
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().hipbfv_Program_Destroy(self._h)
+            try:
+                _load().hipbfv_Program_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
     # -- construction (names follow sunscreen_fhe_program::FheProgramTrait, lib.rs:170-250)

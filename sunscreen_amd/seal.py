@@ -72,9 +72,12 @@ class Modulus:
     def get_handle(self):
         return self._h
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().Modulus_Destroy(self._h)
+            try:
+                _load().Modulus_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
     def __eq__(self, other):
@@ -150,9 +153,12 @@ class EncryptionParameters:
         _check(L.EncParams_GetCoeffModulus(self._h, C.byref(n), out))
         return [Modulus._adopt(out[i]) for i in range(n.value)]
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().EncParams_Destroy(self._h)
+            try:
+                _load().EncParams_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -258,9 +264,12 @@ class Context:
         c._query()
         return c
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().SEALContext_Destroy(self._h)
+            try:
+                _load().SEALContext_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -330,9 +339,12 @@ class Plaintext:
         _check(_lib.load().Plaintext_Load(p._h, ctx.get_handle(), data, len(data), C.byref(read)))
         return p
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().Plaintext_Destroy(self._h)
+            try:
+                _load().Plaintext_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -416,9 +428,12 @@ class Ciphertext:
         _check(_lib.load().Ciphertext_Load(c._h, ctx.get_handle(), data, len(data), C.byref(read)))
         return c
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().Ciphertext_Destroy(self._h)
+            try:
+                _load().Ciphertext_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -430,9 +445,12 @@ class _KSwitchKeys:
     def get_handle(self):
         return self._h
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().KSwitchKeys_Destroy(self._h)
+            try:
+                _load().KSwitchKeys_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -512,9 +530,12 @@ class BFVEvaluator:
     def get_handle(self):
         return self._h
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().Evaluator_Destroy(self._h)
+            try:
+                _load().Evaluator_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
     # -- negate / add / sub (evaluator_base.rs:89-182)
@@ -693,9 +714,12 @@ class _AsymKey:
         _check(getattr(_lib.load(), cls._prefix + "_Load")(k._h, ctx.get_handle(), data, len(data), C.byref(read)))
         return k
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            getattr(_lib.load(), self._prefix + "_Destroy")(self._h)
+            try:
+                getattr(_load(), self._prefix + "_Destroy")(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -767,9 +791,12 @@ class KeyGenerator:
             _check(L.KeyGenerator_CreateGaloisKeysFromElts(self._h, len(galois_elts), arr, False, C.byref(k._h)))
         return k
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().KeyGenerator_Destroy(self._h)
+            try:
+                _load().KeyGenerator_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -812,9 +839,12 @@ class BFVEncoder:
         _check(_lib.load().BatchEncoder_Decode2(self._h, plaintext.get_handle(), C.byref(size), out, None))
         return list(out[: size.value])
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().BatchEncoder_Destroy(self._h)
+            try:
+                _load().BatchEncoder_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -842,9 +872,12 @@ class Decryptor:
         _check(_lib.load().Decryptor_InvariantNoise(self._h, ciphertext.get_handle(), C.byref(v)))
         return v.value
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().Decryptor_Destroy(self._h)
+            try:
+                _load().Decryptor_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -958,9 +991,12 @@ class PolynomialArray:
 
     __hash__ = None
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().PolynomialArray_Destroy(self._h)
+            try:
+                _load().PolynomialArray_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None
 
 
@@ -1026,7 +1062,10 @@ class Encryptor:
                                                                        r.get_handle(), self._seed_words(seed), None))
         return c, e, r
 
-    def __del__(self):
+    def __del__(self, _load=_lib.load):  # the default argument outlives the module globals at interpreter shutdown
         if getattr(self, "_h", None):
-            _lib.load().Encryptor_Destroy(self._h)
+            try:
+                _load().Encryptor_Destroy(self._h)
+            except Exception:  # finalisers never raise
+                pass
             self._h = None

@@ -161,8 +161,12 @@ g = ev.apply_galois(a, 3, GaloisKeys.from_arrays(ctx, gk))
 ev.set_transparent_check(False)  # the extreme rows include all-zero operands; x * x of those is what is compared
 sq = ev.multiply(a, a)            # one operand twice: the squaring specialisation of the split kernels
 sqr = ev.multiply_relin(b, b, RelinearizationKeys.from_array(ctx, rk))
+pl = torch.randint(0, t, (a.shape[0], n), generator=gen, device="cuda:0", dtype=torch.int64)
+pl[1, 1:] = 0; pl[1, 0] = t - 1   # a monomial in the upper half: SEAL's shortcut uses the coefficient without the centred lift
+mp = ev.multiply_plain(a, pl)     # per-op plaintexts
+mp1 = ev.multiply_plain(m, pl[0]) # one plaintext for every op, size-3 ciphertexts
 torch.cuda.synchronize()
-np.save(sys.argv[1], np.concatenate([x.cpu().numpy().ravel() for x in (r, m, g, sq, sqr)]))
+np.save(sys.argv[1], np.concatenate([x.cpu().numpy().ravel() for x in (r, m, g, sq, sqr, mp, mp1)]))
 """ % ROOT
     import tempfile
 
@@ -171,6 +175,7 @@ np.save(sys.argv[1], np.concatenate([x.cpu().numpy().ravel() for x in (r, m, g, 
         ("split_unfused_tail", {"HIPBFV_NO_FUSED_TAIL": "1"}),  # multiply then relinearize through a c0/c1/c2 buffer instead of mulrelin_tail
         ("split_unfused_head", {"HIPBFV_NO_FUSED_HEAD": "1"}),  # c2 through HBM between mul_tail and ks_head instead of mulrelin_head
         ("split_no_square", {"HIPBFV_NO_SQUARE": "1"}),  # x * x as a general product (four forward transforms instead of two)
+        ("unfused_plain", {"HIPBFV_NO_FUSED_PLAIN": "1"}),  # multiply_plain as transform / dyadic product / inverse kernels instead of one
         ("split_unpacked", {"HIPBFV_NO_PACK": "1"}),  # 8-byte instead of 48-bit packed intermediates
         ("split_no_grid", {"HIPBFV_NO_GRID": "1"}),  # base-conversion sums reduced term by term instead of once (griddot.hpp)
         ("whole", {"HIPBFV_NO_SPLIT_MUL": "1", "HIPBFV_NO_SPLIT_KS": "1"}),
@@ -208,8 +213,9 @@ np.save(sys.argv[1], np.concatenate([x.cpu().numpy().ravel() for x in (r, m, g, 
     g_words = count * 2 * K * n
     sq0 = count * 5 * K * n + g_words
     sq = outs[0][sq0 : sq0 + count * 3 * K * n].reshape(count, 3, K, n).astype(np.uint64)
-    sqr = outs[0][sq0 + count * 3 * K * n :].reshape(count, 2, K, n).astype(np.uint64)
-    assert sqr.size == count * 2 * K * n
+    sqr0 = sq0 + count * 3 * K * n
+    sqr = outs[0][sqr0 : sqr0 + count * 2 * K * n].reshape(count, 2, K, n).astype(np.uint64)
+    assert outs[0].size == sqr0 + count * 2 * K * n + count * 2 * K * n + count * 3 * K * n  # ... + mp + mp1
     for i in range(len(xa)):
         assert (sq[9 + i] == o.multiply(xa[i].astype(np.uint64), xa[i].astype(np.uint64))).all(), i
         xs = xb[i].astype(np.uint64)
