@@ -209,6 +209,9 @@ long Evaluator_AddMany(void *thisptr, uint64_t count, void **encrypteds, void *d
 long Evaluator_Sub(void *thisptr, void *encrypted1, void *encrypted2, void *destination);
 long Evaluator_Multiply(void *thisptr, void *encrypted1, void *encrypted2, void *destination, void *pool);
 long Evaluator_MultiplyMany(void *thisptr, uint64_t count, void **encrypteds, void *relin_keys, void *destination, void *pool);
+/* Square = Multiply(x, x) bit for bit; when the two operands of a multiply are ONE ciphertext (here, Evaluator_Multiply with
+ * encrypted1 == encrypted2, hipbfv_batch_multiply* with a == b, a program node whose operands are one node) the kernels extend
+ * and transform it once: two forward transforms per residue instead of four. */
 long Evaluator_Square(void *thisptr, void *encrypted, void *destination, void *pool);
 long Evaluator_Relinearize(void *thisptr, void *encrypted, void *relin_keys, void *destination, void *pool);
 long Evaluator_Exponentiate(void *thisptr, void *encrypted, uint64_t exponent, void *relin_keys, void *destination, void *pool);
