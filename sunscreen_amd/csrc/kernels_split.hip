@@ -452,6 +452,12 @@ constexpr int kHeadThreads = 256;
 #ifndef KS_MID_WAVES
 #define KS_MID_WAVES(L) ((L) <= 13 ? 3 : 2)
 #endif
+#ifndef KS_PREFETCH  // ks_mid: digit pairs with the next pair's loads in flight (see the kernel); at which sizes
+#define KS_PREFETCH 0
+#endif
+#ifndef KS_PREFETCH_AT
+#define KS_PREFETCH_AT(L) ((L) == 14)
+#endif
 
 // -------------------------------------------------------------------------------------------------
 // 48-bit packed storage of FP64-policy intermediates (PACK): every kernel of the split pipelines is HBM-bound or
@@ -889,6 +895,37 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
   };
   u32 J = 0;
+#if KS_PREFETCH
+  if constexpr (KS_PREFETCH_AT(L)) {
+    // pairs of digits with the NEXT pair's rows requested before the current pair is transformed: the loads travel while the
+    // first passes (scalar twiddles: no vmcnt wait) run.  One workgroup per CU is resident at this size, so nothing else
+    // covers its load latency.
+    double cur[2][kBlkEPT], nxt[2][kBlkEPT];
+    if (K >= 2) {
+      load_src(0, cur[0]);
+      load_src(1, cur[1]);
+    }
+    for (; J + 2 <= K; J += 2) {
+      const bool more = J + 4 <= K;
+      if (more) {
+        load_src(J + 2, nxt[0]);
+        load_src(J + 3, nxt[1]);
+      }
+      if (J > 0) __syncthreads();
+      const MulOpD* twf_j = twf;
+      asm volatile("" : "+s"(twf_j));
+      mid_forward_multi<A, L, 2>(ar, cur, smem, tid, blk, twf_j, dm.split_fwd_mask);
+      mac(J, cur[0]);
+      mac(J + 1, cur[1]);
+      if (more) {
+#pragma unroll
+        for (int e = 0; e < kBlkEPT; e++) cur[0][e] = nxt[0][e], cur[1][e] = nxt[1][e];
+      }
+    }
+    if (J < K) group(J, std::integral_constant<int, 1>{});
+    J = K;
+  }
+#endif
   if constexpr (KS_GROUP_MAX(L) >= 4)
     for (; J + 4 <= K; J += 4) group(J, std::integral_constant<int, 4>{});
   for (; J + 2 <= K; J += 2) group(J, std::integral_constant<int, 2>{});
