@@ -12,9 +12,12 @@
 #include <cerrno>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -222,9 +225,42 @@ struct KeysObj : Obj {
   }
 };
 
+// ---- concurrent handle-level calls combined into batched launches ----
+// sunscreen_runtime runs ready graph nodes from a rayon pool (run.rs:415-469): many host threads, each asking ONE evaluator
+// for one multiply / relinearize / rotation at a time.  Issued separately, such calls overlap poorly on the device (one
+// operation's kernels occupy a few CUs for ~100 us; the runtime multiplexes the threads' streams onto a handful of hardware
+// queues: 5 -> 8-12 K multiply+relinearize/s from 1 -> 8 threads, fewer with 32).  Flat combining instead: a caller
+// that finds no operation of its evaluator in flight runs its own at once, exactly as before; callers arriving while one is in
+// flight queue up, and whoever finds the evaluator free next takes every queued request of one kind (same key, same Galois
+// element) and runs them as ONE batch through the batched kernels -- operands gathered into a staging batch and results
+// scattered to the callers' buffers by two copy kernels that read a pointer table in pinned host memory, one transparent flag
+// per item, one stream synchronisation for all.  Batch items are independent: the bits do not depend on who was combined with whom.
+struct CombReq {
+  int kind = 0;  // 0 multiply (2 x 2 -> 3 polynomials), 1 relinearize (3 -> 2), 2 Galois automorphism + key switch (2 -> 2)
+  const u64* in0 = nullptr;
+  const u64* in1 = nullptr;
+  const u64* key = nullptr;
+  u32 elt = 0;
+  u64* out = nullptr;
+  int status = 0;
+  int nonzero = -1;  // transparent check of the result: 1 / 0 (made where the request ran, together with the synchronisation)
+  std::atomic<bool> done{false};
+};
+struct Combiner {
+  std::mutex mu;
+  std::deque<CombReq*> q;
+  std::atomic<int> leaders{0};  // batches in flight
+};
+#ifndef HIPBFV_COMBINE_LEADERS
+#define HIPBFV_COMBINE_LEADERS 1
+#endif
+constexpr int kCombineLeaders = HIPBFV_COMBINE_LEADERS;
+constexpr size_t kCombineMax = 64;  // HIPBFV_NO_COMBINE=1 (read at the first call): every handle-level call launches on its own
+
 struct EvalObj : Obj {
   std::shared_ptr<Context> ctx;
   std::unique_ptr<Evaluator> ev;
+  Combiner comb;
   // evaluators of the lower levels of the modulus-switching chain (SEAL's single Evaluator serves every level of
   // its context; here every level has its own tables): created on first use
   std::mutex mu;
@@ -390,9 +426,140 @@ const u64* level_key(KeysObj* k, EvalObj* e, u32 index) {
 bool same_context(const CipherObj* a, const EvalObj* e) { return a->ctx && a->ctx.get() == e->ctx.get() && a->dev && a->size >= 2; }
 
 // transparent check of the finished result (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT); stream already holds the op
-long finish_result(EvalObj* e, CipherObj* dst, u32 size, u64* buf, size_t words, hipStream_t s, bool check_transparent) {
+// The pointer / flag table of a combined batch: pinned host memory the device addresses directly, one per host thread
+// (only the thread that runs a batch uses its own).
+struct CombTable {
+  const u64* src[2 * kCombineMax];
+  u64* dst[kCombineMax];
+  u32 flags[kCombineMax];
+};
+
+// Runs `batch` (>= 1 requests of one kind / key / element) on stream s and fills in status (and nonzero) of each.
+// Every request is complete on the device and checked when this returns -- also a lone one: its owner may be another thread,
+// whose stream knows nothing about this one, and holding the evaluator until the operation has finished is what lets the
+// requests that arrive meanwhile pile up into the next batch (with the lone request merely launched, four threads ran
+// four interleaved single operations: 10 K instead of 27 K multiply+relinearize/s).
+void combine_execute(EvalObj* e, const std::vector<CombReq*>& batch, hipStream_t s) {
+  Evaluator& ev = *e->ev;
+  CombReq& r0 = *batch[0];
+  const size_t c = batch.size();
+  auto all = [&](int st) {
+    for (CombReq* r : batch) r->status = st;
+  };
+  const size_t poly = (size_t)e->ctx->K() * e->ctx->n();
+  thread_local CombTable* table = nullptr;
+  if (!table && hipHostMalloc((void**)&table, sizeof(CombTable), hipHostMallocMapped) != hipSuccess) {
+    table = nullptr;
+    (void)hipGetLastError();
+    return all(kOutOfMemory);
+  }
+  if (c == 1) {
+    r0.status = r0.kind == 0 ? ev.multiply(r0.in0, 2, r0.in1, 2, r0.out, 1, s)
+              : r0.kind == 1 ? ev.relinearize(r0.in0, r0.key, r0.out, 1, s)
+                             : ev.apply_galois(r0.in0, r0.elt, r0.key, r0.out, 1, s);
+    if (r0.status) return;
+    const size_t out_words = (r0.kind == 0 ? 3 : 2) * poly;
+    table->flags[0] = 1u;
+    if (g_throw_transparent && launch_transparent_flags(r0.out, out_words, poly, table->flags, 1, s) != hipSuccess) return all(kHipError);
+    if (hipStreamSynchronize(s) != hipSuccess) return all(kHipError);
+    r0.nonzero = table->flags[0] ? 1 : 0;
+    return;
+  }
+  bool squares = r0.kind == 0;  // every request multiplies a ciphertext by itself: one staged operand, the squaring kernels
+  for (const CombReq* r : batch) squares = squares && r->in0 == r->in1;
+  const size_t in_polys = r0.kind == 1 ? 3 : 2, nin = r0.kind == 0 && !squares ? 2 : 1, out_polys = r0.kind == 0 ? 3 : 2;
+  const size_t in_words = in_polys * poly, out_words = out_polys * poly;
+  ScratchGuard sg(ev.scratch(), c * (nin * in_words + out_words) * sizeof(u64), s);
+  if (!sg.p) return all(kOutOfMemory);
+  u64* in_stage = (u64*)sg.p;                  // [nin][c][in_polys][K][N]
+  u64* out_stage = in_stage + c * nin * in_words;  // [c][out_polys][K][N]
+  for (size_t i = 0; i < c; i++) {
+    table->src[i] = batch[i]->in0;
+    if (nin == 2) table->src[c + i] = batch[i]->in1;
+    table->dst[i] = batch[i]->out;
+    table->flags[i] = 1u;
+  }
+  if (launch_gather_items(table->src, in_stage, in_words, c * nin, s) != hipSuccess) return all(kHipError);
+  int st = r0.kind == 0 ? ev.multiply(in_stage, 2, in_stage + (squares ? 0 : c * in_words), 2, out_stage, c, s)
+         : r0.kind == 1 ? ev.relinearize(in_stage, r0.key, out_stage, c, s)
+                        : ev.apply_galois(in_stage, r0.elt, r0.key, out_stage, c, s);
+  if (st) return all(st);
+  if (launch_scatter_items(out_stage, table->dst, out_words, c, s) != hipSuccess) return all(kHipError);
+  if (g_throw_transparent && launch_transparent_flags(out_stage, out_words, poly, table->flags, c, s) != hipSuccess) return all(kHipError);
+  if (hipStreamSynchronize(s) != hipSuccess) return all(kHipError);
+  for (size_t i = 0; i < c; i++) {
+    batch[i]->status = kOk;
+    batch[i]->nonzero = table->flags[i] ? 1 : 0;
+  }
+}
+
+// One handle-level operation, possibly executed as part of a batch led by another thread.  On return with status 0 the
+// result is in req.out; req.nonzero >= 0 means it is complete on the device and already checked.
+int combine_run(EvalObj* e, CombReq& req, hipStream_t s) {
+  static const bool enabled = [] {
+    const char* env = std::getenv("HIPBFV_NO_COMBINE");
+    return !(env && env[0] == '1');
+  }();
+  Combiner& cb = e->comb;
+  if (!enabled) {
+    std::vector<CombReq*> one{&req};
+    combine_execute(e, one, s);
+    return req.status;
+  }
+  {
+    std::lock_guard<std::mutex> g(cb.mu);
+    cb.q.push_back(&req);
+  }
+  // Waiting callers watch two atomics -- their own request's `done` and the evaluator's `leaders` -- and only take the mutex to
+  // lead: sixty-odd threads woken through one condition variable spend longer handing its mutex around than the batch took.
+  for (unsigned spins = 0;; spins++) {
+    if (req.done.load(std::memory_order_acquire)) return req.status;
+    if (cb.leaders.load(std::memory_order_relaxed) < kCombineLeaders) {
+      std::unique_lock<std::mutex> lk(cb.mu);
+      if (req.done.load(std::memory_order_acquire)) return req.status;
+      if (cb.leaders.load(std::memory_order_relaxed) < kCombineLeaders && !cb.q.empty()) {
+        // lead: the oldest request and everything queued behind it that can share its launch
+        cb.leaders.fetch_add(1, std::memory_order_relaxed);
+        std::vector<CombReq*> batch;
+        CombReq* head = cb.q.front();
+        for (auto it = cb.q.begin(); it != cb.q.end() && batch.size() < kCombineMax;) {
+          CombReq* r = *it;
+          if (r->kind == head->kind && r->key == head->key && r->elt == head->elt) {
+            batch.push_back(r);
+            it = cb.q.erase(it);
+          } else {
+            ++it;
+          }
+        }
+        lk.unlock();
+        try {
+          combine_execute(e, batch, s);
+        } catch (...) {
+          for (CombReq* r : batch) r->status = kOutOfMemory;
+        }
+        // a request's owner may return (and its CombReq go out of scope) the moment it sees `done`: nothing of r is touched after the store
+        for (CombReq* r : batch) r->done.store(true, std::memory_order_release);
+        cb.leaders.fetch_sub(1, std::memory_order_release);
+        spins = 0;
+        continue;
+      }
+    }
+    if (spins < 4096) {
+      __builtin_ia32_pause();
+    } else {
+      // a long operation (large degree, big batch) is running: stop burning the core
+      struct timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+}
+
+// known: the transparent verdict when a combined batch already produced it (and synchronised): 1 / 0; -1 = check here
+long finish_result(EvalObj* e, CipherObj* dst, u32 size, u64* buf, size_t words, hipStream_t s, bool check_transparent, int known = -1) {
   u32 flag = 1;
-  if (check_transparent && g_throw_transparent) {
+  if (known >= 0) {
+    flag = (u32)known;
+  } else if (check_transparent && g_throw_transparent) {
     // one word of pinned, device-addressable host memory per host thread: the check kernel writes its verdict there
     thread_local u32* host_flag = nullptr;
     if (!host_flag && hipHostMalloc((void**)&host_flag, 64, hipHostMallocMapped) != hipSuccess) {
@@ -1133,12 +1300,20 @@ long Evaluator_Multiply(void* h, void* a, void* b, void* dst, void* pool) HIPBFV
   const size_t words = e->ctx->ct_words(sd);
   u64* buf = g_buffers.get(words);
   if (!buf) return from_status(kOutOfMemory);
-  int st = e->ev->multiply(x->dev, x->size, y->dev, y->size, buf, 1, s);
+  int st, known = -1;
+  if (x->size == 2 && y->size == 2) {
+    CombReq rq;
+    rq.kind = 0, rq.in0 = x->dev, rq.in1 = y->dev, rq.out = buf;
+    st = combine_run(e, rq, s);
+    known = rq.nonzero;
+  } else {
+    st = e->ev->multiply(x->dev, x->size, y->dev, y->size, buf, 1, s);
+  }
   if (st) {
     g_buffers.put(buf, words);
     return from_status(st);
   }
-  return finish_result(e, d, sd, buf, words, s, true);
+  return finish_result(e, d, sd, buf, words, s, true, known);
 HIPBFV_END
 
 long Evaluator_Square(void* h, void* a, void* dst, void* pool) HIPBFV_BEGIN return Evaluator_Multiply(h, a, a, dst, pool); HIPBFV_END
@@ -1170,12 +1345,14 @@ long Evaluator_Relinearize(void* h, void* a, void* keys, void* dst, void* pool) 
   const size_t words = e->ctx->ct_words(2);
   u64* buf = g_buffers.get(words);
   if (!buf) return from_status(kOutOfMemory);
-  int st = e->ev->relinearize(x->dev, rkey, buf, 1, s);
+  CombReq rq;
+  rq.kind = 1, rq.in0 = x->dev, rq.key = rkey, rq.out = buf;
+  int st = combine_run(e, rq, s);
   if (st) {
     g_buffers.put(buf, words);
     return from_status(st);
   }
-  return finish_result(e, d, 2, buf, words, s, true);
+  return finish_result(e, d, 2, buf, words, s, true, rq.nonzero);
 HIPBFV_END
 
 // SEAL Evaluator::multiply_many: pairwise products with relinearisation, results appended to the work list
@@ -1312,12 +1489,14 @@ static long galois_handle(EvalObj* e, CipherObj* x, u32 elt, KeysObj* k, CipherO
   const size_t words = e->ctx->ct_words(2);
   u64* buf = g_buffers.get(words);
   if (!buf) return from_status(kOutOfMemory);
-  int st = e->ev->apply_galois(x->dev, elt, key, buf, 1, s);
+  CombReq rq;
+  rq.kind = 2, rq.in0 = x->dev, rq.key = key, rq.elt = elt, rq.out = buf;
+  int st = combine_run(e, rq, s);
   if (st) {
     g_buffers.put(buf, words);
     return from_status(st);
   }
-  return finish_result(e, d, 2, buf, words, s, true);
+  return finish_result(e, d, 2, buf, words, s, true, rq.nonzero);
 }
 
 // SEAL Evaluator::rotate_internal: use the key for `steps` if present, else the NAF decomposition

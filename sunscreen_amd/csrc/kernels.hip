@@ -1186,6 +1186,36 @@ __global__ __launch_bounds__(kCoefThreads) void transparent_flag_kernel(const u6
   if (threadIdx.x == 0) *host_flag = 0u;
 }
 
+// ---- handle-level calls combined into one batched launch (capi.cpp Combiner) ----
+// Each host thread's operands and results are separate device buffers; `table` (pinned host memory the device can address)
+// lists them.  gather: stage[item][0..words) = *table[item]; scatter: *table[item] = stage[item][..]; 16-byte accesses.
+__global__ __launch_bounds__(kCoefThreads) void gather_items_kernel(const u64* const* __restrict__ table, u64* __restrict__ stage, size_t words) {
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  const u64x2_t* src = reinterpret_cast<const u64x2_t*>(table[blockIdx.y]);
+  u64x2_t* dst = reinterpret_cast<u64x2_t*>(stage + (size_t)blockIdx.y * words);
+  for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < words / 2; i += (size_t)gridDim.x * kCoefThreads) dst[i] = src[i];
+}
+__global__ __launch_bounds__(kCoefThreads) void scatter_items_kernel(const u64* __restrict__ stage, u64* const* __restrict__ table, size_t words) {
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  const u64x2_t* src = reinterpret_cast<const u64x2_t*>(stage + (size_t)blockIdx.y * words);
+  u64x2_t* dst = reinterpret_cast<u64x2_t*>(table[blockIdx.y]);
+  for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < words / 2; i += (size_t)gridDim.x * kCoefThreads) dst[i] = src[i];
+}
+// transparent_flag_kernel for a batch: host_flags[item] = 1 if item's polynomials 1.. hold a non-zero word, else 0
+__global__ __launch_bounds__(kCoefThreads) void transparent_flags_kernel(const u64* __restrict__ ct, size_t words_per_ct, size_t skip_words,
+                                                                        volatile u32* __restrict__ host_flags) {
+  const u64* p = ct + (size_t)blockIdx.x * words_per_ct;
+  for (size_t base = skip_words; base < words_per_ct; base += kCoefThreads) {
+    const size_t i = base + threadIdx.x;
+    const bool nz = i < words_per_ct && p[i] != 0;
+    if (__syncthreads_or(nz)) {
+      if (threadIdx.x == 0) host_flags[blockIdx.x] = 1u;
+      return;
+    }
+  }
+  if (threadIdx.x == 0) host_flags[blockIdx.x] = 0u;
+}
+
 // =====================================================================================
 // host launchers
 // =====================================================================================
@@ -1297,6 +1327,19 @@ hipError_t launch_nonzero_tail(const u64* ct, size_t words_per_ct, size_t skip_w
 
 hipError_t launch_transparent_flag(const u64* ct, size_t words, size_t skip_words, u32* host_flag, hipStream_t s) {
   transparent_flag_kernel<<<dim3(1), kCoefThreads, 0, s>>>(ct, words, skip_words, host_flag);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_items(const u64* const* table, u64* stage, size_t words, size_t items, hipStream_t s) {
+  gather_items_kernel<<<dim3(32, (u32)items), kCoefThreads, 0, s>>>(table, stage, words);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_items(const u64* stage, u64* const* table, size_t words, size_t items, hipStream_t s) {
+  scatter_items_kernel<<<dim3(32, (u32)items), kCoefThreads, 0, s>>>(stage, table, words);
+  return hipGetLastError();
+}
+hipError_t launch_transparent_flags(const u64* ct, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s) {
+  transparent_flags_kernel<<<dim3((u32)items), kCoefThreads, 0, s>>>(ct, words_per_ct, skip_words, host_flags);
   return hipGetLastError();
 }
 

@@ -52,6 +52,10 @@ hipError_t launch_ct_plain(const DevCtx* ctx, const MulOp* twf, const MulOp* twi
                            const u64* in, u64* out, u32 size, size_t ops, hipStream_t s);
 hipError_t launch_dyadic_plain(const DevCtx* ctx, u32 n, u32 K, u64* x, u32 size, const u64* pl, size_t plstride, size_t ops, hipStream_t s);
 hipError_t launch_mono_mul(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t residue_polys, const u64* coeff_rns, u32 e, hipStream_t s);
+// combined handle-level calls (capi.cpp): tables of device pointers / flags live in pinned, device-addressable host memory
+hipError_t launch_gather_items(const u64* const* table, u64* stage, size_t words, size_t items, hipStream_t s);
+hipError_t launch_scatter_items(const u64* stage, u64* const* table, size_t words, size_t items, hipStream_t s);
+hipError_t launch_transparent_flags(const u64* ct, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s);
 hipError_t launch_transparent_flag(const u64* ct, size_t words, size_t skip_words, u32* host_flag, hipStream_t s);
 hipError_t launch_transparent_watch(const u64* ct, size_t words_per_ct, size_t skip_words, u32 first_item, u32* status, size_t ops, hipStream_t s);
 hipError_t launch_nonzero_tail(const u64* ct, size_t words_per_ct, size_t skip_words, u32* flags, size_t ops, hipStream_t s);

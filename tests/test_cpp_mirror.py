@@ -67,3 +67,16 @@ def test_simple_multiply_example_runs_on_the_device(tmp_path, opt):
         chk = _build(tmp_path, "-O0", os.path.join(ROOT, "tests", "native", "interpose_check.cpp"), ["-rdynamic"])
         out = subprocess.run([chk], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "SEALContext_Create -> 0x0" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_concurrent_handle_calls_are_combined_without_changing_a_bit(tmp_path):
+    """sunscreen_runtime runs ready graph nodes from a rayon pool (run.rs:415-469): 24 native threads on one evaluator, mixed
+    multiply / relinearize / rotate / square calls, one thread also asking for a transparent product.  The library combines
+    concurrent calls into batched launches (capi.cpp Combiner); every thread must get the bits it gets alone, and only the
+    offending call may fail.  Run with combining on (default) and off."""
+    exe = _build(tmp_path, "-O1", os.path.join(ROOT, "tests", "native", "combine_check.cpp"), ["-lpthread"])
+    for env in ({}, {"HIPBFV_NO_COMBINE": "1"}):
+        for _ in range(3):  # which calls meet in a batch differs from run to run
+            out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+            assert out.returncode == 0 and "combine ok" in out.stdout, (env, out.returncode, out.stdout, out.stderr)

@@ -44,6 +44,32 @@ def main():
         "rotate_rows_1_us": timed(lambda: ev.rotate_rows(a, 1, gkd)),
         "add_us": timed(lambda: ev.add(a, b)),
     }
+    # several host threads on ONE evaluator handle, each with its own operands (run.rs:415-469 dispatches ready nodes from a
+    # rayon pool): every thread has its own stream inside the library, so the calls overlap on the device.  Python threads
+    # release the GIL inside the ctypes calls.
+    import threading
+
+    def threaded(nthreads, seconds=1.5):
+        cts = [(Ciphertext.from_array(ctx, a.to_array()), Ciphertext.from_array(ctx, b.to_array())) for _ in range(nthreads)]
+        counts = [0] * nthreads
+        stop = time.perf_counter() + seconds
+
+        def work(i):
+            x, y = cts[i]
+            while time.perf_counter() < stop:
+                ev.relinearize(ev.multiply(x, y), rkd)
+                counts[i] += 1
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        return sum(counts) / (time.perf_counter() - t0)
+
+    threaded(2, 0.3)
+    res["multiply_relinearize_ops_per_s_by_threads"] = {str(k): round(threaded(k), 1) for k in (1, 2, 4, 8, 16, 32)}
     # the same on the CPU oracle (single thread, like one SEAL Evaluator call)
     ca, cb = a.to_array(), b.to_array()
     t0 = time.perf_counter()
