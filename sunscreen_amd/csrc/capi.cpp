@@ -236,7 +236,7 @@ struct KeysObj : Obj {
 // scattered to the callers' buffers by two copy kernels that read a pointer table in pinned host memory, one transparent flag
 // per item, one stream synchronisation for all.  Batch items are independent: the bits do not depend on who was combined with whom.
 struct CombReq {
-  int kind = 0;  // 0 multiply (2 x 2 -> 3 polynomials), 1 relinearize (3 -> 2), 2 Galois automorphism + key switch (2 -> 2)
+  int kind = 0;  // 0 multiply (2 x 2 -> 3 polynomials), 1 relinearize (3 -> 2), 2 Galois automorphism + key switch (2 -> 2), 3 add, 4 sub (2, 2 -> 2)
   const u64* in0 = nullptr;
   const u64* in1 = nullptr;
   const u64* key = nullptr;
@@ -456,13 +456,32 @@ void combine_execute(EvalObj* e, const std::vector<CombReq*>& batch, hipStream_t
   if (c == 1) {
     r0.status = r0.kind == 0 ? ev.multiply(r0.in0, 2, r0.in1, 2, r0.out, 1, s)
               : r0.kind == 1 ? ev.relinearize(r0.in0, r0.key, r0.out, 1, s)
-                             : ev.apply_galois(r0.in0, r0.elt, r0.key, r0.out, 1, s);
+              : r0.kind == 2 ? ev.apply_galois(r0.in0, r0.elt, r0.key, r0.out, 1, s)
+              : r0.kind == 3 ? ev.add(r0.in0, r0.in1, r0.out, 2, 1, s)
+                             : ev.sub(r0.in0, r0.in1, r0.out, 2, 1, s);
     if (r0.status) return;
     const size_t out_words = (r0.kind == 0 ? 3 : 2) * poly;
     table->flags[0] = 1u;
     if (g_throw_transparent && launch_transparent_flags(r0.out, out_words, poly, table->flags, 1, s) != hipSuccess) return all(kHipError);
     if (hipStreamSynchronize(s) != hipSuccess) return all(kHipError);
     r0.nonzero = table->flags[0] ? 1 : 0;
+    return;
+  }
+  if (r0.kind >= 3) {  // add / sub: one pass over the callers' own buffers, no staging
+    for (size_t i = 0; i < c; i++) {
+      table->src[i] = batch[i]->in0;
+      table->src[c + i] = batch[i]->in1;
+      table->dst[i] = batch[i]->out;
+      table->flags[i] = 1u;
+    }
+    if (launch_eltwise_items(e->ctx->dev(), (u32)e->ctx->n(), (u32)e->ctx->K(), table->src, table->src + c, table->dst, r0.kind - 3, c, s) != hipSuccess)
+      return all(kHipError);
+    if (g_throw_transparent && launch_transparent_flags_items(table->dst, 2 * poly, poly, table->flags, c, s) != hipSuccess) return all(kHipError);
+    if (hipStreamSynchronize(s) != hipSuccess) return all(kHipError);
+    for (size_t i = 0; i < c; i++) {
+      batch[i]->status = kOk;
+      batch[i]->nonzero = table->flags[i] ? 1 : 0;
+    }
     return;
   }
   bool squares = r0.kind == 0;  // every request multiplies a ciphertext by itself: one staged operand, the squaring kernels
@@ -1247,6 +1266,16 @@ static long add_sub(void* h, void* a, void* b, void* dst, bool sub) {
   const size_t words = e->ctx->ct_words(smax), common = e->ctx->ct_words(smin);
   u64* buf = g_buffers.get(words);
   if (!buf) return from_status(kOutOfMemory);
+  if (smax == 2 && smin == 2) {  // the common case joins concurrent callers' batches
+    CombReq rq;
+    rq.kind = sub ? 4 : 3, rq.in0 = x->dev, rq.in1 = y->dev, rq.out = buf;
+    const int st2 = combine_run(e, rq, s);
+    if (st2) {
+      g_buffers.put(buf, words);
+      return from_status(st2);
+    }
+    return finish_result(e, d, 2, buf, words, s, true, rq.nonzero);
+  }
   int st = sub ? e->ev->sub(x->dev, y->dev, buf, smin, 1, s) : e->ev->add(x->dev, y->dev, buf, smin, 1, s);
   if (st == kOk && smax > smin) {
     const CipherObj* big = x->size > y->size ? x : y;

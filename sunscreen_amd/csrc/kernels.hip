@@ -1201,6 +1201,37 @@ __global__ __launch_bounds__(kCoefThreads) void scatter_items_kernel(const u64* 
   u64x2_t* dst = reinterpret_cast<u64x2_t*>(table[blockIdx.y]);
   for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < words / 2; i += (size_t)gridDim.x * kCoefThreads) dst[i] = src[i];
 }
+// add / sub of size-2 ciphertexts straight through the pointer tables (no staging: the operation is one pass anyway):
+// *out[item] = *a[item] +/- *b[item]; grid (N/2/256, 2K residue rows, items); mode 0 add, 1 sub
+__global__ __launch_bounds__(kCoefThreads) void eltwise_items_kernel(const DevCtx* __restrict__ ctx, const u64* const* __restrict__ ta,
+                                                                     const u64* const* __restrict__ tb, u64* const* __restrict__ tout, int mode) {
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 k = 2u * (blockIdx.x * kCoefThreads + threadIdx.x);
+  const u32 row = blockIdx.y, item = blockIdx.z;
+  if (k >= n) return;
+  const u64 q = ctx->mod[row % K].q;
+  const size_t off = (size_t)row * n + k;
+  const u64x2_t x = *reinterpret_cast<const u64x2_t*>(ta[item] + off), y = *reinterpret_cast<const u64x2_t*>(tb[item] + off);
+  u64x2_t r;
+  r.x = mode == 0 ? add_mod(x.x, y.x, q) : sub_mod(x.x, y.x, q);
+  r.y = mode == 0 ? add_mod(x.y, y.y, q) : sub_mod(x.y, y.y, q);
+  *reinterpret_cast<u64x2_t*>(tout[item] + off) = r;
+}
+// ... and the transparent verdict of results that live in the callers' own buffers
+__global__ __launch_bounds__(kCoefThreads) void transparent_flags_items_kernel(const u64* const* __restrict__ table, size_t words_per_ct, size_t skip_words,
+                                                                              volatile u32* __restrict__ host_flags) {
+  const u64* p = table[blockIdx.x];
+  for (size_t base = skip_words; base < words_per_ct; base += kCoefThreads) {
+    const size_t i = base + threadIdx.x;
+    const bool nz = i < words_per_ct && p[i] != 0;
+    if (__syncthreads_or(nz)) {
+      if (threadIdx.x == 0) host_flags[blockIdx.x] = 1u;
+      return;
+    }
+  }
+  if (threadIdx.x == 0) host_flags[blockIdx.x] = 0u;
+}
 // transparent_flag_kernel for a batch: host_flags[item] = 1 if item's polynomials 1.. hold a non-zero word, else 0
 __global__ __launch_bounds__(kCoefThreads) void transparent_flags_kernel(const u64* __restrict__ ct, size_t words_per_ct, size_t skip_words,
                                                                         volatile u32* __restrict__ host_flags) {
@@ -1336,6 +1367,15 @@ hipError_t launch_gather_items(const u64* const* table, u64* stage, size_t words
 }
 hipError_t launch_scatter_items(const u64* stage, u64* const* table, size_t words, size_t items, hipStream_t s) {
   scatter_items_kernel<<<dim3(32, (u32)items), kCoefThreads, 0, s>>>(stage, table, words);
+  return hipGetLastError();
+}
+hipError_t launch_eltwise_items(const DevCtx* ctx, u32 n, u32 K, const u64* const* ta, const u64* const* tb, u64* const* tout, int mode, size_t items,
+                                hipStream_t s) {
+  eltwise_items_kernel<<<coef_grid(n / 2, 2 * K, (u32)items), kCoefThreads, 0, s>>>(ctx, ta, tb, tout, mode);
+  return hipGetLastError();
+}
+hipError_t launch_transparent_flags_items(const u64* const* table, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s) {
+  transparent_flags_items_kernel<<<dim3((u32)items), kCoefThreads, 0, s>>>(table, words_per_ct, skip_words, host_flags);
   return hipGetLastError();
 }
 hipError_t launch_transparent_flags(const u64* ct, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s) {

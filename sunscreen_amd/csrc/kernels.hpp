@@ -55,6 +55,9 @@ hipError_t launch_mono_mul(const DevCtx* ctx, u32 n, const u64* in, u64* out, si
 // combined handle-level calls (capi.cpp): tables of device pointers / flags live in pinned, device-addressable host memory
 hipError_t launch_gather_items(const u64* const* table, u64* stage, size_t words, size_t items, hipStream_t s);
 hipError_t launch_scatter_items(const u64* stage, u64* const* table, size_t words, size_t items, hipStream_t s);
+hipError_t launch_eltwise_items(const DevCtx* ctx, u32 n, u32 K, const u64* const* ta, const u64* const* tb, u64* const* tout, int mode, size_t items,
+                                hipStream_t s);
+hipError_t launch_transparent_flags_items(const u64* const* table, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s);
 hipError_t launch_transparent_flags(const u64* ct, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s);
 hipError_t launch_transparent_flag(const u64* ct, size_t words, size_t skip_words, u32* host_flag, hipStream_t s);
 hipError_t launch_transparent_watch(const u64* ct, size_t words_per_ct, size_t skip_words, u32 first_item, u32* status, size_t ops, hipStream_t s);

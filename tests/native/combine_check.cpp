@@ -1,4 +1,4 @@
-// tests/native/combine_check.cpp -- many host threads on ONE evaluator handle, mixed operation kinds, the way
+// tests/native/combine_check.cpp -- many host threads on ONE evaluator handle, mixed operation kinds (multiply, relinearize, rotate, square, add, sub), the way
 // sunscreen_runtime dispatches graph nodes from a rayon pool (run.rs:415-469).  Concurrent calls are combined into batched
 // launches inside the library (capi.cpp Combiner): whatever got combined with whatever, every thread must get exactly the
 // bits it gets alone, and a thread whose result is transparent must be the only one that sees an error.
@@ -41,13 +41,15 @@ int main() {
       b.push_back(encryptor.encrypt(encoder.encode_signed(x)));
     }
     // what every thread gets when it is alone
-    std::vector<std::vector<uint64_t>> want_rel(T), want_rot(T), want_sq(T);
+    std::vector<std::vector<uint64_t>> want_rel(T), want_rot(T), want_sq(T), want_add(T), want_sub(T);
     for (int i = 0; i < T; i++) {
       Ciphertext m = ev.multiply(a[i], b[i]);
       check(Evaluator_Relinearize(ev.get_handle(), m.get_handle(), rk.get_handle(), m.get_handle(), nullptr));
       want_rel[i] = words(m);
       want_rot[i] = words(ev.rotate_rows(a[i], 1 + (i % 3), gk));
       want_sq[i] = words(ev.square(b[i]));
+      want_add[i] = words(ev.add(a[i], b[i]));
+      want_sub[i] = words(ev.sub(a[i], b[i]));
     }
     // an operand whose second polynomial is zero (imported raw: the evaluator itself would refuse to produce it): its product
     // with another such operand is (a0 b0, 0, 0) -- transparent
@@ -61,7 +63,7 @@ int main() {
         int last_kind = -1;
         try {
           for (int it = 0; it < iters; it++) {
-            const int what = (i + it) % 4;
+            const int what = (i + it) % 5;
             last_kind = what;
             if (what == 0 || what == 1) {
               Ciphertext m = ev.multiply(a[i], b[i]);
@@ -69,6 +71,8 @@ int main() {
               if (words(m) != want_rel[i]) bad++, std::fprintf(stderr, "thread %d it %d: multiply+relinearize differs\n", i, it);
             } else if (what == 2) {
               if (words(ev.rotate_rows(a[i], 1 + (i % 3), gk)) != want_rot[i]) bad++, std::fprintf(stderr, "thread %d it %d: rotation differs\n", i, it);
+            } else if (what == 4) {
+              if (words(ev.add(a[i], b[i])) != want_add[i] || words(ev.sub(a[i], b[i])) != want_sub[i]) bad++, std::fprintf(stderr, "thread %d it %d: add / sub differs\n", i, it);
             } else {
               if (words(ev.square(b[i])) != want_sq[i]) bad++, std::fprintf(stderr, "thread %d it %d: square differs\n", i, it);
             }
