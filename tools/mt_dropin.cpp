@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -33,7 +34,7 @@ int main(int argc, char** argv) {
     Decryptor decryptor(ctx, gen.secret_key());
     BFVEvaluator ev(ctx);
     std::vector<int64_t> x(encoder.get_slot_count()), y(x.size());
-    for (size_t i = 0; i < x.size(); i++) x[i] = (int64_t)(i % 31) - 15, y[i] = 5;
+    for (size_t i = 0; i < x.size(); i++) x[i] = (int64_t)(i % 7) - 3, y[i] = 2;  // small values: chi_sq raises them to the fourth power
     const int max_threads = 64;
     std::vector<Ciphertext> a, b, out;
     for (int i = 0; i < max_threads; i++) {
@@ -41,7 +42,29 @@ int main(int argc, char** argv) {
       b.push_back(encryptor.encrypt(encoder.encode_signed(y)));
       out.emplace_back();
     }
-    std::printf("{\"n\": %llu, \"multiply_relinearize_ops_per_s_by_threads\": {", (unsigned long long)n);
+    const bool chi = argc > 3 && std::string(argv[3]) == "chi_sq";
+    // chi_sq: every thread evaluates examples/chi_sq (main.rs:59-88: 6 multiply + relinearize of which 4 squares, 8 add, 1 sub)
+    // node by node through the handle-level calls, the way run.rs walks the graph
+    auto mulrel = [&](const Ciphertext& p, const Ciphertext& q) {
+      Ciphertext m = ev.multiply(p, q);
+      check(Evaluator_Relinearize(ev.get_handle(), m.get_handle(), rk.get_handle(), m.get_handle(), nullptr));
+      return m;
+    };
+    auto chi_sq = [&](const Ciphertext& n0, const Ciphertext& n1, const Ciphertext& n2) {
+      const Ciphertext xx = ev.add(ev.add(n0, n0), n1), yy = ev.add(ev.add(n2, n2), n1);
+      Ciphertext n02 = mulrel(n0, n2);
+      n02 = ev.add(n02, n02);
+      n02 = ev.add(n02, n02);
+      const Ciphertext al = ev.sub(n02, mulrel(n1, n1));
+      const Ciphertext alpha = mulrel(al, al);
+      Ciphertext b1 = mulrel(xx, xx);
+      b1 = ev.add(b1, b1);
+      const Ciphertext b2 = mulrel(xx, yy);
+      Ciphertext b3 = mulrel(yy, yy);
+      b3 = ev.add(b3, b3);
+      return alpha;
+    };
+    std::printf("{\"n\": %llu, \"%s_per_s_by_threads\": {", (unsigned long long)n, chi ? "chi_sq_programs" : "multiply_relinearize_ops");
     bool first = true;
     for (int nt : {1, 2, 4, 8, 16, 32, 64}) {
       std::atomic<long> total{0};
@@ -52,6 +75,11 @@ int main(int argc, char** argv) {
         ths.emplace_back([&, i] {
           long cnt = 0;
           while (!stop.load(std::memory_order_relaxed)) {
+            if (chi) {
+              chi_sq(a[i], b[i], a[(i + 1) % max_threads]);
+              cnt++;
+              continue;
+            }
             check(Evaluator_Multiply(ev.get_handle(), a[i].get_handle(), b[i].get_handle(), out[i].get_handle(), nullptr));
             check(Evaluator_Relinearize(ev.get_handle(), out[i].get_handle(), rk.get_handle(), out[i].get_handle(), nullptr));
             cnt++;
@@ -68,9 +96,11 @@ int main(int argc, char** argv) {
     }
     std::printf("}}\n");
     // the last result of thread 0 still decrypts to the product
-    const std::vector<int64_t> got = encoder.decode_signed(decryptor.decrypt(out[0]));
-    for (size_t i = 0; i < got.size(); i++)
-      if (got[i] != x[i] * y[i]) return 3;
+    if (!chi) {
+      const std::vector<int64_t> got = encoder.decode_signed(decryptor.decrypt(out[0]));
+      for (size_t i = 0; i < got.size(); i++)
+        if (got[i] != x[i] * y[i]) return 3;
+    }
   } catch (const Error& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;
