@@ -448,7 +448,7 @@ void combine_execute(EvalObj* e, const std::vector<CombReq*>& batch, hipStream_t
   };
   const size_t poly = (size_t)e->ctx->K() * e->ctx->n();
   thread_local CombTable* table = nullptr;
-  if (!table && hipHostMalloc((void**)&table, sizeof(CombTable), hipHostMallocMapped) != hipSuccess) {
+  if (!table && hipHostMalloc((void**)&table, sizeof(CombTable), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
     table = nullptr;
     (void)hipGetLastError();
     return all(kOutOfMemory);
@@ -581,7 +581,7 @@ long finish_result(EvalObj* e, CipherObj* dst, u32 size, u64* buf, size_t words,
   } else if (check_transparent && g_throw_transparent) {
     // one word of pinned, device-addressable host memory per host thread: the check kernel writes its verdict there
     thread_local u32* host_flag = nullptr;
-    if (!host_flag && hipHostMalloc((void**)&host_flag, 64, hipHostMallocMapped) != hipSuccess) {
+    if (!host_flag && hipHostMalloc((void**)&host_flag, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
       host_flag = nullptr;
       (void)hipGetLastError();
       g_buffers.put(buf, words);
