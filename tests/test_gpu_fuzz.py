@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _configs():
-    # HIPBFV_FUZZ_SEED / HIPBFV_FUZZ_COUNT: extended campaigns (profiles/r02_v2_fuzz_campaign.txt); the defaults are the suite's
+    # HIPBFV_FUZZ_SEED / HIPBFV_FUZZ_COUNT: extended campaigns (profiles/r02_v3_fuzz_campaign.txt); the defaults are the suite's
     rng = np.random.default_rng(int(os.environ.get("HIPBFV_FUZZ_SEED", "20260925")))
     out = []
     for _ in range(int(os.environ.get("HIPBFV_FUZZ_COUNT", "40"))):
