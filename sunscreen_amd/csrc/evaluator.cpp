@@ -179,6 +179,7 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_HEAD")) fuse_head_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SQUARE")) square_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_PLAIN")) fused_plain_ = env[0] != '1';
+  if (const char* env = std::getenv("HIPBFV_NO_SMALL_BATCH")) small_batch_ = env[0] != '1';
   if (hipMalloc((void**)&status_dev_, 256) == hipSuccess)
     (void)hipMemset(status_dev_, 0xFF, 256);
   else {
@@ -228,6 +229,23 @@ u32 Evaluator::galois_elt_from_step(int step) const {
   return (u32)g;
 }
 
+// A FEW ciphertexts (a handle-level call, a small combined batch) are latency-bound: the head / tail kernels of the split
+// pipelines give each thread eight (four) coefficients and a few workgroups per ciphertext, the whole-polynomial pipelines
+// spread the same work over many more, shorter workgroups.  tools/small_batch_sweep.py (time per call, split / whole, us):
+//   N = 8192:  multiply 1: 70 / 59, 16: 113 / 107, 32: 120 / 166;  multiply+relinearize fused 1: 147 (unfused 110), 16: 173 / 174
+//   N = 16384: multiply 1: 118 / 110, 8: 169 / 203;  relinearize 1: 117 / 74, 8: 138 / 141;  rotation 1: 123 / 80, 8: 147 / 151
+//   N = 4096:  the split pipelines win at every count.
+// The results are the same bits either way (test_split_and_whole_polynomial_paths_agree).
+bool Evaluator::few_for_split_mul(size_t count) const {
+  const u32 logn = ctx_->host().logn;
+  return small_batch_ && (logn == 13 ? count <= 16 : logn == 14 ? count <= 4 : false);
+}
+bool Evaluator::few_for_split_ks(size_t count) const { return small_batch_ && ctx_->host().logn == 14 && count <= 4; }
+bool Evaluator::few_for_fused(size_t count) const {
+  const u32 logn = ctx_->host().logn;
+  return small_batch_ && (logn == 13 ? count <= 8 : logn == 14 ? count <= 4 : false);
+}
+
 int Evaluator::ntt(u64* data, size_t polys, u32 nprimes, bool inverse, hipStream_t s) {
   const DevCtx& h = ctx_->host();
   if (nprimes == 0 || nprimes > h.KK) return kInvalidArg;
@@ -260,7 +278,8 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   const NttPlan plan = make_plan(1, mods);
   // the per-coefficient kernels are instantiated for KMAX data primes and KMAX + 2 auxiliary primes
   const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
-  const bool split = split_mul_ && sa == 2 && sb == 2 && (kneed <= 4 || (kneed <= 8 && h.aux_f64)) && h.logn >= 12 && h.logn <= 14;
+  const bool split = split_mul_ && sa == 2 && sb == 2 && (kneed <= 4 || (kneed <= 8 && h.aux_f64)) && h.logn >= 12 && h.logn <= 14 &&
+                     !few_for_split_mul(count);
   // x * x (Evaluator_Square, a program node with one operand twice): the split kernels extend and transform x once
   const bool square = split && square_ && a == b;
   for (size_t off = 0; off < count; off += chunk) {
@@ -295,7 +314,7 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
   u64* ACC = scratch + count * (size_t)KK * K * n;
   std::vector<u32> mods;
   for (u32 i = 0; i < KK; i++) mods.push_back(i);
-  const bool split_ok = split_ks_ && h.logn >= 12 && h.logn <= 14 && h.ks_split_ok;
+  const bool split_ok = split_ks_ && h.logn >= 12 && h.logn <= 14 && h.ks_split_ok && !few_for_split_ks(count);
   if (split_ok) {
     // head / middle / tail split transforms (kernels_split.hip): 3 launches (4 when FP64- and integer-policy key primes are
     // mixed: one middle kernel per policy), no whole-polynomial NTT round trips
@@ -340,7 +359,8 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
   const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
   // Fused pipeline (all-FP64 contexts: every SEAL default set up to N = 16384): six launches; the product's c0 and c1 are
   // formed inside the last one (mulrelin_tail_kernel) and only c2 -- the key-switch target -- is written by mul_tail.
-  const bool fused = fuse_mulrelin_ && split_mul_ && split_ks_ && h.aux_f64 && h.ks_split_ok && h.ks_ni == 0 && kneed <= 8 && h.logn >= 12 && h.logn <= 14;
+  const bool fused = fuse_mulrelin_ && split_mul_ && split_ks_ && h.aux_f64 && h.ks_split_ok && h.ks_ni == 0 && kneed <= 8 && h.logn >= 12 && h.logn <= 14 &&
+                     !few_for_fused(count);
   const bool square = fused && square_ && a == b;  // x * x: the head extends and the middle kernel transforms x once
   if (fused) {
     const size_t ext_words = (size_t)4 * R * n, d_words = (size_t)3 * R * n, t_words = (size_t)KK * K * n, acc_words = (size_t)2 * KK * n, c2_words = (size_t)K * n;

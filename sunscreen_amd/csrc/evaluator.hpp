@@ -128,6 +128,9 @@ class Evaluator {
   u32* batch_status() const { return status_dev_; }
   int take_status(u32* status_dev, u32* first_bad, hipStream_t s);
   int note_result(const u64* ct, u32 size, u32 residues, size_t count, hipStream_t s);
+  bool few_for_split_mul(size_t count) const;
+  bool few_for_split_ks(size_t count) const;
+  bool few_for_fused(size_t count) const;
   Profiler& profiler() { return prof_; }
   ScratchPool& scratch() { return pool_; }
   Context* ctx() const { return ctx_; }
@@ -191,6 +194,7 @@ class Evaluator {
   bool split_ks_ = true;   // head / middle / tail split transforms for key switching (kernels_split.hip)
   bool split_mul_ = true;  // ... and for the BEHZ multiply
   bool fuse_head_ = true;      // ... and c2 formed inside the key switch's first kernel
+  bool small_batch_ = true;    // a few ciphertexts take the whole-polynomial pipelines (HIPBFV_NO_SMALL_BATCH=1: pipelines chosen by parameters only)
   bool fused_plain_ = true;    // multiply_plain as one kernel per chunk (HIPBFV_NO_FUSED_PLAIN=1: lift / transform / dyadic / inverse as separate kernels)
   bool square_ = true;         // multiply(x, x): two forward transforms instead of four (HIPBFV_NO_SQUARE=1: as a general product)
   bool fuse_mulrelin_ = true;  // multiply_relin: c0, c1 of the product formed inside the key switch's last kernel

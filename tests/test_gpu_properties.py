@@ -175,6 +175,7 @@ np.save(sys.argv[1], np.concatenate([x.cpu().numpy().ravel() for x in (r, m, g, 
         ("split_unfused_tail", {"HIPBFV_NO_FUSED_TAIL": "1"}),  # multiply then relinearize through a c0/c1/c2 buffer instead of mulrelin_tail
         ("split_unfused_head", {"HIPBFV_NO_FUSED_HEAD": "1"}),  # c2 through HBM between mul_tail and ks_head instead of mulrelin_head
         ("split_no_square", {"HIPBFV_NO_SQUARE": "1"}),  # x * x as a general product (four forward transforms instead of two)
+        ("small_batch_selection", {"HIPBFV_NO_SMALL_BATCH": "0"}),  # the product default: these 14 ciphertexts take the whole-polynomial multiply
         ("unfused_plain", {"HIPBFV_NO_FUSED_PLAIN": "1"}),  # multiply_plain as transform / dyadic product / inverse kernels instead of one
         ("split_unpacked", {"HIPBFV_NO_PACK": "1"}),  # 8-byte instead of 48-bit packed intermediates
         ("split_no_grid", {"HIPBFV_NO_GRID": "1"}),  # base-conversion sums reduced term by term instead of once (griddot.hpp)
