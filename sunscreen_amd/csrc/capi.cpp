@@ -236,11 +236,15 @@ struct KeysObj : Obj {
 // scattered to the callers' buffers by two copy kernels that read a pointer table in pinned host memory, one transparent flag
 // per item, one stream synchronisation for all.  Batch items are independent: the bits do not depend on who was combined with whom.
 struct CombReq {
-  int kind = 0;  // 0 multiply (2 x 2 -> 3 polynomials), 1 relinearize (3 -> 2), 2 Galois automorphism + key switch (2 -> 2), 3 add, 4 sub (2, 2 -> 2)
+  // 0 multiply (2 x 2 -> 3 polynomials), 1 relinearize (3 -> 2), 2 Galois automorphism + key switch (2 -> 2), 3 add, 4 sub (2, 2 -> 2),
+  // 5 add_plain, 6 sub_plain, 7 multiply_plain (2 polynomials and a plaintext of N coefficients in in1 -> 2)
+  int kind = 0;
   const u64* in0 = nullptr;
   const u64* in1 = nullptr;
   const u64* key = nullptr;
   u32 elt = 0;
+  u64 mono_coeff = 0;  // multiply_plain by a monomial (SEAL's shortcut): coefficient and exponent, used when the request runs alone
+  u32 mono_exp = 0;
   u64* out = nullptr;
   int status = 0;
   int nonzero = -1;  // transparent check of the result: 1 / 0 (made where the request ran, together with the synchronisation)
@@ -458,7 +462,11 @@ void combine_execute(EvalObj* e, const std::vector<CombReq*>& batch, hipStream_t
               : r0.kind == 1 ? ev.relinearize(r0.in0, r0.key, r0.out, 1, s)
               : r0.kind == 2 ? ev.apply_galois(r0.in0, r0.elt, r0.key, r0.out, 1, s)
               : r0.kind == 3 ? ev.add(r0.in0, r0.in1, r0.out, 2, 1, s)
-                             : ev.sub(r0.in0, r0.in1, r0.out, 2, 1, s);
+              : r0.kind == 4 ? ev.sub(r0.in0, r0.in1, r0.out, 2, 1, s)
+              : r0.kind == 5 ? ev.add_plain(r0.in0, 2, r0.in1, 0, r0.out, 1, s)
+              : r0.kind == 6 ? ev.sub_plain(r0.in0, 2, r0.in1, 0, r0.out, 1, s)
+              : r0.mono_coeff ? ev.multiply_plain_mono(r0.in0, 2, r0.mono_coeff, r0.mono_exp, r0.out, 1, s)
+                              : ev.multiply_plain(r0.in0, 2, r0.in1, 0, r0.out, 1, s);
     if (r0.status) return;
     const size_t out_words = (r0.kind == 0 ? 3 : 2) * poly;
     table->flags[0] = 1u;
@@ -467,7 +475,7 @@ void combine_execute(EvalObj* e, const std::vector<CombReq*>& batch, hipStream_t
     r0.nonzero = table->flags[0] ? 1 : 0;
     return;
   }
-  if (r0.kind >= 3) {  // add / sub: one pass over the callers' own buffers, no staging
+  if (r0.kind == 3 || r0.kind == 4) {  // add / sub: one pass over the callers' own buffers, no staging
     for (size_t i = 0; i < c; i++) {
       table->src[i] = batch[i]->in0;
       table->src[c + i] = batch[i]->in1;
@@ -486,22 +494,28 @@ void combine_execute(EvalObj* e, const std::vector<CombReq*>& batch, hipStream_t
   }
   bool squares = r0.kind == 0;  // every request multiplies a ciphertext by itself: one staged operand, the squaring kernels
   for (const CombReq* r : batch) squares = squares && r->in0 == r->in1;
+  const bool plain_op = r0.kind >= 5;
   const size_t in_polys = r0.kind == 1 ? 3 : 2, nin = r0.kind == 0 && !squares ? 2 : 1, out_polys = r0.kind == 0 ? 3 : 2;
-  const size_t in_words = in_polys * poly, out_words = out_polys * poly;
-  ScratchGuard sg(ev.scratch(), c * (nin * in_words + out_words) * sizeof(u64), s);
+  const size_t in_words = in_polys * poly, out_words = out_polys * poly, pl_words = plain_op ? e->ctx->n() : 0;
+  ScratchGuard sg(ev.scratch(), c * (nin * in_words + out_words + pl_words) * sizeof(u64), s);
   if (!sg.p) return all(kOutOfMemory);
-  u64* in_stage = (u64*)sg.p;                  // [nin][c][in_polys][K][N]
+  u64* in_stage = (u64*)sg.p;                      // [nin][c][in_polys][K][N]
   u64* out_stage = in_stage + c * nin * in_words;  // [c][out_polys][K][N]
+  u64* pl_stage = out_stage + c * out_words;       // [c][N] plaintexts of the plain operations
   for (size_t i = 0; i < c; i++) {
     table->src[i] = batch[i]->in0;
-    if (nin == 2) table->src[c + i] = batch[i]->in1;
+    if (nin == 2 || plain_op) table->src[c + i] = batch[i]->in1;
     table->dst[i] = batch[i]->out;
     table->flags[i] = 1u;
   }
   if (launch_gather_items(table->src, in_stage, in_words, c * nin, s) != hipSuccess) return all(kHipError);
+  if (plain_op && launch_gather_items(table->src + c, pl_stage, pl_words, c, s) != hipSuccess) return all(kHipError);
   int st = r0.kind == 0 ? ev.multiply(in_stage, 2, in_stage + (squares ? 0 : c * in_words), 2, out_stage, c, s)
          : r0.kind == 1 ? ev.relinearize(in_stage, r0.key, out_stage, c, s)
-                        : ev.apply_galois(in_stage, r0.elt, r0.key, out_stage, c, s);
+         : r0.kind == 2 ? ev.apply_galois(in_stage, r0.elt, r0.key, out_stage, c, s)
+         : r0.kind == 5 ? ev.add_plain(in_stage, 2, pl_stage, pl_words, out_stage, c, s)
+         : r0.kind == 6 ? ev.sub_plain(in_stage, 2, pl_stage, pl_words, out_stage, c, s)
+                        : ev.multiply_plain(in_stage, 2, pl_stage, pl_words, out_stage, c, s);  // monomials included: same bits as the shortcut
   if (st) return all(st);
   if (launch_scatter_items(out_stage, table->dst, out_words, c, s) != hipSuccess) return all(kHipError);
   if (g_throw_transparent && launch_transparent_flags(out_stage, out_words, poly, table->flags, c, s) != hipSuccess) return all(kHipError);
@@ -1482,6 +1496,20 @@ static long plain_op(void* h, void* a, void* plain, void* dst, int which) {
   if (!buf) {
     g_buffers.put(dplain, e->ctx->n());
     return from_status(kOutOfMemory);
+  }
+  if (x->size == 2) {  // the common case joins concurrent callers' batches
+    CombReq rq;
+    rq.kind = 5 + which, rq.in0 = x->dev, rq.in1 = dplain, rq.out = buf;
+    if (which == 2 && nonzero == 1) rq.mono_coeff = p->coeffs[last], rq.mono_exp = (u32)last;
+    const int st2 = combine_run(e, rq, s);
+    if (st2) {
+      g_buffers.put(buf, x->words);
+      g_buffers.put(dplain, e->ctx->n());
+      return from_status(st2);
+    }
+    hr = finish_result(e, d, 2, buf, x->words, s, true, rq.nonzero);
+    g_buffers.put(dplain, e->ctx->n());
+    return hr;
   }
   int st;
   if (which == 0)
