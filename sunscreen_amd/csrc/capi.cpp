@@ -1459,7 +1459,21 @@ HIPBFV_END
 static long plain_to_device(EvalObj* e, PlainObj* p, u64** out, size_t* nonzero, size_t* last_nonzero) {
   const size_t n = e->ctx->n();
   if (p->coeffs.size() > n) return fail(HIPBFV_E_INVALIDARG, "plain is not valid for encryption parameters");
-  std::vector<u64> padded(n, 0);
+  // staged through pinned memory of the calling thread and copied on its own stream: a plain hipMemcpy from pageable memory
+  // goes through the null stream, where the copies of concurrent callers queue behind one another
+  thread_local u64* padded = nullptr;
+  thread_local size_t padded_words = 0;
+  if (padded_words < n) {
+    if (padded) (void)hipHostFree(padded);
+    padded = nullptr;
+    padded_words = 0;
+    if (hipHostMalloc((void**)&padded, n * sizeof(u64), hipHostMallocPortable) != hipSuccess) {
+      padded = nullptr;
+      (void)hipGetLastError();
+      return from_status(kOutOfMemory);
+    }
+    padded_words = n;
+  }
   *nonzero = 0;
   *last_nonzero = 0;
   for (size_t i = 0; i < p->coeffs.size(); i++) {
@@ -1470,9 +1484,11 @@ static long plain_to_device(EvalObj* e, PlainObj* p, u64** out, size_t* nonzero,
       *last_nonzero = i;
     }
   }
+  for (size_t i = p->coeffs.size(); i < n; i++) padded[i] = 0;
   u64* buf = g_buffers.get(n);
   if (!buf) return from_status(kOutOfMemory);
-  if (hipMemcpy(buf, padded.data(), n * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) {
+  hipStream_t ps = thread_stream();
+  if (hipMemcpyAsync(buf, padded, n * sizeof(u64), hipMemcpyHostToDevice, ps) != hipSuccess || hipStreamSynchronize(ps) != hipSuccess) {
     g_buffers.put(buf, n);
     return from_status(kHipError);
   }
