@@ -71,13 +71,25 @@ def launch_ranks(args) -> int:
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(args.gpus)]
+    import time
+
+    # watch ALL ranks: the first one that fails takes the others down at once (they would otherwise sit in the rendezvous or in a
+    # collective until its timeout -- ten minutes for a rank that died before joining)
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
-        if rc:  # one rank failed: the others would wait in a collective forever
+    while True:
+        states = [p.poll() for p in procs]
+        failed = [c for c in states if c not in (None, 0)]
+        if failed:
+            rc = failed[0]
             for q in procs:
                 if q.poll() is None:
                     q.kill()
+            for q in procs:
+                q.wait()
+            break
+        if all(c == 0 for c in states):
+            break
+        time.sleep(0.2)
     return rc
 
 
@@ -99,6 +111,9 @@ def main():
     # validation knobs for boxes with fewer GPUs than ranks (not used by the driver): all ranks on device 0, gloo
     if os.environ.get("HIPBFV_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py rank {rank}: no GPU for LOCAL_RANK={local_rank} ({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible); "
+                 f"--gpus {args.gpus} needs that many devices on this node")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:

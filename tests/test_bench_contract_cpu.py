@@ -77,3 +77,18 @@ def test_pmc_traffic_tool_reproduces_the_committed_file(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), "mulrelin_n8192", p + "pmc_fetch.txt", p + "pmc_write.txt",
                           str(units), p + "pmc_inst.txt"], capture_output=True, text=True, check=True).stdout
     assert json.loads(out) == committed["workloads"]["mulrelin_n8192"]
+
+
+def test_a_rank_that_dies_takes_the_self_spawned_launch_down_at_once():
+    """`python bench.py --gpus N` spawns its ranks; a rank without a device (here: every rank, there is no GPU) must end the
+    whole launch within seconds, not after the rendezvous timeout of the survivors (600 s, measured the hard way)."""
+    import subprocess
+    import sys
+    import time
+
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                         capture_output=True, text=True, timeout=240, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    assert out.returncode != 0
+    assert "no GPU for LOCAL_RANK" in out.stderr
+    assert time.time() - t0 < 200
