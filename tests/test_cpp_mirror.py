@@ -81,3 +81,10 @@ def test_concurrent_handle_calls_are_combined_without_changing_a_bit(tmp_path):
         for _ in range(3):  # which calls meet in a batch differs from run to run
             out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
             assert out.returncode == 0 and "combine ok" in out.stdout, (env, out.returncode, out.stdout, out.stderr)
+
+
+def test_native_thread_tools_build(tmp_path):
+    """No GPU: the native multi-thread check and the drop-in throughput tool compile and link against the library with
+    warnings as errors (they run in the GPU suite / by hand)."""
+    _build(tmp_path, "-O1", os.path.join(ROOT, "tests", "native", "combine_check.cpp"), ["-lpthread"])
+    _build(tmp_path, "-O2", os.path.join(ROOT, "tools", "mt_dropin.cpp"), ["-lpthread"])
