@@ -94,3 +94,31 @@ def test_mutated_wire_objects_and_program_json_never_crash_the_decoders():
     for seed in (1, 2):
         out = subprocess.run([sys.executable, "-c", CHILD, str(seed), "4000"], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "fuzz ok" in out.stdout, (seed, out.returncode, out.stdout[-400:], out.stderr[-2000:])
+
+
+def test_parsers_are_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The same mutation campaign against the parsers' internal entry points (wire_unpack_*, Program::load_json) in a build with
+    AddressSanitizer + UBSan + leak detection: out-of-bounds reads that do not crash a normal build, signed overflows and leaks
+    abort this one (tests/native/parser_fuzz_asan.cpp; 300 K inputs by hand were clean)."""
+    import shutil
+
+    if not shutil.which("g++") or not os.path.isdir("/opt/rocm/include"):
+        import pytest
+
+        pytest.skip("needs g++ and the HIP headers")
+    sys.path.insert(0, ROOT)
+    from sunscreen_amd.workloads import chi_sq_optimized, dot_product
+
+    seeds = []
+    for name, prog in (("chi.json", chi_sq_optimized()), ("dot.json", dot_product(8))):
+        p = tmp_path / name
+        p.write_text(prog.to_json())
+        seeds.append(str(p))
+    exe = str(tmp_path / "parser_fuzz_asan")
+    csrc = os.path.join(ROOT, "sunscreen_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
+                           "-I/opt/rocm/include", "-I", csrc, "-x", "c++", os.path.join(ROOT, "tests", "native", "parser_fuzz_asan.cpp"),
+                           os.path.join(csrc, "wire.cpp"), os.path.join(csrc, "program.cpp"), "-ldl", "-Wl,--unresolved-symbols=ignore-all", "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe, "7", "4000"] + seeds, capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0 and "asan fuzz ok" in out.stdout, (out.returncode, out.stdout[-300:], out.stderr[-3000:])
