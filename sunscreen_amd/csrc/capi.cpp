@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "evaluator.hpp"
+#include "flat_combiner.hpp"
 #include "program.hpp"
 #include "wire.hpp"
 
@@ -250,11 +251,7 @@ struct CombReq {
   int nonzero = -1;  // transparent check of the result: 1 / 0 (made where the request ran, together with the synchronisation)
   std::atomic<bool> done{false};
 };
-struct Combiner {
-  std::mutex mu;
-  std::deque<CombReq*> q;
-  std::atomic<int> leaders{0};  // batches in flight
-};
+using Combiner = FlatCombiner<CombReq>;  // flat_combiner.hpp: the queueing protocol (ThreadSanitizer-tested on its own)
 #ifndef HIPBFV_COMBINE_LEADERS
 #define HIPBFV_COMBINE_LEADERS 1
 #endif
@@ -533,58 +530,22 @@ int combine_run(EvalObj* e, CombReq& req, hipStream_t s) {
     const char* env = std::getenv("HIPBFV_NO_COMBINE");
     return !(env && env[0] == '1');
   }();
-  Combiner& cb = e->comb;
   if (!enabled) {
     std::vector<CombReq*> one{&req};
     combine_execute(e, one, s);
     return req.status;
   }
-  {
-    std::lock_guard<std::mutex> g(cb.mu);
-    cb.q.push_back(&req);
-  }
-  // Waiting callers watch two atomics -- their own request's `done` and the evaluator's `leaders` -- and only take the mutex to
-  // lead: sixty-odd threads woken through one condition variable spend longer handing its mutex around than the batch took.
-  for (unsigned spins = 0;; spins++) {
-    if (req.done.load(std::memory_order_acquire)) return req.status;
-    if (cb.leaders.load(std::memory_order_relaxed) < kCombineLeaders) {
-      std::unique_lock<std::mutex> lk(cb.mu);
-      if (req.done.load(std::memory_order_acquire)) return req.status;
-      if (cb.leaders.load(std::memory_order_relaxed) < kCombineLeaders && !cb.q.empty()) {
-        // lead: the oldest request and everything queued behind it that can share its launch
-        cb.leaders.fetch_add(1, std::memory_order_relaxed);
-        std::vector<CombReq*> batch;
-        CombReq* head = cb.q.front();
-        for (auto it = cb.q.begin(); it != cb.q.end() && batch.size() < kCombineMax;) {
-          CombReq* r = *it;
-          if (r->kind == head->kind && r->key == head->key && r->elt == head->elt) {
-            batch.push_back(r);
-            it = cb.q.erase(it);
-          } else {
-            ++it;
-          }
-        }
-        lk.unlock();
+  e->comb.run(
+      req, kCombineLeaders, kCombineMax,
+      [](const CombReq& head, const CombReq& r) { return r.kind == head.kind && r.key == head.key && r.elt == head.elt; },
+      [&](const std::vector<CombReq*>& batch) {
         try {
           combine_execute(e, batch, s);
         } catch (...) {
           for (CombReq* r : batch) r->status = kOutOfMemory;
         }
-        // a request's owner may return (and its CombReq go out of scope) the moment it sees `done`: nothing of r is touched after the store
-        for (CombReq* r : batch) r->done.store(true, std::memory_order_release);
-        cb.leaders.fetch_sub(1, std::memory_order_release);
-        spins = 0;
-        continue;
-      }
-    }
-    if (spins < 4096) {
-      __builtin_ia32_pause();
-    } else {
-      // a long operation (large degree, big batch) is running: stop burning the core
-      struct timespec ts = {0, 20000};
-      nanosleep(&ts, nullptr);
-    }
-  }
+      });
+  return req.status;
 }
 
 // known: the transparent verdict when a combined batch already produced it (and synchronised): 1 / 0; -1 = check here
