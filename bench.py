@@ -4,23 +4,34 @@
 One "step" = one pass of the hot path over one batch: `--batch` (default 4096) independent
 ciphertext pairs, n=8192, SEAL default 128-bit parameters (K=4 data primes + 1 special prime,
 t = batching(8192,17) = 114689) -- BASELINE.json configs[2], the configuration the metric is quoted
-on.  Inputs are resident in HBM before the timed region.  `--workload ntt` runs configs[1]
-(batched forward+inverse NTT, n=8192, 3 primes, 4096 polynomials) instead; chi_sq / dot_prod / pir / e2e run the
-reference's example programs and the client-side steps (secondary workloads, same JSON contract).
+on.  Inputs are resident in HBM before the timed region.
+
+BASELINE.json's metric names three quantities ("mul+relin ops/sec at n=8192/16384; NTTs/sec").  The default run
+therefore times all three: the headline line is n=8192 and its `secondary` object carries the n=16384 mul+relin
+(batch/4 pairs, SEAL default K=8+1) and the configs[1] transform workload (forward+inverse NTT, n=8192, 3 primes,
+`--batch` polynomials), each with its own value, ms_per_step, roofline, cpu_baseline and parity gate, measured with the
+same --steps / --warmup in the same process (`--no-secondary` drops them).  `--workload ntt|chi_sq|dot_prod|pir|e2e`
+run one workload alone (the reference's example programs and the client-side steps; same JSON contract).
 
 The CPU oracle appears here in three roles only: client (it generates the keys and the few genuine encryptions the
-parity gate needs -- the library has no key generator), checker (parity gate, after the timed region) and
-`cpu_baseline` (all host cores, OpenMP over the batch).  Nothing in the timed region touches it.
+parity gate needs), checker (parity gate, after the timed region) and `cpu_baseline` (host cores, OpenMP over the
+batch).  Nothing in the timed region touches it.
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank processes its own
-`--batch` items (weak scaling, no data-path collective); time = max over ranks.  Under torchrun the ranks come from the
-environment (WORLD_SIZE must equal --gpus); a bare `python bench.py --gpus N` spawns the N ranks itself.  Rank 0 owns the
-keys and broadcasts them once (sunscreen_amd.dist.replicate_keys); `--gather` additionally times the optional all_gather
-of the results (reported apart from `value`).
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank processes its own `--batch` items (weak
+scaling, no data-path collective) or, with `--total-batch T`, its shard of T items (strong scaling: BASELINE configs[3]
+"1024-input batch sharded across 8"); time = max over ranks.  Under torchrun the ranks come from the environment
+(WORLD_SIZE must equal --gpus); a bare `python bench.py --gpus N` spawns the N ranks itself.  Rank 0 owns the keys and
+broadcasts them once (sunscreen_amd.dist.replicate_keys); `--gather` additionally times the optional gather of the
+results to rank 0 (reported apart from `value`).  `--workload pir` is the one workload with a data-path exchange
+(SURVEY 8e "Exception"): the database is sharded by ROW across the ranks, every rank reduces its rows to one ciphertext
+and `dist.reduce_ciphertexts` sums one ciphertext per GPU on rank 0 inside the timed step.
+`--gpus N --dry-run` validates the launch environment and prints the per-rank shapes without touching a GPU.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import copy
+import hashlib
 import json
 import os
 import sys
@@ -32,29 +43,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+HBM_BYTES = 288 * 10**9
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="ciphertext pairs (or polynomials for --workload ntt) per GPU per step")
+    ap.add_argument("--batch", type=int, default=4096, help="ciphertext pairs (or polynomials for --workload ntt) per GPU per step; "
+                    "pir: database columns (and rows unless --pir-rows)")
+    ap.add_argument("--total-batch", type=int, default=0, help="strong-scaling form: this many items in total, sharded over the ranks "
+                    "(sunscreen_amd.dist.shard_range) instead of --batch per GPU")
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--workload", choices=["mulrelin", "ntt", "chi_sq", "dot_prod", "e2e", "pir"], default="mulrelin",
                     help="mulrelin = the headline; ntt = batched transforms; chi_sq / dot_prod = whole program graphs "
                          "(examples/chi_sq, examples/dot_prod) through the batch graph executor (SURVEY 8d configs 4 / 5b); "
                          "e2e = encode + encrypt both operands, multiply + relinearize, decrypt + decode, all on the device; "
-                         "pir = examples/pir lookup over a (--batch x --batch) plaintext database held in transform form (SURVEY 8d config 5a)")
+                         "pir = examples/pir lookup over a (--pir-rows x --batch) plaintext database held in transform form, rows "
+                         "sharded over the ranks, one cross-GPU sum (SURVEY 8d config 5a)")
+    ap.add_argument("--pir-rows", type=int, default=0, help="pir: database rows in total (default = --batch: a square database)")
     ap.add_argument("--coeff-bits", default="", help="comma-separated prime sizes (CoeffModulus::create, last = special prime) instead of the "
                     "SEAL default set for --n, e.g. 54,54,54,56 for the 3 x 54-bit n=8192 variant BASELINE.json mentions")
     ap.add_argument("--chunk", type=int, default=0, help="override the executor's chunk size (ops per launch group)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="ops in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline run only: skip the n=16384 mul+relin and the NTT workload "
+                    "that the default run reports under `secondary`")
     ap.add_argument("--check-items", type=int, default=64, help="mulrelin: items compared bit for bit with the oracle (BASELINE.md section 3: >= 64)")
-    ap.add_argument("--gather", action="store_true", help="N>1: also time one all_gather of the result batch (reported as result_gather_ms, never part of value)")
-    return ap.parse_args()
+    ap.add_argument("--check-sets", type=int, default=8, help="chi_sq / dot_prod: input sets compared bit for bit with the oracle's graph interpreter")
+    ap.add_argument("--gather", action="store_true", help="N>1: also time one gather of the result batch to rank 0 (reported as result_gather_ms, never part of value)")
+    ap.add_argument("--dry-run", action="store_true", help="validate the launch environment, per-rank shapes and HBM footprint for --gpus N and exit (no GPU needed)")
+    return ap.parse_args(argv)
 
 
 def launch_ranks(args) -> int:
@@ -71,8 +92,6 @@ def launch_ranks(args) -> int:
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(args.gpus)]
-    import time
-
     # watch ALL ranks: the first one that fails takes the others down at once (they would otherwise sit in the rendezvous or in a
     # collective until its timeout -- ten minutes for a rank that died before joining)
     rc = 0
@@ -93,10 +112,123 @@ def launch_ranks(args) -> int:
     return rc
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args))
+# ---------------------------------------------------------------------------------------------------------------------
+# shapes (shared by the run and by --dry-run)
+# ---------------------------------------------------------------------------------------------------------------------
+def default_K(n):
+    # data primes of SEAL's 128-bit default set (CoeffModulus::BFVDefault): key level = K + 1
+    return {1024: 1, 2048: 1, 4096: 2, 8192: 4, 16384: 8, 32768: 15}[n]
+
+
+def rank_items(args, rank, world):
+    """Items of this rank's shard: --batch each (weak) or shard_range(--total-batch) (strong)."""
+    from sunscreen_amd.dist import shard_range
+
+    if args.total_batch:
+        lo, hi = shard_range(args.total_batch, rank, world)
+        return hi - lo
+    return args.batch
+
+
+def plan_bytes(args, rank, world, K):
+    """Resident HBM bytes of one rank's inputs + outputs (the pipeline scratch of one 1024-op chunk comes on top: ~4 GB)."""
+    n = args.n
+    ct = 2 * K * n * 8
+    if args.workload == "pir":
+        from sunscreen_amd.dist import shard_range
+
+        rows = args.pir_rows or args.batch
+        lo, hi = shard_range(rows, rank, world)
+        return {"database_rows": [lo, hi], "database_bytes": (hi - lo) * args.batch * K * n * 8, "query_bytes": (args.batch + rows) * ct,
+                "partial_sum_bytes_to_root": ct}
+    B = rank_items(args, rank, world)
+    if args.workload == "ntt":
+        return {"items": B, "resident_bytes": 2 * B * 3 * n * 8}
+    nin, nout = {"mulrelin": (2, 1), "e2e": (2, 1), "chi_sq": (3, 4), "dot_prod": (2, 1)}[args.workload]
+    return {"items": B, "resident_bytes": B * ct * (nin + nout)}
+
+
+def dry_run(args) -> int:
+    """`--gpus N --dry-run`: everything that can be checked without a GPU -- the launch environment torchrun / the self-spawn
+    provides, the per-rank shards, the HBM footprint against 288 GB, the one-time key broadcast and the collectives the run
+    will issue.  Exit code 0 = the launch is consistent."""
+    from sunscreen_amd.dist import shard_range
+
+    world = args.gpus
+    problems = []
+    env = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY",
+                                          "HIPBFV_BENCH_BACKEND", "HIPBFV_DIST_TIMEOUT_S", "NCCL_DEBUG", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
+    if env["WORLD_SIZE"] is not None and int(env["WORLD_SIZE"]) != world:
+        problems.append(f"WORLD_SIZE={env['WORLD_SIZE']} contradicts --gpus {world}")
+    if env["WORLD_SIZE"] is not None and env["MASTER_ADDR"] not in (None, "127.0.0.1", "localhost"):
+        problems.append(f"MASTER_ADDR={env['MASTER_ADDR']}: one node only -- use 127.0.0.1 (the container hostname may not resolve)")
+    if world > 1 and (env["HSA_ENABLE_IPC_MODE_LEGACY"] or "0") != "0":
+        problems.append("HSA_ENABLE_IPC_MODE_LEGACY must be 0 (the host driver only supports dmabuf IPC; RCCL fails with hipIpcGetMemHandle otherwise)")
+    K = len(args.coeff_bits.split(",")) - 1 if args.coeff_bits else default_K(args.n)
+    KK = K + 1
+    key_bytes = 16 * K * KK * args.n
+    ranks = []
+    for r in range(world):
+        p = plan_bytes(args, r, world, K)
+        total = p.get("resident_bytes", 0) + p.get("database_bytes", 0) + p.get("query_bytes", 0)
+        if total + (8 << 30) > HBM_BYTES:
+            problems.append(f"rank {r}: {total / 2**30:.1f} GiB resident + scratch exceeds 288 GB of HBM")
+        if args.workload != "pir" and p["items"] == 0:
+            problems.append(f"rank {r} has no items (--total-batch {args.total_batch} < --gpus {world})")
+        ranks.append(dict(rank=r, local_rank=r, **p))
+    if args.workload == "pir" and (args.pir_rows or args.batch) < world:
+        problems.append("fewer database rows than ranks")
+    ngal = {"dot_prod": args.n.bit_length() - 1}.get(args.workload, 0)
+    collectives = [
+        "init_process_group(nccl, timeout=HIPBFV_DIST_TIMEOUT_S or 600 s)",
+        f"broadcast x2 per key object, <= 256 MiB per message: relin keys {key_bytes} B, public key {2 * KK * args.n * 8} B, secret key {KK * args.n * 8} B"
+        + (f", Galois keys {ngal} x {key_bytes} B = {ngal * key_bytes / 2**20:.0f} MiB" if ngal else ""),
+        "barrier(device_ids=[local_rank]) before and after the timed region",
+        "all_reduce(MAX) of the elapsed time (1 double); all_reduce(MIN) of the decrypt gate (1 int64)",
+    ]
+    if args.workload == "pir":
+        collectives.append(f"per step: gather(dst=0) of one ciphertext per rank ({2 * K * args.n * 8} B each) + {world - 1} additions on rank 0")
+        collectives.append("once: broadcast of the query ciphertexts from rank 0 (<= 1 GiB per message)")
+    if args.gather:
+        collectives.append("after the timed region: gather(dst=0) of every rank's result block (padded to the longest shard)")
+    doc = {"dry_run": True, "n_gpus": world, "workload": args.workload, "scaling": scaling_of(args), "poly_modulus_degree": args.n,
+           "coeff_modulus_primes": KK, "environment": env, "ranks": ranks, "collectives": collectives,
+           "launch": (f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {world} --master-addr 127.0.0.1 --master-port P bench.py --gpus {world} ..."
+                      if world > 1 else "python bench.py"),
+           "problems": problems, "ok": not problems}
+    try:
+        import torch
+
+        doc["torch"] = torch.__version__
+        doc["nccl_available"] = bool(torch.distributed.is_nccl_available())
+        doc["visible_devices"] = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception as e:  # torch is plumbing; the shape checks above do not need it
+        doc["torch"] = f"import failed: {e}"
+    from sunscreen_amd import _lib
+
+    try:
+        _lib.load()
+        doc["libhipbfv"] = "loaded, every symbol of include/hipbfv.h exported"
+    except Exception as e:
+        problems.append(f"libhipbfv.so: {e}")
+        doc["ok"] = False
+    print(json.dumps(doc))
+    return 0 if doc["ok"] else 1
+
+
+def scaling_of(args):
+    # pir shards one fixed database by row; --total-batch shards one fixed batch: total work fixed = strong
+    return "strong" if (args.total_batch or args.workload == "pir") else "weak"
+
+
+class Env:
+    """What main() sets up once and every measurement shares."""
+
+    def __init__(self, rank, local_rank, world, dev):
+        self.rank, self.local_rank, self.world, self.dev = rank, local_rank, world, dev
+
+
+def setup(args) -> Env:
     import torch
     import torch.distributed as dist
 
@@ -115,17 +247,41 @@ def main():
         sys.exit(f"bench.py rank {rank}: no GPU for LOCAL_RANK={local_rank} ({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible); "
                  f"--gpus {args.gpus} needs that many devices on this node")
     torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
     if world > 1:
-        dist.init_process_group(os.environ.get("HIPBFV_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        from sunscreen_amd.dist import init_timeout
 
-    from sunscreen_amd import Context, RelinearizationKeys, _lib
-    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+        dist.init_process_group(os.environ.get("HIPBFV_BENCH_BACKEND", "nccl"), rank=rank, world_size=world, timeout=init_timeout())
+    from sunscreen_amd import _lib
 
     _lib.load().hipbfv_set_device(local_rank)
+    return Env(rank, local_rank, world, f"cuda:{local_rank}")
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the device code and the host code that picks launch sequences and reduce masks: the PMC-derived fields of
+    the bench line are only valid for the kernels they were measured on (profiles/pmc_traffic.json records this hash)."""
+    d = os.path.join(ROOT, "sunscreen_amd", "csrc")
+    names = sorted(f for f in os.listdir(d) if f.endswith((".hip", ".hpp")) or f in ("context.cpp", "evaluator.cpp"))
+    h = hashlib.sha256()
+    for f in names:
+        h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def measure(args, env: Env, secondary: bool = False):
+    """Run ONE workload: W warm-up steps, K timed steps between barriers, parity gate, roofline, CPU baseline.
+    Returns the JSON object on rank 0, None on the other ranks."""
+    import torch
+    import torch.distributed as dist
+
+    from sunscreen_amd import Context, RelinearizationKeys
+    from sunscreen_amd import dist as D
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
     # the oracle is the checker and the CPU baseline only
     from oracle import bfv_oracle as O
 
+    rank, world, dev = env.rank, env.world, env.dev
     n = args.n
     primes = O.coeff_modulus_create(n, [int(b) for b in args.coeff_bits.split(",")]) if args.coeff_bits else O.bfv_default(n)
     pset = ("CoeffModulus::create(" + args.coeff_bits + ")") if args.coeff_bits else "SEAL default 128-bit"
@@ -135,9 +291,12 @@ def main():
     if args.chunk:
         ev.set_chunk_ops(args.chunk)
     K, KK = ctx.K, ctx.KK
-    B = args.batch
+    B = rank_items(args, rank, world)
+    total_items = args.total_batch if args.total_batch else B * world
+    share = f"{args.total_batch} in total, sharded" if args.total_batch else f"{B}/GPU"
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x5EA10001 + rank)
+    cdev = dev if D.is_nccl() else "cpu"  # where small collective payloads live
 
     def uniform_residues(shape_prefix, nres, primes_):
         # uniform canonical residues per prime: valid ciphertext / polynomial bit patterns
@@ -146,24 +305,29 @@ def main():
             out[..., i, :] = torch.randint(0, primes_[i % len(primes_)], shape_prefix + (n,), generator=gen, device=dev, dtype=torch.int64)
         return out
 
-    result = {}
-    if args.workload == "mulrelin":
-        from sunscreen_amd import PublicKey, SecretKey
-        from sunscreen_amd import dist as D
+    def owner_keys(seed, galois_elts=None):
+        """Rank 0 is the key owner (the oracle stands in for the client's key generator); the other ranks receive the
+        SEAL-format bytes once and build their device copies from them -- the deployment form, SURVEY 8(e)."""
+        from sunscreen_amd import GaloisKeys, PublicKey, SecretKey
 
-        o = O.Oracle(n, primes, t)
-        # rank 0 is the key owner (the oracle stands in for the client's key generator); the other ranks receive the
-        # SEAL-format bytes once and build their device copies from them -- the deployment form, SURVEY 8(e)
-        rk = sk = None
-        rkd = skd = pkd = None
+        sk = pk = rk = gk = None
+        rkd = skd = pkd = gkd = None
         if rank == 0:
-            O.seed(0xBF5 + 17)
-            sk, pk, rk, _ = o.keygen()
+            O.seed(seed)
+            sk, pk, rk, gk = o.keygen(galois_elts=galois_elts)
             rkd, skd, pkd = RelinearizationKeys.from_array(ctx, rk), SecretKey.from_array(ctx, sk), PublicKey.from_array(ctx, pk)
-        cdev = dev if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+            gkd = GaloisKeys.from_arrays(ctx, gk) if gk else None
         rkd = D.replicate_keys(ctx, rkd, RelinearizationKeys, 0, cdev)
         skd = D.replicate_keys(ctx, skd, SecretKey, 0, cdev)
         pkd = D.replicate_keys(ctx, pkd, PublicKey, 0, cdev)
+        if galois_elts:
+            gkd = D.replicate_keys(ctx, gkd, GaloisKeys, 0, cdev)
+        return sk, pk, rk, gk, rkd, skd, pkd, gkd
+
+    exchange = None
+    if args.workload == "mulrelin":
+        o = O.Oracle(n, primes, t)
+        sk, pk, rk, _, rkd, skd, pkd, _ = owner_keys(0xBF5 + 17)
         # the whole batch is genuine: slot vectors in [-128, 128] (SURVEY 8(d) config 3: products stay below t/2),
         # batch-encoded and encrypted under the public key by the library's own encryptor, resident in HBM
         va = torch.randint(-128, 129, (B, n), generator=gen, device=dev, dtype=torch.int64)
@@ -179,15 +343,10 @@ def main():
         unit_bytes = 48 * K * n  # read 2 ciphertexts, write 1 (compulsory HBM traffic per op)
         units_per_step = B
         metric, unit = "bfv_mul_relin_ops_per_sec", "ops/s"
-        workload = f"BFV ct*ct multiply+relinearize, n={n}, K={K}+1 {pset} primes, t={t}, batch={B} pairs/GPU"
+        workload = f"BFV ct*ct multiply+relinearize, n={n}, K={K}+1 {pset} primes, t={t}, batch={share} pairs"
     elif args.workload == "e2e":
-        from sunscreen_amd import PublicKey, SecretKey
-
         o = O.Oracle(n, primes, t)
-        O.seed(0xE2E + 17)
-        sk, pk, rk, _ = o.keygen()
-        rkd = RelinearizationKeys.from_array(ctx, rk)
-        skd, pkd = SecretKey.from_array(ctx, sk), PublicKey.from_array(ctx, pk)
+        sk, pk, rk, _, rkd, skd, pkd, _ = owner_keys(0xE2E + 17)
         va = torch.randint(0, 257, (B, n), generator=gen, device=dev, dtype=torch.int64)
         vb = torch.randint(0, 257, (B, n), generator=gen, device=dev, dtype=torch.int64)
         holder = {}
@@ -203,47 +362,57 @@ def main():
         units_per_step = B
         metric, unit = "bfv_encrypt_mulrelin_decrypt_per_sec", "ops/s"
         workload = (f"encode+encrypt x2 -> multiply+relinearize -> decrypt+decode on the device, n={n}, K={K}+1 SEAL default primes, "
-                    f"t={t}, batch={B} slot-vector pairs/GPU")
+                    f"t={t}, batch={share} slot-vector pairs")
     elif args.workload == "pir":
-        from sunscreen_amd import PublicKey, SecretKey
-        from sunscreen_amd.workloads import pir_lookup
+        from sunscreen_amd.workloads import pir_lookup_sharded
 
-        side = B  # sqrt(database size): --batch rows x --batch columns of plaintext entries
+        cols = args.batch
+        rows = args.pir_rows or args.batch
+        lo, hi = D.shard_range(rows, rank, world)
         o = O.Oracle(n, primes, t)
-        O.seed(0x914 + 17)
-        sk, pk, rk, _ = o.keygen()
-        rkd = RelinearizationKeys.from_array(ctx, rk)
-        skd, pkd = SecretKey.from_array(ctx, sk), PublicKey.from_array(ctx, pk)
-        vals = torch.randint(1, 1000, (side, side), generator=gen, device=dev, dtype=torch.int64)
-        db_ntt = torch.empty((side, side, K, n), dtype=torch.int64, device=dev)
-        for i in range(side):  # scalar entries (value in coefficient 0), transformed once: the server's static state
-            row = torch.zeros((side, n), dtype=torch.int64, device=dev)
-            row[:, 0] = vals[i]
-            db_ntt[i] = ev.plain_to_ntt(row)
-        sel_r, sel_c = (7 + rank) % side, (side // 3 + rank) % side
-        onehot_c = torch.zeros((side, n), dtype=torch.int64, device=dev)
-        onehot_c[sel_c, 0] = 1
-        onehot_r = torch.zeros((side, n), dtype=torch.int64, device=dev)
-        onehot_r[sel_r, 0] = 1
-        cq = ev.encrypt(onehot_c, pkd, seed=0xC0 + rank)
-        rq = ev.encrypt(onehot_r, pkd, seed=0xD0 + rank)
+        sk, pk, rk, _, rkd, skd, pkd, _ = owner_keys(0x914 + 17)
+        # the database: scalar entries (value in coefficient 0) known to every rank by (row, column); rank r holds rows
+        # [lo, hi) in transform form -- the server's static state, SURVEY 8(d) config 5a "pre-NTT'd and sharded by row"
+        cgen = torch.Generator(device="cpu")
+        cgen.manual_seed(0x914DB)
+        vals = torch.randint(1, 1000, (rows, cols), generator=cgen, dtype=torch.int64)
+        db_ntt = torch.empty((hi - lo, cols, K, n), dtype=torch.int64, device=dev)
+        row = torch.zeros((cols, n), dtype=torch.int64, device=dev)
+        for i in range(lo, hi):
+            row[:, 0] = vals[i].to(dev)
+            db_ntt[i - lo] = ev.plain_to_ntt(row)
+        del row
+        sel_r, sel_c = 7 % rows, (cols // 3) % cols
+        # the client's query (rank 0 stands in for it) reaches every shard once, before the timed region
+        cq = rq = None
+        if rank == 0:
+            onehot_c = torch.zeros((cols, n), dtype=torch.int64, device=dev)
+            onehot_c[sel_c, 0] = 1
+            onehot_r = torch.zeros((rows, n), dtype=torch.int64, device=dev)
+            onehot_r[sel_r, 0] = 1
+            cq = ev.encrypt(onehot_c, pkd, seed=0xC0)
+            rq = ev.encrypt(onehot_r, pkd, seed=0xD0)
+        cq = D.broadcast_tensor(cq, (cols, 2, K, n), torch.int64, dev, 0)
+        rq = D.broadcast_tensor(rq, (rows, 2, K, n), torch.int64, dev, 0)
+        rq_local = rq[lo:hi].contiguous()
         holder = {}
 
         def step():
-            holder["out"] = pir_lookup(ev, cq, rq, db_ntt, rkd)
+            # rows of this shard -> one partial ciphertext; one ciphertext per GPU summed on rank 0 (SURVEY 8e "Exception")
+            holder["out"] = pir_lookup_sharded(ev, cq, rq_local, db_ntt, rkd)
 
+        exchange = f"gather(dst=0) of one ciphertext per rank ({2 * K * n * 8} B) + {world - 1} additions on rank 0, inside every timed step" if world > 1 else None
         unit_bytes = 8 * K * n  # compulsory traffic per database entry: its transform-domain residues, read once
-        units_per_step = side * side
+        units_per_step = (hi - lo) * cols
+        total_items = rows * cols
         metric, unit = "pir_db_entries_per_sec", "entries/s"
-        workload = (f"examples/pir lookup: {side}x{side} plaintext database in transform form ({side * side * K * n * 8 / 2**30:.1f} GiB), "
-                    f"one encrypted query per step, n={n}, K={K}+1 SEAL default primes, t={t}")
+        workload = (f"examples/pir lookup: {rows}x{cols} plaintext database in transform form ({rows * cols * K * n * 8 / 2**30:.1f} GiB"
+                    + (f", rows sharded over {world} GPUs" if world > 1 else "") + f"), one encrypted query per step, n={n}, K={K}+1 SEAL default primes, t={t}")
     elif args.workload in ("chi_sq", "dot_prod"):
-        from sunscreen_amd import GaloisKeys
-        from sunscreen_amd.workloads import chi_sq_optimized, dot_product
         from oracle.program_interp import run_program
+        from sunscreen_amd.workloads import chi_sq_optimized, dot_product
 
         o = O.Oracle(n, primes, t)
-        O.seed(0xC415 + 17)
         if args.workload == "chi_sq":
             prog, nin, elts = chi_sq_optimized(), 3, None
             lanes = 0
@@ -251,17 +420,15 @@ def main():
             lanes = n // 2
             prog, nin = dot_product(lanes), 2
             elts = sorted({o.galois_elt_from_step(1 << i) for i in range(lanes.bit_length() - 1)} | {2 * n - 1})
-        sk, pk, rk, gk = o.keygen(galois_elts=elts)
-        rkd = RelinearizationKeys.from_array(ctx, rk)
-        gkd = GaloisKeys.from_arrays(ctx, gk) if gk else None
+        sk, pk, rk, gk, rkd, skd, pkd, gkd = owner_keys(0xC415 + 17, elts)
         ins = [uniform_residues((B, 2), K, primes) for _ in range(nin)]
-        ncheck = 0 if args.no_check else 2
-        rng = np.random.default_rng(rank)
-        vals = rng.integers(0, 7, (nin, ncheck, n)).astype(np.uint64)
-        enc = [np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vals[a]]) if ncheck else None for a in range(nin)]
-        for a in range(nin):
+        ncheck = 0 if args.no_check else min(args.check_sets, B)
+        # the first `ncheck` input sets are genuine encryptions (the library's encryptor, under the owner's public key) of small
+        # slot vectors: they decrypt to the program's value AND are compared bit for bit with the oracle's graph interpreter
+        vals = torch.randint(0, 7, (nin, max(ncheck, 1), n), generator=gen, device=dev, dtype=torch.int64)
+        for k in range(nin):
             if ncheck:
-                ins[a][:ncheck] = to_device(enc[a], dev)
+                ins[k][:ncheck] = ev.encrypt(ev.encode(vals[k, :ncheck]), pkd, seed=0xC0 + 8 * rank + k)
         outs_holder = []
 
         def step():
@@ -274,11 +441,12 @@ def main():
         nmul = sum(1 for op, _ in prog.nodes if op == "Multiply")
         nrot = sum(1 for op, _ in prog.nodes if op in ("ShiftLeft", "ShiftRight", "SwapRows"))
         workload = (f"FheProgram graph examples/{args.workload} ({len(prog.nodes)} nodes: {nmul} mul+relin, {nrot} rotations), n={n}, "
-                    f"K={K}+1 SEAL default primes, t={t}, batch={B} input sets/GPU")
+                    f"K={K}+1 SEAL default primes, t={t}, batch={share} input sets")
     else:
         nprimes = 3
         data = uniform_residues((B,), nprimes, primes[:nprimes]).reshape(B * nprimes, n).contiguous()
         ref = data.clone()
+        fwd_keep = None if args.no_check else torch.empty((min(64, B) * nprimes, n), dtype=torch.int64, device=dev)
 
         def step():
             ev.ntt(data, nprimes, inverse=False)
@@ -286,12 +454,12 @@ def main():
 
         unit_bytes = 16 * n  # one single-residue transform: read + write
         units_per_step = 2 * B * nprimes
+        total_items = total_items * 2 * nprimes
         metric, unit = "ntt_single_residue_transforms_per_sec", "NTT/s"
-        workload = f"batched forward+inverse negacyclic NTT, n={n}, {nprimes} primes ({pset}), batch={B} polys/GPU"
+        workload = f"batched forward+inverse negacyclic NTT, n={n}, {nprimes} primes ({pset}), batch={share} polys"
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -308,21 +476,21 @@ def main():
     prof = ev.profile_read()
     ev.profile(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # ---- optional result gather (only if the consumer wants every result on one device), timed apart ----
     gather_ms = None
     if args.gather and world > 1 and args.workload == "mulrelin":
-        from sunscreen_amd import dist as D
-
         barrier()
         t0 = time.perf_counter()
-        full = D.gather_results(out, B * world)
+        full = D.gather_results(out, total_items)
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - t0)
-        assert full.shape[0] == B * world and torch.equal(full[rank * B : (rank + 1) * B], out)
+        barrier()
+        if rank == 0:
+            assert full.shape[0] == total_items and torch.equal(full[:B], out)
         del full
 
     # ---- parity gate (after timing so that the timed region is exactly K steps) ----
@@ -335,51 +503,97 @@ def main():
         for i in range(K):
             ok = ok and int(out[:, :, i, :].max()) < primes[i] and int(out[:, :, i, :].min()) >= 0
         if world > 1:
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(int(flag.item()))
         assert ok, "a multiply+relinearize result does not decrypt to the slot-wise product (or is not canonical)"
         # (3) bit-exact vs the oracle on the first `ncheck` items of rank 0's shard (OpenMP over the items)
         if rank == 0:
             ha, hb, got = to_host(a[:ncheck]), to_host(b[:ncheck]), to_host(out[:ncheck])
-            _, ref = o.bench_mul_relin(ha, hb, rk, threads=min(os.cpu_count() or 1, 64))
-            assert (got == ref).all(), "HIP result differs from the CPU oracle"
-            assert (ref[0] == o.relinearize(o.multiply(ha[0], hb[0]), rk)).all()
+            _, refo = o.bench_mul_relin(ha, hb, rk, threads=min(os.cpu_count() or 1, 64))
+            assert (got == refo).all(), "HIP result differs from the CPU oracle"
+            assert (refo[0] == o.relinearize(o.multiply(ha[0], hb[0]), rk)).all()
             budget = o.noise_budget(got[0], sk)
             assert budget > 0
-        parity = f"bit-exact vs oracle on {ncheck} items; all {B * world} results decrypt to the slot-wise products; all outputs canonical"
+        parity = f"bit-exact vs oracle on {ncheck} items; all {total_items} results decrypt to the slot-wise products; all outputs canonical"
     elif args.workload == "pir" and not args.no_check:
-        got = to_host(ev.decrypt(holder["out"], skd))[0]
-        assert int(got[0]) == int(vals[sel_r, sel_c]) and not got[1:].any(), "PIR lookup returned the wrong entry"
-        assert (got == o.decrypt(to_host(holder["out"])[0], sk)).all()
-        parity = f"lookup decrypts to database[{sel_r}][{sel_c}]; decryption bit-exact vs the oracle (matrix-vector bits: tests/test_gpu_program.py)"
+        if rank == 0:
+            res = holder["out"]
+            got = to_host(ev.decrypt(res, skd))[0]
+            assert int(got[0]) == int(vals[sel_r, sel_c]) and not got[1:].any(), "PIR lookup returned the wrong entry"
+            assert (got == o.decrypt(to_host(res)[0], sk)).all()
+        parity = f"lookup decrypts to database[{sel_r}][{sel_c}]; decryption bit-exact vs the oracle"
+        # the sharded answer against the unsharded lookup, bit for bit, whenever rank 0 can hold the whole database
+        full_bytes = rows * cols * K * n * 8
+        if world > 1 and full_bytes <= (8 << 30):
+            if rank == 0:
+                from sunscreen_amd.workloads import pir_lookup
+
+                full_db = torch.empty((rows, cols, K, n), dtype=torch.int64, device=dev)
+                rowbuf = torch.zeros((cols, n), dtype=torch.int64, device=dev)
+                for i in range(rows):
+                    rowbuf[:, 0] = vals[i].to(dev)
+                    full_db[i] = ev.plain_to_ntt(rowbuf)
+                single = pir_lookup(ev, cq, rq, full_db, rkd)
+                assert torch.equal(single, holder["out"]), "row-sharded lookup differs from the single-GPU lookup"
+                del full_db
+            parity += f"; the {world}-way row-sharded answer equals the single-GPU lookup over the whole database bit for bit"
+        else:
+            parity += " (matrix-vector and program bits vs the oracle: tests/test_gpu_program.py)"
     elif args.workload == "e2e" and not args.no_check:
         assert torch.equal(holder["out"], (va * vb) % t), "decoded products differ from the slot-wise products"
-        got = to_host(holder["ct"][:2])
-        pl = to_host(ev.decrypt(holder["ct"][:2], skd))
-        for i in range(2):
-            assert (pl[i] == o.decrypt(got[i], sk)).all(), "HIP decryption differs from the CPU oracle"
+        if rank == 0:
+            got = to_host(holder["ct"][:2])
+            pl = to_host(ev.decrypt(holder["ct"][:2], skd))
+            for i in range(2):
+                assert (pl[i] == o.decrypt(got[i], sk)).all(), "HIP decryption differs from the CPU oracle"
         parity = f"all {B} decoded results equal the slot-wise products mod t; decryption bit-exact vs the oracle on 2 items"
     elif args.workload in ("chi_sq", "dot_prod") and not args.no_check:
-        for i in range(ncheck):
-            refs = run_program(o, prog.nodes, prog.edges, [e[i] for e in enc], rk, gk)
+        if rank == 0 and ncheck:
+            from concurrent.futures import ThreadPoolExecutor
+
+            hin = [to_host(ins[k][:ncheck]) for k in range(nin)]
+            hout = [to_host(outs_holder[k][:ncheck]) for k in range(nout)]
+            with ThreadPoolExecutor(min(ncheck, os.cpu_count() or 1)) as ex:  # the oracle's C calls release the GIL
+                refs = list(ex.map(lambda i: run_program(o, prog.nodes, prog.edges, [h[i] for h in hin], rk, gk), range(ncheck)))
+            for i in range(ncheck):
+                for k in range(nout):
+                    assert (hout[k][i] == refs[i][k]).all(), "HIP program result differs from the CPU oracle"
+            # ... and the genuine sets decrypt to the program's value on the slot vectors
+            v = [x[:ncheck].to(torch.int64) for x in vals]
+            if args.workload == "chi_sq":
+                x_, y_ = 2 * v[0] + v[1], 2 * v[2] + v[1]
+                expect = [(4 * v[0] * v[2] - v[1] * v[1]) ** 2, 2 * x_ * x_, x_ * y_, 2 * y_ * y_]
+            else:
+                # examples/dot_prod: every slot of the result holds the sum of the slot-wise products of its row half... the
+                # rotate-and-add ladder leaves the full dot product of BOTH rows in every slot after swap_rows + add
+                expect = [(v[0] * v[1]).sum(dim=1, keepdim=True).expand(-1, n)]
             for k in range(nout):
-                assert (to_host(outs_holder[k][i : i + 1])[0] == refs[k]).all(), "HIP program result differs from the CPU oracle"
-        parity = f"bit-exact vs the oracle graph interpreter on {ncheck} input sets x {nout} outputs"
+                dec = ev.decode(ev.decrypt(outs_holder[k][:ncheck], skd))
+                assert torch.equal(dec, expect[k] % t), "program output does not decrypt to the expected slot values"
+        parity = f"bit-exact vs the oracle graph interpreter on {ncheck} input sets x {nout} outputs; those sets decrypt to the program's slot values"
     elif args.workload == "ntt" and not args.no_check:
         assert torch.equal(data, ref), "INTT(NTT(x)) != x"
-        parity = "INTT(NTT(x)) == x on the whole batch"
+        # forward transform of the first polynomials against the oracle (SEAL NTTTables convention, pinned by the key fixture)
+        m = fwd_keep.shape[0]
+        fwd_keep.copy_(data[:m])
+        ev.ntt(fwd_keep, nprimes, inverse=False)
+        if rank == 0:
+            oo, href, hgot = O.Oracle(n, primes, t), to_host(ref[:m]), to_host(fwd_keep)
+            for i in range(m):  # polynomial i belongs to key prime i % nprimes (the layout of hipbfv_batch_ntt)
+                assert (oo.ntt(i % nprimes, href[i]) == hgot[i]).all(), "HIP forward NTT differs from the CPU oracle"
+        parity = f"INTT(NTT(x)) == x on the whole batch; NTT(x) bit-exact vs the oracle on {m} polynomials"
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+        return None
 
-    total_units = units_per_step * args.steps * world
+    total_units = total_items * args.steps  # every rank's units of every timed step
     value = total_units / elapsed
     # dominant kernel by accumulated HIP-event time
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
     roofline = None
+    valu = None
+    op_rate_gbs = unit_bytes * (value / world) / 1e9
     if dom:
         name, rec = dom
         # algorithmic bytes of one launch of that kernel
@@ -404,19 +618,25 @@ def main():
         kernel_bytes_per_launch = per_unit * rec["units"] / rec["launches"]
         kernel_rate = kernel_bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # SURVEY 8(d) ALGORITHMIC bytes: the per-unit compulsory figure x the units ONE launch of this kernel processes.
-        # A unit is one op / program run / database entry (the dominant kernel sees total_units / launches of them per
+        # A unit is one op / program run / database entry (the dominant kernel sees this rank's units / launches of them per
         # launch); for the transform workload the unit is one single-residue transform = the kernel's own work unit.
         units_per_launch = rec["units"] / rec["launches"] if args.workload == "ntt" else units_per_step * args.steps / rec["launches"]
         achieved = unit_bytes * units_per_launch / (avg_ms * 1e-3) / 1e9
         # measured HBM bytes per launch and VALU issue occupancy from the committed PMC profile of THIS workload
         # (FETCH_SIZE x2 + WRITE_SIZE, SQ_INSTS_VALU*, GRBM_GUI_ACTIVE in separate rocprofv3 --pmc passes:
-        # tools/gpu_pmc_report.sh, tools/pmc_traffic.py); PMC needs rocprofv3, so it is not re-measured live
+        # tools/gpu_pmc_report.sh, tools/pmc_traffic.py); PMC needs rocprofv3, so it is not re-measured live -- and it is
+        # only reported while the kernels are still the ones the passes ran on (source hash recorded beside the passes)
         traffic = None
-        valu = None
+        traffic_note = None
         wkey = pmc_workload_key(args, n)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"][wkey]["kernels"]
-            if name in pmc:
+            doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pmc = doc["workloads"][wkey]["kernels"]
+            taken_at = doc.get("source_hash", {}).get(wkey)
+            if taken_at != kernel_source_hash():
+                traffic_note = (f"profiles/pmc_traffic.json [{wkey}] was measured on kernel sources {taken_at}, this build is {kernel_source_hash()}: "
+                                "stale PMC figures are not reported (re-run tools/gpu_pmc_report.sh + tools/pmc_merge.sh)")
+            elif name in pmc:
                 traffic = int(pmc[name]["hbm_bytes_per_unit"] * rec["units"] / rec["launches"])
                 if "valu_issue_frac" in pmc[name]:
                     # SURVEY 8(d) asks for the VALU bound beside the HBM one: this path is FP64-issue-bound before it is
@@ -426,12 +646,16 @@ def main():
                             "wave_insts_per_launch": int(pmc[name]["valu_wave_insts_per_dispatch"]),
                             "f64_wave_insts_per_launch": int(pmc[name].get("valu_f64_wave_insts_per_dispatch", 0)),
                             "shader_cycles_per_launch": int(pmc[name]["shader_cycles_per_dispatch"]),
-                            "source": f"profiles/pmc_traffic.json [{wkey}] (rocprofv3 --pmc passes)"}
+                            "source": f"profiles/pmc_traffic.json [{wkey}] (rocprofv3 --pmc passes, kernel sources {taken_at})"}
         except Exception:
             traffic = None
         roofline = {
             "kernel": name,
             "bound": "hbm",
+            # the task contract's figure: SURVEY 8(d) bytes of the units ONE launch of the dominant kernel serves / that launch's
+            # duration.  It prices one kernel of a multi-kernel pipeline against the whole operation's compulsory bytes, so it
+            # is NOT the operation's fraction of the roof: that is `whole_op` below (compulsory bytes x ops/s / peak).
+            "scope": "dominant kernel launch",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -442,15 +666,18 @@ def main():
             "algorithmic_bytes_per_unit": unit_bytes,
             "units_per_launch": round(units_per_launch, 3),
             "algorithmic_bytes_per_launch": int(unit_bytes * units_per_launch),
+            "whole_op": {"achieved": round(op_rate_gbs, 1), "frac": round(op_rate_gbs / HBM_PEAK_GBS, 4),
+                         "definition": "algorithmic_bytes_per_unit x units/s per GPU over ALL kernels of the pipeline (SURVEY 8d: bytes_algorithmic x ops/s / 8e12)"},
             # the kernel's OWN reads and writes (pipeline intermediates included) over the same
             # launch time: what it keeps in flight, not what the operation has to move
             "kernel_hbm": {"bytes_per_launch": int(kernel_bytes_per_launch), "achieved": round(kernel_rate, 1),
                            "frac": round(kernel_rate / HBM_PEAK_GBS, 4)},
         }
-    op_rate_gbs = unit_bytes * (value / world) / 1e9
+        if traffic_note:
+            roofline["traffic_note"] = traffic_note
     cpu = None
     if not args.no_cpu and world == 1:
-        cpu = cpu_baseline(args, O, n, primes, t)
+        cpu = cpu_baseline(args, O, n, primes, t, small=secondary)
     line = {
         "metric": metric,
         "value": round(value, 2),
@@ -460,14 +687,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling_of(args),
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": workload, "batch_per_gpu": B, "poly_modulus_degree": n, "coeff_modulus_primes": KK,
-                   "plain_modulus": t, "parallelism": f"batch-sharded x{world}", "chunk_ops": args.chunk or "auto"},
+                   "plain_modulus": t, "parallelism": (f"database rows sharded x{world}, one cross-GPU sum per query" if args.workload == "pir"
+                                                       else f"batch-sharded x{world}"), "chunk_ops": args.chunk or "auto"},
         "roofline": roofline,
-        "valu": valu if dom else None,
+        "valu": valu,
         "whole_op_hbm": {"algorithmic_bytes_per_unit": unit_bytes, "achieved_GBps_per_gpu": round(op_rate_gbs, 1),
                          "frac_of_peak": round(op_rate_gbs / HBM_PEAK_GBS, 4)},
         "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
@@ -475,10 +703,48 @@ def main():
         "cpu_baseline": cpu,
         "parity": parity,
     }
+    if args.total_batch:
+        line["config"]["total_batch"] = args.total_batch
+    if exchange:
+        line["config"]["exchange"] = exchange
     if gather_ms is not None:
         line["result_gather_ms"] = round(gather_ms, 3)
-    print(json.dumps(line))
-    if world > 1:
+    return line
+
+
+def main():
+    args = parse()
+    if args.dry_run:
+        sys.exit(dry_run(args))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    env = setup(args)
+    import torch
+    import torch.distributed as dist
+
+    line = measure(args, env)
+    # BASELINE.json's metric also names n=16384 and NTTs/sec: the default (headline) run times them too, in this process
+    headline = args.workload == "mulrelin" and args.n == 8192 and not args.coeff_bits and not args.chunk
+    if headline and not args.no_secondary:
+        second = {}
+        for key, over in (("mulrelin_n16384", dict(n=16384, batch=max(args.batch // 4, 1), total_batch=args.total_batch // 4, check_items=16)),
+                          ("ntt_n8192", dict(workload="ntt"))):
+            sub = copy.copy(args)
+            for k, v in over.items():
+                setattr(sub, k, v)
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            rec = measure(sub, env, secondary=True)
+            if rec is not None:
+                second[key] = {k: rec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "config", "roofline", "valu",
+                                                   "kernels_ms_per_step", "cpu_baseline", "parity")}
+        if line is not None:
+            line["secondary"] = second
+    if line is not None:
+        print(json.dumps(line))
+    if env.world > 1:
         dist.destroy_process_group()
 
 
@@ -495,9 +761,10 @@ def ctx_S(ctx):
     return len(ctx.aux_primes)
 
 
-def cpu_baseline(args, O, n, primes, t):
+def cpu_baseline(args, O, n, primes, t, small=False):
     """The CPU oracle (a port of SEAL's algorithms, NOT SEAL itself -- SEAL's source is absent from the
-    reference tree) timed on this host on a bounded sample of the same workload."""
+    reference tree) timed on this host on a bounded sample of the same workload.  small: the secondary measurements of the
+    default run take a quarter of the sample so that the whole run stays within a minute."""
     cores = os.cpu_count() or 1
     threads = min(cores, 256)  # all host cores (SURVEY 8d); the sample scales with them so that every thread gets several items
     o = O.Oracle(n, primes, t)
@@ -506,7 +773,7 @@ def cpu_baseline(args, O, n, primes, t):
     if args.workload == "mulrelin":
         O.seed(99)
         sk, pk, rk, _ = o.keygen()
-        sample = args.cpu_sample or max(threads * (8 if n <= 8192 else 4), 64)
+        sample = args.cpu_sample or max(threads * (8 if n <= 8192 else 4) // (4 if small else 1), 64)
         sample = max(64, min(sample, (6 << 30) // (3 * 2 * K * n * 8)))  # operands + results of the sample stay below 6 GB of host memory
         a = np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)]) for _ in range(2 * sample)]).reshape(sample, 2, K, n)
         b = a[::-1].copy()
@@ -606,7 +873,7 @@ def cpu_baseline(args, O, n, primes, t):
                           f"single-thread rate {one:.3f} programs/s",
                 "single_thread_value": round(one, 3), "host_cpus": cores}
     nprimes = 3
-    sample = args.cpu_sample or threads * 256
+    sample = args.cpu_sample or threads * (64 if small else 256)
     x = np.stack([rng.integers(0, primes[i % nprimes], n, dtype=np.uint64) for i in range(sample)])
     secs1, _ = o.bench_ntt(x[: sample // threads], nprimes, threads=1)
     secs, _ = o.bench_ntt(x, nprimes, threads=threads)

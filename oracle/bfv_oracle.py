@@ -241,6 +241,35 @@ class Oracle:
         self._chk(lib().ora_relinearize(C.c_void_p(self._h), _p(ct3), _p(rk), _p(out)))
         return out
 
+    def multiply_many(self, cts, rk) -> np.ndarray:
+        """SEAL 4.0 Evaluator::multiply_many (seal_fhe/src/evaluator.rs:38-50, bfv_evaluator.rs multiply_many; algorithm
+        [RECALLED] native/src/seal/evaluator.cpp): NOT a left fold -- a work list.  First level: adjacent pairs
+        (0,1), (2,3), ... are multiplied and relinearised, an odd last element is appended as it is; then, walking the list
+        from the front, elements i and i+1 are multiplied, relinearised and APPENDED to the list until one element is
+        left past the cursor; the last element is the result.  The order decides which products share a level, i.e. the
+        noise and the bits.  (SEAL squares a pair whose operands alias; squaring gives the bits of multiply(x, x).)"""
+        cts = [self._ct(c) for c in cts]
+        if not cts:
+            raise ValueError("encrypteds vector must not be empty")
+        if len(cts) == 1:
+            return cts[0].copy()
+        work = [self.relinearize(self.multiply(cts[i], cts[i + 1]), rk) for i in range(0, len(cts) - 1, 2)]
+        if len(cts) & 1:
+            work.append(cts[-1].copy())
+        i = 0
+        while i + 1 < len(work):
+            work.append(self.relinearize(self.multiply(work[i], work[i + 1]), rk))
+            i += 2
+        return work[-1]
+
+    def exponentiate(self, ct, exponent: int, rk) -> np.ndarray:
+        """SEAL 4.0 Evaluator::exponentiate_inplace (seal_fhe/src/evaluator.rs:84-157 exponentiate; [RECALLED]): exponent 0 is
+        an error, 1 returns the input, otherwise multiply_many over `exponent` copies of the ciphertext."""
+        if exponent == 0:
+            raise ValueError("exponent cannot be 0")
+        ct = self._ct(ct)
+        return ct.copy() if exponent == 1 else self.multiply_many([ct] * exponent, rk)
+
     def _gk_ptrs(self, gk: dict[int, np.ndarray]):
         arr = (u64p * self.n)()
         keep = []

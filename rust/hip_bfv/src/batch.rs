@@ -11,12 +11,38 @@ use std::ptr::null_mut;
 use crate::{bindgen, check, BFVEvaluator, GaloisKeys, RelinearizationKeys, Result};
 
 /// A borrowed device buffer of `count` ciphertexts of `size` polynomials (memory is owned by the caller's allocator:
-/// hipMalloc, a torch tensor, ...).
+/// hipMalloc, a torch tensor, ...).  The library cannot check a device address: constructing one is the `unsafe` step, the
+/// operations on a constructed batch are safe.
 #[derive(Clone, Copy)]
 pub struct DeviceBatch {
-    pub ptr: *mut u64,
-    pub size: u64,
-    pub count: u64,
+    ptr: *mut u64,
+    size: u64,
+    count: u64,
+}
+
+impl DeviceBatch {
+    /// # Safety
+    /// `ptr` must be a device address of at least `count * size * K * N` u64 words on the evaluator's device, valid (and,
+    /// for outputs, not aliased by a concurrently running operation) until the stream work that uses it has completed.
+    pub unsafe fn new(ptr: *mut u64, size: u64, count: u64) -> Self {
+        Self { ptr, size, count }
+    }
+    pub fn ptr(&self) -> *mut u64 {
+        self.ptr
+    }
+    pub fn size(&self) -> u64 {
+        self.size
+    }
+    pub fn count(&self) -> u64 {
+        self.count
+    }
+}
+
+fn same_count(a: &DeviceBatch, b: &DeviceBatch) -> Result<()> {
+    if a.count != b.count {
+        return Err(crate::Error::InvalidArgument(format!("batches of {} and {} ciphertexts", a.count, b.count)));
+    }
+    Ok(())
 }
 
 pub struct BatchEvaluator<'e> {
@@ -34,9 +60,13 @@ impl<'e> BatchEvaluator<'e> {
     }
 
     pub fn multiply_relin(&self, a: DeviceBatch, b: DeviceBatch, rk: &RelinearizationKeys, out: DeviceBatch) -> Result<()> {
+        same_count(&a, &b)?;
+        same_count(&a, &out)?;
         check(unsafe { bindgen::hipbfv_batch_multiply_relin(self.h(), a.ptr, b.ptr, rk.get_handle(), out.ptr, a.count, self.stream) })
     }
     pub fn multiply(&self, a: DeviceBatch, b: DeviceBatch, out: DeviceBatch) -> Result<()> {
+        same_count(&a, &b)?;
+        same_count(&a, &out)?;
         check(unsafe { bindgen::hipbfv_batch_multiply(self.h(), a.ptr, a.size, b.ptr, b.size, out.ptr, a.count, self.stream) })
     }
     pub fn relinearize(&self, ct3: DeviceBatch, rk: &RelinearizationKeys, out: DeviceBatch) -> Result<()> {
@@ -49,9 +79,13 @@ impl<'e> BatchEvaluator<'e> {
         check(unsafe { bindgen::hipbfv_batch_rotate_columns(self.h(), a.ptr, gk.get_handle(), out.ptr, a.count, self.stream) })
     }
     pub fn add(&self, a: DeviceBatch, b: DeviceBatch, out: DeviceBatch) -> Result<()> {
+        same_count(&a, &b)?;
+        same_count(&a, &out)?;
         check(unsafe { bindgen::hipbfv_batch_add(self.h(), a.ptr, b.ptr, out.ptr, a.size, a.count, self.stream) })
     }
     pub fn sub(&self, a: DeviceBatch, b: DeviceBatch, out: DeviceBatch) -> Result<()> {
+        same_count(&a, &b)?;
+        same_count(&a, &out)?;
         check(unsafe { bindgen::hipbfv_batch_sub(self.h(), a.ptr, b.ptr, out.ptr, a.size, a.count, self.stream) })
     }
     pub fn negate(&self, a: DeviceBatch, out: DeviceBatch) -> Result<()> {
@@ -74,9 +108,13 @@ unsafe impl Sync for Program {}
 unsafe impl Send for Program {}
 
 pub enum Input {
+    /// `u64[batch][2][K][N]` on the device
     Ciphertexts(*const u64),
-    /// per-item plaintexts `u64[batch][N]` (stride N) or one shared `u64[N]` (stride 0)
+    /// per-item plaintexts `u64[batch][N]` (stride N) or one shared `u64[N]` (stride 0), coefficient form, on the device
     Plaintexts { ptr: *const u64, stride: u64 },
+    /// plaintexts already in transform form, `u64[batch][K][N]` (stride K*N) or shared (stride 0): the output of
+    /// `hipbfv_batch_plain_to_ntt` -- a server's static database (examples/pir) is transformed once, not per query
+    PlaintextsNtt { ptr: *const u64, stride: u64 },
 }
 
 impl Program {
@@ -89,20 +127,28 @@ impl Program {
     }
 
     /// One output buffer `u64[batch][2][K][N]` per `OutputCiphertext` node, in node order.
-    pub fn run(
+    ///
+    /// # Safety
+    /// Every pointer in `inputs` and `outputs` must be a device address of the size its kind implies for `batch` items on
+    /// the evaluator's device, valid until `stream` has drained (this call synchronises it before returning).
+    pub unsafe fn run(
         &self, eval: &BFVEvaluator, batch: u64, inputs: &[Input], rk: Option<&RelinearizationKeys>, gk: Option<&GaloisKeys>,
         outputs: &[*mut u64], stream: *mut c_void,
     ) -> Result<()> {
-        let kinds: Vec<u32> = inputs.iter().map(|i| matches!(i, Input::Plaintexts { .. }) as u32).collect();
-        let ptrs: Vec<*const u64> = inputs.iter().map(|i| match i { Input::Ciphertexts(p) => *p, Input::Plaintexts { ptr, .. } => *ptr }).collect();
-        let strides: Vec<u64> = inputs.iter().map(|i| match i { Input::Ciphertexts(_) => 0, Input::Plaintexts { stride, .. } => *stride }).collect();
-        check(unsafe {
-            bindgen::hipbfv_Program_Run(
-                self.handle, eval.get_handle(), batch, inputs.len() as u64, kinds.as_ptr(), ptrs.as_ptr(), strides.as_ptr(),
-                rk.map_or(null_mut(), |k| k.get_handle()), gk.map_or(null_mut(), |k| k.get_handle()),
-                outputs.len() as u64, outputs.as_ptr(), stream,
-            )
-        })
+        let kinds: Vec<u32> = inputs.iter().map(|i| match i { Input::Ciphertexts(_) => 0, Input::Plaintexts { .. } => 1, Input::PlaintextsNtt { .. } => 2 }).collect();
+        let ptrs: Vec<*const u64> = inputs
+            .iter()
+            .map(|i| match i { Input::Ciphertexts(p) => *p, Input::Plaintexts { ptr, .. } | Input::PlaintextsNtt { ptr, .. } => *ptr })
+            .collect();
+        let strides: Vec<u64> = inputs
+            .iter()
+            .map(|i| match i { Input::Ciphertexts(_) => 0, Input::Plaintexts { stride, .. } | Input::PlaintextsNtt { stride, .. } => *stride })
+            .collect();
+        check(bindgen::hipbfv_Program_Run(
+            self.handle, eval.get_handle(), batch, inputs.len() as u64, kinds.as_ptr(), ptrs.as_ptr(), strides.as_ptr(),
+            rk.map_or(null_mut(), |k| k.get_handle()), gk.map_or(null_mut(), |k| k.get_handle()),
+            outputs.len() as u64, outputs.as_ptr(), stream,
+        ))
     }
 }
 

@@ -42,6 +42,13 @@ impl Context {
         })?;
         Ok(Self { handle })
     }
+
+    /// (poly_modulus_degree N, data primes K, key primes K + 1, plain modulus): the sizes every raw array is checked against.
+    pub fn info(&self) -> Result<(u64, u64, u64, u64)> {
+        let (mut n, mut k, mut kk, mut t) = (0u64, 0u64, 0u64, 0u64);
+        check(unsafe { bindgen::hipbfv_Context_Info(self.handle, &mut n, &mut k, &mut kk, &mut t) })?;
+        Ok((n, k, kk, t))
+    }
 }
 
 impl Ciphertext {

@@ -444,7 +444,10 @@ void combine_execute(EvalObj* e, const std::vector<CombReq*>& batch, hipStream_t
   Evaluator& ev = *e->ev;
   CombReq& r0 = *batch[0];
   const size_t c = batch.size();
+  // Every failure path drains the stream first: kernels of this batch may already be queued on it, and the requests' owners
+  // recycle their buffers (g_buffers) the moment they see a status -- on OTHER threads' streams, which know nothing of this one.
   auto all = [&](int st) {
+    if (st != kOk) (void)hipStreamSynchronize(s);
     for (CombReq* r : batch) r->status = st;
   };
   const size_t poly = (size_t)e->ctx->K() * e->ctx->n();
@@ -464,7 +467,10 @@ void combine_execute(EvalObj* e, const std::vector<CombReq*>& batch, hipStream_t
               : r0.kind == 6 ? ev.sub_plain(r0.in0, 2, r0.in1, 0, r0.out, 1, s)
               : r0.mono_coeff ? ev.multiply_plain_mono(r0.in0, 2, r0.mono_coeff, r0.mono_exp, r0.out, 1, s)
                               : ev.multiply_plain(r0.in0, 2, r0.in1, 0, r0.out, 1, s);
-    if (r0.status) return;
+    if (r0.status) {
+      (void)hipStreamSynchronize(s);
+      return;
+    }
     const size_t out_words = (r0.kind == 0 ? 3 : 2) * poly;
     table->flags[0] = 1u;
     if (g_throw_transparent && launch_transparent_flags(r0.out, out_words, poly, table->flags, 1, s) != hipSuccess) return all(kHipError);
@@ -542,6 +548,7 @@ int combine_run(EvalObj* e, CombReq& req, hipStream_t s) {
         try {
           combine_execute(e, batch, s);
         } catch (...) {
+          (void)hipStreamSynchronize(s);  // nothing of the batch may still be in flight when its owners see the status
           for (CombReq* r : batch) r->status = kOutOfMemory;
         }
       });

@@ -28,7 +28,7 @@ class FlatCombiner {
   void run(Req& req, int max_leaders, size_t max_batch, Compatible&& compatible, Execute&& execute) {
     {
       std::lock_guard<std::mutex> g(mu_);
-      q_.push_back(&req);
+      q_.push_back(&req);  // may throw (nothing is queued then)
     }
     for (unsigned spins = 0;; spins++) {
       if (req.done.load(std::memory_order_acquire)) return;
@@ -36,8 +36,25 @@ class FlatCombiner {
         std::unique_lock<std::mutex> lk(mu_);
         if (req.done.load(std::memory_order_acquire)) return;
         if (leaders_.load(std::memory_order_relaxed) < max_leaders && !q_.empty()) {
-          leaders_.fetch_add(1, std::memory_order_relaxed);
+          // Everything that can throw happens BEFORE any state changes: once the leader slot is taken and requests are off the
+          // queue, nothing below allocates (push_back into reserved storage, deque::erase of pointers), so a batch can neither
+          // be lost nor leaders_ stay raised.  If the reservation itself fails, this caller cannot lead: it withdraws its own
+          // request when that is still queued (then nobody else holds a pointer to it) and reports; if another leader already
+          // took the request, it keeps waiting for it -- the request must not go out of scope under that leader.
           std::vector<Req*> batch;
+          try {
+            batch.reserve(q_.size() < max_batch ? q_.size() : max_batch);
+          } catch (...) {
+            for (auto it = q_.begin(); it != q_.end(); ++it) {
+              if (*it == &req) {
+                q_.erase(it);
+                throw;
+              }
+            }
+            lk.unlock();
+            continue;
+          }
+          leaders_.fetch_add(1, std::memory_order_relaxed);
           Req* head = q_.front();
           for (auto it = q_.begin(); it != q_.end() && batch.size() < max_batch;) {
             if (*it == head || compatible(*head, **it)) {

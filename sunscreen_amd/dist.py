@@ -1,12 +1,16 @@
-"""Multi-GPU plumbing: batch sharding, max-over-ranks timing and the optional result gather.
+"""Multi-GPU plumbing: batch sharding, max-over-ranks timing, the optional result gather and the one
+data-path exchange the scope has (the cross-GPU sum of examples/pir's row-sharded database).
 
 The path shards by independent ciphertexts: rank r owns a contiguous block of the batch,
 context tables and keys are replicated, and there is no collective on the data path.  The only
-collectives are barriers, a MAX all-reduce of elapsed time and (optionally) an all_gather of results.
-Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+collectives are barriers, a MAX all-reduce of elapsed time and (optionally) a gather of results to a root.
+Exception (SURVEY 8e "Exception", config 5a): a database sharded by row leaves one partial ciphertext per
+GPU; `reduce_ciphertexts` gathers them on the root (world x 2*K*N*8 bytes, point-to-point over xGMI) and adds.
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests and by the one-device validation runs.
 """
 from __future__ import annotations
 
+import datetime
 import os
 import time
 from typing import Callable
@@ -30,13 +34,33 @@ def init(backend: str | None = None) -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world, timeout=init_timeout())
     return rank, local_rank, world
 
 
-def barrier_sync() -> None:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def init_timeout() -> datetime.timedelta:
+    """Explicit rendezvous / collective timeout (HIPBFV_DIST_TIMEOUT_S, default 600 s): a rank that never arrives fails
+    the job with a message instead of leaving the others in the default 30-minute wait."""
+    return datetime.timedelta(seconds=int(os.environ.get("HIPBFV_DIST_TIMEOUT_S", "600")))
+
+
+def is_nccl() -> bool:
+    return dist.is_initialized() and dist.get_backend() == "nccl"
+
+
+def barrier() -> None:
+    """dist.barrier on the device this rank drives: under RCCL the barrier is an all-reduce on a device tensor, and
+    without `device_ids` torch guesses the device from the global rank (wrong whenever LOCAL_RANK != RANK % devices)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    if is_nccl():
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
         dist.barrier()
+
+
+def barrier_sync() -> None:
+    barrier()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
 
@@ -61,28 +85,75 @@ def timed_steps(step: Callable[[], None], steps: int, warmup: int, device: str |
     return elapsed
 
 
-def gather_results(local: torch.Tensor, total: int) -> torch.Tensor | None:
-    """Gather per-rank result blocks (shard_range order) on every rank: int64[total, ...].
-    Blocks may differ in length by one item, so they are padded to a common length for all_gather."""
+def _via(t: torch.Tensor) -> torch.Tensor:
+    """The tensor a collective is issued on: device tensors travel as they are under RCCL; gloo gets a host copy."""
+    return t if (is_nccl() or not t.is_cuda) else t.cpu()
+
+
+def gather_results(local: torch.Tensor, total: int, root: int = 0) -> torch.Tensor | None:
+    """Gather per-rank result blocks (shard_range order) on `root`: int64[total, ...] there, None elsewhere (SURVEY 8e:
+    a `gather` to the consumer's device, point-to-point over the 7 xGMI links at once -- not an all_gather, nobody else
+    needs the copy).  Blocks may differ in length by one item, so they are padded to a common length."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     longest = max(shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world))
     pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad)
+    send = _via(pad)
+    parts = [torch.empty_like(send) for _ in range(world)] if rank == root else None
+    dist.gather(send, parts, dst=root)
+    if rank != root:
+        return None
     out = []
     for r in range(world):
         lo, hi = shard_range(total, r, world)
-        out.append(parts[r][: hi - lo])
+        out.append(parts[r][: hi - lo].to(local.device))
     return torch.cat(out, dim=0)
+
+
+def reduce_ciphertexts(local: torch.Tensor, add: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], root: int = 0) -> torch.Tensor | None:
+    """Sum one ciphertext batch per rank on `root` (SURVEY 8e "Exception": examples/pir with the database sharded by row --
+    every GPU holds the partial sum over its rows, the answer is their sum).  local: int64[count, size, K, N] on every
+    rank; `add(a, b)` is the evaluator's ciphertext addition (BatchEvaluator.add on the GPU).  Gather + add rather than an
+    all-reduce: the sum is modulo a different prime per residue row, which RCCL's reductions cannot express, and only the
+    root needs it (world x 2 MiB at n = 16384, point-to-point).  Returns the sum on `root`, None elsewhere; modular
+    addition of canonical residues is associative and commutative, so the bits do not depend on the rank order."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    send = _via(local.contiguous())
+    parts = [torch.empty_like(send) for _ in range(world)] if rank == root else None
+    dist.gather(send, parts, dst=root)
+    if rank != root:
+        return None
+    acc = parts[0].to(local.device)
+    for r in range(1, world):
+        acc = add(acc, parts[r].to(local.device))
+    return acc
+
+
+def broadcast_tensor(t: torch.Tensor | None, shape, dtype, device, src: int = 0) -> torch.Tensor:
+    """One tensor from `src` to every rank (the client's query ciphertexts reaching every database shard)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        assert t is not None
+        return t
+    if dist.get_rank() != src:
+        t = torch.empty(tuple(shape), dtype=dtype, device=device)
+    buf = _via(t.contiguous())
+    # RCCL moves one message per call; keep each below 1 GiB (int32 element counts in some transports)
+    flat = buf.view(-1)
+    step = (1 << 30) // flat.element_size()
+    for o in range(0, flat.numel(), step):
+        dist.broadcast(flat[o : o + step], src=src)
+    return buf.to(device) if buf.device != torch.device(device) else buf
 
 
 def broadcast_bytes(data: bytes | None, src: int = 0, device: str | torch.device = "cpu") -> bytes:
     """One-time replication of a serialised object (keys are broadcast from their owner, 2.6 MB ... 486 MB):
     rank `src` passes the bytes, every other rank passes None; all ranks return the same bytes.  Two collectives (length,
-    payload); over RCCL the payload travels as one uint8 tensor on `device`."""
+    payload); over RCCL the payload travels as uint8 tensors on `device`, in messages of at most 256 MiB (the 486 MB Galois
+    key set of n = 16384 is two of them)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         assert data is not None
         return data
@@ -93,7 +164,9 @@ def broadcast_bytes(data: bytes | None, src: int = 0, device: str | torch.device
         buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
     else:
         buf = torch.empty((int(n.item()),), dtype=torch.uint8, device=device)
-    dist.broadcast(buf, src=src)
+    step = 256 << 20
+    for o in range(0, buf.numel(), step):
+        dist.broadcast(buf[o : o + step], src=src)
     return bytes(buf.cpu().numpy().tobytes())
 
 

@@ -81,3 +81,14 @@ def pir_lookup(ev, col_query, row_query, db_ntt, relin_keys):
         head = ev.add(prod[:half].contiguous(), prod[half : 2 * half].contiguous())
         prod = head if prod.shape[0] == 2 * half else __import__("torch").cat([head, prod[2 * half :]])
     return prod
+
+
+def pir_lookup_sharded(ev, col_query, row_query_local, db_ntt_local, relin_keys, root: int = 0):
+    """examples/pir with the database sharded by ROW over the ranks (SURVEY 8d config 5a, 8e "Exception"): this rank holds
+    rows [lo, hi) of the transform-domain database and the matching slice of the row query; `pir_lookup` over them leaves one
+    partial ciphertext per GPU, and `dist.reduce_ciphertexts` sums them on `root` (gather + add: the only data-path exchange
+    in scope).  Returns int64[1, 2, K, N] on `root`, None elsewhere.  Modular addition is exact and order-free, so the answer
+    has the bits of the unsharded lookup."""
+    from . import dist as D
+
+    return D.reduce_ciphertexts(pir_lookup(ev, col_query, row_query_local, db_ntt_local, relin_keys), ev.add, root)

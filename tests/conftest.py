@@ -9,12 +9,33 @@ if ROOT not in sys.path:
 
 
 # The library sends a FEW ciphertexts (<= 16 at N = 8192, <= 4 at N = 16384) through the whole-polynomial pipelines and larger
-# batches through the head / middle / tail pipelines (Evaluator::few_for_split_*: latency vs throughput, same bits).  The parity
-# tests use two or three ciphertexts per call: without this they would stop exercising the split kernels.  The suite therefore
-# pins the choice to "by parameters only"; the selection itself is covered by the "small_batch_selection" variant of
-# test_split_and_whole_polynomial_paths_agree, by test_concurrent_handle_calls_are_combined_without_changing_a_bit (runs with
-# the product default) and by running the whole suite with HIPBFV_NO_SMALL_BATCH=0 (tools/gpu_variant_suites.sh).
-os.environ.setdefault("HIPBFV_NO_SMALL_BATCH", "1")
+# batches through the head / middle / tail pipelines (Evaluator::few_for_split_*: latency vs throughput, same bits).  The
+# environment of the suite is the PRODUCT DEFAULT (nothing set here).  The parity tests use two or three ciphertexts per call,
+# which alone would never reach the split kernels, so every GPU test runs with the selection pinned to "by parameters only"
+# (`pipeline_selection` = "split": HIPBFV_NO_SMALL_BATCH=1, read by the library when an evaluator is created), and the
+# representative modules below run a SECOND time under the product default ("product_default": the variable unset), inside
+# the same `pytest -m gpu` run.
+BOTH_SELECTIONS = ("test_gpu_parity.py", "test_gpu_baseline_configs.py", "test_gpu_program.py")
+
+
+def _is_gpu_test(definition) -> bool:
+    return definition.get_closest_marker("gpu") is not None
+
+
+def pytest_generate_tests(metafunc):
+    if "pipeline_selection" in metafunc.fixturenames and _is_gpu_test(metafunc.definition):
+        both = os.path.basename(str(metafunc.module.__file__)) in BOTH_SELECTIONS
+        metafunc.parametrize("pipeline_selection", ["split", "product_default"] if both else ["split"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def pipeline_selection(request, monkeypatch):
+    sel = getattr(request, "param", None)
+    if sel == "split":
+        monkeypatch.setenv("HIPBFV_NO_SMALL_BATCH", "1")
+    elif sel == "product_default":
+        monkeypatch.delenv("HIPBFV_NO_SMALL_BATCH", raising=False)
+    return sel
 
 
 def pytest_configure(config):

@@ -92,3 +92,12 @@ def test_a_rank_that_dies_takes_the_self_spawned_launch_down_at_once():
     assert out.returncode != 0
     assert "no GPU for LOCAL_RANK" in out.stderr
     assert time.time() - t0 < 200
+
+
+def test_dry_run_validates_an_eight_gpu_launch_without_touching_a_device():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--workload", "pir", "--n", "16384", "--batch", "1024"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    d = json.loads(p.stdout.splitlines()[-1])
+    assert p.returncode == 0 and d["ok"] and len(d["ranks"]) == 8
+    assert d["ranks"][7]["database_rows"] == [896, 1024] and d["ranks"][0]["database_bytes"] == 128 * 1024 * 8 * 16384 * 8  # 128 GiB of the 1 TiB database

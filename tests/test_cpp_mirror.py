@@ -76,8 +76,8 @@ def test_concurrent_handle_calls_are_combined_without_changing_a_bit(tmp_path):
     concurrent calls into batched launches (capi.cpp Combiner); every thread must get the bits it gets alone, and only the
     offending call may fail.  Run with combining on (default) and off."""
     exe = _build(tmp_path, "-O1", os.path.join(ROOT, "tests", "native", "combine_check.cpp"), ["-lpthread"])
-    # HIPBFV_NO_SMALL_BATCH=0: the product default (conftest.py pins it to 1 for the parity tests)
-    for env in ({"HIPBFV_NO_SMALL_BATCH": "0"}, {"HIPBFV_NO_SMALL_BATCH": "0", "HIPBFV_NO_COMBINE": "1"}, {}):
+    # HIPBFV_NO_SMALL_BATCH=0: the product default (the `pipeline_selection` fixture of conftest.py pins it to 1 for GPU tests)
+    for env in ({"HIPBFV_NO_SMALL_BATCH": "0"}, {"HIPBFV_NO_SMALL_BATCH": "0", "HIPBFV_NO_COMBINE": "1"}, {"HIPBFV_NO_SMALL_BATCH": "1"}):
         for _ in range(3):  # which calls meet in a batch differs from run to run
             out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
             assert out.returncode == 0 and "combine ok" in out.stdout, (env, out.returncode, out.stdout, out.stderr)

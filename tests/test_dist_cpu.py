@@ -55,10 +55,32 @@ def test_two_rank_gloo_timing_and_gather(tmp_path):
             blob = bytes(range(256)) * 1000 + b"tail"
             got = D.broadcast_bytes(blob if rank == 1 else None, src=1)
             assert got == blob
-            full = D.gather_results(local, total)
-            assert full.shape == (total, 2, 3)
-            assert [int(full[i, 0, 0]) for i in range(total)] == [i * 10 for i in range(total)]
-            dist.barrier()
+            full = D.gather_results(local, total, root=1)   # gather to ONE root (SURVEY 8e), not an all_gather
+            if rank == 1:
+                assert full.shape == (total, 2, 3)
+                assert [int(full[i, 0, 0]) for i in range(total)] == [i * 10 for i in range(total)]
+            else:
+                assert full is None
+            # SURVEY 8e "Exception" (examples/pir, database sharded by row): one partial ciphertext per rank, summed on the
+            # root with the evaluator's modular addition (here: a stand-in add modulo one prime per residue row)
+            q = torch.tensor([97, 193], dtype=torch.int64).view(1, 1, 2, 1)
+            g = torch.Generator().manual_seed(7)
+            parts = [torch.randint(0, 97, (1, 2, 2, 8), generator=g, dtype=torch.int64) for _ in range(world)]
+            calls2 = []
+            def add(a, b):
+                calls2.append(1)
+                return (a + b) %% q
+            tot = D.reduce_ciphertexts(parts[rank], add, root=0)
+            if rank == 0:
+                assert torch.equal(tot, (parts[0] + parts[1]) %% q) and len(calls2) == world - 1
+            else:
+                assert tot is None and not calls2
+            # the client's query reaches every shard: one tensor from the root, in messages below 1 GiB
+            qt = torch.arange(24, dtype=torch.int64).view(2, 3, 4) if rank == 0 else None
+            got_q = D.broadcast_tensor(qt, (2, 3, 4), torch.int64, "cpu", src=0)
+            assert torch.equal(got_q, torch.arange(24, dtype=torch.int64).view(2, 3, 4))
+            D.barrier()
+            D.barrier()
             dist.destroy_process_group()
             print("rank", rank, "ok")
             """

@@ -267,8 +267,20 @@ def test_handle_level_api_mirrors_seal_fhe():
     small = Ciphertext.from_array(ctx, b_np)
     e3 = ev.exponentiate(small, 3, rkd)
     assert (dec(e3) == vb**3).all()
+    assert (e3.to_array() == o.exponentiate(b_np, 3, rk)).all()  # bits: SEAL's work-list order (oracle.multiply_many)
     mm = ev.multiply_many([b, b, b, b], rkd)
     assert (dec(mm) == vb**4).all()
+    assert (mm.to_array() == o.multiply_many([b_np] * 4, rk)).all()
+    # five distinct operands: the order matters -- ((c0 c1)(c2 c3)) c4 with c4 entering at the LAST product, not a left fold
+    five = [a_np, b_np, o.add(a_np, b_np), o.negate(b_np), o.sub(a_np, b_np)]
+    m5 = ev.multiply_many([Ciphertext.from_array(ctx, x) for x in five], rkd)
+    assert (m5.to_array() == o.multiply_many(five, rk)).all()
+    fold = five[0]
+    for x in five[1:]:
+        fold = o.relinearize(o.multiply(fold, x), rk)
+    assert not (m5.to_array() == fold).all()
+    e1 = ev.exponentiate(small, 1, rkd)
+    assert (e1.to_array() == b_np).all()
     # plaintext operands
     pb = o.batch_encode((vb % o.t).astype(np.uint64))
     p = Plaintext.from_coefficients([int(x) for x in pb])

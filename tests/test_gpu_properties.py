@@ -171,7 +171,7 @@ np.save(sys.argv[1], np.concatenate([x.cpu().numpy().ravel() for x in (r, m, g, 
     import tempfile
 
     variants = (
-        ("split", {}),
+        ("split", {"HIPBFV_NO_SMALL_BATCH": "1"}),  # every variant below inherits the pin from the `pipeline_selection` fixture too
         ("split_unfused_tail", {"HIPBFV_NO_FUSED_TAIL": "1"}),  # multiply then relinearize through a c0/c1/c2 buffer instead of mulrelin_tail
         ("split_unfused_head", {"HIPBFV_NO_FUSED_HEAD": "1"}),  # c2 through HBM between mul_tail and ks_head instead of mulrelin_head
         ("split_no_square", {"HIPBFV_NO_SQUARE": "1"}),  # x * x as a general product (four forward transforms instead of two)

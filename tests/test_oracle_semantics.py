@@ -220,3 +220,29 @@ def test_symmetric_encryption_and_no_special_prime_context():
     assert (o.decrypt(c, sk) == v).all()
     c2 = o.add(c, o.encrypt(pk, v))
     assert (o.decrypt(c2, sk) == (2 * v) % o.t).all()
+
+
+def test_multiply_many_and_exponentiate(unit):
+    """seal_fhe/src/bfv_evaluator.rs:445-480 can_multiply_many (a*b*c*d slot-wise) and can_exponentiate; plus the structure of
+    SEAL's work list: an odd last operand enters at the LAST product."""
+    o, sk, pk, rk, gk = unit
+    a = make_small_vec(o.n)
+    cts = [enc(o, pk, a) for _ in range(4)]
+    out = o.multiply_many(cts, rk)
+    assert out.shape[0] == 2
+    assert (dec(o, sk, out) == a * a * a * a).all()
+    e = o.exponentiate(cts[0], 2, rk)
+    assert (dec(o, sk, e) == a * a).all()
+    assert (e == o.relinearize(o.multiply(cts[0], cts[0]), rk)).all()
+    assert (o.exponentiate(cts[0], 1, rk) == cts[0]).all()
+    with pytest.raises(ValueError):
+        o.exponentiate(cts[0], 0, rk)
+    three = o.multiply_many(cts[:3], rk)
+    assert (three == o.relinearize(o.multiply(o.relinearize(o.multiply(cts[0], cts[1]), rk), cts[2]), rk)).all()
+    b = np.sign(a)
+    five = [enc(o, pk, b) for _ in range(5)]
+    p01 = o.relinearize(o.multiply(five[0], five[1]), rk)
+    p23 = o.relinearize(o.multiply(five[2], five[3]), rk)
+    # work list [p01, p23, c4] -> append p01*p23 -> [.., c4, p0123] -> append c4 * p0123
+    want = o.relinearize(o.multiply(five[4], o.relinearize(o.multiply(p01, p23), rk)), rk)
+    assert (o.multiply_many(five, rk) == want).all()

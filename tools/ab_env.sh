@@ -6,7 +6,7 @@ OUT=gpurun_out/ab_$VAR; mkdir -p $OUT
 for round in 1 2; do
   for arm in on off; do
     if [ $arm = off ]; then export $VAR=1; else unset $VAR; fi
-    timeout 300 python bench.py "$@" --no-cpu 2>/dev/null | tail -1 > $OUT/${arm}_$round.json
+    timeout 300 python bench.py "$@" --no-cpu --no-secondary 2>/dev/null | tail -1 > $OUT/${arm}_$round.json
     python -c "
 import json; d=json.load(open('$OUT/${arm}_$round.json')); print('$VAR', '$arm', d['value'], d['parity'][:24], d['kernels_ms_per_step'])"
   done

@@ -12,7 +12,7 @@ timeout 300 python bench.py --workload ntt --coeff-bits 54,54,54,56 --steps 10 -
 timeout 300 python tools/latency.py > $OUT/latency_n8192.json 2>$OUT/latency.err
 for w in "mulrelin_n16384 --n 16384 --batch 1024" "ntt_n8192 --workload ntt" "e2e_n8192 --workload e2e --batch 2048"; do
   set -- $w; name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace_$name -- python bench.py "$@" --steps 3 --warmup 1 --no-cpu > $OUT/trace_$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace_$name -- python bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-secondary > $OUT/trace_$name.log 2>&1
   python tools/rocprof_summary.py $OUT/trace_${name}_results.db > $OUT/${name}_kernel_stats.txt 2>/dev/null
   rm -f $OUT/*.db
 done

@@ -25,7 +25,7 @@ for f in sorted(glob.glob("$OUT/ab_*.json")):
         print(f, "unreadable", e)
 PY
 timeout 400 python bench.py --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_mulrelin_n8192.json
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu --no-secondary"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- $CMD > $OUT/trace.log 2>&1
 python tools/rocprof_summary.py $OUT/trace_results.db > $OUT/kernel_stats.txt 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT -o pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1

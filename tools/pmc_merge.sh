@@ -16,5 +16,5 @@ key = os.path.basename(sys.argv[1]).replace("_kernel_stats.txt", "")
 line = json.load(open(os.path.join(os.path.dirname(sys.argv[1]), key + "_bench.json")))
 json.dump(line["kernel_units_per_launch"], sys.stdout)
 PY
-python tools/pmc_traffic.py $KEY $S/${KEY}_pmc_fetch.txt $S/${KEY}_pmc_write.txt /tmp/units_$KEY.json $S/${KEY}_pmc_inst.txt --into profiles/pmc_traffic.json
+python tools/pmc_traffic.py $KEY $S/${KEY}_pmc_fetch.txt $S/${KEY}_pmc_write.txt /tmp/units_$KEY.json $S/${KEY}_pmc_inst.txt --source-hash $(cat $S/${KEY}_source_hash.txt) --into profiles/pmc_traffic.json
 echo merged $KEY

@@ -18,6 +18,8 @@ instructions = SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, 64-bit integer = SQ_INSTS_
 collected them; v_rndne_f64 / v_cvt are in none of those classes, so
 `valu_issue_frac` (the unclassified remainder priced at 2 cycles) is a lower bound and `valu_issue_frac_upper` prices the
 remainder at 4.  Without class counters (older passes) every instruction is priced at 4 and the entry says so.
+--source-hash H records the hash of the kernel sources the passes ran on (bench.kernel_source_hash(); bench.py prints the
+PMC-derived fields as null when the sources have changed since).
 --into merges the entry into an existing multi-workload file (and refreshes the top-level "kernels" alias of the headline
 workload mulrelin_n8192) and writes it back; otherwise the single entry is printed.
 """
@@ -103,6 +105,11 @@ def main():
         i = argv.index("--into")
         into = argv[i + 1]
         del argv[i : i + 2]
+    source_hash = None
+    if "--source-hash" in argv:  # bench.kernel_source_hash() of the tree the passes ran on (tools/gpu_pmc_report.sh records it on the GPU box)
+        i = argv.index("--source-hash")
+        source_hash = argv[i + 1]
+        del argv[i : i + 2]
     key, fetch_p, write_p, units_p = argv[:4]
     inst_p = argv[4] if len(argv) > 4 else None
     e = entry(fetch_p, write_p, json.load(open(units_p)), inst_p)
@@ -116,6 +123,8 @@ def main():
     doc.setdefault("workloads", {})
     doc["source"] = SOURCE
     doc["workloads"][key] = e
+    # bench.py reports these figures only while the kernels are the ones measured here
+    doc.setdefault("source_hash", {})[key] = source_hash
     if "mulrelin_n8192" in doc["workloads"]:
         doc["kernels"] = doc["workloads"]["mulrelin_n8192"]["kernels"]  # alias: the headline workload
     json.dump(doc, open(into, "w"), indent=1)
