@@ -63,6 +63,8 @@ def parse(argv=None):
                          "pir = examples/pir lookup over a (--pir-rows x --batch) plaintext database held in transform form, rows "
                          "sharded over the ranks, one cross-GPU sum (SURVEY 8d config 5a)")
     ap.add_argument("--pir-rows", type=int, default=0, help="pir: database rows in total (default = --batch: a square database)")
+    ap.add_argument("--pir-direct", action="store_true", help="pir: the hand-written batch primitives (workloads.pir_lookup) instead of the "
+                    "compiled `lookup` graph through hipbfv_Program_Run (the A/B arm; same bits)")
     ap.add_argument("--coeff-bits", default="", help="comma-separated prime sizes (CoeffModulus::create, last = special prime) instead of the "
                     "SEAL default set for --n, e.g. 54,54,54,56 for the 3 x 54-bit n=8192 variant BASELINE.json mentions")
     ap.add_argument("--chunk", type=int, default=0, help="override the executor's chunk size (ops per launch group)")
@@ -261,7 +263,8 @@ def kernel_source_hash() -> str:
     """sha256 over the device code and the host code that picks launch sequences and reduce masks: the PMC-derived fields of
     the bench line are only valid for the kernels they were measured on (profiles/pmc_traffic.json records this hash)."""
     d = os.path.join(ROOT, "sunscreen_amd", "csrc")
-    names = sorted(f for f in os.listdir(d) if f.endswith((".hip", ".hpp")) or f in ("context.cpp", "evaluator.cpp"))
+    device_headers = ("devctx.hpp", "devarith.hpp", "griddot.hpp", "nttshape.hpp", "nttcore.hpp", "behzcore.hpp", "kernels.hpp", "rng.hpp")
+    names = sorted(f for f in os.listdir(d) if f.endswith(".hip") or f in device_headers or f in ("context.cpp", "evaluator.cpp"))
     h = hashlib.sha256()
     for f in names:
         h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
@@ -364,7 +367,8 @@ def measure(args, env: Env, secondary: bool = False):
         workload = (f"encode+encrypt x2 -> multiply+relinearize -> decrypt+decode on the device, n={n}, K={K}+1 SEAL default primes, "
                     f"t={t}, batch={share} slot-vector pairs")
     elif args.workload == "pir":
-        from sunscreen_amd.workloads import pir_lookup_sharded
+        from sunscreen_amd.program import FheProgram, TransformedPlaintext
+        from sunscreen_amd.workloads import pir_lookup, pir_lookup_graph
 
         cols = args.batch
         rows = args.pir_rows or args.batch
@@ -396,10 +400,23 @@ def measure(args, env: Env, secondary: bool = False):
         rq = D.broadcast_tensor(rq, (rows, 2, K, n), torch.int64, dev, 0)
         rq_local = rq[lo:hi].contiguous()
         holder = {}
+        if args.pir_direct:
+            run_shard = lambda: pir_lookup(ev, cq, rq_local, db_ntt, rkd)  # noqa: E731
+            via = "hand-written batch primitives (workloads.pir_lookup)"
+        else:
+            # the reference's `lookup` fhe_program (examples/pir/src/main.rs:16-45) for this shard's rows, in the serde JSON form
+            # the compiler emits, run unchanged by the graph executor; one input set (the reference's call shape); the database
+            # entries are plaintext ARGUMENTS, handed over already transformed (the server's static state)
+            prog = FheProgram.from_json(pir_lookup_graph(hi - lo, cols).to_json())
+            pargs = ([cq[j : j + 1] for j in range(cols)] + [rq_local[i : i + 1] for i in range(hi - lo)]
+                     + [TransformedPlaintext(db_ntt[i, j]) for i in range(hi - lo) for j in range(cols)])
+            bound = prog.prepare(ev, pargs, rkd)
+            run_shard = lambda: bound()[0]  # noqa: E731
+            via = f"compiled `lookup` graph ({len(prog.nodes)} nodes) through hipbfv_Program_Run; schedule: " + "; ".join(prog.describe()[:3])
 
         def step():
             # rows of this shard -> one partial ciphertext; one ciphertext per GPU summed on rank 0 (SURVEY 8e "Exception")
-            holder["out"] = pir_lookup_sharded(ev, cq, rq_local, db_ntt, rkd)
+            holder["out"] = D.reduce_ciphertexts(run_shard(), ev.add, 0)
 
         exchange = f"gather(dst=0) of one ciphertext per rank ({2 * K * n * 8} B) + {world - 1} additions on rank 0, inside every timed step" if world > 1 else None
         unit_bytes = 8 * K * n  # compulsory traffic per database entry: its transform-domain residues, read once
@@ -407,7 +424,8 @@ def measure(args, env: Env, secondary: bool = False):
         total_items = rows * cols
         metric, unit = "pir_db_entries_per_sec", "entries/s"
         workload = (f"examples/pir lookup: {rows}x{cols} plaintext database in transform form ({rows * cols * K * n * 8 / 2**30:.1f} GiB"
-                    + (f", rows sharded over {world} GPUs" if world > 1 else "") + f"), one encrypted query per step, n={n}, K={K}+1 SEAL default primes, t={t}")
+                    + (f", rows sharded over {world} GPUs" if world > 1 else "") + f"), one encrypted query per step, n={n}, K={K}+1 SEAL default primes, t={t}; "
+                    + via)
     elif args.workload in ("chi_sq", "dot_prod"):
         from oracle.program_interp import run_program
         from sunscreen_amd.workloads import chi_sq_optimized, dot_product

@@ -353,8 +353,15 @@ long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
  * Edge kinds: 0 Left, 1 Right, 2 Unary.
  * LoadJson accepts the serde JSON form of `FheProgram` (petgraph StableGraph).
  * Run executes the graph over `batch` independent input sets: input i is a device pointer to
- * u64[batch][2][K][N] (kind 0) or to plaintexts u64[batch][N] / one shared u64[N] (kind 1, stride N / 0);
+ * u64[batch][2][K][N] (kind 0), to plaintexts u64[batch][N] / one shared u64[N] (kind 1, stride N / 0), or to plaintexts
+ * already lifted and transformed, u64[batch][K][N] / one shared u64[K][N] (kind 2, stride K*N / 0: the output of
+ * hipbfv_batch_plain_to_ntt -- static data such as examples/pir's database is transformed once, not per query; only
+ * MultiplyPlaintext nodes may consume it, and its zero check is the producer's);
  * one output buffer u64[batch][2][K][N] per OutputCiphertext node, in node order.
+ * Execution follows the reference's `traverse` (sunscreen_runtime/src/run.rs:372-472: every node whose operands are
+ * complete runs at once): ready nodes of one kind are one batched launch, Add / Sub / Negate trees are n-ary sums, sums of
+ * ciphertext-plaintext products stay in the transform domain (program_plan.cpp).  Bits are those of the node-by-node
+ * evaluation; HIPBFV_PROGRAM_SERIAL=1 selects that executor (one node at a time, kinds 0 / 1 only).
  *
  * Transparent results (SEAL built with SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT, seal_fhe/build.rs:46-66: `runtime.run` fails
  * on `a * 0`, sunscreen/tests/features.rs:8-34).  The handle-level Evaluator_* functions check their one result before
@@ -379,6 +386,9 @@ long hipbfv_Program_LoadJson(void *program, const char *json, uint64_t length);
 long hipbfv_batch_status(void *evaluator, uint64_t *first_transparent_item, void *stream);
 long hipbfv_set_batch_transparent_check(void *evaluator, bool enabled);
 long hipbfv_Program_NumOutputs(void *program, uint64_t *count);
+/* The schedule Run follows, one line per step ("mul_relin members=3 square", "sum members=2 terms=6", "plain_matrix members=256
+ * columns=256", ...): `*needed` = bytes including the terminator; `buffer` may be NULL to ask for the size. */
+long hipbfv_Program_Describe(void *program, char *buffer, uint64_t capacity, uint64_t *needed);
 long hipbfv_Program_Run(void *program, void *evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t *input_kinds,
                         const uint64_t *const *input_ptrs, const uint64_t *input_strides, void *relin_keys,
                         void *galois_keys, uint64_t num_outputs, uint64_t *const *outputs, void *stream);

@@ -2029,6 +2029,25 @@ long hipbfv_Program_NumOutputs(void* h, uint64_t* count) HIPBFV_BEGIN
   return HIPBFV_S_OK;
 HIPBFV_END
 
+long hipbfv_Program_Describe(void* h, char* buffer, uint64_t capacity, uint64_t* needed) HIPBFV_BEGIN
+  ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
+  if (!p || !needed) return HIPBFV_E_POINTER;
+  std::string text;
+  const int st = p->prog.describe(&text);
+  *needed = text.size() + 1;
+  if (buffer && capacity) {
+    const size_t c = std::min<size_t>(text.size(), capacity - 1);
+    std::memcpy(buffer, text.data(), c);
+    buffer[c] = 0;
+  }
+  if (st != kOk) {
+    const long hr = from_status(st);
+    tls_error = text;  // the schedule's own message ("error: left operand is not a ciphertext")
+    return hr;
+  }
+  return HIPBFV_S_OK;
+HIPBFV_END
+
 long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t* input_kinds,
                         const uint64_t* const* input_ptrs, const uint64_t* input_strides, void* relin_keys, void* galois_keys,
                         uint64_t num_outputs, uint64_t* const* outputs, void* stream) HIPBFV_BEGIN
@@ -2072,7 +2091,8 @@ long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_i
   }
   if (first_bad != 0xFFFFFFFFu) {
     char msg[128];
-    snprintf(msg, sizeof(msg), "result ciphertext is transparent (input set %u of the batch)", first_bad);
+    // a merged launch numbers its ciphertexts member-major (member * batch + item): the item is what the caller knows
+    snprintf(msg, sizeof(msg), "result ciphertext is transparent (input set %u of the batch)", (unsigned)(first_bad % (batch ? batch : 1)));
     return fail(HIPBFV_COR_E_INVALIDOPERATION, msg);
   }
   return HIPBFV_S_OK;

@@ -193,6 +193,7 @@ thread_local u32* tls_watch = nullptr;
 }
 WatchScope::WatchScope(u32* status_dev) : prev(tls_watch) { tls_watch = status_dev; }
 WatchScope::~WatchScope() { tls_watch = prev; }
+u32* Evaluator::watch_status() { return tls_watch; }
 
 Evaluator::~Evaluator() {
   if (status_dev_) (void)hipFree(status_dev_);

@@ -128,6 +128,7 @@ class Evaluator {
   u32* batch_status() const { return status_dev_; }
   int take_status(u32* status_dev, u32* first_bad, hipStream_t s);
   int note_result(const u64* ct, u32 size, u32 residues, size_t count, hipStream_t s);
+  static u32* watch_status();  // the status word of the calling thread's innermost WatchScope (nullptr outside one)
   bool few_for_split_mul(size_t count) const;
   bool few_for_split_ks(size_t count) const;
   bool few_for_fused(size_t count) const;
@@ -168,9 +169,19 @@ class Evaluator {
   int crt_compose(const u64* consts, u32 kc, const u64* in, u64* out, u32 polys, hipStream_t s);
   int crt_decompose(u32 kc, const u64* in, u64* out, u32 polys, hipStream_t s);
   int keygen_kswitch(const RngSeed& seed, u64 stream, const u64* sk_coeff, const u64* sk_ntt, u32 galois_elt, u64* key, hipStream_t s);
-  int plain_to_ntt(const u64* plain, size_t pstride, u64* pntt, size_t count, hipStream_t s);
+  // watch_zero: an all-zero plaintext raises the transparent-result status of the enclosing WatchScope -- 1: the plaintexts are
+  // the items of a batch (item = index), 2: they are shared by the whole batch (item 0): the graph executor's transform-domain
+  // sums never form the single product SEAL's multiply_plain would have refused
+  int plain_to_ntt(const u64* plain, size_t pstride, u64* pntt, size_t count, hipStream_t s, int watch_zero = 0);
   int ct_to_ntt(const u64* ct, u32 size, u64* ctn, size_t count, hipStream_t s);
   int dot_plain_ntt(const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* out, hipStream_t s);
+  // the graph executor's form: ctn u64[cols][batch][2][K][N] (transform domain), tab [rows][cols] device descriptors of
+  // transform-domain plaintexts, out u64[rows][batch][2][K][N] in coefficient form
+  int dot_plain_tab(const u64* ctn, u32 cols, const PlainNttRef* tab, u32 rows, u32 batch, u64* out, hipStream_t s);
+  // ct (.) plaintext given in transform form (u64[K][N] at pntt + item * pnstride): transform, product, inverse transform
+  int multiply_plain_ntt(const u64* ct, u32 size, const u64* pntt, size_t pnstride, u64* out, size_t count, hipStream_t s);
+  // the transparent-result watch of one n-ary sum launch (device descriptor table)
+  int note_nary(const NaryOut* douts, u32 nouts, u32 batch, hipStream_t s);
   int phase(const u64* ct, u32 size, const u64* sk_ntt, u64* out, size_t count, hipStream_t s);
   int encrypt(const u64* plain, size_t pstride, const u64* pk, const RngSeed& seed, u64 first_op, u64* ct2, size_t count, hipStream_t s);
 

@@ -161,7 +161,7 @@ int Evaluator::keygen_kswitch(const RngSeed& seed, u64 stream, const u64* sk_coe
 // ---- plaintext-matrix x ciphertext-vector products (the first loop nest of examples/pir/src/main.rs:16-45) ----
 // pntt[op][K][N] = NTT(centred lift of plain[op]) -- what SEAL's multiply_plain computes internally for its plaintext
 // operand (including the monomial rule, kernels.hip plain_lift_kernel).  A static database is transformed once.
-int Evaluator::plain_to_ntt(const u64* plain, size_t pstride, u64* pntt, size_t count, hipStream_t s) {
+int Evaluator::plain_to_ntt(const u64* plain, size_t pstride, u64* pntt, size_t count, hipStream_t s, int watch_zero) {
   const DevCtx& h = ctx_->host();
   if (h.logn > 15) return kUnsupported;
   const u32 n = h.n, K = h.K;
@@ -173,6 +173,7 @@ int Evaluator::plain_to_ntt(const u64* plain, size_t pstride, u64* pntt, size_t 
     const size_t c = std::min(chunk, count - off);
     u64* out = pntt + off * (size_t)K * n;
     HC_CHECK(launch_plain_lift(ctx_->dev(), n, plain + off * pstride, pstride, out, c, (u32*)nz.p, s));
+    if (watch_zero && watch_status()) HC_CHECK(launch_zero_plain_watch((const u32*)nz.p, watch_zero == 1 ? (u32)off : 0u, watch_zero == 1 ? 1u : 0u, (u32)c, watch_status(), s));
     HB_LAUNCH_CLIENT(kKernNttFwd, c * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, out, c * K, plan, false, 0, s));
   }
   return kOk;
@@ -210,6 +211,50 @@ int Evaluator::dot_plain_ntt(const u64* ctn, u32 cols, const u64* pntt, u32 rows
     HB_LAUNCH_CLIENT(kKernPlain, (size_t)c * cols, launch_dot_plain(ctx_->dev(), n, K, ctn, cols, pntt + (size_t)off * cols * K * n, c, o, s));
     HB_LAUNCH_CLIENT(kKernNttInv, (size_t)c * 2 * K, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, o, (size_t)c * 2 * K, plan, true, 0, s));
   }
+  return kOk;
+}
+
+// The graph executor's matrix-vector product (program_plan.cpp): as dot_plain_ntt with the plaintexts behind a descriptor table
+// and a batch dimension.
+int Evaluator::dot_plain_tab(const u64* ctn, u32 cols, const PlainNttRef* tab, u32 rows, u32 batch, u64* out, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (h.logn > 15) return kUnsupported;
+  if (!cols || !rows || !batch) return kInvalidArg;
+  const u32 n = h.n, K = h.K;
+  const NttPlan plan = range_plan(K);
+  HB_LAUNCH_CLIENT(kKernPlain, (size_t)rows * cols * batch, launch_dot_plain_tab(ctx_->dev(), n, K, ctn, cols, tab, rows, batch, out, s));
+  const size_t polys = (size_t)rows * batch * 2 * K, step = (65535 / K) * K;
+  for (size_t off = 0; off < polys; off += step) {
+    const size_t c = std::min(step, polys - off);
+    HB_LAUNCH_CLIENT(kKernNttInv, c, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, out + off * n, c, plan, true, 0, s));
+  }
+  return kOk;
+}
+
+int Evaluator::multiply_plain_ntt(const u64* ct, u32 size, const u64* pntt, size_t pnstride, u64* out, size_t count, hipStream_t s) {
+  const DevCtx& h = ctx_->host();
+  if (size < 2 || !pntt) return kInvalidArg;
+  if (h.logn > 15) return kUnsupported;
+  const u32 n = h.n, K = h.K;
+  if (int rc = ct_to_ntt(ct, size, out, count, s)) return rc;
+  const NttPlan plan = range_plan(K);
+  const size_t cs = ctx_->ct_words(size);
+  for (size_t off = 0; off < count; off += 65535) {
+    const size_t c = std::min<size_t>(65535, count - off);
+    HC_CHECK(launch_dyadic_plain(ctx_->dev(), n, K, out + off * cs, size, pntt + off * pnstride, pnstride, c, s));
+  }
+  const size_t polys = count * size * K, step = (65535 / K) * K;
+  for (size_t off = 0; off < polys; off += step) {
+    const size_t c = std::min(step, polys - off);
+    HB_LAUNCH_CLIENT(kKernNttInv, c, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, out + off * n, c, plan, true, 0, s));
+  }
+  return note_result(out, size, K, count, s);
+}
+
+int Evaluator::note_nary(const NaryOut* douts, u32 nouts, u32 batch, hipStream_t s) {
+  u32* status = watch_status();
+  if (!status || !nouts) return kOk;
+  HC_CHECK(launch_transparent_watch_nary(ctx_->dev(), douts, nouts, batch, status, s));
   return kOk;
 }
 

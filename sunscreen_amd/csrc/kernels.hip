@@ -14,6 +14,7 @@
 // wavefront's 64 lanes touch 512 contiguous bytes (coefficient-parallel kernels) or one
 // workgroup owns one residue polynomial (NTT kernels, staged through LDS).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -1171,6 +1172,29 @@ __global__ __launch_bounds__(kCoefThreads) void transparent_watch_kernel(const u
   if (threadIdx.x == 0) atomicMin(status, first_item + op);
 }
 
+// The graph executor's forms.  (1) the outputs of one n-ary sum launch, through its own descriptor table: workgroup (output, item).
+__global__ __launch_bounds__(kCoefThreads) void transparent_watch_nary_kernel(const DevCtx* __restrict__ ctx, const NaryOut* __restrict__ outs, u32 batch,
+                                                                              u32* __restrict__ status) {
+  const NaryOut o = outs[blockIdx.x / batch];
+  const u32 b = blockIdx.x % batch;
+  const size_t poly = (size_t)ctx->K * ctx->n;
+  const u64* p = o.out + (size_t)b * o.size * poly + poly;
+  const size_t len = (size_t)(o.size - 1) * poly;
+  for (size_t base = 0; base < len; base += kCoefThreads) {
+    const size_t i = base + threadIdx.x;
+    const bool nz = i < len && p[i] != 0;
+    if (__syncthreads_or(nz)) return;
+  }
+  if (threadIdx.x == 0) atomicMin(status, b);
+}
+// (2) a plaintext that is identically zero makes SEAL's multiply_plain fail (transparent product); a sum of products kept in
+// the transform domain never materialises the single products, so the zero plaintext itself raises the status: nonzero[op] is
+// plain_count_kernel's count of non-zero coefficients, item = first_item + op * item_step.
+__global__ void zero_plain_watch_kernel(const u32* __restrict__ nonzero, u32 first_item, u32 item_step, u32 count, u32* __restrict__ status) {
+  const u32 op = blockIdx.x * blockDim.x + threadIdx.x;
+  if (op < count && nonzero[op] == 0) atomicMin(status, first_item + op * item_step);
+}
+
 // The handle-level form of the same check: ONE ciphertext, the verdict (1 = not transparent) written straight into a word of
 // pinned host memory the device can address -- the caller only has to synchronise its stream, no memset, no copy back.
 __global__ __launch_bounds__(kCoefThreads) void transparent_flag_kernel(const u64* __restrict__ ct, size_t words, size_t skip_words,
@@ -1217,6 +1241,33 @@ __global__ __launch_bounds__(kCoefThreads) void eltwise_items_kernel(const DevCt
   r.x = mode == 0 ? add_mod(x.x, y.x, q) : sub_mod(x.x, y.x, q);
   r.y = mode == 0 ? add_mod(x.y, y.y, q) : sub_mod(x.y, y.y, q);
   *reinterpret_cast<u64x2_t*>(tout[item] + off) = r;
+}
+// ---- graph executor (program.cpp): signed n-ary sums through descriptor tables ----
+// Every maximal Add / Sub / Negate tree of a program is one output here: out = sum_t sign_t * term_t (mod q_i), exact canonical
+// arithmetic, so the bits are those of the reference's node-by-node evaluation whatever the association order
+// (sunscreen_runtime/src/run.rs:217-236,283-311).  Terms may be shorter than the output (run.rs accepts add / sub of different
+// ciphertext sizes): missing polynomials count as zero.  grid (N/2/256, max_size * K rows, outputs * batch).
+__global__ __launch_bounds__(kCoefThreads) void nary_sum_kernel(const DevCtx* __restrict__ ctx, const NaryOut* __restrict__ outs,
+                                                                const NaryTerm* __restrict__ terms, u32 batch) {
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 k = 2u * (blockIdx.x * kCoefThreads + threadIdx.x);
+  const u32 row = blockIdx.y;
+  const NaryOut o = outs[blockIdx.z / batch];
+  const u32 b = blockIdx.z % batch;
+  if (k >= n || row >= o.size * K) return;
+  const u32 poly = row / K;
+  const u64 q = ctx->mod[row % K].q;
+  u64x2_t acc;
+  acc.x = 0, acc.y = 0;
+  for (u32 t = 0; t < o.count; t++) {
+    const NaryTerm tm = terms[o.first + t];
+    if (poly >= tm.size) continue;
+    const u64x2_t x = *reinterpret_cast<const u64x2_t*>(tm.ptr + ((size_t)b * tm.size * K + row) * n + k);
+    acc.x = tm.sign > 0 ? add_mod(acc.x, x.x, q) : sub_mod(acc.x, x.x, q);
+    acc.y = tm.sign > 0 ? add_mod(acc.y, x.y, q) : sub_mod(acc.y, x.y, q);
+  }
+  *reinterpret_cast<u64x2_t*>(o.out + ((size_t)b * o.size * K + row) * n + k) = acc;
 }
 // ... and the transparent verdict of results that live in the callers' own buffers
 __global__ __launch_bounds__(kCoefThreads) void transparent_flags_items_kernel(const u64* const* __restrict__ table, size_t words_per_ct, size_t skip_words,
@@ -1374,12 +1425,34 @@ hipError_t launch_eltwise_items(const DevCtx* ctx, u32 n, u32 K, const u64* cons
   eltwise_items_kernel<<<coef_grid(n / 2, 2 * K, (u32)items), kCoefThreads, 0, s>>>(ctx, ta, tb, tout, mode);
   return hipGetLastError();
 }
+hipError_t launch_nary_sum(const DevCtx* ctx, u32 n, u32 K, const NaryOut* outs, const NaryTerm* terms, u32 nouts, u32 max_size, u32 batch, hipStream_t s) {
+  // grid z <= 65535: the outputs go in slices (the tables are indexed from the slice's first output)
+  const u32 per = std::max(1u, 65535u / batch);
+  for (u32 off = 0; off < nouts; off += per) {
+    const u32 c = std::min(per, nouts - off);
+    nary_sum_kernel<<<coef_grid(n / 2, max_size * K, c * batch), kCoefThreads, 0, s>>>(ctx, outs + off, terms, batch);
+  }
+  return hipGetLastError();
+}
 hipError_t launch_transparent_flags_items(const u64* const* table, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s) {
   transparent_flags_items_kernel<<<dim3((u32)items), kCoefThreads, 0, s>>>(table, words_per_ct, skip_words, host_flags);
   return hipGetLastError();
 }
 hipError_t launch_transparent_flags(const u64* ct, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s) {
   transparent_flags_kernel<<<dim3((u32)items), kCoefThreads, 0, s>>>(ct, words_per_ct, skip_words, host_flags);
+  return hipGetLastError();
+}
+
+hipError_t launch_transparent_watch_nary(const DevCtx* ctx, const NaryOut* outs, u32 nouts, u32 batch, u32* status, hipStream_t s) {
+  const u32 per = std::max(1u, 0x7FFFFFFFu / batch);
+  for (u32 off = 0; off < nouts; off += per) {
+    const u32 c = std::min(per, nouts - off);
+    transparent_watch_nary_kernel<<<dim3(c * batch), kCoefThreads, 0, s>>>(ctx, outs + off, batch, status);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_zero_plain_watch(const u32* nonzero, u32 first_item, u32 item_step, u32 count, u32* status, hipStream_t s) {
+  zero_plain_watch_kernel<<<dim3((count + 255) / 256), 256, 0, s>>>(nonzero, first_item, item_step, count, status);
   return hipGetLastError();
 }
 

@@ -7,6 +7,24 @@
 
 namespace hipbfv {
 
+// Descriptor tables of the graph executor's table-driven kernels (program.cpp); they live in device memory for one run.
+// One output of an n-ary signed sum: out u64[batch][size][K][N] = sum over terms[first .. first + count)
+struct NaryOut {
+  u64* out;
+  u32 first, count, size, pad;
+};
+// One term: ciphertexts u64[batch][size][K][N]; polynomials beyond `size` count as zero; sign +1 / -1
+struct NaryTerm {
+  const u64* ptr;
+  u32 size;
+  int sign;
+};
+// A plaintext in transform form: u64[K][N] at ptr + item * stride (stride 0: one plaintext for the whole batch)
+struct PlainNttRef {
+  const u64* ptr;
+  u64 stride;
+};
+
 // Which modulus a residue polynomial of a batched buffer belongs to:
 // modulus id of polynomial p = mod[(p / div) % period].
 struct NttPlan {
@@ -52,6 +70,11 @@ hipError_t launch_ct_plain(const DevCtx* ctx, const MulOp* twf, const MulOp* twi
                            const u64* in, u64* out, u32 size, size_t ops, hipStream_t s);
 hipError_t launch_dyadic_plain(const DevCtx* ctx, u32 n, u32 K, u64* x, u32 size, const u64* pl, size_t plstride, size_t ops, hipStream_t s);
 hipError_t launch_mono_mul(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t residue_polys, const u64* coeff_rns, u32 e, hipStream_t s);
+// graph executor (program.cpp): every Add / Sub / Negate tree of a scheduling round as ONE launch over descriptor tables
+hipError_t launch_nary_sum(const DevCtx* ctx, u32 n, u32 K, const NaryOut* outs, const NaryTerm* terms, u32 nouts, u32 max_size, u32 batch, hipStream_t s);
+// sum_j ct_j (.) plain[row][j] in the transform domain with the plaintexts behind a pointer table: ctn u64[cols][batch][2][K][N],
+// tab [rows][cols], acc u64[rows][batch][2][K][N] (still in transform form)
+hipError_t launch_dot_plain_tab(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const PlainNttRef* tab, u32 rows, u32 batch, u64* acc, hipStream_t s);
 // combined handle-level calls (capi.cpp): tables of device pointers / flags live in pinned, device-addressable host memory
 hipError_t launch_gather_items(const u64* const* table, u64* stage, size_t words, size_t items, hipStream_t s);
 hipError_t launch_scatter_items(const u64* stage, u64* const* table, size_t words, size_t items, hipStream_t s);
@@ -60,6 +83,8 @@ hipError_t launch_eltwise_items(const DevCtx* ctx, u32 n, u32 K, const u64* cons
 hipError_t launch_transparent_flags_items(const u64* const* table, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s);
 hipError_t launch_transparent_flags(const u64* ct, size_t words_per_ct, size_t skip_words, u32* host_flags, size_t items, hipStream_t s);
 hipError_t launch_transparent_flag(const u64* ct, size_t words, size_t skip_words, u32* host_flag, hipStream_t s);
+hipError_t launch_transparent_watch_nary(const DevCtx* ctx, const NaryOut* outs, u32 nouts, u32 batch, u32* status, hipStream_t s);
+hipError_t launch_zero_plain_watch(const u32* nonzero, u32 first_item, u32 item_step, u32 count, u32* status, hipStream_t s);
 hipError_t launch_transparent_watch(const u64* ct, size_t words_per_ct, size_t skip_words, u32 first_item, u32* status, size_t ops, hipStream_t s);
 hipError_t launch_nonzero_tail(const u64* ct, size_t words_per_ct, size_t skip_words, u32* flags, size_t ops, hipStream_t s);
 

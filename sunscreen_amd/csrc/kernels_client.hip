@@ -7,6 +7,7 @@
 // The transforms themselves are the library's NTT kernels (launch_ntt); this file holds the coefficient-parallel
 // kernels around them.  Coefficient-parallel layout as in kernels.hip: thread = coefficient, residues N apart.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "devarith.hpp"
 #include "kernels.hpp"
@@ -458,7 +459,77 @@ __global__ __launch_bounds__(kClientThreads) void dot_plain2_kernel(const DevCtx
   }
 }
 
+// The graph executor's form (program.cpp: MultiplyPlaintext -> Add chains kept in the transform domain): the plaintexts of a
+// (row, term) sit behind a descriptor table instead of one dense matrix -- program arguments are separate buffers -- and a batch
+// dimension rides on grid z.  ctn u64[cols][batch][2][K][N]; tab [rows][cols]; acc u64[rows][batch][2][K][N].  The table reads are
+// wave-uniform (scalar loads); everything else is dot_plain2_kernel.
+template <int RT>
+__global__ __launch_bounds__(kClientThreads) void dot_plain_tab_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 cols,
+                                                                       const PlainNttRef* __restrict__ tab, u32 rows, u32 batch, u64* __restrict__ acc) {
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 x = 2 * (blockIdx.x * kClientThreads + threadIdx.x);
+  const u32 i = blockIdx.y, r0 = (blockIdx.z / batch) * RT, b = blockIdx.z % batch;
+  if (x >= n) return;
+  const DevMod& dm = ctx->mod[i];
+  u128 a0[RT][2], a1[RT][2];
+#pragma unroll
+  for (int r = 0; r < RT; r++) a0[r][0] = a0[r][1] = a1[r][0] = a1[r][1] = 0;
+  const size_t in_row = (size_t)i * n + x;
+  for (u32 j = 0; j < cols; j++) {
+    const u64* cj = ctn + ((size_t)j * batch + b) * 2 * K * n + in_row;
+    const u64x2_t c0 = *reinterpret_cast<const u64x2_t*>(cj);
+    const u64x2_t c1 = *reinterpret_cast<const u64x2_t*>(cj + (size_t)K * n);
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      if (r0 + r < rows) {
+        const PlainNttRef ref = tab[(size_t)(r0 + r) * cols + j];
+        const u64x2_t* src = reinterpret_cast<const u64x2_t*>(ref.ptr + (size_t)b * ref.stride + in_row);
+#if PIR_NT
+        const u64x2_t pv = __builtin_nontemporal_load(src);
+#else
+        const u64x2_t pv = *src;
+#endif
+        a0[r][0] += (u128)c0.x * pv.x;
+        a0[r][1] += (u128)c0.y * pv.y;
+        a1[r][0] += (u128)c1.x * pv.x;
+        a1[r][1] += (u128)c1.y * pv.y;
+      }
+    }
+    if ((j & 15u) == 15u) {
+#pragma unroll
+      for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) a0[r][e] = reduce128_fast(a0[r][e], dm), a1[r][e] = reduce128_fast(a1[r][e], dm);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RT; r++) {
+    if (r0 + r < rows) {
+      u64x2_t o0, o1;
+      o0.x = reduce128_fast(a0[r][0], dm), o0.y = reduce128_fast(a0[r][1], dm);
+      o1.x = reduce128_fast(a1[r][0], dm), o1.y = reduce128_fast(a1[r][1], dm);
+      u64* dst = acc + ((size_t)(r0 + r) * batch + b) * 2 * K * n + in_row;
+      *reinterpret_cast<u64x2_t*>(dst) = o0;
+      *reinterpret_cast<u64x2_t*>(dst + (size_t)K * n) = o1;
+    }
+  }
+}
+
 // ---- launchers ----
+hipError_t launch_dot_plain_tab(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const PlainNttRef* tab, u32 rows, u32 batch, u64* acc, hipStream_t s) {
+  constexpr int RT = 4;
+  // grid z <= 65535: row blocks go in slices
+  const u32 per = std::max(1u, 65535u / batch);  // row blocks per launch
+  const u32 blocks = (rows + RT - 1) / RT;
+  for (u32 off = 0; off < blocks; off += per) {
+    const u32 c = std::min(per, blocks - off);
+    const u32 r_off = off * RT, r_cnt = std::min(rows - r_off, c * RT);
+    dot_plain_tab_kernel<RT><<<cgrid(n / 2, K, c * batch), kClientThreads, 0, s>>>(ctx, ctn, cols, tab + (size_t)r_off * cols, r_cnt, batch,
+                                                                                   acc + (size_t)r_off * batch * 2 * K * n);
+  }
+  return hipGetLastError();
+}
 hipError_t launch_keygen_ternary(const DevCtx* ctx, u32 n, const RngSeed& seed, u64 stream, u64* s_out, hipStream_t s) {
   keygen_ternary_kernel<<<cgrid(n, 1), kClientThreads, 0, s>>>(ctx, seed.secret, stream, s_out);
   return hipGetLastError();

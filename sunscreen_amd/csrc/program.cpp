@@ -189,6 +189,7 @@ bool op_from_name(const std::string& s, OpKind* k) {
 }  // namespace
 
 int Program::add_node(OpKind op, u64 arg) {
+  drop_plan();
   nodes_.push_back(Node{op, arg, -1, -1});
   return (int)nodes_.size() - 1;
 }
@@ -237,6 +238,7 @@ int Program::add_plaintext_literal(const uint8_t* bytes, size_t len, std::string
 
 int Program::add_edge(int src, int dst, EdgeKind kind) {
   if (src < 0 || dst < 0 || src >= (int)nodes_.size() || dst >= (int)nodes_.size() || src == dst) return kInvalidArg;
+  drop_plan();
   Node& d = nodes_[dst];
   if (kind == kEdgeRight) {
     if (d.right >= 0) return kInvalidArg;
@@ -262,6 +264,7 @@ int Program::load_json(const char* text, size_t len, std::string* err) {
   if (!nodes || !edges || nodes->kind != JValue::kArr || edges->kind != JValue::kArr) return fail("graph needs nodes and edges");
   const JValue* holes = g->get("node_holes");
   if (holes && holes->kind == JValue::kArr && !holes->arr.empty()) return fail("graphs with node holes are not supported");
+  drop_plan();
   nodes_.clear();
   literals_.clear();
   for (const JValue& nv : nodes->arr) {
@@ -382,6 +385,16 @@ bool Program::topo_order(std::vector<int>* order) const {
 int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
                  const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs_given, hipStream_t s,
                  std::string* err) const {
+  // read per run (not cached): the tests switch executors inside one process to compare their outputs word for word
+  const char* env = std::getenv("HIPBFV_PROGRAM_SERIAL");
+  const bool serial = env && env[0] == '1';
+  return serial ? run_serial(ev, batch, inputs, num_inputs, relin_key, galois_keys, outputs, num_outputs_given, s, err)
+                : run_plan(ev, batch, inputs, num_inputs, relin_key, galois_keys, outputs, num_outputs_given, s, err);
+}
+
+int Program::run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
+                        const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs_given, hipStream_t s,
+                        std::string* err) const {
   auto fail = [&](int code, const char* m) {
     if (err) *err = m;
     return code;
@@ -508,6 +521,7 @@ int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t
           v.ct = in.ptr;
           v.size = 2;
         } else {
+          if (in.kind == 2) return cleanup(kUnsupported, "transform-domain plaintext arguments need the scheduled executor (unset HIPBFV_PROGRAM_SERIAL)");
           if (in.kind != 1 || !in.ptr) return cleanup(kInvalidArg, "argument is not a plaintext");
           v.plain = in.ptr;
           v.pstride = in.stride;

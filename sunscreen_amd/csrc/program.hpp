@@ -3,6 +3,8 @@
 #include <cstdint>
 #include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,8 +36,10 @@ enum OpKind : int {
 enum EdgeKind : int { kEdgeLeft = 0, kEdgeRight = 1, kEdgeUnary = 2 };
 
 // One program argument for a batch: kind 0 = ciphertexts u64[batch][2][K][N], kind 1 = plaintexts
-// u64[batch][N] (stride N) or one shared plaintext (stride 0).  Ciphertext and plaintext arguments share
-// one index space, as in run.rs:160-172.
+// u64[batch][N] (stride N) or one shared plaintext (stride 0), kind 2 = plaintexts already in transform form
+// u64[batch][K][N] (stride K*N) or shared (stride 0) -- the output of hipbfv_batch_plain_to_ntt: a server's static data
+// (examples/pir's database) is lifted and transformed once, not once per query; only MultiplyPlaintext consumes it.
+// Ciphertext and plaintext arguments share one index space, as in run.rs:160-172.
 struct ProgramInput {
   int kind;
   const u64* ptr;
@@ -54,9 +58,23 @@ class Program {
   size_t num_nodes() const { return nodes_.size(); }
   size_t num_outputs() const;
   // outputs: one device buffer u64[batch][2][K][N] per OutputCiphertext node, in node-index order (run.rs:343-356)
+  // The scheduled executor (program_plan.cpp) unless HIPBFV_PROGRAM_SERIAL=1 selects the node-by-node one (program.cpp).
   int run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
           const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs, hipStream_t s,
           std::string* err) const;
+  // one node at a time in topological order on one stream (round 1 / 2's executor; kept as the A/B and cross-check arm)
+  int run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
+                 const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs, hipStream_t s,
+                 std::string* err) const;
+  // Level-scheduled execution: every node that is ready runs in the same round (run.rs:372-472 runs them concurrently on
+  // rayon); ready nodes of one kind become ONE batched launch, Add / Sub / Negate trees become n-ary sums, sums of
+  // ciphertext-plaintext products stay in the transform domain.
+  int run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
+               const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs, hipStream_t s,
+               std::string* err) const;
+  struct Plan;
+  // one line per step of the schedule: "<kind> members=<m> ..." (diagnostics; tests/test_program_plan_cpu.py reads it)
+  int describe(std::string* out) const;
 
  private:
   struct Node {
@@ -70,8 +88,12 @@ class Program {
     std::vector<u64> coeffs;
   };
   bool topo_order(std::vector<int>* order) const;
+  std::shared_ptr<const Plan> plan() const;  // built on first use, dropped whenever the graph changes
+  void drop_plan();
   std::vector<Node> nodes_;
   std::vector<PlainLiteral> literals_;
+  mutable std::mutex plan_mu_;
+  mutable std::shared_ptr<const Plan> plan_;
 };
 
 }  // namespace hipbfv

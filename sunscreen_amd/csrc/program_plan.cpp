@@ -1,0 +1,1074 @@
+// sunscreen_amd/csrc/program_plan.cpp -- the scheduled executor for compiled FHE program graphs.
+//
+// The reference runs a compiled FheProgram with `traverse` (sunscreen_runtime/src/run.rs:372-472): every node whose
+// operands are complete is spawned on the rayon pool, so all ready nodes run concurrently, each as one SEAL call on one
+// ciphertext.  On a GPU "concurrently" means "in one launch": this file turns the graph -- once per Program, cached --
+// into a PLAN of rounds, and a run walks the plan:
+//
+//   * Add / Sub / Negate trees whose inner nodes have a single user collapse into n-ary signed sums (exact canonical
+//     arithmetic: any association order gives the bits of the node-by-node evaluation, run.rs:217-236,283-311); all sums
+//     that are ready in a round are ONE table-driven launch (nary_sum_kernel).  Operands of different ciphertext sizes
+//     are accepted as run.rs accepts them.  A tree node whose terms cancel identically (x - x) is never folded into its
+//     user: it stays a result of its own, so the transparent-ciphertext failure of the reference's SEAL build
+//     (seal_fhe/build.rs:46-66, sunscreen/tests/features.rs:8-34) still happens where SEAL raises it.
+//   * a sum all of whose terms are products by plaintexts (examples/pir/src/main.rs:26-36: col[i] = sum_j db[i][j] *
+//     col_query[j]) stays in the TRANSFORM DOMAIN: every ciphertext is transformed once however many products consume
+//     it, the products are accumulated there (sum INTT(x_i) = INTT(sum x_i) exactly) and one inverse transform per sum
+//     follows; sums over the same ciphertext list (the rows of a matrix-vector product) are one launch.  Plaintext
+//     arguments may arrive already lifted and transformed (ProgramInput kind 2: a server's static database).
+//   * ready Multiply->Relinearize pairs, stand-alone relinearisations and rotations by one Galois element become ONE
+//     batched launch sequence over (members x batch) ciphertexts when the batch is small (a single input set -- the
+//     reference's own call shape -- is latency-bound: five kernels per product); operands that are not already adjacent
+//     in memory are staged by a pointer-table gather.  With a large batch every member already fills the device and
+//     runs on its own, and an Add whose other operand is complete is folded into the key switch's last kernel.
+//   * results that only feed an OutputCiphertext node are written straight into the caller's output buffer.
+//
+// The node-by-node executor of rounds 1-2 (program.cpp run_serial, HIPBFV_PROGRAM_SERIAL=1) is the cross-check arm:
+// tests/test_gpu_program.py runs every graph through both and against the oracle interpreter.
+#include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <iterator>
+#include <map>
+#include <unordered_map>
+
+#include "program.hpp"
+
+namespace hipbfv {
+
+namespace {
+
+enum StepKind : int {
+  kStepNary = 0,    // all ready Add/Sub/Negate trees of a round: one table-driven launch
+  kStepLinComb,     // sums of ciphertext x plaintext products over ONE ciphertext list, in the transform domain
+  kStepMulRelin,    // fused Multiply -> Relinearize members (all squares or none)
+  kStepMultiply,    // Multiply without a fused Relinearize (any operand sizes): one member
+  kStepRelin,       // Relinearize of a materialised ciphertext (size 3 -> 2; size 2 is a copy)
+  kStepGalois,      // rotations by one signed step count (one Galois element; NAF chain when its key is absent)
+  kStepPlainOp,     // AddPlaintext / SubPlaintext / MultiplyPlaintext outside a transform-domain sum: one member
+  kStepOutput,      // OutputCiphertext: copy unless the producer wrote the caller's buffer directly
+};
+
+struct Term {
+  int slot;
+  int sign;
+};
+
+}  // namespace
+
+struct Program::Plan {
+  struct Fold {  // an Add that can ride in this key-switching member's last kernel when the member runs unmerged
+    int nary_step = -1, nary_member = -1, other_slot = -1;
+  };
+  struct Step {
+    int kind = 0;
+    std::vector<int> node;   // member -> graph node (diagnostics, literal lookup)
+    std::vector<int> out;    // member -> output slot
+    std::vector<int> a, b;   // member -> operand slots (b: second factor; -1 when unused)
+    std::vector<Fold> fold;  // key-switching kinds: per member
+    // kStepNary
+    std::vector<u32> first;  // member -> offset into terms (size = members + 1)
+    std::vector<Term> terms;
+    // kStepLinComb: cts = the shared ciphertext list (cols); plain[member * cols + j] = plaintext NODE of term j
+    std::vector<int> cts;
+    std::vector<int> plain;
+    bool square = false;
+    int rot_steps = 0;       // kStepGalois: signed step count; swap = true for SwapRows
+    bool swap = false;
+    int plain_op = 0;        // kStepPlainOp: OpKind
+    u32 out_size = 2;
+    int out_index = -1;      // kStepOutput
+    std::vector<int> release;  // slots whose last reader is this step
+  };
+  int rc = kOk;
+  std::string err;
+  std::vector<Step> steps;
+  int nslots = 0;
+  std::vector<u32> slot_size;
+  std::vector<int> slot_input;   // slot -> program argument index (input ciphertexts), else -1
+  std::vector<int> slot_direct;  // slot -> output index when its only reader is that OutputCiphertext node, else -1
+  std::vector<int> plain_nodes;  // every InputPlaintext / LiteralPlaintext node some step reads
+  std::vector<int> literal_nodes;
+};
+
+void Program::drop_plan() {
+  std::lock_guard<std::mutex> g(plan_mu_);
+  plan_.reset();
+}
+
+std::shared_ptr<const Program::Plan> Program::plan() const {
+  std::lock_guard<std::mutex> g(plan_mu_);
+  if (plan_) return plan_;
+  auto P = std::make_shared<Plan>();
+  auto fail = [&](int rc, const char* m) {
+    P->rc = rc;
+    P->err = m;
+    plan_ = P;
+    return plan_;
+  };
+  std::string verr;
+  if (int rc = validate(&verr)) return fail(rc, verr.c_str());
+  std::vector<int> order;
+  if (!topo_order(&order)) return fail(kInvalidArg, "program graph has a cycle");
+  const int nn = (int)nodes_.size();
+
+  // ---- types, sizes, users ----
+  enum { kTyNone = 0, kTyCt, kTyPlain, kTyU64 };
+  std::vector<int> ty(nn, kTyNone);
+  std::vector<u32> size(nn, 0);
+  std::vector<int> uses(nn, 0);
+  std::vector<int> user0(nn, -1);  // one user (the only one when uses == 1)
+  for (int i = 0; i < nn; i++)
+    for (int src : {nodes_[i].left, nodes_[i].right})
+      if (src >= 0) {
+        uses[src]++;
+        user0[src] = i;
+      }
+  auto is_linear = [&](int i) { return nodes_[i].op == kOpAdd || nodes_[i].op == kOpSub || nodes_[i].op == kOpNegate; };
+  for (int id : order) {
+    const Node& nd = nodes_[id];
+    const int L = nd.left, R = nd.right;
+    switch (nd.op) {
+      case kOpInputCiphertext:
+        ty[id] = kTyCt, size[id] = 2;
+        break;
+      case kOpInputPlaintext:
+      case kOpLiteralPlaintext:
+        ty[id] = kTyPlain;
+        break;
+      case kOpLiteralU64:
+        ty[id] = kTyU64;
+        break;
+      case kOpMultiply:
+        if (ty[L] != kTyCt) return fail(kInvalidArg, "left operand is not a ciphertext");
+        if (ty[R] != kTyCt) return fail(kInvalidArg, "right operand is not a ciphertext");
+        ty[id] = kTyCt, size[id] = size[L] + size[R] - 1;
+        break;
+      case kOpAdd:
+      case kOpSub:
+        if (ty[L] != kTyCt) return fail(kInvalidArg, "left operand is not a ciphertext");
+        if (ty[R] != kTyCt) return fail(kInvalidArg, "right operand is not a ciphertext");
+        ty[id] = kTyCt, size[id] = std::max(size[L], size[R]);
+        break;
+      case kOpNegate:
+        if (ty[L] != kTyCt) return fail(kInvalidArg, "left operand is not a ciphertext");
+        ty[id] = kTyCt, size[id] = size[L];
+        break;
+      case kOpRelinearize:
+        if (ty[L] != kTyCt) return fail(kInvalidArg, "left operand is not a ciphertext");
+        if (size[L] != 2 && size[L] != 3) return fail(kInvalidArg, "operation failed");  // SEAL relinearises size 3 -> 2 only
+        ty[id] = kTyCt, size[id] = 2;
+        break;
+      case kOpAddPlaintext:
+      case kOpSubPlaintext:
+      case kOpMultiplyPlaintext:
+        if (ty[L] != kTyCt) return fail(kInvalidArg, "left operand is not a ciphertext");
+        if (ty[R] != kTyPlain) return fail(kInvalidArg, "right operand is not a plaintext");
+        ty[id] = kTyCt, size[id] = size[L];
+        break;
+      case kOpShiftLeft:
+      case kOpShiftRight:
+        if (ty[L] != kTyCt) return fail(kInvalidArg, "left operand is not a ciphertext");
+        if (nodes_[R].op != kOpLiteralU64) return fail(kInvalidArg, "shift amount must be a Literal::U64 (run.rs:177-183)");
+        if (size[L] != 2) return fail(kInvalidArg, "rotation needs a size-2 ciphertext");
+        ty[id] = kTyCt, size[id] = 2;
+        break;
+      case kOpSwapRows:
+        if (ty[L] != kTyCt) return fail(kInvalidArg, "left operand is not a ciphertext");
+        if (size[L] != 2) return fail(kInvalidArg, "rotation needs a size-2 ciphertext");
+        ty[id] = kTyCt, size[id] = 2;
+        break;
+      case kOpOutputCiphertext:
+        if (ty[L] != kTyCt || size[L] != 2) return fail(kInvalidArg, "program output must be a size-2 ciphertext");
+        break;
+      default:
+        return fail(kInvalidArg, "unsupported operation");
+    }
+    if (ty[id] == kTyCt && size[id] > 16) return fail(kInvalidArg, "operation failed");
+  }
+
+  // ---- Multiply -> Relinearize fusion: the product of two size-2 ciphertexts with the Relinearize as its only user ----
+  std::vector<char> virt(nn, 0);  // nodes that never materialise (fused products, absorbed sums, products inside transform-domain sums)
+  std::vector<int> fused_mul(nn, -1);
+  for (int i = 0; i < nn; i++)
+    if (nodes_[i].op == kOpRelinearize) {
+      const int m = nodes_[i].left;
+      if (nodes_[m].op == kOpMultiply && uses[m] == 1 && size[nodes_[m].left] == 2 && size[nodes_[m].right] == 2) fused_mul[i] = m, virt[m] = 1;
+    }
+
+  // ---- Add / Sub / Negate trees -> n-ary sums over LEAF nodes ----
+  // terms[v] exists for linear nodes that are roots (or are still waiting to be absorbed by their user)
+  struct Lin {
+    std::vector<std::pair<int, int>> t;  // (leaf node, sign)
+    long sum = 0;                        // sum of the signs
+  };
+  std::vector<Lin> lin(nn);
+  // Would SEAL have refused this node's result?  Its build throws on a TRANSPARENT ciphertext (every polynomial but the first
+  // identically zero).  For a node that materialises, the device check sees that; a node folded into its user never
+  // materialises, so the fold is only allowed when the node's "tail" -- polynomials 1.. as a formal combination of opaque
+  // values -- does not vanish identically.  Opaque values are compared by VALUE NUMBER (same operation on the same operands
+  // is the same value: x*y - x*y cancels although the two products are different nodes); AddPlaintext / SubPlaintext leave the
+  // tail of their operand unchanged (x - (x + p) is transparent without being zero).  Coincidental cancellation of random
+  // residues is not a concern (probability 2^-(bits of q) per word).
+  std::vector<int> vn(nn, -1);
+  {
+    std::map<std::array<long long, 4>, int> table;
+    for (int id : order) {
+      const Node& nd = nodes_[id];
+      long long l = nd.left >= 0 ? vn[nd.left] : -1, r = nd.right >= 0 ? vn[nd.right] : -1;
+      if ((nd.op == kOpAdd || nd.op == kOpMultiply) && l > r) std::swap(l, r);
+      const bool has_arg = nd.op == kOpInputCiphertext || nd.op == kOpInputPlaintext || nd.op == kOpLiteralU64 || nd.op == kOpLiteralPlaintext;
+      if (nd.op == kOpOutputCiphertext) {
+        vn[id] = id;
+        continue;
+      }
+      auto it = table.emplace(std::array<long long, 4>{(long long)nd.op, l, r, has_arg ? (long long)nd.arg : 0}, id);
+      vn[id] = it.first->second;
+    }
+  }
+  typedef std::unordered_map<int, long> TailMap;
+  std::unordered_map<int, TailMap> tail_memo;
+  long tail_budget = 4000000;  // map entries this analysis may create; beyond it the answer is the conservative "may cancel"
+  std::function<const TailMap*(int)> tail_of = [&](int v) -> const TailMap* {
+    v = vn[v];
+    auto it = tail_memo.find(v);
+    if (it != tail_memo.end()) return &it->second;
+    if (tail_budget <= 0) return nullptr;
+    const Node& nd = nodes_[v];
+    TailMap m;
+    if (nd.op == kOpAddPlaintext || nd.op == kOpSubPlaintext) {
+      const TailMap* a = tail_of(nd.left);
+      if (!a) return nullptr;
+      m = *a;
+    } else if (is_linear(v)) {
+      const TailMap* a = tail_of(nd.left);
+      if (!a) return nullptr;
+      const long sa = nd.op == kOpNegate ? -1 : 1;
+      for (auto& kv : *a) m[kv.first] += sa * kv.second;
+      if (nd.op != kOpNegate) {
+        const TailMap* b = tail_of(nd.right);
+        if (!b) return nullptr;
+        const long sb = nd.op == kOpSub ? -1 : 1;
+        for (auto& kv : *b) m[kv.first] += sb * kv.second;
+      }
+      for (auto i2 = m.begin(); i2 != m.end();) i2 = i2->second ? std::next(i2) : m.erase(i2);
+    } else {
+      m[v] = 1;
+    }
+    tail_budget -= (long)m.size() + 1;
+    return &tail_memo.emplace(v, std::move(m)).first->second;
+  };
+  auto opaque = [&](int v) { return !is_linear(v) && nodes_[v].op != kOpAddPlaintext && nodes_[v].op != kOpSubPlaintext; };
+  auto cancels = [&](int node, const Lin& l) {
+    // the cheap certificate first: distinct opaque values with a non-zero sign sum cannot cancel (a sum of products, a chain of Adds)
+    bool simple = l.sum != 0;
+    for (size_t i = 0; i < l.t.size() && simple; i++) simple = opaque(l.t[i].first);
+    if (simple) {
+      bool all_plus = true;
+      for (auto& p : l.t) all_plus = all_plus && p.second > 0;
+      if (all_plus) return false;
+    }
+    const TailMap* m = tail_of(node);
+    return !m || m->empty();
+  };
+  for (int id : order) {
+    if (!is_linear(id)) continue;
+    const Node& nd = nodes_[id];
+    Lin& me = lin[id];
+    auto take = [&](int src, int sign) {
+      // absorb a linear operand whose only user is this node and whose tail does not vanish identically
+      if (is_linear(src) && uses[src] == 1 && !virt[src] && !cancels(src, lin[src])) {
+        Lin& o = lin[src];
+        for (auto& p : o.t) me.t.push_back({p.first, p.second * sign});
+        me.sum += o.sum * sign;
+        std::vector<std::pair<int, int>>().swap(o.t);
+        virt[src] = 1;
+      } else {
+        me.t.push_back({src, sign});
+        me.sum += sign;
+      }
+    };
+    take(nd.left, nd.op == kOpNegate ? -1 : 1);
+    if (nd.op != kOpNegate) take(nd.right, nd.op == kOpSub ? -1 : 1);
+  }
+  // roots all of whose terms are +1 products by plaintexts of size-2 ciphertexts, each product used here only: transform-domain sums
+  std::vector<char> lincomb(nn, 0);
+  for (int id = 0; id < nn; id++) {
+    if (!is_linear(id) || virt[id]) continue;
+    const Lin& l = lin[id];
+    if (l.t.size() < 2) continue;
+    bool ok = true;
+    for (auto& p : l.t) {
+      const int leaf = p.first;
+      if (p.second != 1 || nodes_[leaf].op != kOpMultiplyPlaintext || uses[leaf] != 1 || size[leaf] != 2 || virt[leaf]) {
+        ok = false;
+        break;
+      }
+    }
+    // a product may appear once only (a repeated leaf would have uses >= 2 anyway)
+    if (ok) {
+      lincomb[id] = 1;
+      for (auto& p : l.t) virt[p.first] = 1;
+    }
+  }
+
+  // ---- value slots: one per materialised ciphertext node ----
+  std::vector<int> slot(nn, -1);
+  for (int id = 0; id < nn; id++)
+    if (ty[id] == kTyCt && !virt[id]) {
+      slot[id] = P->nslots++;
+      P->slot_size.push_back(size[id]);
+      P->slot_input.push_back(nodes_[id].op == kOpInputCiphertext ? (int)nodes_[id].arg : -1);
+    }
+  P->slot_direct.assign(P->nslots, -1);
+  {
+    int out_idx = 0;
+    for (int i = 0; i < nn; i++)
+      if (nodes_[i].op == kOpOutputCiphertext) {
+        const int src = nodes_[i].left;
+        if (uses[src] == 1 && nodes_[src].op != kOpInputCiphertext) P->slot_direct[slot[src]] = out_idx;
+        out_idx++;
+      }
+  }
+
+  // ---- macro nodes and their operand slots ----
+  // work[id] = 1 for nodes that execute as a member of some step
+  std::vector<char> work(nn, 0);
+  std::vector<std::vector<int>> deps(nn);  // operand NODES (materialised ciphertexts) a macro node waits for
+  for (int id = 0; id < nn; id++) {
+    const Node& nd = nodes_[id];
+    if (virt[id]) continue;
+    if (nd.op == kOpOutputCiphertext) {
+      work[id] = 1;
+      deps[id] = {nd.left};
+      continue;
+    }
+    if (ty[id] != kTyCt || nd.op == kOpInputCiphertext) continue;
+    work[id] = 1;
+    if (is_linear(id)) {
+      for (auto& p : lin[id].t) deps[id].push_back(lincomb[id] ? nodes_[p.first].left : p.first);
+    } else if (nd.op == kOpRelinearize && fused_mul[id] >= 0) {
+      deps[id] = {nodes_[fused_mul[id]].left, nodes_[fused_mul[id]].right};
+    } else if (nd.op == kOpMultiply || nd.op == kOpAdd || nd.op == kOpSub) {
+      deps[id] = {nd.left, nd.right};
+    } else {
+      deps[id] = {nd.left};
+    }
+  }
+  // ---- rounds ----
+  std::vector<char> done(nn, 0);
+  std::vector<int> produced_at(P->nslots, -1);  // step that wrote the slot (-1: program input)
+  for (int id = 0; id < nn; id++)
+    if (!work[id]) done[id] = 1;  // inputs, literals, virtual nodes: nothing to wait for (virtual nodes are never operands)
+  std::vector<int> pending;
+  for (int id : order)
+    if (work[id]) pending.push_back(id);
+  auto ready = [&](int id) {
+    for (int d : deps[id])
+      if (!done[d]) return false;
+    return true;
+  };
+  auto is_cheap = [&](int id) {
+    const OpKind op = nodes_[id].op;
+    return (is_linear(id) && !lincomb[id]) || op == kOpAddPlaintext || op == kOpSubPlaintext || op == kOpOutputCiphertext;
+  };
+  std::vector<int> nary_step_of(nn, -1), nary_member_of(nn, -1);
+  while (!pending.empty()) {
+    std::vector<int> rd, rest;
+    for (int id : pending) (ready(id) ? rd : rest).push_back(id);
+    if (rd.empty()) return fail(kInvalidArg, "program graph has a cycle");
+    std::vector<int> cheap, heavy;
+    for (int id : rd) (is_cheap(id) ? cheap : heavy).push_back(id);
+    std::vector<int> run_now = cheap.empty() ? heavy : cheap;
+    if (!cheap.empty()) rest.insert(rest.end(), heavy.begin(), heavy.end());  // the expensive kinds wait until every cheap node that can run has run: more of them meet in one launch
+    // keep `pending` in topological order for determinism
+    {
+      std::vector<char> in_rest(nn, 0);
+      for (int id : rest) in_rest[id] = 1;
+      std::vector<int> nxt;
+      for (int id : pending)
+        if (in_rest[id]) nxt.push_back(id);
+      pending.swap(nxt);
+    }
+    if (!cheap.empty()) {
+      Plan::Step nary;
+      nary.kind = kStepNary;
+      for (int id : run_now) {
+        const Node& nd = nodes_[id];
+        if (is_linear(id)) {
+          nary.node.push_back(id);
+          nary.out.push_back(slot[id]);
+          nary.first.push_back((u32)nary.terms.size());
+          for (auto& p : lin[id].t) nary.terms.push_back(Term{slot[p.first], p.second});
+        } else if (nd.op == kOpOutputCiphertext) {
+          continue;  // below, after the sums of this round
+        } else {
+          Plan::Step st;
+          st.kind = kStepPlainOp;
+          st.plain_op = nd.op;
+          st.node = {id};
+          st.out = {slot[id]};
+          st.a = {slot[nd.left]};
+          st.plain = {nd.right};
+          st.out_size = size[id];
+          produced_at[slot[id]] = (int)P->steps.size();
+          P->steps.push_back(std::move(st));
+        }
+      }
+      if (!nary.node.empty()) {
+        nary.first.push_back((u32)nary.terms.size());
+        const int sidx = (int)P->steps.size();
+        for (size_t m = 0; m < nary.node.size(); m++) {
+          produced_at[nary.out[m]] = sidx;
+          nary_step_of[nary.node[m]] = sidx;
+          nary_member_of[nary.node[m]] = (int)m;
+        }
+        P->steps.push_back(std::move(nary));
+      }
+      {
+        int out_idx = 0;
+        std::vector<int> out_index_of(nn, -1);
+        for (int i = 0; i < nn; i++)
+          if (nodes_[i].op == kOpOutputCiphertext) out_index_of[i] = out_idx++;
+        for (int id : run_now)
+          if (nodes_[id].op == kOpOutputCiphertext) {
+            Plan::Step st;
+            st.kind = kStepOutput;
+            st.node = {id};
+            st.a = {slot[nodes_[id].left]};
+            st.out_index = out_index_of[id];
+            P->steps.push_back(std::move(st));
+          }
+      }
+      for (int id : run_now) done[id] = 1;
+      continue;
+    }
+    // ---- the expensive kinds: group the ready members ----
+    std::vector<Plan::Step> groups;
+    auto group_for = [&](auto&& match, auto&& init) -> Plan::Step& {
+      for (auto& g : groups)
+        if (match(g)) return g;
+      groups.emplace_back();
+      init(groups.back());
+      return groups.back();
+    };
+    for (int id : run_now) {
+      const Node& nd = nodes_[id];
+      if (lincomb[id]) {
+        std::vector<int> cts;
+        for (auto& p : lin[id].t) cts.push_back(slot[nodes_[p.first].left]);
+        Plan::Step& g = group_for([&](const Plan::Step& s) { return s.kind == kStepLinComb && s.cts == cts; },
+                                  [&](Plan::Step& s) {
+                                    s.kind = kStepLinComb;
+                                    s.cts = cts;
+                                  });
+        g.node.push_back(id);
+        g.out.push_back(slot[id]);
+        for (auto& p : lin[id].t) g.plain.push_back(nodes_[p.first].right);
+      } else if (nd.op == kOpRelinearize && fused_mul[id] >= 0) {
+        const Node& mn = nodes_[fused_mul[id]];
+        const bool sq = mn.left == mn.right;
+        Plan::Step& g = group_for([&](const Plan::Step& s) { return s.kind == kStepMulRelin && s.square == sq; },
+                                  [&](Plan::Step& s) {
+                                    s.kind = kStepMulRelin;
+                                    s.square = sq;
+                                  });
+        g.node.push_back(id);
+        g.out.push_back(slot[id]);
+        g.a.push_back(slot[mn.left]);
+        g.b.push_back(slot[mn.right]);
+      } else if (nd.op == kOpRelinearize) {
+        const u32 in_size = size[nd.left];
+        Plan::Step& g = group_for([&](const Plan::Step& s) { return s.kind == kStepRelin && s.out_size == in_size; },
+                                  [&](Plan::Step& s) {
+                                    s.kind = kStepRelin;
+                                    s.out_size = in_size;  // the INPUT size of a relinearisation group (its result is always 2)
+                                  });
+        g.node.push_back(id);
+        g.out.push_back(slot[id]);
+        g.a.push_back(slot[nd.left]);
+        g.b.push_back(-1);
+      } else if (nd.op == kOpShiftLeft || nd.op == kOpShiftRight || nd.op == kOpSwapRows) {
+        const bool swap = nd.op == kOpSwapRows;
+        const int k = swap ? 0 : (int)nodes_[nd.right].arg;
+        const int steps = nd.op == kOpShiftLeft ? k : -k;
+        Plan::Step& g = group_for([&](const Plan::Step& s) { return s.kind == kStepGalois && s.swap == swap && s.rot_steps == steps; },
+                                  [&](Plan::Step& s) {
+                                    s.kind = kStepGalois;
+                                    s.swap = swap;
+                                    s.rot_steps = steps;
+                                  });
+        g.node.push_back(id);
+        g.out.push_back(slot[id]);
+        g.a.push_back(slot[nd.left]);
+        g.b.push_back(-1);
+      } else if (nd.op == kOpMultiply) {
+        groups.emplace_back();
+        Plan::Step& g = groups.back();
+        g.kind = kStepMultiply;
+        g.node = {id};
+        g.out = {slot[id]};
+        g.a = {slot[nd.left]};
+        g.b = {slot[nd.right]};
+        g.out_size = size[id];
+      } else if (nd.op == kOpMultiplyPlaintext) {
+        groups.emplace_back();
+        Plan::Step& g = groups.back();
+        g.kind = kStepPlainOp;
+        g.plain_op = nd.op;
+        g.node = {id};
+        g.out = {slot[id]};
+        g.a = {slot[nd.left]};
+        g.plain = {nd.right};
+        g.out_size = size[id];
+      } else {
+        return fail(kInvalidArg, "unsupported operation");
+      }
+    }
+    for (auto& g : groups) {
+      const int sidx = (int)P->steps.size();
+      if (g.kind == kStepMulRelin || g.kind == kStepRelin || g.kind == kStepGalois) {
+        g.fold.resize(g.node.size());
+        // an Add (a two-term sum, both +1, size 2) of this member's result -- its only user -- and a ciphertext that is
+        // already complete: the member's last kernel can add it when the member runs on its own
+        for (size_t m = 0; m < g.node.size(); m++) {
+          const int id = g.node[m];
+          if (g.kind == kStepRelin && g.out_size != 3) continue;
+          if (uses[id] != 1) continue;
+          const int u = user0[id];
+          if (!is_linear(u) || virt[u] || lincomb[u]) continue;
+          const Lin& l = lin[u];
+          if (l.t.size() != 2 || l.t[0].second != 1 || l.t[1].second != 1 || size[u] != 2) continue;
+          const int other = l.t[0].first == id ? l.t[1].first : l.t[0].first;
+          if (other == id || size[other] != 2 || !done[other]) continue;
+          g.fold[m].other_slot = slot[other];
+          g.fold[m].nary_member = u;  // node id for now; resolved to (step, member) after the sum is scheduled
+        }
+      }
+      for (size_t m = 0; m < g.out.size(); m++) produced_at[g.out[m]] = sidx;
+      P->steps.push_back(std::move(g));
+    }
+    for (int id : run_now) done[id] = 1;
+  }
+  // resolve the folds: the sum node -> its (step, member)
+  for (auto& st : P->steps)
+    for (auto& f : st.fold)
+      if (f.other_slot >= 0) {
+        const int u = f.nary_member;
+        f.nary_step = nary_step_of[u];
+        f.nary_member = nary_member_of[u];
+        if (f.nary_step < 0) f = Plan::Fold();
+      }
+
+  // ---- release lists: the last step that reads each slot ----
+  std::vector<int> last_read(P->nslots, -1);
+  for (int si = 0; si < (int)P->steps.size(); si++) {
+    const Plan::Step& st = P->steps[si];
+    auto rd = [&](int sl) {
+      if (sl >= 0) last_read[sl] = si;
+    };
+    for (int sl : st.a) rd(sl);
+    for (int sl : st.b) rd(sl);
+    for (int sl : st.cts) rd(sl);
+    for (auto& t : st.terms) rd(t.slot);
+  }
+  for (int sl = 0; sl < P->nslots; sl++) {
+    if (P->slot_input[sl] >= 0) continue;
+    const int at = last_read[sl] >= 0 ? last_read[sl] : produced_at[sl];  // a value nobody reads dies where it was made
+    if (at >= 0) P->steps[at].release.push_back(sl);
+  }
+  for (int id = 0; id < nn; id++)
+    if (nodes_[id].op == kOpLiteralPlaintext) P->literal_nodes.push_back(id);
+  plan_ = P;
+  return plan_;
+}
+
+int Program::describe(std::string* out) const {
+  std::shared_ptr<const Plan> Pp = plan();
+  const Plan& P = *Pp;
+  if (P.rc) {
+    *out = "error: " + P.err;
+    return P.rc;
+  }
+  static const char* names[] = {"sum", "plain_matrix", "mul_relin", "multiply", "relinearize", "rotate", "plain_op", "output"};
+  std::string t;
+  for (const Plan::Step& st : P.steps) {
+    t += names[st.kind];
+    t += " members=" + std::to_string(st.node.size());
+    if (st.kind == kStepNary) t += " terms=" + std::to_string(st.terms.size());
+    if (st.kind == kStepLinComb) t += " columns=" + std::to_string(st.cts.size());
+    if (st.kind == kStepMulRelin && st.square) t += " square";
+    if (st.kind == kStepGalois) t += st.swap ? " swap_rows" : " steps=" + std::to_string(st.rot_steps);
+    size_t folds = 0;
+    for (auto& f : st.fold) folds += f.other_slot >= 0;
+    if (folds) t += " add_foldable=" + std::to_string(folds);
+    size_t direct = 0;
+    for (int sl : st.out) direct += sl >= 0 && P.slot_direct[sl] >= 0;
+    if (direct && st.kind != kStepOutput) t += " direct_outputs=" + std::to_string(direct);
+    t += "\n";
+  }
+  *out = t;
+  return kOk;
+}
+
+// =====================================================================================
+// one run of a plan
+// =====================================================================================
+namespace {
+
+// pinned, device-addressable staging for the descriptor tables of one run (one buffer per host thread, grown on demand)
+struct TableArena {
+  unsigned char* host = nullptr;
+  size_t cap = 0, used = 0;
+  bool reserve(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (host) (void)hipHostFree(host);
+    host = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(bytes, 1 << 20);
+    if (hipHostMalloc((void**)&host, want, hipHostMallocPortable) != hipSuccess) {
+      host = nullptr;
+      (void)hipGetLastError();
+      return false;
+    }
+    cap = want;
+    return true;
+  }
+};
+
+size_t merge_max_batch() {
+  static const size_t v = [] {
+    const char* env = std::getenv("HIPBFV_PROGRAM_MERGE_MAX_BATCH");
+    return env ? (size_t)std::strtoull(env, nullptr, 10) : (size_t)32;
+  }();
+  return v;
+}
+
+}  // namespace
+
+int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
+                      const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs_given, hipStream_t s,
+                      std::string* err) const {
+  auto fail = [&](int code, const char* m) {
+    if (err) *err = m;
+    return code;
+  };
+  std::shared_ptr<const Plan> Pp = plan();
+  const Plan& P = *Pp;
+  if (P.rc) return fail(P.rc, P.err.c_str());
+  if (num_outputs_given != num_outputs()) return fail(kInvalidArg, "wrong number of output buffers");
+  if (!batch) return fail(kInvalidArg, "empty batch");
+  Context* ctx = ev.ctx();
+  const DevCtx& h = ctx->host();
+  const size_t n = ctx->n(), K = ctx->K();
+  const size_t poly = K * n;
+  ScratchPool& pool = ev.scratch();
+
+  // ---- slot storage: blocks with reference counts (members of a merged launch share one block; a folded Add shares its producer's) ----
+  struct Block {
+    void* ptr;
+    int refs;
+    bool owned;
+  };
+  std::vector<Block> blocks;
+  std::vector<const u64*> sp(P.nslots, nullptr);
+  std::vector<int> block_of(P.nslots, -1);
+  std::vector<char> direct_written(num_outputs_given, 0);
+  std::vector<void*> temps;  // staging buffers released when the run ends (stream-ordered)
+  auto cleanup = [&](int code, const char* m) {
+    for (Block& b : blocks)
+      if (b.owned && b.refs > 0) pool.release(b.ptr, s);
+    for (void* t : temps) pool.release(t, s);
+    (void)hipStreamSynchronize(s);  // descriptor tables of this run live in this thread's arena
+    return fail(code, m);
+  };
+  auto new_block = [&](size_t words) -> int {
+    void* p = pool.acquire(words * sizeof(u64), s);
+    if (!p) return -1;
+    blocks.push_back(Block{p, 0, true});
+    return (int)blocks.size() - 1;
+  };
+  auto bind = [&](int slot, int blk, const u64* ptr) {
+    sp[slot] = ptr;
+    block_of[slot] = blk;
+    if (blk >= 0) blocks[blk].refs++;
+  };
+  auto unbind = [&](int slot) {
+    const int blk = block_of[slot];
+    if (blk < 0) return;
+    block_of[slot] = -1;
+    if (--blocks[blk].refs == 0 && blocks[blk].owned) pool.release(blocks[blk].ptr, s);
+  };
+  auto slot_words = [&](int slot) { return batch * (size_t)P.slot_size[slot] * poly; };
+  // a member's own output buffer: the caller's output buffer when the value only feeds an OutputCiphertext node
+  auto alloc_member = [&](int slot) -> u64* {
+    const int d = P.slot_direct[slot];
+    if (d >= 0) {
+      direct_written[d] = 1;
+      blocks.push_back(Block{outputs[d], 0, false});
+      bind(slot, (int)blocks.size() - 1, outputs[d]);
+      return outputs[d];
+    }
+    const int blk = new_block(slot_words(slot));
+    if (blk < 0) return nullptr;
+    bind(slot, blk, (const u64*)blocks[blk].ptr);
+    return (u64*)blocks[blk].ptr;
+  };
+
+  // ---- program arguments ----
+  for (int sl = 0; sl < P.nslots; sl++) {
+    const int arg = P.slot_input[sl];
+    if (arg < 0) continue;
+    if ((size_t)arg >= num_inputs) return fail(kInvalidArg, "input index out of range");
+    if (inputs[arg].kind != 0 || !inputs[arg].ptr) return fail(kInvalidArg, "argument is not a ciphertext");
+    sp[sl] = inputs[arg].ptr;
+  }
+  // plaintext operands: program arguments as they are, literals uploaded once per run
+  struct PlainVal {
+    const u64* ptr = nullptr;
+    size_t stride = 0;
+    int kind = 1;
+  };
+  std::unordered_map<int, PlainVal> literal_val;
+  if (!P.literal_nodes.empty()) {
+    const std::vector<u64>& kp = ctx->key_primes();
+    u64* dev = (u64*)pool.acquire(P.literal_nodes.size() * n * sizeof(u64), s);
+    if (!dev) return fail(kOutOfMemory, "scratch allocation failed");
+    temps.push_back(dev);
+    std::vector<u64> host(P.literal_nodes.size() * n, 0);
+    for (size_t i = 0; i < P.literal_nodes.size(); i++) {
+      const PlainLiteral& lit = literals_[nodes_[P.literal_nodes[i]].arg];
+      if (lit.n != n || lit.t != h.t || lit.primes.size() != kp.size() || !std::equal(kp.begin(), kp.end(), lit.primes.begin()))
+        return cleanup(kInvalidArg, "plaintext literal was built for different encryption parameters");
+      std::copy(lit.coeffs.begin(), lit.coeffs.end(), host.begin() + i * n);
+      literal_val[P.literal_nodes[i]] = PlainVal{dev + i * n, 0, 1};
+    }
+    // ordered after earlier users of the recycled buffer on this stream; drained so `host` may go out of scope
+    if (hipMemcpyAsync(dev, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return cleanup(kHipError, "copy failed");
+  }
+  auto plain_of = [&](int node, PlainVal* out) -> const char* {
+    const Node& nd = nodes_[node];
+    if (nd.op == kOpLiteralPlaintext) {
+      *out = literal_val[node];
+      return nullptr;
+    }
+    if (nd.arg >= num_inputs) return "input index out of range";
+    const ProgramInput& in = inputs[nd.arg];
+    if ((in.kind != 1 && in.kind != 2) || !in.ptr) return "argument is not a plaintext";
+    *out = PlainVal{in.ptr, in.stride, in.kind};
+    return nullptr;
+  };
+
+  // ---- descriptor tables: pinned host arena -> one device buffer per table ----
+  thread_local TableArena arena;
+  arena.used = 0;
+  bool tables_used = false;
+  // reserve the worst case up front so that the host pointers handed out stay valid for the whole run
+  {
+    size_t need = 0;
+    for (const Plan::Step& st : P.steps) {
+      need += (st.node.size() + 1) * sizeof(NaryOut) + st.terms.size() * sizeof(NaryTerm) + st.plain.size() * sizeof(PlainNttRef) +
+              (st.a.size() + st.b.size() + st.cts.size() + 4) * sizeof(u64*) + 256;
+    }
+    if (!arena.reserve(need + 4096)) return cleanup(kOutOfMemory, "descriptor table allocation failed");
+  }
+  auto stage_table = [&](const void* src, size_t bytes) -> const void* {  // returns the DEVICE copy
+    const size_t off = (arena.used + 63) & ~(size_t)63;
+    unsigned char* hp = arena.host + off;
+    std::memcpy(hp, src, bytes);
+    arena.used = off + bytes;
+    void* dev = pool.acquire(bytes, s);
+    if (!dev) return nullptr;
+    temps.push_back(dev);
+    if (hipMemcpyAsync(dev, hp, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+    tables_used = true;
+    return dev;
+  };
+
+  auto galois_key = [&](u32 elt) -> const u64* {
+    auto it = galois_keys.find((elt - 1) >> 1);
+    return it == galois_keys.end() ? nullptr : it->second;
+  };
+  // rotate `in` by `steps` into `out` following SEAL's rotate_internal (direct key or NAF chain)
+  std::function<int(const u64*, int, u64*)> rotate = [&](const u64* in, int steps, u64* out) -> int {
+    if (steps == 0) {
+      if (in != out && hipMemcpyAsync(out, in, batch * 2 * poly * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess) return kHipError;
+      return kOk;
+    }
+    const u32 elt = ev.galois_elt_from_step(steps);
+    if (!elt) return kInvalidArg;
+    if (const u64* key = galois_key(elt)) return ev.apply_galois(in, elt, key, out, batch, s);
+    std::vector<int> naf;
+    const bool neg = steps < 0;
+    int v = neg ? -steps : steps;
+    for (int i = 0; v; i++) {
+      const int zi = (v & 1) ? 2 - (v & 3) : 0;
+      v = (v - zi) >> 1;
+      if (zi) naf.push_back((neg ? -zi : zi) * (1 << i));
+    }
+    if (naf.size() == 1) return kNoKey;
+    const u64* cur = in;
+    for (int part : naf) {
+      if ((size_t)(part < 0 ? -part : part) == (n >> 1)) continue;
+      int rc = rotate(cur, part, out);
+      if (rc) return rc;
+      cur = out;
+    }
+    return kOk;
+  };
+
+  // operands of a merged launch as ONE array: used in place when the members' buffers are adjacent and in order, staged otherwise
+  auto as_array = [&](const std::vector<int>& slots, size_t words_each, const u64** out) -> int {
+    bool adjacent = true;
+    for (size_t m = 1; m < slots.size() && adjacent; m++) adjacent = sp[slots[m]] == sp[slots[0]] + m * words_each;
+    if (adjacent) {
+      *out = sp[slots[0]];
+      return kOk;
+    }
+    std::vector<const u64*> tab(slots.size());
+    for (size_t m = 0; m < slots.size(); m++) tab[m] = sp[slots[m]];
+    const u64* const* dtab = (const u64* const*)stage_table(tab.data(), tab.size() * sizeof(u64*));
+    u64* stage = (u64*)pool.acquire(slots.size() * words_each * sizeof(u64), s);
+    if (!dtab || !stage) return kOutOfMemory;
+    temps.push_back(stage);
+    for (size_t off = 0; off < slots.size(); off += 65535) {
+      const size_t c = std::min<size_t>(65535, slots.size() - off);
+      if (launch_gather_items(dtab + off, stage + off * words_each, words_each, c, s) != hipSuccess) return kHipError;
+    }
+    *out = stage;
+    return kOk;
+  };
+
+  // which sums were folded into their producer at run time: (step, member) -> the slot that carries the result
+  std::vector<std::vector<int>> folded_into(P.steps.size());
+  auto try_fold = [&](const Plan::Step& st, size_t m) -> const u64* {  // the addend to hand to the key-switching kernel, or nullptr
+    if (st.fold.empty() || st.fold[m].other_slot < 0) return nullptr;
+    return sp[st.fold[m].other_slot];
+  };
+  auto mark_folded = [&](const Plan::Step& st, size_t m) {
+    const Plan::Fold& f = st.fold[m];
+    auto& v = folded_into[f.nary_step];
+    if (v.empty()) v.assign(P.steps[f.nary_step].node.size(), -1);
+    v[f.nary_member] = st.out[m];
+  };
+  // the buffer a key-switching member writes when its Add is folded: the sum's own destination
+  auto alloc_for_fold = [&](const Plan::Step& st, size_t m) -> u64* {
+    const Plan::Fold& f = st.fold[m];
+    const int sum_slot = P.steps[f.nary_step].out[f.nary_member];
+    u64* p = alloc_member(sum_slot);  // binds the SUM's slot; the member's own slot aliases it
+    if (!p) return nullptr;
+    bind(st.out[m], block_of[sum_slot], p);
+    return p;
+  };
+
+  const bool small = batch <= merge_max_batch();
+  for (size_t si = 0; si < P.steps.size(); si++) {
+    const Plan::Step& st = P.steps[si];
+    const size_t members = st.node.size();
+    int rc = kOk;
+    switch (st.kind) {
+      case kStepNary: {
+        std::vector<NaryOut> outs;
+        std::vector<NaryTerm> terms;
+        u32 max_size = 0;
+        const std::vector<int>& fv = folded_into[si];
+        for (size_t m = 0; m < members; m++) {
+          if (!fv.empty() && fv[m] >= 0) continue;  // its producer already added the other operand and wrote this slot
+          const int osl = st.out[m];
+          u64* o = alloc_member(osl);
+          if (!o) return cleanup(kOutOfMemory, "out of device memory");
+          NaryOut d;
+          d.out = o;
+          d.first = (u32)terms.size();
+          d.count = st.first[m + 1] - st.first[m];
+          d.size = P.slot_size[osl];
+          d.pad = 0;
+          max_size = std::max(max_size, d.size);
+          for (u32 t = st.first[m]; t < st.first[m + 1]; t++) terms.push_back(NaryTerm{sp[st.terms[t].slot], P.slot_size[st.terms[t].slot], st.terms[t].sign});
+          outs.push_back(d);
+        }
+        if (outs.empty()) break;
+        const NaryOut* douts = (const NaryOut*)stage_table(outs.data(), outs.size() * sizeof(NaryOut));
+        const NaryTerm* dterms = (const NaryTerm*)stage_table(terms.data(), terms.size() * sizeof(NaryTerm));
+        if (!douts || !dterms) return cleanup(kOutOfMemory, "descriptor table allocation failed");
+        ev.profiler().begin(kKernEltwise, outs.size() * batch * max_size * K, s);
+        const hipError_t e = launch_nary_sum(ctx->dev(), (u32)n, (u32)K, douts, dterms, (u32)outs.size(), max_size, (u32)batch, s);
+        ev.profiler().end(s);
+        if (e != hipSuccess) return cleanup(kHipError, "operation failed");
+        rc = ev.note_nary(douts, (u32)outs.size(), (u32)batch, s);
+        break;
+      }
+      case kStepMulRelin:
+      case kStepRelin:
+      case kStepGalois: {
+        const bool is_mul = st.kind == kStepMulRelin, is_rot = st.kind == kStepGalois;
+        if (!is_rot && !relin_key && !(st.kind == kStepRelin && st.out_size == 2)) return cleanup(kNoKey, "operation failed");
+        u32 elt = 0;
+        const u64* gkey = nullptr;
+        if (is_rot) {
+          if (!ctx->batching()) return cleanup(kUnsupported, "encryption parameters do not support batching");
+          elt = st.swap ? 2 * (u32)n - 1 : (st.rot_steps ? ev.galois_elt_from_step(st.rot_steps) : 0);
+          if (st.swap || st.rot_steps) {
+            if (!elt) return cleanup(kInvalidArg, "operation failed");
+            gkey = galois_key(elt);
+            if (st.swap && !gkey) return cleanup(kNoKey, "Galois key for the column rotation is missing");
+          }
+        }
+        const u32 in_size = st.kind == kStepRelin ? st.out_size : 2;
+        const size_t in_words = batch * in_size * poly, out_words = batch * 2 * poly;
+        const bool direct_ks = is_mul || (st.kind == kStepRelin && in_size == 3) || (is_rot && gkey);
+        if (small && members > 1 && direct_ks) {
+          // ONE launch sequence over members x batch ciphertexts
+          const u64 *A = nullptr, *B2 = nullptr;
+          if ((rc = as_array(st.a, in_words, &A))) return cleanup(rc, "operation failed");
+          if (is_mul && !st.square && (rc = as_array(st.b, in_words, &B2))) return cleanup(rc, "operation failed");
+          const int blk = new_block(members * out_words);
+          if (blk < 0) return cleanup(kOutOfMemory, "out of device memory");
+          u64* out = (u64*)blocks[blk].ptr;
+          for (size_t m = 0; m < members; m++) bind(st.out[m], blk, out + m * out_words);
+          const size_t count = members * batch;
+          rc = is_mul ? ev.multiply_relin(A, st.square ? A : B2, relin_key, out, count, s)
+             : is_rot ? ev.apply_galois(A, elt, gkey, out, count, s)
+                      : ev.relinearize(A, relin_key, out, count, s);
+          break;
+        }
+        for (size_t m = 0; m < members && !rc; m++) {
+          const u64* addend = direct_ks ? try_fold(st, m) : nullptr;
+          u64* out = addend ? alloc_for_fold(st, m) : alloc_member(st.out[m]);
+          if (!out) return cleanup(kOutOfMemory, "out of device memory");
+          const u64* a = sp[st.a[m]];
+          if (is_mul)
+            rc = ev.multiply_relin(a, sp[st.b[m]], relin_key, out, batch, s, addend);
+          else if (st.kind == kStepRelin && in_size == 2)
+            rc = hipMemcpyAsync(out, a, out_words * sizeof(u64), hipMemcpyDeviceToDevice, s) == hipSuccess ? (int)kOk : (int)kHipError;
+          else if (st.kind == kStepRelin)
+            rc = ev.relinearize(a, relin_key, out, batch, s, addend);
+          else if (gkey)
+            rc = ev.apply_galois(a, elt, gkey, out, batch, s, addend);
+          else
+            rc = rotate(a, st.rot_steps, out);
+          if (addend && !rc) mark_folded(st, m);
+        }
+        break;
+      }
+      case kStepMultiply: {
+        u64* out = alloc_member(st.out[0]);
+        if (!out) return cleanup(kOutOfMemory, "out of device memory");
+        rc = ev.multiply(sp[st.a[0]], P.slot_size[st.a[0]], sp[st.b[0]], P.slot_size[st.b[0]], out, batch, s);
+        break;
+      }
+      case kStepPlainOp: {
+        PlainVal pv;
+        if (const char* m = plain_of(st.plain[0], &pv)) return cleanup(kInvalidArg, m);
+        const u32 sz = P.slot_size[st.a[0]];
+        if (pv.kind == 2 && st.plain_op != kOpMultiplyPlaintext)
+          return cleanup(kInvalidArg, "a transform-domain plaintext argument can only be an operand of MultiplyPlaintext");
+        u64* out = alloc_member(st.out[0]);
+        if (!out) return cleanup(kOutOfMemory, "out of device memory");
+        if (st.plain_op == kOpAddPlaintext)
+          rc = ev.add_plain(sp[st.a[0]], sz, pv.ptr, pv.stride, out, batch, s);
+        else if (st.plain_op == kOpSubPlaintext)
+          rc = ev.sub_plain(sp[st.a[0]], sz, pv.ptr, pv.stride, out, batch, s);
+        else if (pv.kind == 1)
+          rc = ev.multiply_plain(sp[st.a[0]], sz, pv.ptr, pv.stride, out, batch, s);
+        else
+          rc = ev.multiply_plain_ntt(sp[st.a[0]], sz, pv.ptr, pv.stride, out, batch, s);
+        break;
+      }
+      case kStepLinComb: {
+        // out[row] = sum_j cts[j] (.) plain[row][j]: transform the ciphertexts once, accumulate in the transform domain, one inverse per row
+        const size_t cols = st.cts.size(), rows = members;
+        const size_t ct_words = batch * 2 * poly;
+        const u64* staged = nullptr;
+        {
+          // always a copy: the transform runs in place.  Adjacent operands are copied with one memcpy.
+          bool adjacent = true;
+          for (size_t j = 1; j < cols && adjacent; j++) adjacent = sp[st.cts[j]] == sp[st.cts[0]] + j * ct_words;
+          u64* ctn = (u64*)pool.acquire(cols * ct_words * sizeof(u64), s);
+          if (!ctn) return cleanup(kOutOfMemory, "out of device memory");
+          temps.push_back(ctn);
+          if (adjacent) {
+            if (hipMemcpyAsync(ctn, sp[st.cts[0]], cols * ct_words * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess) return cleanup(kHipError, "copy failed");
+          } else {
+            std::vector<const u64*> tab(cols);
+            for (size_t j = 0; j < cols; j++) tab[j] = sp[st.cts[j]];
+            const u64* const* dtab = (const u64* const*)stage_table(tab.data(), cols * sizeof(u64*));
+            if (!dtab) return cleanup(kOutOfMemory, "descriptor table allocation failed");
+            for (size_t off = 0; off < cols; off += 65535) {
+              const size_t c = std::min<size_t>(65535, cols - off);
+              if (launch_gather_items(dtab + off, ctn + off * ct_words, ct_words, c, s) != hipSuccess) return cleanup(kHipError, "operation failed");
+            }
+          }
+          if ((rc = ev.ct_to_ntt(ctn, 2, ctn, cols * batch, s))) return cleanup(rc, "operation failed");
+          staged = ctn;
+        }
+        // the plaintexts: transform-domain arguments as they are; coefficient-form ones are lifted and transformed now (runs of
+        // adjacent plaintexts in one call), and an all-zero one raises the transparent-result failure SEAL's multiply_plain raises
+        std::vector<PlainNttRef> tab(rows * cols);
+        std::vector<PlainVal> pv(rows * cols);
+        size_t need_ntt = 0;
+        for (size_t e = 0; e < rows * cols; e++) {
+          if (const char* m = plain_of(st.plain[e], &pv[e])) return cleanup(kInvalidArg, m);
+          if (pv[e].kind == 1) need_ntt += pv[e].stride ? batch : 1;
+        }
+        u64* pscratch = nullptr;
+        if (need_ntt) {
+          pscratch = (u64*)pool.acquire(need_ntt * poly * sizeof(u64), s);
+          if (!pscratch) return cleanup(kOutOfMemory, "out of device memory");
+          temps.push_back(pscratch);
+        }
+        size_t pos = 0;
+        for (size_t e = 0; e < rows * cols;) {
+          if (pv[e].kind == 2) {
+            tab[e] = PlainNttRef{pv[e].ptr, (u64)pv[e].stride};
+            e++;
+            continue;
+          }
+          if (pv[e].stride) {  // per-item plaintexts u64[batch][N]
+            if ((rc = ev.plain_to_ntt(pv[e].ptr, pv[e].stride, pscratch + pos * poly, batch, s, 1))) return cleanup(rc, "operation failed");
+            tab[e] = PlainNttRef{pscratch + pos * poly, (u64)poly};
+            pos += batch;
+            e++;
+            continue;
+          }
+          size_t run = 1;  // shared plaintexts that sit next to each other in memory: one lift + transform launch for the run
+          while (e + run < rows * cols && pv[e + run].kind == 1 && !pv[e + run].stride && pv[e + run].ptr == pv[e].ptr + run * n) run++;
+          if ((rc = ev.plain_to_ntt(pv[e].ptr, n, pscratch + pos * poly, run, s, 2))) return cleanup(rc, "operation failed");
+          for (size_t r = 0; r < run; r++) tab[e + r] = PlainNttRef{pscratch + (pos + r) * poly, 0};
+          pos += run;
+          e += run;
+        }
+        const PlainNttRef* dtab = (const PlainNttRef*)stage_table(tab.data(), tab.size() * sizeof(PlainNttRef));
+        if (!dtab) return cleanup(kOutOfMemory, "descriptor table allocation failed");
+        const int blk = new_block(rows * ct_words);
+        if (blk < 0) return cleanup(kOutOfMemory, "out of device memory");
+        u64* out = (u64*)blocks[blk].ptr;
+        for (size_t m = 0; m < rows; m++) bind(st.out[m], blk, out + m * ct_words);
+        if ((rc = ev.dot_plain_tab(staged, (u32)cols, dtab, (u32)rows, (u32)batch, out, s))) return cleanup(rc, "operation failed");
+        rc = ev.note_result(out, 2, (u32)K, rows * batch, s);
+        break;
+      }
+      case kStepOutput: {
+        if (direct_written[st.out_index]) break;
+        if (hipMemcpyAsync(outputs[st.out_index], sp[st.a[0]], batch * 2 * poly * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess)
+          return cleanup(kHipError, "copy failed");
+        break;
+      }
+      default:
+        return cleanup(kInvalidArg, "unsupported operation");
+    }
+    if (rc) return cleanup(rc, st.kind == kStepMulRelin ? "multiply+relinearize failed" : "operation failed");
+    for (int sl : st.release) unbind(sl);
+  }
+  for (Block& b : blocks)
+    if (b.owned && b.refs > 0) pool.release(b.ptr, s);
+  for (void* t : temps) pool.release(t, s);
+  // the descriptor tables were copied from this thread's pinned arena: they must have left it before the next run reuses it
+  if (tables_used && hipStreamSynchronize(s) != hipSuccess) return fail(kHipError, "stream synchronisation failed");
+  return kOk;
+}
+
+}  // namespace hipbfv

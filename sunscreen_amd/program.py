@@ -39,6 +39,15 @@ def encode_plaintext_literal(n: int, key_primes: Sequence[int], t: int, seal_pla
     return out
 
 
+class TransformedPlaintext:
+    """A plaintext argument already lifted to the data primes and transformed (BatchEvaluator.plain_to_ntt): int64[K,N]
+    shared by the batch or int64[batch,K,N].  Only MultiplyPlaintext nodes may consume it (ProgramInput kind 2)."""
+
+    def __init__(self, tensor: torch.Tensor):
+        assert tensor.is_cuda and tensor.dtype == torch.int64 and tensor.is_contiguous()
+        self.tensor = tensor
+
+
 class FheProgram:
     def __init__(self):
         self._h = C.c_void_p()
@@ -168,22 +177,36 @@ class FheProgram:
             }
         )
 
+    def describe(self) -> list[str]:
+        """The schedule `run` follows: one line per step (kind, members, ...)."""
+        need = C.c_uint64()
+        _check(_lib.load().hipbfv_Program_Describe(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        _check(_lib.load().hipbfv_Program_Describe(self._h, buf, need.value, C.byref(need)))
+        return buf.value.decode().splitlines()
+
     def num_outputs(self) -> int:
         n = C.c_uint64()
         _check(_lib.load().hipbfv_Program_NumOutputs(self._h, C.byref(n)))
         return n.value
 
-    def run(
+    def run(self, ev, inputs, relin_keys=None, galois_keys=None) -> list[torch.Tensor]:
+        return self.prepare(ev, inputs, relin_keys, galois_keys)()
+
+    def prepare(
         self,
         ev: BatchEvaluator,
         inputs: Sequence[torch.Tensor],
         relin_keys: RelinearizationKeys | None = None,
         galois_keys: GaloisKeys | None = None,
-    ) -> list[torch.Tensor]:
-        """inputs[i]: int64[batch,2,K,N] ciphertext batch, or int64[batch,N] / int64[N] plaintext(s)."""
+    ):
+        """Bind the arguments once and return a callable that runs the program on them (the argument tables are built here:
+        a graph with tens of thousands of arguments -- examples/pir's database -- is run many times on the same buffers)."""
+        """inputs[i]: int64[batch,2,K,N] ciphertext batch, int64[batch,N] / int64[N] plaintext(s) in coefficient form, or a
+        `TransformedPlaintext` (int64[batch,K,N] / int64[K,N] from BatchEvaluator.plain_to_ntt: static data transformed once)."""
         batch = None
         for t in inputs:
-            if t.dim() == 4:
+            if not isinstance(t, TransformedPlaintext) and t.dim() == 4:
                 batch = t.shape[0]
         assert batch is not None, "need at least one ciphertext argument"
         n_in = len(inputs)
@@ -191,7 +214,12 @@ class FheProgram:
         ptrs = (C.c_void_p * n_in)()
         strides = (C.c_uint64 * n_in)()
         for i, t in enumerate(inputs):
-            if t.dim() == 4:
+            if isinstance(t, TransformedPlaintext):
+                t = t.tensor
+                assert t.shape[-2:] == (ev.K, ev.n) and (t.dim() == 2 or (t.dim() == 3 and t.shape[0] in (1, batch)))
+                kinds[i] = 2
+                strides[i] = 0 if t.dim() == 2 or t.shape[0] == 1 else ev.K * ev.n
+            elif t.dim() == 4:
                 assert t.shape[0] == batch and t.shape[1] == 2
                 kinds[i], strides[i] = 0, 0
             else:
@@ -199,15 +227,17 @@ class FheProgram:
                 strides[i] = 0 if t.dim() == 1 or t.shape[0] == 1 else ev.n
             ptrs[i] = _ptr(t)
         n_out = self.num_outputs()
-        dev = inputs[0].device
-        outs = [torch.empty((batch, 2, ev.K, ev.n), dtype=torch.int64, device=dev) for _ in range(n_out)]
-        optrs = (C.c_void_p * n_out)(*[_ptr(o) for o in outs])
-        _check(
-            _lib.load().hipbfv_Program_Run(
-                self._h, ev._h, batch, n_in, kinds, ptrs, strides,
-                relin_keys.get_handle() if relin_keys is not None else None,
-                galois_keys.get_handle() if galois_keys is not None else None,
-                n_out, optrs, _stream(),
-            )
-        )
-        return outs
+        dev = next(t for t in inputs if not isinstance(t, TransformedPlaintext)).device
+        keep = list(inputs)  # the tables hold raw addresses: the tensors must outlive the callable
+        fn = _lib.load().hipbfv_Program_Run
+        rk = relin_keys.get_handle() if relin_keys is not None else None
+        gk = galois_keys.get_handle() if galois_keys is not None else None
+
+        def call() -> list[torch.Tensor]:
+            assert keep is not None
+            outs = [torch.empty((batch, 2, ev.K, ev.n), dtype=torch.int64, device=dev) for _ in range(n_out)]
+            optrs = (C.c_void_p * n_out)(*[_ptr(o) for o in outs])
+            _check(fn(self._h, ev._h, batch, n_in, kinds, ptrs, strides, rk, gk, n_out, optrs, _stream()))
+            return outs
+
+        return call

@@ -65,6 +65,27 @@ def pir_row(columns: int) -> FheProgram:
     return p
 
 
+def pir_lookup_graph(rows: int, columns: int) -> FheProgram:
+    """The WHOLE `lookup` program of examples/pir/src/main.rs:16-45 for a rows x columns database, node for node as the
+    compiler emits it: col[i] = db[i][0] * col_query[0]; col[i] = col[i] + db[i][j] * col_query[j]; sum = col[0] * row_query[0];
+    sum = sum + col[i] * row_query[i] (a Relinearize after every Multiply).  Arguments, in the order of the fhe_program's
+    signature: 0..columns-1 = col_query, columns..columns+rows-1 = row_query, then the database row-major
+    (argument columns + rows + i * columns + j = database[i][j]).  One output."""
+    p = FheProgram()
+    cq = [p.append_input_ciphertext(j) for j in range(columns)]
+    rq = [p.append_input_ciphertext(columns + i) for i in range(rows)]
+    total = None
+    for i in range(rows):
+        col = None
+        for j in range(columns):
+            term = p.append_multiply_plaintext(cq[j], p.append_input_plaintext(columns + rows + i * columns + j))
+            col = term if col is None else p.append_add(col, term)
+        prod = _mul(p, col, rq[i])
+        total = prod if total is None else p.append_add(total, prod)
+    p.append_output_ciphertext(total)
+    return p
+
+
 def pir_lookup(ev, col_query, row_query, db_ntt, relin_keys):
     """examples/pir/src/main.rs:16-45 `lookup` for a sqrt(DB) x sqrt(DB) database, on the batch primitives instead of a
     node-by-node graph: col[i] = sum_j database[i][j] * col_query[j] as ONE transform-domain matrix-vector product

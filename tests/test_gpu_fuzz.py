@@ -100,11 +100,14 @@ def test_every_operation_on_random_parameter_sets(n, bits, tbits):
             assert (enc[i] == o.batch_encode(vals[i])).all()
 
 
-@pytest.mark.parametrize("seed", range(10))
-def test_random_program_graphs(seed):
+@pytest.mark.parametrize("seed", range(16))
+def test_random_program_graphs(seed, monkeypatch):
     """Random FheProgram DAGs (every ciphertext node kind the compiler emits, run.rs:160-341) through the batch graph
     executor vs the oracle interpreter, bit for bit: exercises operand lifetime / buffer recycling, the fused
-    Multiply->Relinearize, NAF rotation chains with a power-of-two key set and shared / per-item plaintexts."""
+    Multiply->Relinearize, NAF rotation chains with a power-of-two key set and shared / per-item plaintexts.
+    Batches of 1 / 2 take the scheduled executor's merged launches (ready nodes of one kind in one launch sequence, staged
+    operands), batches of 40 its member-by-member path with Adds folded into key-switch tails; every graph also runs through
+    the node-by-node executor (HIPBFV_PROGRAM_SERIAL=1) and the two must agree word for word."""
     from oracle.program_interp import run_program
     from sunscreen_amd import Context, GaloisKeys, RelinearizationKeys
     from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
@@ -124,8 +127,8 @@ def test_random_program_graphs(seed):
     cts = [p.append_input_ciphertext(i) for i in range(3)]
     pls = [p.append_input_plaintext(3), p.append_input_plaintext(4)]
     depth = {c: 0 for c in cts}  # multiplicative depth: keep products decryptable is NOT required, only determinism
-    for _ in range(int(rng.integers(8, 16))):
-        kind = rng.choice(["add", "sub", "neg", "mul", "rotl", "rotr", "swap", "addp", "subp", "mulp"])
+    for _ in range(int(rng.integers(8, 24))):
+        kind = rng.choice(["add", "sub", "neg", "mul", "rotl", "rotr", "swap", "addp", "subp", "mulp", "add", "mulp", "mul"])
         a = int(rng.choice(cts))
         b = int(rng.choice(cts))
         if kind == "add":
@@ -153,7 +156,8 @@ def test_random_program_graphs(seed):
     for c in outs:
         p.append_output_ciphertext(c)
     q = FheProgram.from_json(p.to_json())
-    batch = 2
+    batch = (1, 2, 40)[seed % 3]
+    ncheck = min(batch, 3)
     K = o.K
     ins = [np.stack([rng.integers(0, pr, (batch, 2, n), dtype=np.uint64) for pr in primes[:K]], axis=2) for _ in range(3)]
     shared = rng.integers(1, t, n, dtype=np.uint64)          # one plaintext for the whole batch
@@ -161,7 +165,7 @@ def test_random_program_graphs(seed):
     from sunscreen_amd import HipBfvError
 
     refs, transparent = [], False
-    for i in range(batch):
+    for i in range(ncheck):
         try:
             refs.append(run_program(o, q.nodes, q.edges, [x[i] for x in ins] + [shared, per_item[i]], rk, gk))
         except RuntimeError as e:  # the oracle mirrors SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT
@@ -173,8 +177,12 @@ def test_random_program_graphs(seed):
         return
     got = q.run(ev, [to_device(x) for x in ins] + [to_device(shared), to_device(per_item)], rkd, gkd)
     got = [to_host(g) for g in got]
-    for i in range(batch):
+    for i in range(ncheck):
         ref = refs[i]
         assert len(ref) == len(got)
         for k in range(len(ref)):
-            assert (got[k][i] == ref[k]).all(), (seed, i, k)
+            assert (got[k][i] == ref[k]).all(), (seed, i, k, q.describe())
+    monkeypatch.setenv("HIPBFV_PROGRAM_SERIAL", "1")
+    serial = [to_host(g) for g in q.run(ev, [to_device(x) for x in ins] + [to_device(shared), to_device(per_item)], rkd, gkd)]
+    for k in range(len(got)):
+        assert (serial[k] == got[k]).all(), (seed, k, q.describe())

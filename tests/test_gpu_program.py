@@ -304,3 +304,127 @@ def test_transparent_results_fail_the_run_like_the_reference():
         assert (to_host(outz) == ca).all()  # (x - x) + y == y
     finally:
         assert _lib.load().hipbfv_set_throw_on_transparent(True) == 0
+
+
+def _scalar(o, v):
+    p = np.zeros(o.n, dtype=np.uint64)
+    p[0] = v % o.t
+    return p
+
+
+def test_whole_pir_lookup_graph_through_the_scheduled_executor():
+    """examples/pir/src/main.rs:16-45, the WHOLE `lookup` program as the compiler emits it (one input set, every database entry
+    a plaintext argument), through hipbfv_Program_Run: the schedule is one transform-domain matrix product, one batched
+    multiply+relinearize and one sum.  Database as coefficient-form plaintext arguments and as arguments transformed once
+    (TransformedPlaintext): both equal the oracle's node-by-node evaluation bit for bit, and the hand-written pir_lookup."""
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.program import FheProgram, TransformedPlaintext
+    from sunscreen_amd.workloads import pir_lookup, pir_lookup_graph
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_4096_16")
+    rows, cols = 5, 19
+    prog = FheProgram.from_json(pir_lookup_graph(rows, cols).to_json())
+    assert prog.describe()[:3] == [f"plain_matrix members={rows} columns={cols}", f"mul_relin members={rows}", f"sum members=1 terms={rows} direct_outputs=1"]
+    rng = np.random.default_rng(33)
+    vals = rng.integers(1, 1000, (rows, cols))
+    db = np.stack([np.stack([_scalar(o, int(vals[i, j])) for j in range(cols)]) for i in range(rows)])
+    db[1, 2] = rng.integers(1, o.t, o.n, dtype=np.uint64)  # a general plaintext among the monomials (breaks the one-hot decode of row 1 only)
+    sel_r, sel_c = 3, 11
+    cq = np.stack([o.encrypt(pk, _scalar(o, 1 if j == sel_c else 0)) for j in range(cols)])
+    rq = np.stack([o.encrypt(pk, _scalar(o, 1 if i == sel_r else 0)) for i in range(rows)])
+    host_args = [cq[j] for j in range(cols)] + [rq[i] for i in range(rows)] + [db[i, j] for i in range(rows) for j in range(cols)]
+    (ref,) = run_program(o, prog.nodes, prog.edges, host_args, rk)
+    assert int(o.decrypt(ref, sk)[0]) == int(vals[sel_r, sel_c])
+    dcq, drq, ddb = to_device(cq), to_device(rq), to_device(db)
+    cts = [dcq[j : j + 1] for j in range(cols)] + [drq[i : i + 1] for i in range(rows)]
+    (out1,) = prog.run(ev, cts + [ddb[i, j] for i in range(rows) for j in range(cols)], rkd)
+    assert (to_host(out1)[0] == ref).all()
+    dbn = ev.plain_to_ntt(ddb)
+    run2 = prog.prepare(ev, cts + [TransformedPlaintext(dbn[i, j]) for i in range(rows) for j in range(cols)], rkd)
+    for _ in range(2):  # bound once, run twice
+        (out2,) = run2()
+        assert (to_host(out2)[0] == ref).all()
+    assert (to_host(pir_lookup(ev, dcq, drq, dbn, rkd))[0] == ref).all()
+    # separately allocated arguments (nothing adjacent in memory: every operand list is staged through a pointer table)
+    scattered = [t.clone() for t in cts] + [TransformedPlaintext(dbn[i, j].clone()) for i in range(rows) for j in range(cols)]
+    (out3,) = prog.run(ev, scattered, rkd)
+    assert (to_host(out3)[0] == ref).all()
+
+
+def test_zero_plaintext_inside_a_transform_domain_sum_fails_like_multiply_plain():
+    """sunscreen/tests/features.rs:8-34: a * 0 is an error.  Inside a sum of products that stays in the transform domain the single
+    product never exists, so the zero plaintext itself must raise the failure -- and name the input set."""
+    from sunscreen_amd import HipBfvError
+    from sunscreen_amd.batch import to_device
+    from sunscreen_amd.workloads import pir_row
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("simple_multiply")
+    cols, batch = 3, 4
+    prog = pir_row(cols)
+    assert prog.describe()[0] == f"plain_matrix members=1 columns={cols}"
+    rng = np.random.default_rng(5)
+    row_q = np.stack([o.encrypt(pk, _scalar(o, 1)) for _ in range(batch)])
+    col_q = [np.stack([o.encrypt(pk, _scalar(o, j + 1)) for _ in range(batch)]) for j in range(cols)]
+    db = [rng.integers(1, o.t, (batch, o.n), dtype=np.uint64) for _ in range(cols)]
+    ins = lambda: [to_device(row_q)] + [to_device(c) for c in col_q] + [to_device(d) for d in db]  # noqa: E731
+    prog.run(ev, ins(), rkd)
+    db[1][2] = 0
+    with pytest.raises(HipBfvError, match="input set 2"):
+        prog.run(ev, ins(), rkd)
+    with pytest.raises(RuntimeError, match="transparent"):
+        run_program(o, prog.nodes, prog.edges, [row_q[2]] + [c[2] for c in col_q] + [d[2] for d in db], rk)
+
+
+def test_add_and_sub_of_different_ciphertext_sizes():
+    """run.rs:217-236 hands Add / Sub operands of any sizes to SEAL, which pads the shorter one: (a*b) + a is a size-3 ciphertext,
+    a - (a*b) negates the product's third polynomial.  Relinearised afterwards so that the outputs are size 2."""
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.program import FheProgram
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_4096_16")
+    p = FheProgram()
+    a, b = p.append_input_ciphertext(0), p.append_input_ciphertext(1)
+    m = p.append_multiply(a, b)  # two users: stays an unfused size-3 product
+    p.append_output_ciphertext(p.append_relinearize(p.append_add(m, a)))
+    p.append_output_ciphertext(p.append_relinearize(p.append_sub(b, p.append_negate(m))))
+    p.append_output_ciphertext(p.append_relinearize(p.append_add(p.append_sub(a, m), p.append_add(m, m))))
+    rng = np.random.default_rng(6)
+    for batch in (1, 3, 40):
+        va = rng.integers(0, 30, (batch, o.n)).astype(np.uint64)
+        vb = rng.integers(0, 30, (batch, o.n)).astype(np.uint64)
+        ca = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in va])
+        cb = np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vb])
+        outs = [to_host(t) for t in p.run(ev, [to_device(ca), to_device(cb)], rkd)]
+        for i in range(min(batch, 3)):
+            refs = run_program(o, p.nodes, p.edges, [ca[i], cb[i]], rk)
+            for k in range(3):
+                assert (outs[k][i] == refs[k]).all(), (batch, i, k)
+            prod = va[i].astype(np.int64) * vb[i]
+            expect = [prod + va[i], vb[i] + prod, va[i] + prod]
+            for k in range(3):
+                assert (o.batch_decode(o.decrypt(outs[k][i], sk)) == expect[k] % o.t).all()
+
+
+@pytest.mark.parametrize("batch", [1, 2, 40])
+def test_scheduled_and_node_by_node_executors_agree(batch, monkeypatch):
+    """The reference's examples through both executors -- ready nodes merged into batched launches (batch 1 and 2: the
+    reference's own call shape is ONE input set) or every member on its own with Adds folded into key-switch tails (batch 40)
+    against one node at a time (HIPBFV_PROGRAM_SERIAL=1) -- word for word, and item 0 against the oracle interpreter."""
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.workloads import chi_sq_optimized, dot_product
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_4096_16", galois="all")
+    rng = np.random.default_rng(40 + batch)
+    for prog, nin in ((chi_sq_optimized(), 3), (dot_product(o.n // 2), 2)):
+        vals = rng.integers(0, 7, (nin, batch, o.n)).astype(np.uint64)
+        cts = [np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vals[a]]) for a in range(nin)]
+        dev = [to_device(c) for c in cts]
+        monkeypatch.delenv("HIPBFV_PROGRAM_SERIAL", raising=False)
+        got = [to_host(t) for t in prog.run(ev, dev, rkd, gkd)]
+        monkeypatch.setenv("HIPBFV_PROGRAM_SERIAL", "1")
+        serial = [to_host(t) for t in prog.run(ev, dev, rkd, gkd)]
+        monkeypatch.delenv("HIPBFV_PROGRAM_SERIAL", raising=False)
+        ref = run_program(o, prog.nodes, prog.edges, [c[0] for c in cts], rk, gk)
+        for k in range(len(got)):
+            assert (got[k] == serial[k]).all(), (batch, k)
+            assert (got[k][0] == ref[k]).all(), (batch, k)
