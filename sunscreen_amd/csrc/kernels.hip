@@ -1225,6 +1225,11 @@ __global__ __launch_bounds__(kCoefThreads) void scatter_items_kernel(const u64* 
   u64x2_t* dst = reinterpret_cast<u64x2_t*>(table[blockIdx.y]);
   for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < words / 2; i += (size_t)gridDim.x * kCoefThreads) dst[i] = src[i];
 }
+// words from pinned, device-addressable host memory into device memory, ordered on the stream like any kernel (the graph
+// executor's descriptor tables: a hipMemcpyAsync on the caller's stream drains it first when that stream is the null stream)
+__global__ __launch_bounds__(kCoefThreads) void copy_words_kernel(const u64* __restrict__ src, u64* __restrict__ dst, size_t words) {
+  for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < words; i += (size_t)gridDim.x * kCoefThreads) dst[i] = src[i];
+}
 // add / sub of size-2 ciphertexts straight through the pointer tables (no staging: the operation is one pass anyway):
 // *out[item] = *a[item] +/- *b[item]; grid (N/2/256, 2K residue rows, items); mode 0 add, 1 sub
 __global__ __launch_bounds__(kCoefThreads) void eltwise_items_kernel(const DevCtx* __restrict__ ctx, const u64* const* __restrict__ ta,
@@ -1414,6 +1419,11 @@ hipError_t launch_transparent_flag(const u64* ct, size_t words, size_t skip_word
 
 hipError_t launch_gather_items(const u64* const* table, u64* stage, size_t words, size_t items, hipStream_t s) {
   gather_items_kernel<<<dim3(32, (u32)items), kCoefThreads, 0, s>>>(table, stage, words);
+  return hipGetLastError();
+}
+hipError_t launch_copy_words(const u64* src, u64* dst, size_t words, hipStream_t s) {
+  const u32 blocks = (u32)std::min<size_t>(256, (words + kCoefThreads - 1) / kCoefThreads);
+  copy_words_kernel<<<dim3(blocks ? blocks : 1), kCoefThreads, 0, s>>>(src, dst, words);
   return hipGetLastError();
 }
 hipError_t launch_scatter_items(const u64* stage, u64* const* table, size_t words, size_t items, hipStream_t s) {

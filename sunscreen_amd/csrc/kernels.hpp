@@ -77,6 +77,7 @@ hipError_t launch_nary_sum(const DevCtx* ctx, u32 n, u32 K, const NaryOut* outs,
 hipError_t launch_dot_plain_tab(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const PlainNttRef* tab, u32 rows, u32 batch, u64* acc, hipStream_t s);
 // combined handle-level calls (capi.cpp): tables of device pointers / flags live in pinned, device-addressable host memory
 hipError_t launch_gather_items(const u64* const* table, u64* stage, size_t words, size_t items, hipStream_t s);
+hipError_t launch_copy_words(const u64* src, u64* dst, size_t words, hipStream_t s);  // src may be pinned, device-addressable host memory
 hipError_t launch_scatter_items(const u64* stage, u64* const* table, size_t words, size_t items, hipStream_t s);
 hipError_t launch_eltwise_items(const DevCtx* ctx, u32 n, u32 K, const u64* const* ta, const u64* const* tb, u64* const* tout, int mode, size_t items,
                                 hipStream_t s);

@@ -28,7 +28,9 @@
 #include <algorithm>
 #include <array>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <functional>
 #include <iterator>
 #include <map>
@@ -628,7 +630,7 @@ struct TableArena {
     host = nullptr;
     cap = 0;
     const size_t want = std::max<size_t>(bytes, 1 << 20);
-    if (hipHostMalloc((void**)&host, want, hipHostMallocPortable) != hipSuccess) {
+    if (hipHostMalloc((void**)&host, want, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
       host = nullptr;
       (void)hipGetLastError();
       return false;
@@ -771,7 +773,7 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
     size_t need = 0;
     for (const Plan::Step& st : P.steps) {
       need += (st.node.size() + 1) * sizeof(NaryOut) + st.terms.size() * sizeof(NaryTerm) + st.plain.size() * sizeof(PlainNttRef) +
-              (st.a.size() + st.b.size() + st.cts.size() + 4) * sizeof(u64*) + 256;
+              (st.a.size() + st.b.size() + st.cts.size() + 4) * sizeof(u64*) + 512;
     }
     if (!arena.reserve(need + 4096)) return cleanup(kOutOfMemory, "descriptor table allocation failed");
   }
@@ -779,11 +781,14 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
     const size_t off = (arena.used + 63) & ~(size_t)63;
     unsigned char* hp = arena.host + off;
     std::memcpy(hp, src, bytes);
-    arena.used = off + bytes;
-    void* dev = pool.acquire(bytes, s);
+    const size_t words = (bytes + 7) / 8;
+    arena.used = off + words * 8;
+    void* dev = pool.acquire(words * 8, s);
     if (!dev) return nullptr;
     temps.push_back(dev);
-    if (hipMemcpyAsync(dev, hp, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+    // a kernel, not hipMemcpyAsync: a copy enqueued on the caller's stream waits for the stream to drain on the HOST when that
+    // stream is the null stream (PyTorch's default), and every drained launch queue costs the device idle time
+    if (launch_copy_words((const u64*)hp, (u64*)dev, words, s) != hipSuccess) return nullptr;
     tables_used = true;
     return dev;
   };
@@ -865,10 +870,35 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
   };
 
   const bool small = batch <= merge_max_batch();
+  // HIPBFV_PROGRAM_TRACE=1: drain the stream after every step and print where the time goes (diagnostics only)
+  const char* trace_env = std::getenv("HIPBFV_PROGRAM_TRACE");
+  const bool trace = trace_env && trace_env[0] == '1';
+  auto now_us = [] {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+  };
+  static const char* step_names[] = {"sum", "plain_matrix", "mul_relin", "multiply", "relinearize", "rotate", "plain_op", "output"};
   for (size_t si = 0; si < P.steps.size(); si++) {
     const Plan::Step& st = P.steps[si];
     const size_t members = st.node.size();
     int rc = kOk;
+    const double t_begin = trace ? now_us() : 0.0;
+    struct TraceEnd {
+      bool on;
+      double t0;
+      hipStream_t s;
+      const char* name;
+      size_t members;
+      decltype(now_us)& now;
+      ~TraceEnd() {
+        if (!on) return;
+        const double t1 = now();
+        (void)hipStreamSynchronize(s);
+        const double t2 = now();
+        fprintf(stderr, "[program] %-12s members=%zu host %.0f us, drained after %.0f us\n", name, members, t1 - t0, t2 - t0);
+      }
+    } trace_end{trace, t_begin, s, step_names[st.kind], members, now_us};
     switch (st.kind) {
       case kStepNary: {
         std::vector<NaryOut> outs;
