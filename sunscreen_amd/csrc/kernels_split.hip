@@ -352,7 +352,10 @@ __device__ __forceinline__ void mid_inverse(const A& ar, typename A::V (&v)[kBlk
 // of twiddle fetches per pass serves all NP polynomials, their butterflies are independent instruction streams
 // the scheduler can interleave, and the NP global loads / stores are in flight together.  smem: NP regions of
 // BLOCK elements.
-template <class A, int L, int P, int NP, int EPT = kBlkEPT>
+// PIPE: the next pass's twiddles are fetched before the LDS exchange that precedes it (two sets live: 2 * (EPT - 1) twiddles);
+// false: every pass fetches its own after the exchange (one set live) -- the register diet of the two-workgroups-per-CU
+// instantiations at N = 16384.
+template <class A, int L, int P, int NP, int EPT = kBlkEPT, bool PIPE = true>
 __device__ __forceinline__ void mid_forward_multi_p(const A& ar, typename A::V (&v)[NP][EPT], typename A::V* smem, u32 tid, u32 blk,
                                                     const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[EPT - 1]) {
   using Sh = SplitShape<L, EPT>;
@@ -373,25 +376,32 @@ __device__ __forceinline__ void mid_forward_multi_p(const A& ar, typename A::V (
     if ((mask >> P) & 1u) reduce_all(ar, v[i]);
     if ((mask >> (P + 16)) & 1u) reduce_all(ar, v[i]);
   }
+  if constexpr (PIPE || P == 0) {
 #pragma unroll
-  for (int i = 0; i < NP; i++) Pass::fwd_tw(ar, v[i], w);
+    for (int i = 0; i < NP; i++) Pass::fwd_tw(ar, v[i], w);
+  } else {
+    typename A::Tw wo[EPT - 1];
+    Pass::load_tw_fwd(wo, tid, blk, tw);
+#pragma unroll
+    for (int i = 0; i < NP; i++) Pass::fwd_tw(ar, v[i], wo);
+  }
   if constexpr (more) {
-    Next::load_tw_fwd(wn, tid, blk, tw);
+    if constexpr (PIPE) Next::load_tw_fwd(wn, tid, blk, tw);
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::store_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
-    mid_forward_multi_p<A, L, PN, NP, EPT>(ar, v, smem, tid, blk, tw, mask, wn);
+    mid_forward_multi_p<A, L, PN, NP, EPT, PIPE>(ar, v, smem, tid, blk, tw, mask, PIPE ? wn : w);
   }
 }
-template <class A, int L, int NP, int EPT = kBlkEPT>
+template <class A, int L, int NP, int EPT = kBlkEPT, bool PIPE = true>
 __device__ __forceinline__ void mid_forward_multi(const A& ar, typename A::V (&v)[NP][EPT], typename A::V* smem, u32 tid, u32 blk,
                                                   const typename A::Tw* tw, u32 mask) {
   using Pass = BlkPass<A, L, split_fwd_low(L, 0), split_fwd_radix(L, 0), EPT>;
   typename A::Tw w[EPT - 1];
   Pass::load_tw_fwd(w, tid, blk, tw);
-  mid_forward_multi_p<A, L, 0, NP, EPT>(ar, v, smem, tid, blk, tw, mask, w);
+  mid_forward_multi_p<A, L, 0, NP, EPT, PIPE>(ar, v, smem, tid, blk, tw, mask, w);
 }
 
-template <class A, int L, int P, int NP, int EPT = kBlkEPT>
+template <class A, int L, int P, int NP, int EPT = kBlkEPT, bool PIPE = true>
 __device__ __forceinline__ void mid_inverse_multi_p(const A& ar, typename A::V (&v)[NP][EPT], typename A::V* smem, u32 tid, u32 blk,
                                                     const typename A::Tw* tw, u32 mask, const typename A::Tw (&w)[EPT - 1]) {
   using Sh = SplitShape<L, EPT>;
@@ -412,22 +422,29 @@ __device__ __forceinline__ void mid_inverse_multi_p(const A& ar, typename A::V (
     if ((mask >> P) & 1u) reduce_all(ar, v[i]);
     if ((mask >> (P + 16)) & 1u) reduce_all(ar, v[i]);
   }
+  if constexpr (PIPE || P == 0) {
 #pragma unroll
-  for (int i = 0; i < NP; i++) Pass::inv_tw(ar, v[i], w);
+    for (int i = 0; i < NP; i++) Pass::inv_tw(ar, v[i], w);
+  } else {
+    typename A::Tw wo[EPT - 1];
+    Pass::load_tw_inv(wo, tid, blk, tw);
+#pragma unroll
+    for (int i = 0; i < NP; i++) Pass::inv_tw(ar, v[i], wo);
+  }
   if constexpr (more) {
-    Next::load_tw_inv(wn, tid, blk, tw);
+    if constexpr (PIPE) Next::load_tw_inv(wn, tid, blk, tw);
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::store_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
-    mid_inverse_multi_p<A, L, PN, NP, EPT>(ar, v, smem, tid, blk, tw, mask, wn);
+    mid_inverse_multi_p<A, L, PN, NP, EPT, PIPE>(ar, v, smem, tid, blk, tw, mask, PIPE ? wn : w);
   }
 }
-template <class A, int L, int NP, int EPT = kBlkEPT>
+template <class A, int L, int NP, int EPT = kBlkEPT, bool PIPE = true>
 __device__ __forceinline__ void mid_inverse_multi(const A& ar, typename A::V (&v)[NP][EPT], typename A::V* smem, u32 tid, u32 blk,
                                                   const typename A::Tw* tw, u32 mask) {
   using Pass = BlkPass<A, L, split_inv_low(L, 0), split_inv_radix(L, 0), EPT>;
   typename A::Tw w[EPT - 1];
   Pass::load_tw_inv(w, tid, blk, tw);
-  mid_inverse_multi_p<A, L, 0, NP, EPT>(ar, v, smem, tid, blk, tw, mask, w);
+  mid_inverse_multi_p<A, L, 0, NP, EPT, PIPE>(ar, v, smem, tid, blk, tw, mask, w);
 }
 
 constexpr int kHeadThreads = 256;
@@ -436,6 +453,9 @@ constexpr int kHeadThreads = 256;
 // the regions are small anyway and the extra barriers cost 37 %; at N = 16384 one workgroup fills the CU either way.
 #ifndef MID_FWD_PAIRS
 #define MID_FWD_PAIRS(L) ((L) == 13)
+#endif
+#ifndef MID_TW_PIPE  // mul_mid (pass-batched bodies): next pass's twiddles fetched before the exchange (a second set of twiddle registers)
+#define MID_TW_PIPE(L) true
 #endif
 #ifndef MID_WAVES_D
 #define MID_WAVES_D(L) ((L) == 13 ? 3 : 2)
@@ -451,6 +471,12 @@ constexpr int kHeadThreads = 256;
 #endif
 #ifndef KS_MID_WAVES
 #define KS_MID_WAVES(L) ((L) <= 13 ? 3 : 2)
+#endif
+#ifndef KS_TW_PIPE  // ks_mid: twiddles of the next pass fetched before the exchange (costs a second set of twiddle registers)
+#define KS_TW_PIPE(L) true
+#endif
+#ifndef KS_MAC_CHUNK  // ks_mid: key words loaded per accumulation step (elements; 8 = a whole window at once)
+#define KS_MAC_CHUNK(L) 8
 #endif
 #ifndef KS_PREFETCH  // ks_mid: digit pairs with the next pair's loads in flight (see the kernel); at which sizes
 #define KS_PREFETCH 0
@@ -859,19 +885,23 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
     for (int g = 0; g < Last::G; g++) {
       const u32 base = Last::elem(tid, blk, g, 0);
       constexpr int W = 1 << RL;
-      ulonglong2 ka[W / 2], kc[W / 2];
+      constexpr int CH = KS_MAC_CHUNK(L) < W ? KS_MAC_CHUNK(L) : W;  // key words in flight per step (register diet at N = 16384)
 #pragma unroll
-      for (int k = 0; k < W; k += 2) {
-        ka[k / 2] = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
-        kc[k / 2] = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
-      }
+      for (int c0 = 0; c0 < W; c0 += CH) {
+        ulonglong2 ka[CH / 2], kc[CH / 2];
 #pragma unroll
-      for (int h = 0; h < W / 2; h++) {
-        const int e = g * W + 2 * h;
-        acc[0][e] += ar.mul_var(v[e], ar.from_u64(ka[h].x));
-        acc[0][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(ka[h].y));
-        acc[1][e] += ar.mul_var(v[e], ar.from_u64(kc[h].x));
-        acc[1][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(kc[h].y));
+        for (int k = 0; k < CH; k += 2) {
+          ka[k / 2] = *reinterpret_cast<const ulonglong2*>(k0 + base + c0 + k);
+          kc[k / 2] = *reinterpret_cast<const ulonglong2*>(k1 + base + c0 + k);
+        }
+#pragma unroll
+        for (int h = 0; h < CH / 2; h++) {
+          const int e = g * W + c0 + 2 * h;
+          acc[0][e] += ar.mul_var(v[e], ar.from_u64(ka[h].x));
+          acc[0][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(ka[h].y));
+          acc[1][e] += ar.mul_var(v[e], ar.from_u64(kc[h].x));
+          acc[1][e + 1] += ar.mul_var(v[e + 1], ar.from_u64(kc[h].y));
+        }
       }
     }
     if ((J & 3u) == 3u) {
@@ -890,7 +920,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
     // out of the loop and keeps ~100 registers of them alive.  Re-materialise the pointer.
     const MulOpD* twf_j = twf;
     asm volatile("" : "+s"(twf_j));
-    mid_forward_multi<A, L, NP>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
+    mid_forward_multi<A, L, NP, kBlkEPT, KS_TW_PIPE(L)>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
 #pragma unroll
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
   };
@@ -935,7 +965,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
   constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
   using Out = BlkPass<A, L, LOWI, RI>;
   __syncthreads();
-  mid_inverse_multi<A, L, 2>(ar, acc, smem, tid, blk, twi, dm.split_inv_mask);
+  mid_inverse_multi<A, L, 2, kBlkEPT, KS_TW_PIPE(L)>(ar, acc, smem, tid, blk, twi, dm.split_inv_mask);
 #pragma unroll
   for (int c = 0; c < 2; c++) {
     double* dst = ACC + (((size_t)op * 2 + c) * KK + I) * Sh::N;
@@ -1397,7 +1427,7 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   }
   using Pair = typename A::V[2][EPT];
   if constexpr (SQUARE) {
-    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
+    mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
   } else if constexpr (MODE == 1) {
     // two pairs through 2 (of the 3) exchange regions: 48 KB of LDS per workgroup instead of 64 KB -> 3 workgroups per CU
     // The pair that is not being transformed would sit in 32 registers; one of its two polynomials waits in the third
@@ -1406,24 +1436,24 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
     typename A::V* park = smem + 2 * Sh::BLOCK + tid;
 #pragma unroll
     for (int e = 0; e < EPT; e++) park[e * Sh::TPB] = v[3][e];
-    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
+    mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
       v[3][e] = park[e * Sh::TPB];
       park[e * Sh::TPB] = v[0][e];
     }
-    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[2]), smem, tid, blk, twf, dm.split_fwd_mask);
+    mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&v[2]), smem, tid, blk, twf, dm.split_fwd_mask);
 #pragma unroll
     for (int e = 0; e < EPT; e++) v[0][e] = park[e * Sh::TPB];
   } else if constexpr (MODE == 2) {
-    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
+    mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
     load_poly(2);
     load_poly(3);
     __syncthreads();  // the first pair's last pass may still be reading the exchange buffer
-    mid_forward_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&v[2]), smem, tid, blk, twf, dm.split_fwd_mask);
+    mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&v[2]), smem, tid, blk, twf, dm.split_fwd_mask);
   } else {
-    mid_forward_multi<A, L, 4, EPT>(ar, v, smem, tid, blk, twf, dm.split_fwd_mask);
+    mid_forward_multi<A, L, 4, EPT, MID_TW_PIPE(L)>(ar, v, smem, tid, blk, twf, dm.split_fwd_mask);
   }
   typename A::V d[3][EPT];
 #pragma unroll
@@ -1441,11 +1471,11 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   __syncthreads();  // the last forward pass may still be reading the exchange buffer
   if constexpr (MODE == 2) {
     using One = typename A::V[1][EPT];
-    mid_inverse_multi<A, L, 2, EPT>(ar, *reinterpret_cast<Pair*>(&d[0]), smem, tid, blk, twi, dm.split_inv_mask);
+    mid_inverse_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&d[0]), smem, tid, blk, twi, dm.split_inv_mask);
     __syncthreads();
-    mid_inverse_multi<A, L, 1, EPT>(ar, *reinterpret_cast<One*>(&d[2]), smem, tid, blk, twi, dm.split_inv_mask);
+    mid_inverse_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<One*>(&d[2]), smem, tid, blk, twi, dm.split_inv_mask);
   } else {
-    mid_inverse_multi<A, L, 3, EPT>(ar, d, smem, tid, blk, twi, dm.split_inv_mask);
+    mid_inverse_multi<A, L, 3, EPT, MID_TW_PIPE(L)>(ar, d, smem, tid, blk, twi, dm.split_inv_mask);
   }
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -1477,14 +1507,18 @@ template <int L, bool POLICY_D>
 struct MulMidGeom {
   static constexpr int EPT = POLICY_D ? mid_ept_d(L) : kBlkEPT;
   static constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
-#ifdef MID_MODE_14  // experiment hook: exchange-region scheme of the FP64 middle kernel at N = 16384 (with MID_WAVES_14)
+#if defined(MID_MODE_OF)  // experiment hook: exchange-region scheme of the FP64 middle kernel per degree (with MID_WAVES_OF)
+  static constexpr int MODE = !POLICY_D ? 0 : MID_MODE_OF(L);
+#elif defined(MID_MODE_14)  // experiment hook: exchange-region scheme of the FP64 middle kernel at N = 16384 (with MID_WAVES_14)
   static constexpr int MODE = !POLICY_D ? 0 : (L == 14 ? MID_MODE_14 : EPT > kBlkEPT ? 2 : MID_FWD_PAIRS(L) ? 1 : 0);
 #else
   static constexpr int MODE = !POLICY_D ? 0 : EPT > kBlkEPT ? 2 : MID_FWD_PAIRS(L) ? 1 : 0;
 #endif
   static constexpr int REGIONS = !batched ? 1 : MODE == 2 ? 2 : MODE == 1 ? 3 : 4;
   static constexpr int TPB = SplitShape<L, EPT>::TPB;
-#ifdef MID_WAVES_14
+#if defined(MID_WAVES_OF)
+  static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : MID_WAVES_OF(L);
+#elif defined(MID_WAVES_14)
   static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : L == 14 ? MID_WAVES_14 : MID_WAVES_D(L);
 #else
   static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : EPT > kBlkEPT ? 2 : MID_WAVES_D(L);

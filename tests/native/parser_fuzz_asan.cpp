@@ -2,8 +2,8 @@
 // AddressSanitizer + UndefinedBehaviorSanitizer and fed mutated inputs through their internal C++ entry points: reads past a
 // buffer, overflows and leaks that a plain run survives are reported.  Built and run by tests/test_decoder_fuzz_cpu.py:
 //   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Isunscreen_amd/csrc -x c++ \
-//       tests/native/parser_fuzz_asan.cpp sunscreen_amd/csrc/wire.cpp sunscreen_amd/csrc/program.cpp -ldl -Wl,--unresolved-symbols=ignore-all
-// (program.cpp also holds the executor, whose device calls stay unresolved and uncalled).  argv: seed, iterations, JSON seed files.
+//       tests/native/parser_fuzz_asan.cpp sunscreen_amd/csrc/wire.cpp sunscreen_amd/csrc/program.cpp sunscreen_amd/csrc/program_plan.cpp -ldl -Wl,--unresolved-symbols=ignore-all
+// (program.cpp / program_plan.cpp also hold the executors, whose device calls stay unresolved and uncalled).  argv: seed, iterations, JSON seed files.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

@@ -118,7 +118,7 @@ def test_parsers_are_clean_under_address_and_ub_sanitizers(tmp_path):
     csrc = os.path.join(ROOT, "sunscreen_amd", "csrc")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
                            "-I/opt/rocm/include", "-I", csrc, "-x", "c++", os.path.join(ROOT, "tests", "native", "parser_fuzz_asan.cpp"),
-                           os.path.join(csrc, "wire.cpp"), os.path.join(csrc, "program.cpp"), "-ldl", "-Wl,--unresolved-symbols=ignore-all", "-o", exe],
+                           os.path.join(csrc, "wire.cpp"), os.path.join(csrc, "program.cpp"), os.path.join(csrc, "program_plan.cpp"), "-ldl", "-Wl,--unresolved-symbols=ignore-all", "-o", exe],
                           stderr=subprocess.DEVNULL)
     out = subprocess.run([exe, "7", "4000"] + seeds, capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0 and "asan fuzz ok" in out.stdout, (out.returncode, out.stdout[-300:], out.stderr[-3000:])
