@@ -772,7 +772,7 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
   {
     size_t need = 0;
     for (const Plan::Step& st : P.steps) {
-      need += (st.node.size() + 1) * sizeof(NaryOut) + st.terms.size() * sizeof(NaryTerm) + st.plain.size() * sizeof(PlainNttRef) +
+      need += (st.node.size() + 1 + st.terms.size() / 8) * sizeof(NaryOut) + 2 * st.terms.size() * sizeof(NaryTerm) + st.plain.size() * sizeof(PlainNttRef) +
               (st.a.size() + st.b.size() + st.cts.size() + 4) * sizeof(u64*) + 512;
     }
     if (!arena.reserve(need + 4096)) return cleanup(kOutOfMemory, "descriptor table allocation failed");
@@ -901,26 +901,63 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
     } trace_end{trace, t_begin, s, step_names[st.kind], members, now_us};
     switch (st.kind) {
       case kStepNary: {
-        std::vector<NaryOut> outs;
-        std::vector<NaryTerm> terms;
-        u32 max_size = 0;
+        // A long sum (examples/pir: 256 products into one ciphertext) is one output per thread column: its terms are added
+        // one after the other.  Sums of more than kLongSum terms go in two levels -- partial sums of kSumChunk terms, which
+        // are many independent outputs, then the sum of the partials (modular addition is associative: same bits).
+        constexpr u32 kLongSum = 32, kSumChunk = 16;
+        std::vector<NaryOut> pre_outs, outs;
+        std::vector<NaryTerm> pre_terms, terms;
+        u32 max_size = 0, pre_max = 0;
         const std::vector<int>& fv = folded_into[si];
         for (size_t m = 0; m < members; m++) {
           if (!fv.empty() && fv[m] >= 0) continue;  // its producer already added the other operand and wrote this slot
           const int osl = st.out[m];
           u64* o = alloc_member(osl);
           if (!o) return cleanup(kOutOfMemory, "out of device memory");
+          const u32 count = st.first[m + 1] - st.first[m], osz = P.slot_size[osl];
           NaryOut d;
           d.out = o;
           d.first = (u32)terms.size();
-          d.count = st.first[m + 1] - st.first[m];
-          d.size = P.slot_size[osl];
+          d.size = osz;
           d.pad = 0;
-          max_size = std::max(max_size, d.size);
-          for (u32 t = st.first[m]; t < st.first[m + 1]; t++) terms.push_back(NaryTerm{sp[st.terms[t].slot], P.slot_size[st.terms[t].slot], st.terms[t].sign});
+          max_size = std::max(max_size, osz);
+          if (count > kLongSum) {
+            const u32 chunks = (count + kSumChunk - 1) / kSumChunk;
+            u64* part = (u64*)pool.acquire((size_t)chunks * batch * osz * poly * sizeof(u64), s);
+            if (!part) return cleanup(kOutOfMemory, "out of device memory");
+            temps.push_back(part);
+            pre_max = std::max(pre_max, osz);
+            for (u32 c = 0; c < chunks; c++) {
+              NaryOut pd;
+              pd.out = part + (size_t)c * batch * osz * poly;
+              pd.first = (u32)pre_terms.size();
+              pd.count = std::min(kSumChunk, count - c * kSumChunk);
+              pd.size = osz;
+              pd.pad = 0;
+              for (u32 t = 0; t < pd.count; t++) {
+                const Term& tm = st.terms[st.first[m] + c * kSumChunk + t];
+                pre_terms.push_back(NaryTerm{sp[tm.slot], P.slot_size[tm.slot], tm.sign});
+              }
+              pre_outs.push_back(pd);
+              terms.push_back(NaryTerm{pd.out, osz, 1});
+            }
+            d.count = chunks;
+          } else {
+            d.count = count;
+            for (u32 t = st.first[m]; t < st.first[m + 1]; t++) terms.push_back(NaryTerm{sp[st.terms[t].slot], P.slot_size[st.terms[t].slot], st.terms[t].sign});
+          }
           outs.push_back(d);
         }
         if (outs.empty()) break;
+        if (!pre_outs.empty()) {
+          const NaryOut* dpo = (const NaryOut*)stage_table(pre_outs.data(), pre_outs.size() * sizeof(NaryOut));
+          const NaryTerm* dpt = (const NaryTerm*)stage_table(pre_terms.data(), pre_terms.size() * sizeof(NaryTerm));
+          if (!dpo || !dpt) return cleanup(kOutOfMemory, "descriptor table allocation failed");
+          ev.profiler().begin(kKernEltwise, pre_outs.size() * batch * pre_max * K, s);
+          const hipError_t e = launch_nary_sum(ctx->dev(), (u32)n, (u32)K, dpo, dpt, (u32)pre_outs.size(), pre_max, (u32)batch, s);
+          ev.profiler().end(s);
+          if (e != hipSuccess) return cleanup(kHipError, "operation failed");
+        }
         const NaryOut* douts = (const NaryOut*)stage_table(outs.data(), outs.size() * sizeof(NaryOut));
         const NaryTerm* dterms = (const NaryTerm*)stage_table(terms.data(), terms.size() * sizeof(NaryTerm));
         if (!douts || !dterms) return cleanup(kOutOfMemory, "descriptor table allocation failed");
@@ -1012,6 +1049,58 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
         // out[row] = sum_j cts[j] (.) plain[row][j]: transform the ciphertexts once, accumulate in the transform domain, one inverse per row
         const size_t cols = st.cts.size(), rows = members;
         const size_t ct_words = batch * 2 * poly;
+        // The plaintexts first (host work, then one table upload) so that the device is not left waiting for the table between
+        // the ciphertext transforms and the product.  Transform-domain arguments are used as they are; coefficient-form ones
+        // are lifted and transformed now (runs of adjacent plaintexts in one call), and an all-zero one raises the
+        // transparent-result failure SEAL's multiply_plain raises.
+        const size_t entries = rows * cols;
+        std::vector<PlainNttRef> tab(entries);
+        size_t need_ntt = 0;
+        for (size_t e = 0; e < entries; e++) {
+          const Node& nd = nodes_[st.plain[e]];
+          if (nd.op == kOpInputPlaintext && nd.arg < num_inputs && inputs[nd.arg].kind == 2 && inputs[nd.arg].ptr) {  // the common case, kept tight
+            tab[e] = PlainNttRef{inputs[nd.arg].ptr, (u64)inputs[nd.arg].stride};
+            continue;
+          }
+          PlainVal v;
+          if (const char* m = plain_of(st.plain[e], &v)) return cleanup(kInvalidArg, m);
+          tab[e] = PlainNttRef{nullptr, 0};  // filled below
+          need_ntt += v.stride ? batch : 1;
+        }
+        if (need_ntt) {
+          u64* pscratch = (u64*)pool.acquire(need_ntt * poly * sizeof(u64), s);
+          if (!pscratch) return cleanup(kOutOfMemory, "out of device memory");
+          temps.push_back(pscratch);
+          size_t pos = 0;
+          for (size_t e = 0; e < entries;) {
+            if (tab[e].ptr) {
+              e++;
+              continue;
+            }
+            PlainVal v;
+            (void)plain_of(st.plain[e], &v);
+            if (v.stride) {  // per-item plaintexts u64[batch][N]
+              if ((rc = ev.plain_to_ntt(v.ptr, v.stride, pscratch + pos * poly, batch, s, 1))) return cleanup(rc, "operation failed");
+              tab[e] = PlainNttRef{pscratch + pos * poly, (u64)poly};
+              pos += batch;
+              e++;
+              continue;
+            }
+            size_t run = 1;  // shared plaintexts that sit next to each other in memory: one lift + transform launch for the run
+            while (e + run < entries && !tab[e + run].ptr) {
+              PlainVal w;
+              (void)plain_of(st.plain[e + run], &w);
+              if (w.stride || w.ptr != v.ptr + run * n) break;
+              run++;
+            }
+            if ((rc = ev.plain_to_ntt(v.ptr, n, pscratch + pos * poly, run, s, 2))) return cleanup(rc, "operation failed");
+            for (size_t r = 0; r < run; r++) tab[e + r] = PlainNttRef{pscratch + (pos + r) * poly, 0};
+            pos += run;
+            e += run;
+          }
+        }
+        const PlainNttRef* dtab = (const PlainNttRef*)stage_table(tab.data(), tab.size() * sizeof(PlainNttRef));
+        if (!dtab) return cleanup(kOutOfMemory, "descriptor table allocation failed");
         const u64* staged = nullptr;
         {
           // always a copy: the transform runs in place.  Adjacent operands are copied with one memcpy.
@@ -1023,56 +1112,18 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
           if (adjacent) {
             if (hipMemcpyAsync(ctn, sp[st.cts[0]], cols * ct_words * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess) return cleanup(kHipError, "copy failed");
           } else {
-            std::vector<const u64*> tab(cols);
-            for (size_t j = 0; j < cols; j++) tab[j] = sp[st.cts[j]];
-            const u64* const* dtab = (const u64* const*)stage_table(tab.data(), cols * sizeof(u64*));
-            if (!dtab) return cleanup(kOutOfMemory, "descriptor table allocation failed");
+            std::vector<const u64*> ctab(cols);
+            for (size_t j = 0; j < cols; j++) ctab[j] = sp[st.cts[j]];
+            const u64* const* dctab = (const u64* const*)stage_table(ctab.data(), cols * sizeof(u64*));
+            if (!dctab) return cleanup(kOutOfMemory, "descriptor table allocation failed");
             for (size_t off = 0; off < cols; off += 65535) {
               const size_t c = std::min<size_t>(65535, cols - off);
-              if (launch_gather_items(dtab + off, ctn + off * ct_words, ct_words, c, s) != hipSuccess) return cleanup(kHipError, "operation failed");
+              if (launch_gather_items(dctab + off, ctn + off * ct_words, ct_words, c, s) != hipSuccess) return cleanup(kHipError, "operation failed");
             }
           }
           if ((rc = ev.ct_to_ntt(ctn, 2, ctn, cols * batch, s))) return cleanup(rc, "operation failed");
           staged = ctn;
         }
-        // the plaintexts: transform-domain arguments as they are; coefficient-form ones are lifted and transformed now (runs of
-        // adjacent plaintexts in one call), and an all-zero one raises the transparent-result failure SEAL's multiply_plain raises
-        std::vector<PlainNttRef> tab(rows * cols);
-        std::vector<PlainVal> pv(rows * cols);
-        size_t need_ntt = 0;
-        for (size_t e = 0; e < rows * cols; e++) {
-          if (const char* m = plain_of(st.plain[e], &pv[e])) return cleanup(kInvalidArg, m);
-          if (pv[e].kind == 1) need_ntt += pv[e].stride ? batch : 1;
-        }
-        u64* pscratch = nullptr;
-        if (need_ntt) {
-          pscratch = (u64*)pool.acquire(need_ntt * poly * sizeof(u64), s);
-          if (!pscratch) return cleanup(kOutOfMemory, "out of device memory");
-          temps.push_back(pscratch);
-        }
-        size_t pos = 0;
-        for (size_t e = 0; e < rows * cols;) {
-          if (pv[e].kind == 2) {
-            tab[e] = PlainNttRef{pv[e].ptr, (u64)pv[e].stride};
-            e++;
-            continue;
-          }
-          if (pv[e].stride) {  // per-item plaintexts u64[batch][N]
-            if ((rc = ev.plain_to_ntt(pv[e].ptr, pv[e].stride, pscratch + pos * poly, batch, s, 1))) return cleanup(rc, "operation failed");
-            tab[e] = PlainNttRef{pscratch + pos * poly, (u64)poly};
-            pos += batch;
-            e++;
-            continue;
-          }
-          size_t run = 1;  // shared plaintexts that sit next to each other in memory: one lift + transform launch for the run
-          while (e + run < rows * cols && pv[e + run].kind == 1 && !pv[e + run].stride && pv[e + run].ptr == pv[e].ptr + run * n) run++;
-          if ((rc = ev.plain_to_ntt(pv[e].ptr, n, pscratch + pos * poly, run, s, 2))) return cleanup(rc, "operation failed");
-          for (size_t r = 0; r < run; r++) tab[e + r] = PlainNttRef{pscratch + (pos + r) * poly, 0};
-          pos += run;
-          e += run;
-        }
-        const PlainNttRef* dtab = (const PlainNttRef*)stage_table(tab.data(), tab.size() * sizeof(PlainNttRef));
-        if (!dtab) return cleanup(kOutOfMemory, "descriptor table allocation failed");
         const int blk = new_block(rows * ct_words);
         if (blk < 0) return cleanup(kOutOfMemory, "out of device memory");
         u64* out = (u64*)blocks[blk].ptr;
