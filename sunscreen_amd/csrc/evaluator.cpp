@@ -169,8 +169,10 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   const DevCtx& h = ctx_->host();
   const size_t R = h.K + h.S;
   const size_t per_op = (size_t)(4 * R + 3 * R + 3 * h.K + (size_t)h.KK * h.K + 2 * h.KK) * h.n * sizeof(u64);
-  // up to 8 GiB of scratch per chunk (of 288 GB): launches of >= 1024 ops amortise the tail of each kernel
-  size_t c = ((size_t)8 << 30) / per_op;
+  // up to 32 GiB of scratch per chunk (of 288 GB): launches of 1024 ops at every degree up to N = 16384.  Measured at N = 16384
+  // (r03, one box): chunks of 256 / 512 / 1024 ops give 49.6 / 50.2 / 51.3 K mul+relin/s -- a longer walk over one key slice
+  // per XCD in ks_mid (5.86 -> 5.48 ms) and fewer launch tails; the 8 GiB cap of rounds 1-2 meant 292 ops there.
+  size_t c = ((size_t)32 << 30) / per_op;
   if (const char* env = std::getenv("HIPBFV_CHUNK_OPS")) c = (size_t)std::strtoull(env, nullptr, 10);
   chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 1024));
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS")) split_ks_ = env[0] != '1';

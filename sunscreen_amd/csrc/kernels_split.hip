@@ -467,10 +467,17 @@ constexpr int kHeadThreads = 256;
 // allocation aims at.  Pairs + 3 waves: -5.5 % at N = 8192, -11 % at N = 4096; at N = 16384 (32 KB regions, K = 8) groups
 // of four at 2 waves stay faster (+4 % the other way).
 #ifndef KS_GROUP_MAX
-#define KS_GROUP_MAX(L) ((L) <= 13 ? 2 : 4)
+#define KS_GROUP_MAX(L) ((L) <= 13 || HIPBFV_GEOM14 == 4 ? 2 : 4)
 #endif
 #ifndef KS_MID_WAVES
 #define KS_MID_WAVES(L) ((L) <= 13 ? 3 : 2)
+#endif
+// r03, N = 16384: 16 elements per thread (256-thread workgroups) with the digits in PAIRS: 64 KB of LDS and 256 registers per
+// workgroup, two workgroups per CU whose load / compute / store phases overlap -- ks_mid 5.53 -> 5.29 ms per 1024 ops
+// (interleaved A/B; the first configuration with two resident workgroups that does not spill: two 512-thread workgroups would
+// have to live in 128 registers each, and every such variant spilt and lost 4-11 %).  One digit at a time (32 KB) is slower (5.93).
+#ifndef KS_EPT  // ks_mid (FP64 policy): elements per thread
+#define KS_EPT(L) ((L) == 14 && HIPBFV_GEOM14 == 4 ? 16 : kBlkEPT)
 #endif
 #ifndef KS_TW_PIPE  // ks_mid: twiddles of the next pass fetched before the exchange (costs a second set of twiddle registers)
 #define KS_TW_PIPE(L) true
@@ -838,12 +845,14 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
 // -------------------------------------------------------------------------------------------------
 // residues / nres: the key-prime indices this launch handles (DevCtx::ks_res_d: the FP64-policy ones, all of them for the
 // SEAL default sets; the integer-policy ones go through ks_mid_int_kernel below)
-template <int L, bool PACK>
-__global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+// EPT (KS_EPT(L), experiment hook): elements per thread; 16 = two radix-8 groups per thread and half the threads per workgroup
+// (N = 16384: 256-thread workgroups, of which two fit a CU's registers without the 128-VGPR ceiling of two 512-thread ones)
+template <int L, bool PACK, int EPT = KS_EPT(L)>
+__global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                        const MulOp* __restrict__ twi_base, const double* __restrict__ T,
                                                                        const u64* __restrict__ key, double* __restrict__ ACC, u32 ops,
                                                                        const unsigned char* __restrict__ residues, u32 nres) {
-  using Sh = SplitShape<L>;
+  using Sh = SplitShape<L, EPT>;
   using A = ArithD;
   __shared__ double smem[KS_GROUP_MAX(L) * Sh::BLOCK];
   const u32 tid = threadIdx.x;
@@ -864,13 +873,13 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
   const MulOpD* twf = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * Sh::N);
   const MulOpD* twi = reinterpret_cast<const MulOpD*>(twi_base + (size_t)I * Sh::N);
   constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
-  using First = BlkPass<A, L, LOWF0, RF0>;
+  using First = BlkPass<A, L, LOWF0, RF0, EPT>;
   constexpr int RL = split_fwd_radix(L, Sh::NPF - 1);  // last forward window: LOW = 0
-  using Last = BlkPass<A, L, 0, RL>;
-  double acc[2][kBlkEPT];
+  using Last = BlkPass<A, L, 0, RL, EPT>;
+  double acc[2][EPT];
 #pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) acc[0][e] = 0.0, acc[1][e] = 0.0;
-  auto load_src = [&](u32 J, double(&dst)[kBlkEPT]) {
+  for (int e = 0; e < EPT; e++) acc[0][e] = 0.0, acc[1][e] = 0.0;
+  auto load_src = [&](u32 J, double(&dst)[EPT]) {
     const double* src = T + (((size_t)op * KK + I) * K + J) * Sh::N;
 #pragma unroll
     for (int g = 0; g < First::G; g++)
@@ -878,7 +887,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
       for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = nat_load<PACK, NtSites<L>::ks_mid_ld>(src, Sh::N, First::elem(tid, blk, g, k));
   };
   // key rows of digit J for the group g of the last forward window (the elements this thread holds): 16-byte loads
-  auto mac = [&](u32 J, const double(&v)[kBlkEPT]) {
+  auto mac = [&](u32 J, const double(&v)[EPT]) {
     const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
     const u64* k1 = key + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
 #pragma unroll
@@ -905,14 +914,14 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
       }
     }
     if ((J & 3u) == 3u) {
-      reduce_all(ar, acc[0]);
-      reduce_all(ar, acc[1]);
+      reduce_all<A, EPT>(ar, acc[0]);
+      reduce_all<A, EPT>(ar, acc[1]);
     }
   };
   // digits are transformed in groups of 4 / 2 / 1, each group advanced pass by pass (mid_forward_multi)
   auto group = [&](u32 J0, auto np_tag) {
     constexpr int NP = decltype(np_tag)::value;
-    double v[NP][kBlkEPT];
+    double v[NP][EPT];
 #pragma unroll
     for (int i = 0; i < NP; i++) load_src(J0 + i, v[i]);
     if (J0 > 0) __syncthreads();  // the previous group's last pass may still be reading LDS
@@ -920,7 +929,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
     // out of the loop and keeps ~100 registers of them alive.  Re-materialise the pointer.
     const MulOpD* twf_j = twf;
     asm volatile("" : "+s"(twf_j));
-    mid_forward_multi<A, L, NP, kBlkEPT, KS_TW_PIPE(L)>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
+    mid_forward_multi<A, L, NP, EPT, KS_TW_PIPE(L)>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
 #pragma unroll
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
   };
@@ -930,7 +939,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
     // pairs of digits with the NEXT pair's rows requested before the current pair is transformed: the loads travel while the
     // first passes (scalar twiddles: no vmcnt wait) run.  One workgroup per CU is resident at this size, so nothing else
     // covers its load latency.
-    double cur[2][kBlkEPT], nxt[2][kBlkEPT];
+    double cur[2][EPT], nxt[2][EPT];
     if (K >= 2) {
       load_src(0, cur[0]);
       load_src(1, cur[1]);
@@ -944,12 +953,12 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
       if (J > 0) __syncthreads();
       const MulOpD* twf_j = twf;
       asm volatile("" : "+s"(twf_j));
-      mid_forward_multi<A, L, 2>(ar, cur, smem, tid, blk, twf_j, dm.split_fwd_mask);
+      mid_forward_multi<A, L, 2, EPT>(ar, cur, smem, tid, blk, twf_j, dm.split_fwd_mask);
       mac(J, cur[0]);
       mac(J + 1, cur[1]);
       if (more) {
 #pragma unroll
-        for (int e = 0; e < kBlkEPT; e++) cur[0][e] = nxt[0][e], cur[1][e] = nxt[1][e];
+        for (int e = 0; e < EPT; e++) cur[0][e] = nxt[0][e], cur[1][e] = nxt[1][e];
       }
     }
     if (J < K) group(J, std::integral_constant<int, 1>{});
@@ -958,14 +967,22 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), KS_MID_WAVES(L)) void ks_mid_
 #endif
   if constexpr (KS_GROUP_MAX(L) >= 4)
     for (; J + 4 <= K; J += 4) group(J, std::integral_constant<int, 4>{});
-  for (; J + 2 <= K; J += 2) group(J, std::integral_constant<int, 2>{});
-  if (J < K) group(J, std::integral_constant<int, 1>{});
-  reduce_all(ar, acc[0]);
-  reduce_all(ar, acc[1]);
+  if constexpr (KS_GROUP_MAX(L) >= 2)
+    for (; J + 2 <= K; J += 2) group(J, std::integral_constant<int, 2>{});
+  for (; J < K; J++) group(J, std::integral_constant<int, 1>{});
+  reduce_all<A, EPT>(ar, acc[0]);
+  reduce_all<A, EPT>(ar, acc[1]);
   constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
-  using Out = BlkPass<A, L, LOWI, RI>;
+  using Out = BlkPass<A, L, LOWI, RI, EPT>;
   __syncthreads();
-  mid_inverse_multi<A, L, 2, kBlkEPT, KS_TW_PIPE(L)>(ar, acc, smem, tid, blk, twi, dm.split_inv_mask);
+  if constexpr (KS_GROUP_MAX(L) >= 2) {
+    mid_inverse_multi<A, L, 2, EPT, KS_TW_PIPE(L)>(ar, acc, smem, tid, blk, twi, dm.split_inv_mask);
+  } else {
+    using One = double[1][EPT];
+    mid_inverse_multi<A, L, 1, EPT, KS_TW_PIPE(L)>(ar, *reinterpret_cast<One*>(&acc[0]), smem, tid, blk, twi, dm.split_inv_mask);
+    __syncthreads();
+    mid_inverse_multi<A, L, 1, EPT, KS_TW_PIPE(L)>(ar, *reinterpret_cast<One*>(&acc[1]), smem, tid, blk, twi, dm.split_inv_mask);
+  }
 #pragma unroll
   for (int c = 0; c < 2; c++) {
     double* dst = ACC + (((size_t)op * 2 + c) * KK + I) * Sh::N;
@@ -1502,10 +1519,15 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 #ifndef MID_EPT_14
 #define MID_EPT_14 8
 #endif
-constexpr int mid_ept_d(int logn) { return logn == 14 ? MID_EPT_14 : kBlkEPT; }
-template <int L, bool POLICY_D>
+// The SQUARING instantiation at N = 16384 does take 16 (r03): two transforms instead of four fit the 256 registers of two
+// 256-thread workgroups per CU without scratch (MID_EPT_14_SQ).
+#ifndef MID_EPT_14_SQ
+#define MID_EPT_14_SQ (HIPBFV_GEOM14 == 4 ? 16 : 8)
+#endif
+constexpr int mid_ept_d(int logn, bool square) { return logn == 14 ? (square ? MID_EPT_14_SQ : MID_EPT_14) : kBlkEPT; }
+template <int L, bool POLICY_D, bool SQUARE = false>
 struct MulMidGeom {
-  static constexpr int EPT = POLICY_D ? mid_ept_d(L) : kBlkEPT;
+  static constexpr int EPT = POLICY_D ? mid_ept_d(L, SQUARE) : kBlkEPT;
   static constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
 #if defined(MID_MODE_OF)  // experiment hook: exchange-region scheme of the FP64 middle kernel per degree (with MID_WAVES_OF)
   static constexpr int MODE = !POLICY_D ? 0 : MID_MODE_OF(L);
@@ -1525,10 +1547,10 @@ struct MulMidGeom {
 #endif
 };
 template <int L, bool POLICY_D, bool PACK, bool SQUARE = false>
-__global__ __launch_bounds__((MulMidGeom<L, POLICY_D>::TPB), (MulMidGeom<L, POLICY_D>::WAVES)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+__global__ __launch_bounds__((MulMidGeom<L, POLICY_D, SQUARE>::TPB), (MulMidGeom<L, POLICY_D, SQUARE>::WAVES)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                            const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
                                                                            u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres) {
-  using Geo = MulMidGeom<L, POLICY_D>;
+  using Geo = MulMidGeom<L, POLICY_D, SQUARE>;
   using Sh = SplitShape<L, Geo::EPT>;
   constexpr bool batched = Geo::batched;
   __shared__ u64 smem[Geo::REGIONS * Sh::BLOCK];
@@ -2017,9 +2039,9 @@ static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi
   if (nd) {
     const dim3 grid((unsigned)(ops8 * nd * Sh::NBLK));
     if (pack)
-      ks_mid_kernel<L, true><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd);
+      ks_mid_kernel<L, true><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd);
     else
-      ks_mid_kernel<L, false><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd);
+      ks_mid_kernel<L, false><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd);
   }
   if (ni) {
     const dim3 grid((unsigned)(ops8 * ni * Sh::NBLK));
@@ -2085,8 +2107,9 @@ static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* tw
   constexpr unsigned TD = MulMidGeom<L, true>::TPB, TI = MulMidGeom<L, false>::TPB;
 #if MUL_SQUARE
   if (square) {
-    if (nd && pack) mul_mid_kernel<L, true, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
-    if (nd && !pack) mul_mid_kernel<L, true, false, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+    constexpr unsigned TS = MulMidGeom<L, true, true>::TPB;
+    if (nd && pack) mul_mid_kernel<L, true, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TS, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+    if (nd && !pack) mul_mid_kernel<L, true, false, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TS, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
     if (ni) mul_mid_kernel<L, false, false, true><<<dim3((unsigned)(ops * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
     return hipGetLastError();
   }

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+bash tools/ab_libs.sh "prev" --n 16384 --batch 1024 --steps 5 --warmup 2
+bash tools/ab_libs.sh "prev" --workload chi_sq --n 16384 --batch 256 --steps 3 --warmup 1
+bash tools/ab_libs.sh "prev" --workload dot_prod --n 16384 --batch 256 --steps 3 --warmup 1
