@@ -1422,8 +1422,10 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
   using Out = BlkPass<A, L, LOWI, RI, EPT>;
   typename A::V v[4][EPT];
+  const typename A::V* ext_p = ext_r;  // re-materialised (pin_loads) where a load must not be scheduled above the transform before it
+  auto pin_loads = [&]() { asm volatile("" : "+s"(ext_p) : : "memory"); };
   auto load_poly = [&](int i) {
-    const typename A::V* src = ext_r + (size_t)i * poly_stride;
+    const typename A::V* src = ext_p + (size_t)i * poly_stride;
 #pragma unroll
     for (int g = 0; g < First::G; g++)
 #pragma unroll
@@ -1436,13 +1438,85 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   };
   // MODE 2 loads the second pair only after the first pair's transform: at 16 elements per thread the four operands are 128
   // registers, and holding all of them through the first transform spills (the other resident workgroup covers the latency)
+  using Pair = typename A::V[2][EPT];
+  using One = typename A::V[1][EPT];
+  if constexpr (MODE == 3 && !SQUARE) {
+    // 16 elements per thread, two 256-thread workgroups per CU (r03): the four operands never sit in registers together, and
+    // each product polynomial leaves as soon as it is complete.  (a0, b0) are transformed as a pair, d0 = a0 b0 is taken
+    // through its inverse transform and stored at once; b1 is transformed alone, d1 = a0 b1; a1 alone, d1 += a1 b0,
+    // d2 = a1 b1; (d1, d2) are inverse-transformed as a pair.  Live at the worst point: two operands, one product, the
+    // transform in flight and one set of twiddles -- 184 of the 256 registers.  Two exchange regions (64 KB).
+    auto store_poly = [&](int i, const typename A::V(&dv)[EPT]) {
+      typename A::V* dst = D_r + (size_t)i * dpoly_stride;
+#pragma unroll
+      for (int g = 0; g < Out::G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << RI); k++) {
+          if constexpr (PACK && std::is_same<A, ArithD>::value)
+            nat_store<true, NtSites<L>::mul_mid_st>(dst, Sh::N, Out::elem(tid, blk, g, k), ar.reduce(dv[g * (1 << RI) + k]));
+          else
+            nt_st<NtSites<L>::mul_mid_st>(dst + Out::elem(tid, blk, g, k), dv[g * (1 << RI) + k]);
+        }
+    };
+    auto fresh = [&](const typename A::Tw* tw) {  // keep one transform's twiddle fetches from being merged with another's
+      asm volatile("" : "+s"(tw));
+      return tw;
+    };
+    auto load_into = [&](int i, typename A::V(&dst)[EPT]) {
+      const typename A::V* src = ext_p + (size_t)i * poly_stride;
+#pragma unroll
+      for (int g = 0; g < First::G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << RF0); k++) {
+          if constexpr (PACK && std::is_same<A, ArithD>::value)
+            dst[g * (1 << RF0) + k] = nat_load<true, NtSites<L>::mul_mid_ld>(src, Sh::N, First::elem(tid, blk, g, k));
+          else
+            dst[g * (1 << RF0) + k] = nt_ld<NtSites<L>::mul_mid_ld>(src + First::elem(tid, blk, g, k));
+        }
+    };
+    typename A::V ab[2][EPT];  // (a0, b0); b1 later takes a0's place
+    load_into(0, ab[0]);
+    load_into(2, ab[1]);
+    mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, ab, smem, tid, blk, twf, dm.split_fwd_mask);
+    {
+      typename A::V d0[1][EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; e++) d0[0][e] = ar.mul_var(ab[0][e], ab[1][e]);
+      __syncthreads();  // the pair's last forward pass may still be reading the exchange buffer
+      mid_inverse_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, d0, smem, tid, blk, fresh(twi), dm.split_inv_mask);
+      store_poly(0, d0[0]);
+    }
+    typename A::V x[1][EPT], d12[2][EPT];
+    pin_loads();
+    load_into(3, x[0]);
+    __syncthreads();
+    mid_forward_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, x, smem, tid, blk, fresh(twf), dm.split_fwd_mask);  // b1
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      d12[0][e] = ar.mul_var(ab[0][e], x[0][e]);  // a0 b1
+      ab[0][e] = x[0][e];                          // b1 takes a0's place
+    }
+    pin_loads();
+    load_into(1, x[0]);
+    __syncthreads();
+    mid_forward_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, x, smem, tid, blk, fresh(twf), dm.split_fwd_mask);  // a1
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      d12[0][e] = ar.mul_add(x[0][e], ab[1][e], d12[0][e]);  // + a1 b0
+      d12[1][e] = ar.mul_var(x[0][e], ab[0][e]);              // a1 b1
+    }
+    __syncthreads();
+    mid_inverse_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, d12, smem, tid, blk, fresh(twi), dm.split_inv_mask);
+    store_poly(1, d12[0]);
+    store_poly(2, d12[1]);
+    return;
+  }
   load_poly(0);
   load_poly(1);
   if constexpr (MODE != 2 && !SQUARE) {
     load_poly(2);
     load_poly(3);
   }
-  using Pair = typename A::V[2][EPT];
   if constexpr (SQUARE) {
     mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
   } else if constexpr (MODE == 1) {
@@ -1486,8 +1560,7 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
     }
   }
   __syncthreads();  // the last forward pass may still be reading the exchange buffer
-  if constexpr (MODE == 2) {
-    using One = typename A::V[1][EPT];
+  if constexpr (MODE == 2 || MODE == 3) {
     mid_inverse_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&d[0]), smem, tid, blk, twi, dm.split_inv_mask);
     __syncthreads();
     mid_inverse_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<One*>(&d[2]), smem, tid, blk, twi, dm.split_inv_mask);
@@ -1534,9 +1607,9 @@ struct MulMidGeom {
 #elif defined(MID_MODE_14)  // experiment hook: exchange-region scheme of the FP64 middle kernel at N = 16384 (with MID_WAVES_14)
   static constexpr int MODE = !POLICY_D ? 0 : (L == 14 ? MID_MODE_14 : EPT > kBlkEPT ? 2 : MID_FWD_PAIRS(L) ? 1 : 0);
 #else
-  static constexpr int MODE = !POLICY_D ? 0 : EPT > kBlkEPT ? 2 : MID_FWD_PAIRS(L) ? 1 : 0;
+  static constexpr int MODE = !POLICY_D ? 0 : EPT > kBlkEPT ? (SQUARE ? 2 : 3) : MID_FWD_PAIRS(L) ? 1 : 0;
 #endif
-  static constexpr int REGIONS = !batched ? 1 : MODE == 2 ? 2 : MODE == 1 ? 3 : 4;
+  static constexpr int REGIONS = !batched ? 1 : (MODE == 2 || MODE == 3) ? 2 : MODE == 1 ? 3 : 4;
   static constexpr int TPB = SplitShape<L, EPT>::TPB;
 #if defined(MID_WAVES_OF)
   static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : MID_WAVES_OF(L);
