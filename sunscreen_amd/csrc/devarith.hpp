@@ -16,6 +16,17 @@ namespace hipbfv {
 
 typedef unsigned __int128 u128;
 
+// A pointer that was LOADED from memory (the descriptor / pointer tables of the combined handle-level calls and of the graph
+// executor) has no provenance the compiler could infer an address space from: accesses through it would be flat_load /
+// flat_store, which also count against lgkmcnt and pay the aperture check.  Everything those tables point to is device or
+// pinned host memory, i.e. the global address space: say so.
+template <class T>
+using global_ptr = __attribute__((address_space(1))) T*;
+template <class T>
+__device__ __forceinline__ global_ptr<T> as_global(T* p) {
+  return (global_ptr<T>)p;
+}
+
 __device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 
 // x * w mod q in [0, 2q) for any 64-bit x (w < q, wq = floor(w*2^64/q))

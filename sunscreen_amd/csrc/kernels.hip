@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(kCoefThreads) void transparent_watch_nary_kernel(co
   const NaryOut o = outs[blockIdx.x / batch];
   const u32 b = blockIdx.x % batch;
   const size_t poly = (size_t)ctx->K * ctx->n;
-  const u64* p = o.out + (size_t)b * o.size * poly + poly;
+  const auto p = as_global((const u64*)(o.out + (size_t)b * o.size * poly + poly));
   const size_t len = (size_t)(o.size - 1) * poly;
   for (size_t base = 0; base < len; base += kCoefThreads) {
     const size_t i = base + threadIdx.x;
@@ -1215,14 +1215,14 @@ __global__ __launch_bounds__(kCoefThreads) void transparent_flag_kernel(const u6
 // lists them.  gather: stage[item][0..words) = *table[item]; scatter: *table[item] = stage[item][..]; 16-byte accesses.
 __global__ __launch_bounds__(kCoefThreads) void gather_items_kernel(const u64* const* __restrict__ table, u64* __restrict__ stage, size_t words) {
   typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-  const u64x2_t* src = reinterpret_cast<const u64x2_t*>(table[blockIdx.y]);
+  const auto src = as_global(reinterpret_cast<const u64x2_t*>(table[blockIdx.y]));
   u64x2_t* dst = reinterpret_cast<u64x2_t*>(stage + (size_t)blockIdx.y * words);
   for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < words / 2; i += (size_t)gridDim.x * kCoefThreads) dst[i] = src[i];
 }
 __global__ __launch_bounds__(kCoefThreads) void scatter_items_kernel(const u64* __restrict__ stage, u64* const* __restrict__ table, size_t words) {
   typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
   const u64x2_t* src = reinterpret_cast<const u64x2_t*>(stage + (size_t)blockIdx.y * words);
-  u64x2_t* dst = reinterpret_cast<u64x2_t*>(table[blockIdx.y]);
+  const auto dst = as_global(reinterpret_cast<u64x2_t*>(table[blockIdx.y]));
   for (size_t i = (size_t)blockIdx.x * kCoefThreads + threadIdx.x; i < words / 2; i += (size_t)gridDim.x * kCoefThreads) dst[i] = src[i];
 }
 // words from pinned, device-addressable host memory into device memory, ordered on the stream like any kernel (the graph
@@ -1241,11 +1241,11 @@ __global__ __launch_bounds__(kCoefThreads) void eltwise_items_kernel(const DevCt
   if (k >= n) return;
   const u64 q = ctx->mod[row % K].q;
   const size_t off = (size_t)row * n + k;
-  const u64x2_t x = *reinterpret_cast<const u64x2_t*>(ta[item] + off), y = *reinterpret_cast<const u64x2_t*>(tb[item] + off);
+  const u64x2_t x = *as_global(reinterpret_cast<const u64x2_t*>(ta[item] + off)), y = *as_global(reinterpret_cast<const u64x2_t*>(tb[item] + off));
   u64x2_t r;
   r.x = mode == 0 ? add_mod(x.x, y.x, q) : sub_mod(x.x, y.x, q);
   r.y = mode == 0 ? add_mod(x.y, y.y, q) : sub_mod(x.y, y.y, q);
-  *reinterpret_cast<u64x2_t*>(tout[item] + off) = r;
+  *as_global(reinterpret_cast<u64x2_t*>(tout[item] + off)) = r;
 }
 // ---- graph executor (program.cpp): signed n-ary sums through descriptor tables ----
 // Every maximal Add / Sub / Negate tree of a program is one output here: out = sum_t sign_t * term_t (mod q_i), exact canonical
@@ -1268,16 +1268,16 @@ __global__ __launch_bounds__(kCoefThreads) void nary_sum_kernel(const DevCtx* __
   for (u32 t = 0; t < o.count; t++) {
     const NaryTerm tm = terms[o.first + t];
     if (poly >= tm.size) continue;
-    const u64x2_t x = *reinterpret_cast<const u64x2_t*>(tm.ptr + ((size_t)b * tm.size * K + row) * n + k);
+    const u64x2_t x = *as_global(reinterpret_cast<const u64x2_t*>(tm.ptr + ((size_t)b * tm.size * K + row) * n + k));
     acc.x = tm.sign > 0 ? add_mod(acc.x, x.x, q) : sub_mod(acc.x, x.x, q);
     acc.y = tm.sign > 0 ? add_mod(acc.y, x.y, q) : sub_mod(acc.y, x.y, q);
   }
-  *reinterpret_cast<u64x2_t*>(o.out + ((size_t)b * o.size * K + row) * n + k) = acc;
+  *as_global(reinterpret_cast<u64x2_t*>(o.out + ((size_t)b * o.size * K + row) * n + k)) = acc;
 }
 // ... and the transparent verdict of results that live in the callers' own buffers
 __global__ __launch_bounds__(kCoefThreads) void transparent_flags_items_kernel(const u64* const* __restrict__ table, size_t words_per_ct, size_t skip_words,
                                                                               volatile u32* __restrict__ host_flags) {
-  const u64* p = table[blockIdx.x];
+  const auto p = as_global(table[blockIdx.x]);
   for (size_t base = skip_words; base < words_per_ct; base += kCoefThreads) {
     const size_t i = base + threadIdx.x;
     const bool nz = i < words_per_ct && p[i] != 0;

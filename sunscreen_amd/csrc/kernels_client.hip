@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kClientThreads) void dot_plain_tab_kernel(const Dev
     for (int r = 0; r < RT; r++) {
       if (r0 + r < rows) {
         const PlainNttRef ref = tab[(size_t)(r0 + r) * cols + j];
-        const u64x2_t* src = reinterpret_cast<const u64x2_t*>(ref.ptr + (size_t)b * ref.stride + in_row);
+        const auto src = as_global(reinterpret_cast<const u64x2_t*>(ref.ptr + (size_t)b * ref.stride + in_row));  // global_load, not flat_load
 #if PIR_NT
         const u64x2_t pv = __builtin_nontemporal_load(src);
 #else

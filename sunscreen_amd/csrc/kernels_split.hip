@@ -927,8 +927,7 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
     if (J0 > 0) __syncthreads();  // the previous group's last pass may still be reading LDS
     // The twiddles do not depend on the group: without this the compiler hoists every twiddle load of all passes
     // out of the loop and keeps ~100 registers of them alive.  Re-materialise the pointer.
-    const MulOpD* twf_j = twf;
-    asm volatile("" : "+s"(twf_j));
+    const MulOpD* twf_j = opaque_uniform(twf);  // (an opaque OFFSET: the pointer keeps its address space, nttcore.hpp)
     mid_forward_multi<A, L, NP, EPT, KS_TW_PIPE(L)>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
 #pragma unroll
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
@@ -951,8 +950,7 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
         load_src(J + 3, nxt[1]);
       }
       if (J > 0) __syncthreads();
-      const MulOpD* twf_j = twf;
-      asm volatile("" : "+s"(twf_j));
+      const MulOpD* twf_j = opaque_uniform(twf);
       mid_forward_multi<A, L, 2, EPT>(ar, cur, smem, tid, blk, twf_j, dm.split_fwd_mask);
       mac(J, cur[0]);
       mac(J + 1, cur[1]);
@@ -1067,8 +1065,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(con
 #pragma unroll
     for (int i = 0; i < NP; i++) load_src(J0 + i, v[i]);
     if (J0 > 0) __syncthreads();
-    const MulOp* twf_j = twf;
-    asm volatile("" : "+s"(twf_j));
+    const MulOp* twf_j = opaque_uniform(twf);
     mid_forward_multi<A, L, NP>(ar, v, smem, tid, blk, twf_j, 0u);
 #pragma unroll
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
@@ -1422,8 +1419,12 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
   using Out = BlkPass<A, L, LOWI, RI, EPT>;
   typename A::V v[4][EPT];
-  const typename A::V* ext_p = ext_r;  // re-materialised (pin_loads) where a load must not be scheduled above the transform before it
-  auto pin_loads = [&]() { asm volatile("" : "+s"(ext_p) : : "memory"); };
+  const typename A::V* ext_p = ext_r;  // re-based (pin_loads) where a load must not be scheduled above the transform before it
+  auto pin_loads = [&]() {
+    u32 zero = 0;
+    asm volatile("" : "+s"(zero) : : "memory");
+    ext_p = ext_r + zero;  // an opaque offset keeps the pointer's address space (nttcore.hpp opaque_uniform)
+  };
   auto load_poly = [&](int i) {
     const typename A::V* src = ext_p + (size_t)i * poly_stride;
 #pragma unroll
@@ -1440,6 +1441,102 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   // registers, and holding all of them through the first transform spills (the other resident workgroup covers the latency)
   using Pair = typename A::V[2][EPT];
   using One = typename A::V[1][EPT];
+  if constexpr (MODE == 4 && !SQUARE) {
+    // 16 elements per thread, two 256-thread workgroups per CU (r03).  (a0, a1) are transformed as a pair and PARKED IN PLACE:
+    // every thread writes the 2 x 16 transformed values it holds over the block's own words of the two ext rows (unpacked
+    // 8-byte rows: MulMidGeom) -- 16-byte stores of the runs of 8 consecutive coefficients the last pass leaves -- and reads
+    // them back, from L2, when the tensor product wants them; nothing else ever reads these rows again.  (b0, b1) follow as a
+    // second pair; (d0, d1) and then d2 go through the inverse passes.  Two exchange regions (64 KB), no more than two operands
+    // and three products in registers.
+    static_assert(!(PACK && std::is_same<A, ArithD>::value), "parking needs unpacked rows");
+    static_assert(std::is_same<typename A::V, double>::value, "FP64 policy");
+    constexpr int RLW = split_fwd_radix(L, Sh::NPF - 1);
+    using Last = BlkPass<A, L, 0, RLW, EPT>;
+    static_assert((1 << RLW) % 2 == 0, "runs of an even number of consecutive coefficients");
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    // global-address-space views of the rows (a pointer that went through an asm would otherwise come back as a FLAT pointer and
+    // every access through it as flat_load / flat_store); `gext` is re-materialised where an access must not move up
+    typedef __attribute__((address_space(1))) double gdouble;
+    typedef __attribute__((address_space(1))) dbl2 gdbl2;
+    unsigned long long gbits = (unsigned long long)ext_r;
+    auto rows = [&]() {
+      asm volatile("" : "+s"(gbits) : : "memory");
+      return (gdouble*)gbits;
+    };
+    typename A::V v2[2][EPT];
+    auto load_into = [&](gdouble* base, int i, typename A::V(&dst)[EPT]) {
+      gdouble* src = base + (size_t)i * poly_stride;
+#pragma unroll
+      for (int g = 0; g < First::G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
+    };
+    {
+      gdouble* base = rows();
+      load_into(base, 0, v2[0]);
+      load_into(base, 1, v2[1]);
+    }
+    mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, v2, smem, tid, blk, twf, dm.split_fwd_mask);
+    {
+      gdouble* base = rows();
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int g = 0; g < Last::G; g++) {
+          gdbl2* dst = (gdbl2*)(base + (size_t)i * poly_stride + Last::elem(tid, blk, g, 0));
+#pragma unroll
+          for (int k = 0; k < (1 << RLW); k += 2) {
+            dbl2 w;
+            w.x = v2[i][g * (1 << RLW) + k], w.y = v2[i][g * (1 << RLW) + k + 1];
+            dst[k / 2] = w;
+          }
+        }
+    }
+    {
+      gdouble* base = rows();  // "memory": the parked values have left; b0, b1 are not requested before this point
+      load_into(base, 2, v2[0]);
+      load_into(base, 3, v2[1]);
+    }
+    __syncthreads();  // the first pair's last pass may still be reading the exchange buffer
+    {
+      mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, v2, smem, tid, blk, opaque_uniform(twf), dm.split_fwd_mask);
+    }
+    typename A::V d01[2][EPT], d2[1][EPT];
+#pragma unroll
+    for (int g = 0; g < Last::G; g++) {
+      gdouble* base = rows();  // one group's parked values in flight at a time (a group = 2 x 8 values = 32 registers)
+      const gdbl2* p0 = (const gdbl2*)(base + Last::elem(tid, blk, g, 0));
+      const gdbl2* p1 = (const gdbl2*)(base + poly_stride + Last::elem(tid, blk, g, 0));
+#pragma unroll
+      for (int k = 0; k < (1 << RLW); k += 2) {
+        const dbl2 a0 = p0[k / 2], a1 = p1[k / 2];
+        const int e = g * (1 << RLW) + k;
+        d01[0][e] = ar.mul_var(a0.x, v2[0][e]);
+        d01[0][e + 1] = ar.mul_var(a0.y, v2[0][e + 1]);
+        d01[1][e] = ar.mul_add(a0.x, v2[1][e], ar.mul_var(a1.x, v2[0][e]));
+        d01[1][e + 1] = ar.mul_add(a0.y, v2[1][e + 1], ar.mul_var(a1.y, v2[0][e + 1]));
+        d2[0][e] = ar.mul_var(a1.x, v2[1][e]);
+        d2[0][e + 1] = ar.mul_var(a1.y, v2[1][e + 1]);
+      }
+    }
+    __syncthreads();  // the last forward pass may still be reading the exchange buffer
+    mid_inverse_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, d01, smem, tid, blk, twi, dm.split_inv_mask);
+    auto store_poly = [&](int i, const typename A::V(&dv)[EPT]) {
+      typename A::V* dst = D_r + (size_t)i * dpoly_stride;
+#pragma unroll
+      for (int g = 0; g < Out::G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << RI); k++) nt_st<NtSites<L>::mul_mid_st>(dst + Out::elem(tid, blk, g, k), dv[g * (1 << RI) + k]);
+    };
+    store_poly(0, d01[0]);
+    store_poly(1, d01[1]);
+    __syncthreads();
+    {
+      mid_inverse_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, d2, smem, tid, blk, opaque_uniform(twi), dm.split_inv_mask);
+    }
+    store_poly(2, d2[0]);
+    return;
+  }
   if constexpr (MODE == 3 && !SQUARE) {
     // 16 elements per thread, two 256-thread workgroups per CU (r03): the four operands never sit in registers together, and
     // each product polynomial leaves as soon as it is complete.  (a0, b0) are transformed as a pair, d0 = a0 b0 is taken
@@ -1458,10 +1555,7 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
             nt_st<NtSites<L>::mul_mid_st>(dst + Out::elem(tid, blk, g, k), dv[g * (1 << RI) + k]);
         }
     };
-    auto fresh = [&](const typename A::Tw* tw) {  // keep one transform's twiddle fetches from being merged with another's
-      asm volatile("" : "+s"(tw));
-      return tw;
-    };
+    auto fresh = [&](const typename A::Tw* tw) { return opaque_uniform(tw); };  // keep one transform's twiddle fetches from being merged with another's
     auto load_into = [&](int i, typename A::V(&dst)[EPT]) {
       const typename A::V* src = ext_p + (size_t)i * poly_stride;
 #pragma unroll
@@ -1597,19 +1691,28 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 #ifndef MID_EPT_14_SQ
 #define MID_EPT_14_SQ (HIPBFV_GEOM14 == 4 ? 16 : 8)
 #endif
-constexpr int mid_ept_d(int logn, bool square) { return logn == 14 ? (square ? MID_EPT_14_SQ : MID_EPT_14) : kBlkEPT; }
-template <int L, bool POLICY_D, bool SQUARE = false>
+// MID_EPT16_MODE: how the general (four-operand) body lives in 256 registers at 16 elements per thread -- 3: operands folded into
+// the products one at a time (three forward rounds); 4: the first pair's transforms PARKED IN PLACE in `ext` (global memory, read
+// back from L2 at the tensor product; two forward rounds).  Parking overwrites the block's own words of an 8-byte row, so it
+// needs unpacked intermediates: with 48-bit packed rows (PACK) the general body stays at 8 elements per thread.
+#ifndef MID_EPT16_MODE
+#define MID_EPT16_MODE 4
+#endif
+constexpr int mid_ept_d(int logn, bool square, bool pack) {
+  return logn == 14 ? (square ? MID_EPT_14_SQ : (pack && MID_EPT16_MODE == 4) ? kBlkEPT : MID_EPT_14) : kBlkEPT;
+}
+template <int L, bool POLICY_D, bool SQUARE = false, bool PACK = false>
 struct MulMidGeom {
-  static constexpr int EPT = POLICY_D ? mid_ept_d(L, SQUARE) : kBlkEPT;
+  static constexpr int EPT = POLICY_D ? mid_ept_d(L, SQUARE, PACK) : kBlkEPT;
   static constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
 #if defined(MID_MODE_OF)  // experiment hook: exchange-region scheme of the FP64 middle kernel per degree (with MID_WAVES_OF)
   static constexpr int MODE = !POLICY_D ? 0 : MID_MODE_OF(L);
 #elif defined(MID_MODE_14)  // experiment hook: exchange-region scheme of the FP64 middle kernel at N = 16384 (with MID_WAVES_14)
   static constexpr int MODE = !POLICY_D ? 0 : (L == 14 ? MID_MODE_14 : EPT > kBlkEPT ? 2 : MID_FWD_PAIRS(L) ? 1 : 0);
 #else
-  static constexpr int MODE = !POLICY_D ? 0 : EPT > kBlkEPT ? (SQUARE ? 2 : 3) : MID_FWD_PAIRS(L) ? 1 : 0;
+  static constexpr int MODE = !POLICY_D ? 0 : EPT > kBlkEPT ? (SQUARE ? 2 : MID_EPT16_MODE) : MID_FWD_PAIRS(L) ? 1 : 0;
 #endif
-  static constexpr int REGIONS = !batched ? 1 : (MODE == 2 || MODE == 3) ? 2 : MODE == 1 ? 3 : 4;
+  static constexpr int REGIONS = !batched ? 1 : (MODE >= 2) ? 2 : MODE == 1 ? 3 : 4;
   static constexpr int TPB = SplitShape<L, EPT>::TPB;
 #if defined(MID_WAVES_OF)
   static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : MID_WAVES_OF(L);
@@ -1620,10 +1723,10 @@ struct MulMidGeom {
 #endif
 };
 template <int L, bool POLICY_D, bool PACK, bool SQUARE = false>
-__global__ __launch_bounds__((MulMidGeom<L, POLICY_D, SQUARE>::TPB), (MulMidGeom<L, POLICY_D, SQUARE>::WAVES)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+__global__ __launch_bounds__((MulMidGeom<L, POLICY_D, SQUARE, PACK>::TPB), (MulMidGeom<L, POLICY_D, SQUARE, PACK>::WAVES)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                            const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
                                                                            u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres) {
-  using Geo = MulMidGeom<L, POLICY_D, SQUARE>;
+  using Geo = MulMidGeom<L, POLICY_D, SQUARE, PACK>;
   using Sh = SplitShape<L, Geo::EPT>;
   constexpr bool batched = Geo::batched;
   __shared__ u64 smem[Geo::REGIONS * Sh::BLOCK];
@@ -2177,17 +2280,17 @@ template <int L>
 static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
                             const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, bool square, hipStream_t s) {
   using Sh = SplitShape<L>;
-  constexpr unsigned TD = MulMidGeom<L, true>::TPB, TI = MulMidGeom<L, false>::TPB;
+  constexpr unsigned TDP = MulMidGeom<L, true, false, true>::TPB, TD = MulMidGeom<L, true, false, false>::TPB, TI = MulMidGeom<L, false>::TPB;
 #if MUL_SQUARE
   if (square) {
-    constexpr unsigned TS = MulMidGeom<L, true, true>::TPB;
-    if (nd && pack) mul_mid_kernel<L, true, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TS, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+    constexpr unsigned TSP = MulMidGeom<L, true, true, true>::TPB, TS = MulMidGeom<L, true, true, false>::TPB;
+    if (nd && pack) mul_mid_kernel<L, true, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TSP, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
     if (nd && !pack) mul_mid_kernel<L, true, false, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TS, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
     if (ni) mul_mid_kernel<L, false, false, true><<<dim3((unsigned)(ops * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
     return hipGetLastError();
   }
 #endif
-  if (nd && pack) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
+  if (nd && pack) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TDP, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
   if (nd && !pack) mul_mid_kernel<L, true, false><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
   if (ni) mul_mid_kernel<L, false, false><<<dim3((unsigned)(ops * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
   return hipGetLastError();

@@ -62,13 +62,16 @@ __device__ __forceinline__ u32 pass_pos_base(u32 tid) { return lds_pos(elem_inde
 
 // A pointer the compiler can prove wave-uniform (scalar loads stay possible) but cannot hoist loads through:
 // used to keep twiddle loads inside the transform that consumes them.
+// The opacity comes from an OFFSET (an SGPR holding zero that went through an asm), not from the pointer itself: a pointer
+// rebuilt from an integer loses its address space, and every load through it becomes a flat_load -- which counts against
+// lgkmcnt as well as vmcnt, so the LDS exchanges' `s_waitcnt lgkmcnt(0)` wait for the twiddle fetches they were supposed to
+// overlap with (found in r03: the key-switch middle kernels fetched all their vector twiddles that way).  `p + zero` keeps the
+// provenance of p (a kernel argument: global address space), so the loads stay global_load / s_load.
 template <class T>
 __device__ __forceinline__ const T* opaque_uniform(const T* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
-  unsigned long long r = ((unsigned long long)hi << 32) | lo;
-  asm volatile("" : "+s"(r));
-  return reinterpret_cast<const T*>(r);
+  u32 zero = 0;
+  asm volatile("" : "+s"(zero));
+  return p + zero;
 }
 
 // ---- arithmetic policies -------------------------------------------------------------
