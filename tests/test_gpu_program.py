@@ -428,3 +428,96 @@ def test_scheduled_and_node_by_node_executors_agree(batch, monkeypatch):
         for k in range(len(got)):
             assert (got[k] == serial[k]).all(), (batch, k)
             assert (got[k][0] == ref[k]).all(), (batch, k)
+
+
+def test_scheduled_executor_corner_cases_against_the_oracle_and_the_node_by_node_executor(monkeypatch):
+    """Shapes the examples do not have: sums of plaintext products over DIFFERENT ciphertext lists (two matrix groups) with
+    per-item, shared, literal and pre-transformed plaintexts mixed in one sum; two rotations by the same step (one merged
+    launch at small batch) next to a different step and a NAF chain; Relinearize of a size-2 value (a copy) and of a product
+    with two users (unfused); a node that is output twice; an input that is output unchanged; a value nobody uses."""
+    from sunscreen_amd import Plaintext
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.program import FheProgram, TransformedPlaintext, encode_plaintext_literal
+
+    name = "default_4096_16"
+    n, primes, t = params(name)
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx(name, galois=[3, 9, 81, 2 * 4096 - 1])  # steps 1, 2, 4 and the column swap
+    rng = np.random.default_rng(77)
+    lit_coeffs = o.batch_encode(rng.integers(1, 50, n).astype(np.uint64))
+    blob = encode_plaintext_literal(n, primes, t, Plaintext.from_coefficients([int(c) for c in lit_coeffs]).as_bytes())
+
+    p = FheProgram()
+    a, b, c = (p.append_input_ciphertext(i) for i in range(3))
+    p_item, p_shared, p_ntt = p.append_input_plaintext(3), p.append_input_plaintext(4), p.append_input_plaintext(5)
+    lit = p.append_plaintext_literal(blob)
+    # group 1: sums over (a, b, c); group 2: a sum over (b, a)
+    s1 = p.append_add(p.append_add(p.append_multiply_plaintext(a, p_item), p.append_multiply_plaintext(b, p_shared)), p.append_multiply_plaintext(c, lit))
+    s2 = p.append_add(p.append_add(p.append_multiply_plaintext(a, p_ntt), p.append_multiply_plaintext(b, lit)), p.append_multiply_plaintext(c, p_item))
+    s3 = p.append_add(p.append_multiply_plaintext(b, p_shared), p.append_multiply_plaintext(a, p_item))
+    r1 = p.append_rotate_left(s1, p.append_input_literal(1))
+    r2 = p.append_rotate_left(s2, p.append_input_literal(1))      # same step: one merged launch at small batch
+    r3 = p.append_rotate_left(s3, p.append_input_literal(5))      # no key for step 5: the NAF chain 1 + 4 (rotate_internal)
+    r4 = p.append_swap_rows(r1)
+    m = p.append_multiply(r2, r3)                                 # two users: stays an unfused product
+    rl = p.append_relinearize(m)
+    big = p.append_relinearize(p.append_add(m, m))                # relinearise the size-3 sum
+    cp = p.append_relinearize(a)                                  # size 2: a copy
+    p.append_negate(c)                                            # a value nobody uses
+    for node in (rl, big, cp, r4, r4, a, p.append_sub(rl, r4)):
+        p.append_output_ciphertext(node)
+    q = FheProgram.from_json(p.to_json())
+    for batch in (1, 3, 40):
+        cts = [np.stack([o.encrypt(pk, o.batch_encode(rng.integers(0, 20, n).astype(np.uint64))) for _ in range(batch)]) for _ in range(3)]
+        per_item = rng.integers(1, t, (batch, n), dtype=np.uint64)
+        shared = rng.integers(1, t, n, dtype=np.uint64)
+        for_ntt = rng.integers(1, t, n, dtype=np.uint64)
+        dev = [to_device(x) for x in cts] + [to_device(per_item), to_device(shared), TransformedPlaintext(ev.plain_to_ntt(to_device(for_ntt)))]
+        monkeypatch.delenv("HIPBFV_PROGRAM_SERIAL", raising=False)
+        got = [to_host(x) for x in q.run(ev, dev, rkd, gkd)]
+        assert len(got) == 7
+        for i in range(min(batch, 2)):
+            ref = run_program(o, q.nodes, q.edges, [x[i] for x in cts] + [per_item[i], shared, for_ntt], rk, gk, literals={lit: lit_coeffs})
+            for k in range(7):
+                assert (got[k][i] == ref[k]).all(), (batch, i, k, q.describe())
+        # the node-by-node executor takes coefficient-form plaintexts only: same program, the pre-transformed argument as coefficients
+        monkeypatch.setenv("HIPBFV_PROGRAM_SERIAL", "1")
+        serial = [to_host(x) for x in q.run(ev, dev[:5] + [to_device(for_ntt)], rkd, gkd)]
+        monkeypatch.delenv("HIPBFV_PROGRAM_SERIAL", raising=False)
+        for k in range(7):
+            assert (serial[k] == got[k]).all(), (batch, k)
+
+
+def test_one_program_object_run_from_several_threads():
+    """sunscreen_runtime shares one compiled program between requests; the schedule is built once (under a lock) and every
+    run keeps its tables in its own thread's arena."""
+    import threading
+
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.workloads import chi_sq_optimized
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_4096_16")
+    prog = chi_sq_optimized()
+    rng = np.random.default_rng(5)
+    sets = []
+    for _ in range(4):
+        vals = rng.integers(0, 7, (3, 2, o.n)).astype(np.uint64)
+        sets.append([to_device(np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vals[a]])) for a in range(3)])
+    want = [[to_host(x) for x in prog.run(ev, s, rkd)] for s in sets]
+    errors = []
+
+    def work(i):
+        try:
+            import torch
+
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(5):
+                    got = [to_host(x) for x in prog.run(ev, sets[i], rkd)]
+                    for k in range(4):
+                        assert (got[k] == want[i][k]).all(), (i, k)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [x.start() for x in ths]
+    [x.join() for x in ths]
+    assert not errors, errors
