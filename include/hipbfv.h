@@ -386,6 +386,11 @@ long hipbfv_Program_LoadJson(void *program, const char *json, uint64_t length);
 long hipbfv_batch_status(void *evaluator, uint64_t *first_transparent_item, void *stream);
 long hipbfv_set_batch_transparent_check(void *evaluator, bool enabled);
 long hipbfv_Program_NumOutputs(void *program, uint64_t *count);
+/* Diagnostic: one multiply + relinearize of ONE ciphertext pair (device pointers u64[2][K][N], a relinearisation key
+ * u64[K][2][K+1][N], result u64[2][K][N]) timed from the host, launched kernel by kernel and replayed from a captured hipGraph
+ * (microseconds per repetition, one stream synchronisation each). */
+long hipbfv_debug_graph_probe(void *context, const uint64_t *a, const uint64_t *b, const uint64_t *relin_key, uint64_t *out,
+                              uint64_t iterations, double *us_direct, double *us_graph);
 /* The schedule Run follows, one line per step ("mul_relin members=3 square", "sum members=2 terms=6", "plain_matrix members=256
  * columns=256", ...): `*needed` = bytes including the terminator; `buffer` may be NULL to ask for the size. */
 long hipbfv_Program_Describe(void *program, char *buffer, uint64_t capacity, uint64_t *needed);

@@ -2029,6 +2029,68 @@ long hipbfv_Program_NumOutputs(void* h, uint64_t* count) HIPBFV_BEGIN
   return HIPBFV_S_OK;
 HIPBFV_END
 
+// Diagnostic (tools/graph_probe.py): one multiply + relinearize of a single ciphertext pair, (1) launched kernel by kernel as
+// the handle-level calls do, (2) the same launches captured once into a hipGraph and replayed.  Both are timed from the host
+// with one stream synchronisation per repetition, i.e. what a caller of the SEAL-named entry points waits for.
+long hipbfv_debug_graph_probe(void* context, const uint64_t* a, const uint64_t* b, const uint64_t* relin_key, uint64_t* out, uint64_t iterations,
+                              double* us_direct, double* us_graph) HIPBFV_BEGIN
+  ContextObj* c = as<ContextObj>(context, kMagicContext);
+  if (!c || !a || !b || !relin_key || !out || !us_direct || !us_graph || !iterations) return HIPBFV_E_POINTER;
+  Evaluator ev(c->ctx.get());  // its own scratch pool: events recorded during capture never meet another stream
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return from_status(kHipError);
+  const size_t w3 = c->ctx->ct_words(3);
+  u64* tmp = nullptr;
+  if (hipMalloc((void**)&tmp, w3 * sizeof(u64)) != hipSuccess) {
+    (void)hipStreamDestroy(s);
+    return from_status(kOutOfMemory);
+  }
+  auto once = [&]() -> int {
+    int st = ev.multiply((const u64*)a, 2, (const u64*)b, 2, tmp, 1, s, false);
+    if (!st) st = ev.relinearize(tmp, (const u64*)relin_key, (u64*)out, 1, s, nullptr, false);
+    return st;
+  };
+  auto now_us = [] {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+  };
+  long hr = HIPBFV_S_OK;
+  int st = once();  // warm: the scratch pool allocates here, not inside the capture
+  if (!st && hipStreamSynchronize(s) != hipSuccess) st = kHipError;
+  if (!st) {
+    const double t0 = now_us();
+    for (uint64_t i = 0; i < iterations && !st; i++) {
+      st = once();
+      if (!st && hipStreamSynchronize(s) != hipSuccess) st = kHipError;
+    }
+    *us_direct = (now_us() - t0) / (double)iterations;
+  }
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (!st) {
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) st = kHipError;
+    if (!st) st = once();
+    if (hipStreamEndCapture(s, &graph) != hipSuccess || !graph) st = st ? st : (int)kHipError;
+    if (!st && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) st = kHipError;
+  }
+  if (!st) {
+    for (int i = 0; i < 3 && !st; i++)
+      if (hipGraphLaunch(exec, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = kHipError;
+    const double t0 = now_us();
+    for (uint64_t i = 0; i < iterations && !st; i++)
+      if (hipGraphLaunch(exec, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = kHipError;
+    *us_graph = (now_us() - t0) / (double)iterations;
+  }
+  if (st) hr = from_status(st);
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  (void)hipStreamDestroy(s);
+  return hr;
+HIPBFV_END
+
 long hipbfv_Program_Describe(void* h, char* buffer, uint64_t capacity, uint64_t* needed) HIPBFV_BEGIN
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   if (!p || !needed) return HIPBFV_E_POINTER;
