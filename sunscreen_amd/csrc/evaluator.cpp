@@ -368,7 +368,9 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
   if (fused) {
     const size_t ext_words = (size_t)4 * R * n, d_words = (size_t)3 * R * n, t_words = (size_t)KK * K * n, acc_words = (size_t)2 * KK * n, c2_words = (size_t)K * n;
     const size_t per_op = ext_words + d_words + t_words + acc_words + c2_words;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>({chunk_ops_, (size_t)65535 / (R * 4), (size_t)65535 / ((size_t)KK * K)}));
+    // every kernel of this path puts the ops on grid z and its residue / block count on grid x: no 65535 limit but z's, which
+    // the 1024-op cap of chunk_ops_ is far below (the limits of the whole-polynomial launches made N = 16384 run 910 + 114)
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535));
     ScratchGuard sg(pool_, std::min(chunk, count) * per_op * sizeof(u64), s);
     if (!sg.p) return kOutOfMemory;
     const size_t cc = std::min(chunk, count);

@@ -1,4 +1,4 @@
-bash tools/gpu_pmc_report.sh r02_v3 mulrelin_n8192
-bash tools/gpu_pmc_report.sh r02_v3 mulrelin_n16384 --n 16384 --batch 1024
-bash tools/gpu_pmc_report.sh r02_v3 ntt_n8192 --workload ntt
-bash tools/gpu_pmc_report.sh r02_v3 mulrelin_n8192_bits54-54-54-56 --coeff-bits 54,54,54,56
+bash tools/gpu_pmc_report.sh ${PMC_TAG:-r03_v1} mulrelin_n8192
+bash tools/gpu_pmc_report.sh ${PMC_TAG:-r03_v1} mulrelin_n16384 --n 16384 --batch 1024
+bash tools/gpu_pmc_report.sh ${PMC_TAG:-r03_v1} ntt_n8192 --workload ntt
+bash tools/gpu_pmc_report.sh ${PMC_TAG:-r03_v1} mulrelin_n8192_bits54-54-54-56 --coeff-bits 54,54,54,56
