@@ -448,6 +448,12 @@ __device__ __forceinline__ void mid_inverse_multi(const A& ar, typename A::V (&v
 }
 
 constexpr int kHeadThreads = 256;
+// Minimum waves per SIMD the 8-prime head / tail instantiations are compiled for (experiment hook; 0 = the compiler's choice,
+// which is 2 at 178-196 registers)
+#ifndef EDGE8_WAVES
+#define EDGE8_WAVES 0
+#endif
+#define EDGE_BOUNDS(KMAX) __launch_bounds__(kHeadThreads, ((KMAX) > 4 && EDGE8_WAVES ? EDGE8_WAVES : 1))
 // mul_mid, FP64 instantiation: at N = 8192 the four forward transforms go through the exchange buffer as two pairs
 // (48 KB of LDS per workgroup instead of 64 KB: 3 workgroups = 12 waves per CU instead of 2 = 8; -5 % mul_mid).  At N = 4096
 // the regions are small anyway and the extra barriers cost 37 %; at N = 16384 one workgroup fills the CU either way.
@@ -1230,7 +1236,7 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 // AUXD (DevCtx::aux_f64): every residue, auxiliary base included, takes the FP64 policy and the base extension
 // itself runs in FP64 (behz_extend_coeff_d).
 template <int L, int KMAX, bool AUXD, bool PACK>
-__global__ __launch_bounds__(kHeadThreads) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+__global__ EDGE_BOUNDS(KMAX) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
                                                                 u64* __restrict__ ext) {
   using G = EdgeGeom<L>;
@@ -1832,7 +1838,7 @@ template <int L, int KMAX, bool AUXD, bool PACK, bool GRID>
 // poly0 / out_polys: the launch covers product polynomials poly0 .. poly0 + gridDim.y - 1 and writes them to
 // out[op][out_polys][K][N] (3 polynomials from 0 for a stand-alone multiply; only c2, compactly, in the fused
 // multiply + relinearize, whose last kernel forms c0 and c1 itself: mulrelin_tail_kernel)
-__global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+__global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                 const u64* __restrict__ D, u64* __restrict__ out, u32 poly0, u32 out_polys) {
   using G = EdgeGeom<L>;
   constexpr u32 N = 1u << L;
@@ -1907,7 +1913,7 @@ __global__ __launch_bounds__(kHeadThreads) void mul_tail_kernel(const DevCtx* __
 // only (the SEAL default parameter sets).  grid: (N/4/256, 2, ops)
 // -------------------------------------------------------------------------------------------------
 template <int L, int KMAX, bool PACKM, bool GRID, bool PACKK>
-__global__ __launch_bounds__(kHeadThreads) void mulrelin_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+__global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                      const u64* __restrict__ D, const double* __restrict__ ACC,
                                                                      const u64* __restrict__ extra, u64* __restrict__ out) {
   using G = EdgeGeom<L>;
@@ -1964,7 +1970,7 @@ __global__ __launch_bounds__(kHeadThreads) void mulrelin_tail_kernel(const DevCt
 // All-FP64 contexts only.  grid: (N/NC/256, 1, ops)
 // -------------------------------------------------------------------------------------------------
 template <int L, int KMAX, bool PACKM, bool GRID, bool PACKK>
-__global__ __launch_bounds__(kHeadThreads) void mulrelin_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+__global__ EDGE_BOUNDS(KMAX) void mulrelin_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                      const MulOp* __restrict__ twf_base, const u64* __restrict__ D,
                                                                      double* __restrict__ T) {
   using G = EdgeGeom<L>;
