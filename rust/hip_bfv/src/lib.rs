@@ -2,7 +2,9 @@
 //!
 //! The types and the [`Evaluator`] trait carry the names `sunscreen_runtime` already uses
 //! (`seal_fhe/src/evaluator.rs:7-280`; the runtime needs `E: Evaluator + Sync + Send`,
-//! `sunscreen_runtime/src/run.rs:100`), so switching a build from `seal_fhe` to this crate is a `use` change.
+//! `sunscreen_runtime/src/run.rs:100`), and `client.rs` carries the parameter / key / encoder / encryptor / decryptor types
+//! `runtime.rs:20-23` imports, so switching a build from `seal_fhe` to this crate is a `use` change for the BFV path (the
+//! fork-only `PolynomialArray` / `*Components` API that logproof consumes is exported by the C ABI but not wrapped here).
 //! Underneath is the C ABI of `include/hipbfv.h`: every handle is an opaque pointer owned by exactly one Rust value
 //! whose `Drop` calls `X_Destroy`; `Clone` is a deep copy; errors are SEAL's HRESULTs (`seal_fhe/src/lib.rs:28-34`).
 //!
@@ -20,10 +22,16 @@ pub(crate) mod bindgen {
 }
 
 pub mod batch;
+mod client;
 mod evaluator;
 mod handles;
 mod raw;
 
+pub use client::{
+    enc_marker, Asym, AsymmetricEncryptor, BFVEncoder, BfvEncryptionParametersBuilder, CoefficientModulus, CompressionType, Decryptor,
+    EncryptionParameters, Encryptor, FromBytes, KeyGenerator, Modulus, PlainModulus, PublicKey, SchemeType, SecretKey, SecurityLevel, Sym,
+    SymAsym, SymAsymEncryptor, SymmetricEncryptor, ToBytes,
+};
 pub use evaluator::{BFVEvaluator, Evaluator};
 pub use handles::{Ciphertext, Context, GaloisKeys, Plaintext, RelinearizationKeys};
 

@@ -662,6 +662,9 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
   if (P.rc) return fail(P.rc, P.err.c_str());
   if (num_outputs_given != num_outputs()) return fail(kInvalidArg, "wrong number of output buffers");
   if (!batch) return fail(kInvalidArg, "empty batch");
+  // the table-driven kernels put (output, item) on grid z: beyond that many input sets per call the node-by-node executor, which
+  // chunks every operation, takes over (same bits)
+  if (batch > 32768) return run_serial(ev, batch, inputs, num_inputs, relin_key, galois_keys, outputs, num_outputs_given, s, err);
   Context* ctx = ev.ctx();
   const DevCtx& h = ctx->host();
   const size_t n = ctx->n(), K = ctx->K();

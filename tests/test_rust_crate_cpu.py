@@ -59,9 +59,42 @@ def test_every_ffi_call_of_the_rust_crate_matches_the_header():
             nargs = len(_split_args(src[m.end() : i - 1]))
             assert nargs == decl[name], f"{f}: bindgen::{name} called with {nargs} arguments, declared with {decl[name]}"
             calls += 1
-        for m in re.finditer(r"owned_handle!\(\w+,\s*(\w+)\)", src):
+        for m in re.finditer(r"(?:owned_handle|plain_handle)!\(\w+,\s*(\w+)\)", src):
             assert decl.get(m.group(1)) == 1, m.group(1)
-    assert calls >= 60
+        # serialisable!(Type, ctor, X_SaveSize, X_Save, X_Load): SEAL's arities 3 / 5 / 5
+        for m in re.finditer(r"^serialisable!\(\w+,\s*[\w:]+,\s*(\w+),\s*(\w+),\s*(\w+)\)", src, flags=re.M):
+            assert [decl.get(m.group(i)) for i in (1, 2, 3)] == [3, 5, 5], m.group(0)
+    assert calls >= 100
+
+
+# what sunscreen_runtime imports from seal_fhe (runtime.rs:20-23, keys.rs, serialization.rs) plus the types its public API hands out
+CLIENT_SURFACE = {
+    "Modulus": "new value",
+    "CoefficientModulus": "create bfv_default max_bit_count",
+    "PlainModulus": "batching raw",
+    "BfvEncryptionParametersBuilder": "new set_poly_modulus_degree set_coefficient_modulus set_plain_modulus set_plain_modulus_u64 build",
+    "EncryptionParameters": "get_poly_modulus_degree get_scheme get_plain_modulus get_coefficient_modulus",
+    "Context": "new new_insecure",
+    "KeyGenerator": "new new_from_secret_key secret_key create_public_key create_relinearization_keys create_galois_keys",
+    "BFVEncoder": "new get_slot_count encode_unsigned encode_signed decode_unsigned decode_signed",
+    "Encryptor": "with_public_and_secret_key with_public_key with_secret_key encrypt encrypt_symmetric",
+    "Decryptor": "new decrypt invariant_noise_budget invariant_noise",
+}
+
+
+def test_the_crate_carries_the_client_side_surface_the_runtime_imports():
+    src = open(os.path.join(CRATE, "src", "client.rs")).read()
+    lib = open(os.path.join(CRATE, "src", "lib.rs")).read()
+    exported = lib[lib.index("pub use client::") : lib.index("pub use evaluator::")]
+    for ty, methods in CLIENT_SURFACE.items():
+        if ty != "Context":
+            assert re.search(rf"\b{ty}\b", exported), f"{ty} is not re-exported from lib.rs"
+        body = "".join(m.group(0) for m in re.finditer(rf"^impl(?:<[^>]*>)? {ty}(?:<T>)? \{{.*?^\}}", src, flags=re.M | re.S))
+        for name in methods.split():
+            assert re.search(rf"pub fn {name}\(", body), f"{ty}::{name}"
+    for ty in "PublicKey SecretKey Ciphertext Plaintext RelinearizationKeys GaloisKeys".split():
+        assert re.search(rf"^serialisable!\({ty},", src, flags=re.M), f"{ty}: ToBytes / FromBytes"
+    assert "ToBytes" in exported and "FromBytes" in exported and "SecurityLevel" in exported
 
 
 def test_the_crate_implements_the_whole_evaluator_trait():
