@@ -52,6 +52,11 @@ __device__ __forceinline__ T ntt_ld(const T* p) {
 }
 template <bool NT, class T>
 __device__ __forceinline__ void ntt_st(T* p, T v) {
+#if NTT_PROBE == 2
+  unsigned long long head;
+  __builtin_memcpy(&head, &v, 8);
+  if (head != 0x5a5a5a5a5a5a5a5aull) return;  // data-dependent: in practice never stores
+#endif
   if constexpr (NT) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
@@ -78,6 +83,34 @@ __device__ __forceinline__ void ntt_st(T* p, T v) {
 #endif
 #ifndef NTT_WIDE_STORE
 #define NTT_WIDE_STORE 0
+#endif
+// Polynomials per workgroup of the stand-alone transforms at N >= 8192 (ntt_*_stream_kernel): a workgroup walks NTT_STREAM
+// consecutive polynomials and fetches polynomial i + 1 into registers while it transforms polynomial i, so that neither the
+// kernel prologue nor the HBM latency of the loads sits between two transforms.  1 = one polynomial per workgroup.
+#ifndef NTT_STREAM
+#define NTT_STREAM 1
+#endif
+// Workgroups of one launch start together and, with two of them per CU contending symmetrically, STAY together: both load,
+// both compute, both store (probes: removing the loads, the stores or the butterflies each saves nearly its full cost -- nothing
+// overlaps).  NTT_STAGGER > 0 holds back the second resident workgroup of every CU (blockIdx 256 .. 511: the dispatcher fills
+// one slot per CU across the 8 XCDs before the second) by that many s_sleep(127) (8128 cycles each) once, at the start of the
+// launch, so that one streams while the other computes.
+#ifndef NTT_STAGGER
+#define NTT_STAGGER 0
+#endif
+__device__ __forceinline__ void ntt_stagger() {
+#if NTT_STAGGER > 0
+  if (blockIdx.x >= 256u && blockIdx.x < 512u && gridDim.x >= 1024u) {
+#pragma unroll 1
+    for (int i = 0; i < NTT_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+}
+// Timing probes for the stand-alone transforms (WRONG RESULTS, never in a shipped build; tools/gpu_r03_ntt_probe.sh):
+// 1 = no global loads of the polynomial, 2 = no stores, 3 = vector twiddle loads made wave-uniform (scalar),
+// 4 = the same for the passes over element bits >= 3 only, 5 = no butterflies (data movement only: global + LDS traffic as in the real kernel)
+#ifndef NTT_PROBE
+#define NTT_PROBE 0
 #endif
 constexpr int wave_bit_target(int b, int low, int r) { return b >= low ? b + r : b; }
 // pa, pb: forward pass numbers of the two passes an exchange connects
@@ -122,9 +155,16 @@ __device__ __forceinline__ void fwd_pass_compute(const A& ar, typename A::V (&v)
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
-        const u32 widx = (1u << (S0 + j)) + ((hi << j) | (u32)(k >> (R - j)));
+        u32 widx = (1u << (S0 + j)) + ((hi << j) | (u32)(k >> (R - j)));
+#if NTT_PROBE == 3
+        widx = __builtin_amdgcn_readfirstlane(widx);
+#elif NTT_PROBE == 4
+        if constexpr (LOW >= 3) widx = __builtin_amdgcn_readfirstlane(widx);
+#endif
+#if NTT_PROBE != 5
         const typename A::Tw w = tw[widx];
         ar.fwd(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w);
+#endif
       }
     }
   }
@@ -181,7 +221,12 @@ __device__ __forceinline__ void ntt_fwd_to_lds(const A& ar, const u64* __restric
 #pragma unroll
   for (int g = 0; g < G0; g++)
 #pragma unroll
-    for (int k = 0; k < (1 << R0); k++) v[g * (1 << R0) + k] = ar.from_u64(ntt_ld<(NTT_NT_FWD & 1) != 0>(src + elem_index<LOW0, R0>(tid + g * Sh::T, k)));
+    for (int k = 0; k < (1 << R0); k++)
+#if NTT_PROBE == 1
+      v[g * (1 << R0) + k] = ar.from_u64((u64)(tid * 16u + (u32)k));
+#else
+      v[g * (1 << R0) + k] = ar.from_u64(ntt_ld<(NTT_NT_FWD & 1) != 0>(src + elem_index<LOW0, R0>(tid + g * Sh::T, k)));
+#endif
   FwdPasses<A, LOGN, EPT, 0>::run(ar, v, smem, tid, tw, reduce_mask);
 }
 
@@ -215,16 +260,24 @@ __device__ __forceinline__ void inv_pass_compute(const A& ar, typename A::V (&v)
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
         // global gap 2^(LOW+j): m = N >> (LOW+j+1) blocks, block index = element >> (LOW+j+1)
-        const u32 widx = (1u << (LOGN - 1 - LOW - j)) + ((hi << (R - 1 - j)) | (u32)(k >> (j + 1)));
+        u32 widx = (1u << (LOGN - 1 - LOW - j)) + ((hi << (R - 1 - j)) | (u32)(k >> (j + 1)));
+#if NTT_PROBE == 3
+        widx = __builtin_amdgcn_readfirstlane(widx);
+#elif NTT_PROBE == 4
+        if constexpr (LOW >= 3) widx = __builtin_amdgcn_readfirstlane(widx);
+#endif
+#if NTT_PROBE != 5
         const typename A::Tw w = tw[widx];
         ar.inv(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w);
+#endif
       }
     }
   }
 }
 
-template <class A, int LOGN, int EPT, int PASS, bool FROM_REGS = false>
+template <class A, int LOGN, int EPT, int PASS, bool FROM_REGS = false, int STOP = 99>
 struct InvPasses {
+  // STOP: run passes [PASS, STOP) only (the exchange write that follows pass STOP - 1 included); a second call continues
   // inverse pass PASS covers the same bit window as forward pass NPASS-1-PASS.
   // FROM_REGS: pass 0 takes its input from v (the layout a KEEP_REGS forward transform leaves) instead of LDS.
   static __device__ __forceinline__ void run(const A& ar, typename A::V (&v)[EPT], typename A::V* smem, u32 tid,
@@ -260,7 +313,7 @@ struct InvPasses {
       for (int g = 0; g < G; g++)
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) smem[pass_pos<LOW, R, Sh::T>(P, tid, g, k)] = v[g * (1 << R) + k];
-      InvPasses<A, LOGN, EPT, PASS + 1, FROM_REGS>::run(ar, v, smem, tid, tw, reduce_mask);
+      if constexpr (PASS + 1 < STOP) InvPasses<A, LOGN, EPT, PASS + 1, FROM_REGS, STOP>::run(ar, v, smem, tid, tw, reduce_mask);
     }
   }
 };
@@ -275,13 +328,10 @@ __device__ __forceinline__ void ntt_inv_from_lds(const A& ar, typename A::V (&v)
 
 __device__ __forceinline__ u32 plan_mod(const NttPlan& plan, u32 poly) { return plan.mod[(poly / plan.div) % plan.period]; }
 
+// the store half of a forward transform whose last pass left its results in LDS
 template <class A, int LOGN>
-__device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid) {
+__device__ __forceinline__ void ntt_fwd_store(const A& ar, u64* x, typename A::V* smem, u32 tid) {
   using Sh = NttShape<LOGN>;
-  const A ar(dm);
-  // (storing the last pass's 2^R-element runs straight from registers was measured 15 % slower than this staged,
-  // fully coalesced store; the mirror-image direct LOAD in ntt_inv_body is 25 % faster than staging)
-  ntt_fwd_to_lds<A, LOGN>(ar, x, smem, tid, tw, dm.fwd_reduce_mask);
   if constexpr (NTT_WAVE_PRIVATE && Sh::T >= 64) {
     // every wavefront stores the coefficients its own last pass produced: no barrier before the store either
     exchange_sync<true>();
@@ -316,12 +366,44 @@ __device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A:
   }
 }
 
+template <class A, int LOGN>
+__device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid) {
+  const A ar(dm);
+  // (storing the last pass's 2^R-element runs straight from registers was measured 15 % slower than this staged,
+  // fully coalesced store; the mirror-image direct LOAD in ntt_inv_body is 25 % faster than staging)
+  ntt_fwd_to_lds<A, LOGN>(ar, x, smem, tid, tw, dm.fwd_reduce_mask);
+  ntt_fwd_store<A, LOGN>(ar, x, smem, tid);
+}
+
+// ---- streaming form: raw words of the NEXT polynomial travel while this one is transformed ----
+template <int LOGN>
+__device__ __forceinline__ void ntt_fwd_fetch(u64 (&raw)[kElemsPerThread], const u64* src, u32 tid) {
+  using Sh = NttShape<LOGN>;
+  constexpr int R0 = Sh::radix(0), LOW0 = LOGN - R0, G0 = kElemsPerThread >> R0;
+#pragma unroll
+  for (int g = 0; g < G0; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R0); k++) raw[g * (1 << R0) + k] = ntt_ld<(NTT_NT_FWD & 1) != 0>(src + elem_index<LOW0, R0>(tid + g * Sh::T, k));
+}
+template <class A, int LOGN>
+__device__ __forceinline__ void ntt_fwd_stream_body(const DevMod& dm, const typename A::Tw* tw, u64* x, const u64* next, typename A::V* smem, u32 tid,
+                                                    u64 (&raw)[kElemsPerThread]) {
+  const A ar(dm);
+  typename A::V v[kElemsPerThread];
+#pragma unroll
+  for (int e = 0; e < kElemsPerThread; e++) v[e] = ar.from_u64(raw[e]);
+  if (next) ntt_fwd_fetch<LOGN>(raw, next, tid);  // in flight until the next iteration's conversions
+  FwdPasses<A, LOGN, kElemsPerThread, 0>::run(ar, v, smem, tid, tw, dm.fwd_reduce_mask);
+  ntt_fwd_store<A, LOGN>(ar, x, smem, tid);
+}
+
 template <int LOGN>
 __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase, u64* data, NttPlan plan) {
   using Sh = NttShape<LOGN>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const u32 tid = threadIdx.x;
   const u32 poly = blockIdx.x;
+  ntt_stagger();
   const u32 m = plan_mod(plan, poly);
   const DevMod& dm = ctx->mod[m];
   u64* x = data + (size_t)poly * Sh::N;
@@ -351,7 +433,13 @@ __device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A:
 #pragma unroll
       for (int k = 0; k < (1 << RF); k += 2) {
         typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+#if NTT_PROBE == 1
+        u64x2_t wv;
+        wv.x = tid * 16u + (u32)k;
+        wv.y = tid * 16u + (u32)k + 1u;
+#else
         const u64x2_t wv = ntt_ld<(NTT_NT_INV & 1) != 0>(reinterpret_cast<const u64x2_t*>(src + (k >> 1)));
+#endif
         const ulonglong2 w = make_ulonglong2(wv.x, wv.y);
         v[g * (1 << RF) + k] = ar.from_u64(w.x);
         v[g * (1 << RF) + k + 1] = ar.from_u64(w.y);
@@ -388,6 +476,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const u32 tid = threadIdx.x;
   const u32 poly = blockIdx.x;
+  ntt_stagger();
   const u32 m = plan_mod(plan, poly);
   const DevMod& dm = ctx->mod[m];
   u64* x = data + (size_t)poly * Sh::N;
@@ -400,6 +489,113 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
     MulOp sc = dm.ninv;
     if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
     ntt_inv_body<ArithI, LOGN>(dm, tw, sc, x, reinterpret_cast<u64*>(smem_raw), tid);
+  }
+}
+
+// ---- streaming kernels (NTT_STREAM polynomials per workgroup) ----
+// plan_mod through the scalar unit: a byte load from the kernel arguments would be a VECTOR load, and inside the loop its
+// s_waitcnt vmcnt(0) would also wait for every store of the previous polynomial (vmcnt retires in order)
+__device__ __forceinline__ u32 plan_mod_scalar(const NttPlan& plan, u32 poly) {
+  const u32 i = __builtin_amdgcn_readfirstlane((poly / plan.div) % plan.period);
+  const u32* words = reinterpret_cast<const u32*>(plan.mod);
+  return (words[i >> 2] >> ((i & 3u) * 8u)) & 0xffu;
+}
+// threadIdx.x rebuilt from the wave number (an SGPR) and the lane number: nothing derived from it stays in vector registers
+// across the polynomial loop, where the prefetched words already take 32 of them
+__device__ __forceinline__ u32 stream_tid(u32& wave) {
+  asm volatile("" : "+s"(wave));
+  return (wave << 6) | __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+template <int LOGN, int POLICY>
+__global__ __launch_bounds__(NttShape<LOGN>::T) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_fwd_stream_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase, u64* data, NttPlan plan,
+                                                                           u32 polys) {
+  using Sh = NttShape<LOGN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const u32 tid0 = threadIdx.x;
+  u32 wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const u32 first = blockIdx.x * (u32)NTT_STREAM;
+  const u32 last = first + (u32)NTT_STREAM < polys ? first + (u32)NTT_STREAM : polys;
+  u64 raw[kElemsPerThread];
+  ntt_fwd_fetch<LOGN>(raw, data + (size_t)first * Sh::N, tid0);
+  for (u32 poly = first; poly < last; poly++) {
+    // the store half of the previous transform reads LDS wave by wave; this transform's first exchange writes all of it
+    if (poly != first) __syncthreads();
+    const u32 tid = stream_tid(wave);
+    const u32 m = plan_mod_scalar(plan, poly);
+    const DevMod& dm = ctx->mod[m];
+    u64* x = data + (size_t)poly * Sh::N;
+    const u64* next = poly + 1 < last ? x + Sh::N : nullptr;
+    const MulOp* tw = twbase + (size_t)m * Sh::N;
+    if (POLICY == 1 || (POLICY == 0 && dm.use_f64))
+      ntt_fwd_stream_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), x, next, reinterpret_cast<double*>(smem_raw), tid, raw);
+    else
+      ntt_fwd_stream_body<ArithI, LOGN>(dm, tw, x, next, reinterpret_cast<u64*>(smem_raw), tid, raw);
+  }
+}
+
+typedef unsigned long long ntt_u64x2 __attribute__((ext_vector_type(2)));
+template <int LOGN>
+__device__ __forceinline__ void ntt_inv_fetch(ntt_u64x2 (&raw)[kElemsPerThread / 2], const u64* src, u32 tid) {
+  using Sh = NttShape<LOGN>;
+  constexpr int RF = Sh::radix(Sh::NPASS - 1), GF = kElemsPerThread >> RF;
+#pragma unroll
+  for (int g = 0; g < GF; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << RF); k += 2)
+      raw[(g * (1 << RF) + k) >> 1] = ntt_ld<(NTT_NT_INV & 1) != 0>(reinterpret_cast<const ntt_u64x2*>(src + ((size_t)(tid + g * Sh::T) << RF) + k));
+}
+template <class A, int LOGN>
+__device__ __forceinline__ void ntt_inv_stream_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Tw& sc, u64* x, const u64* next,
+                                                    typename A::V* smem, u32 tid, ntt_u64x2 (&raw)[kElemsPerThread / 2]) {
+  using Sh = NttShape<LOGN>;
+  const A ar(dm);
+  typename A::V v[kElemsPerThread];
+#pragma unroll
+  for (int e = 0; e < kElemsPerThread; e += 2) {
+    v[e] = ar.from_u64(raw[e >> 1].x);
+    v[e + 1] = ar.from_u64(raw[e >> 1].y);
+  }
+  // vmcnt retires in order: a fetch issued before the passes whose twiddles are VECTOR loads (element windows below bit 6:
+  // the first NV passes of an inverse transform) would be waited for at their first twiddle.  It goes out after them.
+  constexpr int NV = (6 + Sh::radix(Sh::NPASS - 1) - 1) / Sh::radix(Sh::NPASS - 1) < Sh::NPASS - 1 ? (6 + Sh::radix(Sh::NPASS - 1) - 1) / Sh::radix(Sh::NPASS - 1) : Sh::NPASS - 1;
+  InvPasses<A, LOGN, kElemsPerThread, 0, true, NV>::run(ar, v, smem, tid, tw, dm.inv_reduce_mask);
+  if (next) ntt_inv_fetch<LOGN>(raw, next, tid);
+  InvPasses<A, LOGN, kElemsPerThread, NV, true>::run(ar, v, smem, tid, tw, dm.inv_reduce_mask);
+  constexpr int R = Sh::radix(0), LOW = LOGN - R, G = kElemsPerThread >> R;
+#pragma unroll
+  for (int g = 0; g < G; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) ntt_st<(NTT_NT_INV & 2) != 0>(x + elem_index<LOW, R>(tid + g * Sh::T, k), ar.scale_canonical(v[g * (1 << R) + k], sc));
+}
+template <int LOGN, int POLICY>
+__global__ __launch_bounds__(NttShape<LOGN>::T) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_inv_stream_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase, u64* data, NttPlan plan,
+                                                                           int scale_mode, u32 polys) {
+  using Sh = NttShape<LOGN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const u32 tid0 = threadIdx.x;
+  u32 wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const u32 first = blockIdx.x * (u32)NTT_STREAM;
+  const u32 last = first + (u32)NTT_STREAM < polys ? first + (u32)NTT_STREAM : polys;
+  ntt_u64x2 raw[kElemsPerThread / 2];
+  ntt_inv_fetch<LOGN>(raw, data + (size_t)first * Sh::N, tid0);
+  for (u32 poly = first; poly < last; poly++) {
+    // the last pass of the previous transform read LDS across wavefronts; this transform's first pass writes it
+    if (poly != first) __syncthreads();
+    const u32 tid = stream_tid(wave);
+    const u32 m = plan_mod_scalar(plan, poly);
+    const DevMod& dm = ctx->mod[m];
+    u64* x = data + (size_t)poly * Sh::N;
+    const u64* next = poly + 1 < last ? x + Sh::N : nullptr;
+    const MulOp* tw = twbase + (size_t)m * Sh::N;
+    if (POLICY == 1 || (POLICY == 0 && dm.use_f64)) {
+      MulOpD sc = dm.ninv_d;
+      if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q_d[m] : ctx->intt_scale_bsk_d[m - ctx->KK];
+      ntt_inv_stream_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), sc, x, next, reinterpret_cast<double*>(smem_raw), tid, raw);
+    } else {
+      MulOp sc = dm.ninv;
+      if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
+      ntt_inv_stream_body<ArithI, LOGN>(dm, tw, sc, x, next, reinterpret_cast<u64*>(smem_raw), tid, raw);
+    }
   }
 }
 
@@ -615,7 +811,11 @@ static void allow_dynamic_lds(const void* kernel, size_t bytes) {
 template <int LOGN>
 static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
   using Sh = NttShape<LOGN>;
+#ifdef NTT_LDS_PAD  // occupancy probe: ask for more LDS than the transform uses (one workgroup per CU at N = 8192 with 2)
+  const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64) * NTT_LDS_PAD;
+#else
   const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
+#endif
 #if NTT_PAIRS
   if constexpr (LOGN <= 12) {  // measured: +5 % at N = 4096; at N = 8192 (128 KB of LDS, one workgroup per CU) 5 % slower
     // as many polynomials as possible go two per workgroup; the remainder (< 2 * period) one per workgroup below
@@ -631,6 +831,19 @@ static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, si
       data += paired * Sh::N;
       polys -= paired;  // paired is a multiple of the period: the plan's modulus cycle continues unchanged
     }
+  }
+#endif
+#if NTT_STREAM > 1 && NTT_DIRECT_LOAD
+  if (LOGN == 13 && polys >= 2048 * (size_t)NTT_STREAM && polys < ((size_t)1 << 32)) {  // enough workgroups to fill the device either way
+    const unsigned groups = (unsigned)((polys + NTT_STREAM - 1) / NTT_STREAM);
+    if (inverse) {
+      allow_dynamic_lds((const void*)ntt_inv_stream_kernel<LOGN, 1>, lds);
+      ntt_inv_stream_kernel<LOGN, 1><<<dim3(groups), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan, scale_mode, (u32)polys);
+    } else {
+      allow_dynamic_lds((const void*)ntt_fwd_stream_kernel<LOGN, 1>, lds);
+      ntt_fwd_stream_kernel<LOGN, 1><<<dim3(groups), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan, (u32)polys);
+    }
+    return hipGetLastError();
   }
 #endif
   if (inverse) {

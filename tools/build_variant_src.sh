@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/build_variant_src.sh <tag> <source-stem> <-D flags...> -- like build_variant.sh, for macros of ONE other translation
+# unit (kernels | kernels_client | evaluator ...): sunscreen_amd/lib/variants/libhipbfv_<tag>.so = the default objects with
+# <source-stem> recompiled under the given definitions.
+set -e
+TAG=$1; STEM=$2; shift 2
+ROOT=$(cd $(dirname $0)/.. && pwd)
+make -s -C $ROOT/sunscreen_amd/csrc
+mkdir -p $ROOT/sunscreen_amd/lib/variants $ROOT/build/variants
+SRC=$ROOT/sunscreen_amd/csrc/$STEM.hip; X=""
+[ -f $SRC ] || { SRC=$ROOT/sunscreen_amd/csrc/$STEM.cpp; X="-x hip"; }
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden --offload-arch=gfx950 "$@" $X -c $SRC -o $ROOT/build/variants/${STEM}_$TAG.o
+OBJS=$(ls $ROOT/build/hipbfv_*.o | grep -v "hipbfv_$STEM.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$ROOT/sunscreen_amd/csrc/exports.map -o $ROOT/sunscreen_amd/lib/variants/libhipbfv_$TAG.so $OBJS $ROOT/build/variants/${STEM}_$TAG.o -ldl
+echo built $TAG
