@@ -108,10 +108,17 @@ inline MulOpD make_mulop_d(u64 w, u64 q) {
 // |T| <= q*(0.5 + |Y|*2^-52); butterflies only add and subtract, so magnitudes grow per stage and
 // every value must stay below 2^53.  This simulates the worst-case growth (in units of q) through the
 // kernel's pass structure and decides at which pass starts all values must be reduced mod q.
+// A twiddle product estimates its quotient from the ROUNDED product and the rounded 1/q (ArithD::mul_tw): relative error
+// 3 * 2^-53 instead of the 2 * 2^-53 of a precomputed W/q, i.e. |T| <= q*(0.5 + |Y| * kTwEps * 2^-52).
+constexpr double kTwEps = 1.5;
+// ArithD::reduce(v) = v - rint(fl(v * fl(1/q))) * q: the quotient v/q = M is estimated with two roundings, off by M * 2^-52
+// (no factor q: v is exact), so what is left is within q * (0.5 + M * 2^-52).  (Rounds 1-2 priced a reduction like a twiddle
+// product, 0.5 + M * q * 2^-52: safe, but with 1.5 x that the 48- and 49-bit primes of N = 16384 ran out of range.)
+inline double reduced(double M) { return 0.5 + M * 1.01 / 4503599627370496.0; }
 bool plan_f64_path(u64 q, int logn, int ept, u32* fwd_mask, u32* inv_mask) {
   if (q >= (1ull << 50)) return false;
   const double limit = 0.98 * 9007199254740992.0 / (double)q;  // 2^53 / q with a margin
-  const double eps = (double)q / 4503599627370496.0;           // q * 2^-52
+  const double eps = kTwEps * (double)q / 4503599627370496.0;  // q * 1.5 * 2^-52
   const int np = ntt_num_passes(logn, ept);
   // forward (Cooley-Tukey): X' = X + T, Y' = X - T
   {
@@ -131,10 +138,10 @@ bool plan_f64_path(u64 q, int logn, int ept, u32* fwd_mask, u32* inv_mask) {
       double m = run(M, &ok);
       if (!ok) {
         mask |= 1u << p;
-        m = run(0.5 + M * eps, &ok);
+        m = run(reduced(M), &ok);
         if (!ok) {  // bit p+16: reduce twice at the start of pass p
           mask |= 1u << (p + 16);
-          m = run(0.5 + (0.5 + M * eps) * eps, &ok);
+          m = run(reduced(reduced(M)), &ok);
           if (!ok) return false;
         }
       }
@@ -162,10 +169,10 @@ bool plan_f64_path(u64 q, int logn, int ept, u32* fwd_mask, u32* inv_mask) {
       double m = run(M, &ok);
       if (!ok) {
         mask |= 1u << p;
-        m = run(0.5 + M * eps, &ok);
+        m = run(reduced(M), &ok);
         if (!ok) {  // bit p+16: reduce twice at the start of pass p
           mask |= 1u << (p + 16);
-          m = run(0.5 + (0.5 + M * eps) * eps, &ok);
+          m = run(reduced(reduced(M)), &ok);
           if (!ok) return false;
         }
       }
@@ -180,7 +187,7 @@ bool plan_f64_path(u64 q, int logn, int ept, u32* fwd_mask, u32* inv_mask) {
 bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
   if (q >= (1ull << 50) || logn < 12 || logn > 15) return false;
   const double limit = 0.98 * 9007199254740992.0 / (double)q;
-  const double eps = (double)q / 4503599627370496.0;
+  const double eps = kTwEps * (double)q / 4503599627370496.0;
   {  // forward: head does head_log(logn) stages from canonical input, then the middle passes
     double M = 1.0;
     for (int s = 0; s < head_log(logn); s++) {
@@ -202,10 +209,10 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
       double m = run(M, &ok);
       if (!ok) {
         mask |= 1u << p;
-        m = run(0.5 + M * eps, &ok);
+        m = run(reduced(M), &ok);
         if (!ok) {  // reduce twice: the second reduction starts from a value already close to q/2
           mask |= 1u << (p + 16);
-          m = run(0.5 + (0.5 + M * eps) * eps, &ok);
+          m = run(reduced(reduced(M)), &ok);
           if (!ok) return false;
         }
       }
@@ -235,10 +242,10 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
       double m = run(M, r, &ok);
       if (!ok) {
         mask |= tail ? (1u << 8) : (1u << p);
-        m = run(0.5 + M * eps, r, &ok);
+        m = run(reduced(M), r, &ok);
         if (!ok) {
           mask |= tail ? (1u << 24) : (1u << (p + 16));
-          m = run(0.5 + (0.5 + M * eps) * eps, r, &ok);
+          m = run(reduced(reduced(M)), r, &ok);
           if (!ok) return false;
         }
       }
@@ -494,9 +501,10 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     for (u32 i = 0; i < n; i++) {
       const u32 k = bit_reverse(i, h.logn);
       if (dm.use_f64) {
-        const MulOpD f = make_mulop_d(pw, p), b = make_mulop_d(ipw, p);
-        std::memcpy(&twf[(size_t)m * n + k], &f, sizeof(MulOp));
-        std::memcpy(&twi[(size_t)m * n + k], &b, sizeof(MulOp));
+        // FP64 policy: the modulus' region holds n doubles (the twiddle alone, ArithD::Tw) in its first half
+        const double f = (double)pw, b = (double)ipw;
+        std::memcpy(reinterpret_cast<double*>(&twf[(size_t)m * n]) + k, &f, sizeof(double));
+        std::memcpy(reinterpret_cast<double*>(&twi[(size_t)m * n]) + k, &b, sizeof(double));
       } else {
         twf[(size_t)m * n + k] = make_mulop(pw, p);
         twi[(size_t)m * n + k] = make_mulop(ipw, p);

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx
   u64* x = data + (size_t)poly * Sh::N;
   const MulOp* tw = twbase + (size_t)m * Sh::N;  // kernel argument: known global address space, scalar loads possible
   if (dm.use_f64)
-    ntt_fwd_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem_raw), tid);
+    ntt_fwd_body<ArithD, LOGN>(dm, reinterpret_cast<const double*>(tw), x, reinterpret_cast<double*>(smem_raw), tid);
   else
     ntt_fwd_body<ArithI, LOGN>(dm, tw, x, reinterpret_cast<u64*>(smem_raw), tid);
 }
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx
 // mul_a / mul_b (both or neither): the transform's input is the pointwise product mul_a (.) mul_b mod q (canonical
 // operands) instead of x -- the dyadic multiply that precedes an inverse transform costs no pass of its own
 template <class A, int LOGN>
-__device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Tw& sc, u64* x,
+__device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Sc& sc, u64* x,
                                              typename A::V* smem, u32 tid, const u64* __restrict__ mul_a = nullptr,
                                              const u64* __restrict__ mul_b = nullptr) {
   using Sh = NttShape<LOGN>;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
   if (dm.use_f64) {
     MulOpD sc = dm.ninv_d;
     if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q_d[m] : ctx->intt_scale_bsk_d[m - ctx->KK];
-    ntt_inv_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), sc, x, reinterpret_cast<double*>(smem_raw), tid);
+    ntt_inv_body<ArithD, LOGN>(dm, reinterpret_cast<const double*>(tw), sc, x, reinterpret_cast<double*>(smem_raw), tid);
   } else {
     MulOp sc = dm.ninv;
     if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) __attribute__((amdgpu_waves_per_
     const u64* next = poly + 1 < last ? x + Sh::N : nullptr;
     const MulOp* tw = twbase + (size_t)m * Sh::N;
     if (POLICY == 1 || (POLICY == 0 && dm.use_f64))
-      ntt_fwd_stream_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), x, next, reinterpret_cast<double*>(smem_raw), tid, raw);
+      ntt_fwd_stream_body<ArithD, LOGN>(dm, reinterpret_cast<const double*>(tw), x, next, reinterpret_cast<double*>(smem_raw), tid, raw);
     else
       ntt_fwd_stream_body<ArithI, LOGN>(dm, tw, x, next, reinterpret_cast<u64*>(smem_raw), tid, raw);
   }
@@ -545,7 +545,7 @@ __device__ __forceinline__ void ntt_inv_fetch(ntt_u64x2 (&raw)[kElemsPerThread /
       raw[(g * (1 << RF) + k) >> 1] = ntt_ld<(NTT_NT_INV & 1) != 0>(reinterpret_cast<const ntt_u64x2*>(src + ((size_t)(tid + g * Sh::T) << RF) + k));
 }
 template <class A, int LOGN>
-__device__ __forceinline__ void ntt_inv_stream_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Tw& sc, u64* x, const u64* next,
+__device__ __forceinline__ void ntt_inv_stream_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Sc& sc, u64* x, const u64* next,
                                                     typename A::V* smem, u32 tid, ntt_u64x2 (&raw)[kElemsPerThread / 2]) {
   using Sh = NttShape<LOGN>;
   const A ar(dm);
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) __attribute__((amdgpu_waves_per_
     if (POLICY == 1 || (POLICY == 0 && dm.use_f64)) {
       MulOpD sc = dm.ninv_d;
       if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q_d[m] : ctx->intt_scale_bsk_d[m - ctx->KK];
-      ntt_inv_stream_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), sc, x, next, reinterpret_cast<double*>(smem_raw), tid, raw);
+      ntt_inv_stream_body<ArithD, LOGN>(dm, reinterpret_cast<const double*>(tw), sc, x, next, reinterpret_cast<double*>(smem_raw), tid, raw);
     } else {
       MulOp sc = dm.ninv;
       if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_dyadic_kernel(const
   const u64* pb = b + ((size_t)j * bstride + m) * Sh::N;  // b: u64[nb][bstride][N] (bstride >= nmod rows per polynomial)
   const MulOp* tw = twbase + (size_t)m * Sh::N;
   if (dm.use_f64)
-    ntt_inv_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(tw), dm.ninv_d, x, reinterpret_cast<double*>(smem_raw), tid, pa, pb);
+    ntt_inv_body<ArithD, LOGN>(dm, reinterpret_cast<const double*>(tw), dm.ninv_d, x, reinterpret_cast<double*>(smem_raw), tid, pa, pb);
   else
     ntt_inv_body<ArithI, LOGN>(dm, tw, dm.ninv, x, reinterpret_cast<u64*>(smem_raw), tid, pa, pb);
 }
@@ -727,7 +727,7 @@ __device__ __forceinline__ void ntt_fwd2_body(const DevMod& dm, const typename A
 }
 
 template <class A, int LOGN>
-__device__ __forceinline__ void ntt_inv2_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Tw& sc, u64* x0, u64* x1,
+__device__ __forceinline__ void ntt_inv2_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Sc& sc, u64* x0, u64* x1,
                                               typename A::V* smem, u32 tid) {
   using Sh = NttShape<LOGN>;
   const A ar(dm);
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T, 2) void ntt_pair_kernel(const De
   u64* x1 = data + (size_t)p1 * Sh::N;
   const MulOp* tw = twbase + (size_t)m * Sh::N;
   if (dm.use_f64) {
-    const MulOpD* twd = reinterpret_cast<const MulOpD*>(tw);
+    const double* twd = reinterpret_cast<const double*>(tw);
     double* sm = reinterpret_cast<double*>(smem_raw);
     if constexpr (INVERSE) {
       MulOpD sc = dm.ninv_d;
@@ -880,7 +880,7 @@ static hipError_t launch_ntt_inv_dyadic_t(const DevCtx* ctx, const MulOp* tw, co
 #define CT_PLAIN_FUSED 1
 #endif
 template <class A, int LOGN>
-__device__ __forceinline__ void ct_plain_body(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi, const typename A::Tw& ninv,
+__device__ __forceinline__ void ct_plain_body(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi, const typename A::Sc& ninv,
                                               const u64* __restrict__ pn, const u64* x, u64* y, typename A::V* smem, u32 tid) {
   using Sh = NttShape<LOGN>;
   typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ct_plain_kernel(const DevCt
   const MulOp* twf = twf_base + (size_t)i * Sh::N;
   const MulOp* twi = twi_base + (size_t)i * Sh::N;
   if constexpr (POLICY_D)
-    ct_plain_body<ArithD, LOGN>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi), dm.ninv_d, p, x, y,
+    ct_plain_body<ArithD, LOGN>(dm, reinterpret_cast<const double*>(twf), reinterpret_cast<const double*>(twi), dm.ninv_d, p, x, y,
                                 reinterpret_cast<double*>(smem_raw), tid);
   else
     ct_plain_body<ArithI, LOGN>(dm, twf, twi, dm.ninv, p, x, y, reinterpret_cast<u64*>(smem_raw), tid);

@@ -659,13 +659,9 @@ __device__ __forceinline__ u64 pin_scalar(u64 v) {
   asm volatile("" : "+s"(v));
   return v;
 }
-__device__ __forceinline__ MulOpD pick_tw(const MulOpD& a, const MulOpD& b, bool upper) {
-  const u64 aw = pin_scalar((u64)__double_as_longlong(a.w)), aq = pin_scalar((u64)__double_as_longlong(a.wq));
-  const u64 bw = pin_scalar((u64)__double_as_longlong(b.w)), bq = pin_scalar((u64)__double_as_longlong(b.wq));
-  MulOpD r;
-  r.w = __longlong_as_double((long long)(upper ? bw : aw));
-  r.wq = __longlong_as_double((long long)(upper ? bq : aq));
-  return r;
+__device__ __forceinline__ double pick_tw(double a, double b, bool upper) {
+  const u64 aw = pin_scalar((u64)__double_as_longlong(a)), bw = pin_scalar((u64)__double_as_longlong(b));
+  return __longlong_as_double((long long)(upper ? bw : aw));
 }
 __device__ __forceinline__ MulOp pick_tw(const MulOp& a, const MulOp& b, bool upper) {
   const u64 aw = pin_scalar(a.w), aq = pin_scalar(a.wq), bw = pin_scalar(b.w), bq = pin_scalar(b.wq);
@@ -820,7 +816,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
       }
     }
     const ArithD ar(dm);
-    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * N);
+    const double* tw = reinterpret_cast<const double*>(twf_base + (size_t)I * N);
     const bool need_reduce = qJ > dm.q;
     double v[NC];
 #pragma unroll
@@ -876,8 +872,8 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
   if (op >= ops) return;
   const DevMod& dm = ctx->mod[I];
   const A ar(dm);
-  const MulOpD* twf = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * Sh::N);
-  const MulOpD* twi = reinterpret_cast<const MulOpD*>(twi_base + (size_t)I * Sh::N);
+  const double* twf = reinterpret_cast<const double*>(twf_base + (size_t)I * Sh::N);
+  const double* twi = reinterpret_cast<const double*>(twi_base + (size_t)I * Sh::N);
   constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
   using First = BlkPass<A, L, LOWF0, RF0, EPT>;
   constexpr int RL = split_fwd_radix(L, Sh::NPF - 1);  // last forward window: LOW = 0
@@ -933,7 +929,7 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
     if (J0 > 0) __syncthreads();  // the previous group's last pass may still be reading LDS
     // The twiddles do not depend on the group: without this the compiler hoists every twiddle load of all passes
     // out of the loop and keeps ~100 registers of them alive.  Re-materialise the pointer.
-    const MulOpD* twf_j = opaque_uniform(twf);  // (an opaque OFFSET: the pointer keeps its address space, nttcore.hpp)
+    const double* twf_j = opaque_uniform(twf);  // (an opaque OFFSET: the pointer keeps its address space, nttcore.hpp)
     mid_forward_multi<A, L, NP, EPT, KS_TW_PIPE(L)>(ar, v, smem, tid, blk, twf_j, dm.split_fwd_mask);
 #pragma unroll
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
@@ -956,7 +952,7 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
         load_src(J + 3, nxt[1]);
       }
       if (J > 0) __syncthreads();
-      const MulOpD* twf_j = opaque_uniform(twf);
+      const double* twf_j = opaque_uniform(twf);
       mid_forward_multi<A, L, 2, EPT>(ar, cur, smem, tid, blk, twf_j, dm.split_fwd_mask);
       mac(J, cur[0]);
       mac(J + 1, cur[1]);
@@ -1156,7 +1152,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
   if (!sp_done) {
     const DevMod& sp = ctx->mod[KK - 1];
     const ArithD ar(sp);
-    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK - 1) * N);
+    const double* tw = reinterpret_cast<const double*>(twi_base + (size_t)(KK - 1) * N);
     double v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)(KK - 1) * N, N, G::tail_in(t, k));
@@ -1184,7 +1180,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     }
     if (!done) {
       const ArithD ar(mj);
-      const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)J * N);
+      const double* tw = reinterpret_cast<const double*>(twi_base + (size_t)J * N);
       double v[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, G::tail_in(t, k));
@@ -1262,7 +1258,7 @@ __global__ EDGE_BOUNDS(KMAX) void mul_head_kernel(const DevCtx* __restrict__ ctx
         double v[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) v[k] = x[i][k];
-        head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const MulOpD*>(twf_base + (size_t)i * N), t);
+        head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(twf_base + (size_t)i * N), t);
         double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
         if constexpr (PACK) {
 #pragma unroll
@@ -1275,7 +1271,7 @@ __global__ EDGE_BOUNDS(KMAX) void mul_head_kernel(const DevCtx* __restrict__ ctx
     // fetched once), and run the head stages of each auxiliary residue as soon as it is complete
     behz_extend_multi_d<KMAX, NC>(ctx, x, [&](u32 j, double(&ev)[NC]) {
       const ArithD ar(ctx->mod[KK + j]);
-      head_fwd_owned<ArithD, L>(ar, ev, reinterpret_cast<const MulOpD*>(twf_base + (size_t)(KK + j) * N), t);
+      head_fwd_owned<ArithD, L>(ar, ev, reinterpret_cast<const double*>(twf_base + (size_t)(KK + j) * N), t);
       double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
       if constexpr (PACK) {
 #pragma unroll
@@ -1302,7 +1298,7 @@ __global__ EDGE_BOUNDS(KMAX) void mul_head_kernel(const DevCtx* __restrict__ ctx
         double v[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) v[k] = ar.from_u64(x[i][k]);
-        head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const MulOpD*>(tw), t);
+        head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(tw), t);
         double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
 #pragma unroll
         for (int k = 0; k < NC; k++) o[G::head_out(t, k)] = v[k];
@@ -1756,13 +1752,13 @@ __global__ __launch_bounds__((MulMidGeom<L, POLICY_D, SQUARE, PACK>::TPB), (MulM
   const MulOp* twi = twi_base + (size_t)m * Sh::N;
   static_assert(batched || !SQUARE, "the squaring specialisation exists in the pass-batched bodies only");
   if constexpr (batched && POLICY_D)
-    mul_mid_body_batched<ArithD, L, PACK, Geo::EPT, Geo::MODE, SQUARE>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
+    mul_mid_body_batched<ArithD, L, PACK, Geo::EPT, Geo::MODE, SQUARE>(dm, reinterpret_cast<const double*>(twf), reinterpret_cast<const double*>(twi),
                                     reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                                     reinterpret_cast<double*>(smem), tid, blk);
   else if constexpr (batched)
     mul_mid_body_batched<ArithI, L, false, kBlkEPT, 0, SQUARE>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
   else if constexpr (POLICY_D)
-    mul_mid_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(twf), reinterpret_cast<const MulOpD*>(twi),
+    mul_mid_body<ArithD, L>(dm, reinterpret_cast<const double*>(twf), reinterpret_cast<const double*>(twi),
                             reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                             reinterpret_cast<double*>(smem), reinterpret_cast<double*>(park), tid, blk);
   else
@@ -1773,7 +1769,7 @@ __global__ __launch_bounds__((MulMidGeom<L, POLICY_D, SQUARE, PACK>::TPB), (MulM
 // src: the residue row (not offset by t)
 template <class A, int L>
 __device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V* __restrict__ src, u32 t, const typename A::Tw* __restrict__ tw,
-                                                const typename A::Tw& sc, u32 mask, u64 (&out)[4]) {
+                                                const typename A::Sc& sc, u32 mask, u64 (&out)[4]) {
   typename A::V v[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) v[k] = src[EdgeGeom<L>::tail_in(t, k)];
@@ -1784,7 +1780,7 @@ __device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V
 
 // the same for the FP64 epilogue: reduced doubles out (|out| <= q/2)
 template <int L, bool PACK>
-__device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const NatRaw<PACK> (&raw)[4], const MulOpD* __restrict__ tw, const MulOpD& sc,
+__device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const NatRaw<PACK> (&raw)[4], const double* __restrict__ tw, const MulOpD& sc,
                                                   u32 mask, u32 t, double (&out)[4]) {
   double v[4];
 #pragma unroll
@@ -1815,7 +1811,7 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
       NatRaw<PACK> raw[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d + (size_t)i * N), N, G::tail_in(t, k));
-      tail_inv4_scale_d<L, PACK>(ar, raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+      tail_inv4_scale_d<L, PACK>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
 #pragma unroll
       for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
     }
@@ -1828,7 +1824,7 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
       },
       [&](u32 j, const NatRaw<PACK>(&raw)[4], double(&xb)[4]) {
         const DevMod& dm = ctx->mod[KK + j];
-        tail_inv4_scale_d<L, PACK>(ArithD(dm), raw, reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j],
+        tail_inv4_scale_d<L, PACK>(ArithD(dm), raw, reinterpret_cast<const double*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j],
                                    dm.split_inv_mask, t, xb);
       },
       res);
@@ -1866,7 +1862,7 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
       u64 r4[4];
       if (residue_is_f64(dm)) {
         const ArithD ar(dm);
-        tail_inv4_scale<ArithD, L>(ar, reinterpret_cast<const double*>(d + (size_t)i * N), t, reinterpret_cast<const MulOpD*>(twi_base + (size_t)i * N),
+        tail_inv4_scale<ArithD, L>(ar, reinterpret_cast<const double*>(d + (size_t)i * N), t, reinterpret_cast<const double*>(twi_base + (size_t)i * N),
                                    ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
       } else {
         const ArithI ar(dm);
@@ -1928,7 +1924,7 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
   {
     const DevMod& sp = ctx->mod[KK - 1];
     const ArithD ar(sp);
-    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)(KK - 1) * N);
+    const double* tw = reinterpret_cast<const double*>(twi_base + (size_t)(KK - 1) * N);
     double v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = nat_load<PACKK, NtSites<L>::tail_ld>(acc + (size_t)(KK - 1) * N, N, G::tail_in(t, k));
@@ -1942,7 +1938,7 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
     if ((u32)J >= K) break;
     const DevMod& mj = ctx->mod[J];
     const ArithD ar(mj);
-    const MulOpD* tw = reinterpret_cast<const MulOpD*>(twi_base + (size_t)J * N);
+    const double* tw = reinterpret_cast<const double*>(twi_base + (size_t)J * N);
     double v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = nat_load<PACKK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, G::tail_in(t, k));
@@ -2000,7 +1996,7 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_head_kernel(const DevCtx* __restrict_
     for (u32 I = 0; I < KK; I++) {
       const DevMod& dm = ctx->mod[I];
       const ArithD ar(dm);
-      const MulOpD* tw = reinterpret_cast<const MulOpD*>(twf_base + (size_t)I * N);
+      const double* tw = reinterpret_cast<const double*>(twf_base + (size_t)I * N);
       const bool need_reduce = qJ > dm.q;
       double v[NC];
 #pragma unroll
@@ -2043,7 +2039,7 @@ __global__ __launch_bounds__(kHeadThreads) void ntt_head_kernel(const DevCtx* __
     double v[NC];
 #pragma unroll
     for (int k = 0; k < NC; k++) v[k] = ar.from_u64(x[(size_t)k * Q]);
-    head_fwd(ar, v, reinterpret_cast<const MulOpD*>(tw));
+    head_fwd(ar, v, reinterpret_cast<const double*>(tw));
     double* o = reinterpret_cast<double*>(x);
 #pragma unroll
     for (int k = 0; k < NC; k++) o[(size_t)k * Q] = v[k];
@@ -2091,7 +2087,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB)) void ntt_midfwd_kernel(const 
   u64* x = data + (size_t)poly * Sh::N;
   const MulOp* tw = twf_base + (size_t)m * Sh::N;
   if (residue_is_f64(dm))
-    ntt_midfwd_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem), threadIdx.x, blk);
+    ntt_midfwd_body<ArithD, L>(dm, reinterpret_cast<const double*>(tw), x, reinterpret_cast<double*>(smem), threadIdx.x, blk);
   else
     ntt_midfwd_body<ArithI, L>(dm, tw, x, smem, threadIdx.x, blk);
 }
@@ -2128,7 +2124,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB)) void ntt_midinv_kernel(const 
   u64* x = data + (size_t)poly * Sh::N;
   const MulOp* tw = twi_base + (size_t)m * Sh::N;
   if (residue_is_f64(dm))
-    ntt_midinv_body<ArithD, L>(dm, reinterpret_cast<const MulOpD*>(tw), x, reinterpret_cast<double*>(smem), threadIdx.x, blk);
+    ntt_midinv_body<ArithD, L>(dm, reinterpret_cast<const double*>(tw), x, reinterpret_cast<double*>(smem), threadIdx.x, blk);
   else
     ntt_midinv_body<ArithI, L>(dm, tw, x, smem, threadIdx.x, blk);
 }
@@ -2149,7 +2145,7 @@ __global__ __launch_bounds__(kHeadThreads) void ntt_tail_kernel(const DevCtx* __
   if (residue_is_f64(dm)) {
     const ArithD ar(dm);
     const MulOpD sc = scale_mode == 1 ? (m < ctx->KK ? ctx->intt_scale_q_d[m] : ctx->intt_scale_bsk_d[m - ctx->KK]) : dm.ninv_d;
-    tail_inv4_scale<ArithD, L>(ar, reinterpret_cast<const double*>(x), t, reinterpret_cast<const MulOpD*>(tw), sc, dm.split_inv_mask, o);
+    tail_inv4_scale<ArithD, L>(ar, reinterpret_cast<const double*>(x), t, reinterpret_cast<const double*>(tw), sc, dm.split_inv_mask, o);
   } else {
     const ArithI ar(dm);
     MulOp sc = dm.ninv;

@@ -78,7 +78,8 @@ __device__ __forceinline__ const T* opaque_uniform(const T* p) {
 // ArithI: 64-bit integers, Harvey lazy butterflies with Shoup twiddles (any prime < 2^62).
 struct ArithI {
   using V = u64;
-  using Tw = MulOp;
+  using Tw = MulOp;  // a twiddle factor
+  using Sc = MulOp;  // a per-modulus constant (n^-1, the fused BEHZ scalings)
   u64 q, q2;
   const DevMod* dm;
   __device__ __forceinline__ explicit ArithI(const DevMod& m) : q(m.q), q2(m.q << 1), dm(&m) {}
@@ -104,25 +105,38 @@ struct ArithI {
     v = v >= q2 ? v - q2 : v;
     return v >= q ? v - q : v;
   }
-  __device__ __forceinline__ u64 scale_canonical(V v, const Tw& sc) const { return mul_shoup(v, sc.w, sc.wq, q); }
+  __device__ __forceinline__ u64 scale_canonical(V v, const Sc& sc) const { return mul_shoup(v, sc.w, sc.wq, q); }
 };
 
 // ArithD: residues as exact integers in doubles (primes < 2^50).  T = Y*W - rint(Y*(W/q))*q is exact:
 // the product is split error-free with an fma, the quotient estimate is off by at most
 // 0.5 + |Y|*2^-52, and every intermediate is an integer below 2^53 (range plan: context.cpp).
+// A TWIDDLE is the 8-byte W alone (r03): the quotient is estimated from the rounded product, rint(fl(Y*W) * fl(1/q)) -- three
+// roundings instead of two, off by at most 0.5 + |Y|*1.5*2^-52, which the range plan prices (kTwEps) -- so a transform
+// fetches half the twiddle bytes it did with (W, W/q) pairs and a staged twiddle takes two registers instead of four.  Every
+// workload runs at the package power cap (profiles/r03_power_samples.txt): bytes moved are time.  Per-modulus CONSTANTS
+// (Sc: n^-1, the BEHZ scalings) keep the pair: they come through the scalar cache once per kernel.
 struct ArithD {
   using V = double;
-  using Tw = MulOpD;
+  using Tw = double;
+  using Sc = MulOpD;
   double q, qinv;
   __device__ __forceinline__ explicit ArithD(const DevMod& m) : q(m.qd), qinv(m.qinv) {}
   static __device__ __forceinline__ V from_u64(u64 x) {
     // exact for x < 2^52: plant the integer in the mantissa of 2^52 and subtract 2^52
     return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0;
   }
-  __device__ __forceinline__ V mul_const(V y, const Tw& w) const {
+  __device__ __forceinline__ V mul_const(V y, const Sc& w) const {
     const double qf = rint(y * w.wq);
     const double xh = y * w.w;
     const double xl = fma(y, w.w, -xh);
+    return fma(-qf, q, xh) + xl;
+  }
+  // y * W mod q for a twiddle W in [0, q): |result| <= q*(0.5 + |y|*1.5*2^-52)
+  __device__ __forceinline__ V mul_tw(V y, Tw w) const {
+    const double xh = y * w;
+    const double xl = fma(y, w, -xh);
+    const double qf = rint(xh * qinv);
     return fma(-qf, q, xh) + xl;
   }
   __device__ __forceinline__ V reduce(V v) const { return fma(-rint(v * qinv), q, v); }
@@ -135,14 +149,14 @@ struct ArithD {
   }
   __device__ __forceinline__ V mul_add(V a, V b, V c) const { return reduce(mul_var(a, b) + c); }
   __device__ __forceinline__ void fwd(V& X, V& Y, const Tw& w) const {
-    const double t = mul_const(Y, w), x = X;
+    const double t = mul_tw(Y, w), x = X;
     X = x + t;
     Y = x - t;
   }
   __device__ __forceinline__ void inv(V& X, V& Y, const Tw& w) const {
     const double u = X, y = Y;
     X = u + y;
-    Y = mul_const(u - y, w);
+    Y = mul_tw(u - y, w);
   }
   static __device__ __forceinline__ u64 to_bits(V v) {  // v an integer in [0, 2^52)
     return (u64)__double_as_longlong(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
@@ -152,7 +166,7 @@ struct ArithD {
     return to_bits(v);
   }
   __device__ __forceinline__ u64 canonical(V v) const { return to_u64(reduce(v)); }
-  __device__ __forceinline__ u64 scale_canonical(V v, const Tw& sc) const { return to_u64(reduce(mul_const(v, sc))); }
+  __device__ __forceinline__ u64 scale_canonical(V v, const Sc& sc) const { return to_u64(reduce(mul_const(v, sc))); }
 };
 
 }  // namespace hipbfv
