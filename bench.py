@@ -71,6 +71,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=0, help="ops in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--settle-ms", type=float, default=150.0, help="keep running untimed steps after the W warmup steps until this much wall time "
+                    "has passed (device clocks under the power cap settle in tens of ms; 0 = exactly W warmup steps)")
+    ap.add_argument("--power", action="store_true", help="N=1: after the measurement, sample rocm-smi (package power, shader clock) while the steps "
+                    "keep running and report it as `power` (about 3 s)")
     ap.add_argument("--no-secondary", action="store_true", help="headline run only: skip the n=16384 mul+relin and the NTT workload "
                     "that the default run reports under `secondary`")
     ap.add_argument("--check-items", type=int, default=64, help="mulrelin: items compared bit for bit with the oracle (BASELINE.md section 3: >= 64)")
@@ -117,6 +121,48 @@ def launch_ranks(args) -> int:
 # ---------------------------------------------------------------------------------------------------------------------
 # shapes (shared by the run and by --dry-run)
 # ---------------------------------------------------------------------------------------------------------------------
+def power_leg(step, sync, seconds=2.5):
+    """Package power and shader clock while the workload runs (untimed, after the measurement): rocm-smi is sampled from a
+    thread while this thread keeps launching steps.  Every workload of this repository runs at the package power cap, which
+    is what bounds the VALU-issue and HBM fractions the line reports; None when rocm-smi is missing or prints nothing usable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    dev = os.environ.get("LOCAL_RANK", "0")
+    samples, done = [], threading.Event()
+
+    def sampler():
+        time.sleep(0.6)  # past the ramp
+        for _ in range(3):
+            try:
+                out = subprocess.run([smi, "-d", dev, "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                break
+            w = re.search(r"(?:Current Socket|Average) Graphics Package Power \(W\): ([0-9.]+)", out)
+            c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+            cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", out)
+            if w and c:
+                samples.append((float(w.group(1)), int(c.group(1)), float(cap.group(1)) if cap else None))
+        done.set()
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while not done.is_set() and time.perf_counter() - t0 < 30.0:
+        step()
+        sync()
+    th.join(timeout=5)
+    if not samples:
+        return None
+    return {"package_w": round(sum(x[0] for x in samples) / len(samples), 1), "sclk_mhz": int(sum(x[1] for x in samples) / len(samples)),
+            "cap_w": samples[0][2], "samples": len(samples), "source": "rocm-smi while the workload's steps run (untimed leg after the measurement)"}
+
+
 def default_K(n):
     # data primes of SEAL's 128-bit default set (CoeffModulus::BFVDefault): key level = K + 1
     return {1024: 1, 2048: 1, 4096: 2, 8192: 4, 16384: 8, 32768: 15}[n]
@@ -482,6 +528,19 @@ def measure(args, env: Env, secondary: bool = False):
 
     for _ in range(args.warmup):
         step()
+    # Every workload here runs at the package power cap (profiles/r03_power_samples.txt: 1365-1395 W of 1400 W, sclk 1.98-2.15
+    # GHz), and the clock the firmware settles on takes tens of milliseconds to reach: W steps of a sub-millisecond workload
+    # (the NTT: 0.87 ms) end before that, and the K steps after them were measured 12 % below the sustained rate.  Untimed
+    # steps continue until --settle-ms of wall time have passed since the first one; the timed region is still exactly K steps.
+    settle_steps = 0
+    if args.settle_ms > 0:
+        torch.cuda.synchronize()
+        t_settle = time.perf_counter()
+        while args.warmup and (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(max(args.warmup, 1)):
+                step()
+                settle_steps += 1
+            torch.cuda.synchronize()
     barrier()
     ev.profile(True)
     ev.profile_reset()
@@ -696,6 +755,9 @@ def measure(args, env: Env, secondary: bool = False):
     cpu = None
     if not args.no_cpu and world == 1:
         cpu = cpu_baseline(args, O, n, primes, t, small=secondary)
+    power = None
+    if args.power and world == 1 and not secondary:
+        power = power_leg(step, torch.cuda.synchronize)
     line = {
         "metric": metric,
         "value": round(value, 2),
@@ -703,6 +765,7 @@ def measure(args, env: Env, secondary: bool = False):
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "settle_steps": settle_steps,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True,
         "scaling": scaling_of(args),
@@ -721,6 +784,8 @@ def measure(args, env: Env, secondary: bool = False):
         "cpu_baseline": cpu,
         "parity": parity,
     }
+    if power:
+        line["power"] = power
     if args.total_batch:
         line["config"]["total_batch"] = args.total_batch
     if exchange:
@@ -746,7 +811,7 @@ def main():
     if headline and not args.no_secondary:
         second = {}
         for key, over in (("mulrelin_n16384", dict(n=16384, batch=max(args.batch // 4, 1), total_batch=args.total_batch // 4, check_items=16)),
-                          ("ntt_n8192", dict(workload="ntt"))):
+                          ("ntt_n8192", dict(workload="ntt", steps=max(args.steps, 100)))):  # a step is 0.85 ms: time at least 85 ms
             sub = copy.copy(args)
             for k, v in over.items():
                 setattr(sub, k, v)

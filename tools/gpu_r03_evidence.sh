@@ -13,8 +13,8 @@ import json; d=json.load(open('$OUT/bench_$name.json')); print('$name', d['value
 ( time python bench.py --steps 20 --warmup 3 ) > $OUT/bench_default.txt 2>$OUT/bench_default.err; grep '^{' $OUT/bench_default.txt | tail -1 > $OUT/bench_default.json; tail -3 $OUT/bench_default.err
 run mulrelin_n4096 --n 4096 --batch 8192 --steps 5 --warmup 2
 run mulrelin_n32768 --n 32768 --batch 256 --steps 2 --warmup 1
-run ntt_n16384 --workload ntt --n 16384 --batch 2048 --steps 10 --warmup 2
-run ntt_n8192_bits54-54-54-56 --workload ntt --coeff-bits 54,54,54,56 --steps 10 --warmup 2
+run ntt_n16384 --workload ntt --n 16384 --batch 2048 --steps 50 --warmup 2
+run ntt_n8192_bits54-54-54-56 --workload ntt --coeff-bits 54,54,54,56 --steps 100 --warmup 2
 run chi_sq_n16384 --workload chi_sq --n 16384 --batch 256 --steps 3 --warmup 1
 run dot_prod_n16384 --workload dot_prod --n 16384 --batch 256 --steps 3 --warmup 1
 run e2e_n8192 --workload e2e --batch 2048 --steps 5 --warmup 2
