@@ -73,8 +73,10 @@ def parse(argv=None):
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--settle-ms", type=float, default=150.0, help="keep running untimed steps after the W warmup steps until this much wall time "
                     "has passed (device clocks under the power cap settle in tens of ms; 0 = exactly W warmup steps)")
-    ap.add_argument("--power", action="store_true", help="N=1: after the measurement, sample rocm-smi (package power, shader clock) while the steps "
-                    "keep running and report it as `power` (about 3 s)")
+    ap.add_argument("--no-power", dest="power", action="store_false", help="skip the `power` leg (N=1: after the measurement, rocm-smi is sampled for package "
+                    "power and shader clock while the steps keep running, about 3 s)")
+    ap.add_argument("--power", dest="power", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(power=True)
     ap.add_argument("--no-secondary", action="store_true", help="headline run only: skip the n=16384 mul+relin and the NTT workload "
                     "that the default run reports under `secondary`")
     ap.add_argument("--check-items", type=int, default=64, help="mulrelin: items compared bit for bit with the oracle (BASELINE.md section 3: >= 64)")
@@ -531,16 +533,25 @@ def measure(args, env: Env, secondary: bool = False):
     # Every workload here runs at the package power cap (profiles/r03_power_samples.txt: 1365-1395 W of 1400 W, sclk 1.98-2.15
     # GHz), and the clock the firmware settles on takes tens of milliseconds to reach: W steps of a sub-millisecond workload
     # (the NTT: 0.87 ms) end before that, and the K steps after them were measured 12 % below the sustained rate.  Untimed
-    # steps continue until --settle-ms of wall time have passed since the first one; the timed region is still exactly K steps.
+    # steps continue for about --settle-ms of device time; the timed region is still exactly K steps.
     settle_steps = 0
-    if args.settle_ms > 0:
+    if args.settle_ms > 0 and args.warmup > 0:
+        # the number of extra steps is agreed between the ranks (a step may contain a collective): W more steps are timed,
+        # their rate sizes the rest, the slowest rank's count is the one every rank runs
         torch.cuda.synchronize()
         t_settle = time.perf_counter()
-        while args.warmup and (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-            for _ in range(max(args.warmup, 1)):
-                step()
-                settle_steps += 1
-            torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        per_step = max((time.perf_counter() - t_settle) / args.warmup, 1e-5)
+        more = min(max(int(args.settle_ms * 1e-3 / per_step + 0.999) - args.warmup, 0), 100000)
+        if world > 1:
+            mt = torch.tensor([more], dtype=torch.int64, device=cdev)
+            dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+            more = int(mt.item())
+        for _ in range(more):
+            step()
+        settle_steps = args.warmup + more
     barrier()
     ev.profile(True)
     ev.profile_reset()
