@@ -391,6 +391,10 @@ long hipbfv_Program_NumOutputs(void *program, uint64_t *count);
  * (microseconds per repetition, one stream synchronisation each). */
 long hipbfv_debug_graph_probe(void *context, const uint64_t *a, const uint64_t *b, const uint64_t *relin_key, uint64_t *out,
                               uint64_t iterations, double *us_direct, double *us_graph);
+/* Diagnostic, host only (no device): the FP64 range plans of one prime at degree 2^log_n -- out6 = {FP64 policy possible,
+ * forward reduce mask, inverse reduce mask, split pipelines possible, split forward mask, split inverse mask}; bit p of a mask =
+ * every value is reduced mod q at the start of pass p (bit 8 of the split inverse mask: at the start of the tail stages). */
+long hipbfv_debug_f64_plan(uint64_t prime, uint32_t log_n, uint32_t *out6);
 /* The schedule Run follows, one line per step ("mul_relin members=3 square", "sum members=2 terms=6", "plain_matrix members=256
  * columns=256", ...): `*needed` = bytes including the terminator; `buffer` may be NULL to ask for the size. */
 long hipbfv_Program_Describe(void *program, char *buffer, uint64_t capacity, uint64_t *needed);

@@ -2029,6 +2029,17 @@ long hipbfv_Program_NumOutputs(void* h, uint64_t* count) HIPBFV_BEGIN
   return HIPBFV_S_OK;
 HIPBFV_END
 
+// Diagnostic, host only: the FP64 range plans of one prime (context.cpp); the CPU suite replays them against an independent
+// worst-case model of the butterfly arithmetic.
+long hipbfv_debug_f64_plan(uint64_t prime, uint32_t log_n, uint32_t* out6) HIPBFV_BEGIN
+  if (!out6) return fail(HIPBFV_E_POINTER, "null output");
+  if (log_n < 10 || log_n > 15) return fail(HIPBFV_E_INVALIDARG, "log_n outside 10..15");
+  u32 out[6];
+  debug_f64_plan(prime, (int)log_n, out);
+  for (int i = 0; i < 6; i++) out6[i] = out[i];
+  return HIPBFV_S_OK;
+HIPBFV_END
+
 // Diagnostic (tools/graph_probe.py): one multiply + relinearize of a single ciphertext pair, (1) launched kernel by kernel as
 // the handle-level calls do, (2) the same launches captured once into a hipGraph and replayed.  Both are timed from the host
 // with one stream synchronisation per repetition, i.e. what a caller of the SEAL-named entry points waits for.

@@ -258,6 +258,12 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
 
 }  // namespace
 
+void debug_f64_plan(u64 q, int logn, u32 out[6]) {
+  for (int i = 0; i < 6; i++) out[i] = 0;
+  out[0] = plan_f64_path(q, logn, 16, &out[1], &out[2]) ? 1u : 0u;
+  out[3] = out[0] && plan_f64_split(q, logn, &out[4], &out[5]) ? 1u : 0u;
+}
+
 bool is_prime_u64(u64 v) {
   if (v < 2) return false;
   for (u64 p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {

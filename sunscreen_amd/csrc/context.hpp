@@ -18,6 +18,9 @@
 namespace hipbfv {
 
 bool is_prime_u64(u64 v);
+// Host-only view of the FP64 range plans of a prime at degree 2^logn (no device needed: tests/test_fp64_range_plan_cpu.py):
+// out = {use_f64, fwd_reduce_mask, inv_reduce_mask, split_ok, split_fwd_mask, split_inv_mask}
+void debug_f64_plan(u64 q, int logn, u32 out[6]);
 // primes == 1 (mod factor), descending from just below 2^bits
 std::vector<u64> find_primes(u64 factor, int bits, size_t count);
 u64 minimal_primitive_root(u64 two_n, u64 q);

@@ -460,6 +460,11 @@ constexpr int kHeadThreads = 256;
 #ifndef MID_FWD_PAIRS
 #define MID_FWD_PAIRS(L) ((L) == 13)
 #endif
+// MODE 3: the two single-operand forward transforms run while two transformed operands and one product row are live (96
+// registers): whether they also prefetch the next pass's twiddles (a second set of twiddle registers)
+#ifndef MID3_PIPE_SINGLE
+#define MID3_PIPE_SINGLE true  // measured: 6.10-6.15 with, 6.19-6.34 ms without; the scratch is the same either way
+#endif
 #ifndef MID_TW_PIPE  // mul_mid (pass-batched bodies): next pass's twiddles fetched before the exchange (a second set of twiddle registers)
 #define MID_TW_PIPE(L) true
 #endif
@@ -1586,7 +1591,7 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
     pin_loads();
     load_into(3, x[0]);
     __syncthreads();
-    mid_forward_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, x, smem, tid, blk, fresh(twf), dm.split_fwd_mask);  // b1
+    mid_forward_multi<A, L, 1, EPT, MID3_PIPE_SINGLE>(ar, x, smem, tid, blk, fresh(twf), dm.split_fwd_mask);  // b1
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
       d12[0][e] = ar.mul_var(ab[0][e], x[0][e]);  // a0 b1
@@ -1595,7 +1600,7 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
     pin_loads();
     load_into(1, x[0]);
     __syncthreads();
-    mid_forward_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, x, smem, tid, blk, fresh(twf), dm.split_fwd_mask);  // a1
+    mid_forward_multi<A, L, 1, EPT, MID3_PIPE_SINGLE>(ar, x, smem, tid, blk, fresh(twf), dm.split_fwd_mask);  // a1
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
       d12[0][e] = ar.mul_add(x[0][e], ab[1][e], d12[0][e]);  // + a1 b0
@@ -1684,9 +1689,12 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 // Elements per thread of the FP64 middle kernels at N = 16384.  16 (256-thread workgroups, two exchange regions, two workgroups
 // per CU instead of one) was built and measured in round 2: the four operands of the tensor product are 128 registers, the 14
 // vector twiddles of a pass and of the prefetched next pass another 112, the kernel spills 860 bytes per lane and mul_mid takes
-// 16.5 ms instead of 6.4 (bit-exact, `-DMID_EPT_14=16`).  8 stays.
+// 16.5 ms instead of 6.4 (bit-exact).  Round 3 built two ways round the four operands (MID_EPT16_MODE below); with 16-byte
+// twiddles both lost to the 8-element kernel (8.7 and 7.1 ms against 6.5), with 8-byte twiddles (nttcore.hpp) MODE 3 fits 256
+// registers but for 92 bytes of scratch and wins: mul_mid 6.10-6.22 against 6.27-6.57 ms per 1024 ops (interleaved A/B on two
+// boxes, mul+relin +0.3...2.4 %).  16 is the default; `-DMID_EPT_14=8` is the one-workgroup-per-CU kernel of rounds 1-2.
 #ifndef MID_EPT_14
-#define MID_EPT_14 8
+#define MID_EPT_14 (HIPBFV_GEOM14 == 4 ? 16 : 8)
 #endif
 // The SQUARING instantiation at N = 16384 does take 16 (r03): two transforms instead of four fit the 256 registers of two
 // 256-thread workgroups per CU without scratch (MID_EPT_14_SQ).
@@ -1698,7 +1706,7 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 // back from L2 at the tensor product; two forward rounds).  Parking overwrites the block's own words of an 8-byte row, so it
 // needs unpacked intermediates: with 48-bit packed rows (PACK) the general body stays at 8 elements per thread.
 #ifndef MID_EPT16_MODE
-#define MID_EPT16_MODE 4
+#define MID_EPT16_MODE 3
 #endif
 constexpr int mid_ept_d(int logn, bool square, bool pack) {
   return logn == 14 ? (square ? MID_EPT_14_SQ : (pack && MID_EPT16_MODE == 4) ? kBlkEPT : MID_EPT_14) : kBlkEPT;

@@ -1,0 +1,181 @@
+"""The FP64 policy keeps residues as exact integers in doubles (sunscreen_amd/csrc/nttcore.hpp, ArithD).  Two things make that
+safe and neither needs a GPU to check:
+
+ (1) the twiddle product `mul_tw` -- T = Y*W - rint(fl(Y*W) * fl(1/q)) * q computed with an error-free split -- is EXACT and
+     |T| <= q * (0.5 + |Y| * 1.5 * 2^-52): replayed here in exact integer arithmetic plus IEEE double roundings (Python floats),
+     on random and on adversarial operands, for every prime the FP64 policy is used with;
+ (2) the range plan (context.cpp: at which passes everything is reduced) keeps every intermediate below 2^53 under that
+     bound: the plans come out of the library (hipbfv_debug_f64_plan, host only) and are replayed against a worst-case model
+     written independently here, pass structure (nttshape.hpp) included.
+"""
+import ctypes as C
+import math
+import random
+
+import pytest
+
+from oracle import bfv_oracle as O
+
+TWO52 = float(1 << 52)
+LIMIT = 1 << 53
+
+
+def _mul_tw(y: int, w: int, q: int):
+    """ArithD::mul_tw with every rounding made explicit; returns (T, exact) where exact says no rounding lost anything."""
+    qinv = 1.0 / float(q)                  # fl(1/q)
+    xh = float(y) * float(w)               # fl(y*w): Python floats are IEEE doubles, round to nearest even
+    xl_exact = y * w - int(xh)             # fma(y, w, -xh) computes this exactly when it is representable
+    exact = float(xl_exact) == xl_exact and abs(xl_exact) < LIMIT
+    qf = round(xh * qinv)                  # v_rndne_f64: round half to even, as Python's round() on a float
+    t_exact = int(xh) - qf * q             # fma(-qf, q, xh): exact when the result is representable
+    exact = exact and abs(t_exact) < LIMIT
+    total = t_exact + xl_exact
+    exact = exact and abs(total) < LIMIT   # the final add of two integers in doubles
+    return total, exact
+
+
+def _fp64_primes():
+    primes = set()
+    for n in (4096, 8192, 16384):
+        primes.update(O.bfv_default(n))
+    # the auxiliary bases are chosen below 2^48; the policy's hard limit is 2^50
+    primes.update(O.get_primes(2 * 16384, 47, 3))
+    primes.update(O.get_primes(2 * 16384, 50, 2))
+    return sorted(p for p in primes if p < (1 << 50))
+
+
+@pytest.mark.parametrize("q", _fp64_primes())
+def test_twiddle_product_is_exact_and_within_the_priced_bound(q):
+    rng = random.Random(q)
+    ymax = int(0.98 * LIMIT)  # the plan keeps |Y| below 0.98 * 2^53
+    ys = [ymax, -ymax, ymax - 1, q - 1, -(q - 1), 1, -1, 0, (q - 1) // 2, q // 2 + 1]
+    ws = [q - 1, 1, (q - 1) // 2, (q + 1) // 2, 2, q - 2]
+    cases = [(y, w) for y in ys for w in ws]
+    cases += [(rng.randrange(-ymax, ymax + 1), rng.randrange(q)) for _ in range(4000)]
+    # operands whose exact quotient sits next to a half-integer: the rounding of the estimate decides the result's sign
+    for _ in range(2000):
+        w = rng.randrange(1, q)
+        k = rng.randrange(1, ymax // q)
+        y = ((2 * k + 1) * q // 2 + rng.randrange(-2, 3)) * pow(w, -1, q) % q + q * rng.randrange(0, ymax // q)
+        cases.append((y if rng.random() < 0.5 else -y, w))
+    worst = 0.0
+    for y, w in cases:
+        t, exact = _mul_tw(y, w, q)
+        assert exact, (y, w)
+        assert (t - y * w) % q == 0, (y, w)
+        bound = q * (0.5 + abs(y) * 1.5 / TWO52)
+        assert abs(t) <= bound * (1 + 1e-12), (y, w, t, bound)
+        worst = max(worst, abs(t) / bound)
+    assert worst > 0.3  # the cases do reach into the bound
+
+
+# ---- pass structure, restated from nttshape.hpp ----
+def _whole_radices(logn, ept_log=4):
+    npass = (logn + ept_log - 1) // ept_log
+    return [logn // npass + (1 if p < logn % npass else 0) for p in range(npass)]
+
+
+def _head_log(logn):
+    return 2 if logn == 14 else 3
+
+
+def _split_fwd_radices(logn):
+    rem = logn - _head_log(logn)
+    return {9: [3, 3, 3], 10: [3, 3, 2, 2], 11: [3, 3, 3, 2], 12: [3, 3, 3, 3]}[rem]
+
+
+def _split_inv_radices(logn):
+    rem = logn - 2
+    return {10: [3, 3, 2, 2], 11: [2, 3, 3, 3], 12: [3, 3, 3, 3], 13: [3, 3, 3, 2, 2]}[rem]
+
+
+class _Model:
+    """Worst-case magnitudes in units of q.  A twiddle product of a value of magnitude m is within 0.5 + m*q*1.5*2^-52
+    (test above); a reduction v - rint(v * fl(1/q)) * q estimates v/q with two roundings: within 0.5 + m * 2^-51 (loose)."""
+
+    def __init__(self, q):
+        self.q = q
+        self.peak = 0.0
+
+    def see(self, m):
+        self.peak = max(self.peak, m)
+        return m
+
+    def tw(self, m):
+        return 0.5 + m * self.q * 1.5 / TWO52
+
+    def red(self, m):
+        return 0.5 + m / float(1 << 51)
+
+    def reduce_by_mask(self, m, mask, p, second=16):
+        if (mask >> p) & 1:
+            m = self.red(m)
+        if (mask >> (p + second)) & 1:
+            m = self.red(m)
+        return m
+
+    def fwd_stage(self, m):  # X' = X + T, Y' = X - T
+        self.see(m)  # the operand of the product
+        return self.see(m + self.tw(m))
+
+    def inv_stage(self, m):  # X' = X + Y, Y' = (X - Y) * W
+        d = self.see(2.0 * m)
+        return max(d, self.tw(d))
+
+
+def _plan(q, logn):
+    out = (C.c_uint32 * 6)()
+    from sunscreen_amd import _lib
+
+    rc = _lib.load().hipbfv_debug_f64_plan(C.c_uint64(q), C.c_uint32(logn), out)
+    assert rc == 0
+    return list(out)
+
+
+@pytest.mark.parametrize("n", [4096, 8192, 16384])
+def test_range_plans_of_the_default_primes_hold_under_an_independent_model(n):
+    logn = n.bit_length() - 1
+    for q in O.bfv_default(n):
+        use, fmask, imask, split, sfmask, simask = _plan(q, logn)
+        assert use == 1 and split == 1, (n, q)  # every SEAL-default prime of these degrees runs on the FP64 pipe, split pipelines included
+        room = LIMIT / q
+        # whole-polynomial transforms, 16 elements per thread
+        mod = _Model(q)
+        m = 1.0
+        for p, r in enumerate(_whole_radices(logn)):
+            m = mod.reduce_by_mask(m, fmask, p)
+            for _ in range(r):
+                m = mod.fwd_stage(m)
+        mi = 1.0
+        rad = _whole_radices(logn)
+        for p in range(len(rad)):
+            mi = mod.reduce_by_mask(mi, imask, p)
+            for _ in range(rad[len(rad) - 1 - p]):
+                mi = mod.inv_stage(mi)
+        assert mod.peak < room, (n, q, mod.peak, room)
+        # head / middle / tail transforms
+        mod = _Model(q)
+        m = 1.0
+        for _ in range(_head_log(logn)):
+            m = mod.fwd_stage(m)
+        for p, r in enumerate(_split_fwd_radices(logn)):
+            m = mod.reduce_by_mask(m, sfmask, p)
+            for _ in range(r):
+                m = mod.fwd_stage(m)
+        assert (m * q) ** 2 < 2.0 ** 105  # the tensor product multiplies two such values
+        mi = 2.5  # products and accumulators entering the inverse middle passes
+        for p, r in enumerate(_split_inv_radices(logn)):
+            mi = mod.reduce_by_mask(mi, simask, p)
+            for _ in range(r):
+                mi = mod.inv_stage(mi)
+        mi = mod.reduce_by_mask(mi, simask, 8)  # bit 8 / 24: at the start of the tail stages
+        for _ in range(2):
+            mi = mod.inv_stage(mi)
+        assert mod.peak < room, (n, q, mod.peak, room)
+
+
+def test_primes_beyond_the_policy_are_refused():
+    for q in O.get_primes(2 * 8192, 54, 2) + O.get_primes(2 * 8192, 51, 1):
+        assert _plan(q, 13)[0] == 0
+    big = _plan(O.get_primes(2 * 16384, 50, 1)[0], 14)
+    assert big[0] in (0, 1)  # just below 2^50: whichever the plan says, it says it without a device
