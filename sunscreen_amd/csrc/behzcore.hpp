@@ -177,6 +177,99 @@ __device__ __forceinline__ void behz_floor_sk_coeff_d(const DevCtx* __restrict__
   }
 }
 
+// ---- mixed base (DevCtx::aux_mixed): integer-policy data primes (up to 2^56), FP64-policy auxiliary primes (below 2^48) ----
+// Every sum whose TARGET is an auxiliary prime runs in exact FP64 like the forms above; a data residue y enters as two
+// halves at bit 30, y = yh * 2^30 + yl (yh < 2^32 for any y < 2^62, both exact in a double; the high half meets the constant
+// pre-multiplied by 2^30), so a
+// K-term sum has 2K products of magnitude <= p/2 each -- far below 2^53.  Sums whose target is a DATA prime (the last step
+// of the Shenoy-Kumaresan conversion) stay in 128-bit integers.  Same integers as behz_extend_coeff / behz_floor_sk_coeff.
+__device__ __forceinline__ void split30(u64 y, double& hi, double& lo) {
+  hi = (double)(u32)(y >> 30);
+  lo = (double)(u32)(y & ((1u << 30) - 1u));
+}
+
+// x[i] = canonical residue mod q_i (u64)  ->  out[j] = a representative mod Bsk_j with |out[j]| < Bsk_j (double)
+template <int KMAX>
+__device__ __forceinline__ void behz_extend_coeff_mixed(const DevCtx* __restrict__ ctx, const u64 (&x)[KMAX], double (&out)[KMAX + 2]) {
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK;
+  double yh[KMAX], yl[KMAX];
+  u32 rm = 0;
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const u64 y = mul_shoup(x[i], ctx->ext_scale[i], ctx->mod[i].q);
+      split30(y, yh[i], yl[i]);
+      rm += (u32)y * ctx->q_to_mtilde[i];
+    }
+  }
+  rm *= ctx->neg_inv_q_mod_mtilde;  // r_mtilde = -x/q mod 2^32
+  const double rc = (double)(int)rm;  // centred representative in [-2^31, 2^31)
+#pragma unroll
+  for (int j = 0; j < KMAX + 2; j++) {
+    if ((u32)j < S) {
+      const ArithD ar(ctx->mod[KK + j]);
+      double acc = ar.mul_var(rc, ctx->q_mod_bsk_d[j]);
+#pragma unroll
+      for (int i = 0; i < KMAX; i++)
+        if ((u32)i < K) acc += ar.mul_var(yh[i], ctx->q_to_bsk_hi_d[j][i]) + ar.mul_var(yl[i], ctx->q_to_bsk_d[j][i]);
+      out[j] = ar.mul_const(ar.reduce(acc), ctx->inv_mtilde_mod_bsk_d[j]);
+    }
+  }
+}
+
+// y[i] = x*t*(q/q_i)^{-1} mod q_i, canonical (u64); xb[j] = x*t mod Bsk_j, canonical (u64, below 2^48);
+// out[i] = canonical residue of floor(t*x/q) mod q_i, identical to behz_floor_sk_coeff
+template <int KMAX>
+__device__ __forceinline__ void behz_floor_sk_coeff_mixed(const DevCtx* __restrict__ ctx, const u64 (&y)[KMAX], const u64 (&xb)[KMAX + 2],
+                                                          u64 (&out)[KMAX]) {
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, nB = ctx->nB;
+  double yh[KMAX], yl[KMAX];
+#pragma unroll
+  for (int i = 0; i < KMAX; i++)
+    if ((u32)i < K) split30(y[i], yh[i], yl[i]);
+  u64 yb[KMAX + 1];
+  const ArithD am(ctx->mod[KK + nB]);
+  double amsk = 0.0, fl_msk = 0.0;
+#pragma unroll
+  for (int j = 0; j < KMAX + 2; j++) {
+    if ((u32)j < S) {
+      const ArithD ar(ctx->mod[KK + j]);
+      double conv = 0.0;
+#pragma unroll
+      for (int i = 0; i < KMAX; i++)
+        if ((u32)i < K) conv += ar.mul_var(yh[i], ctx->q_to_bsk_hi_d[j][i]) + ar.mul_var(yl[i], ctx->q_to_bsk_d[j][i]);
+      const double fl = ar.mul_const(ar.reduce(ArithD::from_u64(xb[j]) - conv), ctx->inv_q_mod_bsk_d[j]);
+      if ((u32)j < nB) {
+        const double ybd = canonical_d(ar, ar.mul_const(fl, ctx->inv_punct_B_d[j]));
+        amsk += am.mul_var(ybd, ctx->B_to_msk_d[j]);
+        if (j < KMAX + 1) yb[j < KMAX + 1 ? j : 0] = ArithD::to_bits(ybd);
+      } else {
+        fl_msk = fl;
+      }
+    }
+  }
+  // alpha_sk as the small signed integer it stands for (SEAL branches on alpha_sk > m_sk/2 to the same effect)
+  const double alpha = am.reduce(am.mul_const(am.reduce(amsk - fl_msk), ctx->inv_B_mod_msk_d));
+  const bool neg = alpha < 0.0;
+  const u64 amag = (u64)(u32)(int)(neg ? -alpha : alpha);  // |alpha_sk| <= |B|
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    if ((u32)i < K) {
+      const DevMod& qm = ctx->mod[i];
+      u128 a = 0;
+#pragma unroll
+      for (int j = 0; j < KMAX + 1; j++)
+        if ((u32)j < nB) a += (u128)yb[j] * ctx->B_to_q[i][j];
+      // floor = sum - alpha * B: a negative alpha ADDS |alpha| * B, a positive one adds alpha * (q_i - B mod q_i)
+      if (neg)
+        a += (u128)amag * ctx->B_mod_q[i];
+      else
+        a += (u128)amag * (qm.q - ctx->B_mod_q[i]);
+      out[i] = reduce128(a, qm);
+    }
+  }
+}
+
 // ---- the FP64 conversions for NC coefficients at once (the head / tail kernels own 8 / 4 coefficients per thread):
 // every base-conversion constant is fetched once and applied to all NC coefficients (NC independent chains), and the
 // Shenoy-Kumaresan sums are accumulated as soon as each auxiliary residue is finished, so no per-residue arrays of
@@ -221,6 +314,59 @@ __device__ __forceinline__ void behz_extend_multi_d(const DevCtx* __restrict__ c
         const double c = ctx->q_to_bsk_d[j][i];
 #pragma unroll
         for (int k = 0; k < NC; k++) acc[k] += ar.mul_var(x[i][k], c);
+      }
+    }
+    const MulOpD inv = ctx->inv_mtilde_mod_bsk_d[j];
+#pragma unroll
+    for (int k = 0; k < NC; k++) acc[k] = ar.mul_const(ar.reduce(acc[k]), inv);
+    ext(j, acc);
+  }
+}
+
+// The mixed-base extension for NC coefficients at once (mul_head owns 8 per thread): the data residues stay packed as two
+// 32-bit halves per coefficient (64 registers for K <= 4, NC = 8) and are widened to doubles where a product needs them;
+// ext(j, out) is called once per auxiliary prime with out[k] = representative of the extended value, |out[k]| < Bsk_j.
+template <int KMAX, int NC, class Sink>
+__device__ __forceinline__ void behz_extend_multi_mixed(const DevCtx* __restrict__ ctx, const u64 (&x)[KMAX][NC], Sink&& ext) {
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK;
+  u32 yh[KMAX][NC], yl[KMAX][NC], rm[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) rm[k] = 0;
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    const MulOp sc = ctx->ext_scale[(u32)i < K ? i : 0];
+    const u64 q = ctx->mod[(u32)i < K ? i : 0].q;
+    const u32 qm = ctx->q_to_mtilde[(u32)i < K ? i : 0];
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+      const u64 y = (u32)i < K ? mul_shoup(x[i][k], sc, q) : 0;
+      yh[i][k] = (u32)(y >> 30);
+      yl[i][k] = (u32)y & ((1u << 30) - 1u);
+      rm[k] += (u32)i < K ? (u32)y * qm : 0u;
+    }
+  }
+  double rc[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) rc[k] = (double)(int)(rm[k] * ctx->neg_inv_q_mod_mtilde);
+#pragma unroll 1
+  for (u32 j = 0; j < S; j++) {
+    const ArithD ar(ctx->mod[KK + j]);
+    double acc[NC];
+    const double qmb = ctx->q_mod_bsk_d[j];
+#pragma unroll
+    for (int k = 0; k < NC; k++) acc[k] = ar.mul_var(rc[k], qmb);
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+      if ((u32)i < K) {
+        const double ch = ctx->q_to_bsk_hi_d[j][i], cl = ctx->q_to_bsk_d[j][i];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+          // widened HERE, per auxiliary prime: left to itself the compiler hoists the 2 * K * NC conversions out of the loop
+          // and keeps 128 registers of doubles alive across it
+          u32 h = yh[i][k], l = yl[i][k];
+          asm volatile("" : "+v"(h), "+v"(l));
+          acc[k] += ar.mul_var((double)h, ch) + ar.mul_var((double)l, cl);
+        }
       }
     }
     const MulOpD inv = ctx->inv_mtilde_mod_bsk_d[j];

@@ -412,7 +412,7 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
   const int need_bits = 32 + t_bits + q_bits;
   std::vector<u64> B;
   u64 m_sk = 0;
-  bool own_base = false;
+  bool own_base = false, data_f64 = true;
   {
     bool want = true;
     if (const char* env = std::getenv("HIPBFV_SEAL_AUX")) want = env[0] != '1';
@@ -424,7 +424,14 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       if (h.logn >= 12 && h.logn <= 15 && !plan_f64_split(p, (int)h.logn, &a, &b)) return false;
       return true;
     };
-    for (u64 p : q) want = want && fp64_ok(p);
+    for (u64 p : q) data_f64 = data_f64 && fp64_ok(p);
+    // Integer-policy data primes (wider than 50 bits: the north star's 3 x 54-bit set) still gain from FP64 AUXILIARY residues
+    // where the split multiply runs them: more than half of mul_mid's rows move from the integer butterfly (28 instructions)
+    // to the FP64 one (8).  The conversions stay in integers -- they are generic in the auxiliary primes -- so only the head /
+    // middle / tail kernels' per-row policy changes (mixed base: own_base without aux_f64).
+    if (!data_f64) want = want && K <= 4 && h.logn >= 12 && h.logn <= 14;
+    if (const char* env = std::getenv("HIPBFV_NO_MIXED_AUX"))
+      if (env[0] == '1' && !data_f64) want = false;
     for (u32 cnt = 2; want && !own_base && cnt <= (u32)kMaxBsk; cnt++) {
       int bits = (need_bits + 1 + (int)cnt - 1) / (int)cnt + 1;  // cnt primes >= 2^(bits-1): product >= 2^(need_bits+1)
       if (bits > 48) continue;
@@ -455,7 +462,8 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     m_sk = aux[0];
     B.assign(aux.begin() + 2, aux.end());
   }
-  h.aux_f64 = own_base ? 1u : 0u;
+  h.aux_f64 = own_base && data_f64 ? 1u : 0u;
+  h.aux_mixed = own_base && !data_f64 ? 1u : 0u;
   h.S = h.nB + 1;
   h.P = KK + h.S;
   if (h.S > (u32)kMaxBsk) return fail("too many primes");
@@ -592,6 +600,24 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     h.conv_magic = ok ? magic : 0.0;
     if (const char* env = std::getenv("HIPBFV_NO_GRID"))
       if (env[0] == '1') h.conv_grid = 0;
+  }
+
+  if (h.aux_mixed) {  // the Bsk-side constants in FP64 form (every auxiliary prime is FP64-capable by selection)
+    for (u32 j = 0; j < h.S; j++) {
+      const u64 p = Bsk[j];
+      for (u32 i = 0; i < K; i++) {
+        h.q_to_bsk_d[j][i] = (double)h.q_to_bsk[j][i];
+        h.q_to_bsk_hi_d[j][i] = (double)mulm(h.q_to_bsk[j][i], (1ull << 30) % p, p);
+      }
+      h.q_mod_bsk_d[j] = (double)h.q_mod_bsk[j];
+      h.inv_mtilde_mod_bsk_d[j] = make_mulop_d(h.inv_mtilde_mod_bsk[j].w, p);
+      h.inv_q_mod_bsk_d[j] = make_mulop_d(h.inv_q_mod_bsk[j].w, p);
+    }
+    for (u32 j = 0; j < h.nB; j++) {
+      h.inv_punct_B_d[j] = make_mulop_d(h.inv_punct_B[j].w, B[j]);
+      h.B_to_msk_d[j] = (double)h.B_to_msk[j];
+    }
+    h.inv_B_mod_msk_d = make_mulop_d(h.inv_B_mod_msk.w, m_sk);
   }
 
   h.mid_nd = h.mid_ni = 0;

@@ -92,11 +92,16 @@ struct DevCtx {
   // takes the FP64 split path, the auxiliary base is the library's own (context.cpp), and the head / tail
   // kernels run the BEHZ conversions in exact double arithmetic
   u32 aux_f64;
+  // mixed base (context.cpp): integer-policy data primes beside FP64-policy auxiliary primes.  aux_f64 == 0, but the FP64
+  // copies of the Bsk-side constants below are valid and the conversions whose TARGET is an auxiliary prime run in exact FP64:
+  // a data residue y < 2^62 enters them as two halves, y = yh * 2^30 + yl, with the constant q_to_bsk_hi_d for the high one
+  u32 aux_mixed;
   // 48-bit packed intermediates in the split pipelines (kernels_split.hip nat_load/nat_store): every modulus involved is an
   // FP64-policy prime below 2^48.  pack_ks: the KK key primes; pack_mul: aux_f64 and the K data + S auxiliary primes.
   unsigned char pack_ks, pack_mul, pad3[2];
   MulOpD ext_scale_d[kMaxKey];
   double q_to_bsk_d[kMaxBsk][kMaxKey];
+  double q_to_bsk_hi_d[kMaxBsk][kMaxKey];  // 2^30 * (q/q_i) mod Bsk_j (mixed base)
   double q_mod_bsk_d[kMaxBsk];
   MulOpD inv_mtilde_mod_bsk_d[kMaxBsk];
   MulOpD intt_scale_bsk_d[kMaxBsk];

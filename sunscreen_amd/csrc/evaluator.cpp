@@ -289,9 +289,9 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
     const size_t c = std::min(chunk, count - off);
     if (split) {
       // head / middle / tail split transforms (kernels_split.hip): 3 launches instead of 5, 40 % less HBM traffic
-      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, h.aux_f64 != 0, h.pack_mul != 0, kneed, a + off * 2 * K * n, b + off * 2 * K * n, ext, c, s, square ? 2u : 4u));
+      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, h.aux_f64 != 0, h.aux_f64 ? h.pack_mul != 0 : h.aux_mixed != 0, kneed, a + off * 2 * K * n, b + off * 2 * K * n, ext, c, s, square ? 2u : 4u));
       HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_mul != 0, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
-      HB_LAUNCH(kKernMulTail, c * 3, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, h.aux_f64 != 0, h.pack_mul != 0, h.conv_grid != 0, kneed, D, out + off * 3 * K * n, c, s));
+      HB_LAUNCH(kKernMulTail, c * 3, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, h.aux_f64 != 0, h.aux_f64 ? h.pack_mul != 0 : h.aux_mixed != 0, h.conv_grid != 0, kneed, D, out + off * 3 * K * n, c, s));
       continue;
     }
     HB_LAUNCH(kKernBehzExtend, c * (sa + sb), launch_behz_extend(ctx_->dev(), n, kneed, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));

@@ -453,6 +453,12 @@ constexpr int kHeadThreads = 256;
 #ifndef EDGE8_WAVES
 #define EDGE8_WAVES 0
 #endif
+// the mixed-base head (integer data primes, FP64 auxiliary primes: the <L, 4, AUXD = false, PACK = true> instantiations): waves per
+// SIMD its registers are limited for.  Measured on the 3 x 54-bit workload: 3 (168 registers, 76 bytes of scratch) 2.66-2.81 ms,
+// the compiler's choice (185 registers, 2 waves) 2.90-3.01, 4 (128 registers, 236 bytes) 3.03-3.07.
+#ifndef HEAD_MIXED_WAVES
+#define HEAD_MIXED_WAVES 3
+#endif
 #define EDGE_BOUNDS(KMAX) __launch_bounds__(kHeadThreads, ((KMAX) > 4 && EDGE8_WAVES ? EDGE8_WAVES : 1))
 // mul_mid, FP64 instantiation: at N = 8192 the four forward transforms go through the exchange buffer as two pairs
 // (48 KB of LDS per workgroup instead of 64 KB: 3 workgroups = 12 waves per CU instead of 2 = 8; -5 % mul_mid).  At N = 4096
@@ -1237,7 +1243,7 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 // AUXD (DevCtx::aux_f64): every residue, auxiliary base included, takes the FP64 policy and the base extension
 // itself runs in FP64 (behz_extend_coeff_d).
 template <int L, int KMAX, bool AUXD, bool PACK>
-__global__ EDGE_BOUNDS(KMAX) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+__global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : ((KMAX) > 4 && EDGE8_WAVES ? EDGE8_WAVES : 1))) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
                                                                 u64* __restrict__ ext) {
   using G = EdgeGeom<L>;
@@ -1320,6 +1326,17 @@ __global__ EDGE_BOUNDS(KMAX) void mul_head_kernel(const DevCtx* __restrict__ ctx
     }
   }
   // auxiliary base: extend every owned coefficient, then the head stages per Bsk prime
+  if constexpr (!AUXD && PACK) {  // the MIXED instantiation (PACK has no meaning of its own without AUXD)
+    // mixed base (context.cpp): integer data primes, auxiliary primes on the FP64 pipe; the extension sums run in exact FP64
+    behz_extend_multi_mixed<KMAX, NC>(ctx, x, [&](u32 j, double(&ev)[NC]) {
+      const ArithD ar(ctx->mod[KK + j]);
+      head_fwd_owned<ArithD, L>(ar, ev, reinterpret_cast<const double*>(twf_base + (size_t)(KK + j) * N), t);
+      double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
+#pragma unroll
+      for (int k = 0; k < NC; k++) o[G::head_out(t, k)] = ev[k];
+    });
+    return;
+  }
   u64 ev[KMAX + 2][NC];
 #pragma unroll
   for (int k = 0; k < NC; k++) {
@@ -1862,6 +1879,7 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
       }
     return;
   }
+  constexpr bool mixed = !AUXD && PACK;  // the MIXED instantiation: integer data primes, FP64 auxiliary primes, Bsk-side sums in exact FP64
   u64 y[4][KMAX], xb[4][KMAX + 2];
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
@@ -1884,9 +1902,15 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
   for (int j = 0; j < KMAX + 2; j++) {
     if ((u32)j < S) {
       const DevMod& dm = ctx->mod[KK + j];
-      const ArithI ar(dm);
       u64 r4[4];
-      tail_inv4_scale<ArithI, L>(ar, d + (size_t)(K + j) * N, t, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], 0u, r4);
+      if constexpr (mixed) {  // the auxiliary rows come back from the FP64 middle kernel as doubles
+        const ArithD ar(dm);
+        tail_inv4_scale<ArithD, L>(ar, reinterpret_cast<const double*>(d + (size_t)(K + j) * N), t, reinterpret_cast<const double*>(twi_base + (size_t)(KK + j) * N),
+                                   ctx->intt_scale_bsk_d[j], dm.split_inv_mask, r4);
+      } else {
+        const ArithI ar(dm);
+        tail_inv4_scale<ArithI, L>(ar, d + (size_t)(K + j) * N, t, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], 0u, r4);
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) xb[k][j] = r4[k];
     }
@@ -1896,7 +1920,10 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
 #pragma unroll 1
   for (int k = 0; k < 4; k++) {
     u64 r[KMAX];
-    behz_floor_sk_coeff<KMAX>(ctx, y[0], xb[0], r);
+    if constexpr (mixed)
+      behz_floor_sk_coeff_mixed<KMAX>(ctx, y[0], xb[0], r);
+    else
+      behz_floor_sk_coeff<KMAX>(ctx, y[0], xb[0], r);
 #pragma unroll
     for (int i = 0; i < KMAX; i++)
       if ((u32)i < K) o[(size_t)i * N + G::tail_out(t, k)] = r[i];
@@ -2272,6 +2299,8 @@ static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, 
       mul_head_kernel<L, 4, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
     else
       mul_head_kernel<L, 4, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+  } else if (pack) {  // mixed base: integer data primes, FP64 auxiliary primes (DevCtx::aux_mixed)
+    mul_head_kernel<L, 4, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   } else {
     mul_head_kernel<L, 4, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   }
@@ -2279,11 +2308,11 @@ static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, 
 }
 // aux_f64: DevCtx::aux_f64 of the context behind `ctx` (selects the all-FP64 instantiation)
 // kneed: max(data primes, auxiliary primes - 2) -- selects the 4- or 8-prime instantiation
-// pack: DevCtx::pack_mul (only with aux_f64)
+// pack: DevCtx::pack_mul with aux_f64; WITHOUT aux_f64 it selects the mixed-base instantiation (DevCtx::aux_mixed)
 // npolys: 4 = (a0, a1, b0, b1); 2 = the first operand only (squaring: ext polys 2, 3 stay unwritten and unread)
 hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
                            size_t ops, hipStream_t s, u32 npolys) {
-  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack && aux_f64, kneed, a, b, ext, ops, npolys, s)
+  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack, kneed, a, b, ext, ops, npolys, s)
 }
 
 template <int L>
@@ -2332,6 +2361,8 @@ static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, 
       mul_tail_kernel<L, 4, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
     else
       mul_tail_kernel<L, 4, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
+  } else if (pack) {  // mixed base
+    mul_tail_kernel<L, 4, false, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
   } else {
     mul_tail_kernel<L, 4, false, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
   }
@@ -2341,7 +2372,7 @@ static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, 
 // poly0, npolys: which product polynomials to finish (0, 3 = all; 2, 1 = only c2, written compactly as out[op][K][N])
 hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, bool pack, bool conv_grid, u32 kneed, const u64* D, u64* out,
                            size_t ops, hipStream_t s, u32 poly0, u32 npolys) {
-  SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, pack && aux_f64, conv_grid && aux_f64, kneed, D, out, ops, poly0, npolys, s)
+  SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, pack, conv_grid && aux_f64, kneed, D, out, ops, poly0, npolys, s)
 }
 
 template <int L>

@@ -248,6 +248,7 @@ class Context:
         _check(_lib.load().hipbfv_Context_AuxBase(self._h, C.byref(cnt), buf, cnt.value, C.byref(own)))
         self.aux_primes = list(buf)  # B..., m_sk (internal to multiply; see include/hipbfv.h)
         self.aux_fp64 = bool(own.value & 1)
+        self.aux_mixed = bool(own.value & 16)  # integer-policy data primes beside FP64-policy auxiliary primes
         self.packed_mul = bool(own.value & 2)  # 48-bit packed intermediates in the split multiply / key switch
         self.packed_ks = bool(own.value & 4)
         self.conv_grid = bool(own.value & 8)  # base-conversion sums formed exactly and reduced once (griddot.hpp)

@@ -402,25 +402,40 @@ _own_base_off = os.environ.get("HIPBFV_SEAL_AUX") == "1" or os.environ.get("HIPB
 def test_auxiliary_base_choice_and_bound():
     """The BEHZ auxiliary base is internal to multiply.  FP64-capable data primes -> the library's own base of
     primes below 2^48 whose product covers the same bound SEAL sizes its base for (2^(32 + bits(t) + bits(q)));
-    wide data primes -> SEAL's own 61-bit base, identical to the oracle's."""
+    wide data primes where the split multiply runs (K <= 4, 4096 <= n <= 16384) -> the MIXED base: the same kind of
+    auxiliary primes (FP64 rows in the middle kernel) beside integer data rows; wide data primes elsewhere -> SEAL's own
+    61-bit base, identical to the oracle's."""
     from sunscreen_amd import Context
+
+    def covers(ctx, primes, t, n):
+        q = 1
+        for p in primes[:-1]:
+            q *= p
+        prod = 1
+        for p in ctx.aux_primes:
+            assert p < 2**48 and p % (2 * n) == 1 and p not in primes and O.is_prime(p)
+            prod *= p
+        assert len(set(ctx.aux_primes)) == len(ctx.aux_primes)
+        assert prod.bit_length() > 32 + t.bit_length() + q.bit_length()
 
     n, primes, t = params("default_8192_17")
     ctx = Context.from_raw(n, primes, t)
-    assert ctx.aux_fp64 and len(ctx.aux_primes) >= 2
-    q = 1
-    for p in primes[:-1]:
-        q *= p
-    prod = 1
-    for p in ctx.aux_primes:
-        assert p < 2**48 and p % (2 * n) == 1 and p not in primes and O.is_prime(p)
-        prod *= p
-    assert len(set(ctx.aux_primes)) == len(ctx.aux_primes)
-    assert prod.bit_length() > 32 + t.bit_length() + q.bit_length()
+    assert ctx.aux_fp64 and not ctx.aux_mixed and len(ctx.aux_primes) >= 2
+    covers(ctx, primes, t, n)
     wide = O.coeff_modulus_create(4096, [58, 59, 60])
-    ctx2 = Context.from_raw(4096, wide, O.plain_batching(4096, 16))
-    o2 = O.Oracle(4096, wide, O.plain_batching(4096, 16))
-    assert not ctx2.aux_fp64 and ctx2.aux_primes == [int(p) for p in o2.bsk]
+    t2 = O.plain_batching(4096, 16)
+    ctx2 = Context.from_raw(4096, wide, t2)
+    if os.environ.get("HIPBFV_NO_MIXED_AUX") == "1":
+        o2 = O.Oracle(4096, wide, t2)
+        assert not ctx2.aux_fp64 and not ctx2.aux_mixed and ctx2.aux_primes == [int(p) for p in o2.bsk]
+    else:
+        assert ctx2.aux_mixed and not ctx2.aux_fp64
+        covers(ctx2, wide, t2, 4096)
+    wide3 = O.coeff_modulus_create(2048, [54, 55])  # n = 2048: no split pipelines, SEAL's base
+    t3 = O.plain_batching(2048, 16)
+    ctx3 = Context.from_raw(2048, wide3, t3)
+    o3 = O.Oracle(2048, wide3, t3)
+    assert not ctx3.aux_fp64 and not ctx3.aux_mixed and ctx3.aux_primes == [int(p) for p in o3.bsk]
 
 
 @pytest.mark.skipif(_own_base_off, reason="the own auxiliary base is switched off by the environment")
