@@ -179,3 +179,36 @@ def test_primes_beyond_the_policy_are_refused():
         assert _plan(q, 13)[0] == 0
     big = _plan(O.get_primes(2 * 16384, 50, 1)[0], 14)
     assert big[0] in (0, 1)  # just below 2^50: whichever the plan says, it says it without a device
+
+
+def _mul_var(a: int, b: int, q: int):
+    """ArithD::mul_var (two variable operands): the same error-free split with the quotient estimated from the rounded product."""
+    return _mul_tw(a, b, q)
+
+
+@pytest.mark.parametrize("data_bits", [54, 56, 61])
+def test_mixed_base_sums_take_wide_data_residues_as_two_exact_halves(data_bits):
+    """DevCtx::aux_mixed (behzcore.hpp, behz_extend_multi_mixed / behz_floor_sk_coeff_mixed): a data residue y < 2^62 enters a sum
+    modulo an FP64-pipe auxiliary prime p < 2^48 as y = yh * 2^30 + yl, the high half against the constant pre-multiplied by
+    2^30.  Replayed here with every rounding explicit: each product is exact, congruent, within p * (0.5 + tiny), and a K-term
+    sum (2K products + the r_mtilde term) stays far below 2^53."""
+    rng = random.Random(data_bits)
+    for p in O.get_primes(2 * 8192, 44, 2) + O.get_primes(2 * 8192, 47, 2):
+        for _ in range(500):
+            ys = [rng.randrange(1 << data_bits) for _ in range(4)]
+            cs = [rng.randrange(p) for _ in range(4)]
+            acc, exact_sum = 0, 0
+            for y, c in zip(ys, cs):
+                yh, yl = y >> 30, y & ((1 << 30) - 1)
+                assert yh < (1 << 32) and float(yh) == yh and float(yl) == yl
+                c_hi = (c << 30) % p
+                for a, b in ((yh, c_hi), (yl, c)):
+                    t, exact = _mul_var(a, b, p)
+                    assert exact and (t - a * b) % p == 0 and abs(t) <= p * 0.5000001
+                    acc += t
+                exact_sum += y * c
+            rc = rng.randrange(-(1 << 31), 1 << 31)
+            t, exact = _mul_var(rc, rng.randrange(p), p)
+            assert exact
+            assert abs(acc) + abs(t) < LIMIT / 1000  # nine terms of at most p/2 each: nowhere near 2^53
+            assert (acc - exact_sum) % p == 0
