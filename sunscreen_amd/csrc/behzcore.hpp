@@ -217,55 +217,79 @@ __device__ __forceinline__ void behz_extend_coeff_mixed(const DevCtx* __restrict
   }
 }
 
-// y[i] = x*t*(q/q_i)^{-1} mod q_i, canonical (u64); xb[j] = x*t mod Bsk_j, canonical (u64, below 2^48);
-// out[i] = canonical residue of floor(t*x/q) mod q_i, identical to behz_floor_sk_coeff
-template <int KMAX>
-__device__ __forceinline__ void behz_floor_sk_coeff_mixed(const DevCtx* __restrict__ ctx, const u64 (&y)[KMAX], const u64 (&xb)[KMAX + 2],
-                                                          u64 (&out)[KMAX]) {
+// y[c][i] = x*t*(q/q_i)^{-1} mod q_i, canonical (u64); xb[c][j] = x*t mod Bsk_j, canonical (u64, below 2^48), for NC
+// coefficients c at once (independent chains: the tail kernel takes its four coefficients two at a time);
+// out[c][i] = canonical residue of floor(t*x/q) mod q_i, identical to behz_floor_sk_coeff
+template <int KMAX, int NC>
+__device__ __forceinline__ void behz_floor_sk_coeff_mixed(const DevCtx* __restrict__ ctx, const u64 (&y)[NC][KMAX], const u64 (&xb)[NC][KMAX + 2],
+                                                          u64 (&out)[NC][KMAX]) {
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, nB = ctx->nB;
-  double yh[KMAX], yl[KMAX];
+  double yh[NC][KMAX], yl[NC][KMAX];
 #pragma unroll
-  for (int i = 0; i < KMAX; i++)
-    if ((u32)i < K) split30(y[i], yh[i], yl[i]);
-  u64 yb[KMAX + 1];
+  for (int c = 0; c < NC; c++)
+#pragma unroll
+    for (int i = 0; i < KMAX; i++)
+      if ((u32)i < K) split30(y[c][i], yh[c][i], yl[c][i]);
+  u64 yb[NC][KMAX + 1];
   const ArithD am(ctx->mod[KK + nB]);
-  double amsk = 0.0, fl_msk = 0.0;
+  double amsk[NC], fl_msk[NC];
+#pragma unroll
+  for (int c = 0; c < NC; c++) amsk[c] = 0.0, fl_msk[c] = 0.0;
 #pragma unroll
   for (int j = 0; j < KMAX + 2; j++) {
     if ((u32)j < S) {
       const ArithD ar(ctx->mod[KK + j]);
-      double conv = 0.0;
+      double conv[NC];
 #pragma unroll
-      for (int i = 0; i < KMAX; i++)
-        if ((u32)i < K) conv += ar.mul_var(yh[i], ctx->q_to_bsk_hi_d[j][i]) + ar.mul_var(yl[i], ctx->q_to_bsk_d[j][i]);
-      const double fl = ar.mul_const(ar.reduce(ArithD::from_u64(xb[j]) - conv), ctx->inv_q_mod_bsk_d[j]);
+      for (int c = 0; c < NC; c++) conv[c] = 0.0;
+#pragma unroll
+      for (int i = 0; i < KMAX; i++) {
+        if ((u32)i < K) {
+          const double ch = ctx->q_to_bsk_hi_d[j][i], cl = ctx->q_to_bsk_d[j][i];
+#pragma unroll
+          for (int c = 0; c < NC; c++) conv[c] += ar.mul_var(yh[c][i], ch) + ar.mul_var(yl[c][i], cl);
+        }
+      }
+      const MulOpD invq = ctx->inv_q_mod_bsk_d[j];
+      double fl[NC];
+#pragma unroll
+      for (int c = 0; c < NC; c++) fl[c] = ar.mul_const(ar.reduce(ArithD::from_u64(xb[c][j]) - conv[c]), invq);
       if ((u32)j < nB) {
-        const double ybd = canonical_d(ar, ar.mul_const(fl, ctx->inv_punct_B_d[j]));
-        amsk += am.mul_var(ybd, ctx->B_to_msk_d[j]);
-        if (j < KMAX + 1) yb[j < KMAX + 1 ? j : 0] = ArithD::to_bits(ybd);
+        const MulOpD ip = ctx->inv_punct_B_d[j];
+        const double bm = ctx->B_to_msk_d[j];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+          const double ybd = canonical_d(ar, ar.mul_const(fl[c], ip));
+          amsk[c] += am.mul_var(ybd, bm);
+          if (j < KMAX + 1) yb[c][j < KMAX + 1 ? j : 0] = ArithD::to_bits(ybd);
+        }
       } else {
-        fl_msk = fl;
+#pragma unroll
+        for (int c = 0; c < NC; c++) fl_msk[c] = fl[c];
       }
     }
   }
-  // alpha_sk as the small signed integer it stands for (SEAL branches on alpha_sk > m_sk/2 to the same effect)
-  const double alpha = am.reduce(am.mul_const(am.reduce(amsk - fl_msk), ctx->inv_B_mod_msk_d));
-  const bool neg = alpha < 0.0;
-  const u64 amag = (u64)(u32)(int)(neg ? -alpha : alpha);  // |alpha_sk| <= |B|
 #pragma unroll
-  for (int i = 0; i < KMAX; i++) {
-    if ((u32)i < K) {
-      const DevMod& qm = ctx->mod[i];
-      u128 a = 0;
+  for (int c = 0; c < NC; c++) {
+    // alpha_sk as the small signed integer it stands for (SEAL branches on alpha_sk > m_sk/2 to the same effect)
+    const double alpha = am.reduce(am.mul_const(am.reduce(amsk[c] - fl_msk[c]), ctx->inv_B_mod_msk_d));
+    const bool neg = alpha < 0.0;
+    const u64 amag = (u64)(u32)(int)(neg ? -alpha : alpha);  // |alpha_sk| <= |B|
 #pragma unroll
-      for (int j = 0; j < KMAX + 1; j++)
-        if ((u32)j < nB) a += (u128)yb[j] * ctx->B_to_q[i][j];
-      // floor = sum - alpha * B: a negative alpha ADDS |alpha| * B, a positive one adds alpha * (q_i - B mod q_i)
-      if (neg)
-        a += (u128)amag * ctx->B_mod_q[i];
-      else
-        a += (u128)amag * (qm.q - ctx->B_mod_q[i]);
-      out[i] = reduce128(a, qm);
+    for (int i = 0; i < KMAX; i++) {
+      if ((u32)i < K) {
+        const DevMod& qm = ctx->mod[i];
+        u128 a = 0;
+#pragma unroll
+        for (int j = 0; j < KMAX + 1; j++)
+          if ((u32)j < nB) a += (u128)yb[c][j] * ctx->B_to_q[i][j];
+        // floor = sum - alpha * B: a negative alpha ADDS |alpha| * B, a positive one adds alpha * (q_i - B mod q_i)
+        if (neg)
+          a += (u128)amag * ctx->B_mod_q[i];
+        else
+          a += (u128)amag * (qm.q - ctx->B_mod_q[i]);
+        out[c][i] = reduce128(a, qm);
+      }
     }
   }
 }

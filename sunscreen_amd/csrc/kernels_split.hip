@@ -456,6 +456,10 @@ constexpr int kHeadThreads = 256;
 // the mixed-base head (integer data primes, FP64 auxiliary primes: the <L, 4, AUXD = false, PACK = true> instantiations): waves per
 // SIMD its registers are limited for.  Measured on the 3 x 54-bit workload: 3 (168 registers, 76 bytes of scratch) 2.66-2.81 ms,
 // the compiler's choice (185 registers, 2 waves) 2.90-3.01, 4 (128 registers, 236 bytes) 3.03-3.07.
+// coefficients per trip of the mixed-base tail's epilogue (1, 2 or 4 of the thread's four)
+#ifndef TAIL_MIXED_NC
+#define TAIL_MIXED_NC 4  // measured on the 3 x 54-bit workload: 1 -> 3.56, 2 -> 3.66-3.71, 4 (fully unrolled, 154 registers) -> 3.22 ms
+#endif
 #ifndef HEAD_MIXED_WAVES
 #define HEAD_MIXED_WAVES 3
 #endif
@@ -1917,13 +1921,40 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
   }
   // The per-coefficient epilogue is too large to unroll four times; a rolled loop must not index y/xb by k
   // (dynamic indexing puts them in scratch), so each trip consumes row 0 and the rows rotate down.
+  if constexpr (mixed) {
+    // the mixed epilogue takes TAIL_MIXED_NC coefficients per trip (independent chains through the FP64 sums)
+    constexpr int NCM = TAIL_MIXED_NC;
+    static_assert(NCM == 1 || NCM == 2 || NCM == 4, "coefficients per trip");
+#pragma unroll 1
+    for (int k = 0; k < 4; k += NCM) {
+      u64 yy[NCM][KMAX], xx[NCM][KMAX + 2], r[NCM][KMAX];
+#pragma unroll
+      for (int c = 0; c < NCM; c++) {
+#pragma unroll
+        for (int i = 0; i < KMAX; i++) yy[c][i] = y[c][i];
+#pragma unroll
+        for (int j = 0; j < KMAX + 2; j++) xx[c][j] = xb[c][j];
+      }
+      behz_floor_sk_coeff_mixed<KMAX, NCM>(ctx, yy, xx, r);
+#pragma unroll
+      for (int c = 0; c < NCM; c++)
+#pragma unroll
+        for (int i = 0; i < KMAX; i++)
+          if ((u32)i < K) o[(size_t)i * N + G::tail_out(t, k + c)] = r[c][i];
+#pragma unroll
+      for (int kk = 0; kk + NCM < 4; kk++) {
+#pragma unroll
+        for (int i = 0; i < KMAX; i++) y[kk][i] = y[kk + NCM][i];
+#pragma unroll
+        for (int j = 0; j < KMAX + 2; j++) xb[kk][j] = xb[kk + NCM][j];
+      }
+    }
+    return;
+  }
 #pragma unroll 1
   for (int k = 0; k < 4; k++) {
     u64 r[KMAX];
-    if constexpr (mixed)
-      behz_floor_sk_coeff_mixed<KMAX>(ctx, y[0], xb[0], r);
-    else
-      behz_floor_sk_coeff<KMAX>(ctx, y[0], xb[0], r);
+    behz_floor_sk_coeff<KMAX>(ctx, y[0], xb[0], r);
 #pragma unroll
     for (int i = 0; i < KMAX; i++)
       if ((u32)i < K) o[(size_t)i * N + G::tail_out(t, k)] = r[i];
