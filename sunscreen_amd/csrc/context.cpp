@@ -618,6 +618,13 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       h.B_to_msk_d[j] = (double)h.B_to_msk[j];
     }
     h.inv_B_mod_msk_d = make_mulop_d(h.inv_B_mod_msk.w, m_sk);
+    // the mixed sums are formed exactly on one grid and reduced once (griddot.hpp): 2K + 1 terms, each a half of a data
+    // residue (below 2^32; the r_mtilde term below 2^31) times a constant below the target auxiliary prime
+    long double bmax = 0, bmin = 1e30L;
+    for (u64 p : Bsk) bmax = std::max(bmax, (long double)p), bmin = std::min(bmin, (long double)p);
+    double magic = 0;
+    if (!plan_grid_dot(4294967296.0L, bmax, 2 * K + 1, bmin, bmax, &magic)) return fail("internal: no exact-sum grid for the mixed auxiliary base");
+    h.conv_magic = magic;
   }
 
   h.mid_nd = h.mid_ni = 0;
