@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/gpu_r03_lines.sh <tag> -- after tools/pmc_merge.sh: the bench lines of the four PMC workloads (their `traffic` / `valu` fields now
 # come from passes taken on these very kernel sources) and the default line with its `secondary` object
-TAG=${1:-r03_v6}
+TAG=${1:-r03_v7}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 run() { name=$1; shift; timeout 600 python bench.py "$@" 2>$OUT/$name.err | tail -1 > $OUT/bench_$name.json; python -c "
