@@ -125,6 +125,54 @@ def test_north_star_literal_3x54bit_primes_mul_relin_and_rotate():
         assert (got[i] == o.relinearize(o.multiply(ext[i], ext[1 - i]), rk)).all()
 
 
+def test_3x54bit_mixed_and_seal_auxiliary_bases_give_the_same_bits():
+    """The mixed auxiliary base (integer data primes, the library's FP64-pipe auxiliary primes: DESIGN.md 4.3) is the default for the
+    north star's literal prime set; HIPBFV_NO_MIXED_AUX=1 keeps SEAL's 61-bit base.  BEHZ's result does not depend on the base:
+    the same seeded operands (random, and every residue at its maximum) through both, in separate processes, word for word --
+    and the default one against the oracle."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    script = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import bfv_oracle as O
+from sunscreen_amd import Context
+from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+n = 8192
+primes = O.coeff_modulus_create(n, [54, 54, 54, 56]); t = O.plain_batching(n, 17)
+ctx = Context.from_raw(n, primes, t); ev = BatchEvaluator(ctx)
+assert ctx.aux_mixed == (sys.argv[2] == "mixed"), (ctx.aux_mixed, ctx.aux_primes)
+rng = np.random.default_rng(5454)
+a = np.stack([rng.integers(0, q, (6, 2, n), dtype=np.uint64) for q in primes[:3]], axis=2)
+b = np.stack([rng.integers(0, q, (6, 2, n), dtype=np.uint64) for q in primes[:3]], axis=2)
+for i, q in enumerate(primes[:3]):
+    a[5, :, i, :] = q - 1; b[5, :, i, :] = q - 1; b[4, :, i, ::2] = 0
+np.save(sys.argv[1], to_host(ev.multiply(to_device(a), to_device(b))))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        out = {}
+        for tag, env in (("mixed", {"HIPBFV_NO_MIXED_AUX": "0"}), ("seal", {"HIPBFV_NO_MIXED_AUX": "1"})):
+            path = os.path.join(d, tag + ".npy")
+            subprocess.check_call([sys.executable, "-c", script, path, tag], env=dict(os.environ, **env))
+            out[tag] = np.load(path)
+    assert out["mixed"].shape == (6, 3, 3, 8192) and (out["mixed"] == out["seal"]).all()
+    n = 8192
+    primes = O.coeff_modulus_create(n, [54, 54, 54, 56])
+    o = O.Oracle(n, primes, O.plain_batching(n, 17))
+    rng = np.random.default_rng(5454)
+    a = np.stack([rng.integers(0, q, (6, 2, n), dtype=np.uint64) for q in primes[:3]], axis=2)
+    b = np.stack([rng.integers(0, q, (6, 2, n), dtype=np.uint64) for q in primes[:3]], axis=2)
+    for i, q in enumerate(primes[:3]):
+        a[5, :, i, :] = q - 1
+        b[5, :, i, :] = q - 1
+        b[4, :, i, ::2] = 0
+    for i in (0, 4, 5):
+        assert (out["mixed"][i] == o.multiply(a[i], b[i])).all(), i
+
+
 def test_config4_chi_sq_at_n16384():
     from sunscreen_amd.batch import to_device, to_host
     from sunscreen_amd.workloads import chi_sq_optimized
