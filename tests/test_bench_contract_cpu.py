@@ -104,3 +104,24 @@ def test_dry_run_validates_an_eight_gpu_launch_without_touching_a_device():
     d = json.loads(p.stdout.splitlines()[-1])
     assert p.returncode == 0 and d["ok"] and len(d["ranks"]) == 8
     assert d["ranks"][7]["database_rows"] == [896, 1024] and d["ranks"][0]["database_bytes"] == 128 * 1024 * 8 * 16384 * 8  # 128 GiB of the 1 TiB database
+
+
+def test_power_leg_parses_rocm_smi_and_survives_its_absence(tmp_path, monkeypatch):
+    """bench.power_leg samples `rocm-smi` while the steps keep running: the text it parses is the tool's (ROCm 7.2) and nothing it
+    prints -- or its absence -- may fail the benchmark."""
+    import bench
+
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\ncat <<'EOF'\n"
+                    "GPU[0]\t\t: fclk clock level: 0: (1250Mhz)\nGPU[0]\t\t: mclk clock level: 0: (2000Mhz)\nGPU[0]\t\t: sclk clock level: 1: (2156Mhz)\n"
+                    "=================================== Power Consumption ====================================\n"
+                    "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1374.0\n"
+                    "======================================= Power Cap ========================================\n"
+                    "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\nEOF\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    steps = []
+    rec = bench.power_leg(lambda: steps.append(1), lambda: None)
+    assert rec["package_w"] == 1374.0 and rec["sclk_mhz"] == 2156 and rec["cap_w"] == 1400.0 and rec["samples"] == 3 and steps
+    fake.write_text("#!/bin/sh\necho nothing useful\n")
+    assert bench.power_leg(lambda: None, lambda: None) is None
