@@ -10,7 +10,7 @@ BASELINE.json's metric names three quantities ("mul+relin ops/sec at n=8192/1638
 therefore times all three: the headline line is n=8192 and its `secondary` object carries the n=16384 mul+relin
 (batch/4 pairs, SEAL default K=8+1) and the configs[1] transform workload (forward+inverse NTT, n=8192, 3 primes,
 `--batch` polynomials), each with its own value, ms_per_step, roofline, cpu_baseline and parity gate, measured with the
-same --steps / --warmup in the same process (`--no-secondary` drops them).  `--workload ntt|chi_sq|dot_prod|pir|e2e`
+same --warmup in the same process (`--no-secondary` drops them; the NTT workload times at least 100 of its 0.73 ms steps).  `--workload ntt|chi_sq|dot_prod|pir|e2e`
 run one workload alone (the reference's example programs and the client-side steps; same JSON contract).
 
 The CPU oracle appears here in three roles only: client (it generates the keys and the few genuine encryptions the
@@ -26,6 +26,11 @@ results to rank 0 (reported apart from `value`).  `--workload pir` is the one wo
 (SURVEY 8e "Exception"): the database is sharded by ROW across the ranks, every rank reduces its rows to one ciphertext
 and `dist.reduce_ciphertexts` sums one ciphertext per GPU on rank 0 inside the timed step.
 `--gpus N --dry-run` validates the launch environment and prints the per-rank shapes without touching a GPU.
+
+Timing: W warmup steps, then untimed steps for about `--settle-ms` (150 ms: the shader clock settles under the package power
+cap these kernels run at; the count is agreed between the ranks and reported as `settle_steps`), then EXACTLY K steps between
+two barriers.  At N = 1 an untimed leg after the measurement samples `rocm-smi` while the steps keep running (`power`:
+package watts, shader clock, cap; `--no-power` skips it).
 
 Prints ONE JSON line on rank 0.
 """
