@@ -339,7 +339,10 @@ long hipbfv_batch_encrypt_seeded(void *evaluator, const uint64_t *plain, uint64_
  * the way Evaluator_MultiplyPlain does internally (a static database is transformed once); ct_to_ntt transforms every
  * polynomial of the ciphertexts; dot_plain_ntt produces, for size-2 ciphertexts, out[row] = sum_j MultiplyPlain(ct_j,
  * plain[row][j]) in coefficient form, bit-identical to the reference's sequence of multiply_plain and add.
- * ctn: u64[cols][2][K][N], pntt: u64[rows][cols][K][N], out: u64[rows][2][K][N]. */
+ * ctn: u64[cols][2][K][N], pntt: u64[rows][cols][K][N], out: u64[rows][2][K][N].
+ * An ALL-ZERO plaintext has no transformed form: SEAL refuses every product with it (transparent result), and the consumers
+ * of `pntt` cannot see it any more, so plain_to_ntt records the index of the first all-zero plaintext in the evaluator's
+ * status word -- hipbfv_batch_status returns COR_E_INVALIDOPERATION for it, as for any transparent batch result. */
 long hipbfv_batch_plain_to_ntt(void *evaluator, const uint64_t *plain, uint64_t plain_stride, uint64_t *pntt, uint64_t count, void *stream);
 long hipbfv_batch_ct_to_ntt(void *evaluator, const uint64_t *ct, uint64_t size, uint64_t *ctn, uint64_t count, void *stream);
 long hipbfv_batch_dot_plain_ntt(void *evaluator, const uint64_t *ctn, uint64_t cols, const uint64_t *pntt, uint64_t rows, uint64_t *out,
@@ -357,7 +360,7 @@ long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
  * u64[batch][2][K][N] (kind 0), to plaintexts u64[batch][N] / one shared u64[N] (kind 1, stride N / 0), or to plaintexts
  * already lifted and transformed, u64[batch][K][N] / one shared u64[K][N] (kind 2, stride K*N / 0: the output of
  * hipbfv_batch_plain_to_ntt -- static data such as examples/pir's database is transformed once, not per query; only
- * MultiplyPlaintext nodes may consume it, and its zero check is the producer's);
+ * MultiplyPlaintext nodes may consume it, and its zero check is the producer's: hipbfv_batch_plain_to_ntt + hipbfv_batch_status);
  * one output buffer u64[batch][2][K][N] per OutputCiphertext node, in node order.
  * Execution follows the reference's `traverse` (sunscreen_runtime/src/run.rs:372-472: every node whose operands are
  * complete runs at once): ready nodes of one kind are one batched launch, Add / Sub / Negate trees are n-ary sums, sums of
@@ -368,7 +371,8 @@ long hipbfv_set_chunk_ops(void *evaluator, uint64_t chunk_ops);
  * on `a * 0`, sunscreen/tests/features.rs:8-34).  The handle-level Evaluator_* functions check their one result before
  * they return.  The batched paths check on the device: every operation records, in a status word, the smallest batch
  * index whose result is transparent.  Program_Run owns such a word per run, reads it once at exit (one stream
- * synchronisation per run) and returns COR_E_INVALIDOPERATION -- hipbfv_last_error names the input set.  The
+ * synchronisation per run) and returns COR_E_INVALIDOPERATION -- hipbfv_last_error names AN input set whose result is
+ * transparent (merged launches number their ciphertexts member-major, so it need not be the lowest such set).  The
  * hipbfv_batch_* operations stay asynchronous on `stream` and record into their evaluator's word; hipbfv_batch_status
  * synchronises `stream`, reads and resets it: COR_E_INVALIDOPERATION + the first transparent item (of any operation since
  * the previous call), S_OK + ~0 otherwise.  hipbfv_set_batch_transparent_check(evaluator, false) switches the recording

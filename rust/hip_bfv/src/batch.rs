@@ -91,6 +91,17 @@ impl<'e> BatchEvaluator<'e> {
     pub fn negate(&self, a: DeviceBatch, out: DeviceBatch) -> Result<()> {
         check(unsafe { bindgen::hipbfv_batch_negate(self.h(), a.ptr, out.ptr, a.size, a.count, self.stream) })
     }
+    /// Lift `count` coefficient-form plaintexts (`u64[count][N]`, stride `plain_stride` words) to the data primes and transform
+    /// them: `pntt` = `u64[count][K][N]`, the operand `Input::PlaintextsNtt` takes.  An all-zero plaintext has no transformed
+    /// form -- SEAL refuses every product with it (`sunscreen/tests/features.rs:8-34`) and the consumers cannot see it any
+    /// more -- so this call ends with [`BatchEvaluator::check`] and fails with the index of the first one.
+    ///
+    /// # Safety
+    /// `plain` and `pntt` must be device addresses of `count` plaintexts / `count * K * N` words on the evaluator's device.
+    pub unsafe fn plain_to_ntt(&self, plain: *const u64, plain_stride: u64, pntt: *mut u64, count: u64) -> Result<()> {
+        check(bindgen::hipbfv_batch_plain_to_ntt(self.h(), plain, plain_stride, pntt, count, self.stream))?;
+        self.check()
+    }
     /// Synchronise the stream; `Err(InternalError(COR_E_INVALIDOPERATION, ..))` if any operation since the last call
     /// produced a transparent ciphertext.
     pub fn check(&self) -> Result<()> {

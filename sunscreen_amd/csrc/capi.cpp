@@ -2139,36 +2139,56 @@ long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_i
   std::string err;
   // the reference's runtime.run fails when any node's result is transparent (SEAL built with throw-on-transparent,
   // seal_fhe/build.rs:46-66; sunscreen/tests/features.rs:8-34; error collapse run.rs:78-82): every node's results are
-  // watched in a status word owned by this run and read once at exit
+  // watched in a status word owned by this run and read once at the end of every chunk
   hipStream_t s = (hipStream_t)stream;
   u32* status = g_throw_transparent ? (u32*)e->ev->scratch().acquire(256, s) : nullptr;
   if (g_throw_transparent && (!status || hipMemsetAsync(status, 0xFF, sizeof(u32), s) != hipSuccess)) {
     if (status) e->ev->scratch().release(status, s);
     return from_status(kOutOfMemory);
   }
-  int st;
-  {
-    WatchScope watch(status);
-    st = p->prog.run(*e->ev, batch, ins.data(), ins.size(), rk, gk, (u64* const*)outputs, num_outputs, s, &err);
+  // The scheduled executor's table-driven kernels put (output, item) on grid z: a run takes at most kRunChunk input sets, and
+  // a larger batch is a sequence of such runs over offset pointers (input sets are independent: the same bits) -- every kind of
+  // argument, transform-domain plaintexts included, works at every batch size (beyond 32768 the node-by-node
+  // executor used to take over, and it refuses kind 2).
+  constexpr uint64_t kRunChunk = 32768;
+  const size_t ct_words = e->ctx->ct_words(2);
+  std::vector<u64*> outs(num_outputs);
+  long hr = HIPBFV_S_OK;
+  for (uint64_t off = 0; off < batch || (batch == 0 && off == 0); off += kRunChunk) {
+    const uint64_t c = batch ? std::min<uint64_t>(kRunChunk, batch - off) : 0;  // an empty batch is the executor's to refuse
+    for (uint64_t i = 0; i < num_inputs; i++) {
+      ins[i] = ProgramInput{(int)input_kinds[i], (const u64*)input_ptrs[i], (size_t)input_strides[i]};
+      if (!ins[i].ptr) continue;
+      if (ins[i].kind == 0) ins[i].ptr += off * ct_words;
+      else ins[i].ptr += off * ins[i].stride;  // stride 0: one shared plaintext
+    }
+    for (uint64_t k = 0; k < num_outputs; k++) outs[k] = outputs[k] ? (u64*)outputs[k] + off * ct_words : nullptr;
+    int st;
+    {
+      WatchScope watch(status);
+      st = p->prog.run(*e->ev, c, ins.data(), ins.size(), rk, gk, outs.data(), num_outputs, s, &err);
+    }
+    u32 first_bad = 0xFFFFFFFFu;
+    if (status) {
+      const int st2 = e->ev->take_status(status, &first_bad, s);  // reads and resets the word
+      if (st == kOk) st = st2;
+    }
+    if (st != kOk) {
+      hr = from_status(st);
+      if (!err.empty()) tls_error = err;
+      break;
+    }
+    if (first_bad != 0xFFFFFFFFu) {
+      char msg[128];
+      // a merged launch numbers its ciphertexts member-major (member * batch + item): the item is what the caller knows
+      snprintf(msg, sizeof(msg), "result ciphertext is transparent (input set %llu of the batch)", (unsigned long long)(off + first_bad % (c ? c : 1)));
+      hr = fail(HIPBFV_COR_E_INVALIDOPERATION, msg);
+      break;
+    }
+    if (!batch) break;
   }
-  u32 first_bad = 0xFFFFFFFFu;
-  if (status) {
-    const int st2 = e->ev->take_status(status, &first_bad, s);
-    e->ev->scratch().release(status, s);
-    if (st == kOk) st = st2;
-  }
-  if (st != kOk) {
-    long hr = from_status(st);
-    if (!err.empty()) tls_error = err;
-    return hr;
-  }
-  if (first_bad != 0xFFFFFFFFu) {
-    char msg[128];
-    // a merged launch numbers its ciphertexts member-major (member * batch + item): the item is what the caller knows
-    snprintf(msg, sizeof(msg), "result ciphertext is transparent (input set %u of the batch)", (unsigned)(first_bad % (batch ? batch : 1)));
-    return fail(HIPBFV_COR_E_INVALIDOPERATION, msg);
-  }
-  return HIPBFV_S_OK;
+  if (status) e->ev->scratch().release(status, s);
+  return hr;
 HIPBFV_END
 
 long hipbfv_batch_status(void* h, uint64_t* first_transparent_item, void* stream) HIPBFV_BEGIN
@@ -2786,10 +2806,14 @@ long hipbfv_batch_encrypt_seeded(void* evaluator, const uint64_t* plain, uint64_
 HIPBFV_END
 
 // ------------------------------------------------------------------ plaintext-matrix x ciphertext-vector (PIR, examples/pir)
+// A transformed plaintext is only ever consumed by a ciphertext-plaintext product, and SEAL refuses the product with an all-zero
+// plaintext (transparent result; sunscreen/tests/features.rs:8-34).  The consumers (dot_plain_ntt, Program_Run's kind-2
+// arguments) no longer see coefficients, so the PRODUCER records the first all-zero plaintext in the evaluator's status word,
+// like every other hipbfv_batch_* operation records its transparent results: hipbfv_batch_status reports it.
 long hipbfv_batch_plain_to_ntt(void* evaluator, const uint64_t* plain, uint64_t plain_stride, uint64_t* pntt, uint64_t count, void* stream) HIPBFV_BEGIN
-  Evaluator* ev = eval_of(evaluator);
-  if (!ev || !plain || !pntt) return HIPBFV_E_POINTER;
-  return from_status(ev->plain_to_ntt((const u64*)plain, plain_stride, (u64*)pntt, count, (hipStream_t)stream));
+  EVAL_OR_RETURN(evaluator);
+  if (!plain || !pntt) return HIPBFV_E_POINTER;
+  return from_status(e->ev->plain_to_ntt((const u64*)plain, plain_stride, (u64*)pntt, count, (hipStream_t)stream, 1));
 HIPBFV_END
 long hipbfv_batch_ct_to_ntt(void* evaluator, const uint64_t* ct, uint64_t size, uint64_t* ctn, uint64_t count, void* stream) HIPBFV_BEGIN
   Evaluator* ev = eval_of(evaluator);

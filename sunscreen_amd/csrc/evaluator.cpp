@@ -271,10 +271,11 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   const u32 n = h.n, K = h.K, S = h.S, R = K + S, sd = sa + sb - 1;
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / (R * (sa + sb))));
   const size_t ext_words = (size_t)(sa + sb) * R * n, d_words = (size_t)sd * R * n;
-  ScratchGuard sg(pool_, chunk * (ext_words + d_words) * sizeof(u64), s);
+  const size_t cc = std::min(chunk, count);  // a handle-level call (count = 1) reserves one op's scratch, not a chunk's
+  ScratchGuard sg(pool_, cc * (ext_words + d_words) * sizeof(u64), s);
   if (!sg.p) return kOutOfMemory;
   u64* ext = (u64*)sg.p;
-  u64* D = ext + chunk * ext_words;
+  u64* D = ext + cc * ext_words;
   std::vector<u32> mods;
   for (u32 i = 0; i < K; i++) mods.push_back(i);
   for (u32 j = 0; j < S; j++) mods.push_back(h.KK + j);
@@ -342,7 +343,7 @@ int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t coun
   if (h.logn > 15) return kUnsupported;
   const u32 n = h.n, K = h.K;
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / ((size_t)h.KK * K)));
-  ScratchGuard sg(pool_, chunk * ks_scratch_words() * sizeof(u64), s);
+  ScratchGuard sg(pool_, std::min(chunk, count) * ks_scratch_words() * sizeof(u64), s);
   if (!sg.p) return kOutOfMemory;
   const size_t cs = (size_t)3 * K * n;
   for (size_t off = 0; off < count; off += chunk) {
@@ -420,10 +421,11 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, 
   const u32 ginv = (u32)(inv & (2 * n - 1));
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / ((size_t)h.KK * K)));
   const size_t rot_words = (size_t)2 * K * n;
-  ScratchGuard sg(pool_, chunk * (rot_words + ks_scratch_words()) * sizeof(u64), s);
+  const size_t cc = std::min(chunk, count);
+  ScratchGuard sg(pool_, cc * (rot_words + ks_scratch_words()) * sizeof(u64), s);
   if (!sg.p) return kOutOfMemory;
   u64* rot = (u64*)sg.p;
-  u64* ks = rot + chunk * rot_words;
+  u64* ks = rot + cc * rot_words;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     HB_LAUNCH(kKernGalois, c * 2, launch_galois(ctx_->dev(), n, K, ct2 + off * rot_words, rot, c * 2, ginv, s));

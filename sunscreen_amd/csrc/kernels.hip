@@ -21,12 +21,6 @@
 
 #include "devarith.hpp"
 #include "kernels.hpp"
-#ifndef NTT_PAIRS
-#define NTT_PAIRS 1
-#endif
-#ifndef NTT_DIRECT_LOAD
-#define NTT_DIRECT_LOAD 1
-#endif
 
 #include "behzcore.hpp"
 #include "nttcore.hpp"
@@ -52,11 +46,6 @@ __device__ __forceinline__ T ntt_ld(const T* p) {
 }
 template <bool NT, class T>
 __device__ __forceinline__ void ntt_st(T* p, T v) {
-#if NTT_PROBE == 2
-  unsigned long long head;
-  __builtin_memcpy(&head, &v, 8);
-  if (head != 0x5a5a5a5a5a5a5a5aull) return;  // data-dependent: in practice never stores
-#endif
   if constexpr (NT) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
@@ -80,37 +69,6 @@ __device__ __forceinline__ void ntt_st(T* p, T v) {
 // blocks independently, so their load / compute / store phases stagger instead of meeting at every pass.
 #ifndef NTT_WAVE_PRIVATE
 #define NTT_WAVE_PRIVATE 1
-#endif
-#ifndef NTT_WIDE_STORE
-#define NTT_WIDE_STORE 0
-#endif
-// Polynomials per workgroup of the stand-alone transforms at N >= 8192 (ntt_*_stream_kernel): a workgroup walks NTT_STREAM
-// consecutive polynomials and fetches polynomial i + 1 into registers while it transforms polynomial i, so that neither the
-// kernel prologue nor the HBM latency of the loads sits between two transforms.  1 = one polynomial per workgroup.
-#ifndef NTT_STREAM
-#define NTT_STREAM 1
-#endif
-// Workgroups of one launch start together and, with two of them per CU contending symmetrically, STAY together: both load,
-// both compute, both store (probes: removing the loads, the stores or the butterflies each saves nearly its full cost -- nothing
-// overlaps).  NTT_STAGGER > 0 holds back the second resident workgroup of every CU (blockIdx 256 .. 511: the dispatcher fills
-// one slot per CU across the 8 XCDs before the second) by that many s_sleep(127) (8128 cycles each) once, at the start of the
-// launch, so that one streams while the other computes.
-#ifndef NTT_STAGGER
-#define NTT_STAGGER 0
-#endif
-__device__ __forceinline__ void ntt_stagger() {
-#if NTT_STAGGER > 0
-  if (blockIdx.x >= 256u && blockIdx.x < 512u && gridDim.x >= 1024u) {
-#pragma unroll 1
-    for (int i = 0; i < NTT_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
-}
-// Timing probes for the stand-alone transforms (WRONG RESULTS, never in a shipped build; tools/gpu_r03_ntt_probe.sh):
-// 1 = no global loads of the polynomial, 2 = no stores, 3 = vector twiddle loads made wave-uniform (scalar),
-// 4 = the same for the passes over element bits >= 3 only, 5 = no butterflies (data movement only: global + LDS traffic as in the real kernel)
-#ifndef NTT_PROBE
-#define NTT_PROBE 0
 #endif
 constexpr int wave_bit_target(int b, int low, int r) { return b >= low ? b + r : b; }
 // pa, pb: forward pass numbers of the two passes an exchange connects
@@ -156,15 +114,8 @@ __device__ __forceinline__ void fwd_pass_compute(const A& ar, typename A::V (&v)
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
         u32 widx = (1u << (S0 + j)) + ((hi << j) | (u32)(k >> (R - j)));
-#if NTT_PROBE == 3
-        widx = __builtin_amdgcn_readfirstlane(widx);
-#elif NTT_PROBE == 4
-        if constexpr (LOW >= 3) widx = __builtin_amdgcn_readfirstlane(widx);
-#endif
-#if NTT_PROBE != 5
         const typename A::Tw w = tw[widx];
         ar.fwd(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w);
-#endif
       }
     }
   }
@@ -222,11 +173,7 @@ __device__ __forceinline__ void ntt_fwd_to_lds(const A& ar, const u64* __restric
   for (int g = 0; g < G0; g++)
 #pragma unroll
     for (int k = 0; k < (1 << R0); k++)
-#if NTT_PROBE == 1
-      v[g * (1 << R0) + k] = ar.from_u64((u64)(tid * 16u + (u32)k));
-#else
       v[g * (1 << R0) + k] = ar.from_u64(ntt_ld<(NTT_NT_FWD & 1) != 0>(src + elem_index<LOW0, R0>(tid + g * Sh::T, k)));
-#endif
   FwdPasses<A, LOGN, EPT, 0>::run(ar, v, smem, tid, tw, reduce_mask);
 }
 
@@ -261,15 +208,8 @@ __device__ __forceinline__ void inv_pass_compute(const A& ar, typename A::V (&v)
         if (k & half) continue;
         // global gap 2^(LOW+j): m = N >> (LOW+j+1) blocks, block index = element >> (LOW+j+1)
         u32 widx = (1u << (LOGN - 1 - LOW - j)) + ((hi << (R - 1 - j)) | (u32)(k >> (j + 1)));
-#if NTT_PROBE == 3
-        widx = __builtin_amdgcn_readfirstlane(widx);
-#elif NTT_PROBE == 4
-        if constexpr (LOW >= 3) widx = __builtin_amdgcn_readfirstlane(widx);
-#endif
-#if NTT_PROBE != 5
         const typename A::Tw w = tw[widx];
         ar.inv(v[g * (1 << R) + k], v[g * (1 << R) + k + half], w);
-#endif
       }
     }
   }
@@ -335,19 +275,6 @@ __device__ __forceinline__ void ntt_fwd_store(const A& ar, u64* x, typename A::V
   if constexpr (NTT_WAVE_PRIVATE && Sh::T >= 64) {
     // every wavefront stores the coefficients its own last pass produced: no barrier before the store either
     exchange_sync<true>();
-#if NTT_WIDE_STORE
-    // 16-byte stores: the wavefront's j-th and (j+1)-th runs of 64 coefficients are adjacent (j bit 0 is element bit 6), so a
-    // lane takes two neighbouring coefficients of the 128 and the wavefront writes 1 KB contiguous per instruction
-#pragma unroll
-    for (u32 j = 0; j < (u32)kElemsPerThread; j += 2) {
-      typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-      const u32 e = own_element_after_fwd<LOGN, kElemsPerThread>(tid & ~63u, j) + 2u * (tid & 63u);
-      u64x2_t w;
-      w.x = ar.canonical(smem[lds_pos(e)]);
-      w.y = ar.canonical(smem[lds_pos(e + 1)]);
-      ntt_st<(NTT_NT_FWD & 2) != 0>(reinterpret_cast<u64x2_t*>(x + e), w);
-    }
-#else
     {
       // per-thread and compile-time parts of the position, as in pass_pos
       const u32 e0 = own_element_after_fwd<LOGN, kElemsPerThread>(tid, 0), P = lds_pos(e0);
@@ -355,11 +282,10 @@ __device__ __forceinline__ void ntt_fwd_store(const A& ar, u64* x, typename A::V
 #pragma unroll
       for (u32 j = 0; j < (u32)kElemsPerThread; j++) {
         const u32 C = own_element_after_fwd<LOGN, kElemsPerThread>(0, j), X = lds_pos(C);
-        const u32 pos = NTT_SPLIT_LDS_ADDR ? (P ^ (X & 31u)) + (X & ~31u) : lds_pos(e0 | C);
+        const u32 pos = (P ^ (X & 31u)) + (X & ~31u);
         ntt_st<(NTT_NT_FWD & 2) != 0>(x0 + C, ar.canonical(smem[pos]));
       }
     }
-#endif
   } else {
     __syncthreads();
     for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) ntt_st<(NTT_NT_FWD & 2) != 0>(x + e, ar.canonical(smem[lds_pos(e)]));
@@ -375,35 +301,12 @@ __device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A:
   ntt_fwd_store<A, LOGN>(ar, x, smem, tid);
 }
 
-// ---- streaming form: raw words of the NEXT polynomial travel while this one is transformed ----
-template <int LOGN>
-__device__ __forceinline__ void ntt_fwd_fetch(u64 (&raw)[kElemsPerThread], const u64* src, u32 tid) {
-  using Sh = NttShape<LOGN>;
-  constexpr int R0 = Sh::radix(0), LOW0 = LOGN - R0, G0 = kElemsPerThread >> R0;
-#pragma unroll
-  for (int g = 0; g < G0; g++)
-#pragma unroll
-    for (int k = 0; k < (1 << R0); k++) raw[g * (1 << R0) + k] = ntt_ld<(NTT_NT_FWD & 1) != 0>(src + elem_index<LOW0, R0>(tid + g * Sh::T, k));
-}
-template <class A, int LOGN>
-__device__ __forceinline__ void ntt_fwd_stream_body(const DevMod& dm, const typename A::Tw* tw, u64* x, const u64* next, typename A::V* smem, u32 tid,
-                                                    u64 (&raw)[kElemsPerThread]) {
-  const A ar(dm);
-  typename A::V v[kElemsPerThread];
-#pragma unroll
-  for (int e = 0; e < kElemsPerThread; e++) v[e] = ar.from_u64(raw[e]);
-  if (next) ntt_fwd_fetch<LOGN>(raw, next, tid);  // in flight until the next iteration's conversions
-  FwdPasses<A, LOGN, kElemsPerThread, 0>::run(ar, v, smem, tid, tw, dm.fwd_reduce_mask);
-  ntt_fwd_store<A, LOGN>(ar, x, smem, tid);
-}
-
 template <int LOGN>
 __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_fwd_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase, u64* data, NttPlan plan) {
   using Sh = NttShape<LOGN>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const u32 tid = threadIdx.x;
   const u32 poly = blockIdx.x;
-  ntt_stagger();
   const u32 m = plan_mod(plan, poly);
   const DevMod& dm = ctx->mod[m];
   u64* x = data + (size_t)poly * Sh::N;
@@ -423,7 +326,6 @@ __device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A:
   using Sh = NttShape<LOGN>;
   const A ar(dm);
   typename A::V v[kElemsPerThread];
-#if NTT_DIRECT_LOAD
   {  // the first inverse pass consumes runs of 2^R consecutive elements per thread: load them straight into registers
     constexpr int RF = Sh::radix(Sh::NPASS - 1), GF = kElemsPerThread >> RF;
 #pragma unroll
@@ -433,13 +335,7 @@ __device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A:
 #pragma unroll
       for (int k = 0; k < (1 << RF); k += 2) {
         typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-#if NTT_PROBE == 1
-        u64x2_t wv;
-        wv.x = tid * 16u + (u32)k;
-        wv.y = tid * 16u + (u32)k + 1u;
-#else
         const u64x2_t wv = ntt_ld<(NTT_NT_INV & 1) != 0>(reinterpret_cast<const u64x2_t*>(src + (k >> 1)));
-#endif
         const ulonglong2 w = make_ulonglong2(wv.x, wv.y);
         v[g * (1 << RF) + k] = ar.from_u64(w.x);
         v[g * (1 << RF) + k + 1] = ar.from_u64(w.y);
@@ -456,10 +352,6 @@ __device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A:
     }
     InvPasses<A, LOGN, kElemsPerThread, 0, true>::run(ar, v, smem, tid, tw, dm.inv_reduce_mask);
   }
-#else
-  for (u32 e = tid; e < (u32)Sh::N; e += Sh::T) smem[lds_pos(e)] = mul_b ? ar.mul_var(ar.from_u64(mul_a[e]), ar.from_u64(mul_b[e])) : ar.from_u64(x[e]);
-  ntt_inv_from_lds<A, LOGN>(ar, v, smem, tid, tw, dm.inv_reduce_mask);
-#endif
   constexpr int R = Sh::radix(0);
   constexpr int LOW = LOGN - R;
   constexpr int G = kElemsPerThread >> R;
@@ -476,7 +368,6 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const u32 tid = threadIdx.x;
   const u32 poly = blockIdx.x;
-  ntt_stagger();
   const u32 m = plan_mod(plan, poly);
   const DevMod& dm = ctx->mod[m];
   u64* x = data + (size_t)poly * Sh::N;
@@ -489,113 +380,6 @@ __global__ __launch_bounds__(NttShape<LOGN>::T) void ntt_inv_kernel(const DevCtx
     MulOp sc = dm.ninv;
     if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
     ntt_inv_body<ArithI, LOGN>(dm, tw, sc, x, reinterpret_cast<u64*>(smem_raw), tid);
-  }
-}
-
-// ---- streaming kernels (NTT_STREAM polynomials per workgroup) ----
-// plan_mod through the scalar unit: a byte load from the kernel arguments would be a VECTOR load, and inside the loop its
-// s_waitcnt vmcnt(0) would also wait for every store of the previous polynomial (vmcnt retires in order)
-__device__ __forceinline__ u32 plan_mod_scalar(const NttPlan& plan, u32 poly) {
-  const u32 i = __builtin_amdgcn_readfirstlane((poly / plan.div) % plan.period);
-  const u32* words = reinterpret_cast<const u32*>(plan.mod);
-  return (words[i >> 2] >> ((i & 3u) * 8u)) & 0xffu;
-}
-// threadIdx.x rebuilt from the wave number (an SGPR) and the lane number: nothing derived from it stays in vector registers
-// across the polynomial loop, where the prefetched words already take 32 of them
-__device__ __forceinline__ u32 stream_tid(u32& wave) {
-  asm volatile("" : "+s"(wave));
-  return (wave << 6) | __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-template <int LOGN, int POLICY>
-__global__ __launch_bounds__(NttShape<LOGN>::T) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_fwd_stream_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase, u64* data, NttPlan plan,
-                                                                           u32 polys) {
-  using Sh = NttShape<LOGN>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const u32 tid0 = threadIdx.x;
-  u32 wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const u32 first = blockIdx.x * (u32)NTT_STREAM;
-  const u32 last = first + (u32)NTT_STREAM < polys ? first + (u32)NTT_STREAM : polys;
-  u64 raw[kElemsPerThread];
-  ntt_fwd_fetch<LOGN>(raw, data + (size_t)first * Sh::N, tid0);
-  for (u32 poly = first; poly < last; poly++) {
-    // the store half of the previous transform reads LDS wave by wave; this transform's first exchange writes all of it
-    if (poly != first) __syncthreads();
-    const u32 tid = stream_tid(wave);
-    const u32 m = plan_mod_scalar(plan, poly);
-    const DevMod& dm = ctx->mod[m];
-    u64* x = data + (size_t)poly * Sh::N;
-    const u64* next = poly + 1 < last ? x + Sh::N : nullptr;
-    const MulOp* tw = twbase + (size_t)m * Sh::N;
-    if (POLICY == 1 || (POLICY == 0 && dm.use_f64))
-      ntt_fwd_stream_body<ArithD, LOGN>(dm, reinterpret_cast<const double*>(tw), x, next, reinterpret_cast<double*>(smem_raw), tid, raw);
-    else
-      ntt_fwd_stream_body<ArithI, LOGN>(dm, tw, x, next, reinterpret_cast<u64*>(smem_raw), tid, raw);
-  }
-}
-
-typedef unsigned long long ntt_u64x2 __attribute__((ext_vector_type(2)));
-template <int LOGN>
-__device__ __forceinline__ void ntt_inv_fetch(ntt_u64x2 (&raw)[kElemsPerThread / 2], const u64* src, u32 tid) {
-  using Sh = NttShape<LOGN>;
-  constexpr int RF = Sh::radix(Sh::NPASS - 1), GF = kElemsPerThread >> RF;
-#pragma unroll
-  for (int g = 0; g < GF; g++)
-#pragma unroll
-    for (int k = 0; k < (1 << RF); k += 2)
-      raw[(g * (1 << RF) + k) >> 1] = ntt_ld<(NTT_NT_INV & 1) != 0>(reinterpret_cast<const ntt_u64x2*>(src + ((size_t)(tid + g * Sh::T) << RF) + k));
-}
-template <class A, int LOGN>
-__device__ __forceinline__ void ntt_inv_stream_body(const DevMod& dm, const typename A::Tw* tw, const typename A::Sc& sc, u64* x, const u64* next,
-                                                    typename A::V* smem, u32 tid, ntt_u64x2 (&raw)[kElemsPerThread / 2]) {
-  using Sh = NttShape<LOGN>;
-  const A ar(dm);
-  typename A::V v[kElemsPerThread];
-#pragma unroll
-  for (int e = 0; e < kElemsPerThread; e += 2) {
-    v[e] = ar.from_u64(raw[e >> 1].x);
-    v[e + 1] = ar.from_u64(raw[e >> 1].y);
-  }
-  // vmcnt retires in order: a fetch issued before the passes whose twiddles are VECTOR loads (element windows below bit 6:
-  // the first NV passes of an inverse transform) would be waited for at their first twiddle.  It goes out after them.
-  constexpr int NV = (6 + Sh::radix(Sh::NPASS - 1) - 1) / Sh::radix(Sh::NPASS - 1) < Sh::NPASS - 1 ? (6 + Sh::radix(Sh::NPASS - 1) - 1) / Sh::radix(Sh::NPASS - 1) : Sh::NPASS - 1;
-  InvPasses<A, LOGN, kElemsPerThread, 0, true, NV>::run(ar, v, smem, tid, tw, dm.inv_reduce_mask);
-  if (next) ntt_inv_fetch<LOGN>(raw, next, tid);
-  InvPasses<A, LOGN, kElemsPerThread, NV, true>::run(ar, v, smem, tid, tw, dm.inv_reduce_mask);
-  constexpr int R = Sh::radix(0), LOW = LOGN - R, G = kElemsPerThread >> R;
-#pragma unroll
-  for (int g = 0; g < G; g++)
-#pragma unroll
-    for (int k = 0; k < (1 << R); k++) ntt_st<(NTT_NT_INV & 2) != 0>(x + elem_index<LOW, R>(tid + g * Sh::T, k), ar.scale_canonical(v[g * (1 << R) + k], sc));
-}
-template <int LOGN, int POLICY>
-__global__ __launch_bounds__(NttShape<LOGN>::T) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_inv_stream_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twbase, u64* data, NttPlan plan,
-                                                                           int scale_mode, u32 polys) {
-  using Sh = NttShape<LOGN>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const u32 tid0 = threadIdx.x;
-  u32 wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const u32 first = blockIdx.x * (u32)NTT_STREAM;
-  const u32 last = first + (u32)NTT_STREAM < polys ? first + (u32)NTT_STREAM : polys;
-  ntt_u64x2 raw[kElemsPerThread / 2];
-  ntt_inv_fetch<LOGN>(raw, data + (size_t)first * Sh::N, tid0);
-  for (u32 poly = first; poly < last; poly++) {
-    // the last pass of the previous transform read LDS across wavefronts; this transform's first pass writes it
-    if (poly != first) __syncthreads();
-    const u32 tid = stream_tid(wave);
-    const u32 m = plan_mod_scalar(plan, poly);
-    const DevMod& dm = ctx->mod[m];
-    u64* x = data + (size_t)poly * Sh::N;
-    const u64* next = poly + 1 < last ? x + Sh::N : nullptr;
-    const MulOp* tw = twbase + (size_t)m * Sh::N;
-    if (POLICY == 1 || (POLICY == 0 && dm.use_f64)) {
-      MulOpD sc = dm.ninv_d;
-      if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q_d[m] : ctx->intt_scale_bsk_d[m - ctx->KK];
-      ntt_inv_stream_body<ArithD, LOGN>(dm, reinterpret_cast<const double*>(tw), sc, x, next, reinterpret_cast<double*>(smem_raw), tid, raw);
-    } else {
-      MulOp sc = dm.ninv;
-      if (scale_mode == 1) sc = m < ctx->KK ? ctx->intt_scale_q[m] : ctx->intt_scale_bsk[m - ctx->KK];
-      ntt_inv_stream_body<ArithI, LOGN>(dm, tw, sc, x, next, reinterpret_cast<u64*>(smem_raw), tid, raw);
-    }
   }
 }
 
@@ -811,12 +595,7 @@ static void allow_dynamic_lds(const void* kernel, size_t bytes) {
 template <int LOGN>
 static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, size_t polys, const NttPlan& plan, bool inverse, int scale_mode, hipStream_t s) {
   using Sh = NttShape<LOGN>;
-#ifdef NTT_LDS_PAD  // occupancy probe: ask for more LDS than the transform uses (one workgroup per CU at N = 8192 with 2)
-  const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64) * NTT_LDS_PAD;
-#else
   const size_t lds = (size_t)Sh::LDS_WORDS * sizeof(u64);
-#endif
-#if NTT_PAIRS
   if constexpr (LOGN <= 12) {  // measured: +5 % at N = 4096; at N = 8192 (128 KB of LDS, one workgroup per CU) 5 % slower
     // as many polynomials as possible go two per workgroup; the remainder (< 2 * period) one per workgroup below
     const size_t paired = plan.div == 1 ? polys / (2 * (size_t)plan.period) * (2 * (size_t)plan.period) : 0;
@@ -832,20 +611,6 @@ static hipError_t launch_ntt_t(const DevCtx* ctx, const MulOp* tw, u64* data, si
       polys -= paired;  // paired is a multiple of the period: the plan's modulus cycle continues unchanged
     }
   }
-#endif
-#if NTT_STREAM > 1 && NTT_DIRECT_LOAD
-  if (LOGN == 13 && polys >= 2048 * (size_t)NTT_STREAM && polys < ((size_t)1 << 32)) {  // enough workgroups to fill the device either way
-    const unsigned groups = (unsigned)((polys + NTT_STREAM - 1) / NTT_STREAM);
-    if (inverse) {
-      allow_dynamic_lds((const void*)ntt_inv_stream_kernel<LOGN, 1>, lds);
-      ntt_inv_stream_kernel<LOGN, 1><<<dim3(groups), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan, scale_mode, (u32)polys);
-    } else {
-      allow_dynamic_lds((const void*)ntt_fwd_stream_kernel<LOGN, 1>, lds);
-      ntt_fwd_stream_kernel<LOGN, 1><<<dim3(groups), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan, (u32)polys);
-    }
-    return hipGetLastError();
-  }
-#endif
   if (inverse) {
     allow_dynamic_lds((const void*)ntt_inv_kernel<LOGN>, lds);
     ntt_inv_kernel<LOGN><<<dim3((unsigned)polys), dim3(Sh::T), lds, s>>>(ctx, tw, data, plan, scale_mode);
@@ -876,9 +641,6 @@ static hipError_t launch_ntt_inv_dyadic_t(const DevCtx* ctx, const MulOp* tw, co
 // transforms' worth of live values the kernel needs > 128 registers at N = 16384 -- 536 bytes of scratch -- and the
 // loop-invariant twiddle / address hoisting has to be fought; one polynomial per workgroup needs neither.)
 // =====================================================================================
-#ifndef CT_PLAIN_FUSED
-#define CT_PLAIN_FUSED 1
-#endif
 template <class A, int LOGN>
 __device__ __forceinline__ void ct_plain_body(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi, const typename A::Sc& ninv,
                                               const u64* __restrict__ pn, const u64* x, u64* y, typename A::V* smem, u32 tid) {
@@ -966,7 +728,6 @@ static hipError_t launch_ct_plain_t(const DevCtx* ctx, const MulOp* twf, const M
 hipError_t launch_ct_plain(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, u32 K, bool any_d, bool any_i, const u64* pn, size_t pnstride,
                            const u64* in, u64* out, u32 size, size_t ops, hipStream_t s) {
   if (ops == 0) return hipSuccess;
-#if CT_PLAIN_FUSED
   switch (logn) {
     case 10: return launch_ct_plain_t<10>(ctx, twf, twi, K, any_d, any_i, pn, pnstride, in, out, size, ops, s);
     case 11: return launch_ct_plain_t<11>(ctx, twf, twi, K, any_d, any_i, pn, pnstride, in, out, size, ops, s);
@@ -975,7 +736,6 @@ hipError_t launch_ct_plain(const DevCtx* ctx, const MulOp* twf, const MulOp* twi
     case 14: return launch_ct_plain_t<14>(ctx, twf, twi, K, any_d, any_i, pn, pnstride, in, out, size, ops, s);
     default: break;
   }
-#endif
   return hipErrorNotSupported;
 }
 
@@ -1210,9 +970,6 @@ __global__ __launch_bounds__(kCoefThreads) void galois_kernel(const DevCtx* __re
 // (position (s >> 1) + (s & 1) * N/2): a lane's two outputs 2j, 2j+1 come from sources 2j*ginv (even) and 2j*ginv + ginv
 // (odd), so across the lanes of a wavefront each of the two LDS reads walks one half with the odd stride ginv --
 // conflict-free -- and the staging writes are contiguous in each half.
-#ifndef GALOIS_LDS
-#define GALOIS_LDS 1
-#endif
 constexpr int kGaloisThreads = 1024;
 template <int LOGN>
 __global__ __launch_bounds__(kGaloisThreads) void galois_lds_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ in, u64* __restrict__ out, u32 ginv) {
@@ -1575,7 +1332,6 @@ hipError_t launch_mod_switch(const DevCtx* ctx, u32 n, const u64* in, u64* out, 
 }
 
 hipError_t launch_galois(const DevCtx* ctx, u32 n, u32 K, const u64* in, u64* out, size_t polys, u32 ginv, hipStream_t s) {
-#if GALOIS_LDS
   // polys * K residue polynomials, one workgroup each (the host reads K from its own copy of the context: see the caller)
   switch (n) {
     case 4096: galois_lds_kernel<12><<<dim3((unsigned)(polys * K)), kGaloisThreads, 0, s>>>(ctx, in, out, ginv); return hipGetLastError();
@@ -1583,7 +1339,6 @@ hipError_t launch_galois(const DevCtx* ctx, u32 n, u32 K, const u64* in, u64* ou
     case 16384: galois_lds_kernel<14><<<dim3((unsigned)(polys * K)), kGaloisThreads, 0, s>>>(ctx, in, out, ginv); return hipGetLastError();
     default: break;
   }
-#endif
   galois_kernel<<<coef_grid(n, (u32)polys), kCoefThreads, 0, s>>>(ctx, in, out, ginv);
   return hipGetLastError();
 }
@@ -1650,6 +1405,7 @@ hipError_t launch_eltwise_items(const DevCtx* ctx, u32 n, u32 K, const u64* cons
 }
 hipError_t launch_nary_sum(const DevCtx* ctx, u32 n, u32 K, const NaryOut* outs, const NaryTerm* terms, u32 nouts, u32 max_size, u32 batch, hipStream_t s) {
   // grid z <= 65535: the outputs go in slices (the tables are indexed from the slice's first output)
+  if (batch == 0 || batch > 65535u) return hipErrorInvalidValue;  // one output's items must fit grid z (callers chunk the batch)
   const u32 per = std::max(1u, 65535u / batch);
   for (u32 off = 0; off < nouts; off += per) {
     const u32 c = std::min(per, nouts - off);

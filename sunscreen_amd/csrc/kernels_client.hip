@@ -520,6 +520,7 @@ __global__ __launch_bounds__(kClientThreads) void dot_plain_tab_kernel(const Dev
 hipError_t launch_dot_plain_tab(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const PlainNttRef* tab, u32 rows, u32 batch, u64* acc, hipStream_t s) {
   constexpr int RT = 4;
   // grid z <= 65535: row blocks go in slices
+  if (batch == 0 || batch > 65535u) return hipErrorInvalidValue;  // one row block's items must fit grid z (callers chunk the batch)
   const u32 per = std::max(1u, 65535u / batch);  // row blocks per launch
   const u32 blocks = (rows + RT - 1) / RT;
   for (u32 off = 0; off < blocks; off += per) {

@@ -41,7 +41,7 @@ __device__ __forceinline__ u32 blk_pos(u32 e) {
 
 // EPT: elements per middle-kernel thread (8).  At N = 16384 a block is 4096 coefficients, and 512-thread workgroups with four
 // 32 KB exchange regions leave room for ONE workgroup per CU -- nothing overlaps its load and store phases (an N = 8192 middle
-// kernel padded down to one workgroup per CU runs 1.7x slower: -DMID_LDS_PAD).  The machinery is parametrised on EPT so that 16
+// kernel padded down to one workgroup per CU ran 1.7x slower in an r02 experiment).  The machinery is parametrised on EPT so that 16
 // elements per thread (256-thread workgroups, two of them resident) could be tried there: see MID_EPT_14.
 template <int L, int EPT = kBlkEPT>
 struct SplitShape {
@@ -69,14 +69,10 @@ struct BlkPass {
   // position inside the block's LDS image: per-thread part ^ / + compile-time parts (nttcore.hpp pass_pos: the DS
   // instructions take the constant part as their immediate offset)
   static __device__ __forceinline__ u32 pos(u32 tid, u32 blk, int g, int k) {
-#if NTT_SPLIT_LDS_ADDR
     static_assert((Sh::TPB & (Sh::TPB - 1)) == 0, "tid and g*TPB must occupy disjoint bits");
     const u32 P = blk_pos(elem_index<LOW, R>(tid, 0));
     const u32 X = blk_pos(elem_index<LOW, R>((u32)g * Sh::TPB, (u32)k));
     return (P ^ (X & 31u)) + (X & ~31u);
-#else
-    return blk_pos(elem(tid, blk, g, k) & (Sh::BLOCK - 1));
-#endif
   }
   static __device__ __forceinline__ void load_lds(typename A::V (&v)[EPT], const typename A::V* smem, u32 tid, u32 blk) {
 #pragma unroll
@@ -216,15 +212,6 @@ __device__ __forceinline__ void reduce_all(const A& ar, typename A::V (&v)[EPT])
 
 // TW_PIPE_D / TW_PIPE_I (FP64 / integer policy): 0 = every pass fetches its twiddles when it needs them; 1 = the next pass's twiddles are fetched
 // before the LDS exchange that precedes it; 2 = before the current pass's butterflies (needs both sets live).
-#ifndef MUL_SQUARE  // squaring specialisation of the multiply's head and middle kernels (0: x * x runs as a general product)
-#define MUL_SQUARE 1
-#endif
-#ifndef MID_BATCHED_D
-#define MID_BATCHED_D true
-#endif
-#ifndef MID_BATCHED_I
-#define MID_BATCHED_I true
-#endif
 #ifndef TW_PIPE_D
 #define TW_PIPE_D 1
 #endif
@@ -448,11 +435,6 @@ __device__ __forceinline__ void mid_inverse_multi(const A& ar, typename A::V (&v
 }
 
 constexpr int kHeadThreads = 256;
-// Minimum waves per SIMD the 8-prime head / tail instantiations are compiled for (experiment hook; 0 = the compiler's choice,
-// which is 2 at 178-196 registers)
-#ifndef EDGE8_WAVES
-#define EDGE8_WAVES 0
-#endif
 // the mixed-base head (integer data primes, FP64 auxiliary primes: the <L, 4, AUXD = false, PACK = true> instantiations): waves per
 // SIMD its registers are limited for.  Measured on the 3 x 54-bit workload: 3 (168 registers, 76 bytes of scratch) 2.66-2.81 ms,
 // the compiler's choice (185 registers, 2 waves) 2.90-3.01, 4 (128 registers, 236 bytes) 3.03-3.07.
@@ -463,7 +445,7 @@ constexpr int kHeadThreads = 256;
 #ifndef HEAD_MIXED_WAVES
 #define HEAD_MIXED_WAVES 3
 #endif
-#define EDGE_BOUNDS(KMAX) __launch_bounds__(kHeadThreads, ((KMAX) > 4 && EDGE8_WAVES ? EDGE8_WAVES : 1))
+#define EDGE_BOUNDS(KMAX) __launch_bounds__(kHeadThreads)
 // mul_mid, FP64 instantiation: at N = 8192 the four forward transforms go through the exchange buffer as two pairs
 // (48 KB of LDS per workgroup instead of 64 KB: 3 workgroups = 12 waves per CU instead of 2 = 8; -5 % mul_mid).  At N = 4096
 // the regions are small anyway and the extra barriers cost 37 %; at N = 16384 one workgroup fills the CU either way.
@@ -474,6 +456,14 @@ constexpr int kHeadThreads = 256;
 // registers): whether they also prefetch the next pass's twiddles (a second set of twiddle registers)
 #ifndef MID3_PIPE_SINGLE
 #define MID3_PIPE_SINGLE true  // measured: 6.10-6.15 with, 6.19-6.34 ms without; the scratch is the same either way
+#endif
+// MODE 3, last forward round: the first MID3_PARK values of the waiting partial product a0 b1 sit in thread-private LDS slots
+// behind the two exchange regions while a1 is transformed.  r03 left them to the register allocator, which spilt 22 dwords per
+// lane to scratch -- written once, read once, and visible in the PMC passes as 1.6 MB of writes and 1.7 MB of reads per op over
+// the kernel's own model (72 workgroups x 256 lanes x 88 bytes).  6 values: 252 registers, no scratch, 76 KB of LDS per
+// workgroup (two resident per CU); 4 leave 24 bytes of scratch, 8 need the full 80 KB.
+#ifndef MID3_PARK
+#define MID3_PARK 6
 #endif
 #ifndef MID_TW_PIPE  // mul_mid (pass-batched bodies): next pass's twiddles fetched before the exchange (a second set of twiddle registers)
 #define MID_TW_PIPE(L) true
@@ -505,12 +495,6 @@ constexpr int kHeadThreads = 256;
 #endif
 #ifndef KS_MAC_CHUNK  // ks_mid: key words loaded per accumulation step (elements; 8 = a whole window at once)
 #define KS_MAC_CHUNK(L) 8
-#endif
-#ifndef KS_PREFETCH  // ks_mid: digit pairs with the next pair's loads in flight (see the kernel); at which sizes
-#define KS_PREFETCH 0
-#endif
-#ifndef KS_PREFETCH_AT
-#define KS_PREFETCH_AT(L) ((L) == 14)
 #endif
 
 // -------------------------------------------------------------------------------------------------
@@ -633,9 +617,6 @@ struct EdgeGeom {
   static __device__ __forceinline__ u32 tail_out(u32 t, int j) { return base(t) + k_split(t, j) * QT; }
 };
 
-__device__ __forceinline__ u32 swap_adjacent_lanes(u32 v) {
-  return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-}
 // lower half-wave's `lo_side` <-> upper half-wave's `hi_side` (v_permlane32_swap: lanes 32..63 of vdst swap with lanes 0..31 of src)
 __device__ __forceinline__ void half_wave_swap(u32& hi_side, u32& lo_side) {
   const auto r = __builtin_amdgcn_permlane32_swap(hi_side, lo_side, false, false);
@@ -737,46 +718,14 @@ __device__ __forceinline__ void tail_inv_owned(const A& ar, typename A::V (&v)[4
   }
 }
 
-// Packed stores of the NC values a head thread owns (indices t + k*Q), two values per store instruction.  Stored one by one, a
-// packed value costs a 4-byte and a 2-byte store per lane -- the narrowest accesses of the whole pipeline.  Neighbouring
-// lanes own neighbouring coefficients, so a pair of lanes (2i, 2i+1) exchanges halves across the wavefront (one DPP quad_perm
-// swap each for the low words and the high halves): the even lane then stores BOTH lanes' low words of value k as one 8-byte
-// word and both high halves as one 4-byte word, the odd lane does the same for value k+1 -- every lane active, half the
-// store instructions, 8- and 4-byte accesses instead of 4- and 2-byte ones.  The memory image is unchanged.
-#ifndef PACK_PAIR_STORES
-#define PACK_PAIR_STORES 0  // measured (interleaved A/B, r02): mul_head +0.8 %, ks_head +2 % SLOWER with the pair stores: store width is not what limits the head kernels
-#endif
 // the NC head outputs of thread t to their places facing the middle kernels (EdgeGeom::head_out)
 template <int L, bool PACK, bool NT>
 __device__ __forceinline__ void nat_store_head(double* __restrict__ region, u32 t, const double (&v)[EdgeGeom<L>::HEAD_NC]);
 
 template <bool PACK, bool NT, int NC>
 __device__ __forceinline__ void nat_store_owned(double* __restrict__ region, u32 n, u32 t, size_t Q, const double (&v)[NC]) {
-  if constexpr (PACK && PACK_PAIR_STORES && !NT && (NC % 2 == 0)) {
-    typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
-    const bool odd = (t & 1u) != 0;
-    const u32 te = t & ~1u;
-    u32* lo_plane = reinterpret_cast<u32*>(region);
-    short* hi_plane = reinterpret_cast<short*>(reinterpret_cast<char*>(region) + 4 * (size_t)n);
 #pragma unroll
-    for (int k = 0; k < NC; k += 2) {
-      const double ma = v[k] + kPackMagic, mb = v[k + 1] + kPackMagic;
-      const u32 loa = (u32)__double2loint(ma), lob = (u32)__double2loint(mb);
-      const u32 hia = (u32)__double2hiint(ma) & 0xFFFFu, hib = (u32)__double2hiint(mb) & 0xFFFFu;
-      const u32 rlo = swap_adjacent_lanes(odd ? loa : lob);  // even lane receives the odd lane's A, odd lane the even lane's B
-      const u32 rhi = swap_adjacent_lanes(odd ? hia : hib);
-      u32x2_t w;
-      w.x = odd ? rlo : loa;
-      w.y = odd ? lob : rlo;
-      const u32 h = odd ? (rhi | (hib << 16)) : (hia | (rhi << 16));
-      const size_t idx = te + (size_t)(odd ? k + 1 : k) * Q;
-      *reinterpret_cast<u32x2_t*>(lo_plane + idx) = w;
-      *reinterpret_cast<u32*>(hi_plane + idx) = h;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < NC; k++) nat_store<PACK, NT>(region, n, t + (size_t)k * Q, v[k]);
-  }
+  for (int k = 0; k < NC; k++) nat_store<PACK, NT>(region, n, t + (size_t)k * Q, v[k]);
 }
 template <int L, bool PACK, bool NT>
 __device__ __forceinline__ void nat_store_head(double* __restrict__ region, u32 t, const double (&v)[EdgeGeom<L>::HEAD_NC]) {
@@ -950,36 +899,6 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
   };
   u32 J = 0;
-#if KS_PREFETCH
-  if constexpr (KS_PREFETCH_AT(L)) {
-    // pairs of digits with the NEXT pair's rows requested before the current pair is transformed: the loads travel while the
-    // first passes (scalar twiddles: no vmcnt wait) run.  One workgroup per CU is resident at this size, so nothing else
-    // covers its load latency.
-    double cur[2][EPT], nxt[2][EPT];
-    if (K >= 2) {
-      load_src(0, cur[0]);
-      load_src(1, cur[1]);
-    }
-    for (; J + 2 <= K; J += 2) {
-      const bool more = J + 4 <= K;
-      if (more) {
-        load_src(J + 2, nxt[0]);
-        load_src(J + 3, nxt[1]);
-      }
-      if (J > 0) __syncthreads();
-      const double* twf_j = opaque_uniform(twf);
-      mid_forward_multi<A, L, 2, EPT>(ar, cur, smem, tid, blk, twf_j, dm.split_fwd_mask);
-      mac(J, cur[0]);
-      mac(J + 1, cur[1]);
-      if (more) {
-#pragma unroll
-        for (int e = 0; e < EPT; e++) cur[0][e] = nxt[0][e], cur[1][e] = nxt[1][e];
-      }
-    }
-    if (J < K) group(J, std::integral_constant<int, 1>{});
-    J = K;
-  }
-#endif
   if constexpr (KS_GROUP_MAX(L) >= 4)
     for (; J + 4 <= K; J += 4) group(J, std::integral_constant<int, 4>{});
   if constexpr (KS_GROUP_MAX(L) >= 2)
@@ -1247,7 +1166,7 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 // AUXD (DevCtx::aux_f64): every residue, auxiliary base included, takes the FP64 policy and the base extension
 // itself runs in FP64 (behz_extend_coeff_d).
 template <int L, int KMAX, bool AUXD, bool PACK>
-__global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : ((KMAX) > 4 && EDGE8_WAVES ? EDGE8_WAVES : 1))) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+__global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1)) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
                                                                 u64* __restrict__ ext) {
   using G = EdgeGeom<L>;
@@ -1369,66 +1288,7 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : (
   }
 }
 
-// mul middle body for one (op, residue, block)
-template <class A, int L>
-__device__ __forceinline__ void mul_mid_body(const DevMod& dm, const typename A::Tw* twf, const typename A::Tw* twi, const typename A::V* ext_r,
-                                             size_t poly_stride, typename A::V* D_r, size_t dpoly_stride, typename A::V* smem,
-                                             typename A::V* park, u32 tid, u32 blk) {
-  using Sh = SplitShape<L>;
-  const A ar(dm);
-  constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
-  using First = BlkPass<A, L, LOWF0, RF0>;
-  constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
-  using Out = BlkPass<A, L, LOWI, RI>;
-  typename A::V a1[kBlkEPT], d0[kBlkEPT], d1[kBlkEPT], v[kBlkEPT];
-  auto issue = [&](int poly, typename A::V(&dst)[kBlkEPT]) {
-    const typename A::V* src = ext_r + (size_t)poly * poly_stride;
-#pragma unroll
-    for (int g = 0; g < First::G; g++)
-#pragma unroll
-      for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
-  };
-  auto fwd = [&](typename A::V(&dst)[kBlkEPT], bool sync_first) {
-    if (sync_first) __syncthreads();
-    const typename A::Tw* tw = opaque_uniform(twf);  // keep the twiddle loads inside this transform
-    mid_forward<A, L, 0>(ar, dst, smem, tid, blk, tw, dm.split_fwd_mask);
-  };
-  issue(0, v);
-  fwd(v, false);  // a0 -> parked in LDS (thread-private slots)
-#pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) park[e * Sh::TPB + tid] = v[e];
-  issue(1, a1);
-  fwd(a1, true);
-  issue(2, v);
-  fwd(v, true);  // b0
-#pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) {
-    d0[e] = ar.mul_var(park[e * Sh::TPB + tid], v[e]);
-    d1[e] = ar.mul_var(a1[e], v[e]);
-  }
-  issue(3, v);
-  fwd(v, true);  // b1
-#pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) {
-    d1[e] = ar.mul_add(park[e * Sh::TPB + tid], v[e], d1[e]);
-    a1[e] = ar.mul_var(a1[e], v[e]);  // d2
-  }
-  auto inv_store = [&](typename A::V(&d)[kBlkEPT], int poly) {
-    __syncthreads();
-    const typename A::Tw* tw = opaque_uniform(twi);
-    mid_inverse<A, L, 0>(ar, d, smem, tid, blk, tw, dm.split_inv_mask);
-    typename A::V* dst = D_r + (size_t)poly * dpoly_stride;
-#pragma unroll
-    for (int g = 0; g < Out::G; g++)
-#pragma unroll
-      for (int k = 0; k < (1 << RI); k++) dst[Out::elem(tid, blk, g, k)] = d[g * (1 << RI) + k];
-  };
-  inv_store(d0, 0);
-  inv_store(d1, 1);
-  inv_store(a1, 2);
-}
-
-// The same work with the four forward transforms (and then the three inverse ones) advanced together, pass by
+// mul middle body for one (op, residue, block): the four forward transforms (and then the three inverse ones) advance together, pass by
 // pass (mid_forward_multi): smem = 4 regions of BLOCK elements, nothing is parked.
 // MODE 0: the four forward transforms together (4 exchange regions); 1: two pairs, one polynomial of the waiting pair parked in
 // a third region (3 regions, N = 8192); 2: two pairs with nothing parked and the inverse transforms as a pair + one (2 regions:
@@ -1469,102 +1329,6 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
   // registers, and holding all of them through the first transform spills (the other resident workgroup covers the latency)
   using Pair = typename A::V[2][EPT];
   using One = typename A::V[1][EPT];
-  if constexpr (MODE == 4 && !SQUARE) {
-    // 16 elements per thread, two 256-thread workgroups per CU (r03).  (a0, a1) are transformed as a pair and PARKED IN PLACE:
-    // every thread writes the 2 x 16 transformed values it holds over the block's own words of the two ext rows (unpacked
-    // 8-byte rows: MulMidGeom) -- 16-byte stores of the runs of 8 consecutive coefficients the last pass leaves -- and reads
-    // them back, from L2, when the tensor product wants them; nothing else ever reads these rows again.  (b0, b1) follow as a
-    // second pair; (d0, d1) and then d2 go through the inverse passes.  Two exchange regions (64 KB), no more than two operands
-    // and three products in registers.
-    static_assert(!(PACK && std::is_same<A, ArithD>::value), "parking needs unpacked rows");
-    static_assert(std::is_same<typename A::V, double>::value, "FP64 policy");
-    constexpr int RLW = split_fwd_radix(L, Sh::NPF - 1);
-    using Last = BlkPass<A, L, 0, RLW, EPT>;
-    static_assert((1 << RLW) % 2 == 0, "runs of an even number of consecutive coefficients");
-    typedef double dbl2 __attribute__((ext_vector_type(2)));
-    // global-address-space views of the rows (a pointer that went through an asm would otherwise come back as a FLAT pointer and
-    // every access through it as flat_load / flat_store); `gext` is re-materialised where an access must not move up
-    typedef __attribute__((address_space(1))) double gdouble;
-    typedef __attribute__((address_space(1))) dbl2 gdbl2;
-    unsigned long long gbits = (unsigned long long)ext_r;
-    auto rows = [&]() {
-      asm volatile("" : "+s"(gbits) : : "memory");
-      return (gdouble*)gbits;
-    };
-    typename A::V v2[2][EPT];
-    auto load_into = [&](gdouble* base, int i, typename A::V(&dst)[EPT]) {
-      gdouble* src = base + (size_t)i * poly_stride;
-#pragma unroll
-      for (int g = 0; g < First::G; g++)
-#pragma unroll
-        for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = src[First::elem(tid, blk, g, k)];
-    };
-    {
-      gdouble* base = rows();
-      load_into(base, 0, v2[0]);
-      load_into(base, 1, v2[1]);
-    }
-    mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, v2, smem, tid, blk, twf, dm.split_fwd_mask);
-    {
-      gdouble* base = rows();
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int g = 0; g < Last::G; g++) {
-          gdbl2* dst = (gdbl2*)(base + (size_t)i * poly_stride + Last::elem(tid, blk, g, 0));
-#pragma unroll
-          for (int k = 0; k < (1 << RLW); k += 2) {
-            dbl2 w;
-            w.x = v2[i][g * (1 << RLW) + k], w.y = v2[i][g * (1 << RLW) + k + 1];
-            dst[k / 2] = w;
-          }
-        }
-    }
-    {
-      gdouble* base = rows();  // "memory": the parked values have left; b0, b1 are not requested before this point
-      load_into(base, 2, v2[0]);
-      load_into(base, 3, v2[1]);
-    }
-    __syncthreads();  // the first pair's last pass may still be reading the exchange buffer
-    {
-      mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, v2, smem, tid, blk, opaque_uniform(twf), dm.split_fwd_mask);
-    }
-    typename A::V d01[2][EPT], d2[1][EPT];
-#pragma unroll
-    for (int g = 0; g < Last::G; g++) {
-      gdouble* base = rows();  // one group's parked values in flight at a time (a group = 2 x 8 values = 32 registers)
-      const gdbl2* p0 = (const gdbl2*)(base + Last::elem(tid, blk, g, 0));
-      const gdbl2* p1 = (const gdbl2*)(base + poly_stride + Last::elem(tid, blk, g, 0));
-#pragma unroll
-      for (int k = 0; k < (1 << RLW); k += 2) {
-        const dbl2 a0 = p0[k / 2], a1 = p1[k / 2];
-        const int e = g * (1 << RLW) + k;
-        d01[0][e] = ar.mul_var(a0.x, v2[0][e]);
-        d01[0][e + 1] = ar.mul_var(a0.y, v2[0][e + 1]);
-        d01[1][e] = ar.mul_add(a0.x, v2[1][e], ar.mul_var(a1.x, v2[0][e]));
-        d01[1][e + 1] = ar.mul_add(a0.y, v2[1][e + 1], ar.mul_var(a1.y, v2[0][e + 1]));
-        d2[0][e] = ar.mul_var(a1.x, v2[1][e]);
-        d2[0][e + 1] = ar.mul_var(a1.y, v2[1][e + 1]);
-      }
-    }
-    __syncthreads();  // the last forward pass may still be reading the exchange buffer
-    mid_inverse_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, d01, smem, tid, blk, twi, dm.split_inv_mask);
-    auto store_poly = [&](int i, const typename A::V(&dv)[EPT]) {
-      typename A::V* dst = D_r + (size_t)i * dpoly_stride;
-#pragma unroll
-      for (int g = 0; g < Out::G; g++)
-#pragma unroll
-        for (int k = 0; k < (1 << RI); k++) nt_st<NtSites<L>::mul_mid_st>(dst + Out::elem(tid, blk, g, k), dv[g * (1 << RI) + k]);
-    };
-    store_poly(0, d01[0]);
-    store_poly(1, d01[1]);
-    __syncthreads();
-    {
-      mid_inverse_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, d2, smem, tid, blk, opaque_uniform(twi), dm.split_inv_mask);
-    }
-    store_poly(2, d2[0]);
-    return;
-  }
   if constexpr (MODE == 3 && !SQUARE) {
     // 16 elements per thread, two 256-thread workgroups per CU (r03): the four operands never sit in registers together, and
     // each product polynomial leaves as soon as it is complete.  (a0, b0) are transformed as a pair, d0 = a0 b0 is taken
@@ -1618,14 +1382,18 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
       d12[0][e] = ar.mul_var(ab[0][e], x[0][e]);  // a0 b1
       ab[0][e] = x[0][e];                          // b1 takes a0's place
     }
+    typename A::V* parked = smem + 2 * Sh::BLOCK + tid;  // thread-private slots behind the two exchange regions (MulMidGeom::PARK)
+#pragma unroll
+    for (int e = 0; e < MID3_PARK; e++) parked[e * Sh::TPB] = d12[0][e];
     pin_loads();
     load_into(1, x[0]);
     __syncthreads();
     mid_forward_multi<A, L, 1, EPT, MID3_PIPE_SINGLE>(ar, x, smem, tid, blk, fresh(twf), dm.split_fwd_mask);  // a1
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
-      d12[0][e] = ar.mul_add(x[0][e], ab[1][e], d12[0][e]);  // + a1 b0
-      d12[1][e] = ar.mul_var(x[0][e], ab[0][e]);              // a1 b1
+      const typename A::V a0b1 = e < MID3_PARK ? parked[e * Sh::TPB] : d12[0][e];
+      d12[0][e] = ar.mul_add(x[0][e], ab[1][e], a0b1);  // + a1 b0
+      d12[1][e] = ar.mul_var(x[0][e], ab[0][e]);        // a1 b1
     }
     __syncthreads();
     mid_inverse_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, d12, smem, tid, blk, fresh(twi), dm.split_inv_mask);
@@ -1710,7 +1478,7 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 // Elements per thread of the FP64 middle kernels at N = 16384.  16 (256-thread workgroups, two exchange regions, two workgroups
 // per CU instead of one) was built and measured in round 2: the four operands of the tensor product are 128 registers, the 14
 // vector twiddles of a pass and of the prefetched next pass another 112, the kernel spills 860 bytes per lane and mul_mid takes
-// 16.5 ms instead of 6.4 (bit-exact).  Round 3 built two ways round the four operands (MID_EPT16_MODE below); with 16-byte
+// 16.5 ms instead of 6.4 (bit-exact).  Round 3 built two ways round the four operands (see below); with 16-byte
 // twiddles both lost to the 8-element kernel (8.7 and 7.1 ms against 6.5), with 8-byte twiddles (nttcore.hpp) MODE 3 fits 256
 // registers but for 92 bytes of scratch and wins: mul_mid 6.10-6.22 against 6.27-6.57 ms per 1024 ops (interleaved A/B on two
 // boxes, mul+relin +0.3...2.4 %).  16 is the default; `-DMID_EPT_14=8` is the one-workgroup-per-CU kernel of rounds 1-2.
@@ -1722,56 +1490,54 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
 #ifndef MID_EPT_14_SQ
 #define MID_EPT_14_SQ (HIPBFV_GEOM14 == 4 ? 16 : 8)
 #endif
-// MID_EPT16_MODE: how the general (four-operand) body lives in 256 registers at 16 elements per thread -- 3: operands folded into
-// the products one at a time (three forward rounds); 4: the first pair's transforms PARKED IN PLACE in `ext` (global memory, read
-// back from L2 at the tensor product; two forward rounds).  Parking overwrites the block's own words of an 8-byte row, so it
-// needs unpacked intermediates: with 48-bit packed rows (PACK) the general body stays at 8 elements per thread.
-#ifndef MID_EPT16_MODE
-#define MID_EPT16_MODE 3
+// The general (four-operand) body at 16 elements per thread is MODE 3 of mul_mid_body_batched: operands folded into the products
+// one at a time (three forward rounds).  (r03 also built a form that parked the first pair's transforms in place in `ext` and read
+// them back from L2 at the tensor product: scratch-free, two rounds, and slower -- 6.7 against 6.1 ms; removed in r04.)
+// Workgroup order of mul_mid: 1 = slice-major per XCD (see the kernel).  At N = 16384 the 36 vector-twiddle tables of a multiply
+// (18 moduli, forward and inverse, 128 KB each) are 4.7 MB -- more than one XCD's 4 MB L2, which also has the intermediates
+// streaming through it; r03's PMC passes showed mul_mid<14> fetching 1.3 MB per op beyond its rows and its scratch.
+#ifndef MUL_MID_SLICE
+#define MUL_MID_SLICE(L) ((L) == 14)
 #endif
-constexpr int mid_ept_d(int logn, bool square, bool pack) {
-  return logn == 14 ? (square ? MID_EPT_14_SQ : (pack && MID_EPT16_MODE == 4) ? kBlkEPT : MID_EPT_14) : kBlkEPT;
+constexpr int mid_ept_d(int logn, bool square) {
+  return logn == 14 ? (square ? MID_EPT_14_SQ : MID_EPT_14) : kBlkEPT;
 }
 template <int L, bool POLICY_D, bool SQUARE = false, bool PACK = false>
 struct MulMidGeom {
-  static constexpr int EPT = POLICY_D ? mid_ept_d(L, SQUARE, PACK) : kBlkEPT;
-  static constexpr bool batched = POLICY_D ? MID_BATCHED_D : MID_BATCHED_I;
-#if defined(MID_MODE_OF)  // experiment hook: exchange-region scheme of the FP64 middle kernel per degree (with MID_WAVES_OF)
-  static constexpr int MODE = !POLICY_D ? 0 : MID_MODE_OF(L);
-#elif defined(MID_MODE_14)  // experiment hook: exchange-region scheme of the FP64 middle kernel at N = 16384 (with MID_WAVES_14)
-  static constexpr int MODE = !POLICY_D ? 0 : (L == 14 ? MID_MODE_14 : EPT > kBlkEPT ? 2 : MID_FWD_PAIRS(L) ? 1 : 0);
-#else
-  static constexpr int MODE = !POLICY_D ? 0 : EPT > kBlkEPT ? (SQUARE ? 2 : MID_EPT16_MODE) : MID_FWD_PAIRS(L) ? 1 : 0;
-#endif
-  static constexpr int REGIONS = !batched ? 1 : (MODE >= 2) ? 2 : MODE == 1 ? 3 : 4;
+  static constexpr int EPT = POLICY_D ? mid_ept_d(L, SQUARE) : kBlkEPT;
+  static constexpr int MODE = !POLICY_D ? 0 : EPT > kBlkEPT ? (SQUARE ? 2 : 3) : MID_FWD_PAIRS(L) ? 1 : 0;
+  static constexpr int REGIONS = MODE >= 2 ? 2 : MODE == 1 ? 3 : 4;
   static constexpr int TPB = SplitShape<L, EPT>::TPB;
-#if defined(MID_WAVES_OF)
-  static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : MID_WAVES_OF(L);
-#elif defined(MID_WAVES_14)
-  static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : L == 14 ? MID_WAVES_14 : MID_WAVES_D(L);
-#else
+  static constexpr int PARK = (POLICY_D && MODE == 3 && !SQUARE) ? MID3_PARK * TPB : 0;  // LDS words behind the exchange regions
   static constexpr int WAVES = !POLICY_D ? MID_WAVES_I : EPT > kBlkEPT ? 2 : MID_WAVES_D(L);
-#endif
 };
 template <int L, bool POLICY_D, bool PACK, bool SQUARE = false>
 __global__ __launch_bounds__((MulMidGeom<L, POLICY_D, SQUARE, PACK>::TPB), (MulMidGeom<L, POLICY_D, SQUARE, PACK>::WAVES)) void mul_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                            const MulOp* __restrict__ twi_base, const u64* __restrict__ ext,
-                                                                           u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres) {
+                                                                           u64* __restrict__ D, const unsigned char* __restrict__ residues, u32 nres, u32 ops) {
   using Geo = MulMidGeom<L, POLICY_D, SQUARE, PACK>;
   using Sh = SplitShape<L, Geo::EPT>;
-  constexpr bool batched = Geo::batched;
-  __shared__ u64 smem[Geo::REGIONS * Sh::BLOCK];
-  __shared__ u64 park[batched ? 1 : Sh::BLOCK];
-#ifdef MID_LDS_PAD  // occupancy experiment: extra LDS per workgroup lowers the number of resident workgroups per CU
-  __shared__ u64 lds_pad[L == 13 ? MID_LDS_PAD / 8 : 64];
-  if (ext == nullptr) lds_pad[threadIdx.x] = 1, D[0] = lds_pad[(threadIdx.x + 1) & 63];
-#endif
+  __shared__ u64 smem[Geo::REGIONS * Sh::BLOCK + Geo::PARK];
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   const u32 b = blockIdx.x;
-  const u32 blk = b % Sh::NBLK;
-  const u32 r = residues[(b / Sh::NBLK) % nres];
-  const u32 op = b / (Sh::NBLK * nres);
+  u32 blk, r, op;
+  if constexpr (MUL_MID_SLICE(L)) {
+    // slice-major per XCD (the order ks_mid uses for its key rows): workgroups are dealt round-robin to the 8 XCDs, and within
+    // one XCD consecutive workgroups walk the ops of ONE (residue, block) slice, so the 2 x 32 KB of vector twiddles that slice
+    // uses are fetched into that XCD's L2 once per slice instead of once per workgroup
+    const u32 xcd = b & 7u, slot = b >> 3;
+    const u32 per = (ops + 7u) >> 3;
+    op = (slot % per) * 8u + xcd;
+    const u32 ib = slot / per;
+    blk = ib % Sh::NBLK;
+    r = __builtin_amdgcn_readfirstlane((u32)residues[ib / Sh::NBLK]);
+    if (op >= ops) return;
+  } else {
+    blk = b % Sh::NBLK;
+    r = residues[(b / Sh::NBLK) % nres];
+    op = b / (Sh::NBLK * nres);
+  }
   const u32 m = r < K ? r : KK + (r - K);
   const DevMod& dm = ctx->mod[m];
   const u64* ext_r = ext + ((size_t)op * 4 * R + r) * Sh::N;
@@ -1779,19 +1545,12 @@ __global__ __launch_bounds__((MulMidGeom<L, POLICY_D, SQUARE, PACK>::TPB), (MulM
   const size_t ps = (size_t)R * Sh::N;
   const MulOp* twf = twf_base + (size_t)m * Sh::N;
   const MulOp* twi = twi_base + (size_t)m * Sh::N;
-  static_assert(batched || !SQUARE, "the squaring specialisation exists in the pass-batched bodies only");
-  if constexpr (batched && POLICY_D)
+  if constexpr (POLICY_D)
     mul_mid_body_batched<ArithD, L, PACK, Geo::EPT, Geo::MODE, SQUARE>(dm, reinterpret_cast<const double*>(twf), reinterpret_cast<const double*>(twi),
                                     reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
                                     reinterpret_cast<double*>(smem), tid, blk);
-  else if constexpr (batched)
-    mul_mid_body_batched<ArithI, L, false, kBlkEPT, 0, SQUARE>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
-  else if constexpr (POLICY_D)
-    mul_mid_body<ArithD, L>(dm, reinterpret_cast<const double*>(twf), reinterpret_cast<const double*>(twi),
-                            reinterpret_cast<const double*>(ext_r), ps, reinterpret_cast<double*>(D_r), ps,
-                            reinterpret_cast<double*>(smem), reinterpret_cast<double*>(park), tid, blk);
   else
-    mul_mid_body<ArithI, L>(dm, twf, twi, ext_r, ps, D_r, ps, smem, park, tid, blk);
+    mul_mid_body_batched<ArithI, L, false, kBlkEPT, 0, SQUARE>(dm, twf, twi, ext_r, ps, D_r, ps, smem, tid, blk);
 }
 
 // the tail's inverse stages + BEHZ scaling on the 4 coefficients thread t owns (EdgeGeom): canonical residues out
@@ -2350,19 +2109,18 @@ template <int L>
 static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
                             const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, bool square, hipStream_t s) {
   using Sh = SplitShape<L>;
+  const size_t ops_g = MUL_MID_SLICE(L) ? (ops + 7) / 8 * 8 : ops;  // the slice-major order deals whole groups of 8 ops to the XCDs
   constexpr unsigned TDP = MulMidGeom<L, true, false, true>::TPB, TD = MulMidGeom<L, true, false, false>::TPB, TI = MulMidGeom<L, false>::TPB;
-#if MUL_SQUARE
   if (square) {
     constexpr unsigned TSP = MulMidGeom<L, true, true, true>::TPB, TS = MulMidGeom<L, true, true, false>::TPB;
-    if (nd && pack) mul_mid_kernel<L, true, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TSP, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
-    if (nd && !pack) mul_mid_kernel<L, true, false, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TS, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
-    if (ni) mul_mid_kernel<L, false, false, true><<<dim3((unsigned)(ops * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
+    if (nd && pack) mul_mid_kernel<L, true, true, true><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TSP, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
+    if (nd && !pack) mul_mid_kernel<L, true, false, true><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TS, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
+    if (ni) mul_mid_kernel<L, false, false, true><<<dim3((unsigned)(ops_g * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni, (u32)ops);
     return hipGetLastError();
   }
-#endif
-  if (nd && pack) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TDP, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
-  if (nd && !pack) mul_mid_kernel<L, true, false><<<dim3((unsigned)(ops * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd);
-  if (ni) mul_mid_kernel<L, false, false><<<dim3((unsigned)(ops * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni);
+  if (nd && pack) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TDP, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
+  if (nd && !pack) mul_mid_kernel<L, true, false><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
+  if (ni) mul_mid_kernel<L, false, false><<<dim3((unsigned)(ops_g * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni, (u32)ops);
   return hipGetLastError();
 }
 // res_d / res_i: device arrays listing the residue indices (0..R-1) handled by the FP64 / integer instantiation

@@ -42,20 +42,13 @@ __device__ __forceinline__ u32 elem_index(u32 vt, u32 k) {
 // C = elem_index(g*T, k) on disjoint bits; the swizzle is linear over GF(2), so lds_pos(e0 | C) = lds_pos(e0) ^ lds_pos(C).
 // P = lds_pos(e0) is zero wherever C has bits at positions >= 5 (the swizzle only changes bits 0..4), so those bits of
 // lds_pos(C) are an ADDITION -- which the DS instructions take as their immediate offset -- and only its low five bits
-// need an XOR: one v_xor per DISTINCT low part per pass instead of or + xor + shift-add per access (NTT_SPLIT_LDS_ADDR=0
-// is the A/B build).
-#ifndef NTT_SPLIT_LDS_ADDR
-#define NTT_SPLIT_LDS_ADDR 1
-#endif
+// need an XOR: one v_xor per DISTINCT low part per pass instead of or + xor + shift-add per access (measured in r02
+// against the per-access form: NTT +1-2 %, ks_mid -4.5 %).
 template <int LOW, int R, int T>
 __device__ __forceinline__ u32 pass_pos(u32 P, u32 tid, int g, int k) {
-#if NTT_SPLIT_LDS_ADDR
   static_assert((T & (T - 1)) == 0, "tid and g*T must occupy disjoint bits");
   const u32 X = lds_pos(elem_index<LOW, R>((u32)(g * T), (u32)k));  // a constant once the g, k loops are unrolled
   return (P ^ (X & 31u)) + (X & ~31u);
-#else
-  return lds_pos(elem_index<LOW, R>(tid + (u32)(g * T), (u32)k));
-#endif
 }
 template <int LOW, int R>
 __device__ __forceinline__ u32 pass_pos_base(u32 tid) { return lds_pos(elem_index<LOW, R>(tid, 0)); }

@@ -638,6 +638,11 @@ struct TableArena {
     cap = want;
     return true;
   }
+  // one arena per host thread (thread_local in run_plan): a thread that ends gives its pinned memory back.  Every
+  // run that staged a table drains its stream before it returns, so nothing on the device still reads the arena here.
+  ~TableArena() {
+    if (host) (void)hipHostFree(host);
+  }
 };
 
 size_t merge_max_batch() {
@@ -662,9 +667,9 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
   if (P.rc) return fail(P.rc, P.err.c_str());
   if (num_outputs_given != num_outputs()) return fail(kInvalidArg, "wrong number of output buffers");
   if (!batch) return fail(kInvalidArg, "empty batch");
-  // the table-driven kernels put (output, item) on grid z: beyond that many input sets per call the node-by-node executor, which
-  // chunks every operation, takes over (same bits)
-  if (batch > 32768) return run_serial(ev, batch, inputs, num_inputs, relin_key, galois_keys, outputs, num_outputs_given, s, err);
+  // the table-driven kernels put (output, item) on grid z: hipbfv_Program_Run hands over at most this many input sets per call
+  // (larger batches are a sequence of runs over offset pointers, capi.cpp)
+  if (batch > 32768) return fail(kInvalidArg, "more than 32768 input sets in one scheduled run");
   Context* ctx = ev.ctx();
   const DevCtx& h = ctx->host();
   const size_t n = ctx->n(), K = ctx->K();

@@ -373,6 +373,13 @@ def test_zero_plaintext_inside_a_transform_domain_sum_fails_like_multiply_plain(
         prog.run(ev, ins(), rkd)
     with pytest.raises(RuntimeError, match="transparent"):
         run_program(o, prog.nodes, prog.edges, [row_q[2]] + [c[2] for c in col_q] + [d[2] for d in db], rk)
+    # The same arguments ALREADY TRANSFORMED (TransformedPlaintext, kind 2): the executor no longer sees coefficients, so the
+    # producer is where a * 0 has to fail (it used to pass silently) -- and name the plaintext.
+    good = ev.plain_to_ntt(to_device(db[0]))
+    assert good.shape == (batch, ev.K, o.n)
+    with pytest.raises(HipBfvError, match="batch item 2"):
+        ev.plain_to_ntt(to_device(db[1]))
+    ev.check()  # the status word was reset by the failure: later operations start clean
 
 
 def test_add_and_sub_of_different_ciphertext_sizes():
