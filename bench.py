@@ -6,12 +6,15 @@ ciphertext pairs, n=8192, SEAL default 128-bit parameters (K=4 data primes + 1 s
 t = batching(8192,17) = 114689) -- BASELINE.json configs[2], the configuration the metric is quoted
 on.  Inputs are resident in HBM before the timed region.
 
-BASELINE.json's metric names three quantities ("mul+relin ops/sec at n=8192/16384; NTTs/sec").  The default run
-therefore times all three: the headline line is n=8192 and its `secondary` object carries the n=16384 mul+relin
-(batch/4 pairs, SEAL default K=8+1) and the configs[1] transform workload (forward+inverse NTT, n=8192, 3 primes,
-`--batch` polynomials), each with its own value, ms_per_step, roofline, cpu_baseline and parity gate, measured with the
-same --warmup in the same process (`--no-secondary` drops them; the NTT workload times at least 100 of its 0.73 ms steps).  `--workload ntt|chi_sq|dot_prod|pir|e2e`
-run one workload alone (the reference's example programs and the client-side steps; same JSON contract).
+BASELINE.json's metric names three quantities ("mul+relin ops/sec at n=8192/16384; NTTs/sec") and its `configs` list the
+reference's example programs.  The default run times all of them in one process: the headline line is n=8192 and its
+`secondary` object carries the n=16384 mul+relin (batch/4 pairs, SEAL default K=8+1), the configs[1] transform workload
+(forward+inverse NTT, n=8192, 3 primes), the north star's literal prime set (n=8192, 3 x 54-bit + special prime), and -- on one
+GPU -- examples/chi_sq at n=16384 (the 1024-input batch of configs[3] and one GPU's 128-set share of it), examples/dot_prod
+(256 sets) and examples/pir over 2^17 entries (512 x 256, 128 GiB in transform form), each with its own value, ms_per_step,
+repeats, roofline, cpu_baseline and parity gate (64 items / 8 input sets against the oracle), measured with the same --steps /
+--warmup / --repeats (`--no-secondary` drops them; the NTT workload times at least 100 of its 0.7 ms steps per region; the whole
+default run takes 2-3 minutes).  `--workload ntt|chi_sq|dot_prod|pir|e2e` run one workload alone (same JSON contract).
 
 The CPU oracle appears here in three roles only: client (it generates the keys and the few genuine encryptions the
 parity gate needs), checker (parity gate, after the timed region) and `cpu_baseline` (host cores, OpenMP over the
@@ -28,8 +31,9 @@ and `dist.reduce_ciphertexts` sums one ciphertext per GPU on rank 0 inside the t
 `--gpus N --dry-run` validates the launch environment and prints the per-rank shapes without touching a GPU.
 
 Timing: W warmup steps, then untimed steps for about `--settle-ms` (150 ms: the shader clock settles under the package power
-cap these kernels run at; the count is agreed between the ranks and reported as `settle_steps`), then EXACTLY K steps between
-two barriers.  At N = 1 an untimed leg after the measurement samples `rocm-smi` while the steps keep running (`power`:
+cap these kernels run at; the count is agreed between the ranks and reported as `settle_steps`), then `--repeats` R (5) timed
+regions of EXACTLY K steps each, every region between two barriers (+ torch.cuda.synchronize) and MAX-reduced over the ranks:
+`value` / `ms_per_step` are the MEDIAN region, `values` lists all R and `spread` = (slowest - fastest) / median.  At N = 1 an untimed leg after the measurement samples `rocm-smi` while the steps keep running (`power`:
 package watts, shader clock, cap; `--no-power` skips it).
 
 Prints ONE JSON line on rank 0.
@@ -72,6 +76,9 @@ def parse(argv=None):
                     "compiled `lookup` graph through hipbfv_Program_Run (the A/B arm; same bits)")
     ap.add_argument("--coeff-bits", default="", help="comma-separated prime sizes (CoeffModulus::create, last = special prime) instead of the "
                     "SEAL default set for --n, e.g. 54,54,54,56 for the 3 x 54-bit n=8192 variant BASELINE.json mentions")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each (every one between two barriers); value = the "
+                    "MEDIAN region, all of them are printed (`values`, `spread`): one box differs from the next by 2-3 %, a claim smaller than "
+                    "the spread of its own repeats is noise")
     ap.add_argument("--chunk", type=int, default=0, help="override the executor's chunk size (ops per launch group)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="ops in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -302,7 +309,14 @@ def setup(args) -> Env:
         sys.exit(f"bench.py rank {rank}: no GPU for LOCAL_RANK={local_rank} ({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible); "
                  f"--gpus {args.gpus} needs that many devices on this node")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # HIPBFV_BENCH_FORCE_DIST=1 (validation on a 1-GPU box, tests/test_gpu_dist.py): a process group of ONE rank is created and every
+    # collective of the N>1 path is issued on it -- the RCCL code path executes although no second GPU exists
+    force = world == 1 and os.environ.get("HIPBFV_BENCH_FORCE_DIST") == "1"
+    if force:
+        os.environ["HIPBFV_DIST_FORCE"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force:
         from sunscreen_amd.dist import init_timeout
 
         dist.init_process_group(os.environ.get("HIPBFV_BENCH_BACKEND", "nccl"), rank=rank, world_size=world, timeout=init_timeout())
@@ -317,10 +331,15 @@ def kernel_source_hash() -> str:
     the bench line are only valid for the kernels they were measured on (profiles/pmc_traffic.json records this hash)."""
     d = os.path.join(ROOT, "sunscreen_amd", "csrc")
     device_headers = ("devctx.hpp", "devarith.hpp", "griddot.hpp", "nttshape.hpp", "nttcore.hpp", "behzcore.hpp", "kernels.hpp", "rng.hpp")
-    names = sorted(f for f in os.listdir(d) if f.endswith(".hip") or f in device_headers or f in ("context.cpp", "evaluator.cpp"))
+    names = sorted(f for f in os.listdir(d) if f.endswith(".hip") or f in device_headers or f in ("context.cpp", "evaluator.cpp", "Makefile"))
     h = hashlib.sha256()
     for f in names:
         h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
+    # ... and the flag string the LOADED library was compiled with (hipbfv_build_flags: the Makefile's CXXFLAGS, or the -D set of a
+    # tools/build_variant.sh library selected through HIPBFV_LIB): a -DMID_EPT_14=8 build has the same sources and other kernels
+    from sunscreen_amd import _lib
+
+    h.update(b"flags\0" + _lib.build_flags().encode() + b"\0")
     return h.hexdigest()[:16]
 
 
@@ -338,6 +357,7 @@ def measure(args, env: Env, secondary: bool = False):
     from oracle import bfv_oracle as O
 
     rank, world, dev = env.rank, env.world, env.dev
+    collective = not D.solo()  # world > 1, or a forced single-rank group (HIPBFV_BENCH_FORCE_DIST)
     n = args.n
     primes = O.coeff_modulus_create(n, [int(b) for b in args.coeff_bits.split(",")]) if args.coeff_bits else O.bfv_default(n)
     pset = ("CoeffModulus::create(" + args.coeff_bits + ")") if args.coeff_bits else "SEAL default 128-bit"
@@ -550,32 +570,41 @@ def measure(args, env: Env, secondary: bool = False):
         torch.cuda.synchronize()
         per_step = max((time.perf_counter() - t_settle) / args.warmup, 1e-5)
         more = min(max(int(args.settle_ms * 1e-3 / per_step + 0.999) - args.warmup, 0), 100000)
-        if world > 1:
+        if collective:
             mt = torch.tensor([more], dtype=torch.int64, device=cdev)
             dist.all_reduce(mt, op=dist.ReduceOp.MAX)
             more = int(mt.item())
         for _ in range(more):
             step()
         settle_steps = args.warmup + more
+    # R timed regions of EXACTLY K steps each, every one bracketed by a barrier + torch.cuda.synchronize() on both sides and
+    # reduced with MAX over the ranks; the line reports the MEDIAN region (`values` lists them all).  The HIP-event kernel
+    # times accumulate over all R regions.
+    repeats = max(1, args.repeats)
+    regions = []
     barrier()
     ev.profile(True)
     ev.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        if collective:
+            tt = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        regions.append(el)
     prof = ev.profile_read()
     ev.profile(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = sorted(regions)[len(regions) // 2] if len(regions) % 2 else sum(sorted(regions)[len(regions) // 2 - 1 : len(regions) // 2 + 1]) / 2
 
     # ---- optional result gather (only if the consumer wants every result on one device), timed apart ----
     gather_ms = None
-    if args.gather and world > 1 and args.workload == "mulrelin":
+    if args.gather and collective and args.workload == "mulrelin":
         barrier()
         t0 = time.perf_counter()
         full = D.gather_results(out, total_items)
@@ -595,7 +624,7 @@ def measure(args, env: Env, secondary: bool = False):
         # (2) every output word is a canonical residue
         for i in range(K):
             ok = ok and int(out[:, :, i, :].max()) < primes[i] and int(out[:, :, i, :].min()) >= 0
-        if world > 1:
+        if collective:
             flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(int(flag.item()))
@@ -713,7 +742,7 @@ def measure(args, env: Env, secondary: bool = False):
         # SURVEY 8(d) ALGORITHMIC bytes: the per-unit compulsory figure x the units ONE launch of this kernel processes.
         # A unit is one op / program run / database entry (the dominant kernel sees this rank's units / launches of them per
         # launch); for the transform workload the unit is one single-residue transform = the kernel's own work unit.
-        units_per_launch = rec["units"] / rec["launches"] if args.workload == "ntt" else units_per_step * args.steps / rec["launches"]
+        units_per_launch = rec["units"] / rec["launches"] if args.workload == "ntt" else units_per_step * args.steps * repeats / rec["launches"]
         achieved = unit_bytes * units_per_launch / (avg_ms * 1e-3) / 1e9
         # measured HBM bytes per launch and VALU issue occupancy from the committed PMC profile of THIS workload
         # (FETCH_SIZE x2 + WRITE_SIZE, SQ_INSTS_VALU*, GRBM_GUI_ACTIVE in separate rocprofv3 --pmc passes:
@@ -782,6 +811,9 @@ def measure(args, env: Env, secondary: bool = False):
         "steps": args.steps,
         "warmup": args.warmup,
         "settle_steps": settle_steps,
+        "repeats": repeats,
+        "values": [round(total_units / r, 2) for r in regions],
+        "spread": round((max(regions) - min(regions)) / elapsed, 4),
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True,
         "scaling": scaling_of(args),
@@ -790,12 +822,13 @@ def measure(args, env: Env, secondary: bool = False):
         "data": "synthetic",
         "config": {"workload": workload, "batch_per_gpu": B, "poly_modulus_degree": n, "coeff_modulus_primes": KK,
                    "plain_modulus": t, "parallelism": (f"database rows sharded x{world}, one cross-GPU sum per query" if args.workload == "pir"
-                                                       else f"batch-sharded x{world}"), "chunk_ops": args.chunk or "auto"},
+                                                       else f"batch-sharded x{world}"), "chunk_ops": args.chunk or "auto",
+                   "collectives": (dist.get_backend() if collective else "none (single process, no process group)")},
         "roofline": roofline,
         "valu": valu,
         "whole_op_hbm": {"algorithmic_bytes_per_unit": unit_bytes, "achieved_GBps_per_gpu": round(op_rate_gbs, 1),
                          "frac_of_peak": round(op_rate_gbs / HBM_PEAK_GBS, 4)},
-        "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+        "kernels_ms_per_step": {k: round(v["ms"] / (args.steps * repeats), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         "kernel_units_per_launch": {k: v["units"] / v["launches"] for k, v in prof.items()},
         "cpu_baseline": cpu,
         "parity": parity,
@@ -826,8 +859,24 @@ def main():
     headline = args.workload == "mulrelin" and args.n == 8192 and not args.coeff_bits and not args.chunk
     if headline and not args.no_secondary:
         second = {}
-        for key, over in (("mulrelin_n16384", dict(n=16384, batch=max(args.batch // 4, 1), total_batch=args.total_batch // 4, check_items=16)),
-                          ("ntt_n8192", dict(workload="ntt", steps=max(args.steps, 100)))):  # a step is 0.85 ms: time at least 85 ms
+        q4 = max(args.batch // 4, 1)
+        jobs = [
+            # the other two quantities of the metric
+            ("mulrelin_n16384", dict(n=16384, batch=q4, total_batch=args.total_batch // 4)),
+            ("ntt_n8192", dict(workload="ntt", steps=max(args.steps, 100))),  # a step is 0.7 ms: time at least 70 ms per region
+            # the north star's literal prime set ("n=8192, 3 x 54-bit RNS primes")
+            ("mulrelin_n8192_bits54-54-54-56", dict(coeff_bits="54,54,54,56")),
+        ]
+        if env.world == 1 and not args.total_batch:
+            # BASELINE.json configs[3], [4]: the reference's example programs at n = 16384 (single-GPU forms; the sharded forms are
+            # `--workload chi_sq --total-batch 1024 --gpus 8` and `--workload pir --n 16384 --batch 1024 --gpus 8`)
+            jobs += [
+                ("chi_sq_n16384", dict(workload="chi_sq", n=16384, batch=q4)),                       # configs[3]: the 1024-input batch
+                ("chi_sq_n16384_share128", dict(workload="chi_sq", n=16384, batch=max(q4 // 8, 1), no_cpu=True)),  # ... one GPU's share of it on 8
+                ("dot_prod_n16384", dict(workload="dot_prod", n=16384, batch=max(q4 // 4, 1))),
+                ("pir_n16384_2p17", dict(workload="pir", n=16384, batch=max(q4 // 4, 1), pir_rows=max(q4 // 2, 1))),  # 512 x 256 = 2^17 entries, 128 GiB
+            ]
+        for key, over in jobs:
             sub = copy.copy(args)
             for k, v in over.items():
                 setattr(sub, k, v)
@@ -837,13 +886,13 @@ def main():
             torch.cuda.empty_cache()
             rec = measure(sub, env, secondary=True)
             if rec is not None:
-                second[key] = {k: rec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "config", "roofline", "valu",
-                                                   "kernels_ms_per_step", "cpu_baseline", "parity")}
+                second[key] = {k: rec[k] for k in ("metric", "value", "unit", "steps", "warmup", "repeats", "values", "spread", "ms_per_step", "scaling", "config",
+                                                   "roofline", "valu", "kernels_ms_per_step", "cpu_baseline", "parity")}
         if line is not None:
             line["secondary"] = second
     if line is not None:
         print(json.dumps(line))
-    if env.world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -234,6 +234,7 @@ long Evaluator_ModSwitchToNext2(void *thisptr, void *plain, void *destination);
 /* Library / device */
 long hipbfv_version(uint32_t *major, uint32_t *minor);
 long hipbfv_last_error(char *buffer, uint64_t capacity);       /* thread-local message of the last failure */
+long hipbfv_build_flags(char *buffer, uint64_t capacity);      /* compiler flags (-D set included) this library was built with */
 long hipbfv_set_device(int device);                            /* HIP device used by contexts created afterwards */
 /* SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT switch (seal_fhe `transparent-ciphertexts` feature): default on */
 long hipbfv_set_throw_on_transparent(bool enabled);

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "Evaluator_RotateColumns": [vp, vp, vp, vp, vp],
     "hipbfv_version": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
     "hipbfv_last_error": [C.c_char_p, u64],
+    "hipbfv_build_flags": [C.c_char_p, u64],
     "hipbfv_set_device": [C.c_int],
     "hipbfv_set_throw_on_transparent": [C.c_bool],
     "hipbfv_Context_Create": [u64, u64p, u64, u64, vpp],
@@ -220,6 +221,13 @@ def load() -> C.CDLL:
         fn.restype = C.c_long
     _lib = lib
     return lib
+
+
+def build_flags() -> str:
+    """The compiler flags (macro definitions included) the loaded libhipbfv.so was built with."""
+    buf = C.create_string_buffer(2048)
+    load().hipbfv_build_flags(buf, 2048)
+    return buf.value.decode(errors="replace")
 
 
 def last_error() -> str:

@@ -623,6 +623,21 @@ long hipbfv_version(uint32_t* major, uint32_t* minor) HIPBFV_BEGIN
   return HIPBFV_S_OK;
 HIPBFV_END
 
+// The macro definitions this library was compiled with (the Makefile and tools/build_variant.sh hand every translation unit
+// their own flag string): bench.py folds it into the kernel-source hash that guards the committed PMC figures, so numbers taken
+// on a default build are never printed beside a -D variant's timings.
+#ifndef HIPBFV_BUILD_FLAGS
+#define HIPBFV_BUILD_FLAGS "unknown"
+#endif
+long hipbfv_build_flags(char* buffer, uint64_t capacity) HIPBFV_BEGIN
+  if (!buffer || !capacity) return HIPBFV_E_POINTER;
+  const char* flags = HIPBFV_BUILD_FLAGS;
+  const size_t c = std::min<size_t>(std::strlen(flags), capacity - 1);
+  std::memcpy(buffer, flags, c);
+  buffer[c] = 0;
+  return HIPBFV_S_OK;
+HIPBFV_END
+
 long hipbfv_last_error(char* buffer, uint64_t capacity) HIPBFV_BEGIN
   if (!buffer || capacity == 0) return HIPBFV_E_POINTER;
   std::strncpy(buffer, tls_error.c_str(), capacity - 1);

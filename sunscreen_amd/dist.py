@@ -31,8 +31,9 @@ def init(backend: str | None = None) -> tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("HIPBFV_DIST_FORCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world, timeout=init_timeout())
     return rank, local_rank, world
@@ -48,10 +49,20 @@ def is_nccl() -> bool:
     return dist.is_initialized() and dist.get_backend() == "nccl"
 
 
+def solo() -> bool:
+    """True when no collective needs to be issued: no process group, or a group of ONE rank.  HIPBFV_DIST_FORCE=1 makes a
+    single-rank group issue every collective anyway -- the way a 1-GPU box executes the RCCL code path of this module
+    (tests/test_gpu_dist.py; a world of one is a complete, if trivial, communicator: broadcasts, gathers and all-reduces go
+    through librccl and complete on the device)."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("HIPBFV_DIST_FORCE") != "1"
+
+
 def barrier() -> None:
     """dist.barrier on the device this rank drives: under RCCL the barrier is an all-reduce on a device tensor, and
     without `device_ids` torch guesses the device from the global rank (wrong whenever LOCAL_RANK != RANK % devices)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if solo():
         return
     if is_nccl():
         dist.barrier(device_ids=[torch.cuda.current_device()])
@@ -78,7 +89,7 @@ def timed_steps(step: Callable[[], None], steps: int, warmup: int, device: str |
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier_sync()
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not solo():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -94,7 +105,7 @@ def gather_results(local: torch.Tensor, total: int, root: int = 0) -> torch.Tens
     """Gather per-rank result blocks (shard_range order) on `root`: int64[total, ...] there, None elsewhere (SURVEY 8e:
     a `gather` to the consumer's device, point-to-point over the 7 xGMI links at once -- not an all_gather, nobody else
     needs the copy).  Blocks may differ in length by one item, so they are padded to a common length."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if solo():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     longest = max(shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world))
@@ -119,7 +130,7 @@ def reduce_ciphertexts(local: torch.Tensor, add: Callable[[torch.Tensor, torch.T
     all-reduce: the sum is modulo a different prime per residue row, which RCCL's reductions cannot express, and only the
     root needs it (world x 2 MiB at n = 16384, point-to-point).  Returns the sum on `root`, None elsewhere; modular
     addition of canonical residues is associative and commutative, so the bits do not depend on the rank order."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if solo():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     send = _via(local.contiguous())
@@ -135,7 +146,7 @@ def reduce_ciphertexts(local: torch.Tensor, add: Callable[[torch.Tensor, torch.T
 
 def broadcast_tensor(t: torch.Tensor | None, shape, dtype, device, src: int = 0) -> torch.Tensor:
     """One tensor from `src` to every rank (the client's query ciphertexts reaching every database shard)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if solo():
         assert t is not None
         return t
     if dist.get_rank() != src:
@@ -154,7 +165,7 @@ def broadcast_bytes(data: bytes | None, src: int = 0, device: str | torch.device
     rank `src` passes the bytes, every other rank passes None; all ranks return the same bytes.  Two collectives (length,
     payload); over RCCL the payload travels as uint8 tensors on `device`, in messages of at most 256 MiB (the 486 MB Galois
     key set of n = 16384 is two of them)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if solo():
         assert data is not None
         return data
     rank = dist.get_rank()
@@ -174,7 +185,9 @@ def replicate_keys(ctx, key, cls, src: int = 0, device: str | torch.device = "cp
     """The key owner (rank `src`) holds `key` (a sunscreen_amd.seal RelinearizationKeys / GaloisKeys / PublicKey object);
     every rank returns a device-resident copy, made from the SEAL wire format (uncompressed: the bytes cross xGMI once,
     zstd would cost more host time than the transfer).  Evaluation then needs no further communication."""
-    blob = broadcast_bytes(key.as_bytes(compression=0) if (not dist.is_initialized() or dist.get_rank() == src) else None, src, device)
-    if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_rank() != src:
+    if solo():
+        return key
+    blob = broadcast_bytes(key.as_bytes(compression=0) if dist.get_rank() == src else None, src, device)
+    if dist.get_rank() != src:
         return cls.from_bytes(ctx, blob)
     return key

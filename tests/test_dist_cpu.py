@@ -97,3 +97,46 @@ def test_two_rank_gloo_timing_and_gather(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_a_single_rank_group_issues_its_collectives_when_forced(tmp_path):
+    """HIPBFV_DIST_FORCE=1 (how tests/test_gpu_dist.py runs the RCCL path on a one-GPU box): a process group of one rank is not
+    short-circuited -- the collectives are issued (here over gloo) and return the payloads unchanged; without the variable the
+    module does not touch torch.distributed at world_size 1."""
+    script = tmp_path / "solo.py"
+    script.write_text(
+        textwrap.dedent(
+            """
+            import os, sys
+            sys.path.insert(0, %r)
+            import torch, torch.distributed as dist
+            from sunscreen_amd import dist as D
+            assert D.solo()                      # no process group yet
+            rank, local_rank, world = D.init("gloo")
+            assert world == 1 and dist.is_initialized() and not D.solo() and not D.is_nccl()
+            calls = {"n": 0}
+            real = dist.broadcast
+            def counting(*a, **k):
+                calls["n"] += 1
+                return real(*a, **k)
+            dist.broadcast = counting
+            blob = bytes(range(200)) * 50
+            assert D.broadcast_bytes(blob, 0) == blob and calls["n"] == 2      # length + one payload message
+            t = torch.arange(12, dtype=torch.int64).reshape(3, 2, 2)
+            assert torch.equal(D.broadcast_tensor(t, t.shape, t.dtype, "cpu", 0), t) and calls["n"] == 3
+            assert torch.equal(D.gather_results(t, 3), t)
+            assert torch.equal(D.reduce_ciphertexts(t, lambda a, b: a + b), t)
+            D.barrier()
+            assert D.timed_steps(lambda: None, 2, 1) >= 0.0
+            os.environ.pop("HIPBFV_DIST_FORCE")
+            assert D.solo()                      # the default: a world of one needs no collective
+            dist.destroy_process_group()
+            print("SOLO_OK")
+            """
+            % ROOT
+        )
+    )
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", HIPBFV_DIST_FORCE="1")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "SOLO_OK" in p.stdout, p.stderr[-2000:]
