@@ -721,6 +721,10 @@ def measure(args, env: Env, secondary: bool = False):
         # algorithmic bytes of one launch of that kernel
         S_, R_ = ctx_S(ctx), K + ctx_S(ctx)
         bm, bk = (6 if getattr(ctx, "packed_mul", False) else 8), (6 if getattr(ctx, "packed_ks", False) else 8)
+        if getattr(ctx, "packed_mul_rows", False):
+            # per-row packing (N = 16384 default set: 13 of 18 rows travel as 6 bytes): the average bytes per value over the K + S rows
+            rows_ = list(primes[:K]) + list(ctx.aux_primes)
+            bm = sum(6 if p < (1 << 48) else 8 for p in rows_) / len(rows_)
         per_unit = {
             # whole-polynomial path (kernels.hip)
             "ntt_fwd": 16 * n, "ntt_inv": 16 * n,                    # per residue polynomial: read + write

@@ -627,14 +627,6 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     h.conv_magic = magic;
   }
 
-  h.mid_nd = h.mid_ni = 0;
-  for (u32 r = 0; r < K + h.S; r++) {
-    const u32 m = r < K ? r : KK + (r - K);
-    if (h.mod[m].use_f64 && h.mod[m].split_ok)
-      h.mid_res_d[h.mid_nd++] = (unsigned char)r;
-    else
-      h.mid_res_i[h.mid_ni++] = (unsigned char)r;
-  }
 
   // key switching: a key prime takes the FP64 policy when its split range plan exists, the integer policy when its
   // twiddle tables are Shoup pairs (use_f64 == 0); an FP64-table prime WITHOUT a split plan has neither form
@@ -667,6 +659,37 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     }
     h.pack_ks = ks ? 1 : 0;
     h.pack_mul = mul ? 1 : 0;
+    // r04, per-row packing of the multiply's intermediates: every row FP64-policy and every AUXILIARY
+    // prime below 2^48 (the library's own base always is); data rows pack when their prime is below 2^48.  The 8-prime head /
+    // tail instantiations take the per-row flags (kneed > 4).  OPT-IN (HIPBFV_PACK_ROWS=1), because it measured SLOWER on the
+    // configuration it was built for -- n = 16384, SEAL default primes, 13 of 18 rows packed, interleaved A/B on one box
+    // (profiles/r04_pack_rows_ab.txt): mul_mid 5.72 -> 5.54 ms per 1024 ops, but mul_head 2.69 -> 2.83, the fused key-switch
+    // head 2.29 -> 2.58 and tail 3.16 -> 3.26: 54.95 K -> 54.3 K mul+relin/s (chi_sq 9.52 K -> 9.39 K programs/s).  The rows that
+    // pack save 25 % of their bytes and cost a reduction + pack per stored value and a second load + unpack per loaded one; at
+    // this size the head / tail kernels run 2 waves per SIMD and are bound by their instruction streams, not by HBM.
+    const u32 kneed = std::max(K, h.S > 2 ? h.S - 2 : 0u);
+    bool part = !mul && h.aux_f64 != 0 && h.logn >= 13 && kneed > 4;
+    for (u32 r = 0; r < K + h.S && part; r++) {
+      const DevMod& dm = h.mod[r < K ? r : KK + (r - K)];
+      part = dm.use_f64 && dm.split_ok && (r < K || dm.q < lim);
+    }
+    if (const char* env = std::getenv("HIPBFV_NO_PACK"))
+      if (env[0] == '1' || env[0] == 'm') part = false;
+    const char* rows_env = std::getenv("HIPBFV_PACK_ROWS");
+    if (part && rows_env && rows_env[0] == '1') h.pack_mul = 2;  // (the auxiliary rows alone are S of the K + S rows)
+  }
+  h.mid_nd = h.mid_ndp = h.mid_ni = 0;
+  for (u32 r = 0; r < K + h.S; r++) {
+    const u32 m = r < K ? r : KK + (r - K);
+    h.mul_row_packed[r] = (h.pack_mul == 1 || (h.pack_mul == 2 && h.mod[m].q < (1ull << 48))) ? 1 : 0;
+    if (h.mod[m].use_f64 && h.mod[m].split_ok) {
+      if (h.mul_row_packed[r])
+        h.mid_res_dp[h.mid_ndp++] = (unsigned char)r;
+      else
+        h.mid_res_d[h.mid_nd++] = (unsigned char)r;
+    } else {
+      h.mid_res_i[h.mid_ni++] = (unsigned char)r;
+    }
   }
 
   // ---- key switching ----

@@ -98,6 +98,9 @@ struct DevCtx {
   u32 aux_mixed;
   // 48-bit packed intermediates in the split pipelines (kernels_split.hip nat_load/nat_store): every modulus involved is an
   // FP64-policy prime below 2^48.  pack_ks: the KK key primes; pack_mul: aux_f64 and the K data + S auxiliary primes.
+  // pack_mul == 2 (r04): PER ROW -- every auxiliary prime is below 2^48 and some data primes are (the SEAL default set of
+  // N = 16384 has three 48-bit and five 49-bit data primes beside ten 45-bit auxiliary primes: 13 of 18 rows travel as 6 bytes);
+  // mul_row_packed[r] says which rows of ext / D (r < K: data prime r, else auxiliary prime r - K)
   unsigned char pack_ks, pack_mul, pad3[2];
   MulOpD ext_scale_d[kMaxKey];
   double q_to_bsk_d[kMaxBsk][kMaxKey];
@@ -117,10 +120,13 @@ struct DevCtx {
   u32 conv_grid;
   u32 pad4;
 
-  // split multiply: residue indices (0..K+S-1) handled by the FP64 / integer middle kernel
+  // split multiply: residue indices (0..K+S-1) handled by the FP64 middle kernel with 8-byte rows (mid_res_d), with 48-bit packed
+  // rows (mid_res_dp) and by the integer middle kernel (mid_res_i)
   unsigned char mid_res_d[kMaxMod];
+  unsigned char mid_res_dp[kMaxMod];
   unsigned char mid_res_i[kMaxMod];
-  u32 mid_nd, mid_ni;
+  unsigned char mul_row_packed[kMaxMod];
+  u32 mid_nd, mid_ndp, mid_ni, pad6;
   // split key switch: key-prime indices (0..KK-1) handled by the FP64 / integer middle kernel; ks_split_ok: every key prime
   // has a policy the split kernels implement (FP64 with a split range plan, or integer with Shoup twiddle tables)
   unsigned char ks_res_d[kMaxKey + 3];

@@ -290,9 +290,9 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
     const size_t c = std::min(chunk, count - off);
     if (split) {
       // head / middle / tail split transforms (kernels_split.hip): 3 launches instead of 5, 40 % less HBM traffic
-      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, h.aux_f64 != 0, h.aux_f64 ? h.pack_mul != 0 : h.aux_mixed != 0, kneed, a + off * 2 * K * n, b + off * 2 * K * n, ext, c, s, square ? 2u : 4u));
-      HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_mul != 0, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
-      HB_LAUNCH(kKernMulTail, c * 3, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, h.aux_f64 != 0, h.aux_f64 ? h.pack_mul != 0 : h.aux_mixed != 0, h.conv_grid != 0, kneed, D, out + off * 3 * K * n, c, s));
+      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, h.aux_f64 != 0, h.aux_f64 ? (int)h.pack_mul : (h.aux_mixed ? 1 : 0), kneed, a + off * 2 * K * n, b + off * 2 * K * n, ext, c, s, square ? 2u : 4u));
+      HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_dp, h.mid_ndp, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
+      HB_LAUNCH(kKernMulTail, c * 3, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, h.aux_f64 != 0, h.aux_f64 ? (int)h.pack_mul : (h.aux_mixed ? 1 : 0), h.conv_grid != 0, kneed, D, out + off * 3 * K * n, c, s));
       continue;
     }
     HB_LAUNCH(kKernBehzExtend, c * (sa + sb), launch_behz_extend(ctx_->dev(), n, kneed, a + off * sa * K * n, sa, b + off * sb * K * n, sb, c, ext, s));
@@ -382,16 +382,16 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
     u64* C2 = ACC + cc * acc_words;
     for (size_t off = 0; off < count; off += chunk) {
       const size_t c = std::min(chunk, count - off);
-      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, h.pack_mul != 0, kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u));
-      HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_mul != 0, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
+      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, (int)h.pack_mul, kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u));
+      HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_dp, h.mid_ndp, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
       if (fuse_head_) {
-        HB_LAUNCH(kKernKsHead, c, launch_mulrelin_head(ctx_->dev(), h.tw_inv, h.tw_fwd, h.logn, h.pack_mul != 0, h.conv_grid != 0, h.pack_ks != 0, kneed, D, T, c, s));
+        HB_LAUNCH(kKernKsHead, c, launch_mulrelin_head(ctx_->dev(), h.tw_inv, h.tw_fwd, h.logn, (int)h.pack_mul, h.conv_grid != 0, h.pack_ks != 0, kneed, D, T, c, s));
       } else {
-        HB_LAUNCH(kKernMulTail, c, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, true, h.pack_mul != 0, h.conv_grid != 0, kneed, D, C2, c, s, 2, 1));
+        HB_LAUNCH(kKernMulTail, c, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, true, (int)h.pack_mul, h.conv_grid != 0, kneed, D, C2, c, s, 2, 1));
         HB_LAUNCH(kKernKsHead, c, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, false, K, C2, c2_words, T, c, s));
       }
       HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, rk, ACC, c, s));
-      HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail(ctx_->dev(), h.tw_inv, h.logn, h.pack_mul != 0, h.conv_grid != 0, h.pack_ks != 0, kneed, D, ACC,
+      HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail(ctx_->dev(), h.tw_inv, h.logn, (int)h.pack_mul, h.conv_grid != 0, h.pack_ks != 0, kneed, D, ACC,
                                                     addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s));
     }
     return note_result(out2, 2, K, count, s);

@@ -49,15 +49,15 @@ hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, 
 hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
                           size_t ops, hipStream_t s);
 // split BEHZ multiply (2 x 2 -> 3), K <= 4
-hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
+hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, int pack, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
                            hipStream_t s, u32 npolys = 4);
-hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd,
+hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, const unsigned char* res_dp, u32 ndp, const unsigned char* res_d, u32 nd,
                           const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s, bool square = false);
-hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, bool pack, bool conv_grid, u32 kneed, const u64* D, u64* out,
+hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, int pack, bool conv_grid, u32 kneed, const u64* D, u64* out,
                            size_t ops, hipStream_t s, u32 poly0 = 0, u32 npolys = 3);
-hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed,
+hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed,
                                 const u64* D, u64* T, size_t ops, hipStream_t s);
-hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
+hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
                                 const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s);
 hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out,
                              size_t ops, hipStream_t s);

@@ -460,10 +460,11 @@ constexpr int kHeadThreads = 256;
 // MODE 3, last forward round: the first MID3_PARK values of the waiting partial product a0 b1 sit in thread-private LDS slots
 // behind the two exchange regions while a1 is transformed.  r03 left them to the register allocator, which spilt 22 dwords per
 // lane to scratch -- written once, read once, and visible in the PMC passes as 1.6 MB of writes and 1.7 MB of reads per op over
-// the kernel's own model (72 workgroups x 256 lanes x 88 bytes).  6 values: 252 registers, no scratch, 76 KB of LDS per
-// workgroup (two resident per CU); 4 leave 24 bytes of scratch, 8 need the full 80 KB.
+// the kernel's own model (72 workgroups x 256 lanes x 88 bytes).  8 values: 240 registers (254 with 48-bit packed rows), no
+// scratch, 80 KB of LDS per workgroup -- two are resident per CU (measured: 6 values / 76 KB and 8 / 80 KB run the same 5.76-5.79
+// ms per 1024 ops against 6.10-6.13 with the scratch; 6 leave the packed-row instantiation 24 bytes of scratch, 4 leave both some).
 #ifndef MID3_PARK
-#define MID3_PARK 6
+#define MID3_PARK 8
 #endif
 #ifndef MID_TW_PIPE  // mul_mid (pass-batched bodies): next pass's twiddles fetched before the exchange (a second set of twiddle registers)
 #define MID_TW_PIPE(L) true
@@ -1165,7 +1166,9 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 // mul head: grid (N/8/256, 4 polys (a0,a1,b0,b1), ops); ext = [ops][4][K+S][N] in native representation
 // AUXD (DevCtx::aux_f64): every residue, auxiliary base included, takes the FP64 policy and the base extension
 // itself runs in FP64 (behz_extend_coeff_d).
-template <int L, int KMAX, bool AUXD, bool PACK>
+// PACK (all-FP64 instantiations): 0 = 8-byte rows, 1 = every row 48-bit packed, 2 = per row (DevCtx::mul_row_packed for the data
+// rows -- a wave-uniform branch -- and every auxiliary row packed)
+template <int L, int KMAX, bool AUXD, int PACK>
 __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1)) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
                                                                 u64* __restrict__ ext) {
@@ -1194,11 +1197,14 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
         for (int k = 0; k < NC; k++) v[k] = x[i][k];
         head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(twf_base + (size_t)i * N), t);
         double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
-        if constexpr (PACK) {
+        const bool packed = PACK == 1 || (PACK == 2 && ctx->mul_row_packed[i] != 0);
+        if (packed) {
 #pragma unroll
           for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
+          nat_store_head<L, true, NtSites<L>::head_st>(o, t, v);
+        } else {
+          nat_store_head<L, false, NtSites<L>::head_st>(o, t, v);
         }
-        nat_store_head<L, PACK, NtSites<L>::head_st>(o, t, v);
       }
     }
     // auxiliary base: extend all eight owned coefficients residue by residue (every conversion constant is
@@ -1207,11 +1213,11 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
       const ArithD ar(ctx->mod[KK + j]);
       head_fwd_owned<ArithD, L>(ar, ev, reinterpret_cast<const double*>(twf_base + (size_t)(KK + j) * N), t);
       double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
-      if constexpr (PACK) {
+      if constexpr (PACK != 0) {
 #pragma unroll
         for (int k = 0; k < NC; k++) ev[k] = ar.reduce(ev[k]);
       }
-      nat_store_head<L, PACK, NtSites<L>::head_st>(o, t, ev);
+      nat_store_head<L, (PACK != 0), NtSites<L>::head_st>(o, t, ev);
     });
     return;
   }
@@ -1583,11 +1589,14 @@ __device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const NatRaw
 // All-FP64 tail of the BEHZ multiply for the 4 coefficients {t + k*N/4} of ONE output polynomial: last two inverse stages of
 // every residue, scaling, fast_floor + Shenoy-Kumaresan conversion (behz_floor_sk_multi_d): canonical data residues in res.
 // d: the polynomial's R residue rows in D (not offset by t); thread t owns the coefficients EdgeGeom<L>::tail_out(t, k).
-template <int L, int KMAX, bool PACK, bool GRID>
+// PACK: 0 / 1 / 2 as in mul_head_kernel (2: the data rows' representation is DevCtx::mul_row_packed, the auxiliary rows are packed)
+template <int L, int KMAX, int PACK, bool GRID>
 __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base, const u64* __restrict__ d, u32 t,
                                                    u64 (&res)[KMAX][4]) {
   using G = EdgeGeom<L>;
   constexpr u32 N = 1u << L;
+  constexpr bool PD = PACK == 1;  // data rows, when the choice is static
+  constexpr bool PA = PACK != 0;  // auxiliary rows
   const u32 K = ctx->K, KK = ctx->KK;
     double yc[KMAX][4];
 #pragma unroll
@@ -1595,30 +1604,38 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
     if ((u32)i < K) {
       const DevMod& dm = ctx->mod[i];
       const ArithD ar(dm);
+      const double* row = reinterpret_cast<const double*>(d + (size_t)i * N);
       double r4[4];
-      NatRaw<PACK> raw[4];
+      if (PACK == 2 && ctx->mul_row_packed[i] != 0) {  // wave-uniform
+        NatRaw<true> raw[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d + (size_t)i * N), N, G::tail_in(t, k));
-      tail_inv4_scale_d<L, PACK>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<true, NtSites<L>::tail_ld>(row, N, G::tail_in(t, k));
+        tail_inv4_scale_d<L, true>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+      } else {
+        NatRaw<PD> raw[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PD, NtSites<L>::tail_ld>(row, N, G::tail_in(t, k));
+        tail_inv4_scale_d<L, PD>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
     }
   }
-  behz_floor_sk_multi_d<KMAX, 4, GRID, NatRaw<PACK>>(
+  behz_floor_sk_multi_d<KMAX, 4, GRID, NatRaw<PA>>(
       ctx, yc,
-      [&](u32 j, NatRaw<PACK>(&raw)[4]) {
+      [&](u32 j, NatRaw<PA>(&raw)[4]) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d + (size_t)(K + j) * N), N, G::tail_in(t, k));
+        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PA, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d + (size_t)(K + j) * N), N, G::tail_in(t, k));
       },
-      [&](u32 j, const NatRaw<PACK>(&raw)[4], double(&xb)[4]) {
+      [&](u32 j, const NatRaw<PA>(&raw)[4], double(&xb)[4]) {
         const DevMod& dm = ctx->mod[KK + j];
-        tail_inv4_scale_d<L, PACK>(ArithD(dm), raw, reinterpret_cast<const double*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j],
+        tail_inv4_scale_d<L, PA>(ArithD(dm), raw, reinterpret_cast<const double*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j],
                                    dm.split_inv_mask, t, xb);
       },
       res);
 }
 
-template <int L, int KMAX, bool AUXD, bool PACK, bool GRID>
+template <int L, int KMAX, bool AUXD, int PACK, bool GRID>
 // poly0 / out_polys: the launch covers product polynomials poly0 .. poly0 + gridDim.y - 1 and writes them to
 // out[op][out_polys][K][N] (3 polynomials from 0 for a stand-alone multiply; only c2, compactly, in the fused
 // multiply + relinearize, whose last kernel forms c0 and c1 itself: mulrelin_tail_kernel)
@@ -1733,7 +1750,7 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
 // moves at N = 8192).  Thread t of polynomial c owns the same coefficients {t + k*N/4} in both halves.  All-FP64 contexts
 // only (the SEAL default parameter sets).  grid: (N/4/256, 2, ops)
 // -------------------------------------------------------------------------------------------------
-template <int L, int KMAX, bool PACKM, bool GRID, bool PACKK>
+template <int L, int KMAX, int PACKM, bool GRID, bool PACKK>
 __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                      const u64* __restrict__ D, const double* __restrict__ ACC,
                                                                      const u64* __restrict__ extra, u64* __restrict__ out) {
@@ -1790,7 +1807,7 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
 // into x[J][k]; then, per digit J and key prime I, the conversion and the first forward stages exactly as ks_head_kernel.
 // All-FP64 contexts only.  grid: (N/NC/256, 1, ops)
 // -------------------------------------------------------------------------------------------------
-template <int L, int KMAX, bool PACKM, bool GRID, bool PACKK>
+template <int L, int KMAX, int PACKM, bool GRID, bool PACKK>
 __global__ EDGE_BOUNDS(KMAX) void mulrelin_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                      const MulOp* __restrict__ twf_base, const u64* __restrict__ D,
                                                                      double* __restrict__ T) {
@@ -2076,134 +2093,137 @@ hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pa
 }
 
 template <int L>
-static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
+static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, int pack, u32 kneed, const u64* a, const u64* b, u64* ext,
                              size_t ops, u32 npolys, hipStream_t s) {
   const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, npolys, (unsigned)ops);
   if (kneed > 4) {  // only the all-FP64 instantiation exists for 5..8 data primes (evaluator.cpp checks)
-    if (pack)
-      mul_head_kernel<L, 8, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+    if (pack == 2)
+      mul_head_kernel<L, 8, true, 2><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+    else if (pack)
+      mul_head_kernel<L, 8, true, 1><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
     else
-      mul_head_kernel<L, 8, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 8, true, 0><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   } else if (aux_f64) {
+    if (pack == 2) return hipErrorInvalidValue;  // per-row packing exists in the 8-prime instantiations (context.cpp)
     if (pack)
-      mul_head_kernel<L, 4, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 4, true, 1><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
     else
-      mul_head_kernel<L, 4, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 4, true, 0><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   } else if (pack) {  // mixed base: integer data primes, FP64 auxiliary primes (DevCtx::aux_mixed)
-    mul_head_kernel<L, 4, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+    mul_head_kernel<L, 4, false, 1><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   } else {
-    mul_head_kernel<L, 4, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+    mul_head_kernel<L, 4, false, 0><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
   }
   return hipGetLastError();
 }
 // aux_f64: DevCtx::aux_f64 of the context behind `ctx` (selects the all-FP64 instantiation)
 // kneed: max(data primes, auxiliary primes - 2) -- selects the 4- or 8-prime instantiation
-// pack: DevCtx::pack_mul with aux_f64; WITHOUT aux_f64 it selects the mixed-base instantiation (DevCtx::aux_mixed)
+// pack: DevCtx::pack_mul (0 / 1 / 2) with aux_f64; WITHOUT aux_f64, non-zero selects the mixed-base instantiation (DevCtx::aux_mixed)
 // npolys: 4 = (a0, a1, b0, b1); 2 = the first operand only (squaring: ext polys 2, 3 stay unwritten and unread)
-hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, bool pack, u32 kneed, const u64* a, const u64* b, u64* ext,
+hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, int pack, u32 kneed, const u64* a, const u64* b, u64* ext,
                            size_t ops, hipStream_t s, u32 npolys) {
   SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack, kneed, a, b, ext, ops, npolys, s)
 }
 
 template <int L>
-static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
+static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, const unsigned char* res_dp, u32 ndp, const unsigned char* res_d, u32 nd,
                             const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, bool square, hipStream_t s) {
   using Sh = SplitShape<L>;
   const size_t ops_g = MUL_MID_SLICE(L) ? (ops + 7) / 8 * 8 : ops;  // the slice-major order deals whole groups of 8 ops to the XCDs
   constexpr unsigned TDP = MulMidGeom<L, true, false, true>::TPB, TD = MulMidGeom<L, true, false, false>::TPB, TI = MulMidGeom<L, false>::TPB;
   if (square) {
     constexpr unsigned TSP = MulMidGeom<L, true, true, true>::TPB, TS = MulMidGeom<L, true, true, false>::TPB;
-    if (nd && pack) mul_mid_kernel<L, true, true, true><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TSP, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
-    if (nd && !pack) mul_mid_kernel<L, true, false, true><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TS, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
+    if (ndp) mul_mid_kernel<L, true, true, true><<<dim3((unsigned)(ops_g * ndp * Sh::NBLK)), TSP, 0, s>>>(ctx, twf, twi, ext, D, res_dp, ndp, (u32)ops);
+    if (nd) mul_mid_kernel<L, true, false, true><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TS, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
     if (ni) mul_mid_kernel<L, false, false, true><<<dim3((unsigned)(ops_g * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni, (u32)ops);
     return hipGetLastError();
   }
-  if (nd && pack) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TDP, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
-  if (nd && !pack) mul_mid_kernel<L, true, false><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
+  if (ndp) mul_mid_kernel<L, true, true><<<dim3((unsigned)(ops_g * ndp * Sh::NBLK)), TDP, 0, s>>>(ctx, twf, twi, ext, D, res_dp, ndp, (u32)ops);
+  if (nd) mul_mid_kernel<L, true, false><<<dim3((unsigned)(ops_g * nd * Sh::NBLK)), TD, 0, s>>>(ctx, twf, twi, ext, D, res_d, nd, (u32)ops);
   if (ni) mul_mid_kernel<L, false, false><<<dim3((unsigned)(ops_g * ni * Sh::NBLK)), TI, 0, s>>>(ctx, twf, twi, ext, D, res_i, ni, (u32)ops);
   return hipGetLastError();
 }
-// res_d / res_i: device arrays listing the residue indices (0..R-1) handled by the FP64 / integer instantiation
+// res_dp / res_d / res_i: device arrays listing the residue indices (0..R-1) handled by the FP64 instantiation with 48-bit packed
+// rows, by the FP64 instantiation with 8-byte rows and by the integer instantiation (DevCtx::mid_res_*)
 // square: the operands are one ciphertext -- ext holds polys 0, 1 only (launch_mul_head with npolys = 2)
-hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd,
+hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, const unsigned char* res_dp, u32 ndp, const unsigned char* res_d, u32 nd,
                           const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s, bool square) {
-  SPLIT_DISPATCH(mul_mid_t, ctx, twf, twi, pack && ni == 0, res_d, nd, res_i, ni, ext, D, ops, square, s)
+  SPLIT_DISPATCH(mul_mid_t, ctx, twf, twi, res_dp, ndp, res_d, nd, res_i, ni, ext, D, ops, square, s)
 }
 
 template <int L>
-static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, bool pack, bool conv_grid, u32 kneed, const u64* D, u64* out, size_t ops,
+static hipError_t mul_tail_t(const DevCtx* ctx, const MulOp* twi, bool aux_f64, int pack, bool conv_grid, u32 kneed, const u64* D, u64* out, size_t ops,
                              u32 poly0, u32 npolys, hipStream_t s) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, npolys, (unsigned)ops);
+#define MT(KM, AD, PK, GR) mul_tail_kernel<L, KM, AD, PK, GR><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys)
   if (kneed > 4) {
-    if (pack)
-      if (conv_grid)
-        mul_tail_kernel<L, 8, true, true, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
-      else
-        mul_tail_kernel<L, 8, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
-    else
-      if (conv_grid)
-        mul_tail_kernel<L, 8, true, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
-      else
-        mul_tail_kernel<L, 8, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
+    if (pack == 2) { if (conv_grid) MT(8, true, 2, true); else MT(8, true, 2, false); }
+    else if (pack) { if (conv_grid) MT(8, true, 1, true); else MT(8, true, 1, false); }
+    else { if (conv_grid) MT(8, true, 0, true); else MT(8, true, 0, false); }
   } else if (aux_f64) {
-    if (pack)
-      mul_tail_kernel<L, 4, true, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
-    else
-      mul_tail_kernel<L, 4, true, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
+    if (pack == 2) return hipErrorInvalidValue;
+    if (pack) MT(4, true, 1, false); else MT(4, true, 0, false);
   } else if (pack) {  // mixed base
-    mul_tail_kernel<L, 4, false, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
+    MT(4, false, 1, false);
   } else {
-    mul_tail_kernel<L, 4, false, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, out, poly0, npolys);
+    MT(4, false, 0, false);
   }
+#undef MT
   return hipGetLastError();
 }
 // conv_grid: DevCtx::conv_grid (takes effect in the 8-prime instantiation, kneed > 4)
 // poly0, npolys: which product polynomials to finish (0, 3 = all; 2, 1 = only c2, written compactly as out[op][K][N])
-hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, bool pack, bool conv_grid, u32 kneed, const u64* D, u64* out,
+hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, int pack, bool conv_grid, u32 kneed, const u64* D, u64* out,
                            size_t ops, hipStream_t s, u32 poly0, u32 npolys) {
   SPLIT_DISPATCH(mul_tail_t, ctx, twi, aux_f64, pack, conv_grid && aux_f64, kneed, D, out, ops, poly0, npolys, s)
 }
 
 template <int L>
-static hipError_t mulrelin_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D, const u64* ACC,
+static hipError_t mulrelin_tail_t(const DevCtx* ctx, const MulOp* twi, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D, const u64* ACC,
                                   const u64* extra, u64* out2, size_t ops, hipStream_t s) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
   const double* acc = reinterpret_cast<const double*>(ACC);
 #define MRT(KM, PM, GR, PK) mulrelin_tail_kernel<L, KM, PM, GR, PK><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, acc, extra, out2)
+#define MRT_K(KM, PM, GR) do { if (pack_ks) MRT(KM, PM, GR, true); else MRT(KM, PM, GR, false); } while (0)
   if (kneed > 4) {
-    if (pack_mul) { if (conv_grid) { if (pack_ks) MRT(8, true, true, true); else MRT(8, true, true, false); } else { if (pack_ks) MRT(8, true, false, true); else MRT(8, true, false, false); } }
-    else { if (conv_grid) { if (pack_ks) MRT(8, false, true, true); else MRT(8, false, true, false); } else { if (pack_ks) MRT(8, false, false, true); else MRT(8, false, false, false); } }
+    if (pack_mul == 2) { if (conv_grid) MRT_K(8, 2, true); else MRT_K(8, 2, false); }
+    else if (pack_mul) { if (conv_grid) MRT_K(8, 1, true); else MRT_K(8, 1, false); }
+    else { if (conv_grid) MRT_K(8, 0, true); else MRT_K(8, 0, false); }
   } else {
-    if (pack_mul) { if (pack_ks) MRT(4, true, false, true); else MRT(4, true, false, false); }
-    else { if (pack_ks) MRT(4, false, false, true); else MRT(4, false, false, false); }
+    if (pack_mul == 2) return hipErrorInvalidValue;
+    if (pack_mul) MRT_K(4, 1, false); else MRT_K(4, 0, false);
   }
+#undef MRT_K
 #undef MRT
   return hipGetLastError();
 }
 template <int L>
-static hipError_t mulrelin_head_t(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
+static hipError_t mulrelin_head_t(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
                                   u64* T, size_t ops, hipStream_t s) {
   const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, 1, (unsigned)ops);
   double* t = reinterpret_cast<double*>(T);
 #define MRH(KM, PM, GR, PK) mulrelin_head_kernel<L, KM, PM, GR, PK><<<grid, kHeadThreads, 0, s>>>(ctx, twi, twf, D, t)
+#define MRH_K(KM, PM, GR) do { if (pack_ks) MRH(KM, PM, GR, true); else MRH(KM, PM, GR, false); } while (0)
   if (kneed > 4) {
-    if (pack_mul) { if (conv_grid) { if (pack_ks) MRH(8, true, true, true); else MRH(8, true, true, false); } else { if (pack_ks) MRH(8, true, false, true); else MRH(8, true, false, false); } }
-    else { if (conv_grid) { if (pack_ks) MRH(8, false, true, true); else MRH(8, false, true, false); } else { if (pack_ks) MRH(8, false, false, true); else MRH(8, false, false, false); } }
+    if (pack_mul == 2) { if (conv_grid) MRH_K(8, 2, true); else MRH_K(8, 2, false); }
+    else if (pack_mul) { if (conv_grid) MRH_K(8, 1, true); else MRH_K(8, 1, false); }
+    else { if (conv_grid) MRH_K(8, 0, true); else MRH_K(8, 0, false); }
   } else {
-    if (pack_mul) { if (pack_ks) MRH(4, true, false, true); else MRH(4, true, false, false); }
-    else { if (pack_ks) MRH(4, false, false, true); else MRH(4, false, false, false); }
+    if (pack_mul == 2) return hipErrorInvalidValue;
+    if (pack_mul) MRH_K(4, 1, false); else MRH_K(4, 0, false);
   }
+#undef MRH_K
 #undef MRH
   return hipGetLastError();
 }
 // multiply tail of c2 + key-switch head in one kernel (all-FP64 contexts)
-hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed,
+hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed,
                                 const u64* D, u64* T, size_t ops, hipStream_t s) {
   SPLIT_DISPATCH(mulrelin_head_t, ctx, twi, twf, pack_mul, conv_grid, pack_ks, kneed, D, T, ops, s)
 }
 
 // the last kernel of the fused multiply + relinearize of all-FP64 contexts (DevCtx::aux_f64, every key prime FP64-policy)
-hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
+hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
                                 const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s) {
   SPLIT_DISPATCH(mulrelin_tail_t, ctx, twi, pack_mul, conv_grid, pack_ks, kneed, D, ACC, extra, out2, ops, s)
 }

@@ -308,6 +308,65 @@ def test_multiply_around_the_grid_plan_limit(n, bits):
         assert (m[i] == o.multiply(a[i].astype(np.uint64), b[i].astype(np.uint64))).all(), (i, ctx.aux_fp64, ctx.conv_grid)
 
 
+@pytest.mark.parametrize(
+    "n,bits",
+    [
+        (16384, [48, 48, 48, 49, 49, 49, 49, 49, 49]),  # the SEAL default sizes of n = 16384: rows 0-2 and the 10 auxiliary rows packed
+        (8192, [49, 44, 48, 49, 47, 49, 48]),           # K = 6: packed and 8-byte data rows interleaved (rows 1, 2, 4 packed)
+        (8192, [49, 49, 49, 49, 49, 49]),               # K = 5: no data row packed, every auxiliary row packed
+    ],
+)
+def test_per_row_packing_of_the_multiply_intermediates(n, bits, monkeypatch):
+    """r04: with data primes on both sides of 2^48 the split multiply can pack its intermediates PER ROW (HIPBFV_PACK_ROWS=1 ->
+    DevCtx::pack_mul == 2: the rows whose prime is below 2^48 travel as 6 bytes, the others as 8; opt-in -- it measured 1.2 % slower
+    at n = 16384, context.cpp).  The plain product, the fused multiply + relinearize and the squaring instantiations -- each reads
+    and writes the mixed rows in its own kernels -- equal the oracle on random operands and at the edges of the BEHZ bounds, and the
+    default context (8-byte rows throughout) gives the same bits."""
+    import torch
+
+    from sunscreen_amd import Context, RelinearizationKeys
+    from sunscreen_amd.batch import BatchEvaluator
+
+    if any(os.environ.get(k) == "1" for k in ("HIPBFV_SEAL_AUX", "HIPBFV_NO_F64")):
+        pytest.skip("packed rows exist on the FP64 pipe with the library's own auxiliary base only")
+    primes = O.coeff_modulus_create(n, bits)
+    t = O.plain_batching(n, 17)
+    o = O.Oracle(n, primes, t)
+    o.throw_on_transparent = False  # _extreme_rows has an all-zero operand: the (transparent) product's bits are compared
+    O.seed(31)
+    sk, pk, rk, _ = o.keygen()
+    K = len(primes) - 1
+    rng = np.random.default_rng(n + sum(bits))
+    a = np.stack([rng.integers(0, q, (3, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2).astype(np.int64)
+    b = np.stack([rng.integers(0, q, (3, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2).astype(np.int64)
+    xa, xb = _extreme_rows(primes, K, n)
+    a, b = np.concatenate([a, xa]), np.concatenate([b, xb])
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    got = {}
+    monkeypatch.delenv("HIPBFV_NO_PACK", raising=False)
+    for tag, env in (("rows", "1"), ("bytes8", None)):
+        if env:
+            monkeypatch.setenv("HIPBFV_PACK_ROWS", env)
+        else:
+            monkeypatch.delenv("HIPBFV_PACK_ROWS", raising=False)
+        ctx = Context.from_raw(n, primes, t)  # the switch is read when the context is built
+        ev = BatchEvaluator(ctx)
+        ev.set_transparent_check(False)
+        assert ctx.aux_fp64 and ctx.packed_mul_rows == (env is not None) and (ctx.packed_mul == (env is not None)), (tag, ctx.packed_mul, ctx.packed_mul_rows)
+        rkd = RelinearizationKeys.from_array(ctx, rk)
+        got[tag] = [x.cpu().numpy().astype(np.uint64) for x in (ev.multiply(da, db), ev.multiply_relin(da, db, rkd), ev.multiply(da, da), ev.multiply_relin(db, db, rkd))]
+    for x, y in zip(got["rows"], got["bytes8"]):
+        assert (x == y).all()
+    m, r, sq, sqr = got["rows"]
+    for i in list(range(2)) + list(range(3, len(a))):  # two random items and every edge row
+        ua, ub = a[i].astype(np.uint64), b[i].astype(np.uint64)
+        om = o.multiply(ua, ub)
+        assert (m[i] == om).all(), i
+        assert (r[i] == o.relinearize(om, rk)).all(), i
+        assert (sq[i] == o.multiply(ua, ua)).all(), i
+        assert (sqr[i] == o.relinearize(o.multiply(ub, ub), rk)).all(), i
+
+
 def test_concurrent_host_threads_on_one_evaluator():
     """sunscreen_runtime/src/run.rs:415-469 calls one evaluator from a rayon pool: handle-level calls must be
     thread-safe (one non-blocking HIP stream per host thread, no shared mutable scratch)."""

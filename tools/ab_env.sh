@@ -1,13 +1,13 @@
 #!/bin/bash
-# tools/ab_env.sh <ENVVAR> <bench args...> -- interleaved A/B on one box: default vs ENVVAR=1 (two rounds)
-VAR=$1; shift
+# tools/ab_env.sh "<VAR=value> ..." <bench args...> -- interleaved runs of the default library with and without environment switches
+# (arm "default" = none set; one arm per quoted assignment), two rounds
+ARMS=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/ab_$VAR; mkdir -p $OUT
 for round in 1 2; do
-  for arm in on off; do
-    if [ $arm = off ]; then export $VAR=1; else unset $VAR; fi
-    timeout 300 python bench.py "$@" --no-cpu --no-secondary 2>/dev/null | tail -1 > $OUT/${arm}_$round.json
+  for arm in default $ARMS; do
+    if [ $arm = default ]; then E=""; else E=$arm; fi
+    env $E timeout 600 python bench.py "$@" --no-cpu --no-secondary --no-power 2>/dev/null | tail -1 > /tmp/ab_line.json
     python -c "
-import json; d=json.load(open('$OUT/${arm}_$round.json')); print('$VAR', '$arm', d['value'], d['parity'][:24], d['kernels_ms_per_step'])"
+import json; d=json.load(open('/tmp/ab_line.json')); print('$arm', d['value'], d.get('spread'), d['parity'][:20], d['kernels_ms_per_step'])"
   done
 done
