@@ -407,54 +407,137 @@ __global__ __launch_bounds__(kClientThreads) void dot_plain_kernel(const DevCtx*
 // The same with TWO adjacent coefficients per thread: every access is 16 bytes per lane (1 KB contiguous per wavefront
 // instruction instead of 512 B), half the memory instructions for the same bytes.  RT rows x 2 polynomials x 2 coefficients of
 // 128-bit accumulators per thread.
-template <int RT>
-__global__ __launch_bounds__(kClientThreads) void dot_plain2_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 cols,
-                                                                    const u64* __restrict__ pntt, u32 rows, u64* __restrict__ acc) {
-  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-  const u32 n = ctx->n, K = ctx->K;
-  const u32 x = 2 * (blockIdx.x * kClientThreads + threadIdx.x);
-  const u32 i = blockIdx.y, r0 = blockIdx.z * RT;
-  if (x >= n) return;
-  const DevMod& dm = ctx->mod[i];
-  u128 a0[RT][2], a1[RT][2];
+//
+// r04: the column loop is software-pipelined by hand.  The r02-r03 form tested `r0 + r < rows` inside the loop; the compiler
+// turned each row into its own basic block -- load, s_waitcnt vmcnt(0), multiply -- so ONE 16-byte load per lane was in flight at
+// a time and the database streamed on occupancy alone (4.4-4.9 TB/s).  Now a block of JU columns is fetched as a unit -- the RT x
+// JU database words and the 2 x JU query words issued back to back -- and the NEXT block is requested before the current one is
+// multiplied; rows beyond the matrix are clamped to its last row (read twice, never stored) so the loop body has no branches.
+// Src: where database word (row r of the thread's RT, column j) lives: a dense matrix (dot_plain2_kernel) or a descriptor
+// table (dot_plain_tab_kernel, the graph executor's form).
+typedef unsigned long long pir_u64x2 __attribute__((ext_vector_type(2)));
+template <int RT, int JU>
+struct PirBlock {
+  pir_u64x2 c0[JU], c1[JU], pv[RT][JU];
+};
+template <int RT, int JU, class Query, class Src>
+__device__ __forceinline__ void pir_fetch(PirBlock<RT, JU>& blk, u32 j0, u32 cols, const Query& query, const Src& src) {
+  // first every address (the descriptor-table form reads RT x JU wave-uniform table entries: scalar loads, requested together),
+  // then every vector load back to back
+  const u64* at[RT][JU];
+  u32 jj[JU];
 #pragma unroll
-  for (int r = 0; r < RT; r++) a0[r][0] = a0[r][1] = a1[r][0] = a1[r][1] = 0;
-#ifdef PIR_UNROLL
-#pragma unroll PIR_UNROLL
-#endif
-  for (u32 j = 0; j < cols; j++) {
-    const u64x2_t c0 = *reinterpret_cast<const u64x2_t*>(&ctn[(((size_t)j * 2 + 0) * K + i) * n + x]);
-    const u64x2_t c1 = *reinterpret_cast<const u64x2_t*>(&ctn[(((size_t)j * 2 + 1) * K + i) * n + x]);
+  for (int u = 0; u < JU; u++) {
+    jj[u] = j0 + (u32)u < cols ? j0 + (u32)u : cols - 1;  // a partial last block re-reads the last column (its terms are skipped)
+#pragma unroll
+    for (int r = 0; r < RT; r++) at[r][u] = src(r, jj[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < JU; u++) {
+    const u64* cj = query(jj[u]);
+    blk.c0[u] = *reinterpret_cast<const pir_u64x2*>(cj);
+    blk.c1[u] = *reinterpret_cast<const pir_u64x2*>(cj + query.poly_stride);
 #pragma unroll
     for (int r = 0; r < RT; r++) {
-      if (r0 + r < rows) {
-        const u64x2_t* src = reinterpret_cast<const u64x2_t*>(&pntt[(((size_t)(r0 + r) * cols + j) * K + i) * n + x]);
+      const auto p = as_global(reinterpret_cast<const pir_u64x2*>(at[r][u]));  // global_load, not flat_load
 #if PIR_NT
-        const u64x2_t pv = __builtin_nontemporal_load(src);
+      blk.pv[r][u] = __builtin_nontemporal_load(p);  // the database streams through once
 #else
-        const u64x2_t pv = *src;
+      blk.pv[r][u] = *p;
 #endif
-        a0[r][0] += (u128)c0.x * pv.x;
-        a0[r][1] += (u128)c0.y * pv.y;
-        a1[r][0] += (u128)c1.x * pv.x;
-        a1[r][1] += (u128)c1.y * pv.y;
+    }
+  }
+}
+template <int RT, int JU, class Query, class Src>
+__device__ __forceinline__ void pir_dot_body(const DevMod& dm, u32 cols, const Query& query, const Src& src, u128 (&a0)[RT][2], u128 (&a1)[RT][2]) {
+#pragma unroll
+  for (int r = 0; r < RT; r++) a0[r][0] = a0[r][1] = a1[r][0] = a1[r][1] = 0;
+  PirBlock<RT, JU> nxt;
+  pir_fetch<RT, JU>(nxt, 0, cols, query, src);
+  u32 since = 0;  // products accumulated since the last reduction: below 2^122 each, sixteen fit 128 bits
+  for (u32 j0 = 0; j0 < cols; j0 += JU) {
+    const PirBlock<RT, JU> cur = nxt;
+    if (j0 + JU < cols) pir_fetch<RT, JU>(nxt, j0 + JU, cols, query, src);  // wave-uniform: in flight while `cur` is multiplied
+#pragma unroll
+    for (int u = 0; u < JU; u++) {
+      const bool live = j0 + (u32)u < cols;  // wave-uniform; false only in a partial last block
+      const u64 m = live ? ~0ull : 0ull;
+#pragma unroll
+      for (int r = 0; r < RT; r++) {
+        const u64 px = cur.pv[r][u].x & m, py = cur.pv[r][u].y & m;
+        a0[r][0] += (u128)cur.c0[u].x * px;
+        a0[r][1] += (u128)cur.c0[u].y * py;
+        a1[r][0] += (u128)cur.c1[u].x * px;
+        a1[r][1] += (u128)cur.c1[u].y * py;
       }
     }
-    if ((j & 15u) == 15u) {
+    since += JU;
+    if (since + JU > 16u) {
+      since = 0;
 #pragma unroll
       for (int r = 0; r < RT; r++)
 #pragma unroll
         for (int e = 0; e < 2; e++) a0[r][e] = reduce128_fast(a0[r][e], dm), a1[r][e] = reduce128_fast(a1[r][e], dm);
     }
   }
+}
+#ifndef PIR_JU
+#define PIR_JU 1  // columns per block, two blocks in flight (measured, r04: JU = 1 / 2 / 4 -> the 16 GiB product 2.95 / 3.04 / 5.1 ms)
+#endif
+// Which grid dimension walks the ROW BLOCKS.  Workgroups are dispatched x-fastest, so with the row blocks on x (PIR_ROWS_FAST) the
+// workgroups resident at one time are all row blocks of a few (coefficient range, residue) slices: they read the SAME query words
+// at about the same time, and each XCD's L2 serves them after the first.  With the coefficient ranges on x (the r01-r03 order) the
+// resident workgroups cover all coefficients of 8 row blocks, and every row block re-reads the whole transformed query: at
+// n = 16384 that is 512 MiB per 4 rows -- 64 GiB beside the 128 GiB database, and more than the 256 MB Infinity Cache holds.
+#ifndef PIR_ROWS_FAST
+#define PIR_ROWS_FAST 1
+#endif
+struct PirGrid {
+#if PIR_ROWS_FAST
+  static __device__ __forceinline__ u32 rowblock() { return blockIdx.x; }
+  static __device__ __forceinline__ u32 xblock() { return blockIdx.y; }
+  static __device__ __forceinline__ u32 residue() { return blockIdx.z; }
+  static dim3 grid(u32 xblocks, u32 K, u32 rowblocks) { return dim3(rowblocks, xblocks, K); }
+#else
+  static __device__ __forceinline__ u32 rowblock() { return blockIdx.z; }
+  static __device__ __forceinline__ u32 xblock() { return blockIdx.x; }
+  static __device__ __forceinline__ u32 residue() { return blockIdx.y; }
+  static dim3 grid(u32 xblocks, u32 K, u32 rowblocks) { return dim3(xblocks, K, rowblocks); }
+#endif
+};
+
+template <int RT>
+__global__ __launch_bounds__(kClientThreads) void dot_plain2_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 cols,
+                                                                    const u64* __restrict__ pntt, u32 rows, u64* __restrict__ acc) {
+  const u32 n = ctx->n, K = ctx->K;
+  const u32 x = 2 * (PirGrid::xblock() * kClientThreads + threadIdx.x);
+  const u32 i = PirGrid::residue(), r0 = PirGrid::rowblock() * RT;
+  if (x >= n) return;
+  const DevMod& dm = ctx->mod[i];
+  const size_t in_row = (size_t)i * n + x;
+  struct Query {
+    const u64* base;
+    size_t col_stride, poly_stride;
+    __device__ __forceinline__ const u64* operator()(u32 j) const { return base + (size_t)j * col_stride; }
+  } query{ctn + in_row, (size_t)2 * K * n, (size_t)K * n};
+  struct Src {
+    const u64* base;  // row r0, column 0
+    size_t row_stride, col_stride;
+    u32 last;         // rows - 1 - r0: rows of this thread's RT beyond it are clamped to the matrix's last row
+    __device__ __forceinline__ const u64* operator()(int r, u32 j) const {
+      return base + (size_t)((u32)r < last ? (u32)r : last) * row_stride + (size_t)j * col_stride;
+    }
+  } src{pntt + (size_t)r0 * cols * K * n + in_row, (size_t)cols * K * n, (size_t)K * n, rows - 1 - r0};
+  u128 a0[RT][2], a1[RT][2];
+  pir_dot_body<RT, PIR_JU>(dm, cols, query, src, a0, a1);
 #pragma unroll
   for (int r = 0; r < RT; r++) {
     if (r0 + r < rows) {
-      u64x2_t o0, o1;
+      pir_u64x2 o0, o1;
       o0.x = reduce128_fast(a0[r][0], dm), o0.y = reduce128_fast(a0[r][1], dm);
       o1.x = reduce128_fast(a1[r][0], dm), o1.y = reduce128_fast(a1[r][1], dm);
-      *reinterpret_cast<u64x2_t*>(&acc[((((size_t)(r0 + r)) * 2 + 0) * K + i) * n + x]) = o0;
-      *reinterpret_cast<u64x2_t*>(&acc[((((size_t)(r0 + r)) * 2 + 1) * K + i) * n + x]) = o1;
+      *reinterpret_cast<pir_u64x2*>(&acc[((((size_t)(r0 + r)) * 2 + 0) * K + i) * n + x]) = o0;
+      *reinterpret_cast<pir_u64x2*>(&acc[((((size_t)(r0 + r)) * 2 + 1) * K + i) * n + x]) = o1;
     }
   }
 }
@@ -466,52 +549,37 @@ __global__ __launch_bounds__(kClientThreads) void dot_plain2_kernel(const DevCtx
 template <int RT>
 __global__ __launch_bounds__(kClientThreads) void dot_plain_tab_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 cols,
                                                                        const PlainNttRef* __restrict__ tab, u32 rows, u32 batch, u64* __restrict__ acc) {
-  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
   const u32 n = ctx->n, K = ctx->K;
-  const u32 x = 2 * (blockIdx.x * kClientThreads + threadIdx.x);
-  const u32 i = blockIdx.y, r0 = (blockIdx.z / batch) * RT, b = blockIdx.z % batch;
+  const u32 x = 2 * (PirGrid::xblock() * kClientThreads + threadIdx.x);
+  const u32 i = PirGrid::residue(), r0 = (PirGrid::rowblock() / batch) * RT, b = PirGrid::rowblock() % batch;
   if (x >= n) return;
   const DevMod& dm = ctx->mod[i];
-  u128 a0[RT][2], a1[RT][2];
-#pragma unroll
-  for (int r = 0; r < RT; r++) a0[r][0] = a0[r][1] = a1[r][0] = a1[r][1] = 0;
   const size_t in_row = (size_t)i * n + x;
-  for (u32 j = 0; j < cols; j++) {
-    const u64* cj = ctn + ((size_t)j * batch + b) * 2 * K * n + in_row;
-    const u64x2_t c0 = *reinterpret_cast<const u64x2_t*>(cj);
-    const u64x2_t c1 = *reinterpret_cast<const u64x2_t*>(cj + (size_t)K * n);
-#pragma unroll
-    for (int r = 0; r < RT; r++) {
-      if (r0 + r < rows) {
-        const PlainNttRef ref = tab[(size_t)(r0 + r) * cols + j];
-        const auto src = as_global(reinterpret_cast<const u64x2_t*>(ref.ptr + (size_t)b * ref.stride + in_row));  // global_load, not flat_load
-#if PIR_NT
-        const u64x2_t pv = __builtin_nontemporal_load(src);
-#else
-        const u64x2_t pv = *src;
-#endif
-        a0[r][0] += (u128)c0.x * pv.x;
-        a0[r][1] += (u128)c0.y * pv.y;
-        a1[r][0] += (u128)c1.x * pv.x;
-        a1[r][1] += (u128)c1.y * pv.y;
-      }
+  struct Query {
+    const u64* base;
+    size_t col_stride, poly_stride;
+    __device__ __forceinline__ const u64* operator()(u32 j) const { return base + (size_t)j * col_stride; }
+  } query{ctn + (size_t)b * 2 * K * n + in_row, (size_t)batch * 2 * K * n, (size_t)K * n};
+  struct Src {
+    const PlainNttRef* tab;  // row r0, column 0
+    u32 cols, last, b;
+    size_t in_row;
+    __device__ __forceinline__ const u64* operator()(int r, u32 j) const {
+      const PlainNttRef ref = tab[(size_t)((u32)r < last ? (u32)r : last) * cols + j];  // wave-uniform: a scalar load
+      return ref.ptr + (size_t)b * ref.stride + in_row;
     }
-    if ((j & 15u) == 15u) {
-#pragma unroll
-      for (int r = 0; r < RT; r++)
-#pragma unroll
-        for (int e = 0; e < 2; e++) a0[r][e] = reduce128_fast(a0[r][e], dm), a1[r][e] = reduce128_fast(a1[r][e], dm);
-    }
-  }
+  } src{tab + (size_t)r0 * cols, cols, rows - 1 - r0, b, in_row};
+  u128 a0[RT][2], a1[RT][2];
+  pir_dot_body<RT, PIR_JU>(dm, cols, query, src, a0, a1);
 #pragma unroll
   for (int r = 0; r < RT; r++) {
     if (r0 + r < rows) {
-      u64x2_t o0, o1;
+      pir_u64x2 o0, o1;
       o0.x = reduce128_fast(a0[r][0], dm), o0.y = reduce128_fast(a0[r][1], dm);
       o1.x = reduce128_fast(a1[r][0], dm), o1.y = reduce128_fast(a1[r][1], dm);
       u64* dst = acc + ((size_t)(r0 + r) * batch + b) * 2 * K * n + in_row;
-      *reinterpret_cast<u64x2_t*>(dst) = o0;
-      *reinterpret_cast<u64x2_t*>(dst + (size_t)K * n) = o1;
+      *reinterpret_cast<pir_u64x2*>(dst) = o0;
+      *reinterpret_cast<pir_u64x2*>(dst + (size_t)K * n) = o1;
     }
   }
 }
@@ -526,7 +594,7 @@ hipError_t launch_dot_plain_tab(const DevCtx* ctx, u32 n, u32 K, const u64* ctn,
   for (u32 off = 0; off < blocks; off += per) {
     const u32 c = std::min(per, blocks - off);
     const u32 r_off = off * RT, r_cnt = std::min(rows - r_off, c * RT);
-    dot_plain_tab_kernel<RT><<<cgrid(n / 2, K, c * batch), kClientThreads, 0, s>>>(ctx, ctn, cols, tab + (size_t)r_off * cols, r_cnt, batch,
+    dot_plain_tab_kernel<RT><<<PirGrid::grid((n / 2 + kClientThreads - 1) / kClientThreads, K, c * batch), kClientThreads, 0, s>>>(ctx, ctn, cols, tab + (size_t)r_off * cols, r_cnt, batch,
                                                                                    acc + (size_t)r_off * batch * 2 * K * n);
   }
   return hipGetLastError();
@@ -581,10 +649,10 @@ hipError_t launch_crt_decompose(const DevCtx* ctx, u32 n, u32 KC, const u64* in,
 hipError_t launch_dot_plain(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* acc, hipStream_t s) {
 #if PIR_WIDE == 1
   constexpr int RT = 4;
-  dot_plain2_kernel<RT><<<cgrid(n / 2, K, (rows + RT - 1) / RT), kClientThreads, 0, s>>>(ctx, ctn, cols, pntt, rows, acc);
+  dot_plain2_kernel<RT><<<PirGrid::grid((n / 2 + kClientThreads - 1) / kClientThreads, K, (rows + RT - 1) / RT), kClientThreads, 0, s>>>(ctx, ctn, cols, pntt, rows, acc);
 #elif PIR_WIDE == 2
   constexpr int RT = 8;
-  dot_plain2_kernel<RT><<<cgrid(n / 2, K, (rows + RT - 1) / RT), kClientThreads, 0, s>>>(ctx, ctn, cols, pntt, rows, acc);
+  dot_plain2_kernel<RT><<<PirGrid::grid((n / 2 + kClientThreads - 1) / kClientThreads, K, (rows + RT - 1) / RT), kClientThreads, 0, s>>>(ctx, ctn, cols, pntt, rows, acc);
 #else
   constexpr int RT = 8;  // rows per thread: the query ciphertexts are re-read once per RT database rows (16: fewer, fatter
                          // workgroups -- measured slower)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 4, GPU session 4: PIR product kernels with the row blocks on grid x (query words shared through L2) vs on grid z; parity first
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/s4; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_program.py tests/test_gpu_baseline_configs.py -m gpu -x -q ) > $O/pytest.log 2>&1
+tail -4 $O/pytest.log
+bash tools/ab_libs.sh "pirold pirslow" --workload pir --n 16384 --batch 256 --pir-rows 512 --steps 5 --warmup 2 --repeats 3 > $O/ab_pir16384.txt 2>&1
+cat $O/ab_pir16384.txt
+bash tools/ab_libs.sh "pirold pirslow" --workload pir --batch 256 --steps 10 --warmup 2 --repeats 3 > $O/ab_pir8192.txt 2>&1
+cat $O/ab_pir8192.txt
