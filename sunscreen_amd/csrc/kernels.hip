@@ -788,12 +788,13 @@ __global__ __launch_bounds__(kCoefThreads) void behz_extend_kernel(const DevCtx*
   u64* dst = out + (size_t)poly * (K + S) * n;
   if (k >= n) return;
   u64 x[KMAX], e[KMAX + 2];
+  // branch-free requests, all in flight together: rows i >= K re-read row K - 1 and are discarded (behind `i < K` branches
+  // every load got its own basic block and an s_waitcnt vmcnt(0): KMAX dependent round trips -- r04, kernels_split.hip mul_head)
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) x[i] = src[(size_t)((u32)i < K ? (u32)i : K - 1) * n + k];
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
-    if ((u32)i < K) {
-      x[i] = src[(size_t)i * n + k];
-      dst[(size_t)i * n + k] = x[i];
-    }
+    if ((u32)i < K) dst[(size_t)i * n + k] = x[i];
   }
   if (ctx->aux_f64) {  // the library's own FP64 auxiliary base (context.cpp): exact double arithmetic, canonical words out
     double xd[KMAX], ed[KMAX + 2];
@@ -850,12 +851,11 @@ __global__ __launch_bounds__(kCoefThreads) void behz_floor_sk_kernel(const DevCt
   if (k >= n) return;
   const u64* d = D + (size_t)poly * (K + S) * n;
   u64 y[KMAX], xb[KMAX + 2], r[KMAX];
+  // branch-free requests, all in flight together (rows beyond K / S re-read the last valid row and are ignored below)
 #pragma unroll
-  for (int i = 0; i < KMAX; i++)
-    if ((u32)i < K) y[i] = d[(size_t)i * n + k];  // already x * t * (q/q_i)^{-1} mod q_i
+  for (int i = 0; i < KMAX; i++) y[i] = d[(size_t)((u32)i < K ? (u32)i : K - 1) * n + k];  // already x * t * (q/q_i)^{-1} mod q_i
 #pragma unroll
-  for (int j = 0; j < KMAX + 2; j++)
-    if ((u32)j < S) xb[j] = d[(size_t)(K + j) * n + k];
+  for (int j = 0; j < KMAX + 2; j++) xb[j] = d[(size_t)(K + ((u32)j < S ? (u32)j : S - 1)) * n + k];
   if (ctx->aux_f64) {
     double yd[KMAX], xd[KMAX + 2];
 #pragma unroll

@@ -1096,6 +1096,50 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
   }
   const u64 qsp = ctx->mod[KK - 1].q;
+  if constexpr (!MIXED) {
+    // all-FP64 key primes: accumulator row J + 1 is requested before row J is finished, and the base / addend words of a row
+    // are requested as one group at its start (r04: every one of them used to sit alone behind its own test and wait)
+    NatRaw<PACK> cur[4], nxt[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(acc, N, G::tail_in(t, k));
+    const bool has_base = ((base_mask >> c) & 1u) != 0;
+    for (u32 J = 0; J < K; J++) {
+      const u32 Jn = J + 1 < K ? J + 1 : J;
+#pragma unroll
+      for (int k = 0; k < 4; k++) nxt[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(acc + (size_t)Jn * N, N, G::tail_in(t, k));
+      const DevMod& mj = ctx->mod[J];
+      const ArithD ar(mj);
+      // UNCONDITIONAL requests (an absent operand re-reads a word of the accumulator row, always mapped, and is ignored): a load
+      // under `if (extra)` ends its basic block in a copy of the loaded value, i.e. in an s_waitcnt vmcnt(0) that also waits for
+      // the row just requested
+      u64 bw[4], ex[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u64* dummy = reinterpret_cast<const u64*>(acc) + G::tail_in(t, k);
+        const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
+        bw[k] = *(has_base ? base + (size_t)op * bstride + off : dummy);
+        ex[k] = *(extra ? extra + ((size_t)op * 2) * K * N + off : dummy);
+      }
+      double v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACK>(cur[k]);
+      tail_inv_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(twi_base + (size_t)J * N), mj.split_inv_mask, t);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
+        u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
+        tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+        u64 d = sub_mod(a, tk, mj.q);
+        d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
+        u64 bv = has_base ? bw[k] : 0;
+        bv = extra ? add_mod(bv, ex[k], mj.q) : bv;  // a ciphertext added to the result (fused Add node)
+        out[((size_t)op * 2) * K * N + ((size_t)c * K + J) * N + G::tail_out(t, k)] = add_mod(bv, d, mj.q);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+    }
+    return;
+  }
   for (u32 J = 0; J < K; J++) {
     const DevMod& mj = ctx->mod[J];
     u64 av[4];
@@ -1182,11 +1226,22 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
   const u64* src = (poly < 2 ? in0 + ((size_t)op * 2 + poly) * K * N : in1 + ((size_t)op * 2 + (poly - 2)) * K * N);
   u64* dst = ext + ((size_t)op * 4 + poly) * R * N;
   if constexpr (AUXD) {
+    // Every input word is requested before the first is used, and no request sits behind a branch: rows i >= K (instantiation
+    // wider than the context) re-read row K - 1 and are discarded.  (r01-r03 wrote `i < K ? load : 0`; the compiler gave every
+    // load its own basic block and an s_waitcnt vmcnt(0) -- KMAX x NC dependent HBM round trips per thread, found in r04 by
+    // listing the load / wait sequence of the ISA.)
+    u64 raw[KMAX][NC];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+      const u32 row = (u32)i < K ? (u32)i : K - 1;
+#pragma unroll
+      for (int k = 0; k < NC; k++) raw[i][k] = src[(size_t)row * N + G::head_in(t, k)];
+    }
     double x[KMAX][NC];
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
 #pragma unroll
-      for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? ArithD::from_u64(src[(size_t)i * N + G::head_in(t, k)]) : 0.0;
+      for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? ArithD::from_u64(raw[i][k]) : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
@@ -1224,8 +1279,14 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
   u64 x[KMAX][NC];
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
+    const u32 row = (u32)i < K ? (u32)i : K - 1;  // branch-free requests, all in flight together (see the AUXD branch)
 #pragma unroll
-    for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? src[(size_t)i * N + G::head_in(t, k)] : 0;
+    for (int k = 0; k < NC; k++) x[i][k] = src[(size_t)row * N + G::head_in(t, k)];
+  }
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+#pragma unroll
+    for (int k = 0; k < NC; k++) x[i][k] = (u32)i < K ? x[i][k] : 0;
   }
   // q residues: just the three head stages
 #pragma unroll
@@ -1598,7 +1659,32 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
   constexpr bool PD = PACK == 1;  // data rows, when the choice is static
   constexpr bool PA = PACK != 0;  // auxiliary rows
   const u32 K = ctx->K, KK = ctx->KK;
-    double yc[KMAX][4];
+  double yc[KMAX][4];
+  if constexpr (PACK != 2) {
+    // the words of data row i + 1 are requested before row i is transformed; the requests are branch-free (rows beyond K re-read
+    // row K - 1 and are dropped), so they are not held behind the `i < K` test (r04: see mul_head_kernel)
+    NatRaw<PD> cur[4], nxt[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = nat_fetch<PD, NtSites<L>::tail_ld>(reinterpret_cast<const double*>(d), N, G::tail_in(t, k));
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+      if (i + 1 < KMAX) {
+        const double* next_row = reinterpret_cast<const double*>(d + (size_t)((u32)(i + 1) < K ? (u32)(i + 1) : K - 1) * N);
+#pragma unroll
+        for (int k = 0; k < 4; k++) nxt[k] = nat_fetch<PD, NtSites<L>::tail_ld>(next_row, N, G::tail_in(t, k));
+      }
+      if ((u32)i < K) {
+        const DevMod& dm = ctx->mod[i];
+        const ArithD ar(dm);
+        double r4[4];
+        tail_inv4_scale_d<L, PD>(ar, cur, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
     if ((u32)i < K) {
@@ -1606,20 +1692,21 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
       const ArithD ar(dm);
       const double* row = reinterpret_cast<const double*>(d + (size_t)i * N);
       double r4[4];
-      if (PACK == 2 && ctx->mul_row_packed[i] != 0) {  // wave-uniform
+      if (ctx->mul_row_packed[i] != 0) {  // wave-uniform
         NatRaw<true> raw[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) raw[k] = nat_fetch<true, NtSites<L>::tail_ld>(row, N, G::tail_in(t, k));
         tail_inv4_scale_d<L, true>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
       } else {
-        NatRaw<PD> raw[4];
+        NatRaw<false> raw[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<PD, NtSites<L>::tail_ld>(row, N, G::tail_in(t, k));
-        tail_inv4_scale_d<L, PD>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+        for (int k = 0; k < 4; k++) raw[k] = nat_fetch<false, NtSites<L>::tail_ld>(row, N, G::tail_in(t, k));
+        tail_inv4_scale_d<L, false>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: r4 is reduced
     }
+  }
   }
   behz_floor_sk_multi_d<KMAX, 4, GRID, NatRaw<PA>>(
       ctx, yc,
@@ -1775,28 +1862,47 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
     for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
   }
   const u64 qsp = ctx->mod[KK - 1].q;
+  // accumulator row J + 1 is requested (branch-free: rows beyond K re-read row K - 1) before row J is finished
+  NatRaw<PACKK> cur[4], nxt[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) cur[k] = nat_fetch<PACKK, NtSites<L>::tail_ld>(acc, N, G::tail_in(t, k));
 #pragma unroll
   for (int J = 0; J < KMAX; J++) {
-    if ((u32)J >= K) break;
-    const DevMod& mj = ctx->mod[J];
-    const ArithD ar(mj);
-    const double* tw = reinterpret_cast<const double*>(twi_base + (size_t)J * N);
-    double v[4];
+    if (J + 1 < KMAX) {
+      const double* next_row = acc + (size_t)((u32)(J + 1) < K ? (u32)(J + 1) : K - 1) * N;
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = nat_load<PACKK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, G::tail_in(t, k));
-    tail_inv_owned<ArithD, L>(ar, v, tw, mj.split_inv_mask, t);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
-      u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
-      tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
-      u64 dd = sub_mod(a, tk, mj.q);
-      dd = mul_shoup(dd, ctx->inv_qsp_mod_q[J], mj.q);
-      const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
-      u64 bv = basev[J][k];
-      if (extra) bv = add_mod(bv, extra[((size_t)op * 2) * K * N + off], mj.q);
-      out[((size_t)op * 2) * K * N + off] = add_mod(bv, dd, mj.q);
+      for (int k = 0; k < 4; k++) nxt[k] = nat_fetch<PACKK, NtSites<L>::tail_ld>(next_row, N, G::tail_in(t, k));
     }
+    if ((u32)J < K) {
+      const DevMod& mj = ctx->mod[J];
+      const ArithD ar(mj);
+      const double* tw = reinterpret_cast<const double*>(twi_base + (size_t)J * N);
+      // a ciphertext added to the result (fused Add node): its four words, requested UNCONDITIONALLY (absent: a word of the
+      // accumulator row is re-read and ignored) -- a load under `if (extra)` ends its block in an s_waitcnt vmcnt(0) that would
+      // also wait for the row just requested
+      u64 ex[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        ex[k] = *(extra ? extra + ((size_t)op * 2) * K * N + ((size_t)c * K + J) * N + G::tail_out(t, k) : reinterpret_cast<const u64*>(acc) + G::tail_in(t, k));
+      double v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACKK>(cur[k]);
+      tail_inv_owned<ArithD, L>(ar, v, tw, mj.split_inv_mask, t);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
+        u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
+        tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+        u64 dd = sub_mod(a, tk, mj.q);
+        dd = mul_shoup(dd, ctx->inv_qsp_mod_q[J], mj.q);
+        const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
+        u64 bv = basev[J][k];
+        bv = extra ? add_mod(bv, ex[k], mj.q) : bv;
+        out[((size_t)op * 2) * K * N + off] = add_mod(bv, dd, mj.q);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = nxt[k];
   }
 }
 
