@@ -679,9 +679,11 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     if (part && rows_env && rows_env[0] == '1') h.pack_mul = 2;  // (the auxiliary rows alone are S of the K + S rows)
   }
   h.mid_nd = h.mid_ndp = h.mid_ni = 0;
+  h.mul_row_mask = 0;
   for (u32 r = 0; r < K + h.S; r++) {
     const u32 m = r < K ? r : KK + (r - K);
     h.mul_row_packed[r] = (h.pack_mul == 1 || (h.pack_mul == 2 && h.mod[m].q < (1ull << 48))) ? 1 : 0;
+    if (h.mul_row_packed[r] && r < 32) h.mul_row_mask |= 1u << r;
     if (h.mod[m].use_f64 && h.mod[m].split_ok) {
       if (h.mul_row_packed[r])
         h.mid_res_dp[h.mid_ndp++] = (unsigned char)r;

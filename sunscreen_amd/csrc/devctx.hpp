@@ -5,6 +5,7 @@
 // Bsk = B u {m_sk}, and every per-modulus constant the kernels need.  It lives in device
 // global memory; kernels receive a `const DevCtx*` (uniform loads -> SGPRs).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 namespace hipbfv {
@@ -126,7 +127,8 @@ struct DevCtx {
   unsigned char mid_res_dp[kMaxMod];
   unsigned char mid_res_i[kMaxMod];
   unsigned char mul_row_packed[kMaxMod];
-  u32 mid_nd, mid_ndp, mid_ni, pad6;
+  u32 mid_nd, mid_ndp, mid_ni;
+  u32 mul_row_mask;  // bit r = mul_row_packed[r], r < 32 (the head / tail kernels test it: a scalar load, not a byte load)
   // split key switch: key-prime indices (0..KK-1) handled by the FP64 / integer middle kernel; ks_split_ok: every key prime
   // has a policy the split kernels implement (FP64 with a split range plan, or integer with Shoup twiddle tables)
   unsigned char ks_res_d[kMaxKey + 3];
@@ -162,5 +164,10 @@ struct DevCtx {
   u32 fast_plain_lift;                 // t < every q_i
   u32 pad2;
 };
+
+// the residue lists are read through aligned 32-bit scalar loads (kernels_split.hip residue_of)
+static_assert(offsetof(DevCtx, mid_res_d) % 4 == 0 && offsetof(DevCtx, mid_res_dp) % 4 == 0 && offsetof(DevCtx, mid_res_i) % 4 == 0 &&
+                  offsetof(DevCtx, ks_res_d) % 4 == 0 && offsetof(DevCtx, ks_res_i) % 4 == 0,
+              "residue lists must start at 4-byte-aligned offsets");
 
 }  // namespace hipbfv

@@ -266,7 +266,15 @@ __device__ __forceinline__ void ntt_inv_from_lds(const A& ar, typename A::V (&v)
   InvPasses<A, LOGN, kElemsPerThread, 0>::run(ar, v, smem, tid, tw, reduce_mask);
 }
 
-__device__ __forceinline__ u32 plan_mod(const NttPlan& plan, u32 poly) { return plan.mod[(poly / plan.div) % plan.period]; }
+// Which modulus polynomial `poly` belongs to -- through the SCALAR unit.  `plan.mod[i]` with a run-time i is a byte load from the
+// kernel-argument segment, which gfx950 can only do as a VECTOR load: every workgroup of a transform kernel began with
+// global_load_ubyte + s_waitcnt vmcnt(0), a dependent memory round trip before its first polynomial load could be issued
+// (r04, found in the load / wait listing of the ISA).  The aligned 32-bit word that holds the byte is a wave-uniform s_load.
+__device__ __forceinline__ u32 plan_mod(const NttPlan& plan, u32 poly) {
+  const u32 i = __builtin_amdgcn_readfirstlane((poly / plan.div) % plan.period);
+  const u32* words = reinterpret_cast<const u32*>(plan.mod);
+  return (words[i >> 2] >> ((i & 3u) * 8u)) & 0xffu;
+}
 
 // the store half of a forward transform whose last pass left its results in LDS
 template <class A, int LOGN>
@@ -295,6 +303,11 @@ __device__ __forceinline__ void ntt_fwd_store(const A& ar, u64* x, typename A::V
 template <class A, int LOGN>
 __device__ __forceinline__ void ntt_fwd_body(const DevMod& dm, const typename A::Tw* tw, u64* x, typename A::V* smem, u32 tid) {
   const A ar(dm);
+  // Both arithmetic policies begin with the same polynomial loads; the compiler hoists the first COMMON one above the policy
+  // branch of the kernel, where it stands alone before an s_waitcnt vmcnt(0) -- one extra memory round trip per workgroup ahead of
+  // the other fifteen requests (r04, ISA listing).  An opaque zero offset per instantiation makes the two branches' addresses
+  // distinct values (the pointer keeps its provenance and address space: nttcore.hpp opaque_uniform).
+  x = const_cast<u64*>(opaque_uniform(const_cast<const u64*>(x)));
   // (storing the last pass's 2^R-element runs straight from registers was measured 15 % slower than this staged,
   // fully coalesced store; the mirror-image direct LOAD in ntt_inv_body is 25 % faster than staging)
   ntt_fwd_to_lds<A, LOGN>(ar, x, smem, tid, tw, dm.fwd_reduce_mask);
@@ -325,6 +338,7 @@ __device__ __forceinline__ void ntt_inv_body(const DevMod& dm, const typename A:
                                              const u64* __restrict__ mul_b = nullptr) {
   using Sh = NttShape<LOGN>;
   const A ar(dm);
+  x = const_cast<u64*>(opaque_uniform(const_cast<const u64*>(x)));  // keeps the first load out of the policy branch's common prefix (ntt_fwd_body)
   typename A::V v[kElemsPerThread];
   {  // the first inverse pass consumes runs of 2^R consecutive elements per thread: load them straight into registers
     constexpr int RF = Sh::radix(Sh::NPASS - 1), GF = kElemsPerThread >> RF;
@@ -552,7 +566,7 @@ __global__ __launch_bounds__(NttShape<LOGN>::T, 2) void ntt_pair_kernel(const De
   const u32 tid = threadIdx.x;
   const u32 w = blockIdx.x;
   const u32 p0 = (w / plan.period) * 2 * plan.period + w % plan.period, p1 = p0 + plan.period;
-  const u32 m = plan.mod[w % plan.period];
+  const u32 m = plan_mod(plan, (w % plan.period) * plan.div);  // (scalar lookup; div == 1 for paired launches)
   const DevMod& dm = ctx->mod[m];
   u64* x0 = data + (size_t)p0 * Sh::N;
   u64* x1 = data + (size_t)p1 * Sh::N;

@@ -434,6 +434,16 @@ __device__ __forceinline__ void mid_inverse_multi(const A& ar, typename A::V (&v
   mid_inverse_multi_p<A, L, 0, NP, EPT, PIPE>(ar, v, smem, tid, blk, tw, mask, w);
 }
 
+// Entry `idx` of a residue list (DevCtx::mid_res_* / ks_res_*: byte arrays at 4-byte-aligned offsets of the context) through the
+// SCALAR unit: gfx950 has no scalar byte load, so `list[idx]` is a vector global_load_ubyte followed by s_waitcnt vmcnt(0) -- a
+// dependent HBM / L2 round trip at the very start of every middle-kernel workgroup, before its first polynomial load can be
+// issued (found in r04 in the load / wait listing of the ISA).  The aligned word that holds the byte is a wave-uniform s_load.
+__device__ __forceinline__ u32 residue_of(const unsigned char* __restrict__ list, u32 idx) {
+  idx = __builtin_amdgcn_readfirstlane(idx);
+  const u32 word = reinterpret_cast<const u32*>(list)[idx >> 2];
+  return (word >> ((idx & 3u) * 8u)) & 0xffu;
+}
+
 constexpr int kHeadThreads = 256;
 // the mixed-base head (integer data primes, FP64 auxiliary primes: the <L, 4, AUXD = false, PACK = true> instantiations): waves per
 // SIMD its registers are limited for.  Measured on the 3 x 54-bit workload: 3 (168 registers, 76 bytes of scratch) 2.66-2.81 ms,
@@ -832,7 +842,7 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
   const u32 op = (slot % per) * 8u + xcd;
   const u32 ib = slot / per;
   const u32 blk = ib % Sh::NBLK;
-  const u32 I = __builtin_amdgcn_readfirstlane((u32)residues[ib / Sh::NBLK]);  // a byte load lands in a VGPR: make it scalar again
+  const u32 I = residue_of(residues, ib / Sh::NBLK);
   (void)nres;
   if (op >= ops) return;
   const DevMod& dm = ctx->mod[I];
@@ -952,7 +962,7 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(con
   const u32 op = (slot % per) * 8u + xcd;
   const u32 ib = slot / per;
   const u32 blk = ib % Sh::NBLK;
-  const u32 I = __builtin_amdgcn_readfirstlane((u32)residues[ib / Sh::NBLK]);  // a byte load lands in a VGPR: make it scalar again
+  const u32 I = residue_of(residues, ib / Sh::NBLK);
   (void)nres;
   if (op >= ops) return;
   const DevMod& dm = ctx->mod[I];
@@ -1252,7 +1262,7 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
         for (int k = 0; k < NC; k++) v[k] = x[i][k];
         head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(twf_base + (size_t)i * N), t);
         double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
-        const bool packed = PACK == 1 || (PACK == 2 && ctx->mul_row_packed[i] != 0);
+        const bool packed = PACK == 1 || (PACK == 2 && ((ctx->mul_row_mask >> i) & 1u) != 0);
         if (packed) {
 #pragma unroll
           for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
@@ -1598,11 +1608,11 @@ __global__ __launch_bounds__((MulMidGeom<L, POLICY_D, SQUARE, PACK>::TPB), (MulM
     op = (slot % per) * 8u + xcd;
     const u32 ib = slot / per;
     blk = ib % Sh::NBLK;
-    r = __builtin_amdgcn_readfirstlane((u32)residues[ib / Sh::NBLK]);
+    r = residue_of(residues, ib / Sh::NBLK);
     if (op >= ops) return;
   } else {
     blk = b % Sh::NBLK;
-    r = residues[(b / Sh::NBLK) % nres];
+    r = residue_of(residues, (b / Sh::NBLK) % nres);
     op = b / (Sh::NBLK * nres);
   }
   const u32 m = r < K ? r : KK + (r - K);
@@ -1692,7 +1702,7 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
       const ArithD ar(dm);
       const double* row = reinterpret_cast<const double*>(d + (size_t)i * N);
       double r4[4];
-      if (ctx->mul_row_packed[i] != 0) {  // wave-uniform
+      if (((ctx->mul_row_mask >> i) & 1u) != 0) {  // wave-uniform
         NatRaw<true> raw[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) raw[k] = nat_fetch<true, NtSites<L>::tail_ld>(row, N, G::tail_in(t, k));
@@ -1968,7 +1978,11 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_head_kernel(const DevCtx* __restrict_
 // forward = head stages (streaming) + block-local rest; inverse = block-local stages + tail stages (streaming).
 // The intermediate lives in place in the data buffer, in the policy's native representation.
 // =================================================================================================
-__device__ __forceinline__ u32 plan_mod_split(const NttPlan& plan, u32 poly) { return plan.mod[(poly / plan.div) % plan.period]; }
+__device__ __forceinline__ u32 plan_mod_split(const NttPlan& plan, u32 poly) {  // through the scalar unit: kernels.hip plan_mod
+  const u32 i = __builtin_amdgcn_readfirstlane((poly / plan.div) % plan.period);
+  const u32* words = reinterpret_cast<const u32*>(plan.mod);
+  return (words[i >> 2] >> ((i & 3u) * 8u)) & 0xffu;
+}
 
 // grid (N/8/256, polys)
 template <int L>
