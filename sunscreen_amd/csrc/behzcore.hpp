@@ -8,6 +8,28 @@
 
 namespace hipbfv {
 
+// `asm volatile` uses of wave-uniform doubles: the values must exist (in SGPRs) at this point, so their s_loads cannot be sunk
+// into the conditional blocks that consume them
+__device__ __forceinline__ void pin_scalar_d(double& v) {
+  long long b = __double_as_longlong(v);
+  asm volatile("" : "+s"(b));
+  v = __longlong_as_double(b);
+}
+template <int KMAX>
+__device__ __forceinline__ void pin_scalars_d(double& a, double (&c)[KMAX], MulOpD& m) {
+  pin_scalar_d(a);
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) pin_scalar_d(c[i]);
+  pin_scalar_d(m.w);
+  pin_scalar_d(m.wq);
+}
+#define BEHZ_PIN_SCALARS(a, c, m) \
+  do {                            \
+    double a_ = (a);              \
+    MulOpD m_ = (m);              \
+    pin_scalars_d(a_, c, m_);     \
+  } while (0)
+
 // fastbconv_m_tilde + sm_mrq for one coefficient: x[i] = residue mod q_i  ->  out[j] = residue mod Bsk_j
 // (Evaluator_Multiply steps 1-2, seal_fhe/src/evaluator_base.rs:198-212 -> SEAL bfv_multiply).
 template <int KMAX>
@@ -341,18 +363,24 @@ __device__ __forceinline__ void behz_extend_multi_d(const DevCtx* __restrict__ c
   for (u32 j = 0; j < S; j++) {
     const ArithD ar(ctx->mod[KK + j]);
     double acc[NC];
+    // every constant of this auxiliary prime is requested here, unconditionally and together (one scalar-cache round trip per
+    // trip of the loop): read inside the `i < K` blocks, each was requested where it was used and waited for on the spot
     const double qmb = ctx->q_mod_bsk_d[j];
+    double cj[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) cj[i] = ctx->q_to_bsk_d[j][i];
+    const MulOpD inv = ctx->inv_mtilde_mod_bsk_d[j];
+    BEHZ_PIN_SCALARS(qmb, cj, inv);
 #pragma unroll
     for (int k = 0; k < NC; k++) acc[k] = ar.mul_var(rc[k], qmb);
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
       if ((u32)i < K) {
-        const double c = ctx->q_to_bsk_d[j][i];
+        const double c = cj[i];
 #pragma unroll
         for (int k = 0; k < NC; k++) acc[k] += ar.mul_var(x[i][k], c);
       }
     }
-    const MulOpD inv = ctx->inv_mtilde_mod_bsk_d[j];
 #pragma unroll
     for (int k = 0; k < NC; k++) acc[k] = ar.mul_const(ar.reduce(acc[k]), inv);
     ext(j, acc);
@@ -451,6 +479,18 @@ __device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__
     const ArithD ar(ctx->mod[KK + j]);
     Raw nxt[NC];
     fetch(j + 1 < S ? j + 1 : j, nxt);  // the last round re-reads its own residue (cache hit) to keep the loop uniform
+    // the constants of this auxiliary prime, requested unconditionally and together at the top of the trip (read inside the
+    // `i < K` / `j < nB` blocks, each was requested where it was used and waited for on the spot)
+    double cq[KMAX], cb[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) cq[i] = ctx->q_to_bsk_d[j][i], cb[i] = ctx->B_to_q_d[i][j];
+    MulOpD invq = ctx->inv_q_mod_bsk_d[j], ip = ctx->inv_punct_B_d[j];
+    double bm = ctx->B_to_msk_d[j];
+    {
+      double unused = 0.0;
+      pin_scalars_d(unused, cq, invq);
+      pin_scalars_d(bm, cb, ip);
+    }
     double fl[NC];
     finish(j, cur, fl);
 #pragma unroll
@@ -460,7 +500,7 @@ __device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__
     if constexpr (GRID) {
       double hi[NC], lo[NC];
       {
-        const double c = ctx->q_to_bsk_d[j][0];
+        const double c = cq[0];
 #pragma unroll
         for (int k = 0; k < NC; k++) {
           const GridDot g(magic, yc[0][k], c);
@@ -470,7 +510,7 @@ __device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__
 #pragma unroll
       for (int i = 1; i < KMAX; i++) {
         if ((u32)i < K) {
-          const double c = ctx->q_to_bsk_d[j][i];
+          const double c = cq[i];
 #pragma unroll
           for (int k = 0; k < NC; k++) grid_dot_add(hi[k], lo[k], yc[i][k], c);
         }
@@ -481,19 +521,16 @@ __device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__
 #pragma unroll
       for (int i = 0; i < KMAX; i++) {
         if ((u32)i < K) {
-          const double c = ctx->q_to_bsk_d[j][i];
+          const double c = cq[i];
 #pragma unroll
           for (int k = 0; k < NC; k++) fl[k] -= ar.mul_var(yc[i][k], c);
         }
       }
     }
-    const MulOpD invq = ctx->inv_q_mod_bsk_d[j];
 #pragma unroll
     for (int k = 0; k < NC; k++) fl[k] = ar.mul_const(ar.reduce(fl[k]), invq);
     if (j < nB) {
-      const MulOpD ip = ctx->inv_punct_B_d[j];
       const ArithD am(ctx->mod[KK + nB]);
-      const double bm = ctx->B_to_msk_d[j];
 #pragma unroll
       for (int k = 0; k < NC; k++) {
         fl[k] = canonical_d(ar, ar.mul_const(fl[k], ip));  // yb_j, canonical
@@ -503,7 +540,7 @@ __device__ __forceinline__ void behz_floor_sk_multi_d(const DevCtx* __restrict__
       for (int i = 0; i < KMAX; i++) {
         if ((u32)i < K) {
           const ArithD aq(ctx->mod[i]);
-          const double c = ctx->B_to_q_d[i][j];
+          const double c = cb[i];
 #pragma unroll
           for (int k = 0; k < NC; k++) oacc[i][k] += aq.mul_var(fl[k], c);
         }
