@@ -135,6 +135,8 @@ def test_3x54bit_mixed_and_seal_auxiliary_bases_give_the_same_bits():
     import sys
     import tempfile
 
+    if any(os.environ.get(k) == "1" for k in ("HIPBFV_SEAL_AUX", "HIPBFV_NO_F64")):
+        pytest.skip("the mixed base is the library's own FP64-pipe auxiliary base: these suite-wide switches remove it (r04 variant suites)")
     script = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
