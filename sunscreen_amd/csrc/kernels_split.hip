@@ -1119,13 +1119,13 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
       for (int k = 0; k < 4; k++) nxt[k] = nat_fetch<PACK, NtSites<L>::tail_ld>(acc + (size_t)Jn * N, N, G::tail_in(t, k));
       const DevMod& mj = ctx->mod[J];
       const ArithD ar(mj);
-      // UNCONDITIONAL requests (an absent operand re-reads a word of the accumulator row, always mapped, and is ignored): a load
+      // UNCONDITIONAL requests (an absent operand reads the first word of the accumulator row -- always mapped, one cached line per wavefront -- and is ignored): a load
       // under `if (extra)` ends its basic block in a copy of the loaded value, i.e. in an s_waitcnt vmcnt(0) that also waits for
       // the row just requested
       u64 bw[4], ex[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const u64* dummy = reinterpret_cast<const u64*>(acc) + G::tail_in(t, k);
+        const u64* dummy = reinterpret_cast<const u64*>(acc);  // one word for the whole wavefront: a single cached line
         const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
         bw[k] = *(has_base ? base + (size_t)op * bstride + off : dummy);
         ex[k] = *(extra ? extra + ((size_t)op * 2) * K * N + off : dummy);
@@ -1150,44 +1150,56 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     }
     return;
   }
-  for (u32 J = 0; J < K; J++) {
-    const DevMod& mj = ctx->mod[J];
-    u64 av[4];
-    bool done = false;
-    if constexpr (MIXED) {
+  // MIXED (8-byte rows of either policy): the same pipelining on raw words -- row J + 1 requested before row J is finished, the
+  // base / addend words requested unconditionally at the start of the row
+  {
+    const u64* accw = reinterpret_cast<const u64*>(acc);
+    const bool has_base = ((base_mask >> c) & 1u) != 0;
+    u64 cur[4], nxt[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = accw[G::tail_in(t, k)];
+    for (u32 J = 0; J < K; J++) {
+      const u32 Jn = J + 1 < K ? J + 1 : J;
+#pragma unroll
+      for (int k = 0; k < 4; k++) nxt[k] = accw[(size_t)Jn * N + G::tail_in(t, k)];
+      const DevMod& mj = ctx->mod[J];
+      u64 bw[4], ex[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
+        bw[k] = *(has_base ? base + (size_t)op * bstride + off : accw);
+        ex[k] = *(extra ? extra + ((size_t)op * 2) * K * N + off : accw);
+      }
+      u64 av[4];
       if (!residue_is_f64(mj)) {
         const ArithI ai(mj);
-        const u64* src = reinterpret_cast<const u64*>(acc) + (size_t)J * N;
         u64 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) w[k] = src[G::tail_in(t, k)];
+        for (int k = 0; k < 4; k++) w[k] = cur[k];
         tail_inv_owned<ArithI, L>(ai, w, twi_base + (size_t)J * N, 0u, t);
 #pragma unroll
         for (int k = 0; k < 4; k++) av[k] = ai.scale_canonical(w[k], mj.ninv);
-        done = true;
+      } else {
+        const ArithD ar(mj);
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = __longlong_as_double((long long)cur[k]);
+        tail_inv_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(twi_base + (size_t)J * N), mj.split_inv_mask, t);
+#pragma unroll
+        for (int k = 0; k < 4; k++) av[k] = ar.scale_canonical(v[k], mj.ninv_d);
       }
-    }
-    if (!done) {
-      const ArithD ar(mj);
-      const double* tw = reinterpret_cast<const double*>(twi_base + (size_t)J * N);
-      double v[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)J * N, N, G::tail_in(t, k));
-      tail_inv_owned<ArithD, L>(ar, v, tw, mj.split_inv_mask, t);
+      for (int k = 0; k < 4; k++) {
+        u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
+        tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+        u64 d = sub_mod(av[k], tk, mj.q);
+        d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
+        u64 bv = has_base ? bw[k] : 0;
+        bv = extra ? add_mod(bv, ex[k], mj.q) : bv;  // a ciphertext added to the result (fused Add node)
+        out[((size_t)op * 2) * K * N + ((size_t)c * K + J) * N + G::tail_out(t, k)] = add_mod(bv, d, mj.q);
+      }
 #pragma unroll
-      for (int k = 0; k < 4; k++) av[k] = ar.scale_canonical(v[k], mj.ninv_d);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const u64 a = av[k];
-      u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
-      tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
-      u64 d = sub_mod(a, tk, mj.q);
-      d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
-      const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
-      u64 bv = ((base_mask >> c) & 1u) ? base[(size_t)op * bstride + off] : 0;
-      if (extra) bv = add_mod(bv, extra[((size_t)op * 2) * K * N + off], mj.q);  // a ciphertext added to the result (fused Add node)
-      out[((size_t)op * 2) * K * N + off] = add_mod(bv, d, mj.q);
+      for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
   }
 }
@@ -1643,6 +1655,21 @@ __device__ __forceinline__ void tail_inv4_scale(const A& ar, const typename A::V
   for (int k = 0; k < 4; k++) out[k] = ar.scale_canonical(v[k], sc);
 }
 
+// the same from four words requested earlier (8-byte rows of either policy: doubles or lazy u64)
+template <class A, int L>
+__device__ __forceinline__ void tail_inv4_scale_raw(const A& ar, const u64 (&raw)[4], u32 t, const typename A::Tw* __restrict__ tw,
+                                                    const typename A::Sc& sc, u32 mask, u64 (&out)[4]) {
+  typename A::V v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if constexpr (std::is_same<typename A::V, double>::value) v[k] = __longlong_as_double((long long)raw[k]);
+    else v[k] = raw[k];
+  }
+  tail_inv_owned<A, L>(ar, v, tw, mask, t);
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[k] = ar.scale_canonical(v[k], sc);
+}
+
 // the same for the FP64 epilogue: reduced doubles out (|out| <= q/2)
 template <int L, bool PACK>
 __device__ __forceinline__ void tail_inv4_scale_d(const ArithD& ar, const NatRaw<PACK> (&raw)[4], const double* __restrict__ tw, const MulOpD& sc,
@@ -1758,39 +1785,59 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
   }
   constexpr bool mixed = !AUXD && PACK;  // the MIXED instantiation: integer data primes, FP64 auxiliary primes, Bsk-side sums in exact FP64
   u64 y[4][KMAX], xb[4][KMAX + 2];
+  // The K + S rows of D are visited in order; the four words of the NEXT row are requested (branch-free: beyond the last row the
+  // last row is re-read) before the current row is transformed (r04: each row used to load, wait and compute in its own block).
+  const u32 last_row = K + S - 1;
+  u64 cur[4], nxt[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) cur[k] = d[G::tail_in(t, k)];
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
+    {
+      const u32 nr = (u32)i + 1 < K ? (u32)i + 1 : K;  // after the last data row: the first auxiliary row
+      const u64* next_row = d + (size_t)(nr < last_row ? nr : last_row) * N;
+#pragma unroll
+      for (int k = 0; k < 4; k++) nxt[k] = next_row[G::tail_in(t, k)];
+    }
     if ((u32)i < K) {
       const DevMod& dm = ctx->mod[i];
       u64 r4[4];
       if (residue_is_f64(dm)) {
         const ArithD ar(dm);
-        tail_inv4_scale<ArithD, L>(ar, reinterpret_cast<const double*>(d + (size_t)i * N), t, reinterpret_cast<const double*>(twi_base + (size_t)i * N),
-                                   ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
+        tail_inv4_scale_raw<ArithD, L>(ar, cur, t, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
       } else {
         const ArithI ar(dm);
-        tail_inv4_scale<ArithI, L>(ar, d + (size_t)i * N, t, twi_base + (size_t)i * N, ctx->intt_scale_q[i], 0u, r4);
+        tail_inv4_scale_raw<ArithI, L>(ar, cur, t, twi_base + (size_t)i * N, ctx->intt_scale_q[i], 0u, r4);
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) y[k][i] = r4[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) cur[k] = nxt[k];  // (rows i >= K keep `cur`: it already holds the first auxiliary row)
     }
   }
 #pragma unroll
   for (int j = 0; j < KMAX + 2; j++) {
+    {
+      const u32 nr = K + (u32)j + 1;
+      const u64* next_row = d + (size_t)(nr < last_row ? nr : last_row) * N;
+#pragma unroll
+      for (int k = 0; k < 4; k++) nxt[k] = next_row[G::tail_in(t, k)];
+    }
     if ((u32)j < S) {
       const DevMod& dm = ctx->mod[KK + j];
       u64 r4[4];
       if constexpr (mixed) {  // the auxiliary rows come back from the FP64 middle kernel as doubles
         const ArithD ar(dm);
-        tail_inv4_scale<ArithD, L>(ar, reinterpret_cast<const double*>(d + (size_t)(K + j) * N), t, reinterpret_cast<const double*>(twi_base + (size_t)(KK + j) * N),
-                                   ctx->intt_scale_bsk_d[j], dm.split_inv_mask, r4);
+        tail_inv4_scale_raw<ArithD, L>(ar, cur, t, reinterpret_cast<const double*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j], dm.split_inv_mask, r4);
       } else {
         const ArithI ar(dm);
-        tail_inv4_scale<ArithI, L>(ar, d + (size_t)(K + j) * N, t, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], 0u, r4);
+        tail_inv4_scale_raw<ArithI, L>(ar, cur, t, twi_base + (size_t)(KK + j) * N, ctx->intt_scale_bsk[j], 0u, r4);
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) xb[k][j] = r4[k];
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = nxt[k];
   }
   // The per-coefficient epilogue is too large to unroll four times; a rolled loop must not index y/xb by k
   // (dynamic indexing puts them in scratch), so each trip consumes row 0 and the rows rotate down.
@@ -1887,13 +1934,13 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
       const DevMod& mj = ctx->mod[J];
       const ArithD ar(mj);
       const double* tw = reinterpret_cast<const double*>(twi_base + (size_t)J * N);
-      // a ciphertext added to the result (fused Add node): its four words, requested UNCONDITIONALLY (absent: a word of the
-      // accumulator row is re-read and ignored) -- a load under `if (extra)` ends its block in an s_waitcnt vmcnt(0) that would
+      // a ciphertext added to the result (fused Add node): its four words, requested UNCONDITIONALLY (absent: the first word of the
+      // accumulator row is read and ignored) -- a load under `if (extra)` ends its block in an s_waitcnt vmcnt(0) that would
       // also wait for the row just requested
       u64 ex[4];
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        ex[k] = *(extra ? extra + ((size_t)op * 2) * K * N + ((size_t)c * K + J) * N + G::tail_out(t, k) : reinterpret_cast<const u64*>(acc) + G::tail_in(t, k));
+        ex[k] = *(extra ? extra + ((size_t)op * 2) * K * N + ((size_t)c * K + J) * N + G::tail_out(t, k) : reinterpret_cast<const u64*>(acc));
       double v[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACKK>(cur[k]);

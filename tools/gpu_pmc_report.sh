@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 python -c "import bench; print(bench.kernel_source_hash())" > $OUT/${KEY}_source_hash.txt
 timeout 400 python bench.py "$@" --no-secondary 2>$OUT/${KEY}_bench.err | tail -1 > $OUT/${KEY}_bench.json
-CMD="python bench.py $* --steps 3 --warmup 1 --settle-ms 0 --no-cpu --no-check --no-secondary --no-power"
+CMD="python bench.py $* --steps 3 --warmup 1 --repeats 1 --settle-ms 0 --no-cpu --no-check --no-secondary --no-power"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o ${KEY}_trace -- $CMD > $OUT/${KEY}_trace.log 2>&1
 python tools/rocprof_summary.py $OUT/${KEY}_trace_results.db > $OUT/${KEY}_kernel_stats.txt 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT -o ${KEY}_pmc_fetch -- $CMD > $OUT/${KEY}_pmc_fetch.log 2>&1

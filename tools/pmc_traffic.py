@@ -38,7 +38,7 @@ OTHER = ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT")
 
 # rocprof kernel name -> the profiler record bench.py reports it under (the fused multiply+relinearize kernels run in the
 # key-switch head / tail slots of the pipeline)
-ALIAS = {"mulrelin_head": "ks_head", "mulrelin_tail": "ks_tail", "ks_mid_int": "ks_mid"}
+ALIAS = {"mulrelin_head": "ks_head", "mulrelin_tail": "ks_tail", "ks_mid_int": "ks_mid", "dot_plain_tab": "plain", "dot_plain2": "plain", "dot_plain": "plain"}
 
 
 def parse(path, counter):
