@@ -911,10 +911,24 @@ __global__ __launch_bounds__(kCoefThreads) void ks_mac_kernel(const DevCtx* __re
   if (k >= n) return;
   const DevMod& mI = ctx->mod[I];
   u128 a0 = 0, a1 = 0;
-  for (u32 J = 0; J < K; J++) {
-    const u64 tv = T[(((size_t)op * KK + I) * K + J) * n + k];
-    a0 += (u128)tv * key[(((size_t)J * 2 + 0) * KK + I) * n + k];
-    a1 += (u128)tv * key[(((size_t)J * 2 + 1) * KK + I) * n + k];
+  // four digits per trip, their twelve words requested together and branch-free (digits beyond K re-read digit K - 1 and count
+  // as zero): one digit per trip was one dependent memory round trip per digit -- 15 in a row at n = 32768, and the whole
+  // latency of this kernel when one ciphertext is relinearised (r04)
+  for (u32 J0 = 0; J0 < K; J0 += 4) {
+    u64 tv[4], ka[4], kb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const u32 J = J0 + (u32)u < K ? J0 + (u32)u : K - 1;
+      tv[u] = T[(((size_t)op * KK + I) * K + J) * n + k];
+      ka[u] = key[(((size_t)J * 2 + 0) * KK + I) * n + k];
+      kb[u] = key[(((size_t)J * 2 + 1) * KK + I) * n + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const u64 tu = J0 + (u32)u < K ? tv[u] : 0;
+      a0 += (u128)tu * ka[u];
+      a1 += (u128)tu * kb[u];
+    }
   }
   ACC[(((size_t)op * 2 + 0) * KK + I) * n + k] = reduce128(a0, mI);
   ACC[(((size_t)op * 2 + 1) * KK + I) * n + k] = reduce128(a1, mI);
@@ -932,15 +946,32 @@ __global__ __launch_bounds__(kCoefThreads) void ks_moddown_kernel(const DevCtx* 
   const DevMod& sp = ctx->mod[KK - 1];
   const u64* acc = ACC + ((size_t)op * 2 + c) * KK * n;
   const u64 tl = add_mod(acc[(size_t)(KK - 1) * n + k], ctx->qsp_half, sp.q);
-  for (u32 J = 0; J < K; J++) {
-    const DevMod& mj = ctx->mod[J];
-    u64 tk = sp.q > mj.q ? reduce64(tl, mj) : tl;
-    tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
-    u64 d = sub_mod(acc[(size_t)J * n + k], tk, mj.q);
-    d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
-    u64 b = ((base_mask >> c) & 1u) ? base[(size_t)op * bstride + ((size_t)c * K + J) * n + k] : 0;
-    if (extra) b = add_mod(b, extra[(((size_t)op * 2 + c) * K + J) * n + k], mj.q);
-    out[(((size_t)op * 2 + c) * K + J) * n + k] = add_mod(b, d, mj.q);
+  const bool has_base = ((base_mask >> c) & 1u) != 0;
+  // four data primes per trip: their accumulator, base and addend words are requested together and unconditionally (an absent
+  // operand reads the first accumulator word -- one cached line per wavefront -- and is ignored; primes beyond K re-read K - 1)
+  for (u32 J0 = 0; J0 < K; J0 += 4) {
+    u64 av[4], bw[4], ex[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const u32 J = J0 + (u32)u < K ? J0 + (u32)u : K - 1;
+      av[u] = acc[(size_t)J * n + k];
+      bw[u] = *(has_base ? base + (size_t)op * bstride + ((size_t)c * K + J) * n + k : acc);
+      ex[u] = *(extra ? extra + (((size_t)op * 2 + c) * K + J) * n + k : acc);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const u32 J = J0 + (u32)u;
+      if (J < K) {
+        const DevMod& mj = ctx->mod[J];
+        u64 tk = sp.q > mj.q ? reduce64(tl, mj) : tl;
+        tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+        u64 d = sub_mod(av[u], tk, mj.q);
+        d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
+        u64 b = has_base ? bw[u] : 0;
+        b = extra ? add_mod(b, ex[u], mj.q) : b;
+        out[(((size_t)op * 2 + c) * K + J) * n + k] = add_mod(b, d, mj.q);
+      }
+    }
   }
 }
 
