@@ -402,6 +402,11 @@ long hipbfv_debug_graph_probe(void *context, const uint64_t *a, const uint64_t *
  * forward reduce mask, inverse reduce mask, split pipelines possible, split forward mask, split inverse mask}; bit p of a mask =
  * every value is reduced mod q at the start of pass p (bit 8 of the split inverse mask: at the start of the tail stages). */
 long hipbfv_debug_f64_plan(uint64_t prime, uint32_t log_n, uint32_t *out6);
+/* Diagnostic, host only (no device): the auxiliary base a context with these parameters gets -- the same values
+ * hipbfv_Context_AuxBase reports for a live context (B, then m_sk last), `flags` likewise.  tests/test_behz_base_bound_cpu.py
+ * replays the BEHZ floor and Shenoy-Kumaresan steps in exact integers over the base returned here. */
+long hipbfv_debug_aux_base(uint64_t poly_modulus_degree, const uint64_t *coeff_primes, uint64_t prime_count, uint64_t plain_modulus,
+                           uint64_t *count, uint64_t *primes, uint64_t capacity, int *flags);
 /* The schedule Run follows, one line per step ("mul_relin members=3 square", "sum members=2 terms=6", "plain_matrix members=256
  * columns=256", ...): `*needed` = bytes including the terminator; `buffer` may be NULL to ask for the size. */
 long hipbfv_Program_Describe(void *program, char *buffer, uint64_t capacity, uint64_t *needed);

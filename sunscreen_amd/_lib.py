@@ -187,6 +187,7 @@ _SIGNATURES = {
     "hipbfv_Program_NumOutputs": [vp, u64p],
     "hipbfv_Program_Describe": [vp, C.c_char_p, C.c_uint64, u64p],
     "hipbfv_debug_f64_plan": [u64, C.c_uint32, C.POINTER(C.c_uint32)],
+    "hipbfv_debug_aux_base": [u64, u64p, u64, u64, u64p, u64p, u64, C.POINTER(C.c_int)],
     "hipbfv_debug_graph_probe": [vp, vp, vp, vp, vp, u64, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "hipbfv_Program_Run": [vp, vp, u64, u64, C.POINTER(C.c_uint32), vpp, u64p, vp, vp, u64, vpp, vp],
     "hipbfv_profile_enable": [vp, C.c_bool],

@@ -2055,6 +2055,24 @@ long hipbfv_debug_f64_plan(uint64_t prime, uint32_t log_n, uint32_t* out6) HIPBF
   return HIPBFV_S_OK;
 HIPBFV_END
 
+// Diagnostic, host only: the auxiliary base Context::create would pick for these parameters (no device is touched: the context
+// is built with device = -1 and dropped).  out = {B_1 .. B_nB, m_sk}; flags as hipbfv_Context_AuxBase.
+long hipbfv_debug_aux_base(uint64_t poly_modulus_degree, const uint64_t* coeff_primes, uint64_t prime_count, uint64_t plain_modulus,
+                           uint64_t* count, uint64_t* primes, uint64_t capacity, int* flags) HIPBFV_BEGIN
+  if (!coeff_primes || !count) return HIPBFV_E_POINTER;
+  std::string err;
+  std::unique_ptr<hipbfv::Context> c(hipbfv::Context::create((u32)poly_modulus_degree, std::vector<u64>(coeff_primes, coeff_primes + prime_count), plain_modulus, -1, &err));
+  if (!c) return fail(HIPBFV_E_INVALIDARG, err.c_str());
+  const hipbfv::DevCtx& d = c->host();
+  *count = d.S;
+  if (flags) *flags = (d.aux_f64 ? 1 : 0) | (d.pack_mul ? 2 : 0) | (d.pack_ks ? 4 : 0) | (d.conv_grid ? 8 : 0) | (d.aux_mixed ? 16 : 0) | (d.pack_mul == 2 ? 32 : 0);
+  if (primes) {
+    if (capacity < d.S) return fail(HIPBFV_E_INVALIDARG, "capacity too small");
+    for (uint32_t j = 0; j < d.S; j++) primes[j] = d.mod[d.KK + j].q;
+  }
+  return HIPBFV_S_OK;
+HIPBFV_END
+
 // Diagnostic (tools/graph_probe.py): one multiply + relinearize of a single ciphertext pair, (1) launched kernel by kernel as
 // the handle-level calls do, (2) the same launches captured once into a hipGraph and replayed.  Both are timed from the host
 // with one stream synchronisation per repetition, i.e. what a caller of the SEAL-named entry points waits for.

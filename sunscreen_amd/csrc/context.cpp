@@ -410,6 +410,21 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
   // primes below 2^48 satisfying that bound, so that the auxiliary residues run on the FP64 pipe as well
   // (bit-identical results; tests compare against the oracle, which keeps SEAL's base).
   const int need_bits = 32 + t_bits + q_bits;
+  // [r04] What the base has to hold, derived instead of copied.  Every row computes its residues exactly whatever the size of
+  // the integers behind them; the base size enters in ONE place, the Shenoy-Kumaresan step.  sm_mrq leaves operands
+  // |x'| <= q/2 * (1 + 2K/m~); a tensor coefficient is a sum of at most m = min(size_a, size_b) <= 8 negacyclic products
+  // (Evaluator::multiply accepts size_a + size_b <= 16), so |c'| <= m * N * q^2/4 * (1 + eps) <= 2 N q^2 (1 + eps).  With
+  // T = t * c', fast_floor delivers F = floor(T/q) - a', a' in [0, K), so |F| <= 2 t N q (1 + eps) + K + 1, and the conversion
+  // Bsk -> q recovers F exactly iff its correction alpha = e - floor(F/B), e in [0, nB), is below m_sk/2 in magnitude:
+  // |F| < B * (m_sk/2 - nB - 1).  B * m_sk >= 8 * 2^bits(t) * N * 2^bits(q) = 2^(bits(t) + log2 N + bits(q) + 3) satisfies that
+  // with a factor of two to spare (four for the 2 x 2 multiply the programs issue).  SEAL's 2^(32 + bits(t) + bits(q)) is the
+  // same rule with 32 bits reserved for m * N (rnstool.cpp's comment); at N = 16384 the 15 bits between the two are one
+  // auxiliary prime fewer (17 rows in the multiply instead of 18), at 3 x 54 bits four 49-bit primes instead of five.
+  // HIPBFV_SEAL_BOUND=1 keeps SEAL's sizing (A/B, tests).  tests/test_behz_base_bound_cpu.py replays floor +
+  // Shenoy-Kumaresan in exact integers at the edge of the bound for the bases this code picks.
+  int own_need_bits = t_bits + (int)h.logn + q_bits + 3;
+  if (const char* env = std::getenv("HIPBFV_SEAL_BOUND"))
+    if (env[0] == '1') own_need_bits = need_bits;
   std::vector<u64> B;
   u64 m_sk = 0;
   bool own_base = false, data_f64 = true;
@@ -432,21 +447,28 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     if (!data_f64) want = want && K <= 4 && h.logn >= 12 && h.logn <= 14;
     if (const char* env = std::getenv("HIPBFV_NO_MIXED_AUX"))
       if (env[0] == '1' && !data_f64) want = false;
+    // the fewest primes, and for that count the smallest size, whose ACTUAL product reaches 2^own_need_bits (find_primes
+    // returns the largest primes of a size first, so `cnt` primes of `bits` bits are worth almost cnt * bits bits).  48 bits is
+    // the ceiling: the packed intermediates and the FP64 rows of the mixed base are written for auxiliary primes below 2^48.
+    const int max_bits = 48;
     for (u32 cnt = 2; want && !own_base && cnt <= (u32)kMaxBsk; cnt++) {
-      int bits = (need_bits + 1 + (int)cnt - 1) / (int)cnt + 1;  // cnt primes >= 2^(bits-1): product >= 2^(need_bits+1)
-      if (bits > 48) continue;
-      if (bits < 36) bits = 36;
-      std::vector<u64> cand = find_primes(two_n, bits, cnt + key_primes.size());
-      std::vector<u64> pick;
-      for (u64 p : cand) {
-        if (pick.size() == cnt) break;
-        if (std::find(key_primes.begin(), key_primes.end(), p) != key_primes.end() || t % p == 0 || !fp64_ok(p)) continue;
-        pick.push_back(p);
+      for (int bits = std::max(36, (own_need_bits + (int)cnt - 1) / (int)cnt); bits <= max_bits && !own_base; bits++) {
+        std::vector<u64> cand = find_primes(two_n, bits, cnt + key_primes.size());
+        std::vector<u64> pick;
+        for (u64 p : cand) {
+          if (pick.size() == cnt) break;
+          if (std::find(key_primes.begin(), key_primes.end(), p) != key_primes.end() || t % p == 0 || !fp64_ok(p)) continue;
+          pick.push_back(p);
+        }
+        if (pick.size() != cnt) continue;
+        BigUint prod;
+        prod.w[0] = 1;
+        for (u64 p : pick) prod.mul(p);
+        if (prod.bits() <= own_need_bits) continue;  // product < 2^own_need_bits
+        own_base = true;
+        m_sk = pick[0];
+        B.assign(pick.begin() + 1, pick.end());
       }
-      if (pick.size() != cnt) continue;
-      own_base = true;
-      m_sk = pick[0];
-      B.assign(pick.begin() + 1, pick.end());
     }
   }
   // the split multiply (kernels_split.hip) is instantiated for at most 4 data and 6 auxiliary primes: a large plain
@@ -595,11 +617,22 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     for (u32 i = 0; i < K; i++) qmax = std::max(qmax, (long double)q[i]);
     for (u64 p : Bsk) bmax = std::max(bmax, (long double)p), bmin = std::min(bmin, (long double)p);
     double magic = 0;
-    const bool ok = plan_grid_dot(qmax, bmax, K + 1, bmin, bmax, &magic);
+    bool ok = plan_grid_dot(qmax, bmax, K + 1, bmin, bmax, &magic);
+    // [r04] 49-bit data primes beside the 48-bit auxiliary primes of the derived base bound (n = 16384: nine of them) are one
+    // bit over that plan.  The floor's sums have exactly K terms, and a constant c mod Bsk_j may as well be its CENTRED
+    // representative c - Bsk_j (|c| <= Bsk_j / 2): every consumer of q_to_bsk_d forms y * c with a sign-symmetric reduction
+    // (ArithD::mul_var, GridDot) and the sums are reduced before use, so the canonical results are the same; the plan then
+    // closes with one bit to spare (tests/native/griddot_check.cpp: 49 x 47 bits, 8 terms, signed constants).
+    bool centred = false;
+    if (!ok) ok = centred = plan_grid_dot(qmax, std::floor(bmax / 2) + 1, K, bmin, bmax, &magic);
+    if (const char* env = std::getenv("HIPBFV_NO_GRID"))
+      if (env[0] == '1') ok = false;
     h.conv_grid = ok ? 1u : 0u;
     h.conv_magic = ok ? magic : 0.0;
-    if (const char* env = std::getenv("HIPBFV_NO_GRID"))
-      if (env[0] == '1') h.conv_grid = 0;
+    if (ok && centred)
+      for (u32 j = 0; j < h.S; j++)
+        for (u32 i = 0; i < K; i++)
+          if (h.q_to_bsk[j][i] > Bsk[j] / 2) h.q_to_bsk_d[j][i] = -(double)(Bsk[j] - h.q_to_bsk[j][i]);
   }
 
   if (h.aux_mixed) {  // the Bsk-side constants in FP64 form (every auxiliary prime is FP64-capable by selection)
@@ -771,6 +804,7 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
   }
 
   // ---- upload ----
+  if (device < 0) return c.release();  // host-only view (hipbfv_debug_aux_base): the tables above, nothing on a device
   if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
   const size_t tw_bytes = twf.size() * sizeof(MulOp);
   if (hipMalloc((void**)&c->tw_fwd_, tw_bytes) != hipSuccess || hipMalloc((void**)&c->tw_inv_, tw_bytes) != hipSuccess ||

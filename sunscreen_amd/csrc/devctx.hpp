@@ -100,7 +100,8 @@ struct DevCtx {
   // 48-bit packed intermediates in the split pipelines (kernels_split.hip nat_load/nat_store): every modulus involved is an
   // FP64-policy prime below 2^48.  pack_ks: the KK key primes; pack_mul: aux_f64 and the K data + S auxiliary primes.
   // pack_mul == 2 (r04): PER ROW -- every auxiliary prime is below 2^48 and some data primes are (the SEAL default set of
-  // N = 16384 has three 48-bit and five 49-bit data primes beside ten 45-bit auxiliary primes: 13 of 18 rows travel as 6 bytes);
+  // N = 16384 has three 48-bit and five 49-bit data primes beside nine 48-bit auxiliary primes -- ten 45-bit ones when this was
+  // measured: 13 of 18 rows travel as 6 bytes);
   // mul_row_packed[r] says which rows of ext / D (r < K: data prime r, else auxiliary prime r - K)
   unsigned char pack_ks, pack_mul, pad3[2];
   MulOpD ext_scale_d[kMaxKey];

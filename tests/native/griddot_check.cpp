@@ -29,7 +29,8 @@ int main() {
   std::mt19937_64 rng(0x5EA1u);
   // (source modulus bits, target modulus bits, terms, bits of the modulus the sum is reduced by)
   const Case cases[] = {{44, 46, 5, 46}, {46, 44, 5, 44}, {44, 46, 4, 46}, {49, 45, 9, 45}, {45, 49, 10, 49}, {37, 40, 3, 40},
-                        {50, 48, 5, 48}, {48, 50, 5, 50}, {50, 48, 9, 48}, {36, 36, 2, 36}, {20, 20, 8, 20}, {49, 45, 18, 45}};
+                        {50, 48, 5, 48}, {48, 50, 5, 50}, {50, 48, 9, 48}, {36, 36, 2, 36}, {20, 20, 8, 20}, {49, 45, 18, 45},
+                        {49, 47, 8, 48} /* r04: 49-bit data primes, CENTRED constants of 48-bit auxiliary primes */};
   long long total = 0;
   int planned = 0;
   for (const Case& cs : cases) {
@@ -59,6 +60,7 @@ int main() {
         y[i] = (long long)yv;
         c[i] = (long long)cv;
         if (mode == 4 && (rng() & 1)) y[i] = -y[i];  // signed operands (the centred r_mtilde and alpha_sk terms)
+        if ((mode == 4 || mode == 3) && (rng() & 1)) c[i] = -c[i];  // centred constants (context.cpp, r04)
       }
       GridDot gd(magic, (double)y[0], (double)c[0]);
       i128 exact = (i128)y[0] * c[0];

@@ -401,7 +401,9 @@ _own_base_off = os.environ.get("HIPBFV_SEAL_AUX") == "1" or os.environ.get("HIPB
 @pytest.mark.skipif(_own_base_off, reason="the own auxiliary base is switched off by the environment")
 def test_auxiliary_base_choice_and_bound():
     """The BEHZ auxiliary base is internal to multiply.  FP64-capable data primes -> the library's own base of
-    primes below 2^48 whose product covers the same bound SEAL sizes its base for (2^(32 + bits(t) + bits(q)));
+    primes below 2^48 whose product covers 2^(bits(t) + log2 n + bits(q) + 3) (context.cpp derives it; SEAL reserves 32 bits
+    where this has log2 n + 3, and HIPBFV_SEAL_BOUND=1 sizes the base SEAL's way; tests/test_behz_base_bound_cpu.py replays
+    the steps the bound protects in exact integers);
     wide data primes where the split multiply runs (K <= 4, 4096 <= n <= 16384) -> the MIXED base: the same kind of
     auxiliary primes (FP64 rows in the middle kernel) beside integer data rows; wide data primes elsewhere -> SEAL's own
     61-bit base, identical to the oracle's."""
@@ -416,7 +418,8 @@ def test_auxiliary_base_choice_and_bound():
             assert p < 2**48 and p % (2 * n) == 1 and p not in primes and O.is_prime(p)
             prod *= p
         assert len(set(ctx.aux_primes)) == len(ctx.aux_primes)
-        assert prod.bit_length() > 32 + t.bit_length() + q.bit_length()
+        reserve = 32 if os.environ.get("HIPBFV_SEAL_BOUND") == "1" else n.bit_length() - 1 + 3
+        assert prod.bit_length() > reserve + t.bit_length() + q.bit_length()
 
     n, primes, t = params("default_8192_17")
     ctx = Context.from_raw(n, primes, t)
@@ -443,7 +446,10 @@ def test_auxiliary_base_choice_and_bound():
 def test_multiply_large_plain_modulus_own_base(n, tbits):
     """Large plain moduli push the integers that pass through the auxiliary base towards its size bound
     (floor(t*c/q) grows with t): the own-base product must still equal the oracle's (SEAL-base) product, on
-    random operands and on operands with every residue at q_i - 1."""
+    random operands, on operands with every residue at q_i - 1, and on the operands that drive the tensor to its largest
+    magnitude: every coefficient of every polynomial = floor(q/2) (the Montgomery step leaves |x'| ~ q/2 whatever the sign,
+    the negacyclic products then reach N * q^2/4 at coefficient N - 1 and -(N - 1) * q^2/4 at coefficient 0, and c1 is two of
+    them), and the same with alternating signs."""
     from sunscreen_amd import Context
     from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
 
@@ -455,13 +461,55 @@ def test_multiply_large_plain_modulus_own_base(n, tbits):
     ev = BatchEvaluator(ctx)
     K = len(primes) - 1
     rng = np.random.default_rng(tbits)
-    a = np.stack([rng.integers(0, q, (3, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
-    b = np.stack([rng.integers(0, q, (3, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    a = np.stack([rng.integers(0, q, (5, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    b = np.stack([rng.integers(0, q, (5, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    Q = 1
+    for q in primes[:K]:
+        Q *= q
+    half = Q // 2
+    sign = np.where(np.arange(n) % 2 == 0, 1, -1)
     for i, q in enumerate(primes[:K]):
         a[2, :, i, :] = q - 1
         b[2, :, i, :] = q - 1
+        a[3, :, i, :] = half % q
+        b[3, :, i, :] = half % q
+        # +half, -half, +half, ... against all +half: the other sign pattern of the extreme sums
+        a[4, :, i, :] = np.where(sign > 0, half % q, (Q - half) % q).astype(np.uint64)
+        b[4, :, i, :] = half % q
     m = to_host(ev.multiply(to_device(a), to_device(b)))
-    for i in range(3):
+    for i in range(5):
+        assert (m[i] == o.multiply(a[i], b[i])).all(), i
+
+
+@pytest.mark.skipif(_own_base_off, reason="the own auxiliary base is switched off by the environment")
+@pytest.mark.parametrize("n,tbits,size", [(4096, 30, 8), (8192, 50, 4), (8192, 17, 3)])
+def test_multiply_extreme_operands_of_larger_sizes_own_base(n, tbits, size):
+    """Evaluator::multiply accepts size_a + size_b <= 16: a coefficient of the tensor is then a sum of up to 8 negacyclic
+    products, the factor the base bound reserves its 3 bits for (context.cpp).  All-floor(q/2) operands of size `size` x `size`
+    reach that sum; the product equals the oracle's (SEAL's base, sized with 32 bits of reserve)."""
+    from sunscreen_amd import Context
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    primes = O.bfv_default(n)
+    t = O.plain_batching(n, tbits)
+    o = O.Oracle(n, primes, t)
+    ctx = Context.from_raw(n, primes, t)
+    assert ctx.aux_fp64
+    ev = BatchEvaluator(ctx)
+    K = len(primes) - 1
+    Q = 1
+    for q in primes[:K]:
+        Q *= q
+    half = Q // 2
+    rng = np.random.default_rng(size)
+    a = np.stack([rng.integers(0, q, (2, size, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    b = np.stack([rng.integers(0, q, (2, size, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    for i, q in enumerate(primes[:K]):
+        a[1, :, i, :] = half % q
+        b[1, :, i, :] = half % q
+    m = to_host(ev.multiply(to_device(a), to_device(b)))
+    assert m.shape[1] == 2 * size - 1
+    for i in range(2):
         assert (m[i] == o.multiply(a[i], b[i])).all(), i
 
 
