@@ -305,10 +305,13 @@ __device__ __forceinline__ void behz_floor_sk_coeff_mixed(const DevCtx* __restri
   }
 #pragma unroll
   for (int c = 0; c < NC; c++) {
-    // alpha_sk as the small signed integer it stands for (SEAL branches on alpha_sk > m_sk/2 to the same effect)
+    // alpha_sk as the signed integer it stands for (SEAL branches on alpha_sk > m_sk/2 to the same effect)
     const double alpha = am.reduce(am.mul_const(am.reduce(amsk[c] - fl_msk[c]), ctx->inv_B_mod_msk_d));
     const bool neg = alpha < 0.0;
-    const u64 amag = (u64)(u32)(int)(neg ? -alpha : alpha);  // |alpha_sk| <= |B|
+    // alpha_sk = e - floor(F / B), e in [0, nB): as large as F / B, i.e. up to m_sk / 4 under the derived base bound (context.cpp;
+    // a 32-bit cast here held only while SEAL's sizing kept |F / B| below 2^25 -- the fuzz suite caught it).  An exact integer
+    // below 2^48 in magnitude: its bits come out of the double exactly.
+    const u64 amag = ArithD::to_bits(neg ? -alpha : alpha);
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
       if ((u32)i < K) {

@@ -461,8 +461,9 @@ def test_multiply_large_plain_modulus_own_base(n, tbits):
     ev = BatchEvaluator(ctx)
     K = len(primes) - 1
     rng = np.random.default_rng(tbits)
-    a = np.stack([rng.integers(0, q, (5, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
-    b = np.stack([rng.integers(0, q, (5, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    cnt = 20  # beyond the few-operations threshold (evaluator.cpp few_for_split_mul): the split pipelines run these
+    a = np.stack([rng.integers(0, q, (cnt, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    b = np.stack([rng.integers(0, q, (cnt, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
     Q = 1
     for q in primes[:K]:
         Q *= q
@@ -477,8 +478,12 @@ def test_multiply_large_plain_modulus_own_base(n, tbits):
         a[4, :, i, :] = np.where(sign > 0, half % q, (Q - half) % q).astype(np.uint64)
         b[4, :, i, :] = half % q
     m = to_host(ev.multiply(to_device(a), to_device(b)))
-    for i in range(5):
+    for i in (0, 1, 2, 3, 4, cnt - 1):
         assert (m[i] == o.multiply(a[i], b[i])).all(), i
+    # and the same five through the whole-polynomial kernels (a call of five operands stays below the threshold at n = 8192)
+    if n == 8192:
+        m5 = to_host(ev.multiply(to_device(a[:5]), to_device(b[:5])))
+        assert (m5 == m[:5]).all()
 
 
 @pytest.mark.skipif(_own_base_off, reason="the own auxiliary base is switched off by the environment")
@@ -510,6 +515,44 @@ def test_multiply_extreme_operands_of_larger_sizes_own_base(n, tbits, size):
     m = to_host(ev.multiply(to_device(a), to_device(b)))
     assert m.shape[1] == 2 * size - 1
     for i in range(2):
+        assert (m[i] == o.multiply(a[i], b[i])).all(), i
+
+
+@pytest.mark.skipif(_own_base_off or os.environ.get("HIPBFV_NO_MIXED_AUX") == "1", reason="the mixed auxiliary base is switched off by the environment")
+@pytest.mark.parametrize("n,bits,tbits,size", [(8192, [54, 54, 54, 56], 17, 2), (16384, [52, 54], 26, 2), (4096, [57, 51], 20, 2),
+                                               (16384, [58, 52, 59, 52, 53], 25, 2), (8192, [54, 54, 54, 56], 40, 3)])
+def test_multiply_extreme_operands_mixed_base(n, bits, tbits, size):
+    """The same extreme operands through the MIXED base (integer data rows, FP64 auxiliary rows).  Under the derived base bound
+    the Shenoy-Kumaresan correction alpha_sk = e - floor(F/B) is as large as m_sk/4 -- the 32-bit cast the mixed tail used to
+    apply to it (adequate under SEAL's sizing, |F/B| < 2^25) gave wrong products on three parameter sets of the fuzz suite the
+    day the bound changed; this test holds the largest |F| there is: all-floor(q/2) operands, both sign patterns, and random
+    ones, against the oracle (SEAL's base)."""
+    from sunscreen_amd import Context
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    primes = O.coeff_modulus_create(n, bits)
+    t = O.plain_batching(n, tbits)
+    o = O.Oracle(n, primes, t)
+    ctx = Context.from_raw(n, primes, t)
+    assert ctx.aux_mixed
+    ev = BatchEvaluator(ctx)
+    K = len(primes) - 1
+    Q = 1
+    for q in primes[:K]:
+        Q *= q
+    half = Q // 2
+    rng = np.random.default_rng(n + size)
+    cnt = 20  # beyond the few-operations threshold: the split pipelines (mul_head / mul_mid / mul_tail) when size == 2
+    a = np.stack([rng.integers(0, q, (cnt, size, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    b = np.stack([rng.integers(0, q, (cnt, size, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    sign = np.where(np.arange(n) % 2 == 0, 1, -1)
+    for i, q in enumerate(primes[:K]):
+        a[1, :, i, :] = half % q
+        b[1, :, i, :] = half % q
+        a[2, :, i, :] = np.where(sign > 0, half % q, (Q - half) % q).astype(np.uint64)
+        b[2, :, i, :] = half % q
+    m = to_host(ev.multiply(to_device(a), to_device(b)))
+    for i in (0, 1, 2, cnt - 1):
         assert (m[i] == o.multiply(a[i], b[i])).all(), i
 
 
