@@ -16,7 +16,9 @@
  *   - every decrypt-and-compare evaluator test (seal_fhe/src/bfv_evaluator.rs:322-970,
  *     seal_fhe/tests/assumptions.rs, sunscreen_runtime/src/run.rs:546-882).
  * Ciphertext-bit parity of multiply/relinearize/rotate with real SEAL is NOT pinned by any
- * reference test ("parity unpinned" for those bits).
+ * reference test ("parity unpinned" for those bits).  What stands in for it
+ * on multiply: tests/test_oracle_behz_exact.py carries BEHZ out over the integers (no auxiliary
+ * base) and gets this library's bits, random and extreme operands, n = 1024 ... 16384.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
  *
