@@ -18,7 +18,9 @@
  * Ciphertext-bit parity of multiply/relinearize/rotate with real SEAL is NOT pinned by any
  * reference test ("parity unpinned" for those bits).  What stands in for it
  * on multiply: tests/test_oracle_behz_exact.py carries BEHZ out over the integers (no auxiliary
- * base) and gets this library's bits, random and extreme operands, n = 1024 ... 16384.
+ * base) and gets this library's bits, random and extreme operands, n = 1024 ... 16384;
+ * tests/test_oracle_keyswitch_exact.py / test_oracle_plain_exact.py do the same for relinearize, apply_galois,
+ * mod_switch_to_next and the plaintext operations.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
  *
