@@ -26,7 +26,7 @@ def _operands(q, n, rng):
     return a, b
 
 
-@pytest.mark.parametrize("n,bits,tbits", [(4096, None, 17), (8192, None, 20), (8192, [54, 54, 54, 56], 20)])
+@pytest.mark.parametrize("n,bits,tbits", [(4096, None, 17), (8192, None, 20), (8192, [54, 54, 54, 56], 20), (16384, None, 20)])
 def test_multiply_equals_behz_over_the_integers(n, bits, tbits):
     from sunscreen_amd import Context
     from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
