@@ -10,7 +10,7 @@ TOP=$ROOT/build/variants/src_$TAG
 SRC=$TOP/sunscreen_amd/csrc   # same depth as the tree: capi.cpp includes ../../include/hipbfv.h
 rm -rf $TOP; mkdir -p $SRC $ROOT/sunscreen_amd/lib/variants
 ln -s $ROOT/include $TOP/include
-cp $ROOT/sunscreen_amd/csrc/*.hip $ROOT/sunscreen_amd/csrc/*.hpp $ROOT/sunscreen_amd/csrc/*.cpp $ROOT/sunscreen_amd/csrc/exports.map $SRC/
+cp $ROOT/sunscreen_amd/csrc/*.hip $ROOT/sunscreen_amd/csrc/*.hpp $ROOT/sunscreen_amd/csrc/*.cpp $ROOT/sunscreen_amd/csrc/exports.map $ROOT/sunscreen_amd/csrc/Makefile $SRC/
 ( cd $TOP && patch -p1 < $PATCH )
 BASE="-O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden --offload-arch=gfx950"
 OBJS=""
