@@ -736,6 +736,8 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
       u64 inv;
       invm(qsp % q[i], q[i], &inv);
       h.inv_qsp_mod_q[i] = make_mulop(inv, q[i]);
+      h.inv_qsp_mod_q_d[i] = make_mulop_d(inv, q[i]);
+      h.qsp_half_mod_q_d[i] = (double)h.qsp_half_mod_q[i];
     }
   }
 

@@ -140,6 +140,8 @@ struct DevCtx {
   u64 qsp_half;                        // q_sp >> 1
   u64 qsp_half_mod_q[kMaxKey];         // (q_sp >> 1) mod q_i
   MulOp inv_qsp_mod_q[kMaxKey];        // q_sp^{-1} mod q_i
+  MulOpD inv_qsp_mod_q_d[kMaxKey];     // the same constants for the FP64 mod-down (moddown_d.hpp): valid for FP64-policy q_i
+  double qsp_half_mod_q_d[kMaxKey];
 
   // ---- the steps either side of the evaluator (kernels_client.hip): BatchEncoder, Decryptor, Encryptor ----
   u32 batching;                        // t is a prime == 1 (mod 2N): mod[t_mod] = t with NTT tables

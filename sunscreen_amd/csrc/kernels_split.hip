@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "behzcore.hpp"
+#include "moddown_d.hpp"
 #include "kernels.hpp"
 #include "nttcore.hpp"
 
@@ -1107,6 +1108,9 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
   }
   const u64 qsp = ctx->mod[KK - 1].q;
   if constexpr (!MIXED) {
+    double tld[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) tld[k] = ArithD::from_u64(tl[k]);
     // all-FP64 key primes: accumulator row J + 1 is requested before row J is finished, and the base / addend words of a row
     // are requested as one group at its start (r04: every one of them used to sit alone behind its own test and wait)
     NatRaw<PACK> cur[4], nxt[4];
@@ -1134,16 +1138,18 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACK>(cur[k]);
       tail_inv_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(twi_base + (size_t)J * N), mj.split_inv_mask, t);
+      // the mod-down in exact FP64 on the representative the transform leaves (moddown_d.hpp): no canonical u64 of `a`, no 64-bit
+      // Barrett / Shoup chain per output value
+      const MulOpD iw = ctx->inv_qsp_mod_q_d[J];
+      const double hf = ctx->qsp_half_mod_q_d[J];
+      const bool p_above_q = qsp > mj.q;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
-        u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
-        tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
-        u64 d = sub_mod(a, tk, mj.q);
-        d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
-        u64 bv = has_base ? bw[k] : 0;
-        bv = extra ? add_mod(bv, ex[k], mj.q) : bv;  // a ciphertext added to the result (fused Add node)
-        out[((size_t)op * 2) * K * N + ((size_t)c * K + J) * N + G::tail_out(t, k)] = add_mod(bv, d, mj.q);
+        const double s = ar.mul_const(v[k], mj.ninv_d);
+        double bd = has_base ? ArithD::from_u64(bw[k]) : 0.0;
+        bd += extra ? ArithD::from_u64(ex[k]) : 0.0;  // a ciphertext added to the result (fused Add node)
+        const double r = mod_down_d(ar.q, ar.qinv, iw.w, iw.wq, hf, p_above_q, s, tld[k], bd);
+        out[((size_t)op * 2) * K * N + ((size_t)c * K + J) * N + G::tail_out(t, k)] = ArithD::to_bits(r);
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) cur[k] = nxt[k];
@@ -1919,6 +1925,9 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
     for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
   }
   const u64 qsp = ctx->mod[KK - 1].q;
+  double tld[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) tld[k] = ArithD::from_u64(tl[k]);
   // accumulator row J + 1 is requested (branch-free: rows beyond K re-read row K - 1) before row J is finished
   NatRaw<PACKK> cur[4], nxt[4];
 #pragma unroll
@@ -1945,17 +1954,17 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACKK>(cur[k]);
       tail_inv_owned<ArithD, L>(ar, v, tw, mj.split_inv_mask, t);
+      const MulOpD iw = ctx->inv_qsp_mod_q_d[J];
+      const double hf = ctx->qsp_half_mod_q_d[J];
+      const bool p_above_q = qsp > mj.q;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const u64 a = ar.scale_canonical(v[k], mj.ninv_d);
-        u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
-        tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
-        u64 dd = sub_mod(a, tk, mj.q);
-        dd = mul_shoup(dd, ctx->inv_qsp_mod_q[J], mj.q);
+        const double s = ar.mul_const(v[k], mj.ninv_d);
         const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
-        u64 bv = basev[J][k];
-        bv = extra ? add_mod(bv, ex[k], mj.q) : bv;
-        out[((size_t)op * 2) * K * N + off] = add_mod(bv, dd, mj.q);
+        double bd = ArithD::from_u64(basev[J][k]);
+        bd += extra ? ArithD::from_u64(ex[k]) : 0.0;
+        const double r = mod_down_d(ar.q, ar.qinv, iw.w, iw.wq, hf, p_above_q, s, tld[k], bd);  // moddown_d.hpp
+        out[((size_t)op * 2) * K * N + off] = ArithD::to_bits(r);
       }
     }
 #pragma unroll
