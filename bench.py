@@ -91,6 +91,8 @@ def parse(argv=None):
     ap.set_defaults(power=True)
     ap.add_argument("--no-secondary", action="store_true", help="headline run only: skip the n=16384 mul+relin and the NTT workload "
                     "that the default run reports under `secondary`")
+    ap.add_argument("--full-line", action="store_true", help="print every field of every secondary workload (the default line keeps the secondary records "
+                    "compact and ends in `summary`, so that the tail a driver stores carries every quantity of the metric)")
     ap.add_argument("--check-items", type=int, default=64, help="mulrelin: items compared bit for bit with the oracle (BASELINE.md section 3: >= 64)")
     ap.add_argument("--check-sets", type=int, default=8, help="chi_sq / dot_prod: input sets compared bit for bit with the oracle's graph interpreter")
     ap.add_argument("--gather", action="store_true", help="N>1: also time one gather of the result batch to rank 0 (reported as result_gather_ms, never part of value)")
@@ -880,6 +882,7 @@ def main():
                 ("dot_prod_n16384", dict(workload="dot_prod", n=16384, batch=max(q4 // 4, 1))),
                 ("pir_n16384_2p17", dict(workload="pir", n=16384, batch=max(q4 // 4, 1), pir_rows=max(q4 // 2, 1))),  # 512 x 256 = 2^17 entries, 128 GiB
             ]
+        failed = False
         for key, over in jobs:
             sub = copy.copy(args)
             for k, v in over.items():
@@ -888,16 +891,93 @@ def main():
 
             gc.collect()
             torch.cuda.empty_cache()
-            rec = measure(sub, env, secondary=True)
+            if sub.workload == "pir":
+                # the database alone is rows x cols x K x n words in transform form (128 GiB for 512 x 256 at n = 16384): on a device
+                # that does not have that much free, say so instead of running out of memory with the headline unprinted
+                from oracle import bfv_oracle as O_
+
+                need = (sub.pir_rows or sub.batch) * sub.batch * (len(O_.bfv_default(sub.n)) - 1) * sub.n * 8 + (12 << 30)
+                free = torch.cuda.mem_get_info()[0]
+                if free < need:
+                    second[key] = {"skipped": f"needs {need >> 30} GiB of device memory, {free >> 30} GiB free"}
+                    continue
+            # a failure in one secondary job (out of memory next to another process, a parity assertion) must not lose the headline
+            # measured above: it is recorded under the job's key, the line is printed, and the exit status says so
+            try:
+                rec = measure(sub, env, secondary=True)
+            except Exception as e:  # noqa: BLE001 -- recorded, and the process exits non-zero after printing
+                failed = True
+                if env.rank == 0:
+                    second[key] = {"error": f"{type(e).__name__}: {e}"[:300], "parity_ok": False}
+                continue
             if rec is not None:
-                second[key] = {k: rec[k] for k in ("metric", "value", "unit", "steps", "warmup", "repeats", "values", "spread", "ms_per_step", "scaling", "config",
-                                                   "roofline", "valu", "kernels_ms_per_step", "cpu_baseline", "parity")}
+                second[key] = rec if args.full_line else compact_secondary(rec)
         if line is not None:
             line["secondary"] = second
     if line is not None:
+        # LAST key: the quantities BASELINE.json's metric names, one small object each (the driver keeps the tail of the line)
+        line["summary"] = summary_of(line)
+        if not args.full_line:
+            trim_headline(line)
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()
+    if headline and not args.no_secondary and failed:
+        sys.exit(1)
+
+
+SUMMARY_KEYS = {"mulrelin_n16384": "mulrelin_n16384", "ntt_n8192": "ntt_n8192", "mulrelin_n8192_bits54-54-54-56": "3x54", "chi_sq_n16384": "chi_sq_1024",
+                "chi_sq_n16384_share128": "chi_sq_128", "dot_prod_n16384": "dot_prod", "pir_n16384_2p17": "pir_2p17"}
+
+
+def summary_entry(rec):
+    """{value, ms_per_step, frac, whole_op_frac, traffic_ratio, parity_ok} of one measured workload."""
+    if "value" not in rec:
+        return {k: rec[k] for k in ("error", "skipped") if k in rec} | {"parity_ok": False}
+    roof = rec.get("roofline") or {}
+    whole = roof.get("whole_op", {}).get("frac", roof.get("whole_op_frac"))
+    ratio = roof.get("traffic_ratio")
+    if ratio is None and roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
+        ratio = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 3)
+    parity = rec.get("parity", "")
+    return {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "frac": roof.get("frac"), "whole_op_frac": whole, "traffic_ratio": ratio,
+            "parity_ok": rec.get("parity_ok", parity.startswith(("bit-exact", "INTT(NTT(x)) == x", "lookup decrypts", "all ")))}
+
+
+def summary_of(line):
+    name = "mulrelin_n8192" if line["config"].get("poly_modulus_degree") == 8192 and line["metric"] == "bfv_mul_relin_ops_per_sec" else "headline"
+    out = {name: summary_entry(line)}
+    for key, rec in (line.get("secondary") or {}).items():
+        out[SUMMARY_KEYS.get(key, key)] = summary_entry(rec)
+    return out
+
+
+def compact_secondary(rec):
+    """A secondary workload's record without the prose (profiles/README.md explains every field; `--full-line` prints everything):
+    what was run, the measurement, the roofline figures, the CPU baseline and whether the parity gate passed."""
+    roof = rec.get("roofline") or {}
+    cpu = rec.get("cpu_baseline") or {}
+    kern = sorted((rec.get("kernels_ms_per_step") or {}).items(), key=lambda kv: -kv[1])[:4]
+    out = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
+           "repeats": rec["repeats"], "spread": rec["spread"],
+           "config": {"n": rec["config"].get("poly_modulus_degree"), "primes": rec["config"].get("coeff_modulus_primes"), "batch": rec["config"].get("batch_per_gpu")},
+           "roofline": {"kernel": roof.get("kernel"), "bound": roof.get("bound"), "achieved": roof.get("achieved"), "frac": roof.get("frac"),
+                        "traffic": roof.get("traffic"), "avg_launch_ms": roof.get("avg_launch_ms"),
+                        "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch"), "whole_op_frac": roof.get("whole_op", {}).get("frac")},
+           "valu_issue_frac": (rec.get("valu") or {}).get("frac"),
+           "kernels_ms_per_step": dict(kern),
+           "cpu_baseline": ({"value": cpu.get("value"), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind")} if cpu else None),
+           "parity_ok": summary_entry(rec)["parity_ok"]}
+    return out
+
+
+def trim_headline(line):
+    """The headline keeps every field of the contract; the explanatory strings inside roofline / valu go (they are in profiles/README.md)."""
+    roof = line.get("roofline") or {}
+    if "whole_op" in roof:
+        roof["whole_op"].pop("definition", None)
+    if line.get("valu"):
+        line["valu"].pop("source", None)
 
 
 def pmc_workload_key(args, n):

@@ -29,6 +29,11 @@ struct MulOpD {
   double wq;
 };
 
+// flags in DevMod::split_fwd_mask / split_inv_mask beside the per-pass reduce bits (context.cpp plan_f64_split)
+constexpr u32 kPlanStoreReduce = 1u << 30;  // fwd: the head's outputs / inv: the middle kernel's outputs exceed the 48-bit packed range
+                                            // unless reduced in front of the store (packed rows only; 8-byte rows never reduce there)
+constexpr u32 kPlanScaleReduce = 1u << 29;  // inv: the tail's scaling product must be reduced before one conditional add makes it canonical
+
 struct DevMod {
   u64 q;
   u64 q2;       // 2q
@@ -40,7 +45,8 @@ struct DevMod {
   u32 use_f64;
   u32 fwd_reduce_mask;   // pass structure with 16 elements per thread (stand-alone transforms)
   u32 inv_reduce_mask;
-  // split transforms (nttshape.hpp): bit p = reduce at the start of middle pass p; bit 8 = reduce at the start of the tail
+  // split transforms (nttshape.hpp): bit p = reduce at the start of middle pass p; bit 8 = reduce at the start of the tail;
+  // kPlanStoreReduce / kPlanScaleReduce below
   u32 split_fwd_mask;
   u32 split_inv_mask;
   u32 split_ok;          // the FP64 range plan of the split structure succeeded

@@ -179,8 +179,6 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_MUL")) split_mul_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_TAIL")) fuse_mulrelin_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_HEAD")) fuse_head_ = env[0] != '1';
-  if (const char* env = std::getenv("HIPBFV_NO_SQUARE")) square_ = env[0] != '1';
-  if (const char* env = std::getenv("HIPBFV_NO_FUSED_PLAIN")) fused_plain_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SMALL_BATCH")) small_batch_ = env[0] != '1';
   if (hipMalloc((void**)&status_dev_, 256) == hipSuccess)
     (void)hipMemset(status_dev_, 0xFF, 256);
@@ -285,12 +283,12 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   const bool split = split_mul_ && sa == 2 && sb == 2 && (kneed <= 4 || (kneed <= 8 && h.aux_f64)) && h.logn >= 12 && h.logn <= 14 &&
                      !few_for_split_mul(count);
   // x * x (Evaluator_Square, a program node with one operand twice): the split kernels extend and transform x once
-  const bool square = split && square_ && a == b;
+  const bool square = split && a == b;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     if (split) {
       // head / middle / tail split transforms (kernels_split.hip): 3 launches instead of 5, 40 % less HBM traffic
-      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, h.aux_f64 != 0, h.aux_f64 ? (int)h.pack_mul : (h.aux_mixed ? 1 : 0), kneed, a + off * 2 * K * n, b + off * 2 * K * n, ext, c, s, square ? 2u : 4u));
+      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, h.aux_f64 != 0, h.aux_f64 ? (int)h.pack_mul | (h.conv_grid == 1 ? 4 : 0) : (h.aux_mixed ? 1 : 0), kneed, a + off * 2 * K * n, b + off * 2 * K * n, ext, c, s, square ? 2u : 4u));
       HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_dp, h.mid_ndp, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
       HB_LAUNCH(kKernMulTail, c * 3, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, h.aux_f64 != 0, h.aux_f64 ? (int)h.pack_mul : (h.aux_mixed ? 1 : 0), h.conv_grid != 0, kneed, D, out + off * 3 * K * n, c, s));
       continue;
@@ -365,7 +363,7 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
   // formed inside the last one (mulrelin_tail_kernel) and only c2 -- the key-switch target -- is written by mul_tail.
   const bool fused = fuse_mulrelin_ && split_mul_ && split_ks_ && h.aux_f64 && h.ks_split_ok && h.ks_ni == 0 && kneed <= 8 && h.logn >= 12 && h.logn <= 14 &&
                      !few_for_fused(count);
-  const bool square = fused && square_ && a == b;  // x * x: the head extends and the middle kernel transforms x once
+  const bool square = fused && a == b;  // x * x: the head extends and the middle kernel transforms x once
   if (fused) {
     const size_t ext_words = (size_t)4 * R * n, d_words = (size_t)3 * R * n, t_words = (size_t)KK * K * n, acc_words = (size_t)2 * KK * n, c2_words = (size_t)K * n;
     const size_t per_op = ext_words + d_words + t_words + acc_words + c2_words;
@@ -382,7 +380,7 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
     u64* C2 = ACC + cc * acc_words;
     for (size_t off = 0; off < count; off += chunk) {
       const size_t c = std::min(chunk, count - off);
-      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, (int)h.pack_mul, kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u));
+      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, (int)h.pack_mul | (h.conv_grid == 1 ? 4 : 0), kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u));
       HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_dp, h.mid_ndp, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
       if (fuse_head_) {
         HB_LAUNCH(kKernKsHead, c, launch_mulrelin_head(ctx_->dev(), h.tw_inv, h.tw_fwd, h.logn, (int)h.pack_mul, h.conv_grid != 0, h.pack_ks != 0, kneed, D, T, c, s));
@@ -517,7 +515,7 @@ int Evaluator::multiply_plain(const u64* ct, u32 size, const u64* plain, size_t 
     HB_CHECK(launch_plain_lift(ctx_->dev(), n, plain, 0, pl, 1, nonzero, s));
     HB_LAUNCH(kKernNttFwd, K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, pl, K, plan, false, 0, s));
   }
-  const bool fused = fused_plain_ && h.logn >= 10 && h.logn <= 14;
+  const bool fused = h.logn >= 10 && h.logn <= 14;
   bool any_d = false, any_i = false;
   for (u32 i = 0; i < K; i++) (h.mod[i].use_f64 ? any_d : any_i) = true;
   if (out != ct && !fused) HB_CHECK(hipMemcpyAsync(out, ct, count * cs * sizeof(u64), hipMemcpyDeviceToDevice, s));

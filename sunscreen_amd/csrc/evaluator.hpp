@@ -206,8 +206,6 @@ class Evaluator {
   bool split_mul_ = true;  // ... and for the BEHZ multiply
   bool fuse_head_ = true;      // ... and c2 formed inside the key switch's first kernel
   bool small_batch_ = true;    // a few ciphertexts take the whole-polynomial pipelines (HIPBFV_NO_SMALL_BATCH=1: pipelines chosen by parameters only)
-  bool fused_plain_ = true;    // multiply_plain as one kernel per chunk (HIPBFV_NO_FUSED_PLAIN=1: lift / transform / dyadic / inverse as separate kernels)
-  bool square_ = true;         // multiply(x, x): two forward transforms instead of four (HIPBFV_NO_SQUARE=1: as a general product)
   bool fuse_mulrelin_ = true;  // multiply_relin: c0, c1 of the product formed inside the key switch's last kernel
 };
 

@@ -33,12 +33,8 @@ namespace hipbfv {
 // polynomials), inverse with non-temporal stores -1.5 %; non-temporal LOADS make the inverse 13 % slower there and in the
 // encrypt / decrypt pipeline (its input was just written by the previous kernel and is partly cache-resident), so it keeps
 // temporal loads.
-#ifndef NTT_NT_FWD
 #define NTT_NT_FWD 3
-#endif
-#ifndef NTT_NT_INV
 #define NTT_NT_INV 2
-#endif
 template <bool NT, class T>
 __device__ __forceinline__ T ntt_ld(const T* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
@@ -67,9 +63,7 @@ __device__ __forceinline__ void ntt_st(T* p, T v) {
 // 0..2) only the first exchange of a forward transform (the last of an inverse one) couples wavefronts: 1 workgroup
 // barrier per transform instead of 4, and after it the eight wavefronts of a workgroup run their 2 x 512-coefficient
 // blocks independently, so their load / compute / store phases stagger instead of meeting at every pass.
-#ifndef NTT_WAVE_PRIVATE
 #define NTT_WAVE_PRIVATE 1
-#endif
 constexpr int wave_bit_target(int b, int low, int r) { return b >= low ? b + r : b; }
 // pa, pb: forward pass numbers of the two passes an exchange connects
 constexpr bool exchange_is_wave_private(int logn, int ept, int pa, int pb) {

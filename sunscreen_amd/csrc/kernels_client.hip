@@ -360,48 +360,6 @@ __global__ __launch_bounds__(kClientThreads) void crt_decompose_kernel(const Dev
 // acc[row][p][i][x] = sum_j ctn[j][p][i][x] * pntt[row][j][i][x] mod q_i     (all NTT form, canonical residues)
 // One thread = one coefficient of one residue, RT consecutive rows and both ciphertext polynomials: every ciphertext
 // word is read once per RT rows, the plaintext matrix (the database) streams through exactly once.
-#ifndef PIR_NT
-#define PIR_NT 1
-#endif
-template <int RT>
-__global__ __launch_bounds__(kClientThreads) void dot_plain_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 cols,
-                                                                   const u64* __restrict__ pntt, u32 rows, u64* __restrict__ acc) {
-  const u32 n = ctx->n, K = ctx->K;
-  const u32 x = blockIdx.x * kClientThreads + threadIdx.x;
-  const u32 i = blockIdx.y, r0 = blockIdx.z * RT;
-  if (x >= n) return;
-  const DevMod& dm = ctx->mod[i];
-  u128 a0[RT], a1[RT];
-#pragma unroll
-  for (int r = 0; r < RT; r++) a0[r] = 0, a1[r] = 0;
-  for (u32 j = 0; j < cols; j++) {
-    const u64 c0 = ctn[(((size_t)j * 2 + 0) * K + i) * n + x];
-    const u64 c1 = ctn[(((size_t)j * 2 + 1) * K + i) * n + x];
-#pragma unroll
-    for (int r = 0; r < RT; r++) {
-      if (r0 + r < rows) {
-#if PIR_NT
-        const u64 pv = __builtin_nontemporal_load(&pntt[(((size_t)(r0 + r) * cols + j) * K + i) * n + x]);  // the database streams through once
-#else
-        const u64 pv = pntt[(((size_t)(r0 + r) * cols + j) * K + i) * n + x];
-#endif
-        a0[r] += (u128)c0 * pv;
-        a1[r] += (u128)c1 * pv;
-      }
-    }
-    if ((j & 15u) == 15u) {  // products are below 2^122: sixteen of them fit 128 bits
-#pragma unroll
-      for (int r = 0; r < RT; r++) a0[r] = reduce128_fast(a0[r], dm), a1[r] = reduce128_fast(a1[r], dm);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < RT; r++) {
-    if (r0 + r < rows) {
-      acc[((((size_t)(r0 + r)) * 2 + 0) * K + i) * n + x] = reduce128_fast(a0[r], dm);
-      acc[((((size_t)(r0 + r)) * 2 + 1) * K + i) * n + x] = reduce128_fast(a1[r], dm);
-    }
-  }
-}
 
 
 // The same with TWO adjacent coefficients per thread: every access is 16 bytes per lane (1 KB contiguous per wavefront
@@ -440,11 +398,7 @@ __device__ __forceinline__ void pir_fetch(PirBlock<RT, JU>& blk, u32 j0, u32 col
 #pragma unroll
     for (int r = 0; r < RT; r++) {
       const auto p = as_global(reinterpret_cast<const pir_u64x2*>(at[r][u]));  // global_load, not flat_load
-#if PIR_NT
       blk.pv[r][u] = __builtin_nontemporal_load(p);  // the database streams through once
-#else
-      blk.pv[r][u] = *p;
-#endif
     }
   }
 }
@@ -481,29 +435,17 @@ __device__ __forceinline__ void pir_dot_body(const DevMod& dm, u32 cols, const Q
     }
   }
 }
-#ifndef PIR_JU
 #define PIR_JU 1  // columns per block, two blocks in flight (measured, r04: JU = 1 / 2 / 4 -> the 16 GiB product 2.95 / 3.04 / 5.1 ms)
-#endif
 // Which grid dimension walks the ROW BLOCKS.  Workgroups are dispatched x-fastest, so with the row blocks on x (PIR_ROWS_FAST) the
 // workgroups resident at one time are all row blocks of a few (coefficient range, residue) slices: they read the SAME query words
 // at about the same time, and each XCD's L2 serves them after the first.  With the coefficient ranges on x (the r01-r03 order) the
 // resident workgroups cover all coefficients of 8 row blocks, and every row block re-reads the whole transformed query: at
 // n = 16384 that is 512 MiB per 4 rows -- 64 GiB beside the 128 GiB database, and more than the 256 MB Infinity Cache holds.
-#ifndef PIR_ROWS_FAST
-#define PIR_ROWS_FAST 1
-#endif
-struct PirGrid {
-#if PIR_ROWS_FAST
+struct PirGrid {  // row blocks on x
   static __device__ __forceinline__ u32 rowblock() { return blockIdx.x; }
   static __device__ __forceinline__ u32 xblock() { return blockIdx.y; }
   static __device__ __forceinline__ u32 residue() { return blockIdx.z; }
   static dim3 grid(u32 xblocks, u32 K, u32 rowblocks) { return dim3(rowblocks, xblocks, K); }
-#else
-  static __device__ __forceinline__ u32 rowblock() { return blockIdx.z; }
-  static __device__ __forceinline__ u32 xblock() { return blockIdx.x; }
-  static __device__ __forceinline__ u32 residue() { return blockIdx.y; }
-  static dim3 grid(u32 xblocks, u32 K, u32 rowblocks) { return dim3(xblocks, K, rowblocks); }
-#endif
 };
 
 template <int RT>
@@ -643,21 +585,9 @@ hipError_t launch_crt_decompose(const DevCtx* ctx, u32 n, u32 KC, const u64* in,
 // 1 (default): two coefficients and 4 rows per thread -- 16-byte accesses; measured (interleaved A/B, 256 x 256 entries, n = 8192):
 // the product kernel 4.89 -> 3.42 ms, i.e. the 16 GiB database streams at 5.0 TB/s instead of 3.5, 10.5 M -> 13.7 M entries/s.
 // 2: two coefficients and 8 rows (128 registers of accumulators): 4.41 ms.  0: one coefficient, 8 rows, 8-byte accesses.
-#ifndef PIR_WIDE
-#define PIR_WIDE 1
-#endif
 hipError_t launch_dot_plain(const DevCtx* ctx, u32 n, u32 K, const u64* ctn, u32 cols, const u64* pntt, u32 rows, u64* acc, hipStream_t s) {
-#if PIR_WIDE == 1
   constexpr int RT = 4;
   dot_plain2_kernel<RT><<<PirGrid::grid((n / 2 + kClientThreads - 1) / kClientThreads, K, (rows + RT - 1) / RT), kClientThreads, 0, s>>>(ctx, ctn, cols, pntt, rows, acc);
-#elif PIR_WIDE == 2
-  constexpr int RT = 8;
-  dot_plain2_kernel<RT><<<PirGrid::grid((n / 2 + kClientThreads - 1) / kClientThreads, K, (rows + RT - 1) / RT), kClientThreads, 0, s>>>(ctx, ctn, cols, pntt, rows, acc);
-#else
-  constexpr int RT = 8;  // rows per thread: the query ciphertexts are re-read once per RT database rows (16: fewer, fatter
-                         // workgroups -- measured slower)
-  dot_plain_kernel<RT><<<cgrid(n, K, (rows + RT - 1) / RT), kClientThreads, 0, s>>>(ctx, ctn, cols, pntt, rows, acc);
-#endif
   return hipGetLastError();
 }
 hipError_t launch_batch_scatter(const DevCtx* ctx, u32 n, const u32* map, const u64* values, u64* plain, size_t ops, int is_signed, u32* bad,

@@ -620,10 +620,20 @@ int Program::describe(std::string* out) const {
 // =====================================================================================
 namespace {
 
-// pinned, device-addressable staging for the descriptor tables of one run (one buffer per host thread, grown on demand)
+// pinned, device-addressable staging for the descriptor tables of one run (grown on demand).  A run ends by RECORDING an event
+// behind its last table copy instead of draining the stream (r05; ADVICE r03's last item): the arena is not touched again until
+// that event has passed -- `wait_idle` at the start of the run that reuses it.
 struct TableArena {
   unsigned char* host = nullptr;
   size_t cap = 0, used = 0;
+  hipEvent_t done = nullptr;  // behind the last copy out of this arena
+  bool pending = false;
+  // the device has finished reading this arena (usually long ago: the event is from two runs back)
+  bool wait_idle() {
+    if (pending && hipEventSynchronize(done) != hipSuccess) return false;
+    pending = false;
+    return true;
+  }
   bool reserve(size_t bytes) {
     if (bytes <= cap) return true;
     if (host) (void)hipHostFree(host);
@@ -638,20 +648,29 @@ struct TableArena {
     cap = want;
     return true;
   }
-  // one arena per host thread (thread_local in run_plan): a thread that ends gives its pinned memory back.  Every
-  // run that staged a table drains its stream before it returns, so nothing on the device still reads the arena here.
+  // the copies out of the arena are enqueued on `s`: mark their end
+  bool mark(hipStream_t s) {
+    if (!done && hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventRecord(done, s) != hipSuccess) return false;
+    pending = true;
+    return true;
+  }
   ~TableArena() {
+    (void)wait_idle();
+    if (done) (void)hipEventDestroy(done);
     if (host) (void)hipHostFree(host);
   }
 };
+// Two arenas per host thread, used alternately (thread_local in run_plan; a thread that ends gives its pinned memory back, ADVICE
+// r03): while the device still copies run i's tables out of one, the host builds run i + 1's in the other, and a scheduled run
+// returns without a stream synchronisation of its own.
+struct TableArenas {
+  TableArena a[2];
+  unsigned turn = 0;
+  TableArena& next() { return a[turn++ & 1u]; }
+};
 
-size_t merge_max_batch() {
-  static const size_t v = [] {
-    const char* env = std::getenv("HIPBFV_PROGRAM_MERGE_MAX_BATCH");
-    return env ? (size_t)std::strtoull(env, nullptr, 10) : (size_t)32;
-  }();
-  return v;
-}
+constexpr size_t merge_max_batch() { return 32; }  // (measured in r03: DESIGN.md, the scheduled executor)
 
 }  // namespace
 
@@ -773,7 +792,9 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
   };
 
   // ---- descriptor tables: pinned host arena -> one device buffer per table ----
-  thread_local TableArena arena;
+  thread_local TableArenas arenas;
+  TableArena& arena = arenas.next();
+  if (!arena.wait_idle()) return cleanup(kHipError, "event synchronisation failed");
   arena.used = 0;
   bool tables_used = false;
   // reserve the worst case up front so that the host pointers handed out stay valid for the whole run
@@ -1164,8 +1185,9 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
   for (Block& b : blocks)
     if (b.owned && b.refs > 0) pool.release(b.ptr, s);
   for (void* t : temps) pool.release(t, s);
-  // the descriptor tables were copied from this thread's pinned arena: they must have left it before the next run reuses it
-  if (tables_used && hipStreamSynchronize(s) != hipSuccess) return fail(kHipError, "stream synchronisation failed");
+  // the descriptor tables were copied from this thread's pinned arena: an event behind the copies guards its reuse (two runs from
+  // now: TableArenas) -- the run itself does not wait for the device
+  if (tables_used && !arena.mark(s)) return fail(kHipError, "event record failed");
   return kOk;
 }
 

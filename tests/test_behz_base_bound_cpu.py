@@ -111,7 +111,7 @@ def test_own_base_holds_the_largest_floor_the_multiply_can_produce(name, n, bits
     Q, K = _prod(q), len(q)
     assert len(set(aux)) == len(aux) and not set(aux) & set(key)
     assert all(p % (2 * n) == 1 and p < (1 << 48) for p in aux)
-    reserve = 32 if os.environ.get("HIPBFV_SEAL_BOUND") == "1" else n.bit_length() - 1 + 3
+    reserve = n.bit_length() - 1 + 3
     assert (_prod(B) * m_sk).bit_length() > t.bit_length() + Q.bit_length() + reserve
     # the largest |t * c'|: operands after the Montgomery step |x'| <= q/2 + q*K/m~, 8 cross terms of N products each
     xmax = Q // 2 + (Q * K) // M_TILDE + 1
@@ -153,31 +153,11 @@ def test_the_replay_fails_once_the_integer_outgrows_the_base():
 
 def test_the_new_bound_saves_a_row_where_it_is_claimed_to():
     """n = 16384, SEAL default primes: nine auxiliary primes instead of ten (17 rows in the multiply instead of 18)."""
-    if os.environ.get("HIPBFV_SEAL_BOUND") == "1" or os.environ.get("HIPBFV_SEAL_AUX") == "1" or os.environ.get("HIPBFV_NO_F64") == "1":
+    if os.environ.get("HIPBFV_SEAL_AUX") == "1" or os.environ.get("HIPBFV_NO_F64") == "1":
         pytest.skip("base sizing switched by the environment")
     key = _default_primes(16384)
     aux, flags = _aux_base(16384, key, _plain_batching(16384, 17))
     assert flags & 1 and len(aux) == 9 and all(p < (1 << 48) for p in aux)
-
-
-def test_seal_sizing_is_one_switch_away(monkeypatch):
-    """HIPBFV_SEAL_BOUND=1 (read at every context creation): the base covers 2^(32 + bits(t) + bits(q)) again -- ten 45-bit primes
-    at n = 16384 -- and the replay holds there as well (a larger base can only be safer)."""
-    if os.environ.get("HIPBFV_SEAL_AUX") == "1" or os.environ.get("HIPBFV_NO_F64") == "1":
-        pytest.skip("own base switched off by the environment")
-    monkeypatch.setenv("HIPBFV_SEAL_BOUND", "1")
-    key = _default_primes(16384)
-    t = _plain_batching(16384, 17)
-    aux, flags = _aux_base(16384, key, t)
-    assert flags & 1 and len(aux) == 10
-    q = key[:-1]
-    assert (_prod(aux)).bit_length() > 32 + t.bit_length() + _prod(q).bit_length()
-    B, m_sk = aux[:-1], aux[-1]
-    Q = _prod(q)
-    xmax = Q // 2 + (Q * len(q)) // M_TILDE + 1
-    for T in (t * 8 * 16384 * xmax * xmax, -(t * 8 * 16384 * xmax * xmax), 12345 * Q + 7):
-        got, F = floor_then_sk(T, q, B, m_sk)
-        assert got == [F % p for p in q]
 
 
 def test_a_plain_modulus_too_large_for_the_own_base_falls_back_to_seals():

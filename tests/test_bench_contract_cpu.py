@@ -125,3 +125,31 @@ def test_power_leg_parses_rocm_smi_and_survives_its_absence(tmp_path, monkeypatc
     assert rec["package_w"] == 1374.0 and rec["sclk_mhz"] == 2156 and rec["cap_w"] == 1400.0 and rec["samples"] == 3 and steps
     fake.write_text("#!/bin/sh\necho nothing useful\n")
     assert bench.power_leg(lambda: None, lambda: None) is None
+
+
+def test_default_line_is_compact_and_ends_in_the_summary_of_every_metric_quantity():
+    """The driver stores the TAIL of the printed line (2000 characters): the last key is `summary`, it carries the three quantities
+    BASELINE.json's metric names (mul+relin at n = 8192 and 16384, NTTs/s) and the program workloads, and the whole line stays
+    below 8 KB.  Replayed on a committed full line (round 4's, 16 KB) through the functions bench.py's main() uses."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = json.load(open(_newest("r*_bench_default.json")))
+    full.pop("summary", None)
+    line = dict(full)
+    line["secondary"] = {k: (bench.compact_secondary(v) if "algorithmic_bytes_per_unit" in (v.get("roofline") or {}) else v) for k, v in full["secondary"].items()}
+    line["summary"] = bench.summary_of(line)
+    bench.trim_headline(line)
+    text = json.dumps(line)
+    assert len(text) < 8192, len(text)
+    assert list(line)[-1] == "summary"
+    tail = text[-2000:]
+    assert tail.index('"summary"') >= 0
+    summ = json.loads(tail[tail.index('"summary"') + len('"summary": '):-1])
+    for key in ("mulrelin_n8192", "mulrelin_n16384", "ntt_n8192", "3x54", "chi_sq_1024", "chi_sq_128", "dot_prod", "pir_2p17"):
+        e = summ[key]
+        assert set(e) == {"value", "ms_per_step", "frac", "whole_op_frac", "traffic_ratio", "parity_ok"}, key
+        assert e["value"] > 0 and e["parity_ok"] is True, key
+    # a failed or skipped secondary job is visible in the summary and never passes for a measurement
+    assert bench.summary_entry({"error": "OutOfMemoryError: ..."}) == {"error": "OutOfMemoryError: ...", "parity_ok": False}
+    assert bench.summary_entry({"skipped": "needs 140 GiB"})["parity_ok"] is False

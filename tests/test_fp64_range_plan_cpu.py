@@ -154,24 +154,95 @@ def test_range_plans_of_the_default_primes_hold_under_an_independent_model(n):
                 mi = mod.inv_stage(mi)
         assert mod.peak < room, (n, q, mod.peak, room)
         # head / middle / tail transforms
-        mod = _Model(q)
-        m = 1.0
-        for _ in range(_head_log(logn)):
+        _replay_split_plan(q, logn, sfmask, simask)
+
+
+PLAN_STORE_REDUCE = 1 << 30  # devctx.hpp kPlanStoreReduce / kPlanScaleReduce
+PLAN_SCALE_REDUCE = 1 << 29
+PACK_RANGE = float(1 << 47)  # a 48-bit packed row holds |v| < 2^47 (kernels_split.hip nat_store)
+
+
+def _replay_split_plan(q, logn, sfmask, simask):
+    """The split plan of one prime against the independent model: every intermediate below 2^53; rows that travel 48-bit packed
+    WITHOUT a reduction in front of the store (flag clear) fit the packed range; the tail's scaling product is canonical after
+    one conditional add unless the plan asks for a reduction first.  Rows are modelled as 8-byte doubles (no reduction at a
+    store): a packed row that does reduce there only starts the next kernel smaller."""
+    room = LIMIT / q
+    mod = _Model(q)
+    m = 1.0
+    for _ in range(_head_log(logn)):
+        m = mod.fwd_stage(m)
+    if not sfmask & PLAN_STORE_REDUCE:
+        assert m * q < PACK_RANGE, (q, logn, m)
+    for p, r in enumerate(_split_fwd_radices(logn)):
+        m = mod.reduce_by_mask(m, sfmask, p)
+        for _ in range(r):
             m = mod.fwd_stage(m)
-        for p, r in enumerate(_split_fwd_radices(logn)):
-            m = mod.reduce_by_mask(m, sfmask, p)
-            for _ in range(r):
-                m = mod.fwd_stage(m)
-        assert (m * q) ** 2 < 2.0 ** 105  # the tensor product multiplies two such values
-        mi = 2.5  # products and accumulators entering the inverse middle passes
-        for p, r in enumerate(_split_inv_radices(logn)):
-            mi = mod.reduce_by_mask(mi, simask, p)
-            for _ in range(r):
-                mi = mod.inv_stage(mi)
-        mi = mod.reduce_by_mask(mi, simask, 8)  # bit 8 / 24: at the start of the tail stages
-        for _ in range(2):
+    assert (m * q) ** 2 < 2.0 ** 105  # the tensor product multiplies two such values
+    # what enters the inverse middle passes: a product a * b of two forward outputs (ArithD::mul_var, bound checked by
+    # test_variable_product_bound below) or a freshly reduced accumulator
+    mi = max(mod.red(4 * m), 0.5 + m * m * q * 1.5 / TWO52)
+    if logn == 15:
+        mi = 1.0  # only the stand-alone two-kernel inverse exists at this degree: canonical residues in, no product in split form
+    for p, r in enumerate(_split_inv_radices(logn)):
+        mi = mod.reduce_by_mask(mi, simask, p)
+        for _ in range(r):
             mi = mod.inv_stage(mi)
-        assert mod.peak < room, (n, q, mod.peak, room)
+    if not simask & PLAN_STORE_REDUCE:
+        assert mi * q < PACK_RANGE, (q, logn, mi)
+    mi = mod.reduce_by_mask(mi, simask, 8)  # bit 8 / 24: at the start of the tail stages
+    for _ in range(2):
+        mi = mod.inv_stage(mi)
+    assert mod.peak < room, (q, logn, mod.peak, room)
+    if not simask & PLAN_SCALE_REDUCE:
+        # ArithD::mul_const(v, c), c < q: q * (0.5 + |v| * 2^-52); below q (here: 0.97 q) one conditional add makes it canonical
+        assert 0.5 + mi * q / TWO52 < 0.97, (q, logn, mi)
+    return m, mi
+
+
+@pytest.mark.parametrize("logn", [12, 13, 14, 15])
+def test_split_plans_hold_for_every_prime_size_the_policy_admits(logn):
+    """Beyond the SEAL default sets: the library's own auxiliary primes (36 ... 48 bits) and user primes up to the policy's 2^50.
+    Whatever the plan decides (skip the store reduction or keep it, where the one reduction of the inverse goes) must hold."""
+    skipped_store, kept_store = 0, 0
+    for bits in range(36, 51):
+        for q in O.get_primes(2 << logn, bits, 2):
+            use, _, _, split, sfmask, simask = _plan(q, logn)
+            if not (use and split):
+                assert bits >= 49, (q, bits)  # every prime below 2^48 keeps the FP64 pipe at every degree
+                continue
+            _replay_split_plan(q, logn, sfmask, simask)
+            if simask & PLAN_STORE_REDUCE:
+                kept_store += 1
+            else:
+                skipped_store += 1
+    assert skipped_store > 0 and kept_store > 0  # both arms are exercised
+
+
+def test_default_headline_primes_need_no_store_or_scale_reduction():
+    """n = 8192, SEAL default set + the 42-bit auxiliary base: the reductions in front of packed stores and after the tail's scaling are
+    all skipped, and the inverse reduces once, at the start of its last middle pass (the r05 instruction cut)."""
+    for q in O.bfv_default(8192) + O.get_primes(2 * 8192, 42, 5):
+        use, _, _, split, sfmask, simask = _plan(q, 13)
+        assert use and split
+        assert sfmask == 0, hex(sfmask)
+        assert simask == 1 << 3, hex(simask)
+
+
+@pytest.mark.parametrize("q", _fp64_primes())
+def test_variable_product_bound(q):
+    """ArithD::mul_var(a, b) with BOTH operands lazy (|a|, |b| up to a few q): exact, congruent, and within
+    q * (0.5 + |a * b| / q * 1.5 * 2^-52) -- the entry bound of the inverse middle passes."""
+    rng = random.Random(q ^ 0x5A5A)
+    for scale in (1, 3, 8):
+        top = min(scale * q, int(2.0 ** 52.4))
+        if (top * top) >= (1 << 105):
+            continue
+        for _ in range(1500):
+            a, b = rng.randrange(-top, top + 1), rng.randrange(-top, top + 1)
+            t, exact = _mul_var(a, b, q)
+            assert exact and (t - a * b) % q == 0
+            assert abs(t) <= q * (0.5 + abs(a * b) / q * 1.5 / TWO52) * (1 + 1e-12)
 
 
 def test_primes_beyond_the_policy_are_refused():

@@ -127,7 +127,7 @@ def test_north_star_literal_3x54bit_primes_mul_relin_and_rotate():
 
 def test_3x54bit_mixed_and_seal_auxiliary_bases_give_the_same_bits():
     """The mixed auxiliary base (integer data primes, the library's FP64-pipe auxiliary primes: DESIGN.md 4.3) is the default for the
-    north star's literal prime set; HIPBFV_NO_MIXED_AUX=1 keeps SEAL's 61-bit base.  BEHZ's result does not depend on the base:
+    north star's literal prime set; HIPBFV_SEAL_AUX=1 keeps SEAL's 61-bit base.  BEHZ's result does not depend on the base:
     the same seeded operands (random, and every residue at its maximum) through both, in separate processes, word for word --
     and the default one against the oracle."""
     import os
@@ -156,7 +156,7 @@ np.save(sys.argv[1], to_host(ev.multiply(to_device(a), to_device(b))))
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as d:
         out = {}
-        for tag, env in (("mixed", {"HIPBFV_NO_MIXED_AUX": "0"}), ("seal", {"HIPBFV_NO_MIXED_AUX": "1"})):
+        for tag, env in (("mixed", {"HIPBFV_SEAL_AUX": "0"}), ("seal", {"HIPBFV_SEAL_AUX": "1"})):
             path = os.path.join(d, tag + ".npy")
             subprocess.check_call([sys.executable, "-c", script, path, tag], env=dict(os.environ, **env))
             out[tag] = np.load(path)

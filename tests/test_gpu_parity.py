@@ -402,7 +402,7 @@ _own_base_off = os.environ.get("HIPBFV_SEAL_AUX") == "1" or os.environ.get("HIPB
 def test_auxiliary_base_choice_and_bound():
     """The BEHZ auxiliary base is internal to multiply.  FP64-capable data primes -> the library's own base of
     primes below 2^48 whose product covers 2^(bits(t) + log2 n + bits(q) + 3) (context.cpp derives it; SEAL reserves 32 bits
-    where this has log2 n + 3, and HIPBFV_SEAL_BOUND=1 sizes the base SEAL's way; tests/test_behz_base_bound_cpu.py replays
+    where this has log2 n + 3; tests/test_behz_base_bound_cpu.py replays
     the steps the bound protects in exact integers);
     wide data primes where the split multiply runs (K <= 4, 4096 <= n <= 16384) -> the MIXED base: the same kind of
     auxiliary primes (FP64 rows in the middle kernel) beside integer data rows; wide data primes elsewhere -> SEAL's own
@@ -418,7 +418,7 @@ def test_auxiliary_base_choice_and_bound():
             assert p < 2**48 and p % (2 * n) == 1 and p not in primes and O.is_prime(p)
             prod *= p
         assert len(set(ctx.aux_primes)) == len(ctx.aux_primes)
-        reserve = 32 if os.environ.get("HIPBFV_SEAL_BOUND") == "1" else n.bit_length() - 1 + 3
+        reserve = n.bit_length() - 1 + 3
         assert prod.bit_length() > reserve + t.bit_length() + q.bit_length()
 
     n, primes, t = params("default_8192_17")
@@ -428,12 +428,8 @@ def test_auxiliary_base_choice_and_bound():
     wide = O.coeff_modulus_create(4096, [58, 59, 60])
     t2 = O.plain_batching(4096, 16)
     ctx2 = Context.from_raw(4096, wide, t2)
-    if os.environ.get("HIPBFV_NO_MIXED_AUX") == "1":
-        o2 = O.Oracle(4096, wide, t2)
-        assert not ctx2.aux_fp64 and not ctx2.aux_mixed and ctx2.aux_primes == [int(p) for p in o2.bsk]
-    else:
-        assert ctx2.aux_mixed and not ctx2.aux_fp64
-        covers(ctx2, wide, t2, 4096)
+    assert ctx2.aux_mixed and not ctx2.aux_fp64
+    covers(ctx2, wide, t2, 4096)
     wide3 = O.coeff_modulus_create(2048, [54, 55])  # n = 2048: no split pipelines, SEAL's base
     t3 = O.plain_batching(2048, 16)
     ctx3 = Context.from_raw(2048, wide3, t3)
@@ -518,7 +514,7 @@ def test_multiply_extreme_operands_of_larger_sizes_own_base(n, tbits, size):
         assert (m[i] == o.multiply(a[i], b[i])).all(), i
 
 
-@pytest.mark.skipif(_own_base_off or os.environ.get("HIPBFV_NO_MIXED_AUX") == "1", reason="the mixed auxiliary base is switched off by the environment")
+@pytest.mark.skipif(_own_base_off, reason="the own auxiliary bases are switched off by the environment")
 @pytest.mark.parametrize("n,bits,tbits,size", [(8192, [54, 54, 54, 56], 17, 2), (16384, [52, 54], 26, 2), (4096, [57, 51], 20, 2),
                                                (16384, [58, 52, 59, 52, 53], 25, 2), (8192, [54, 54, 54, 56], 40, 3)])
 def test_multiply_extreme_operands_mixed_base(n, bits, tbits, size):

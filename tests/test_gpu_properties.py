@@ -174,15 +174,13 @@ np.save(sys.argv[1], np.concatenate([x.cpu().numpy().ravel() for x in (r, m, g, 
         ("split", {"HIPBFV_NO_SMALL_BATCH": "1"}),  # every variant below inherits the pin from the `pipeline_selection` fixture too
         ("split_unfused_tail", {"HIPBFV_NO_FUSED_TAIL": "1"}),  # multiply then relinearize through a c0/c1/c2 buffer instead of mulrelin_tail
         ("split_unfused_head", {"HIPBFV_NO_FUSED_HEAD": "1"}),  # c2 through HBM between mul_tail and ks_head instead of mulrelin_head
-        ("split_no_square", {"HIPBFV_NO_SQUARE": "1"}),  # x * x as a general product (four forward transforms instead of two)
         ("small_batch_selection", {"HIPBFV_NO_SMALL_BATCH": "0"}),  # the product default: these 14 ciphertexts take the whole-polynomial multiply
-        ("unfused_plain", {"HIPBFV_NO_FUSED_PLAIN": "1"}),  # multiply_plain as transform / dyadic product / inverse kernels instead of one
         ("split_unpacked", {"HIPBFV_NO_PACK": "1"}),  # 8-byte instead of 48-bit packed intermediates
         ("split_no_grid", {"HIPBFV_NO_GRID": "1"}),  # base-conversion sums reduced term by term instead of once (griddot.hpp)
         ("whole", {"HIPBFV_NO_SPLIT_MUL": "1", "HIPBFV_NO_SPLIT_KS": "1"}),
         ("seal_aux", {"HIPBFV_SEAL_AUX": "1"}),
         ("seal_aux_whole", {"HIPBFV_SEAL_AUX": "1", "HIPBFV_NO_SPLIT_MUL": "1", "HIPBFV_NO_SPLIT_KS": "1"}),
-        ("int", {"HIPBFV_NO_F64": "1", "HIPBFV_NO_PM61": "1"}),
+        ("int", {"HIPBFV_NO_F64": "1"}),
     )
     outs = []
     with tempfile.TemporaryDirectory() as td:
