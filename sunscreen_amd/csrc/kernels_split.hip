@@ -38,12 +38,8 @@ namespace hipbfv {
 // seen in the ISA of the mod-down), which is exactly the work the condition was there to skip.
 #define HIPBFV_KEEP_BRANCH() asm volatile("")
 
-// LDS placement inside a block: XOR swizzle found by tools/lds_swizzle_search.py -- conflict free for every
-// pass window of the middle kernels at L = 12, 13, 14 (bank bits ^= e5*00101 ^ e6*01010 ^ e7*10001).
-__device__ __forceinline__ u32 blk_pos(u32 e) {
-  const u32 m = (((e >> 5) & 1u) * 0x05u) ^ (((e >> 6) & 1u) * 0x0Au) ^ (((e >> 7) & 1u) * 0x11u);
-  return e ^ m;
-}
+// LDS placement inside a block: the map of the whole-polynomial kernels (nttcore.hpp lds_pos; one search covers both families)
+__device__ __forceinline__ u32 blk_pos(u32 e) { return lds_pos(e); }
 
 // EPT: elements per middle-kernel thread (8).  At N = 16384 a block is 4096 coefficients, and 512-thread workgroups with four
 // 32 KB exchange regions leave room for ONE workgroup per CU -- nothing overlaps its load and store phases (an N = 8192 middle
@@ -818,6 +814,16 @@ __device__ __forceinline__ u64 ld_head_in(const BufRow& row, u32 t, int k) {
   return buf_ld64<false>(row.r, X::head_in_lane(t, k) * 8u, row.soff + X::head_uni(k) * 8u);
 }
 template <int L>
+__device__ __forceinline__ void st_head_out(const BufRow& row, u32 t, int k, u64 v) {  // 8-byte rows of either policy
+  using X = EdgeSplitIdx<L>;
+  buf_st64<false>(row.r, X::head_out_lane(t, k) * 8u, row.soff + X::head_uni(k) * 8u, v);
+}
+template <int L>
+__device__ __forceinline__ u64 ld_tail_in(const BufRow& row, u32 t, int k) {
+  using X = EdgeSplitIdx<L>;
+  return buf_ld64<false>(row.r, X::tail_in_lane(t, k) * 8u, row.soff + X::tail_uni(k) * 8u);
+}
+template <int L>
 __device__ __forceinline__ u64 ld_tail_out(const BufRow& row, u32 t, int k) {
   using X = EdgeSplitIdx<L>;
   return buf_ld64<false>(row.r, X::tail_out_lane(t, k) * 8u, row.soff + X::tail_uni(k) * 8u);
@@ -864,9 +870,8 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
 #pragma unroll
         for (int k = 0; k < NC; k++) w[k] = shrink ? reduce64(x[k], dm) : x[k];
         head_fwd_owned<ArithI, L>(ai, w, twf_base + (size_t)I * N, t);
-        u64* dsti = reinterpret_cast<u64*>(T) + (((size_t)op * KK + I) * K + J) * N;
 #pragma unroll
-        for (int k = 0; k < NC; k++) dsti[G::head_out(t, k)] = w[k];
+        for (int k = 0; k < NC; k++) st_head_out<L>(buf_row(rout, ((size_t)I * K + J) * N), t, k, w[k]);
         continue;
       }
     }
@@ -1250,16 +1255,19 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     return;
   }
   // MIXED (8-byte rows of either policy): the special prime's residue as a canonical u64
+  const bool has_base = ((base_mask >> c) & 1u) != 0;
+  const BufRsrc racc = buf_rsrc(acc), rout = buf_rsrc(out + ((size_t)op * 2 + c) * K * N);  // buffer addressing: see BufRow
+  const BufRsrc rbase = buf_rsrc_opt(has_base ? base + (size_t)op * bstride + (size_t)c * K * N : nullptr, acc);
+  const BufRsrc rex = buf_rsrc_opt(extra ? extra + ((size_t)op * 2 + c) * K * N : nullptr, acc);
   u64 tl[4];
   bool sp_done = false;
   {
     const DevMod& sp = ctx->mod[KK - 1];
     if (!residue_is_f64(sp)) {
       const ArithI ai(sp);
-      const u64* src = reinterpret_cast<const u64*>(acc) + (size_t)(KK - 1) * N;
       u64 w[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) w[k] = src[G::tail_in(t, k)];
+      for (int k = 0; k < 4; k++) w[k] = ld_tail_in<L>(buf_row(racc, (size_t)(KK - 1) * N), t, k);
       tail_inv_owned<ArithI, L>(ai, w, twi_base + (size_t)(KK - 1) * N, 0u, t);
 #pragma unroll
       for (int k = 0; k < 4; k++) tl[k] = add_mod(ai.scale_canonical(w[k], sp.ninv), ctx->qsp_half, sp.q);
@@ -1272,7 +1280,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     const double* tw = reinterpret_cast<const double*>(twi_base + (size_t)(KK - 1) * N);
     double v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = nat_load<PACK, NtSites<L>::tail_ld>(acc + (size_t)(KK - 1) * N, N, G::tail_in(t, k));
+    for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACK>(nat_fetch_tail<L, PACK, NtSites<L>::tail_ld>(buf_row(racc, (size_t)(KK - 1) * N), t, k));
     tail_inv_owned<ArithD, L>(ar, v, tw, sp.split_inv_mask, t);
 #pragma unroll
     for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
@@ -1281,22 +1289,19 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
   // MIXED (8-byte rows of either policy): the same pipelining on raw words -- row J + 1 requested before row J is finished, the
   // base / addend words requested unconditionally at the start of the row
   {
-    const u64* accw = reinterpret_cast<const u64*>(acc);
-    const bool has_base = ((base_mask >> c) & 1u) != 0;
     u64 cur[4], nxt[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) cur[k] = accw[G::tail_in(t, k)];
+    for (int k = 0; k < 4; k++) cur[k] = ld_tail_in<L>(buf_row(racc, 0), t, k);
     for (u32 J = 0; J < K; J++) {
       const u32 Jn = J + 1 < K ? J + 1 : J;
 #pragma unroll
-      for (int k = 0; k < 4; k++) nxt[k] = accw[(size_t)Jn * N + G::tail_in(t, k)];
+      for (int k = 0; k < 4; k++) nxt[k] = ld_tail_in<L>(buf_row(racc, (size_t)Jn * N), t, k);
       const DevMod& mj = ctx->mod[J];
-      u64 bw[4], ex[4];
+      u64 bw[4], ex[4];  // (absent operands: descriptors of zero records, the loads return 0)
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const size_t off = ((size_t)c * K + J) * N + G::tail_out(t, k);
-        bw[k] = *(has_base ? base + (size_t)op * bstride + off : accw);
-        ex[k] = *(extra ? extra + ((size_t)op * 2) * K * N + off : accw);
+        bw[k] = ld_tail_out<L>(buf_row(rbase, (size_t)J * N), t, k);
+        ex[k] = ld_tail_out<L>(buf_row(rex, (size_t)J * N), t, k);
       }
       u64 av[4];
       if (!residue_is_f64(mj)) {
@@ -1322,9 +1327,8 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
         tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
         u64 d = sub_mod(av[k], tk, mj.q);
         d = mul_shoup(d, ctx->inv_qsp_mod_q[J], mj.q);
-        u64 bv = has_base ? bw[k] : 0;
-        bv = extra ? add_mod(bv, ex[k], mj.q) : bv;  // a ciphertext added to the result (fused Add node)
-        out[((size_t)op * 2) * K * N + ((size_t)c * K + J) * N + G::tail_out(t, k)] = add_mod(bv, d, mj.q);
+        const u64 bv = add_mod(bw[k], ex[k], mj.q);  // the base ciphertext + a fused Add node's (absent: 0)
+        st_tail_out<L>(buf_row(rout, (size_t)J * N), t, k, add_mod(bv, d, mj.q));
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) cur[k] = nxt[k];
@@ -1377,12 +1381,12 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
   // src / dst: the polynomial's rows; owned coefficients sit at G::head_in(t, k) (inputs) / G::head_out(t, k) (outputs)
   const u64* src = (poly < 2 ? in0 + ((size_t)op * 2 + poly) * K * N : in1 + ((size_t)op * 2 + (poly - 2)) * K * N);
   u64* dst = ext + ((size_t)op * 4 + poly) * R * N;
+  const BufRsrc rin = buf_rsrc(src), rout = buf_rsrc(dst);  // buffer addressing: see BufRow
   if constexpr (AUXD) {
     // Every input word is requested before the first is used, and no request sits behind a branch: rows i >= K (instantiation
     // wider than the context) re-read row K - 1 and are discarded.  (r01-r03 wrote `i < K ? load : 0`; the compiler gave every
     // load its own basic block and an s_waitcnt vmcnt(0) -- KMAX x NC dependent HBM round trips per thread, found in r04 by
     // listing the load / wait sequence of the ISA.)
-    const BufRsrc rin = buf_rsrc(src), rout = buf_rsrc(dst);  // buffer addressing: see BufRow
     u64 raw[KMAX][NC];
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
@@ -1440,7 +1444,7 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
   for (int i = 0; i < KMAX; i++) {
     const u32 row = (u32)i < K ? (u32)i : K - 1;  // branch-free requests, all in flight together (see the AUXD branch)
 #pragma unroll
-    for (int k = 0; k < NC; k++) x[i][k] = src[(size_t)row * N + G::head_in(t, k)];
+    for (int k = 0; k < NC; k++) x[i][k] = ld_head_in<L>(buf_row(rin, (size_t)row * N), t, k);
   }
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
@@ -1459,18 +1463,16 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
 #pragma unroll
         for (int k = 0; k < NC; k++) v[k] = ar.from_u64(x[i][k]);
         head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(tw), t);
-        double* o = reinterpret_cast<double*>(dst + (size_t)i * N);
 #pragma unroll
-        for (int k = 0; k < NC; k++) o[G::head_out(t, k)] = v[k];
+        for (int k = 0; k < NC; k++) st_head_out<L>(buf_row(rout, (size_t)i * N), t, k, (u64)__double_as_longlong(v[k]));
       } else {
         const ArithI ar(dm);
         u64 v[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) v[k] = x[i][k];
         head_fwd_owned<ArithI, L>(ar, v, tw, t);
-        u64* o = dst + (size_t)i * N;
 #pragma unroll
-        for (int k = 0; k < NC; k++) o[G::head_out(t, k)] = v[k];
+        for (int k = 0; k < NC; k++) st_head_out<L>(buf_row(rout, (size_t)i * N), t, k, v[k]);
       }
     }
   }
@@ -1480,9 +1482,8 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
     behz_extend_multi_mixed<KMAX, NC>(ctx, x, [&](u32 j, double(&ev)[NC]) {
       const ArithD ar(ctx->mod[KK + j]);
       head_fwd_owned<ArithD, L>(ar, ev, reinterpret_cast<const double*>(twf_base + (size_t)(KK + j) * N), t);
-      double* o = reinterpret_cast<double*>(dst + (size_t)(K + j) * N);
 #pragma unroll
-      for (int k = 0; k < NC; k++) o[G::head_out(t, k)] = ev[k];
+      for (int k = 0; k < NC; k++) st_head_out<L>(buf_row(rout, (size_t)(K + j) * N), t, k, (u64)__double_as_longlong(ev[k]));
     });
     return;
   }
@@ -1507,9 +1508,8 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
 #pragma unroll
       for (int k = 0; k < NC; k++) v[k] = ev[j][k];
       head_fwd_owned<ArithI, L>(ar, v, twf_base + (size_t)(KK + j) * N, t);
-      u64* o = dst + (size_t)(K + j) * N;
 #pragma unroll
-      for (int k = 0; k < NC; k++) o[G::head_out(t, k)] = v[k];
+      for (int k = 0; k < NC; k++) st_head_out<L>(buf_row(rout, (size_t)(K + j) * N), t, k, v[k]);
     }
   }
 }
@@ -1925,12 +1925,12 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
   if constexpr (AUXD) {
     u64 res[KMAX][4];
     mul_tail_compute_d<L, KMAX, PACK, GRID>(ctx, twi_base, d, t, res);
-    const BufRsrc ro = buf_rsrc(o);
+    const BufRsrc rres = buf_rsrc(o);
 #pragma unroll
     for (int i = 0; i < KMAX; i++)
       if ((u32)i < K) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) st_tail_out<L>(buf_row(ro, (size_t)i * N), t, k, res[i][k]);
+        for (int k = 0; k < 4; k++) st_tail_out<L>(buf_row(rres, (size_t)i * N), t, k, res[i][k]);
       }
     return;
   }
@@ -1939,16 +1939,17 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
   // The K + S rows of D are visited in order; the four words of the NEXT row are requested (branch-free: beyond the last row the
   // last row is re-read) before the current row is transformed (r04: each row used to load, wait and compute in its own block).
   const u32 last_row = K + S - 1;
+  const BufRsrc rd = buf_rsrc(d), ro = buf_rsrc(o);  // buffer addressing: see BufRow
   u64 cur[4], nxt[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) cur[k] = d[G::tail_in(t, k)];
+  for (int k = 0; k < 4; k++) cur[k] = ld_tail_in<L>(buf_row(rd, 0), t, k);
 #pragma unroll
   for (int i = 0; i < KMAX; i++) {
     {
       const u32 nr = (u32)i + 1 < K ? (u32)i + 1 : K;  // after the last data row: the first auxiliary row
-      const u64* next_row = d + (size_t)(nr < last_row ? nr : last_row) * N;
+      const BufRow next_row = buf_row(rd, (size_t)(nr < last_row ? nr : last_row) * N);
 #pragma unroll
-      for (int k = 0; k < 4; k++) nxt[k] = next_row[G::tail_in(t, k)];
+      for (int k = 0; k < 4; k++) nxt[k] = ld_tail_in<L>(next_row, t, k);
     }
     if ((u32)i < K) {
       const DevMod& dm = ctx->mod[i];
@@ -1970,9 +1971,9 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
   for (int j = 0; j < KMAX + 2; j++) {
     {
       const u32 nr = K + (u32)j + 1;
-      const u64* next_row = d + (size_t)(nr < last_row ? nr : last_row) * N;
+      const BufRow next_row = buf_row(rd, (size_t)(nr < last_row ? nr : last_row) * N);
 #pragma unroll
-      for (int k = 0; k < 4; k++) nxt[k] = next_row[G::tail_in(t, k)];
+      for (int k = 0; k < 4; k++) nxt[k] = ld_tail_in<L>(next_row, t, k);
     }
     if ((u32)j < S) {
       const DevMod& dm = ctx->mod[KK + j];
@@ -2011,7 +2012,7 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
       for (int c = 0; c < NCM; c++)
 #pragma unroll
         for (int i = 0; i < KMAX; i++)
-          if ((u32)i < K) o[(size_t)i * N + G::tail_out(t, k + c)] = r[c][i];
+          if ((u32)i < K) st_tail_out<L>(buf_row(ro, (size_t)i * N), t, k + c, r[c][i]);
 #pragma unroll
       for (int kk = 0; kk + NCM < 4; kk++) {
 #pragma unroll
@@ -2028,7 +2029,7 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
     behz_floor_sk_coeff<KMAX>(ctx, y[0], xb[0], r);
 #pragma unroll
     for (int i = 0; i < KMAX; i++)
-      if ((u32)i < K) o[(size_t)i * N + G::tail_out(t, k)] = r[i];
+      if ((u32)i < K) st_tail_out<L>(buf_row(ro, (size_t)i * N), t, k, r[i]);
 #pragma unroll
     for (int kk = 0; kk < 3; kk++) {
 #pragma unroll

@@ -8,12 +8,21 @@
 
 namespace hipbfv {
 
-// LDS placement of coefficient e: an XOR swizzle of the low five (bank) bits with bits 5..8, chosen so
-// that every access pattern of every pass (strides 1, 8, 16 words and the split 8+64 / 16+256 patterns of
-// the middle passes) maps the 32 lanes of a half-wave to 32 distinct 8-byte banks.  bank = e[0:5] ^
-// (e5 ? 00001) ^ (e6 ? 01010) ^ (e7 ? 10100) ^ (e8 ? 11000); it is a bijection on each 32-word block.
+// LDS placement of coefficient e: a GF(2)-linear map of the low five index bits (a bijection on each 32-word block), found by
+// tools/lds_swizzle_search.py under the LDS model of MI355X_MICROARCH.md:
+//   ds_read_b64                          : two groups of 32 lanes, 32 eight-byte banks -> the five lowest lane bits must reach five
+//                                          independent bank vectors;
+//   ds_write_b64, ds_read2 / ds_write2   : FOUR groups of 16 contiguous lanes, 16 eight-byte banks -> the four lowest lane bits must
+//                                          be independent modulo bank bit 4.
+// r01-r04 searched under the first rule only (bits 0..4 ^= e5*00001 ^ e6*01010 ^ e7*10100 ^ e8*11000 here, another map in the
+// middle kernels): conflict free for the reads, 25-33 % extra LDS cycles on every store whose 16 lanes reach index bit 4 -- measured
+// in r05 as SQ_LDS_BANK_CONFLICT = 27-29 % of SQ_LDS_IDX_ACTIVE in mul_mid<13> / ks_mid<13> (profiles/r05_s5_*_pmc_lds.txt).  No map
+// that leaves bit 4 alone satisfies both rules.  This one is conflict free under BOTH for every pass window of the whole-polynomial
+// transforms (N = 1024 ... 16384, 8 and 16 elements per thread, the linear read-out included) AND of the middle kernels
+// (kernels_split.hip blk_pos: L = 12 ... 15, 8 and 16 elements per thread):
+//   low5(e) = e[0:5] ^ e4*00101 ^ e5*01110 ^ e6*01001 ^ e7*11000 ^ e8*10000
 __device__ __forceinline__ u32 lds_pos(u32 e) {
-  const u32 m = ((e >> 5) & 1u) ^ (((e >> 6) & 1u) * 0x0Au) ^ (((e >> 7) & 1u) * 0x14u) ^ (((e >> 8) & 1u) * 0x18u);
+  const u32 m = (((e >> 4) & 1u) * 0x05u) ^ (((e >> 5) & 1u) * 0x0Eu) ^ (((e >> 6) & 1u) * 0x09u) ^ (((e >> 7) & 1u) * 0x18u) ^ (((e >> 8) & 1u) * 0x10u);
   return e ^ m;
 }
 

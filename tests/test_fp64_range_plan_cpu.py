@@ -283,3 +283,34 @@ def test_mixed_base_sums_take_wide_data_residues_as_two_exact_halves(data_bits):
             assert exact
             assert abs(acc) + abs(t) <= 4.5 * p * 1.000001 and 4.5 * p < LIMIT / 8  # nine terms of at most p/2 each: nowhere near 2^53
             assert (acc - exact_sum) % p == 0
+
+
+def test_lds_placement_is_conflict_free_under_both_lane_group_rules():
+    """nttcore.hpp lds_pos (= kernels_split.hip blk_pos) against tools/lds_swizzle_search.py: the map in the header is the one the tool
+    holds, and every pass window of every transform shape is conflict free both for 32-lane loads over 32 eight-byte banks and for
+    16-lane stores / merged loads over 16 (the LDS model of MI355X_MICROARCH.md; lane-by-lane simulation + the linear criterion)."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import lds_swizzle_search as S
+
+    src = open(os.path.join(root, "sunscreen_amd", "csrc", "nttcore.hpp")).read()
+    body = src[src.index("u32 lds_pos(u32 e) {"):]
+    body = body[:body.index("}")]
+    cols = {int(b): int(c, 16) for b, c in re.findall(r"\(\(e >> (\d+)\) & 1u\) \* (0x[0-9A-Fa-f]+)u", body)}
+    assert cols, "could not read the map out of nttcore.hpp"
+    for b, c in cols.items():
+        assert S.IN_TREE[b] == (c ^ ((1 << b) if b < 5 else 0)), (b, hex(c))
+    assert set(cols) == {b for b in S.IN_TREE if S.IN_TREE[b] != ((1 << b) if b < 5 else 0)}
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "lds_swizzle_search.py"), "check"], capture_output=True).returncode == 0
+    # the map of rounds 1-4 passes the 32-lane rule and fails the 16-lane one: the measurement that prompted the new search
+    old = {0: 1, 1: 2, 2: 4, 3: 8, 4: 16, 5: 0b00101, 6: 0b01010, 7: 0b10001}
+    cons = S.constraints()
+    split = [c for c in cons]
+    assert not S.satisfies(old, split)
+    got, floor = S.simulate(old, ("split", 13, 8))
+    assert got > floor
