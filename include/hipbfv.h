@@ -410,6 +410,9 @@ long hipbfv_debug_aux_base(uint64_t poly_modulus_degree, const uint64_t *coeff_p
 /* The schedule Run follows, one line per step ("mul_relin members=3 square", "sum members=2 terms=6", "plain_matrix members=256
  * columns=256", ...): `*needed` = bytes including the terminator; `buffer` may be NULL to ask for the size. */
 long hipbfv_Program_Describe(void *program, char *buffer, uint64_t capacity, uint64_t *needed);
+/* Run: one stream synchronisation per 32768 input sets (the status word is read once per such chunk; batches up to 32768 --
+ * every BASELINE configuration -- synchronise once, at exit).  A batch above 32768 runs as consecutive chunks over offset
+ * pointers: a failure or a transparent result in chunk k returns its error with the outputs of chunks 0 .. k-1 already written. */
 long hipbfv_Program_Run(void *program, void *evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t *input_kinds,
                         const uint64_t *const *input_ptrs, const uint64_t *input_strides, void *relin_keys,
                         void *galois_keys, uint64_t num_outputs, uint64_t *const *outputs, void *stream);

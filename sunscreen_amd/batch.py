@@ -221,7 +221,9 @@ class BatchEvaluator:
         out = torch.empty((flat.shape[0], self.K, self.n), dtype=torch.int64, device=plain.device)
         _check(_lib.load().hipbfv_batch_plain_to_ntt(self._h, _ptr(flat), self.n, _ptr(out), flat.shape[0], _stream()))
         # an all-zero plaintext has no transformed form (SEAL refuses every product with it, and the consumers of `out` cannot
-        # see it any more): the producer recorded it, and this is where the caller learns -- static data is transformed once
+        # see it any more): the producer recorded it, and this is where the caller learns -- static data is transformed once.
+        # check() synchronises the stream and reads-and-resets the evaluator's ONE status word: what it raises covers every
+        # batched operation since the previous check, not this call alone ("Asynchronous status").
         self.check()
         return out.reshape(tuple(plain.shape[:-1]) + (self.K, self.n))
 

@@ -742,6 +742,7 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     const char* rows_env = std::getenv("HIPBFV_PACK_ROWS");
     if (part && rows_env && rows_env[0] == '1') h.pack_mul = 2;  // (the auxiliary rows alone are S of the K + S rows)
   }
+  if (h.pack_mul == 2 && K + h.S > 32) return fail("internal: per-row packing covers at most 32 rows (DevCtx::mul_row_mask)");
   h.mid_nd = h.mid_ndp = h.mid_ni = 0;
   h.mul_row_mask = 0;
   for (u32 r = 0; r < K + h.S; r++) {

@@ -43,6 +43,8 @@ hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u
 hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse,
                             int scale_mode, hipStream_t s);
 // split (head / middle / tail) key switch, kernels_split.hip
+// res_* (here and in launch_mul_mid): device byte lists of residue indices, read through the scalar unit as 32-bit words -- they must be
+// 4-byte aligned and readable up to the next word boundary (the DevCtx members are; the launchers refuse anything else)
 hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
 hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd, const unsigned char* res_i, u32 ni,
                          const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s);

@@ -2376,6 +2376,7 @@ template <int L>
 static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
                            const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s) {
   using Sh = SplitShape<L>;
+  if (((reinterpret_cast<uintptr_t>(res_d) | reinterpret_cast<uintptr_t>(res_i)) & 3u) != 0) return hipErrorInvalidValue;  // residue_of reads words
   const size_t ops8 = (ops + 7) / 8 * 8;
   if (nd) {
     const dim3 grid((unsigned)(ops8 * nd * Sh::NBLK));
@@ -2458,6 +2459,7 @@ template <int L>
 static hipError_t mul_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, const unsigned char* res_dp, u32 ndp, const unsigned char* res_d, u32 nd,
                             const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, bool square, hipStream_t s) {
   using Sh = SplitShape<L>;
+  if (((reinterpret_cast<uintptr_t>(res_dp) | reinterpret_cast<uintptr_t>(res_d) | reinterpret_cast<uintptr_t>(res_i)) & 3u) != 0) return hipErrorInvalidValue;
   const size_t ops_g = MUL_MID_SLICE(L) ? (ops + 7) / 8 * 8 : ops;  // the slice-major order deals whole groups of 8 ops to the XCDs
   constexpr unsigned TDP = MulMidGeom<L, true, false, true>::TPB, TD = MulMidGeom<L, true, false, false>::TPB, TI = MulMidGeom<L, false>::TPB;
   if (square) {
