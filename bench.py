@@ -720,7 +720,7 @@ def measure(args, env: Env, secondary: bool = False):
     op_rate_gbs = unit_bytes * (value / world) / 1e9
     if dom:
         name, rec = dom
-        # algorithmic bytes of one launch of that kernel (DESIGN.md section 5)
+        # algorithmic bytes of one launch of that kernel (DESIGN.md section 5.2)
         S_, R_ = ctx_S(ctx), K + ctx_S(ctx)
         bm, bk = (6 if getattr(ctx, "packed_mul", False) else 8), (6 if getattr(ctx, "packed_ks", False) else 8)
         if getattr(ctx, "packed_mul_rows", False):
@@ -796,7 +796,7 @@ def measure(args, env: Env, secondary: bool = False):
             "algorithmic_bytes_per_launch": int(unit_bytes * units_per_launch),
             "whole_op": {"achieved": round(op_rate_gbs, 1), "frac": round(op_rate_gbs / HBM_PEAK_GBS, 4),
                          "definition": "algorithmic_bytes_per_unit x units/s per GPU over ALL kernels of the pipeline (SURVEY 8d: bytes_algorithmic x ops/s / 8e12)"},
-            # the kernel's OWN reads and writes (pipeline intermediates included, DESIGN.md section 5.4) over the same
+            # the kernel's OWN reads and writes (pipeline intermediates included, DESIGN.md section 5.2) over the same
             # launch time: what it keeps in flight, not what the operation has to move
             "kernel_hbm": {"bytes_per_launch": int(kernel_bytes_per_launch), "achieved": round(kernel_rate, 1),
                            "frac": round(kernel_rate / HBM_PEAK_GBS, 4)},
@@ -957,9 +957,9 @@ def compact_secondary(rec):
     what was run, the measurement, the roofline figures, the CPU baseline and whether the parity gate passed."""
     roof = rec.get("roofline") or {}
     cpu = rec.get("cpu_baseline") or {}
-    kern = sorted((rec.get("kernels_ms_per_step") or {}).items(), key=lambda kv: -kv[1])[:4]
+    kern = sorted((rec.get("kernels_ms_per_step") or {}).items(), key=lambda kv: -kv[1])[:3]
     out = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
-           "repeats": rec["repeats"], "spread": rec["spread"],
+           "spread": rec["spread"],
            "config": {"n": rec["config"].get("poly_modulus_degree"), "primes": rec["config"].get("coeff_modulus_primes"), "batch": rec["config"].get("batch_per_gpu")},
            "roofline": {"kernel": roof.get("kernel"), "bound": roof.get("bound"), "achieved": roof.get("achieved"), "frac": roof.get("frac"),
                         "traffic": roof.get("traffic"), "avg_launch_ms": roof.get("avg_launch_ms"),

@@ -595,7 +595,7 @@ long finish_result(EvalObj* e, CipherObj* dst, u32 size, u64* buf, size_t words,
 }  // namespace
 
 // The C ABI is the library's only interface: with `make HIDDEN=1` (-fvisibility=hidden) everything else stays inside the DSO
-// (the internal hipbfv:: C++ symbols are otherwise exported and can be interposed by user code).
+// (HISTORY.md section 11: the internal hipbfv:: C++ symbols are otherwise exported and can be interposed by user code).
 //
 // Exception barrier: no C++ exception may unwind through an extern "C" frame into Rust / ctypes (abort or UB there).  Every
 // exported function is a function-try-block that maps what is thrown to the HRESULT SEAL's C layer would return

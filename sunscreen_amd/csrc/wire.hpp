@@ -8,7 +8,7 @@ namespace hipbfv {
 
 // kWireSeeded: a seed-compressed ("compact") object -- SEAL stores the first polynomial and a PRNG seed for the second;
 // expanding it means reproducing SEAL's Blake2xb / SHAKE256 stream and rejection sampling bit for bit, which nothing here
-// could be checked against (DESIGN.md 10): refused with its own message instead of loading as garbage
+// could be checked against (DESIGN.md section 9): refused with its own message instead of loading as garbage
 enum WireStatus : int { kWireOk = 0, kWireBadArg = -1, kWireIo = -2, kWireNoZstd = -3, kWireSeeded = -4 };
 
 struct WireCiphertext {

@@ -126,7 +126,7 @@ def test_north_star_literal_3x54bit_primes_mul_relin_and_rotate():
 
 
 def test_3x54bit_mixed_and_seal_auxiliary_bases_give_the_same_bits():
-    """The mixed auxiliary base (integer data primes, the library's FP64-pipe auxiliary primes: DESIGN.md 4.3) is the default for the
+    """The mixed auxiliary base (integer data primes, the library's FP64-pipe auxiliary primes: DESIGN.md section 4) is the default for the
     north star's literal prime set; HIPBFV_SEAL_AUX=1 keeps SEAL's 61-bit base.  BEHZ's result does not depend on the base:
     the same seeded operands (random, and every residue at its maximum) through both, in separate processes, word for word --
     and the default one against the oracle."""

@@ -2,7 +2,7 @@
 
 tests/test_oracle_behz_exact.py and tests/test_oracle_keyswitch_exact.py (CPU suite) hold the integer restatements and show that
 the oracle gives their bits.  Here the library's multiply and multiply + relinearize are compared with the same integer
-models directly: the library's own auxiliary base (sized by the derived bound, DESIGN.md 4.3) never appears in the model, so
+models directly: the library's own auxiliary base (sized by the derived bound, DESIGN.md section 4) never appears in the model, so
 this is the claim "the product does not depend on which auxiliary primes are used" tested on the device.  (The oracle is
 used only to generate keys and to bring them to coefficient form.)
 """

@@ -14,7 +14,7 @@ has an integer meaning that does not mention the auxiliary base at all:
 The oracle (oracle/ora_eval.c) and the library do this in residues with an auxiliary base (SEAL's 61-bit one in the oracle, the
 library's own in libhipbfv); here it is done with Python integers and Kronecker substitution for the products, for random
 operands and for the operands that drive every intermediate to its largest magnitude.  Agreement pins the oracle's multiply on
-something that is not a transcription of it -- and is the direct form of DESIGN.md 4.3's claim that the product does not
+something that is not a transcription of it -- and is the direct form of DESIGN.md section 4's claim that the product does not
 depend on WHICH auxiliary primes are used.
 
 Test infrastructure: imports oracle/ as the thing under test.
