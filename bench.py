@@ -332,7 +332,7 @@ def kernel_source_hash() -> str:
     """sha256 over the device code and the host code that picks launch sequences and reduce masks: the PMC-derived fields of
     the bench line are only valid for the kernels they were measured on (profiles/pmc_traffic.json records this hash)."""
     d = os.path.join(ROOT, "sunscreen_amd", "csrc")
-    device_headers = ("devctx.hpp", "devarith.hpp", "griddot.hpp", "nttshape.hpp", "nttcore.hpp", "behzcore.hpp", "kernels.hpp", "rng.hpp")
+    device_headers = ("devctx.hpp", "devarith.hpp", "griddot.hpp", "moddown_d.hpp", "nttshape.hpp", "nttcore.hpp", "behzcore.hpp", "kernels.hpp", "rng.hpp")
     names = sorted(f for f in os.listdir(d) if f.endswith(".hip") or f in device_headers or f in ("context.cpp", "evaluator.cpp", "Makefile"))
     h = hashlib.sha256()
     for f in names:

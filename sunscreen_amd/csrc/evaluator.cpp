@@ -172,9 +172,12 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   // up to 32 GiB of scratch per chunk (of 288 GB): launches of 1024 ops at every degree up to N = 16384.  Measured at N = 16384
   // (r03, one box): chunks of 256 / 512 / 1024 ops give 49.6 / 50.2 / 51.3 K mul+relin/s -- a longer walk over one key slice
   // per XCD in ks_mid (5.86 -> 5.48 ms) and fewer launch tails; the 8 GiB cap of rounds 1-2 meant 292 ops there.
+  // r05: the cap on ops per chunk is 4096 (was 1024): at N <= 8192 a chunk is then limited by the cap, at N = 16384 by the 32 GiB of
+  // scratch (~1100 ops).  Interleaved on one box (profiles/r05_chunk_ab.txt): n = 8192, batch 4096: 330.0 K -> 331.8 K (2048 per chunk)
+  // -> 332.2 K (4096); n = 16384, batch 2048, 1024 -> 2048 per chunk: 58.1 K -> 59.2 K -- fewer launch tails, as r03 found below 1024.
   size_t c = ((size_t)32 << 30) / per_op;
   if (const char* env = std::getenv("HIPBFV_CHUNK_OPS")) c = (size_t)std::strtoull(env, nullptr, 10);
-  chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 1024));
+  chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 4096));
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS")) split_ks_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_MUL")) split_mul_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_TAIL")) fuse_mulrelin_ = env[0] != '1';

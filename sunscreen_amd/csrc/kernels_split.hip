@@ -737,14 +737,18 @@ __device__ __forceinline__ BufRsrc buf_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
 }
 // an OPTIONAL operand: absent = a descriptor of zero records, whose loads return 0 without touching memory (the hardware bounds
-// check) -- so the request can be issued unconditionally, beside the others, and costs nothing when there is nothing to read
-// (the inputs go through readfirstlane: left to itself the compiler selects between the two pointers with v_cndmask, holds the
-// descriptor in VGPRs and wraps every load in a waterfall loop -- seen in the first listing of this code)
-__device__ __forceinline__ BufRsrc buf_rsrc_opt(const void* base, const void* fallback) {
-  const u64 p = reinterpret_cast<u64>(base ? base : fallback);
-  const u32 lo = __builtin_amdgcn_readfirstlane((u32)p), hi = __builtin_amdgcn_readfirstlane((u32)(p >> 32));
-  const int records = (int)__builtin_amdgcn_readfirstlane(base ? 0xFFFFFFFFu : 0u);
-  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((u64)hi << 32) | lo), 0, records, 0x00020000);
+// check) -- so the request can be issued unconditionally, beside the others, and costs nothing when there is nothing to read.
+// `base` is used as it is (for an absent operand it may be null + an offset: never dereferenced).  The record count is formed by a
+// SCALAR instruction inside an asm: written as `present ? ~0 : 0` it is lowered to v_cndmask (and a readfirstlane of it is dropped as
+// redundant -- the value IS uniform), the descriptor ends up half in VGPRs and every load from it is wrapped in a waterfall loop
+// (4 v_readfirstlane, 2 v_cmp_eq_u64, s_and_saveexec ...: 12 such loops in mulrelin_tail<13,4>, 29 in <14,8>, 8 in every ks_tail,
+// found in the ISA listing).  Removing them is -6 ... -20 % static instructions in those kernels and no measurable time
+// (profiles/r05_s8_no_waterfall_*.txt: a waterfall over a uniform value runs once, mostly on the scalar unit).
+__device__ __forceinline__ BufRsrc buf_rsrc_opt(const void* base, bool present) {
+  const u32 flag = __builtin_amdgcn_readfirstlane(present ? 1u : 0u);
+  u32 records;
+  asm volatile("s_sub_u32 %0, 0, %1" : "=s"(records) : "s"(flag) : "scc");  // 0 or 0xFFFFFFFF, in an SGPR
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)records, 0x00020000);
 }
 struct BufRow {
   BufRsrc r;
@@ -1199,8 +1203,8 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
     // buffer addressing (BufRow): the accumulator rows, the two optional operands (absent = a descriptor of zero records) and the output
     const bool has_base = ((base_mask >> c) & 1u) != 0;
     const BufRsrc racc = buf_rsrc(acc), rout = buf_rsrc(out + ((size_t)op * 2 + c) * K * N);
-    const BufRsrc rbase = buf_rsrc_opt(has_base ? base + (size_t)op * bstride + (size_t)c * K * N : nullptr, acc);
-    const BufRsrc rex = buf_rsrc_opt(extra ? extra + ((size_t)op * 2 + c) * K * N : nullptr, acc);
+    const BufRsrc rbase = buf_rsrc_opt(base + (size_t)op * bstride + (size_t)c * K * N, has_base);
+    const BufRsrc rex = buf_rsrc_opt(extra + ((size_t)op * 2 + c) * K * N, extra != nullptr);
     double v[4], tld[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACK>(nat_fetch_tail<L, PACK, NtSites<L>::tail_ld>(buf_row(racc, (size_t)(KK - 1) * N), t, k));
@@ -1257,8 +1261,8 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
   // MIXED (8-byte rows of either policy): the special prime's residue as a canonical u64
   const bool has_base = ((base_mask >> c) & 1u) != 0;
   const BufRsrc racc = buf_rsrc(acc), rout = buf_rsrc(out + ((size_t)op * 2 + c) * K * N);  // buffer addressing: see BufRow
-  const BufRsrc rbase = buf_rsrc_opt(has_base ? base + (size_t)op * bstride + (size_t)c * K * N : nullptr, acc);
-  const BufRsrc rex = buf_rsrc_opt(extra ? extra + ((size_t)op * 2 + c) * K * N : nullptr, acc);
+  const BufRsrc rbase = buf_rsrc_opt(base + (size_t)op * bstride + (size_t)c * K * N, has_base);
+  const BufRsrc rex = buf_rsrc_opt(extra + ((size_t)op * 2 + c) * K * N, extra != nullptr);
   u64 tl[4];
   bool sp_done = false;
   {
@@ -2060,7 +2064,7 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
   const double* acc = ACC + ((size_t)op * 2 + c) * KK * N;
   // buffer addressing (BufRow): the accumulator rows, the optional addend and the output
   const BufRsrc racc = buf_rsrc(acc), rout = buf_rsrc(out + ((size_t)op * 2 + c) * K * N);
-  const BufRsrc rex = buf_rsrc_opt(extra ? extra + ((size_t)op * 2 + c) * K * N : nullptr, acc);
+  const BufRsrc rex = buf_rsrc_opt(extra + ((size_t)op * 2 + c) * K * N, extra != nullptr);
   double tld[4];
   {
     const DevMod& sp = ctx->mod[KK - 1];

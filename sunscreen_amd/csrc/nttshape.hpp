@@ -47,7 +47,7 @@ constexpr int tail_log(int logn) { return lane_split(logn) ? 3 : 2; }
 constexpr int kHeadLogMax = 3;
 constexpr int kTailLog = 2;  // degrees without lane splitting
 // Elements per middle-kernel thread: 8 (radix <= 8 passes).  4 (radix <= 4 passes, twice the threads, about half the
-// registers, ~40 % more passes) is a build-time experiment (-DHIPBFV_BLK_EPT=4), see DESIGN.md 5.5.
+// registers, ~40 % more passes) is a build-time experiment (-DHIPBFV_BLK_EPT=4), see HISTORY.md 5.5.
 #ifndef HIPBFV_BLK_EPT
 #define HIPBFV_BLK_EPT 8
 #endif
