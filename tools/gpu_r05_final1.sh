@@ -4,7 +4,7 @@
 # trace of the driver's default command.  Step 2 (container): tools/pmc_merge.sh r05_final <key> per key -> profiles/pmc_traffic.json.
 # Step 3 (GPU): tools/gpu_r05_final2.sh.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-T=r05_final2
+T=r05_final
 O=gpurun_out/$T; mkdir -p $O
 ( time timeout 1200 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log
 bash tools/gpu_variant_suites.sh > $O/variant_suites.txt 2>&1; cat $O/variant_suites.txt
