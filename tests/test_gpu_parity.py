@@ -483,6 +483,64 @@ def test_multiply_large_plain_modulus_own_base(n, tbits):
 
 
 @pytest.mark.skipif(_own_base_off, reason="the own auxiliary base is switched off by the environment")
+@pytest.mark.parametrize("n,bits", [(8192, [46, 47, 47, 48]), (8192, [45, 45, 46, 46, 47]), (16384, [46, 47, 47, 47, 47, 48])])
+def test_plan_flags_on_primes_that_keep_their_store_side_reductions(n, bits):
+    """r05's range plan skips the reduction in front of a packed store and after the tail's scaling where a prime is small enough
+    (every prime of the default sets at n = 8192).  These sets sit on the OTHER side of those decisions -- 45 ... 48-bit data and
+    key primes, packed rows (all below 2^48), kPlanStoreReduce set for the head's and / or the middle kernel's outputs, the one
+    reduction of the inverse not in the last pass -- and must give the oracle's bits too: multiply and the fused multiply +
+    relinearize (K <= 4: five launches; K = 5: the 8-prime instantiations), on random operands and on the ones that drive
+    every intermediate to its extreme (all q_i - 1, all floor(q/2), alternating signs)."""
+    import ctypes as C
+
+    from sunscreen_amd import Context, RelinearizationKeys, _lib
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    primes = O.coeff_modulus_create(n, bits)
+    t = O.plain_batching(n, 17)
+    o = O.Oracle(n, primes, t)
+    o.throw_on_transparent = False
+    O.seed(4647)
+    sk, pk, rk, _ = o.keygen()
+    logn = n.bit_length() - 1
+    flags = 0
+    for q in primes:  # the plans really are on the far side of at least one skip for some prime of the set
+        out = (C.c_uint32 * 6)()
+        assert _lib.load().hipbfv_debug_f64_plan(C.c_uint64(int(q)), C.c_uint32(logn), out) == 0 and out[0] == 1 and out[3] == 1
+        flags |= (out[4] | out[5]) & (1 << 30)
+    assert flags, "no prime of this set keeps a store-side reduction: the test would not test what it says"
+    ctx = Context.from_raw(n, primes, t)
+    assert ctx.aux_fp64 and ctx.packed_mul
+    ev = BatchEvaluator(ctx)
+    ev.set_transparent_check(False)
+    rkd = RelinearizationKeys.from_array(ctx, rk)
+    K = len(primes) - 1
+    rng = np.random.default_rng(sum(bits))
+    cnt = 20  # beyond the few-operations threshold: the split pipelines run these
+    a = np.stack([rng.integers(0, q, (cnt, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    b = np.stack([rng.integers(0, q, (cnt, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2)
+    Q = 1
+    for q in primes[:K]:
+        Q *= q
+    half = Q // 2
+    sign = np.where(np.arange(n) % 2 == 0, 1, -1)
+    for i, q in enumerate(primes[:K]):
+        a[2, :, i, :] = q - 1
+        b[2, :, i, :] = q - 1
+        a[3, :, i, :] = half % q
+        b[3, :, i, :] = half % q
+        a[4, :, i, :] = np.where(sign > 0, half % q, (Q - half) % q).astype(np.uint64)
+        b[4, :, i, :] = half % q
+    da, db = to_device(a), to_device(b)
+    m = to_host(ev.multiply(da, db))
+    r = to_host(ev.multiply_relin(da, db, rkd))
+    for i in (0, 1, 2, 3, 4, cnt - 1):
+        om = o.multiply(a[i], b[i])
+        assert (m[i] == om).all(), ("multiply", i)
+        assert (r[i] == o.relinearize(om, rk)).all(), ("multiply_relin", i)
+
+
+@pytest.mark.skipif(_own_base_off, reason="the own auxiliary base is switched off by the environment")
 @pytest.mark.parametrize("n,tbits,size", [(4096, 30, 8), (8192, 50, 4), (8192, 17, 3)])
 def test_multiply_extreme_operands_of_larger_sizes_own_base(n, tbits, size):
     """Evaluator::multiply accepts size_a + size_b <= 16: a coefficient of the tensor is then a sum of up to 8 negacyclic
