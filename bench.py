@@ -906,6 +906,8 @@ def main():
             try:
                 rec = measure(sub, env, secondary=True)
             except Exception as e:  # noqa: BLE001 -- recorded, and the process exits non-zero after printing
+                if env.world > 1:
+                    raise  # one rank skipping ahead would leave the others in this job's barrier: fail the launch as before
                 failed = True
                 if env.rank == 0:
                     second[key] = {"error": f"{type(e).__name__}: {e}"[:300], "parity_ok": False}
