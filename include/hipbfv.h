@@ -302,6 +302,29 @@ long hipbfv_batch_rotate_rows(void *evaluator, const uint64_t *ct2, int steps, v
                               uint64_t count, void *stream);
 long hipbfv_batch_rotate_columns(void *evaluator, const uint64_t *ct2, void *galois_keys, uint64_t *out2,
                                  uint64_t count, void *stream);
+/* Per-key batches (multi-tenant serving).  The reference hands the keys over with every call
+ * (sunscreen_runtime/src/run.rs:100-105: `relin_keys: &Option<&RelinearizationKeys>`, `galois_keys: &Option<&GaloisKeys>`;
+ * runtime.rs:310-327), so a server that batches the calls of many clients holds one key set per client.  These are the
+ * three key-switching operations above with `num_key_sets` key handles (RelinearizationKeys resp. GaloisKeys objects of the
+ * evaluator's context) and, per item, the set it uses: key_index is a HOST array of `count` entries < num_key_sets, read
+ * before the call returns.  Item i gives the bits of the single-key call with key_sets[key_index[i]].  Items need not be
+ * grouped by key: the key-switch kernel walks them in key order, so items of one client share that client's key rows in
+ * one XCD's L2; with one key set per item the key (16 K (K+1) N bytes) is part of every item's compulsory traffic.
+ * rotate_rows_keys follows SEAL's rotate_internal: the direct key when EVERY set holds it, the NAF chain otherwise. */
+long hipbfv_batch_relinearize_keys(void *evaluator, const uint64_t *ct3, void *const *relin_key_sets, uint64_t num_key_sets,
+                                   const uint32_t *key_index, uint64_t *out2, uint64_t count, void *stream);
+long hipbfv_batch_multiply_relin_keys(void *evaluator, const uint64_t *a, const uint64_t *b, void *const *relin_key_sets,
+                                      uint64_t num_key_sets, const uint32_t *key_index, uint64_t *out2, uint64_t count,
+                                      void *stream);
+long hipbfv_batch_apply_galois_keys(void *evaluator, const uint64_t *ct2, uint32_t galois_elt, void *const *galois_key_sets,
+                                    uint64_t num_key_sets, const uint32_t *key_index, uint64_t *out2, uint64_t count,
+                                    void *stream);
+long hipbfv_batch_rotate_rows_keys(void *evaluator, const uint64_t *ct2, int steps, void *const *galois_key_sets,
+                                   uint64_t num_key_sets, const uint32_t *key_index, uint64_t *out2, uint64_t count,
+                                   void *stream);
+long hipbfv_batch_rotate_columns_keys(void *evaluator, const uint64_t *ct2, void *const *galois_key_sets,
+                                      uint64_t num_key_sets, const uint32_t *key_index, uint64_t *out2, uint64_t count,
+                                      void *stream);
 long hipbfv_batch_add(void *evaluator, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t size,
                       uint64_t count, void *stream);
 long hipbfv_batch_sub(void *evaluator, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t size,
@@ -416,6 +439,14 @@ long hipbfv_Program_Describe(void *program, char *buffer, uint64_t capacity, uin
 long hipbfv_Program_Run(void *program, void *evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t *input_kinds,
                         const uint64_t *const *input_ptrs, const uint64_t *input_strides, void *relin_keys,
                         void *galois_keys, uint64_t num_outputs, uint64_t *const *outputs, void *stream);
+
+/* Run with one key set per client: input set i of the batch uses relin_keys[key_index[i]] / galois_keys[key_index[i]]
+ * (HOST arrays: num_key_sets handles each -- an entry may be NULL when the program needs no such key -- and `batch`
+ * indices).  Same bits per input set as hipbfv_Program_Run with that set's keys (the reference's call, run.rs:100-105). */
+long hipbfv_Program_RunKeys(void *program, void *evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t *input_kinds,
+                            const uint64_t *const *input_ptrs, const uint64_t *input_strides, uint64_t num_key_sets,
+                            void *const *relin_keys, void *const *galois_keys, const uint32_t *key_index,
+                            uint64_t num_outputs, uint64_t *const *outputs, void *stream);
 
 /* Per-kernel timing (HIP events recorded on the launch stream, around every kernel launch):
  * total milliseconds, number of launches and work units (residue polynomials for the NTT kernels,

@@ -9,6 +9,7 @@ only for device memory and streams -- all arithmetic happens in libhipbfv.so.
 from __future__ import annotations
 
 import ctypes as C
+from typing import Sequence
 
 import numpy as np
 import torch
@@ -125,6 +126,53 @@ class BatchEvaluator:
         self._shape_ok(ct, 2)
         out = out if out is not None else self._new(ct.shape[0], 2, ct)
         _check(_lib.load().hipbfv_batch_rotate_columns(self._h, _ptr(ct), gk.get_handle(), _ptr(out), ct.shape[0], _stream()))
+        return out
+
+    # ---- per-key batches (multi-tenant: the reference passes the keys per call, sunscreen_runtime/src/run.rs:100-105) ----
+    @staticmethod
+    def _key_sets(key_sets, key_index, count: int):
+        handles = (C.c_void_p * len(key_sets))(*[k.get_handle() for k in key_sets])
+        idx = np.ascontiguousarray(np.asarray(key_index, dtype=np.uint32))
+        assert idx.shape == (count,), (idx.shape, count)
+        return handles, len(key_sets), idx.ctypes.data_as(C.POINTER(C.c_uint32)), idx
+
+    def relinearize_keys(self, ct3: torch.Tensor, key_sets: Sequence[RelinearizationKeys], key_index, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Item i is relinearised with key_sets[key_index[i]] (key_index: `count` host integers)."""
+        self._shape_ok(ct3, 3)
+        out = out if out is not None else self._new(ct3.shape[0], 2, ct3)
+        hs, n, ip, _keep = self._key_sets(key_sets, key_index, ct3.shape[0])
+        _check(_lib.load().hipbfv_batch_relinearize_keys(self._h, _ptr(ct3), hs, n, ip, _ptr(out), ct3.shape[0], _stream()))
+        return out
+
+    def multiply_relin_keys(self, a: torch.Tensor, b: torch.Tensor, key_sets: Sequence[RelinearizationKeys], key_index,
+                            out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(a, 2)
+        self._shape_ok(b, 2)
+        assert a.shape[0] == b.shape[0]
+        out = out if out is not None else self._new(a.shape[0], 2, a)
+        hs, n, ip, _keep = self._key_sets(key_sets, key_index, a.shape[0])
+        _check(_lib.load().hipbfv_batch_multiply_relin_keys(self._h, _ptr(a), _ptr(b), hs, n, ip, _ptr(out), a.shape[0], _stream()))
+        return out
+
+    def apply_galois_keys(self, ct: torch.Tensor, galois_elt: int, key_sets: Sequence[GaloisKeys], key_index, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(ct, 2)
+        out = out if out is not None else self._new(ct.shape[0], 2, ct)
+        hs, n, ip, _keep = self._key_sets(key_sets, key_index, ct.shape[0])
+        _check(_lib.load().hipbfv_batch_apply_galois_keys(self._h, _ptr(ct), galois_elt, hs, n, ip, _ptr(out), ct.shape[0], _stream()))
+        return out
+
+    def rotate_rows_keys(self, ct: torch.Tensor, steps: int, key_sets: Sequence[GaloisKeys], key_index, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(ct, 2)
+        out = out if out is not None else self._new(ct.shape[0], 2, ct)
+        hs, n, ip, _keep = self._key_sets(key_sets, key_index, ct.shape[0])
+        _check(_lib.load().hipbfv_batch_rotate_rows_keys(self._h, _ptr(ct), steps, hs, n, ip, _ptr(out), ct.shape[0], _stream()))
+        return out
+
+    def rotate_columns_keys(self, ct: torch.Tensor, key_sets: Sequence[GaloisKeys], key_index, out: torch.Tensor | None = None) -> torch.Tensor:
+        self._shape_ok(ct, 2)
+        out = out if out is not None else self._new(ct.shape[0], 2, ct)
+        hs, n, ip, _keep = self._key_sets(key_sets, key_index, ct.shape[0])
+        _check(_lib.load().hipbfv_batch_rotate_columns_keys(self._h, _ptr(ct), hs, n, ip, _ptr(out), ct.shape[0], _stream()))
         return out
 
     # ---- a5 ----

@@ -1704,6 +1704,115 @@ long hipbfv_batch_rotate_columns(void* h, const uint64_t* ct2, void* keys, uint6
   return hipbfv_batch_apply_galois(h, ct2, 2 * e->ctx->n() - 1, keys, out2, count, stream);
 HIPBFV_END
 
+// ---- per-key batches: item i of the batch uses key set key_index[i] (include/hipbfv.h) ----
+// the key `index` (0 = relinearisation, (elt - 1) / 2 = Galois) of every set, as the evaluator's per-item selection; `tab` keeps
+// the pointer table alive for the call.  !present(): a handle is not a key object of this context, or a set lacks the key.
+static KeySel keys_sel(void* const* key_sets, uint64_t num_sets, const uint32_t* key_index, uint64_t count, EvalObj* e, u32 index,
+                       std::vector<const u64*>& tab) {
+  tab.assign(num_sets, nullptr);
+  for (uint64_t k = 0; k < num_sets; k++)
+    if (!(tab[k] = key_or_null(key_sets[k], e, index))) return KeySel();
+  KeySel sel;
+  sel.keys = tab.data();
+  sel.nkeys = (u32)num_sets;
+  sel.index = key_index;
+  sel.period = (size_t)count;
+  return sel;
+}
+#define KEYSETS_OR_RETURN()                                                                   \
+  if (!key_sets || !key_index || !num_sets || num_sets > 0xFFFFFFFFull) return HIPBFV_E_POINTER; \
+  for (uint64_t i__ = 0; i__ < count; i__++)                                                  \
+    if (key_index[i__] >= num_sets) return fail(HIPBFV_E_INVALIDARG, "key_index names a key set that was not given");
+
+long hipbfv_batch_relinearize_keys(void* h, const uint64_t* ct3, void* const* key_sets, uint64_t num_sets, const uint32_t* key_index,
+                                   uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
+  EVAL_OR_RETURN(h);
+  if (!ct3 || !out2) return HIPBFV_E_POINTER;
+  KEYSETS_OR_RETURN();
+  if (!count) return HIPBFV_S_OK;
+  std::vector<const u64*> tab;
+  const KeySel sel = keys_sel(key_sets, num_sets, key_index, count, e, 0, tab);
+  if (!sel.present()) return from_status(kNoKey);
+  return from_status(e->ev->relinearize((const u64*)ct3, sel, (u64*)out2, count, (hipStream_t)stream));
+HIPBFV_END
+
+long hipbfv_batch_multiply_relin_keys(void* h, const uint64_t* a, const uint64_t* b, void* const* key_sets, uint64_t num_sets,
+                                      const uint32_t* key_index, uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
+  EVAL_OR_RETURN(h);
+  if (!a || !b || !out2) return HIPBFV_E_POINTER;
+  KEYSETS_OR_RETURN();
+  if (!count) return HIPBFV_S_OK;
+  std::vector<const u64*> tab;
+  const KeySel sel = keys_sel(key_sets, num_sets, key_index, count, e, 0, tab);
+  if (!sel.present()) return from_status(kNoKey);
+  return from_status(e->ev->multiply_relin((const u64*)a, (const u64*)b, sel, (u64*)out2, count, (hipStream_t)stream));
+HIPBFV_END
+
+long hipbfv_batch_apply_galois_keys(void* h, const uint64_t* ct2, uint32_t elt, void* const* key_sets, uint64_t num_sets,
+                                    const uint32_t* key_index, uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
+  EVAL_OR_RETURN(h);
+  if (!ct2 || !out2) return HIPBFV_E_POINTER;
+  if (!(elt & 1) || elt >= 2 * e->ctx->n()) return from_status(kInvalidArg);
+  KEYSETS_OR_RETURN();
+  if (!count) return HIPBFV_S_OK;
+  std::vector<const u64*> tab;
+  const KeySel sel = keys_sel(key_sets, num_sets, key_index, count, e, (elt - 1) >> 1, tab);
+  if (!sel.present()) return from_status(kNoKey);
+  return from_status(e->ev->apply_galois((const u64*)ct2, elt, sel, (u64*)out2, count, (hipStream_t)stream));
+HIPBFV_END
+
+// SEAL's rotate_internal over per-item key sets: the direct key when EVERY set has it, the NAF chain otherwise
+static long batch_rotate_keys_internal(EvalObj* e, const u64* in, int steps, void* const* key_sets, uint64_t num_sets, const uint32_t* key_index,
+                                       u64* out, uint64_t count, hipStream_t s) {
+  if (steps == 0) return HIPBFV_S_OK;
+  const u32 elt = e->ev->galois_elt_from_step(steps);
+  if (!elt) return fail(HIPBFV_E_INVALIDARG, "step count too large");
+  std::vector<const u64*> tab;
+  if (const KeySel sel = keys_sel(key_sets, num_sets, key_index, count, e, (elt - 1) >> 1, tab); sel.present())
+    return from_status(e->ev->apply_galois(in, elt, sel, out, count, s));
+  std::vector<int> naf;
+  const bool neg = steps < 0;
+  int v = neg ? -steps : steps;
+  for (int i = 0; v; i++) {
+    const int zi = (v & 1) ? 2 - (v & 3) : 0;
+    v = (v - zi) >> 1;
+    if (zi) naf.push_back((neg ? -zi : zi) * (1 << i));
+  }
+  if (naf.size() == 1) return from_status(kNoKey);
+  const u64* cur = in;
+  for (int part : naf) {
+    if ((u32)(part < 0 ? -part : part) == (e->ctx->n() >> 1)) continue;
+    long hr = batch_rotate_keys_internal(e, cur, part, key_sets, num_sets, key_index, out, count, s);
+    if (hr != HIPBFV_S_OK) return hr;
+    cur = out;
+  }
+  return HIPBFV_S_OK;
+}
+
+long hipbfv_batch_rotate_rows_keys(void* h, const uint64_t* ct2, int steps, void* const* key_sets, uint64_t num_sets, const uint32_t* key_index,
+                                   uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
+  EVAL_OR_RETURN(h);
+  if (!ct2 || !out2) return HIPBFV_E_POINTER;
+  if (!e->ctx->batching()) return fail(HIPBFV_COR_E_INVALIDOPERATION, "encryption parameters do not support batching");
+  KEYSETS_OR_RETURN();
+  hipStream_t s = (hipStream_t)stream;
+  if (steps == 0) {
+    if ((const u64*)ct2 != (u64*)out2 &&
+        hipMemcpyAsync(out2, ct2, count * e->ctx->ct_words(2) * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return from_status(kHipError);
+    return HIPBFV_S_OK;
+  }
+  if (!count) return HIPBFV_S_OK;
+  return batch_rotate_keys_internal(e, (const u64*)ct2, steps, key_sets, num_sets, key_index, (u64*)out2, count, s);
+HIPBFV_END
+
+long hipbfv_batch_rotate_columns_keys(void* h, const uint64_t* ct2, void* const* key_sets, uint64_t num_sets, const uint32_t* key_index,
+                                      uint64_t* out2, uint64_t count, void* stream) HIPBFV_BEGIN
+  EVAL_OR_RETURN(h);
+  if (!e->ctx->batching()) return fail(HIPBFV_COR_E_INVALIDOPERATION, "encryption parameters do not support batching");
+  return hipbfv_batch_apply_galois_keys(h, ct2, 2 * e->ctx->n() - 1, key_sets, num_sets, key_index, out2, count, stream);
+HIPBFV_END
+
 long hipbfv_batch_add(void* h, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t size, uint64_t count, void* stream) HIPBFV_BEGIN
   EVAL_OR_RETURN(h);
   if (!a || !b || !out) return HIPBFV_E_POINTER;
@@ -2154,21 +2263,28 @@ long hipbfv_Program_Describe(void* h, char* buffer, uint64_t capacity, uint64_t*
   return HIPBFV_S_OK;
 HIPBFV_END
 
-long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t* input_kinds,
-                        const uint64_t* const* input_ptrs, const uint64_t* input_strides, void* relin_keys, void* galois_keys,
-                        uint64_t num_outputs, uint64_t* const* outputs, void* stream) HIPBFV_BEGIN
+// key_index == nullptr: one key set (num_key_sets = 1) for every input set -- the reference's call
+static long program_run_impl(void* h, void* evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t* input_kinds,
+                             const uint64_t* const* input_ptrs, const uint64_t* input_strides, uint64_t num_key_sets, void* const* relin_keys,
+                             void* const* galois_keys, const uint32_t* key_index, uint64_t num_outputs, uint64_t* const* outputs, void* stream) {
   ProgramObj* p = as<ProgramObj>(h, kMagicProgram);
   EvalObj* e = as<EvalObj>(evaluator, kMagicEval);
   if (!p || !e || (num_inputs && (!input_kinds || !input_ptrs || !input_strides)) || (num_outputs && !outputs)) return HIPBFV_E_POINTER;
   std::vector<ProgramInput> ins(num_inputs);
   for (uint64_t i = 0; i < num_inputs; i++) ins[i] = ProgramInput{(int)input_kinds[i], (const u64*)input_ptrs[i], (size_t)input_strides[i]};
-  const u64* rk = nullptr;
-  std::map<u32, const u64*> gk;
-  if (KeysObj* k = as<KeysObj>(relin_keys, kMagicKeys))
-    if (k->ctx.get() == e->ctx.get()) rk = k->find(0);
-  if (KeysObj* k = as<KeysObj>(galois_keys, kMagicKeys))
-    if (k->ctx.get() == e->ctx.get())
-      for (auto& kv : k->keys) gk[kv.first] = kv.second;
+  ProgramKeys keys;
+  keys.relin.assign(num_key_sets, nullptr);
+  keys.galois.resize(num_key_sets);
+  for (uint64_t k = 0; k < num_key_sets; k++) {
+    if (KeysObj* ko = as<KeysObj>(relin_keys ? relin_keys[k] : nullptr, kMagicKeys))
+      if (ko->ctx.get() == e->ctx.get()) keys.relin[k] = ko->find(0);
+    if (KeysObj* ko = as<KeysObj>(galois_keys ? galois_keys[k] : nullptr, kMagicKeys))
+      if (ko->ctx.get() == e->ctx.get())
+        for (auto& kv : ko->keys) keys.galois[k][kv.first] = kv.second;
+  }
+  if (key_index)
+    for (uint64_t i = 0; i < batch; i++)
+      if (key_index[i] >= num_key_sets) return fail(HIPBFV_E_INVALIDARG, "key_index names a key set that was not given");
   std::string err;
   // the reference's runtime.run fails when any node's result is transparent (SEAL built with throw-on-transparent,
   // seal_fhe/build.rs:46-66; sunscreen/tests/features.rs:8-34; error collapse run.rs:78-82): every node's results are
@@ -2196,10 +2312,12 @@ long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_i
       else ins[i].ptr += off * ins[i].stride;  // stride 0: one shared plaintext
     }
     for (uint64_t k = 0; k < num_outputs; k++) outs[k] = outputs[k] ? (u64*)outputs[k] + off * ct_words : nullptr;
+    keys.index = key_index ? key_index + off : nullptr;  // input set i of this chunk = input set off + i of the call
+    keys.period = (size_t)c;
     int st;
     {
       WatchScope watch(status);
-      st = p->prog.run(*e->ev, c, ins.data(), ins.size(), rk, gk, outs.data(), num_outputs, s, &err);
+      st = p->prog.run(*e->ev, c, ins.data(), ins.size(), keys, outs.data(), num_outputs, s, &err);
     }
     u32 first_bad = 0xFFFFFFFFu;
     if (status) {
@@ -2222,6 +2340,22 @@ long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_i
   }
   if (status) e->ev->scratch().release(status, s);
   return hr;
+}
+
+long hipbfv_Program_Run(void* h, void* evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t* input_kinds,
+                        const uint64_t* const* input_ptrs, const uint64_t* input_strides, void* relin_keys, void* galois_keys,
+                        uint64_t num_outputs, uint64_t* const* outputs, void* stream) HIPBFV_BEGIN
+  return program_run_impl(h, evaluator, batch, num_inputs, input_kinds, input_ptrs, input_strides, 1, &relin_keys, &galois_keys, nullptr, num_outputs,
+                          outputs, stream);
+HIPBFV_END
+
+long hipbfv_Program_RunKeys(void* h, void* evaluator, uint64_t batch, uint64_t num_inputs, const uint32_t* input_kinds,
+                            const uint64_t* const* input_ptrs, const uint64_t* input_strides, uint64_t num_key_sets, void* const* relin_keys,
+                            void* const* galois_keys, const uint32_t* key_index, uint64_t num_outputs, uint64_t* const* outputs,
+                            void* stream) HIPBFV_BEGIN
+  if (!num_key_sets || !key_index) return HIPBFV_E_POINTER;
+  return program_run_impl(h, evaluator, batch, num_inputs, input_kinds, input_ptrs, input_strides, num_key_sets, relin_keys, galois_keys, key_index,
+                          num_outputs, outputs, stream);
 HIPBFV_END
 
 long hipbfv_batch_status(void* h, uint64_t* first_transparent_item, void* stream) HIPBFV_BEGIN

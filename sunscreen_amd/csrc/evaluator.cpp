@@ -80,6 +80,62 @@ void ScratchPool::release(void* p, hipStream_t s) {
   }
 }
 
+// ------------------------------------------------------------------ PinnedPool
+
+PinnedPool::~PinnedPool() {
+  for (auto& b : blocks_) {
+    if (b.pending) (void)hipEventSynchronize(b.ev);
+    (void)hipEventDestroy(b.ev);
+    (void)hipHostFree(b.ptr);
+  }
+}
+
+void* PinnedPool::acquire(size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  std::unique_lock<std::mutex> g(mu_);
+  Block* best = nullptr;
+  for (auto& b : blocks_)
+    if (!b.busy && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+  if (best) {
+    best->busy = true;
+    const bool wait = best->pending;
+    hipEvent_t ev = best->ev;
+    void* p = best->ptr;
+    best->pending = false;
+    g.unlock();
+    // the previous copy out of the block (usually long finished) must be over before the host writes it again
+    if (wait && hipEventSynchronize(ev) != hipSuccess) return nullptr;
+    return p;
+  }
+  Block nb{};
+  const size_t want = std::max<size_t>(bytes, (size_t)64 << 10);
+  if (hipHostMalloc(&nb.ptr, want, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (hipEventCreateWithFlags(&nb.ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipHostFree(nb.ptr);
+    return nullptr;
+  }
+  nb.bytes = want;
+  nb.busy = true;
+  nb.pending = false;
+  blocks_.push_back(nb);
+  return nb.ptr;
+}
+
+void PinnedPool::release(void* p, hipStream_t s) {
+  std::lock_guard<std::mutex> g(mu_);
+  for (auto& b : blocks_) {
+    if (b.ptr == p) {
+      b.pending = hipEventRecord(b.ev, s) == hipSuccess;
+      if (!b.pending) (void)hipStreamSynchronize(s);  // no event: drain the stream instead (the copy must not outlive the block)
+      b.busy = false;
+      return;
+    }
+  }
+}
+
 namespace {
 NttPlan make_plan(u32 div, const std::vector<u32>& mods) {
   NttPlan pl{};
@@ -310,9 +366,54 @@ size_t Evaluator::ks_scratch_words() const {
   return ((size_t)h.KK * h.K + 2 * (size_t)h.KK) * h.n;
 }
 
+Evaluator::KeyMapLease::~KeyMapLease() {
+  if (!ev) return;
+  if (host) ev->pinned_.release(host, s);
+  if (dev) ev->pool_.release(dev, s);
+}
+
+// Device tables of a per-item key selection (KeySel): the key pointer table and, for every chunk of the call, the chunk's items
+// sorted by key index (stable: items of one key keep their order).  One pinned staging block and one H2D copy per call; both
+// buffers go back to their pools behind the call's last launch.
+int Evaluator::stage_keymap(const KeySel& sel, size_t count, size_t chunk, hipStream_t s, KeyMapLease& lease) {
+  if (!sel.per_item()) return kOk;
+  if (!sel.nkeys || !sel.index || !sel.period || !count || !chunk) return kInvalidArg;
+  for (u32 k = 0; k < sel.nkeys; k++)
+    if (!sel.keys[k]) return kNoKey;
+  for (size_t i = 0; i < sel.period; i++)
+    if (sel.index[i] >= sel.nkeys) return kInvalidArg;
+  const size_t tab_bytes = ((size_t)sel.nkeys * sizeof(u64*) + 15) & ~(size_t)15;
+  const size_t bytes = tab_bytes + count * sizeof(uint2);
+  lease.ev = this;
+  lease.s = s;
+  lease.host = pinned_.acquire(bytes);
+  // (one size class up to 128 K items: the small block is found again by every later call instead of a chunk-sized one)
+  lease.dev = pool_.acquire(std::max<size_t>(bytes, (size_t)1 << 20), s);
+  if (!lease.host || !lease.dev) return kOutOfMemory;
+  const u64** tab = reinterpret_cast<const u64**>(lease.host);
+  for (u32 k = 0; k < sel.nkeys; k++) tab[k] = sel.keys[k];
+  uint2* order = reinterpret_cast<uint2*>(static_cast<unsigned char*>(lease.host) + tab_bytes);
+  std::vector<u32> start(sel.nkeys + 1);
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t c = std::min(chunk, count - off);
+    // counting sort of the chunk's items by key index
+    std::fill(start.begin(), start.end(), 0u);
+    for (size_t i = 0; i < c; i++) start[sel.index[(sel.first + off + i) % sel.period] + 1]++;
+    for (u32 k = 0; k < sel.nkeys; k++) start[k + 1] += start[k];
+    for (size_t i = 0; i < c; i++) {
+      const u32 k = sel.index[(sel.first + off + i) % sel.period];
+      order[off + start[k]++] = make_uint2((u32)i, k);
+    }
+  }
+  HB_CHECK(hipMemcpyAsync(lease.dev, lease.host, bytes, hipMemcpyHostToDevice, s));
+  lease.km.keys = reinterpret_cast<const u64* const*>(lease.dev);
+  lease.km.order = reinterpret_cast<const uint2*>(static_cast<unsigned char*>(lease.dev) + tab_bytes);
+  return kOk;
+}
+
 // out2[op] = base[op] (masked) + modDown( sum_J NTT(target_J) (.) key[J] ); scratch >= count * ks_scratch_words()
 int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, const u64* base, size_t bstride, u32 base_mask,
-                          u64* out2, size_t count, u64* scratch, hipStream_t s, const u64* extra) {
+                          u64* out2, size_t count, u64* scratch, hipStream_t s, const u64* extra, KeyMap km) {
   const DevCtx& h = ctx_->host();
   const u32 n = h.n, K = h.K, KK = h.KK;
   u64* T = scratch;
@@ -325,40 +426,43 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
     // mixed: one middle kernel per policy), no whole-polynomial NTT round trips
     const bool mixed = h.ks_ni != 0;
     HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, mixed, K, target, tstride, T, count, s));
-    HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, key, ACC, count, s));
+    HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, key, ACC, count, s, km));
     HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, h.pack_ks != 0, mixed, ACC, base, bstride, base_mask, extra, out2, count, s));
     return kOk;
   }
   HB_LAUNCH(kKernKsDecompose, count, launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));
   HB_LAUNCH(kKernNttFwd, count * KK * K, launch_ntt(ctx_->dev(), h.tw_fwd, h.logn, T, count * KK * K, make_plan(K, mods), false, 0, s));
-  HB_LAUNCH(kKernKsMac, count, launch_ks_mac(ctx_->dev(), n, KK, T, key, ACC, count, s));
+  HB_LAUNCH(kKernKsMac, count, launch_ks_mac(ctx_->dev(), n, KK, T, key, ACC, count, s, km));
   HB_LAUNCH(kKernNttInv, count * 2 * KK, launch_ntt(ctx_->dev(), h.tw_inv, h.logn, ACC, count * 2 * KK, make_plan(1, mods), true, 0, s));
   HB_LAUNCH(kKernKsModdown, count, launch_ks_moddown(ctx_->dev(), n, ACC, base, bstride, base_mask, extra, out2, count, s));
   return kOk;
 }
 
 // addend (optional): ciphertexts u64[count][2][K][N] added to the results inside the last kernel (a fused Add node)
-int Evaluator::relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend, bool watch) {
+int Evaluator::relinearize(const u64* ct3, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend, bool watch) {
   const DevCtx& h = ctx_->host();
-  if (h.KK < 2 || !rk) return kNoKey;
+  if (h.KK < 2 || !rk.present()) return kNoKey;
   if (h.logn > 15) return kUnsupported;
   const u32 n = h.n, K = h.K;
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / ((size_t)h.KK * K)));
+  KeyMapLease kl;
+  if (int rc = stage_keymap(rk, count, chunk, s, kl)) return rc;
   ScratchGuard sg(pool_, std::min(chunk, count) * ks_scratch_words() * sizeof(u64), s);
   if (!sg.p) return kOutOfMemory;
   const size_t cs = (size_t)3 * K * n;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
     const u64* ct = ct3 + off * cs;
-    int rc = key_switch(ct + (size_t)2 * K * n, cs, rk, ct, cs, 3u, out2 + off * 2 * K * n, c, (u64*)sg.p, s, addend ? addend + off * 2 * K * n : nullptr);
+    int rc = key_switch(ct + (size_t)2 * K * n, cs, rk.key, ct, cs, 3u, out2 + off * 2 * K * n, c, (u64*)sg.p, s, addend ? addend + off * 2 * K * n : nullptr,
+                        kl.at(off));
     if (rc) return rc;
   }
   return watch ? note_result(out2, 2, K, count, s) : (int)kOk;
 }
 
-int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend) {
+int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend) {
   const DevCtx& h = ctx_->host();
-  if (h.KK < 2 || !rk) return kNoKey;
+  if (h.KK < 2 || !rk.present()) return kNoKey;
   const u32 n = h.n, K = h.K, KK = h.KK, S = h.S, R = K + S;
   const size_t cs = (size_t)3 * K * n, c2 = (size_t)2 * K * n;
   const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
@@ -373,6 +477,8 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
     // every kernel of this path puts the ops on grid z and its residue / block count on grid x: no 65535 limit but z's, which
     // the 1024-op cap of chunk_ops_ is far below (the limits of the whole-polynomial launches made N = 16384 run 910 + 114)
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535));
+    KeyMapLease kl;
+    if (int rc = stage_keymap(rk, count, chunk, s, kl)) return rc;
     ScratchGuard sg(pool_, std::min(chunk, count) * per_op * sizeof(u64), s);
     if (!sg.p) return kOutOfMemory;
     const size_t cc = std::min(chunk, count);
@@ -391,7 +497,7 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
         HB_LAUNCH(kKernMulTail, c, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, true, (int)h.pack_mul, h.conv_grid != 0, kneed, D, C2, c, s, 2, 1));
         HB_LAUNCH(kKernKsHead, c, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, false, K, C2, c2_words, T, c, s));
       }
-      HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, rk, ACC, c, s));
+      HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, rk.key, ACC, c, s, kl.at(off)));
       HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail(ctx_->dev(), h.tw_inv, h.logn, (int)h.pack_mul, h.conv_grid != 0, h.pack_ks != 0, kneed, D, ACC,
                                                     addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s));
     }
@@ -404,17 +510,19 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const u64* rk, u64* ou
     const size_t c = std::min(chunk, count - off);
     int rc = multiply(a + off * c2, 2, b + off * c2, 2, (u64*)sg.p, c, s, false);
     if (rc) return rc;
-    rc = relinearize((const u64*)sg.p, rk, out2 + off * c2, c, s, addend ? addend + off * c2 : nullptr, false);
+    KeySel sub = rk;  // the chunk's items are items first + off ... of the selection
+    sub.first = rk.first + off;
+    rc = relinearize((const u64*)sg.p, sub, out2 + off * c2, c, s, addend ? addend + off * c2 : nullptr, false);
     if (rc) return rc;
   }
   return note_result(out2, 2, h.K, count, s);
 }
 
-int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, size_t count, hipStream_t s, const u64* addend) {
+int Evaluator::apply_galois(const u64* ct2, u32 elt, const KeySel& key, u64* out2, size_t count, hipStream_t s, const u64* addend) {
   const DevCtx& h = ctx_->host();
   const u32 n = h.n, K = h.K;
   if (!(elt & 1) || elt >= 2 * n) return kInvalidArg;
-  if (h.KK < 2 || !key) return kNoKey;
+  if (h.KK < 2 || !key.present()) return kNoKey;
   if (h.logn > 15) return kUnsupported;
   // g^{-1} mod 2n (Newton iteration, g odd)
   u64 inv = 1;
@@ -423,6 +531,8 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, 
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / ((size_t)h.KK * K)));
   const size_t rot_words = (size_t)2 * K * n;
   const size_t cc = std::min(chunk, count);
+  KeyMapLease kl;
+  if (int rc = stage_keymap(key, count, chunk, s, kl)) return rc;
   ScratchGuard sg(pool_, cc * (rot_words + ks_scratch_words()) * sizeof(u64), s);
   if (!sg.p) return kOutOfMemory;
   u64* rot = (u64*)sg.p;
@@ -431,7 +541,8 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const u64* key, u64* out2, 
     const size_t c = std::min(chunk, count - off);
     HB_LAUNCH(kKernGalois, c * 2, launch_galois(ctx_->dev(), n, K, ct2 + off * rot_words, rot, c * 2, ginv, s));
     // base = (sigma(c0), 0); target = sigma(c1)
-    int rc = key_switch(rot + (size_t)K * n, rot_words, key, rot, rot_words, 1u, out2 + off * rot_words, c, ks, s, addend ? addend + off * rot_words : nullptr);
+    int rc = key_switch(rot + (size_t)K * n, rot_words, key.key, rot, rot_words, 1u, out2 + off * rot_words, c, ks, s, addend ? addend + off * rot_words : nullptr,
+                        kl.at(off));
     if (rc) return rc;
   }
   return note_result(out2, 2, K, count, s);

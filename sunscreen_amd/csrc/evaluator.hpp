@@ -95,6 +95,43 @@ class Profiler {
   hipEvent_t get_event();
 };
 
+// Pinned host staging blocks for small tables that a launch sequence reads after the call has returned (the per-item key maps).
+// Like ScratchPool, but a block is handed out again only after the copy out of it has finished (the HOST overwrites it).
+class PinnedPool {
+ public:
+  ~PinnedPool();
+  void* acquire(size_t bytes);
+  void release(void* p, hipStream_t s);  // the copies out of the block were enqueued on `s`
+
+ private:
+  struct Block {
+    void* ptr;
+    size_t bytes;
+    hipEvent_t ev;
+    bool busy, pending;
+  };
+  std::mutex mu_;
+  std::vector<Block> blocks_;
+};
+
+// Which key-switching key each item of a batch uses.  The reference hands the keys over with every call
+// (sunscreen_runtime/src/run.rs:100-105: `relin_keys: &Option<&RelinearizationKeys>`, `galois_keys`; runtime.rs:310-327), so a
+// server that batches the calls of many clients holds one key set per client: item i of the batch uses
+// keys[index[(first + i) % period]] (period = the number of input sets: the graph executor's merged launches number their
+// ciphertexts member-major, item = member * period + set).  keys == nullptr: the one key `key` for every item.
+struct KeySel {
+  const u64* key = nullptr;          // device, u64[K][2][K+1][N]
+  const u64* const* keys = nullptr;  // HOST array of nkeys device pointers
+  u32 nkeys = 0;
+  const u32* index = nullptr;        // HOST array of `period` key indices
+  size_t period = 0;
+  size_t first = 0;                  // the batch's item 0 is item `first` of the selection
+  KeySel() = default;
+  KeySel(const u64* one) : key(one) {}  // NOLINT: every single-key call site passes its pointer
+  bool per_item() const { return keys != nullptr; }
+  bool present() const { return per_item() ? nkeys != 0 : key != nullptr; }
+};
+
 // RAII lease of a scratch-pool buffer on a stream
 struct ScratchGuard {
   ScratchPool& pool;
@@ -139,10 +176,11 @@ class Evaluator {
   // ---- SURVEY 8a rows a1-a5, batched ----
   int multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, size_t count, hipStream_t s, bool watch = true);
   // addend (optional, the three key-switching operations): ciphertexts u64[count][2][K][N] added to the results inside the last kernel
-  int relinearize(const u64* ct3, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr, bool watch = true);
-  int multiply_relin(const u64* a, const u64* b, const u64* rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
+  // rk / key: one key for the whole batch (a device pointer converts) or a per-item selection (KeySel above)
+  int relinearize(const u64* ct3, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr, bool watch = true);
+  int multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
   // out2 = (sigma_g(c0), 0) + switch_key(sigma_g(c1), key)
-  int apply_galois(const u64* ct2, u32 galois_elt, const u64* key, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
+  int apply_galois(const u64* ct2, u32 galois_elt, const KeySel& key, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
   int mod_switch_next(const u64* ct, u32 size, u64* out, size_t count, hipStream_t s);  // out has K-1 residues per polynomial
   int add(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s);
   int sub(const u64* a, const u64* b, u64* out, u32 size, size_t count, hipStream_t s);
@@ -195,8 +233,21 @@ class Evaluator {
 
  private:
   int key_switch(const u64* target, size_t tstride, const u64* key, const u64* base, size_t bstride, u32 base_mask, u64* out2,
-                 size_t count, u64* scratch, hipStream_t s, const u64* extra = nullptr);
+                 size_t count, u64* scratch, hipStream_t s, const u64* extra = nullptr, KeyMap km = KeyMap{});
   size_t ks_scratch_words() const;
+  // the device tables of a per-item key selection for one call: `order` holds, for every chunk of `chunk` items, the chunk's items
+  // (numbered from 0 within the chunk) sorted by key -- the launch over chunk c reads order + c * chunk
+  struct KeyMapLease {
+    Evaluator* ev = nullptr;
+    hipStream_t s = nullptr;
+    void* dev = nullptr;
+    void* host = nullptr;
+    KeyMap km;
+    KeyMap at(size_t off) const { return km.keys ? KeyMap{km.keys, km.order + off} : KeyMap{}; }
+    ~KeyMapLease();
+  };
+  int stage_keymap(const KeySel& sel, size_t count, size_t chunk, hipStream_t s, KeyMapLease& lease);
+  PinnedPool pinned_;
   Context* ctx_;
   u32* status_dev_ = nullptr;
   ScratchPool pool_;

@@ -898,10 +898,15 @@ __global__ __launch_bounds__(kCoefThreads) void ks_decompose_kernel(const DevCtx
 
 // ACC[op][c][I][k] = sum_J T[op][I][J][k] * key[J][c][I][k]   (128-bit lazy sum, one reduction)
 __global__ __launch_bounds__(kCoefThreads) void ks_mac_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ T,
-                                                              const u64* __restrict__ key, u64* __restrict__ ACC) {
+                                                              const u64* __restrict__ key, u64* __restrict__ ACC, KeyMap km) {
   const u32 n = ctx->n, K = ctx->K, KK = ctx->KK;
   const u32 k = blockIdx.x * kCoefThreads + threadIdx.x;
-  const u32 I = blockIdx.y, op = blockIdx.z;
+  u32 I = blockIdx.y, op = blockIdx.z;
+  if (km.keys) {  // per-item keys: walk position -> {item, key index} (kernels.hpp KeyMap)
+    const uint2 m = km.order[op];
+    op = m.x;
+    key = km.keys[m.y];
+  }
   if (k >= n) return;
   const DevMod& mI = ctx->mod[I];
   u128 a0 = 0, a1 = 0;
@@ -914,8 +919,8 @@ __global__ __launch_bounds__(kCoefThreads) void ks_mac_kernel(const DevCtx* __re
     for (int u = 0; u < 4; u++) {
       const u32 J = J0 + (u32)u < K ? J0 + (u32)u : K - 1;
       tv[u] = T[(((size_t)op * KK + I) * K + J) * n + k];
-      ka[u] = key[(((size_t)J * 2 + 0) * KK + I) * n + k];
-      kb[u] = key[(((size_t)J * 2 + 1) * KK + I) * n + k];
+      ka[u] = as_global(key)[(((size_t)J * 2 + 0) * KK + I) * n + k];  // (key may be a loaded pointer: name the address space)
+      kb[u] = as_global(key)[(((size_t)J * 2 + 1) * KK + I) * n + k];
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -1354,8 +1359,8 @@ hipError_t launch_ks_decompose(const DevCtx* ctx, u32 n, u32 K, const u64* targe
   return hipGetLastError();
 }
 
-hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s) {
-  ks_mac_kernel<<<coef_grid(n, KK, (u32)ops), kCoefThreads, 0, s>>>(ctx, T, key, ACC);
+hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km) {
+  ks_mac_kernel<<<coef_grid(n, KK, (u32)ops), kCoefThreads, 0, s>>>(ctx, T, key, ACC, km);
   return hipGetLastError();
 }
 

@@ -25,6 +25,15 @@ struct PlainNttRef {
   u64 stride;
 };
 
+// Per-item key selection of one key-switch launch.  The reference passes the keys with every call (sunscreen_runtime/src/run.rs:100-105,
+// runtime.rs:310-327), so a server that batches the calls of many clients holds one key set per client.  keys == nullptr: every item
+// of the launch uses the launch's one key.  Otherwise position w of the launch's walk handles item order[w].x with the key
+// keys[order[w].y]; `order` lists the items of the launch sorted by key, so that neighbours in the walk share key rows in L2.
+struct KeyMap {
+  const u64* const* keys = nullptr;  // device table of key base pointers (u64[K][2][K+1][N] each)
+  const uint2* order = nullptr;      // device, one {item, key index} entry per item of the launch
+};
+
 // Which modulus a residue polynomial of a batched buffer belongs to:
 // modulus id of polynomial p = mod[(p / div) % period].
 struct NttPlan {
@@ -38,7 +47,7 @@ hipError_t launch_behz_extend(const DevCtx* ctx, u32 n, u32 K, const u64* in0, u
 hipError_t launch_tensor(const DevCtx* ctx, u32 n, u32 R, const u64* ext, u32 sa, u32 sb, u64* D, size_t ops, hipStream_t s);
 hipError_t launch_behz_floor_sk(const DevCtx* ctx, u32 n, u32 K, const u64* D, u64* out, size_t polys, hipStream_t s);
 hipError_t launch_ks_decompose(const DevCtx* ctx, u32 n, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
-hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s);
+hipError_t launch_ks_mac(const DevCtx* ctx, u32 n, u32 KK, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km = KeyMap{});
 // two-kernel stand-alone transforms for N = 32768 (kernels_split.hip)
 hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* data, size_t polys, const NttPlan& plan, bool inverse,
                             int scale_mode, hipStream_t s);
@@ -47,7 +56,7 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
 // 4-byte aligned and readable up to the next word boundary (the DevCtx members are; the launchers refuse anything else)
 hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
 hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd, const unsigned char* res_i, u32 ni,
-                         const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s);
+                         const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km = KeyMap{});
 hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
                           size_t ops, hipStream_t s);
 // split BEHZ multiply (2 x 2 -> 3), K <= 4

@@ -905,6 +905,19 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
   }
 }
 
+// Per-item keys (kernels.hpp KeyMap; multi-tenant batches).  The launch's items arrive sorted by key in km.order; each XCD takes a
+// CONTIGUOUS run of that order (position w = xcd * per + slot % per) instead of every eighth item, so the key rows of one client
+// are fetched into one XCD's L2 (two at a run boundary) and not into all eight.  Wave-uniform: two scalar loads per workgroup.
+typedef unsigned long long key2_t __attribute__((ext_vector_type(2)));  // two key words per load (members .x, .y)
+#define KS_KEYMAP_WALK(km, op, key, xcd, slot, per, ops) \
+  if ((km).keys) {                                        \
+    const u32 w__ = (xcd) * (per) + (slot) % (per);       \
+    if (w__ >= (ops)) return;                             \
+    const uint2 m__ = (km).order[w__];                    \
+    op = m__.x;                                           \
+    key = (km).keys[m__.y];                              \
+  }
+
 // -------------------------------------------------------------------------------------------------
 // key switch, middle: per (op, I, block): finish the K forward transforms, multiply-accumulate with the
 // key rows, run the block-local inverse stages of both accumulators.
@@ -918,7 +931,7 @@ template <int L, bool PACK, int EPT = KS_EPT(L)>
 __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                        const MulOp* __restrict__ twi_base, const double* __restrict__ T,
                                                                        const u64* __restrict__ key, double* __restrict__ ACC, u32 ops,
-                                                                       const unsigned char* __restrict__ residues, u32 nres) {
+                                                                       const unsigned char* __restrict__ residues, u32 nres, KeyMap km) {
   using Sh = SplitShape<L, EPT>;
   using A = ArithD;
   __shared__ double smem[KS_GROUP_MAX(L) * Sh::BLOCK];
@@ -929,11 +942,12 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
   // (I, blk) slice, so the K * 2 key rows of that slice (the only re-used global data) stay in that XCD's L2.
   const u32 xcd = b & 7u, slot = b >> 3;
   const u32 per = (ops + 7u) >> 3;
-  const u32 op = (slot % per) * 8u + xcd;
+  u32 op = (slot % per) * 8u + xcd;
   const u32 ib = slot / per;
   const u32 blk = ib % Sh::NBLK;
   const u32 I = residue_of(residues, ib / Sh::NBLK);
   (void)nres;
+  KS_KEYMAP_WALK(km, op, key, xcd, slot, per, ops)
   if (op >= ops) return;
   const DevMod& dm = ctx->mod[I];
   const A ar(dm);
@@ -955,8 +969,10 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
   };
   // key rows of digit J for the group g of the last forward window (the elements this thread holds): 16-byte loads
   auto mac = [&](u32 J, const double(&v)[EPT]) {
-    const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
-    const u64* k1 = key + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
+    // (the key pointer may come out of the per-item key table: a loaded pointer is generic to the compiler -- name the address space,
+    // or every key load is a flat_load; tests/test_isa_guards_cpu.py)
+    const global_ptr<const u64> k0 = as_global(key) + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
+    const global_ptr<const u64> k1 = as_global(key) + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
 #pragma unroll
     for (int g = 0; g < Last::G; g++) {
       const u32 base = Last::elem(tid, blk, g, 0);
@@ -964,11 +980,11 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
       constexpr int CH = KS_MAC_CHUNK(L) < W ? KS_MAC_CHUNK(L) : W;  // key words in flight per step (register diet at N = 16384)
 #pragma unroll
       for (int c0 = 0; c0 < W; c0 += CH) {
-        ulonglong2 ka[CH / 2], kc[CH / 2];
+        key2_t ka[CH / 2], kc[CH / 2];
 #pragma unroll
         for (int k = 0; k < CH; k += 2) {
-          ka[k / 2] = *reinterpret_cast<const ulonglong2*>(k0 + base + c0 + k);
-          kc[k / 2] = *reinterpret_cast<const ulonglong2*>(k1 + base + c0 + k);
+          ka[k / 2] = *reinterpret_cast<global_ptr<const key2_t>>(k0 + base + c0 + k);
+          kc[k / 2] = *reinterpret_cast<global_ptr<const key2_t>>(k1 + base + c0 + k);
         }
 #pragma unroll
         for (int h = 0; h < CH / 2; h++) {
@@ -1045,7 +1061,7 @@ template <int L>
 __global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                              const MulOp* __restrict__ twi_base, const u64* __restrict__ T,
                                                                              const u64* __restrict__ key, u64* __restrict__ ACC, u32 ops,
-                                                                             const unsigned char* __restrict__ residues, u32 nres) {
+                                                                             const unsigned char* __restrict__ residues, u32 nres, KeyMap km) {
   using Sh = SplitShape<L>;
   using A = ArithI;
   __shared__ u64 smem[KS_MID_INT_GROUP * Sh::BLOCK];
@@ -1054,11 +1070,12 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(con
   const u32 b = blockIdx.x;
   const u32 xcd = b & 7u, slot = b >> 3;
   const u32 per = (ops + 7u) >> 3;
-  const u32 op = (slot % per) * 8u + xcd;
+  u32 op = (slot % per) * 8u + xcd;
   const u32 ib = slot / per;
   const u32 blk = ib % Sh::NBLK;
   const u32 I = residue_of(residues, ib / Sh::NBLK);
   (void)nres;
+  KS_KEYMAP_WALK(km, op, key, xcd, slot, per, ops)
   if (op >= ops) return;
   const DevMod& dm = ctx->mod[I];
   const A ar(dm);
@@ -1079,16 +1096,16 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(con
       for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = nt_ld<NtSites<L>::ks_mid_ld>(src + First::elem(tid, blk, g, k));
   };
   auto mac = [&](u32 J, const u64(&v)[kBlkEPT]) {
-    const u64* k0 = key + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
-    const u64* k1 = key + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
+    const global_ptr<const u64> k0 = as_global(key) + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
+    const global_ptr<const u64> k1 = as_global(key) + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
 #pragma unroll
     for (int g = 0; g < Last::G; g++) {
       const u32 base = Last::elem(tid, blk, g, 0);
       constexpr int W = 1 << RL;
 #pragma unroll
       for (int k = 0; k < W; k += 2) {
-        const ulonglong2 ka = *reinterpret_cast<const ulonglong2*>(k0 + base + k);
-        const ulonglong2 kc = *reinterpret_cast<const ulonglong2*>(k1 + base + k);
+        const key2_t ka = *reinterpret_cast<global_ptr<const key2_t>>(k0 + base + k);
+        const key2_t kc = *reinterpret_cast<global_ptr<const key2_t>>(k1 + base + k);
         const int e = g * W + k;
         wide[0][e] += (u128)v[e] * ka.x;
         wide[0][e + 1] += (u128)v[e + 1] * ka.y;
@@ -2378,26 +2395,26 @@ hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pa
 // res_d / nd, res_i / ni: device lists (inside the DevCtx) of the key primes that take the FP64 / the integer policy
 template <int L>
 static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
-                           const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s) {
+                           const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km) {
   using Sh = SplitShape<L>;
   if (((reinterpret_cast<uintptr_t>(res_d) | reinterpret_cast<uintptr_t>(res_i)) & 3u) != 0) return hipErrorInvalidValue;  // residue_of reads words
   const size_t ops8 = (ops + 7) / 8 * 8;
   if (nd) {
     const dim3 grid((unsigned)(ops8 * nd * Sh::NBLK));
     if (pack)
-      ks_mid_kernel<L, true><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd);
+      ks_mid_kernel<L, true><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd, km);
     else
-      ks_mid_kernel<L, false><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd);
+      ks_mid_kernel<L, false><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd, km);
   }
   if (ni) {
     const dim3 grid((unsigned)(ops8 * ni * Sh::NBLK));
-    ks_mid_int_kernel<L><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, T, key, ACC, (u32)ops, res_i, ni);
+    ks_mid_int_kernel<L><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, T, key, ACC, (u32)ops, res_i, ni, km);
   }
   return hipGetLastError();
 }
 hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd,
-                         const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(ks_mid_t, ctx, twf, twi, pack, res_d, nd, res_i, ni, T, key, ACC, ops, s)
+                         const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km) {
+  SPLIT_DISPATCH(ks_mid_t, ctx, twf, twi, pack, res_d, nd, res_i, ni, T, key, ACC, ops, s, km)
 }
 
 template <int L>

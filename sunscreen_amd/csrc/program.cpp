@@ -382,19 +382,62 @@ bool Program::topo_order(std::vector<int>* order) const {
   return (int)order->size() == n;
 }
 
-int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
-                 const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs_given, hipStream_t s,
+KeySel ProgramKeys::relin_sel() const {
+  if (!index) return KeySel(relin.empty() ? nullptr : relin[0]);
+  for (const u64* k : relin)
+    if (!k) return KeySel();
+  KeySel sel;
+  sel.keys = relin.data();
+  sel.nkeys = (u32)relin.size();
+  sel.index = index;
+  sel.period = period;
+  return sel;
+}
+
+KeySel ProgramKeys::galois_sel(u32 elt) const {
+  const u32 id = (elt - 1) >> 1;
+  if (!index) {
+    if (galois.empty()) return KeySel();
+    auto it = galois[0].find(id);
+    return KeySel(it == galois[0].end() ? nullptr : it->second);
+  }
+  auto cached = tables_.find(id);
+  if (cached == tables_.end()) {
+    std::vector<const u64*> tab;
+    for (auto& g : galois) {
+      auto it = g.find(id);
+      if (it == g.end() || !it->second) {
+        tab.clear();
+        break;
+      }
+      tab.push_back(it->second);
+    }
+    if (tab.size() != galois.size()) tab.clear();
+    cached = tables_.emplace(id, std::move(tab)).first;
+  }
+  if (cached->second.empty()) return KeySel();
+  KeySel sel;
+  sel.keys = cached->second.data();
+  sel.nkeys = (u32)cached->second.size();
+  sel.index = index;
+  sel.period = period;
+  return sel;
+}
+
+int Program::run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const ProgramKeys& keys,
+                 u64* const* outputs, size_t num_outputs_given, hipStream_t s,
                  std::string* err) const {
   // read per run (not cached): the tests switch executors inside one process to compare their outputs word for word
   const char* env = std::getenv("HIPBFV_PROGRAM_SERIAL");
   const bool serial = env && env[0] == '1';
-  return serial ? run_serial(ev, batch, inputs, num_inputs, relin_key, galois_keys, outputs, num_outputs_given, s, err)
-                : run_plan(ev, batch, inputs, num_inputs, relin_key, galois_keys, outputs, num_outputs_given, s, err);
+  return serial ? run_serial(ev, batch, inputs, num_inputs, keys, outputs, num_outputs_given, s, err)
+                : run_plan(ev, batch, inputs, num_inputs, keys, outputs, num_outputs_given, s, err);
 }
 
-int Program::run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
-                        const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs_given, hipStream_t s,
+int Program::run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const ProgramKeys& keys,
+                        u64* const* outputs, size_t num_outputs_given, hipStream_t s,
                         std::string* err) const {
+  const KeySel relin_key = keys.relin_sel();
   auto fail = [&](int code, const char* m) {
     if (err) *err = m;
     return code;
@@ -439,10 +482,7 @@ int Program::run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs,
     for (void* p : live) pool.release(p, s);
     return fail(code, m);
   };
-  auto galois_key = [&](u32 elt) -> const u64* {
-    auto it = galois_keys.find((elt - 1) >> 1);
-    return it == galois_keys.end() ? nullptr : it->second;
-  };
+  auto galois_key = [&](u32 elt) -> KeySel { return keys.galois_sel(elt); };
   // rotate `in` by `steps` into `out` following SEAL's rotate_internal (direct key or NAF chain)
   std::function<int(const u64*, int, u64*)> rotate = [&](const u64* in, int steps, u64* out) -> int {
     if (steps == 0) {
@@ -452,7 +492,7 @@ int Program::run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs,
     }
     const u32 elt = ev.galois_elt_from_step(steps);
     if (!elt) return kInvalidArg;
-    if (const u64* key = galois_key(elt)) return ev.apply_galois(in, elt, key, out, batch, s);
+    if (const KeySel key = galois_key(elt); key.present()) return ev.apply_galois(in, elt, key, out, batch, s);
     std::vector<int> naf;
     const bool neg = steps < 0;
     int v = neg ? -steps : steps;
@@ -591,7 +631,7 @@ int Program::run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs,
             live.erase(std::remove(live.begin(), live.end(), (void*)tmp), live.end());
           } else {
             const u64* addend = addend_for(id);
-            rc = relin_key ? ev.multiply_relin(A.ct, B.ct, relin_key, out, batch, s, addend) : (int)kNoKey;
+            rc = relin_key.present() ? ev.multiply_relin(A.ct, B.ct, relin_key, out, batch, s, addend) : (int)kNoKey;
             if (addend && !rc) folded[add_user[id]] = id;
           }
           v.ct = out;
@@ -606,7 +646,7 @@ int Program::run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs,
           if (hipMemcpyAsync(out, L->ct, batch * ctx->ct_words(2) * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = kHipError;
         } else if (L->size == 3) {
           const u64* addend = addend_for(id);
-          rc = relin_key ? ev.relinearize(L->ct, relin_key, out, batch, s, addend) : (int)kNoKey;
+          rc = relin_key.present() ? ev.relinearize(L->ct, relin_key, out, batch, s, addend) : (int)kNoKey;
           if (addend && !rc) folded[add_user[id]] = id;
         } else {
           rc = kInvalidArg;
@@ -673,8 +713,8 @@ int Program::run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs,
         {
           const int steps = nd.op == kOpShiftLeft ? k : -k;
           const u32 elt = steps ? ev.galois_elt_from_step(steps) : 0;
-          const u64* key = elt ? galois_key(elt) : nullptr;
-          const u64* addend = key ? addend_for(id) : nullptr;  // single key switch: the Add can ride along
+          const KeySel key = elt ? galois_key(elt) : KeySel();
+          const u64* addend = key.present() ? addend_for(id) : nullptr;  // single key switch: the Add can ride along
           if (addend) {
             rc = ev.apply_galois(L->ct, elt, key, out, batch, s, addend);
             if (!rc) folded[add_user[id]] = id;
@@ -690,8 +730,8 @@ int Program::run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs,
         if (L->size != 2) return cleanup(kInvalidArg, "rotation needs a size-2 ciphertext");
         if (!ctx->batching()) return cleanup(kUnsupported, "encryption parameters do not support batching");
         const u32 elt = 2 * (u32)n - 1;
-        const u64* key = galois_key(elt);
-        if (!key) return cleanup(kNoKey, "Galois key for the column rotation is missing");
+        const KeySel key = galois_key(elt);
+        if (!key.present()) return cleanup(kNoKey, "Galois key for the column rotation is missing");
         v.size = 2;
         u64* out = alloc_ct(2);
         if (!out) return cleanup(kOutOfMemory, "out of device memory");

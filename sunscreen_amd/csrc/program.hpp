@@ -46,6 +46,21 @@ struct ProgramInput {
   size_t stride;
 };
 
+// The keys of one run.  The reference's call takes ONE set (run.rs:100-105: `relin_keys`, `galois_keys`); a server that batches the
+// runs of many clients holds one set per client, and input set i of the batch uses set index[i].  index == nullptr: set 0.
+struct ProgramKeys {
+  std::vector<const u64*> relin;                   // per key set: the relinearisation key, nullptr if the set has none
+  std::vector<std::map<u32, const u64*>> galois;   // per key set: (galois_elt - 1) / 2 -> key
+  const u32* index = nullptr;                      // HOST, `period` entries
+  size_t period = 0;  // = the run's batch (merged launches number their items member * batch + set)
+  KeySel relin_sel() const;
+  // the key of `elt` in every set; !present() when any set lacks it (the rotation then takes SEAL's NAF chain, as with one set)
+  KeySel galois_sel(u32 elt) const;
+
+ private:
+  mutable std::map<u32, std::vector<const u64*>> tables_;  // host pointer tables handed out by galois_sel (alive for the run)
+};
+
 class Program {
  public:
   int add_node(OpKind op, u64 arg);
@@ -59,18 +74,18 @@ class Program {
   size_t num_outputs() const;
   // outputs: one device buffer u64[batch][2][K][N] per OutputCiphertext node, in node-index order (run.rs:343-356)
   // The scheduled executor (program_plan.cpp) unless HIPBFV_PROGRAM_SERIAL=1 selects the node-by-node one (program.cpp).
-  int run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
-          const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs, hipStream_t s,
+  int run(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const ProgramKeys& keys,
+          u64* const* outputs, size_t num_outputs, hipStream_t s,
           std::string* err) const;
   // one node at a time in topological order on one stream (round 1 / 2's executor; kept as the A/B and cross-check arm)
-  int run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
-                 const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs, hipStream_t s,
+  int run_serial(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const ProgramKeys& keys,
+                 u64* const* outputs, size_t num_outputs, hipStream_t s,
                  std::string* err) const;
   // Level-scheduled execution: every node that is ready runs in the same round (run.rs:372-472 runs them concurrently on
   // rayon); ready nodes of one kind become ONE batched launch, Add / Sub / Negate trees become n-ary sums, sums of
   // ciphertext-plaintext products stay in the transform domain.
-  int run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
-               const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs, hipStream_t s,
+  int run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const ProgramKeys& keys,
+               u64* const* outputs, size_t num_outputs, hipStream_t s,
                std::string* err) const;
   struct Plan;
   // one line per step of the schedule: "<kind> members=<m> ..." (diagnostics; tests/test_program_plan_cpu.py reads it)

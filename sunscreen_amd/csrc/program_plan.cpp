@@ -674,9 +674,10 @@ constexpr size_t merge_max_batch() { return 32; }  // (measured in r03: DESIGN.m
 
 }  // namespace
 
-int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const u64* relin_key,
-                      const std::map<u32, const u64*>& galois_keys, u64* const* outputs, size_t num_outputs_given, hipStream_t s,
+int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, size_t num_inputs, const ProgramKeys& keys,
+                      u64* const* outputs, size_t num_outputs_given, hipStream_t s,
                       std::string* err) const {
+  const KeySel relin_key = keys.relin_sel();
   auto fail = [&](int code, const char* m) {
     if (err) *err = m;
     return code;
@@ -830,10 +831,7 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
     return stage_commit(hp, bytes);
   };
 
-  auto galois_key = [&](u32 elt) -> const u64* {
-    auto it = galois_keys.find((elt - 1) >> 1);
-    return it == galois_keys.end() ? nullptr : it->second;
-  };
+  auto galois_key = [&](u32 elt) -> KeySel { return keys.galois_sel(elt); };
   // rotate `in` by `steps` into `out` following SEAL's rotate_internal (direct key or NAF chain)
   std::function<int(const u64*, int, u64*)> rotate = [&](const u64* in, int steps, u64* out) -> int {
     if (steps == 0) {
@@ -842,7 +840,7 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
     }
     const u32 elt = ev.galois_elt_from_step(steps);
     if (!elt) return kInvalidArg;
-    if (const u64* key = galois_key(elt)) return ev.apply_galois(in, elt, key, out, batch, s);
+    if (const KeySel key = galois_key(elt); key.present()) return ev.apply_galois(in, elt, key, out, batch, s);
     std::vector<int> naf;
     const bool neg = steps < 0;
     int v = neg ? -steps : steps;
@@ -1009,21 +1007,21 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
       case kStepRelin:
       case kStepGalois: {
         const bool is_mul = st.kind == kStepMulRelin, is_rot = st.kind == kStepGalois;
-        if (!is_rot && !relin_key && !(st.kind == kStepRelin && st.out_size == 2)) return cleanup(kNoKey, "operation failed");
+        if (!is_rot && !relin_key.present() && !(st.kind == kStepRelin && st.out_size == 2)) return cleanup(kNoKey, "operation failed");
         u32 elt = 0;
-        const u64* gkey = nullptr;
+        KeySel gkey;
         if (is_rot) {
           if (!ctx->batching()) return cleanup(kUnsupported, "encryption parameters do not support batching");
           elt = st.swap ? 2 * (u32)n - 1 : (st.rot_steps ? ev.galois_elt_from_step(st.rot_steps) : 0);
           if (st.swap || st.rot_steps) {
             if (!elt) return cleanup(kInvalidArg, "operation failed");
             gkey = galois_key(elt);
-            if (st.swap && !gkey) return cleanup(kNoKey, "Galois key for the column rotation is missing");
+            if (st.swap && !gkey.present()) return cleanup(kNoKey, "Galois key for the column rotation is missing");
           }
         }
         const u32 in_size = st.kind == kStepRelin ? st.out_size : 2;
         const size_t in_words = batch * in_size * poly, out_words = batch * 2 * poly;
-        const bool direct_ks = is_mul || (st.kind == kStepRelin && in_size == 3) || (is_rot && gkey);
+        const bool direct_ks = is_mul || (st.kind == kStepRelin && in_size == 3) || (is_rot && gkey.present());
         if (small && members > 1 && direct_ks) {
           // ONE launch sequence over members x batch ciphertexts
           const u64 *A = nullptr, *B2 = nullptr;
@@ -1050,7 +1048,7 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
             rc = hipMemcpyAsync(out, a, out_words * sizeof(u64), hipMemcpyDeviceToDevice, s) == hipSuccess ? (int)kOk : (int)kHipError;
           else if (st.kind == kStepRelin)
             rc = ev.relinearize(a, relin_key, out, batch, s, addend);
-          else if (gkey)
+          else if (gkey.present())
             rc = ev.apply_galois(a, elt, gkey, out, batch, s, addend);
           else
             rc = rotate(a, st.rot_steps, out);

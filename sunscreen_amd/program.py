@@ -190,8 +190,8 @@ class FheProgram:
         _check(_lib.load().hipbfv_Program_NumOutputs(self._h, C.byref(n)))
         return n.value
 
-    def run(self, ev, inputs, relin_keys=None, galois_keys=None) -> list[torch.Tensor]:
-        return self.prepare(ev, inputs, relin_keys, galois_keys)()
+    def run(self, ev, inputs, relin_keys=None, galois_keys=None, key_index=None) -> list[torch.Tensor]:
+        return self.prepare(ev, inputs, relin_keys, galois_keys, key_index)()
 
     def prepare(
         self,
@@ -199,9 +199,13 @@ class FheProgram:
         inputs: Sequence[torch.Tensor],
         relin_keys: RelinearizationKeys | None = None,
         galois_keys: GaloisKeys | None = None,
+        key_index=None,
     ):
         """Bind the arguments once and return a callable that runs the program on them (the argument tables are built here:
         a graph with tens of thousands of arguments -- examples/pir's database -- is run many times on the same buffers)."""
+        """key_index (optional, `batch` host integers): one key set per client -- relin_keys / galois_keys are then SEQUENCES of key
+        objects (an entry may be None) and input set i runs with relin_keys[key_index[i]], galois_keys[key_index[i]]
+        (hipbfv_Program_RunKeys; the reference passes the keys per call, sunscreen_runtime/src/run.rs:100-105)."""
         """inputs[i]: int64[batch,2,K,N] ciphertext batch, int64[batch,N] / int64[N] plaintext(s) in coefficient form, or a
         `TransformedPlaintext` (int64[batch,K,N] / int64[K,N] from BatchEvaluator.plain_to_ntt: static data transformed once)."""
         batch = None
@@ -229,6 +233,31 @@ class FheProgram:
         n_out = self.num_outputs()
         dev = next(t for t in inputs if not isinstance(t, TransformedPlaintext)).device
         keep = list(inputs)  # the tables hold raw addresses: the tensors must outlive the callable
+        if key_index is not None:
+            import numpy as np
+
+            idx = np.ascontiguousarray(np.asarray(key_index, dtype=np.uint32))
+            assert idx.shape == (batch,), (idx.shape, batch)
+            nsets = max(len(relin_keys) if relin_keys is not None else 0, len(galois_keys) if galois_keys is not None else 0)
+            assert nsets > 0, "key_index needs sequences of key sets"
+
+            def handles(seq):
+                seq = list(seq) if seq is not None else []
+                seq += [None] * (nsets - len(seq))
+                return (C.c_void_p * nsets)(*[k.get_handle() if k is not None else None for k in seq])
+
+            rks, gks = handles(relin_keys), handles(galois_keys)
+            fnk = _lib.load().hipbfv_Program_RunKeys
+            keep.append((idx, relin_keys, galois_keys))
+
+            def call_keys() -> list[torch.Tensor]:
+                outs = [torch.empty((batch, 2, ev.K, ev.n), dtype=torch.int64, device=dev) for _ in range(n_out)]
+                optrs = (C.c_void_p * n_out)(*[_ptr(o) for o in outs])
+                _check(fnk(self._h, ev._h, batch, n_in, kinds, ptrs, strides, nsets, rks, gks, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                           n_out, optrs, _stream()))
+                return outs
+
+            return call_keys
         fn = _lib.load().hipbfv_Program_Run
         rk = relin_keys.get_handle() if relin_keys is not None else None
         gk = galois_keys.get_handle() if galois_keys is not None else None

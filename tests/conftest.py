@@ -15,7 +15,7 @@ if ROOT not in sys.path:
 # (`pipeline_selection` = "split": HIPBFV_NO_SMALL_BATCH=1, read by the library when an evaluator is created), and the
 # representative modules below run a SECOND time under the product default ("product_default": the variable unset), inside
 # the same `pytest -m gpu` run.
-BOTH_SELECTIONS = ("test_gpu_parity.py", "test_gpu_baseline_configs.py", "test_gpu_program.py")
+BOTH_SELECTIONS = ("test_gpu_parity.py", "test_gpu_baseline_configs.py", "test_gpu_program.py", "test_gpu_per_key.py")
 
 
 def _is_gpu_test(definition) -> bool:
