@@ -76,6 +76,10 @@ def parse(argv=None):
                     "compiled `lookup` graph through hipbfv_Program_Run (the A/B arm; same bits)")
     ap.add_argument("--coeff-bits", default="", help="comma-separated prime sizes (CoeffModulus::create, last = special prime) instead of the "
                     "SEAL default set for --n, e.g. 54,54,54,56 for the 3 x 54-bit n=8192 variant BASELINE.json mentions")
+    ap.add_argument("--keys", type=int, default=1, help="mulrelin: this many CLIENTS in the batch, each with its own secret, public and relinearisation "
+                    "key (item i belongs to client i %% keys -- interleaved, the order a batching server sees): the per-key entry point "
+                    "hipbfv_batch_multiply_relin_keys; --keys = --batch is SURVEY 8d config 3's per-ciphertext-key worst case, where the key "
+                    "(16 K (K+1) N bytes) is part of every item's compulsory traffic")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each (every one between two barriers); value = the "
                     "MEDIAN region, all of them are printed (`values`, `spread`): one box differs from the next by 2-3 %, a claim smaller than "
                     "the spread of its own repeats is noise")
@@ -403,7 +407,45 @@ def measure(args, env: Env, secondary: bool = False):
         return sk, pk, rk, gk, rkd, skd, pkd, gkd
 
     exchange = None
-    if args.workload == "mulrelin":
+    nkeys = 1
+    if args.workload == "mulrelin" and args.keys > 1:
+        # ---- per-key batch: `keys` clients, item i belongs to client i % keys (hipbfv_batch_multiply_relin_keys) ----
+        from sunscreen_amd import KeyGenerator
+
+        o = O.Oracle(n, primes, t)
+        nkeys = min(args.keys, B)
+        key_index = (np.arange(B) % nkeys).astype(np.uint32)
+        # every client generates its own secret, public and relinearisation key (the library's device key generator: one SEAL
+        # KeyGenerator per client) and encrypts its own items; a rank's clients are its own (no key crosses ranks)
+        clients = []
+        va = torch.randint(-128, 129, (B, n), generator=gen, device=dev, dtype=torch.int64)
+        vb = torch.randint(-128, 129, (B, n), generator=gen, device=dev, dtype=torch.int64)
+        a = torch.empty((B, 2, K, n), dtype=torch.int64, device=dev)
+        b = torch.empty((B, 2, K, n), dtype=torch.int64, device=dev)
+        pa, pb = ev.encode(va, signed=True), ev.encode(vb, signed=True)
+        for c in range(nkeys):
+            kg = KeyGenerator(ctx, seed=0x6E75 + 7919 * rank + c)
+            cl = {"sk": kg.secret_key(), "pk": kg.create_public_key(), "rk": kg.create_relinearization_keys()}
+            clients.append(cl)
+            mine = torch.arange(c, B, nkeys, device=dev)
+            a[mine] = ev.encrypt(pa[mine], cl["pk"], seed=0xA000 + c)
+            b[mine] = ev.encrypt(pb[mine], cl["pk"], seed=0xB000 + c)
+        del pa, pb
+        rk_sets = [cl["rk"] for cl in clients]
+        ncheck = 0 if args.no_check else min(args.check_items, B)
+        out = torch.empty((B, 2, K, n), dtype=torch.int64, device=dev)
+
+        def step():
+            ev.multiply_relin_keys(a, b, rk_sets, key_index, out=out)
+
+        key_bytes = 16 * K * KK * n
+        # SURVEY 8(d) + the keys that are now compulsory: read 2 ciphertexts, write 1, and every DISTINCT key of the step once
+        unit_bytes = 48 * K * n + key_bytes * nkeys // B
+        units_per_step = B
+        metric, unit = "bfv_mul_relin_ops_per_sec", "ops/s"
+        workload = (f"BFV ct*ct multiply+relinearize, n={n}, K={K}+1 {pset} primes, t={t}, batch={share} pairs of {nkeys} clients "
+                    f"(item i -> client i mod {nkeys}; {nkeys * key_bytes / 2**30:.2f} GiB of relinearisation keys resident)")
+    elif args.workload == "mulrelin":
         o = O.Oracle(n, primes, t)
         sk, pk, rk, _, rkd, skd, pkd, _ = owner_keys(0xBF5 + 17)
         # the whole batch is genuine: slot vectors in [-128, 128] (products stay below t/2),
@@ -619,7 +661,33 @@ def measure(args, env: Env, secondary: bool = False):
 
     # ---- parity gate (after timing so that the timed region is exactly K steps) ----
     parity = "skipped"
-    if args.workload == "mulrelin" and not args.no_check:
+    if args.workload == "mulrelin" and nkeys > 1 and not args.no_check:
+        # (1) every client's items decrypt under THAT client's secret key to the slot-wise products
+        ok = True
+        for c, cl in enumerate(clients):
+            mine = torch.arange(c, B, nkeys, device=dev)
+            dec = ev.decode(ev.decrypt(out[mine].contiguous(), cl["sk"]), signed=True)
+            ok = ok and bool(torch.equal(dec, va[mine] * vb[mine]))
+        for i in range(K):
+            ok = ok and int(out[:, :, i, :].max()) < primes[i] and int(out[:, :, i, :].min()) >= 0
+        if collective:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+        assert ok, "a per-key multiply+relinearize result does not decrypt to the slot-wise product under its client's key (or is not canonical)"
+        # (2) bit-exact vs the oracle on the first `ncheck` items, each relinearised by the oracle with its own client's key
+        if rank == 0:
+            from concurrent.futures import ThreadPoolExecutor
+
+            ha, hb, got = to_host(a[:ncheck]), to_host(b[:ncheck]), to_host(out[:ncheck])
+            hk = {c: clients[c]["rk"].to_array(ctx) for c in sorted({int(key_index[i]) for i in range(ncheck)})}
+            with ThreadPoolExecutor(min(ncheck, os.cpu_count() or 1)) as ex:  # the oracle's C calls release the GIL
+                refs = list(ex.map(lambda i: o.relinearize(o.multiply(ha[i], hb[i]), hk[int(key_index[i])]), range(ncheck)))
+            for i in range(ncheck):
+                assert (got[i] == refs[i]).all(), "HIP per-key result differs from the CPU oracle"
+        parity = (f"bit-exact vs oracle on {ncheck} items of {len({int(k) for k in key_index[:ncheck]})} clients (each with its own key); all {total_items} "
+                  f"results decrypt under their client's secret key to the slot-wise products; all outputs canonical")
+    elif args.workload == "mulrelin" and not args.no_check:
         # (1) decrypt-correct on ALL items of every rank (device decryptor, itself bit-exact vs the oracle: tests/test_gpu_client.py)
         dec = ev.decode(ev.decrypt(out, skd), signed=True)
         ok = bool(torch.equal(dec, va * vb))
@@ -843,6 +911,10 @@ def measure(args, env: Env, secondary: bool = False):
         line["power"] = power
     if args.total_batch:
         line["config"]["total_batch"] = args.total_batch
+    if nkeys > 1:
+        line["config"]["key_sets"] = nkeys
+        line["roofline_note"] = ("algorithmic bytes per op = 48 K N (two inputs, one output) + 16 K (K+1) N x distinct keys / batch (every distinct "
+                                 "relinearisation key is read at least once per step)")
     if exchange:
         line["config"]["exchange"] = exchange
     if gather_ms is not None:
@@ -862,7 +934,7 @@ def main():
 
     line = measure(args, env)
     # BASELINE.json's metric also names n=16384 and NTTs/sec: the default (headline) run times them too, in this process
-    headline = args.workload == "mulrelin" and args.n == 8192 and not args.coeff_bits and not args.chunk
+    headline = args.workload == "mulrelin" and args.n == 8192 and not args.coeff_bits and not args.chunk and args.keys <= 1
     if headline and not args.no_secondary:
         second = {}
         q4 = max(args.batch // 4, 1)
@@ -873,6 +945,14 @@ def main():
             # the north star's literal prime set ("n=8192, 3 x 54-bit RNS primes")
             ("mulrelin_n8192_bits54-54-54-56", dict(coeff_bits="54,54,54,56")),
         ]
+        if not args.total_batch:
+            # SURVEY 8(d) config 3 "also report the per-ciphertext-key worst case": the same batch with one key set per 64 items, one
+            # per item (every item reads its own 2.5 MiB key), and the n = 16384 worst case (18 MiB of key per item)
+            jobs += [
+                ("mulrelin_n8192_keys64", dict(keys=max(args.batch // 64, 1), no_cpu=True)),
+                ("mulrelin_n8192_keys4096", dict(keys=args.batch, no_cpu=True)),
+                ("mulrelin_n16384_keys1024", dict(n=16384, batch=q4, keys=q4, no_cpu=True)),
+            ]
         if env.world == 1 and not args.total_batch:
             # BASELINE.json configs[3], [4]: the reference's example programs at n = 16384 (single-GPU forms; the sharded forms are
             # `--workload chi_sq --total-batch 1024 --gpus 8` and `--workload pir --n 16384 --batch 1024 --gpus 8`)
@@ -928,7 +1008,8 @@ def main():
         sys.exit(1)
 
 
-SUMMARY_KEYS = {"mulrelin_n16384": "mulrelin_n16384", "ntt_n8192": "ntt_n8192", "mulrelin_n8192_bits54-54-54-56": "3x54", "chi_sq_n16384": "chi_sq_1024",
+SUMMARY_KEYS = {"mulrelin_n8192_keys64": "keys64", "mulrelin_n8192_keys4096": "keys4096", "mulrelin_n16384_keys1024": "n16384_keys1024",
+                "mulrelin_n16384": "mulrelin_n16384", "ntt_n8192": "ntt_n8192", "mulrelin_n8192_bits54-54-54-56": "3x54", "chi_sq_n16384": "chi_sq_1024",
                 "chi_sq_n16384_share128": "chi_sq_128", "dot_prod_n16384": "dot_prod", "pir_n16384_2p17": "pir_2p17"}
 
 
@@ -948,6 +1029,8 @@ def summary_entry(rec):
 
 def summary_of(line):
     name = "mulrelin_n8192" if line["config"].get("poly_modulus_degree") == 8192 and line["metric"] == "bfv_mul_relin_ops_per_sec" else "headline"
+    if line["config"].get("key_sets"):  # a stand-alone --keys run
+        name = f"mulrelin_n{line['config'].get('poly_modulus_degree')}_keys{line['config']['key_sets']}"
     out = {name: summary_entry(line)}
     for key, rec in (line.get("secondary") or {}).items():
         out[SUMMARY_KEYS.get(key, key)] = summary_entry(rec)
@@ -985,6 +1068,8 @@ def trim_headline(line):
 def pmc_workload_key(args, n):
     """Key of this run's workload in profiles/pmc_traffic.json (the PMC passes are per workload)."""
     k = f"{args.workload}_n{n}"
+    if getattr(args, "keys", 1) > 1:
+        k += f"_keys{args.keys}"
     if args.coeff_bits:
         k += "_bits" + args.coeff_bits.replace(",", "-")
     return k

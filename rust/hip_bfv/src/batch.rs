@@ -78,6 +78,49 @@ impl<'e> BatchEvaluator<'e> {
     pub fn rotate_columns(&self, a: DeviceBatch, gk: &GaloisKeys, out: DeviceBatch) -> Result<()> {
         check(unsafe { bindgen::hipbfv_batch_rotate_columns(self.h(), a.ptr, gk.get_handle(), out.ptr, a.count, self.stream) })
     }
+    // ---- per-key batches ----
+    // The reference hands the keys over with every call (`sunscreen_runtime/src/run.rs:100-105`: `relin_keys:
+    // &Option<&RelinearizationKeys>`, `galois_keys: &Option<&GaloisKeys>`; `runtime.rs:310-327`): a server that batches the
+    // calls of many clients holds one key set per client.  Item i uses `keys[key_index[i]]`; items need not be grouped by key.
+    fn key_index_ok(key_index: &[u32], sets: usize, count: u64) -> Result<()> {
+        if key_index.len() as u64 != count || key_index.iter().any(|&k| k as usize >= sets) {
+            return Err(crate::Error::InvalidArgument(format!("{} key indices for {} items over {} key sets", key_index.len(), count, sets)));
+        }
+        Ok(())
+    }
+    pub fn multiply_relin_keys(&self, a: DeviceBatch, b: DeviceBatch, keys: &[&RelinearizationKeys], key_index: &[u32], out: DeviceBatch) -> Result<()> {
+        same_count(&a, &b)?;
+        same_count(&a, &out)?;
+        Self::key_index_ok(key_index, keys.len(), a.count)?;
+        let handles: Vec<*mut c_void> = keys.iter().map(|k| k.get_handle()).collect();
+        check(unsafe {
+            bindgen::hipbfv_batch_multiply_relin_keys(self.h(), a.ptr, b.ptr, handles.as_ptr(), handles.len() as u64, key_index.as_ptr(), out.ptr, a.count, self.stream)
+        })
+    }
+    pub fn relinearize_keys(&self, ct3: DeviceBatch, keys: &[&RelinearizationKeys], key_index: &[u32], out: DeviceBatch) -> Result<()> {
+        same_count(&ct3, &out)?;
+        Self::key_index_ok(key_index, keys.len(), ct3.count)?;
+        let handles: Vec<*mut c_void> = keys.iter().map(|k| k.get_handle()).collect();
+        check(unsafe {
+            bindgen::hipbfv_batch_relinearize_keys(self.h(), ct3.ptr, handles.as_ptr(), handles.len() as u64, key_index.as_ptr(), out.ptr, ct3.count, self.stream)
+        })
+    }
+    pub fn rotate_rows_keys(&self, a: DeviceBatch, steps: i32, keys: &[&GaloisKeys], key_index: &[u32], out: DeviceBatch) -> Result<()> {
+        same_count(&a, &out)?;
+        Self::key_index_ok(key_index, keys.len(), a.count)?;
+        let handles: Vec<*mut c_void> = keys.iter().map(|k| k.get_handle()).collect();
+        check(unsafe {
+            bindgen::hipbfv_batch_rotate_rows_keys(self.h(), a.ptr, steps, handles.as_ptr(), handles.len() as u64, key_index.as_ptr(), out.ptr, a.count, self.stream)
+        })
+    }
+    pub fn rotate_columns_keys(&self, a: DeviceBatch, keys: &[&GaloisKeys], key_index: &[u32], out: DeviceBatch) -> Result<()> {
+        same_count(&a, &out)?;
+        Self::key_index_ok(key_index, keys.len(), a.count)?;
+        let handles: Vec<*mut c_void> = keys.iter().map(|k| k.get_handle()).collect();
+        check(unsafe {
+            bindgen::hipbfv_batch_rotate_columns_keys(self.h(), a.ptr, handles.as_ptr(), handles.len() as u64, key_index.as_ptr(), out.ptr, a.count, self.stream)
+        })
+    }
     pub fn add(&self, a: DeviceBatch, b: DeviceBatch, out: DeviceBatch) -> Result<()> {
         same_count(&a, &b)?;
         same_count(&a, &out)?;
@@ -159,6 +202,39 @@ impl Program {
             self.handle, eval.get_handle(), batch, inputs.len() as u64, kinds.as_ptr(), ptrs.as_ptr(), strides.as_ptr(),
             rk.map_or(null_mut(), |k| k.get_handle()), gk.map_or(null_mut(), |k| k.get_handle()),
             outputs.len() as u64, outputs.as_ptr(), stream,
+        ))
+    }
+}
+
+impl Program {
+    /// [`Program::run`] for a batch whose input sets belong to several clients: input set i runs with `rk[key_index[i]]`,
+    /// `gk[key_index[i]]` (an entry may be `None` when the program needs no such key) -- the reference's per-call keys
+    /// (`run.rs:100-105`) kept per input set.
+    ///
+    /// # Safety
+    /// As for [`Program::run`].
+    pub unsafe fn run_keys(
+        &self, eval: &BFVEvaluator, batch: u64, inputs: &[Input], rk: &[Option<&RelinearizationKeys>], gk: &[Option<&GaloisKeys>],
+        key_index: &[u32], outputs: &[*mut u64], stream: *mut c_void,
+    ) -> Result<()> {
+        let sets = rk.len().max(gk.len());
+        if key_index.len() as u64 != batch || key_index.iter().any(|&k| k as usize >= sets) {
+            return Err(crate::Error::InvalidArgument(format!("{} key indices for {} input sets over {} key sets", key_index.len(), batch, sets)));
+        }
+        let kinds: Vec<u32> = inputs.iter().map(|i| match i { Input::Ciphertexts(_) => 0, Input::Plaintexts { .. } => 1, Input::PlaintextsNtt { .. } => 2 }).collect();
+        let ptrs: Vec<*const u64> = inputs
+            .iter()
+            .map(|i| match i { Input::Ciphertexts(p) => *p, Input::Plaintexts { ptr, .. } | Input::PlaintextsNtt { ptr, .. } => *ptr })
+            .collect();
+        let strides: Vec<u64> = inputs
+            .iter()
+            .map(|i| match i { Input::Ciphertexts(_) => 0, Input::Plaintexts { stride, .. } | Input::PlaintextsNtt { stride, .. } => *stride })
+            .collect();
+        let rks: Vec<*mut c_void> = (0..sets).map(|i| rk.get(i).copied().flatten().map_or(null_mut(), |k| k.get_handle())).collect();
+        let gks: Vec<*mut c_void> = (0..sets).map(|i| gk.get(i).copied().flatten().map_or(null_mut(), |k| k.get_handle())).collect();
+        check(bindgen::hipbfv_Program_RunKeys(
+            self.handle, eval.get_handle(), batch, inputs.len() as u64, kinds.as_ptr(), ptrs.as_ptr(), strides.as_ptr(),
+            sets as u64, rks.as_ptr(), gks.as_ptr(), key_index.as_ptr(), outputs.len() as u64, outputs.as_ptr(), stream,
         ))
     }
 }
