@@ -239,6 +239,7 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_TAIL")) fuse_mulrelin_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_HEAD")) fuse_head_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SMALL_BATCH")) small_batch_ = env[0] != '1';
+  if (const char* env = std::getenv("HIPBFV_NO_FUSED_GALOIS")) fuse_galois_ = env[0] != '1';
   if (hipMalloc((void**)&status_dev_, 256) == hipSuccess)
     (void)hipMemset(status_dev_, 0xFF, 256);
   else {
@@ -411,23 +412,29 @@ int Evaluator::stage_keymap(const KeySel& sel, size_t count, size_t chunk, hipSt
   return kOk;
 }
 
+bool Evaluator::ks_split_for(size_t count) const {
+  const DevCtx& h = ctx_->host();
+  return split_ks_ && h.logn >= 12 && h.logn <= 14 && h.ks_split_ok && !few_for_split_ks(count);
+}
+
 // out2[op] = base[op] (masked) + modDown( sum_J NTT(target_J) (.) key[J] ); scratch >= count * ks_scratch_words()
 int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, const u64* base, size_t bstride, u32 base_mask,
-                          u64* out2, size_t count, u64* scratch, hipStream_t s, const u64* extra, KeyMap km) {
+                          u64* out2, size_t count, u64* scratch, hipStream_t s, const u64* extra, KeyMap km, u32 ginv) {
   const DevCtx& h = ctx_->host();
   const u32 n = h.n, K = h.K, KK = h.KK;
   u64* T = scratch;
   u64* ACC = scratch + count * (size_t)KK * K * n;
   std::vector<u32> mods;
   for (u32 i = 0; i < KK; i++) mods.push_back(i);
-  const bool split_ok = split_ks_ && h.logn >= 12 && h.logn <= 14 && h.ks_split_ok && !few_for_split_ks(count);
+  const bool split_ok = ks_split_for(count);
+  if (ginv && !split_ok) return kInvalidArg;  // (apply_galois rotates into a copy for the whole-polynomial kernels)
   if (split_ok) {
     // head / middle / tail split transforms (kernels_split.hip): 3 launches (4 when FP64- and integer-policy key primes are
     // mixed: one middle kernel per policy), no whole-polynomial NTT round trips
     const bool mixed = h.ks_ni != 0;
-    HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, mixed, K, target, tstride, T, count, s));
+    HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, mixed, K, target, tstride, T, count, s, ginv));
     HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, key, ACC, count, s, km));
-    HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, h.pack_ks != 0, mixed, ACC, base, bstride, base_mask, extra, out2, count, s));
+    HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, h.pack_ks != 0, mixed, ACC, base, bstride, base_mask, extra, out2, count, s, ginv));
     return kOk;
   }
   HB_LAUNCH(kKernKsDecompose, count, launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));
@@ -533,12 +540,24 @@ int Evaluator::apply_galois(const u64* ct2, u32 elt, const KeySel& key, u64* out
   const size_t cc = std::min(chunk, count);
   KeyMapLease kl;
   if (int rc = stage_keymap(key, count, chunk, s, kl)) return rc;
-  ScratchGuard sg(pool_, cc * (rot_words + ks_scratch_words()) * sizeof(u64), s);
+  // r06: the split kernels read sigma_g(c1) (head) and sigma_g(c0) (tail) THROUGH the automorphism -- no rotated copy, no galois
+  // launch (2 polynomials written and read again per rotation).  Not in place: the tail would gather from what it overwrites
+  // (SEAL's NAF chains rotate their intermediate in place: those steps keep the copy).
+  const size_t last = count % chunk ? count % chunk : cc;  // every chunk, the short last one included, must take the split kernels
+  const bool fused = fuse_galois_ && ct2 != out2 && ks_split_for(cc) && ks_split_for(last);
+  ScratchGuard sg(pool_, cc * ((fused ? 0 : rot_words) + ks_scratch_words()) * sizeof(u64), s);
   if (!sg.p) return kOutOfMemory;
   u64* rot = (u64*)sg.p;
-  u64* ks = rot + cc * rot_words;
+  u64* ks = rot + (fused ? 0 : cc * rot_words);
   for (size_t off = 0; off < count; off += chunk) {
     const size_t c = std::min(chunk, count - off);
+    if (fused) {
+      const u64* in = ct2 + off * rot_words;
+      int rc = key_switch(in + (size_t)K * n, rot_words, key.key, in, rot_words, 1u, out2 + off * rot_words, c, ks, s, addend ? addend + off * rot_words : nullptr,
+                          kl.at(off), ginv);
+      if (rc) return rc;
+      continue;
+    }
     HB_LAUNCH(kKernGalois, c * 2, launch_galois(ctx_->dev(), n, K, ct2 + off * rot_words, rot, c * 2, ginv, s));
     // base = (sigma(c0), 0); target = sigma(c1)
     int rc = key_switch(rot + (size_t)K * n, rot_words, key.key, rot, rot_words, 1u, out2 + off * rot_words, c, ks, s, addend ? addend + off * rot_words : nullptr,

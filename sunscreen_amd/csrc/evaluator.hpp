@@ -233,7 +233,8 @@ class Evaluator {
 
  private:
   int key_switch(const u64* target, size_t tstride, const u64* key, const u64* base, size_t bstride, u32 base_mask, u64* out2,
-                 size_t count, u64* scratch, hipStream_t s, const u64* extra = nullptr, KeyMap km = KeyMap{});
+                 size_t count, u64* scratch, hipStream_t s, const u64* extra = nullptr, KeyMap km = KeyMap{}, u32 ginv = 0);
+  bool ks_split_for(size_t count) const;  // key_switch takes the head / middle / tail kernels for a batch of this size
   size_t ks_scratch_words() const;
   // the device tables of a per-item key selection for one call: `order` holds, for every chunk of `chunk` items, the chunk's items
   // (numbered from 0 within the chunk) sorted by key -- the launch over chunk c reads order + c * chunk
@@ -257,6 +258,7 @@ class Evaluator {
   bool split_mul_ = true;  // ... and for the BEHZ multiply
   bool fuse_head_ = true;      // ... and c2 formed inside the key switch's first kernel
   bool small_batch_ = true;    // a few ciphertexts take the whole-polynomial pipelines (HIPBFV_NO_SMALL_BATCH=1: pipelines chosen by parameters only)
+  bool fuse_galois_ = true;    // rotations: the automorphism read through the key switch's head / tail loads (no rotated copy)
   bool fuse_mulrelin_ = true;  // multiply_relin: c0, c1 of the product formed inside the key switch's last kernel
 };
 

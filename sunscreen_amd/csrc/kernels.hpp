@@ -54,11 +54,14 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
 // split (head / middle / tail) key switch, kernels_split.hip
 // res_* (here and in launch_mul_mid): device byte lists of residue indices, read through the scalar unit as 32-bit words -- they must be
 // 4-byte aligned and readable up to the next word boundary (the DevCtx members are; the launchers refuse anything else)
-hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s);
+// ginv != 0 (launch_ks_head, launch_ks_tail): a rotation's key switch -- the target / the base polynomials are sigma_g(.) for g = ginv^-1 mod 2N,
+// read through the automorphism instead of from a rotated copy (base and out2 must not alias then)
+hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
+                          u32 ginv = 0);
 hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd, const unsigned char* res_i, u32 ni,
                          const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km = KeyMap{});
 hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
-                          size_t ops, hipStream_t s);
+                          size_t ops, hipStream_t s, u32 ginv = 0);
 // split BEHZ multiply (2 x 2 -> 3), K <= 4
 hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, int pack, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
                            hipStream_t s, u32 npolys = 4);

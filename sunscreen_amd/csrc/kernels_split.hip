@@ -838,6 +838,15 @@ __device__ __forceinline__ void st_tail_out(const BufRow& row, u32 t, int k, u64
   buf_st64<false>(row.r, X::tail_out_lane(t, k) * 8u, row.soff + X::tail_uni(k) * 8u, v);
 }
 
+// coefficient j of sigma_g(p) mod q, p a canonical residue row at byte offset soff of the descriptor: +- p[j * g^-1 mod 2N]
+template <int L>
+__device__ __forceinline__ u64 galois_gather(BufRsrc r, u32 soff, u32 j, u32 ginv, u64 q) {
+  constexpr u32 N = 1u << L;
+  const u32 i2 = (j * ginv) & (2u * N - 1u);
+  const u64 w = buf_ld64<false>(r, (i2 & (N - 1u)) * 8u, soff);
+  return (i2 & N) && w ? q - w : w;
+}
+
 __device__ __forceinline__ bool residue_is_f64(const DevMod& dm) { return dm.use_f64 && dm.split_ok; }
 template <class A, int NC>
 __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], const typename A::Tw* __restrict__ tw);
@@ -851,7 +860,7 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 // -------------------------------------------------------------------------------------------------
 template <int L, bool PACK, bool MIXED>
 __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
-                                                               const u64* __restrict__ target, size_t tstride, double* __restrict__ T) {
+                                                               const u64* __restrict__ target, size_t tstride, double* __restrict__ T, u32 ginv) {
   using G = EdgeGeom<L>;
   constexpr int NC = G::HEAD_NC;
   constexpr u32 N = 1u << L;
@@ -860,10 +869,18 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
   const u32 K = ctx->K, KK = ctx->KK;
   const u64* src = target + (size_t)op * tstride + (size_t)J * N;
   const BufRsrc rout = buf_rsrc(T + (size_t)op * KK * K * N);  // buffer addressing: see BufRow
-  u64 x[NC];
-#pragma unroll
-  for (int k = 0; k < NC; k++) x[k] = ld_head_in<L>(buf_row(buf_rsrc(src), 0), t, k);
   const u64 qJ = ctx->mod[J].q;
+  u64 x[NC];
+  if (ginv) {
+    // a rotation's key switch: the target is sigma_g(c1), read THROUGH the automorphism (SEAL apply_galois, seal_fhe/src/
+    // bfv_evaluator.rs:177-247) instead of from a rotated copy: coefficient j of sigma_g(p) is +- p[j * g^-1 mod 2N] (minus when the
+    // index passes N).  An 8-byte gather per value; every line is used in full by the workgroups of this row (L2 absorbs it).
+#pragma unroll
+    for (int k = 0; k < NC; k++) x[k] = galois_gather<L>(buf_rsrc(src), 0u, EdgeSplitIdx<L>::head_in_lane(t, k) + EdgeSplitIdx<L>::head_uni(k), ginv, qJ);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NC; k++) x[k] = ld_head_in<L>(buf_row(buf_rsrc(src), 0), t, k);
+  }
   for (u32 I = 0; I < KK; I++) {
     const DevMod& dm = ctx->mod[I];
     if constexpr (MIXED) {
@@ -1207,7 +1224,7 @@ __device__ __forceinline__ void tail_special_d(const DevCtx* __restrict__ ctx, c
 template <int L, bool PACK, bool MIXED>
 __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                const double* __restrict__ ACC, const u64* __restrict__ base, size_t bstride,
-                                                               u32 base_mask, const u64* __restrict__ extra, u64* __restrict__ out) {
+                                                               u32 base_mask, const u64* __restrict__ extra, u64* __restrict__ out, u32 ginv) {
   using G = EdgeGeom<L>;
   constexpr u32 N = 1u << L;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
@@ -1242,11 +1259,16 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
       // load under `if (extra)` ends its basic block in a copy of the loaded value, i.e. in an s_waitcnt vmcnt(0) that also waits
       // for the row just requested
       u64 bw[4], ex[4];
+      if (ginv) {  // a rotation: the base is sigma_g(c0), read through the automorphism (ks_head_kernel)
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        bw[k] = ld_tail_out<L>(buf_row(rbase, (size_t)J * N), t, k);
-        ex[k] = ld_tail_out<L>(buf_row(rex, (size_t)J * N), t, k);
+        for (int k = 0; k < 4; k++)
+          bw[k] = galois_gather<L>(rbase, (u32)((size_t)J * N * 8u), EdgeSplitIdx<L>::tail_out_lane(t, k) + EdgeSplitIdx<L>::tail_uni(k), ginv, mj.q);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) bw[k] = ld_tail_out<L>(buf_row(rbase, (size_t)J * N), t, k);
       }
+#pragma unroll
+      for (int k = 0; k < 4; k++) ex[k] = ld_tail_out<L>(buf_row(rex, (size_t)J * N), t, k);
       double v[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = nat_unpack<PACK>(cur[k]);
@@ -1319,11 +1341,16 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
       for (int k = 0; k < 4; k++) nxt[k] = ld_tail_in<L>(buf_row(racc, (size_t)Jn * N), t, k);
       const DevMod& mj = ctx->mod[J];
       u64 bw[4], ex[4];  // (absent operands: descriptors of zero records, the loads return 0)
+      if (ginv) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        bw[k] = ld_tail_out<L>(buf_row(rbase, (size_t)J * N), t, k);
-        ex[k] = ld_tail_out<L>(buf_row(rex, (size_t)J * N), t, k);
+        for (int k = 0; k < 4; k++)
+          bw[k] = galois_gather<L>(rbase, (u32)((size_t)J * N * 8u), EdgeSplitIdx<L>::tail_out_lane(t, k) + EdgeSplitIdx<L>::tail_uni(k), ginv, mj.q);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) bw[k] = ld_tail_out<L>(buf_row(rbase, (size_t)J * N), t, k);
       }
+#pragma unroll
+      for (int k = 0; k < 4; k++) ex[k] = ld_tail_out<L>(buf_row(rex, (size_t)J * N), t, k);
       u64 av[4];
       if (!residue_is_f64(mj)) {
         const ArithI ai(mj);
@@ -2377,19 +2404,22 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
   }
 
 template <int L>
-static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
+static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
+                            u32 ginv) {
   const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, K, (unsigned)ops);
   if (mixed)
-    ks_head_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
+    ks_head_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
   else if (pack)
-    ks_head_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
+    ks_head_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
   else
-    ks_head_kernel<L, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T));
+    ks_head_kernel<L, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
   return hipGetLastError();
 }
 // pack: DevCtx::pack_ks of the context behind `ctx` (48-bit packed intermediates, see nat_load); mixed: DevCtx::ks_ni != 0
-hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(ks_head_t, ctx, twf, pack, mixed, K, target, tstride, T, ops, s)
+// ginv != 0: the target is sigma_g(target) for the Galois element g = ginv^-1 mod 2N, read through the automorphism
+hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
+                          u32 ginv) {
+  SPLIT_DISPATCH(ks_head_t, ctx, twf, pack, mixed, K, target, tstride, T, ops, s, ginv)
 }
 
 // res_d / nd, res_i / ni: device lists (inside the DevCtx) of the key primes that take the FP64 / the integer policy
@@ -2419,20 +2449,20 @@ hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, 
 
 template <int L>
 static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
-                            const u64* extra, u64* out2, size_t ops, hipStream_t s) {
+                            const u64* extra, u64* out2, size_t ops, hipStream_t s, u32 ginv) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
   if (mixed)
-    ks_tail_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
+    ks_tail_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2, ginv);
   else if (pack)
-    ks_tail_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
+    ks_tail_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2, ginv);
   else
-    ks_tail_kernel<L, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2);
+    ks_tail_kernel<L, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2, ginv);
   return hipGetLastError();
 }
-// extra: optional ciphertexts u64[ops][2][K][N] added to the result
+// extra: optional ciphertexts u64[ops][2][K][N] added to the result; ginv != 0: the base polynomials are read through sigma_g (launch_ks_head)
 hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
-                          const u64* extra, u64* out2, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(ks_tail_t, ctx, twi, pack, mixed, ACC, base, bstride, base_mask, extra, out2, ops, s)
+                          const u64* extra, u64* out2, size_t ops, hipStream_t s, u32 ginv) {
+  SPLIT_DISPATCH(ks_tail_t, ctx, twi, pack, mixed, ACC, base, bstride, base_mask, extra, out2, ops, s, ginv)
 }
 
 template <int L>
