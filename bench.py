@@ -89,6 +89,8 @@ def parse(argv=None):
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--settle-ms", type=float, default=150.0, help="keep running untimed steps after the W warmup steps until this much wall time "
                     "has passed (device clocks under the power cap settle in tens of ms; 0 = exactly W warmup steps)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="time the regions WITHOUT the HIP events the library records around every kernel launch "
+                    "(hipbfv_profile_enable): the line then has no roofline (no per-kernel times) -- the one-off measurement of what the events cost")
     ap.add_argument("--no-power", dest="power", action="store_false", help="skip the `power` leg (N=1: after the measurement, rocm-smi is sampled for package "
                     "power and shader clock while the steps keep running, about 3 s)")
     ap.add_argument("--power", dest="power", action="store_true", help=argparse.SUPPRESS)
@@ -627,7 +629,7 @@ def measure(args, env: Env, secondary: bool = False):
     repeats = max(1, args.repeats)
     regions = []
     barrier()
-    ev.profile(True)
+    ev.profile(not args.no_kernel_events)
     ev.profile_reset()
     for _ in range(repeats):
         barrier()

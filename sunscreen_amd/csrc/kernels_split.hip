@@ -185,6 +185,20 @@ struct BlkPass {
 // b >= LOW, else at b.  Two consecutive passes that agree on this for every wave-id bit exchange data inside a wavefront only.
 // At N = 8192 that holds for the last forward exchange (windows 2..3 -> 0..1) and for the inverse exchange 2..4 -> 5..7.
 #define MID_WAVE_PRIVATE 1
+// Experiment hook (tools/build_variant.sh): wave priority around the LDS exchanges of the pass-batched middle kernels.
+// 1 = raised from the exchange's stores until its loads are issued (a wave that reaches the exchange gets through it first),
+// 2 = raised while the butterflies run, normal inside the exchange.  0 = no s_setprio at all (the default build).
+#ifndef MID_SETPRIO
+#define MID_SETPRIO 0
+#endif
+__device__ __forceinline__ void mid_prio_exchange_begin() {
+  if constexpr (MID_SETPRIO == 1) __builtin_amdgcn_s_setprio(3);
+  if constexpr (MID_SETPRIO == 2) __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void mid_prio_exchange_end() {
+  if constexpr (MID_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
+  if constexpr (MID_SETPRIO == 2) __builtin_amdgcn_s_setprio(3);
+}
 template <int L, int EPT = kBlkEPT>
 constexpr bool blk_exchange_private(int lowa, int ra, int lowb, int rb) {
   if (!MID_WAVE_PRIVATE) return false;
@@ -353,6 +367,7 @@ __device__ __forceinline__ void mid_forward_multi_p(const A& ar, typename A::V (
     blk_exchange_sync<blk_exchange_private<L, EPT>(split_fwd_low(L, P > 0 ? P - 1 : 0), split_fwd_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::load_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
+    mid_prio_exchange_end();
   }
 #pragma unroll
   for (int i = 0; i < NP; i++) {
@@ -370,6 +385,7 @@ __device__ __forceinline__ void mid_forward_multi_p(const A& ar, typename A::V (
   }
   if constexpr (more) {
     if constexpr (PIPE) Next::load_tw_fwd(wn, tid, blk, tw);
+    mid_prio_exchange_begin();
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::store_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
     mid_forward_multi_p<A, L, PN, NP, EPT, PIPE>(ar, v, smem, tid, blk, tw, mask, PIPE ? wn : w);
@@ -399,6 +415,7 @@ __device__ __forceinline__ void mid_inverse_multi_p(const A& ar, typename A::V (
     blk_exchange_sync<blk_exchange_private<L, EPT>(split_inv_low(L, P > 0 ? P - 1 : 0), split_inv_radix(L, P > 0 ? P - 1 : 0), LOW, R)>();
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::load_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
+    mid_prio_exchange_end();
   }
 #pragma unroll
   for (int i = 0; i < NP; i++) {
@@ -416,6 +433,7 @@ __device__ __forceinline__ void mid_inverse_multi_p(const A& ar, typename A::V (
   }
   if constexpr (more) {
     if constexpr (PIPE) Next::load_tw_inv(wn, tid, blk, tw);
+    mid_prio_exchange_begin();
 #pragma unroll
     for (int i = 0; i < NP; i++) Pass::store_lds(v[i], smem + i * Sh::BLOCK, tid, blk);
     mid_inverse_multi_p<A, L, PN, NP, EPT, PIPE>(ar, v, smem, tid, blk, tw, mask, PIPE ? wn : w);
