@@ -414,7 +414,8 @@ int Evaluator::stage_keymap(const KeySel& sel, size_t count, size_t chunk, hipSt
 
 bool Evaluator::ks_split_for(size_t count) const {
   const DevCtx& h = ctx_->host();
-  return split_ks_ && h.logn >= 12 && h.logn <= 14 && h.ks_split_ok && !few_for_split_ks(count);
+  // (N = 32768 [r06]: integer-policy key primes only -- kernels_split.hip KS_DISPATCH; the multiply keeps the whole-polynomial kernels there)
+  return split_ks_ && h.logn >= 12 && (h.logn <= 14 || (h.logn == 15 && h.ks_nd == 0)) && h.ks_split_ok && !few_for_split_ks(count);
 }
 
 // out2[op] = base[op] (masked) + modDown( sum_J NTT(target_J) (.) key[J] ); scratch >= count * ks_scratch_words()

@@ -1091,14 +1091,29 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
 // The same for integer-policy key primes (Harvey butterflies on lazy u64 values, Shoup twiddles): the digit rows arrive as
 // u64 in [0, 4q) from the head's integer branch; the products with the key rows are summed in 128 bits and reduced once per
 // four digits (4 * 4q * q < 2^126 for q < 2^61); the accumulators leave as lazy u64 in [0, 2q).
-#define KS_MID_INT_GROUP 2
-template <int L>
-__global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
+#define KS_MID_INT_GROUP_OF(L) ((L) >= 15 ? 1 : 2)  // N = 32768: one 64 KB exchange region
+// N = 32768 [r06]: a block is 8192 coefficients = ONE 1024-thread workgroup per CU with 128 registers per lane, where this kernel
+// wants ~250: it spills ~300 bytes per lane.  Measured (interleaved, profiles/r06_s6_*): as it is 20.7 ms per 256 ops; without the
+// twiddle look-ahead and with 64-bit sums reduced per product (216 bytes of scratch) 21.7; 512 threads of 16 elements (256
+// registers, 80 bytes) 22.2; the next digit's rows requested behind the key words 28.6 -- the time does not follow the registers:
+// with one resident workgroup per CU nothing overlaps a digit's load -> four exchanges -> key loads chain.
+#ifndef KS_MID_INT_EPT15
+#define KS_MID_INT_EPT15 8
+#endif
+#define KS_MID_INT_EPT(L) ((L) >= 15 ? KS_MID_INT_EPT15 : kBlkEPT)
+#ifndef KS_MID_INT_NARROW15
+#define KS_MID_INT_NARROW15 0
+#endif
+template <int L, int EPT = KS_MID_INT_EPT(L)>
+__global__ __launch_bounds__((SplitShape<L, EPT>::TPB), (SplitShape<L, EPT>::TPB >= 1024 ? 4 : 2)) void ks_mid_int_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                              const MulOp* __restrict__ twi_base, const u64* __restrict__ T,
                                                                              const u64* __restrict__ key, u64* __restrict__ ACC, u32 ops,
                                                                              const unsigned char* __restrict__ residues, u32 nres, KeyMap km) {
-  using Sh = SplitShape<L>;
+  using Sh = SplitShape<L, EPT>;
   using A = ArithI;
+  constexpr int KS_MID_INT_GROUP = KS_MID_INT_GROUP_OF(L);
+  constexpr bool NARROW = L >= 15 && KS_MID_INT_NARROW15 != 0;  // experiment hook: 64-bit sums, reduced per product
+  constexpr bool PIPE = !NARROW;                                 // next pass's twiddles held as well
   __shared__ u64 smem[KS_MID_INT_GROUP * Sh::BLOCK];
   const u32 tid = threadIdx.x;
   const u32 K = ctx->K, KK = ctx->KK;
@@ -1117,20 +1132,21 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(con
   const MulOp* twf = twf_base + (size_t)I * Sh::N;
   const MulOp* twi = twi_base + (size_t)I * Sh::N;
   constexpr int RF0 = split_fwd_radix(L, 0), LOWF0 = split_fwd_low(L, 0);
-  using First = BlkPass<A, L, LOWF0, RF0>;
+  using First = BlkPass<A, L, LOWF0, RF0, EPT>;
   constexpr int RL = split_fwd_radix(L, Sh::NPF - 1);
-  using Last = BlkPass<A, L, 0, RL>;
-  u128 wide[2][kBlkEPT];
+  using Last = BlkPass<A, L, 0, RL, EPT>;
+  using Wide = typename std::conditional<NARROW, u64, u128>::type;
+  Wide wide[2][EPT];
 #pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) wide[0][e] = 0, wide[1][e] = 0;
-  auto load_src = [&](u32 J, u64(&dst)[kBlkEPT]) {
+  for (int e = 0; e < EPT; e++) wide[0][e] = 0, wide[1][e] = 0;
+  auto load_src = [&](u32 J, u64(&dst)[EPT]) {
     const u64* src = T + (((size_t)op * KK + I) * K + J) * Sh::N;
 #pragma unroll
     for (int g = 0; g < First::G; g++)
 #pragma unroll
       for (int k = 0; k < (1 << RF0); k++) dst[g * (1 << RF0) + k] = nt_ld<NtSites<L>::ks_mid_ld>(src + First::elem(tid, blk, g, k));
   };
-  auto mac = [&](u32 J, const u64(&v)[kBlkEPT]) {
+  auto mac = [&](u32 J, const u64(&v)[EPT]) {
     const global_ptr<const u64> k0 = as_global(key) + (((size_t)J * 2 + 0) * KK + I) * Sh::N;
     const global_ptr<const u64> k1 = as_global(key) + (((size_t)J * 2 + 1) * KK + I) * Sh::N;
 #pragma unroll
@@ -1142,25 +1158,34 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(con
         const key2_t ka = *reinterpret_cast<global_ptr<const key2_t>>(k0 + base + k);
         const key2_t kc = *reinterpret_cast<global_ptr<const key2_t>>(k1 + base + k);
         const int e = g * W + k;
-        wide[0][e] += (u128)v[e] * ka.x;
-        wide[0][e + 1] += (u128)v[e + 1] * ka.y;
-        wide[1][e] += (u128)v[e] * kc.x;
-        wide[1][e + 1] += (u128)v[e + 1] * kc.y;
+        if constexpr (NARROW) {
+          wide[0][e] = ar.mul_add(v[e], ka.x, wide[0][e]);
+          wide[0][e + 1] = ar.mul_add(v[e + 1], ka.y, wide[0][e + 1]);
+          wide[1][e] = ar.mul_add(v[e], kc.x, wide[1][e]);
+          wide[1][e + 1] = ar.mul_add(v[e + 1], kc.y, wide[1][e + 1]);
+        } else {
+          wide[0][e] += (u128)v[e] * ka.x;
+          wide[0][e + 1] += (u128)v[e + 1] * ka.y;
+          wide[1][e] += (u128)v[e] * kc.x;
+          wide[1][e + 1] += (u128)v[e + 1] * kc.y;
+        }
       }
     }
-    if ((J & 3u) == 3u) {
+    if constexpr (!NARROW) {
+      if ((J & 3u) == 3u) {
 #pragma unroll
-      for (int e = 0; e < kBlkEPT; e++) wide[0][e] = reduce128(wide[0][e], dm), wide[1][e] = reduce128(wide[1][e], dm);
+        for (int e = 0; e < EPT; e++) wide[0][e] = reduce128(wide[0][e], dm), wide[1][e] = reduce128(wide[1][e], dm);
+      }
     }
   };
   auto group = [&](u32 J0, auto np_tag) {
     constexpr int NP = decltype(np_tag)::value;
-    u64 v[NP][kBlkEPT];
+    u64 v[NP][EPT];
 #pragma unroll
     for (int i = 0; i < NP; i++) load_src(J0 + i, v[i]);
     if (J0 > 0) __syncthreads();
     const MulOp* twf_j = opaque_uniform(twf);
-    mid_forward_multi<A, L, NP>(ar, v, smem, tid, blk, twf_j, 0u);
+    mid_forward_multi<A, L, NP, EPT, PIPE>(ar, v, smem, tid, blk, twf_j, 0u);
 #pragma unroll
     for (int i = 0; i < NP; i++) mac(J0 + i, v[i]);
   };
@@ -1168,18 +1193,22 @@ __global__ __launch_bounds__((SplitShape<L>::TPB), 2) void ks_mid_int_kernel(con
   if constexpr (KS_MID_INT_GROUP >= 2)
     for (; J + 2 <= K; J += 2) group(J, std::integral_constant<int, 2>{});
   for (; J < K; J++) group(J, std::integral_constant<int, 1>{});
-  u64 acc[2][kBlkEPT];
+  u64 acc[2][EPT];
 #pragma unroll
-  for (int e = 0; e < kBlkEPT; e++) acc[0][e] = reduce128(wide[0][e], dm), acc[1][e] = reduce128(wide[1][e], dm);
+  for (int e = 0; e < EPT; e++) {
+    if constexpr (NARROW) acc[0][e] = (u64)wide[0][e], acc[1][e] = (u64)wide[1][e];
+    else acc[0][e] = reduce128((u128)wide[0][e], dm), acc[1][e] = reduce128((u128)wide[1][e], dm);
+  }
   constexpr int RI = split_inv_radix(L, Sh::NPI - 1), LOWI = split_inv_low(L, Sh::NPI - 1);
-  using Out = BlkPass<A, L, LOWI, RI>;
+  using Out = BlkPass<A, L, LOWI, RI, EPT>;
   __syncthreads();
   if constexpr (KS_MID_INT_GROUP >= 2) {
-    mid_inverse_multi<A, L, 2>(ar, acc, smem, tid, blk, twi, 0u);
+    mid_inverse_multi<A, L, 2, EPT, PIPE>(ar, acc, smem, tid, blk, twi, 0u);
   } else {
-    mid_inverse<A, L, 0>(ar, acc[0], smem, tid, blk, twi, 0u);
+    using One = u64[1][EPT];
+    mid_inverse_multi<A, L, 1, EPT, PIPE>(ar, *reinterpret_cast<One*>(&acc[0]), smem, tid, blk, twi, 0u);
     __syncthreads();
-    mid_inverse<A, L, 0>(ar, acc[1], smem, tid, blk, twi, 0u);
+    mid_inverse_multi<A, L, 1, EPT, PIPE>(ar, *reinterpret_cast<One*>(&acc[1]), smem, tid, blk, twi, 0u);
   }
 #pragma unroll
   for (int c = 0; c < 2; c++) {
@@ -2421,11 +2450,27 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
     default: return hipErrorInvalidValue;    \
   }
 
+// The key switch also runs split at N = 32768 [r06] -- integer-policy key primes only (SEAL's 55 / 56-bit default set; the mixed
+// head / tail instantiations and ks_mid_int_kernel, one digit at a time: 64 KB of LDS per 1024-thread workgroup).  The head and tail
+// loop over the primes at run time, so K = 15 costs them no registers; the multiply keeps the whole-polynomial kernels there.
+#define KS_DISPATCH(fn, ...)                 \
+  switch (logn) {                            \
+    case 12: return fn<12>(__VA_ARGS__);     \
+    case 13: return fn<13>(__VA_ARGS__);     \
+    case 14: return fn<14>(__VA_ARGS__);     \
+    case 15: return fn<15>(__VA_ARGS__);     \
+    default: return hipErrorInvalidValue;    \
+  }
+
 template <int L>
 static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
                             u32 ginv) {
   const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, K, (unsigned)ops);
-  if (mixed)
+  if constexpr (L == 15) {
+    if (!mixed) return hipErrorInvalidValue;
+    ks_head_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
+    return hipGetLastError();
+  } else if (mixed)
     ks_head_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
   else if (pack)
     ks_head_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
@@ -2437,7 +2482,7 @@ static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, bool pack, bool
 // ginv != 0: the target is sigma_g(target) for the Galois element g = ginv^-1 mod 2N, read through the automorphism
 hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
                           u32 ginv) {
-  SPLIT_DISPATCH(ks_head_t, ctx, twf, pack, mixed, K, target, tstride, T, ops, s, ginv)
+  KS_DISPATCH(ks_head_t, ctx, twf, pack, mixed, K, target, tstride, T, ops, s, ginv)
 }
 
 // res_d / nd, res_i / ni: device lists (inside the DevCtx) of the key primes that take the FP64 / the integer policy
@@ -2447,7 +2492,9 @@ static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi
   using Sh = SplitShape<L>;
   if (((reinterpret_cast<uintptr_t>(res_d) | reinterpret_cast<uintptr_t>(res_i)) & 3u) != 0) return hipErrorInvalidValue;  // residue_of reads words
   const size_t ops8 = (ops + 7) / 8 * 8;
-  if (nd) {
+  if constexpr (L == 15) {
+    if (nd) return hipErrorInvalidValue;  // integer-policy key primes only at this degree (context.cpp: ks_split_ok)
+  } else if (nd) {
     const dim3 grid((unsigned)(ops8 * nd * Sh::NBLK));
     if (pack)
       ks_mid_kernel<L, true><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd, km);
@@ -2456,20 +2503,24 @@ static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi
   }
   if (ni) {
     const dim3 grid((unsigned)(ops8 * ni * Sh::NBLK));
-    ks_mid_int_kernel<L><<<grid, Sh::TPB, 0, s>>>(ctx, twf, twi, T, key, ACC, (u32)ops, res_i, ni, km);
+    ks_mid_int_kernel<L><<<grid, SplitShape<L, KS_MID_INT_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, T, key, ACC, (u32)ops, res_i, ni, km);
   }
   return hipGetLastError();
 }
 hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd,
                          const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km) {
-  SPLIT_DISPATCH(ks_mid_t, ctx, twf, twi, pack, res_d, nd, res_i, ni, T, key, ACC, ops, s, km)
+  KS_DISPATCH(ks_mid_t, ctx, twf, twi, pack, res_d, nd, res_i, ni, T, key, ACC, ops, s, km)
 }
 
 template <int L>
 static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
                             const u64* extra, u64* out2, size_t ops, hipStream_t s, u32 ginv) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
-  if (mixed)
+  if constexpr (L == 15) {
+    if (!mixed) return hipErrorInvalidValue;
+    ks_tail_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2, ginv);
+    return hipGetLastError();
+  } else if (mixed)
     ks_tail_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2, ginv);
   else if (pack)
     ks_tail_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2, ginv);
@@ -2480,7 +2531,7 @@ static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack, bool
 // extra: optional ciphertexts u64[ops][2][K][N] added to the result; ginv != 0: the base polynomials are read through sigma_g (launch_ks_head)
 hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
                           const u64* extra, u64* out2, size_t ops, hipStream_t s, u32 ginv) {
-  SPLIT_DISPATCH(ks_tail_t, ctx, twi, pack, mixed, ACC, base, bstride, base_mask, extra, out2, ops, s, ginv)
+  KS_DISPATCH(ks_tail_t, ctx, twi, pack, mixed, ACC, base, bstride, base_mask, extra, out2, ops, s, ginv)
 }
 
 template <int L>

@@ -646,6 +646,30 @@ def test_largest_degree_n32768_two_kernel_ntt():
     assert (o.batch_decode(o.decrypt(r[0], sk)) == (va * vb) % t).all()
     g = to_host(ev.rotate_rows(to_device(a), 1, GaloisKeys.from_arrays(ctx, gk)))
     assert (g[0] == o.rotate_rows(a[0], 1, gk)).all()
+    # r06: the key switch runs through the head / middle / tail kernels at this degree too (integer-policy key primes, K = 15 digits
+    # of 16 rows each); a few distinct items in one call, the stand-alone relinearisation, and the same bits with the whole-polynomial
+    # key switch (HIPBFV_NO_SPLIT_KS=1 in a fresh evaluator)
+    a3 = np.stack([a[0], b[0], o.encrypt(pk, o.batch_encode((va + vb) % t))])
+    b3 = np.stack([b[0], b[0], a[0]])
+    rkd = RelinearizationKeys.from_array(ctx, rk)
+    prod = ev.multiply(to_device(a3), to_device(b3))
+    r3 = to_host(ev.relinearize(prod, rkd))
+    for i in range(3):
+        assert (r3[i] == o.relinearize(o.multiply(a3[i], b3[i]), rk)).all(), i
+    g3 = to_host(ev.rotate_rows(to_device(a3), 1, GaloisKeys.from_arrays(ctx, gk)))
+    os.environ["HIPBFV_NO_SPLIT_KS"] = "1"
+    try:
+        ev_whole = BatchEvaluator(ctx)
+        assert torch_equal(ev_whole.relinearize(prod, rkd), r3)
+        assert torch_equal(ev_whole.rotate_rows(to_device(a3), 1, GaloisKeys.from_arrays(ctx, gk)), g3)
+    finally:
+        os.environ.pop("HIPBFV_NO_SPLIT_KS", None)
+
+
+def torch_equal(t, host):
+    from sunscreen_amd.batch import to_host
+
+    return bool((to_host(t) == host).all())
 
 
 def test_modulus_switching_chain():
