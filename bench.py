@@ -978,7 +978,8 @@ def main():
                 # that does not have that much free, say so instead of running out of memory with the headline unprinted
                 from oracle import bfv_oracle as O_
 
-                need = (sub.pir_rows or sub.batch) * sub.batch * (len(O_.bfv_default(sub.n)) - 1) * sub.n * 8 + (12 << 30)
+                # + the queries, the executor's chunk scratch for the row-side multiply + relinearize (~28 MB per row at n = 16384) and a margin
+                need = (sub.pir_rows or sub.batch) * sub.batch * (len(O_.bfv_default(sub.n)) - 1) * sub.n * 8 + (28 << 30)
                 free = torch.cuda.mem_get_info()[0]
                 if free < need:
                     second[key] = {"skipped": f"needs {need >> 30} GiB of device memory, {free >> 30} GiB free"}
@@ -998,6 +999,10 @@ def main():
                 second[key] = rec if args.full_line else compact_secondary(rec)
         if line is not None:
             line["secondary"] = second
+            # a job that was skipped (device memory) or failed is named here as well as under its key: a reader of the exit status and
+            # this one field knows whether every quantity of the metric was measured
+            line["skipped_jobs"] = sorted(k for k, v in second.items() if "value" not in v)
+            line["complete"] = not line["skipped_jobs"]
     if line is not None:
         # LAST key: the quantities BASELINE.json's metric names, one small object each (the driver keeps the tail of the line)
         line["summary"] = summary_of(line)

@@ -201,6 +201,9 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
   if (q >= (1ull << 50) || logn < 12 || logn > 15) return false;
   const double limit = 0.98 * 9007199254740992.0 / (double)q;
   const double pack_room = 0.98 * 140737488355328.0 / (double)q;  // 2^47 / q with the same margin
+  const bool packable = q < (1ull << 48);
+  static_assert(split_inv_passes(12) >= 1 && split_inv_passes(13) >= 1 && split_inv_passes(14) >= 1 && split_inv_passes(15) >= 1,
+                "the forced reduction below addresses the last inverse middle pass");
   const double eps = kTwEps * (double)q / 4503599627370496.0;
   double Mf = 1.0;
   {  // forward: head does head_log(logn) stages from canonical input, then the middle passes
@@ -210,7 +213,7 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
       if (M > limit) return false;
     }
     u32 mask = 0;
-    if (M > pack_room) mask |= kPlanStoreReduce;
+    if (packable && M > pack_room) mask |= kPlanStoreReduce;
     for (int p = 0; p < split_fwd_passes(logn); p++) {
       const int r = split_fwd_radix(logn, p);
       auto run = [&](double m, bool* ok) {
@@ -261,7 +264,9 @@ bool plan_f64_split(u64 q, int logn, u32* fwd_mask, u32* inv_mask) {
     for (int p = 0; p <= np; p++) {
       const bool tail = p == np;
       const int r = tail ? tail_log(logn) : split_inv_radix(logn, p);
-      if (tail && M > pack_room) {
+      // (only rows that CAN travel packed -- primes below 2^48 -- need their middle-kernel outputs inside the packed range; a wider
+      // prime's rows are 8-byte doubles in every configuration and keep whatever reductions the growth itself asks for: ADVICE r05)
+      if (tail && packable && M > pack_room) {
         // the middle kernel's outputs do not fit a packed row: reduce at the start of its last pass if that is not planned yet ...
         const int pl = np - 1;
         bool ok = true;

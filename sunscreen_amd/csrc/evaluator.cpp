@@ -233,13 +233,21 @@ Evaluator::Evaluator(Context* ctx) : ctx_(ctx) {
   // -> 332.2 K (4096); n = 16384, batch 2048, 1024 -> 2048 per chunk: 58.1 K -> 59.2 K -- fewer launch tails, as r03 found below 1024.
   size_t c = ((size_t)32 << 30) / per_op;
   if (const char* env = std::getenv("HIPBFV_CHUNK_OPS")) c = (size_t)std::strtoull(env, nullptr, 10);
-  chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 4096));
+  chunk_ops_ = std::max<size_t>(1, std::min<size_t>(c, 4096));  // <= 32 GiB of scratch AND <= 4096 ops (28 GiB at N = 8192, K = 4)
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_KS")) split_ks_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SPLIT_MUL")) split_mul_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_TAIL")) fuse_mulrelin_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_HEAD")) fuse_head_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_SMALL_BATCH")) small_batch_ = env[0] != '1';
   if (const char* env = std::getenv("HIPBFV_NO_FUSED_GALOIS")) fuse_galois_ = env[0] != '1';
+  {
+    // The coefficient-parallel split kernels address one batch item's rows through a buffer descriptor with a 32-bit offset
+    // (kernels_split.hip buf_row): every span they put under one descriptor -- T (KK * K rows), ext (4 R), D (3 R), ACC (2 KK) of ONE
+    // item -- must stay below 4 GiB.  63 MB at most today (N = 32768, K = 15); a context that ever exceeded it takes the
+    // whole-polynomial kernels instead of wrapping silently.
+    const size_t rows = std::max<size_t>(std::max<size_t>((size_t)h.KK * h.K, 4 * R), 2 * (size_t)h.KK);
+    if (rows * h.n * sizeof(u64) >= ((size_t)1 << 32)) split_ks_ = split_mul_ = false;
+  }
   if (hipMalloc((void**)&status_dev_, 256) == hipSuccess)
     (void)hipMemset(status_dev_, 0xFF, 256);
   else {
@@ -483,7 +491,7 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64*
     const size_t ext_words = (size_t)4 * R * n, d_words = (size_t)3 * R * n, t_words = (size_t)KK * K * n, acc_words = (size_t)2 * KK * n, c2_words = (size_t)K * n;
     const size_t per_op = ext_words + d_words + t_words + acc_words + c2_words;
     // every kernel of this path puts the ops on grid z and its residue / block count on grid x: no 65535 limit but z's, which
-    // the 1024-op cap of chunk_ops_ is far below (the limits of the whole-polynomial launches made N = 16384 run 910 + 114)
+    // the 4096-op cap of chunk_ops_ is far below (the limits of the whole-polynomial launches made N = 16384 run 910 + 114)
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535));
     KeyMapLease kl;
     if (int rc = stage_keymap(rk, count, chunk, s, kl)) return rc;

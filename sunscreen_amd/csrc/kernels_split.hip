@@ -487,8 +487,18 @@ constexpr int kHeadThreads = 256;
 // ks_mid: digits transformed together (4 or 2; LDS = that many exchange regions) and waves per SIMD the register
 // allocation aims at.  Pairs + 3 waves: -5.5 % at N = 8192, -11 % at N = 4096; at N = 16384 (32 KB regions, K = 8) groups
 // of four at 2 waves stay faster (+4 % the other way).
-#define KS_GROUP_MAX(L) ((L) <= 13 || HIPBFV_GEOM14 == 4 ? 2 : 4)
-#define KS_MID_WAVES(L) ((L) <= 13 ? 3 : 2)
+// (experiment hooks for N = 16384, tools/build_variant.sh: KS_GROUP_14 digits per group, KS_WAVES_14 waves per SIMD, KS_PIPE_14)
+#ifndef KS_GROUP_14
+#define KS_GROUP_14 (HIPBFV_GEOM14 == 4 ? 2 : 4)
+#endif
+#ifndef KS_WAVES_14
+#define KS_WAVES_14 2
+#endif
+#ifndef KS_PIPE_14
+#define KS_PIPE_14 true
+#endif
+#define KS_GROUP_MAX(L) ((L) <= 13 ? 2 : KS_GROUP_14)
+#define KS_MID_WAVES(L) ((L) <= 13 ? 3 : KS_WAVES_14)
 // r03, N = 16384: 16 elements per thread (256-thread workgroups) with the digits in PAIRS: 64 KB of LDS and 256 registers per
 // workgroup, two workgroups per CU whose load / compute / store phases overlap -- ks_mid 5.53 -> 5.29 ms per 1024 ops
 // (interleaved A/B; the first configuration with two resident workgroups that does not spill: two 512-thread workgroups would
@@ -496,7 +506,7 @@ constexpr int kHeadThreads = 256;
 // ks_mid (FP64 policy): elements per thread
 #define KS_EPT(L) ((L) == 14 && HIPBFV_GEOM14 == 4 ? 16 : kBlkEPT)
 // ks_mid: twiddles of the next pass fetched before the exchange (costs a second set of twiddle registers)
-#define KS_TW_PIPE(L) true
+#define KS_TW_PIPE(L) ((L) == 14 ? KS_PIPE_14 : true)
 // ks_mid: key words loaded per accumulation step (elements; 8 = a whole window at once)
 #define KS_MAC_CHUNK(L) 8
 

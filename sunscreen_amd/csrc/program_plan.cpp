@@ -648,12 +648,25 @@ struct TableArena {
     cap = want;
     return true;
   }
-  // the copies out of the arena are enqueued on `s`: mark their end
+  // the copies out of the arena are enqueued on `s`: mark their end.  The event belongs to the device it was created on: a host
+  // thread that drives evaluators on two devices gets a fresh one when the device changes.  If the event cannot be
+  // created or recorded the stream is drained instead -- the arena is then idle by construction, never "pending" with copies in flight.
+  int done_dev = -1;
   bool mark(hipStream_t s) {
-    if (!done && hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return false;
-    if (hipEventRecord(done, s) != hipSuccess) return false;
-    pending = true;
-    return true;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (done && dev != done_dev) {
+      (void)hipEventDestroy(done);
+      done = nullptr;
+    }
+    if (!done && hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess) done_dev = dev;
+    if (done && hipEventRecord(done, s) == hipSuccess) {
+      pending = true;
+      return true;
+    }
+    (void)hipGetLastError();
+    pending = false;
+    return hipStreamSynchronize(s) == hipSuccess;
   }
   ~TableArena() {
     (void)wait_idle();
@@ -1185,7 +1198,7 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
   for (void* t : temps) pool.release(t, s);
   // the descriptor tables were copied from this thread's pinned arena: an event behind the copies guards its reuse (two runs from
   // now: TableArenas) -- the run itself does not wait for the device
-  if (tables_used && !arena.mark(s)) return fail(kHipError, "event record failed");
+  if (tables_used && !arena.mark(s)) return fail(kHipError, "stream synchronisation failed");
   return kOk;
 }
 

@@ -172,8 +172,11 @@ def _replay_split_plan(q, logn, sfmask, simask):
     m = 1.0
     for _ in range(_head_log(logn)):
         m = mod.fwd_stage(m)
-    if not sfmask & PLAN_STORE_REDUCE:
+    packable = q < (1 << 48)  # rows of wider primes are 8-byte doubles in every configuration (context.cpp: pack_ks / pack_mul / per-row flags)
+    if packable and not sfmask & PLAN_STORE_REDUCE:
         assert m * q < PACK_RANGE, (q, logn, m)
+    if not packable:
+        assert not (sfmask | simask) & PLAN_STORE_REDUCE, (q, logn)  # r06: no packed-range reductions planned for rows that never pack
     for p, r in enumerate(_split_fwd_radices(logn)):
         m = mod.reduce_by_mask(m, sfmask, p)
         for _ in range(r):
@@ -188,7 +191,7 @@ def _replay_split_plan(q, logn, sfmask, simask):
         mi = mod.reduce_by_mask(mi, simask, p)
         for _ in range(r):
             mi = mod.inv_stage(mi)
-    if not simask & PLAN_STORE_REDUCE:
+    if packable and not simask & PLAN_STORE_REDUCE:
         assert mi * q < PACK_RANGE, (q, logn, mi)
     mi = mod.reduce_by_mask(mi, simask, 8)  # bit 8 / 24: at the start of the tail stages
     for _ in range(2):
