@@ -335,7 +335,13 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   if (sa < 2 || sb < 2 || sa + sb > 16) return kInvalidArg;
   if (h.logn > 15) return kUnsupported;
   const u32 n = h.n, K = h.K, S = h.S, R = K + S, sd = sa + sb - 1;
-  const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, 65535 / (R * (sa + sb))));
+  // the per-coefficient kernels are instantiated for KMAX data primes and KMAX + 2 auxiliary primes
+  const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
+  const bool split = split_mul_ && sa == 2 && sb == 2 && (kneed <= 4 || (kneed <= 8 && h.aux_f64)) && h.logn >= 12 && h.logn <= 14 &&
+                     !few_for_split_mul(count);
+  // (the split kernels put the items on grid z; only the whole-polynomial launches count residue polynomials on one grid axis.
+  // r06: the 3 x 54-bit multiply of 4096 items ran as 1820 + 1820 + 456 under the shared limit)
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(chunk_ops_, split ? 65535 : 65535 / (R * (sa + sb))));
   const size_t ext_words = (size_t)(sa + sb) * R * n, d_words = (size_t)sd * R * n;
   const size_t cc = std::min(chunk, count);  // a handle-level call (count = 1) reserves one op's scratch, not a chunk's
   ScratchGuard sg(pool_, cc * (ext_words + d_words) * sizeof(u64), s);
@@ -346,10 +352,6 @@ int Evaluator::multiply(const u64* a, u32 sa, const u64* b, u32 sb, u64* out, si
   for (u32 i = 0; i < K; i++) mods.push_back(i);
   for (u32 j = 0; j < S; j++) mods.push_back(h.KK + j);
   const NttPlan plan = make_plan(1, mods);
-  // the per-coefficient kernels are instantiated for KMAX data primes and KMAX + 2 auxiliary primes
-  const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
-  const bool split = split_mul_ && sa == 2 && sb == 2 && (kneed <= 4 || (kneed <= 8 && h.aux_f64)) && h.logn >= 12 && h.logn <= 14 &&
-                     !few_for_split_mul(count);
   // x * x (Evaluator_Square, a program node with one operand twice): the split kernels extend and transform x once
   const bool square = split && a == b;
   for (size_t off = 0; off < count; off += chunk) {

@@ -1743,6 +1743,47 @@ __device__ __forceinline__ void mul_mid_body_batched(const DevMod& dm, const typ
     load_poly(2);
     load_poly(3);
   }
+  if constexpr (SQUARE && MODE == 2) {
+    // r06: the squaring body of the 16-element geometry sequenced like MODE 3 -- a0^2 leaves (inverse transform, store) before
+    // 2 a0 a1 and a1^2 are formed, so the three products are never live beside both operands: the 48-bit packed instantiation
+    // no longer spills (94 scratch instructions before: the reason per-row packing lost on chi_sq, HISTORY.md R5).  Same sums,
+    // same transforms per polynomial: the bits of the batched form.
+    mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
+    auto store_one = [&](int i, typename A::V(&dv)[EPT]) {
+      typename A::V* dst = D_r + (size_t)i * dpoly_stride;
+      if constexpr (PACK && std::is_same<A, ArithD>::value) {
+        if (store_reduce) reduce_all<A, EPT>(ar, dv);
+      }
+#pragma unroll
+      for (int g = 0; g < Out::G; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << RI); k++) {
+          if constexpr (PACK && std::is_same<A, ArithD>::value)
+            nat_store<true, NtSites<L>::mul_mid_st>(dst, Sh::N, Out::elem(tid, blk, g, k), dv[g * (1 << RI) + k]);
+          else
+            nt_st<NtSites<L>::mul_mid_st>(dst + Out::elem(tid, blk, g, k), dv[g * (1 << RI) + k]);
+        }
+    };
+    {
+      typename A::V d0[1][EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; e++) d0[0][e] = ar.mul_var(v[0][e], v[0][e]);
+      __syncthreads();  // the pair's last forward pass may still be reading the exchange buffer
+      mid_inverse_multi<A, L, 1, EPT, MID_TW_PIPE(L)>(ar, d0, smem, tid, blk, opaque_uniform(twi), dm.split_inv_mask);
+      store_one(0, d0[0]);
+    }
+    typename A::V d12[2][EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      d12[0][e] = ar.mul_add(v[0][e], v[1][e], ar.mul_var(v[1][e], v[0][e]));
+      d12[1][e] = ar.mul_var(v[1][e], v[1][e]);
+    }
+    __syncthreads();
+    mid_inverse_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, d12, smem, tid, blk, opaque_uniform(twi), dm.split_inv_mask);
+    store_one(1, d12[0]);
+    store_one(2, d12[1]);
+    return;
+  }
   if constexpr (SQUARE) {
     mid_forward_multi<A, L, 2, EPT, MID_TW_PIPE(L)>(ar, *reinterpret_cast<Pair*>(&v[0]), smem, tid, blk, twf, dm.split_fwd_mask);
   } else if constexpr (MODE == 1) {
