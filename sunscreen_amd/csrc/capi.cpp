@@ -232,8 +232,8 @@ struct KeysObj : Obj {
 // operation's kernels occupy a few CUs for ~100 us; the runtime multiplexes the threads' streams onto a handful of hardware
 // queues: 5 -> 8-12 K multiply+relinearize/s from 1 -> 8 threads, fewer with 32).  Flat combining instead: a caller
 // that finds no operation of its evaluator in flight runs its own at once, exactly as before; callers arriving while one is in
-// flight queue up, and whoever finds the evaluator free next takes every queued request of one kind (same key, same Galois
-// element) and runs them as ONE batch through the batched kernels -- operands gathered into a staging batch and results
+// flight queue up, and whoever finds the evaluator free next takes every queued request of one kind (same Galois element; since
+// r06 the keys may differ: many clients, each with its own keys, on one evaluator) and runs them as ONE batch through the batched kernels -- operands gathered into a staging batch and results
 // scattered to the callers' buffers by two copy kernels that read a pointer table in pinned host memory, one transparent flag
 // per item, one stream synchronisation for all.  Batch items are independent: the bits do not depend on who was combined with whom.
 struct CombReq {
@@ -513,9 +513,31 @@ void combine_execute(EvalObj* e, const std::vector<CombReq*>& batch, hipStream_t
   }
   if (launch_gather_items(table->src, in_stage, in_words, c * nin, s) != hipSuccess) return all(kHipError);
   if (plain_op && launch_gather_items(table->src + c, pl_stage, pl_words, c, s) != hipSuccess) return all(kHipError);
+  // the batch's keys: one for all (the common case), or the distinct ones with each item's index (a per-item selection)
+  KeySel ksel(r0.key);
+  std::vector<const u64*> keys;
+  std::vector<u32> kidx;
+  if (r0.kind == 1 || r0.kind == 2) {
+    bool one = true;
+    for (const CombReq* r : batch) one = one && r->key == r0.key;
+    if (!one) {
+      kidx.resize(c);
+      for (size_t i = 0; i < c; i++) {
+        size_t k = 0;
+        while (k < keys.size() && keys[k] != batch[i]->key) k++;
+        if (k == keys.size()) keys.push_back(batch[i]->key);
+        kidx[i] = (u32)k;
+      }
+      ksel = KeySel();
+      ksel.keys = keys.data();
+      ksel.nkeys = (u32)keys.size();
+      ksel.index = kidx.data();
+      ksel.period = c;
+    }
+  }
   int st = r0.kind == 0 ? ev.multiply(in_stage, 2, in_stage + (squares ? 0 : c * in_words), 2, out_stage, c, s)
-         : r0.kind == 1 ? ev.relinearize(in_stage, r0.key, out_stage, c, s)
-         : r0.kind == 2 ? ev.apply_galois(in_stage, r0.elt, r0.key, out_stage, c, s)
+         : r0.kind == 1 ? ev.relinearize(in_stage, ksel, out_stage, c, s)
+         : r0.kind == 2 ? ev.apply_galois(in_stage, r0.elt, ksel, out_stage, c, s)
          : r0.kind == 5 ? ev.add_plain(in_stage, 2, pl_stage, pl_words, out_stage, c, s)
          : r0.kind == 6 ? ev.sub_plain(in_stage, 2, pl_stage, pl_words, out_stage, c, s)
                         : ev.multiply_plain(in_stage, 2, pl_stage, pl_words, out_stage, c, s);  // monomials included: same bits as the shortcut
@@ -543,7 +565,9 @@ int combine_run(EvalObj* e, CombReq& req, hipStream_t s) {
   }
   e->comb.run(
       req, kCombineLeaders, kCombineMax,
-      [](const CombReq& head, const CombReq& r) { return r.kind == head.kind && r.key == head.key && r.elt == head.elt; },
+      // r06: requests of one kind (and Galois element) combine ACROSS keys -- many clients' calls on one evaluator, each with its own
+      // keys (the reference passes them per call, run.rs:100-105), run as one per-key batch (Evaluator KeySel)
+      [](const CombReq& head, const CombReq& r) { return r.kind == head.kind && r.elt == head.elt; },
       [&](const std::vector<CombReq*>& batch) {
         try {
           combine_execute(e, batch, s);

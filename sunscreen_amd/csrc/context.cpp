@@ -730,12 +730,11 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     h.pack_mul = mul ? 1 : 0;
     // r04, per-row packing of the multiply's intermediates: every row FP64-policy and every AUXILIARY
     // prime below 2^48 (the library's own base always is); data rows pack when their prime is below 2^48.  The 8-prime head /
-    // tail instantiations take the per-row flags (kneed > 4).  OPT-IN (HIPBFV_PACK_ROWS=1), because it measured SLOWER on the
-    // configuration it was built for -- n = 16384, SEAL default primes, 13 of 18 rows packed, interleaved A/B on one box
-    // (profiles/r04_pack_rows_ab.txt): mul_mid 5.72 -> 5.54 ms per 1024 ops, but mul_head 2.69 -> 2.83, the fused key-switch
-    // head 2.29 -> 2.58 and tail 3.16 -> 3.26: 54.95 K -> 54.3 K mul+relin/s (chi_sq 9.52 K -> 9.39 K programs/s).  The rows that
-    // pack save 25 % of their bytes and cost a reduction + pack per stored value and a second load + unpack per loaded one; at
-    // this size the head / tail kernels run 2 waves per SIMD and are bound by their instruction streams, not by HBM.
+    // tail instantiations take the per-row flags (kneed > 4).  History: opt-in in r04 (slower then: the heads / tails paid more for
+    // the packing than the rows saved); r05's plan-aware stores made it +0.6 % on mul+relin but -1.8 % on chi_sq, whose packed
+    // SQUARING middle kernel spilt 94 instructions to scratch.  r06 sequenced that kernel like MODE 3 (no scratch) and it wins on
+    // every n = 16384 workload (interleaved, one box, profiles/r06_s9_ab_packrows.txt): mul+relin 59.05 -> 59.77 K ops/s (+1.2 %),
+    // chi_sq 10.36 -> 10.45 K programs/s (+0.8 %), dot_prod +0.2 % -- the DEFAULT since; HIPBFV_PACK_ROWS=0 restores 8-byte rows.
     const u32 kneed = std::max(K, h.S > 2 ? h.S - 2 : 0u);
     bool part = !mul && h.aux_f64 != 0 && h.logn >= 13 && kneed > 4;
     for (u32 r = 0; r < K + h.S && part; r++) {
@@ -745,7 +744,7 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     if (const char* env = std::getenv("HIPBFV_NO_PACK"))
       if (env[0] == '1' || env[0] == 'm') part = false;
     const char* rows_env = std::getenv("HIPBFV_PACK_ROWS");
-    if (part && rows_env && rows_env[0] == '1') h.pack_mul = 2;  // (the auxiliary rows alone are S of the K + S rows)
+    if (part && !(rows_env && rows_env[0] == '0')) h.pack_mul = 2;  // (the auxiliary rows alone are S of the K + S rows)
   }
   if (h.pack_mul == 2 && K + h.S > 32) return fail("internal: per-row packing covers at most 32 rows (DevCtx::mul_row_mask)");
   h.mid_nd = h.mid_ndp = h.mid_ni = 0;

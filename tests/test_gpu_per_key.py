@@ -234,3 +234,46 @@ def test_per_key_argument_errors():
         ev.multiply_relin_keys(da, da, [sets[0], foreign], np.array([0, 1, 0], dtype=np.uint32))
     # and the call still works afterwards
     ev.multiply_relin_keys(da, da, sets, np.array([0, 1, 0], dtype=np.uint32))
+
+
+def test_concurrent_clients_with_their_own_keys_on_one_evaluator():
+    """The drop-in shape of a multi-tenant server: host threads (sunscreen_runtime's rayon pool, run.rs:415-469) call ONE
+    evaluator's handle-level relinearize / rotate, each thread with its own client's keys.  Calls that meet in flight are
+    combined into one per-key batch (capi.cpp: requests of one kind combine across keys); every result must be the oracle's for
+    that client's key, whoever it was combined with."""
+    import threading
+
+    from sunscreen_amd import BFVEvaluator, Ciphertext
+
+    o, ctx, bev, ten = _tenants("default_4096_16", 6, galois=[3])
+    ev = BFVEvaluator(ctx)
+    rng = np.random.default_rng(66)
+    nthreads, iters = 6, 8
+    vals = rng.integers(0, 30, (nthreads, 2, o.n)).astype(np.uint64)
+    cts = [[o.encrypt(ten[i]["pk"], o.batch_encode(vals[i, j])) for j in range(2)] for i in range(nthreads)]
+    exp_relin = [o.relinearize(o.multiply(c[0], c[1]), ten[i]["rk"]) for i, c in enumerate(cts)]
+    exp_rot = [o.rotate_rows(c[0], 1, ten[i]["gk"]) for i, c in enumerate(cts)]
+    errors = []
+    start = threading.Barrier(nthreads)
+
+    def worker(i):
+        try:
+            a, b = Ciphertext.from_array(ctx, cts[i][0]), Ciphertext.from_array(ctx, cts[i][1])
+            start.wait()
+            for _ in range(iters):
+                m = ev.multiply(a, b)
+                ev.relinearize_inplace(m, ten[i]["rkd"])
+                if not (m.to_array() == exp_relin[i]).all():
+                    errors.append((i, "relinearize mismatch"))
+                r = ev.rotate_rows(a, 1, ten[i]["gkd"])
+                if not (r.to_array() == exp_rot[i]).all():
+                    errors.append((i, "rotation mismatch"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join()
+    assert not errors, errors

@@ -315,9 +315,9 @@ def test_multiply_around_the_grid_plan_limit(n, bits):
     ],
 )
 def test_per_row_packing_of_the_multiply_intermediates(n, bits, monkeypatch):
-    """r04: with data primes on both sides of 2^48 the split multiply can pack its intermediates PER ROW (HIPBFV_PACK_ROWS=1 ->
-    DevCtx::pack_mul == 2: the rows whose prime is below 2^48 travel as 6 bytes, the others as 8; opt-in -- it measured 1.2 % slower
-    at n = 16384, context.cpp).  The plain product, the fused multiply + relinearize and the squaring instantiations -- each reads
+    """r04: with data primes on both sides of 2^48 the split multiply packs its intermediates PER ROW (DevCtx::pack_mul == 2: the
+    rows whose prime is below 2^48 travel as 6 bytes, the others as 8; the default since r06, HIPBFV_PACK_ROWS=0 restores 8-byte
+    rows -- context.cpp).  The plain product, the fused multiply + relinearize and the squaring instantiations -- each reads
     and writes the mixed rows in its own kernels -- equal the oracle on random operands and at the edges of the BEHZ bounds, and the
     default context (8-byte rows throughout) gives the same bits."""
     import torch
@@ -342,7 +342,7 @@ def test_per_row_packing_of_the_multiply_intermediates(n, bits, monkeypatch):
     da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     got = {}
     monkeypatch.delenv("HIPBFV_NO_PACK", raising=False)
-    for tag, env in (("rows", "1"), ("bytes8", None)):
+    for tag, env in (("rows", None), ("bytes8", "0")):
         if env:
             monkeypatch.setenv("HIPBFV_PACK_ROWS", env)
         else:
@@ -350,7 +350,7 @@ def test_per_row_packing_of_the_multiply_intermediates(n, bits, monkeypatch):
         ctx = Context.from_raw(n, primes, t)  # the switch is read when the context is built
         ev = BatchEvaluator(ctx)
         ev.set_transparent_check(False)
-        assert ctx.aux_fp64 and ctx.packed_mul_rows == (env is not None) and (ctx.packed_mul == (env is not None)), (tag, ctx.packed_mul, ctx.packed_mul_rows)
+        assert ctx.aux_fp64 and ctx.packed_mul_rows == (env is None) and (ctx.packed_mul == (env is None)), (tag, ctx.packed_mul, ctx.packed_mul_rows)
         rkd = RelinearizationKeys.from_array(ctx, rk)
         got[tag] = [x.cpu().numpy().astype(np.uint64) for x in (ev.multiply(da, db), ev.multiply_relin(da, db, rkd), ev.multiply(da, da), ev.multiply_relin(db, db, rkd))]
     for x, y in zip(got["rows"], got["bytes8"]):

@@ -52,7 +52,11 @@ def _pick(kernels, pattern):
 HOT = (r"15mul_head_kernelILi13ELi4ELb1ELi1ELb[01]E", r"14mul_mid_kernelILi13ELb1ELb1ELb[01]E", r"20mulrelin_head_kernelILi13ELi4ELi1ELb0ELb1E",
        r"13ks_mid_kernelILi13ELb1ELi8E", r"20mulrelin_tail_kernelILi13ELi4ELi1ELb0ELb1E", r"14ks_head_kernelILi13ELb1ELb0E", r"14ks_tail_kernelILi13ELb1ELb0E",
        r"15mul_head_kernelILi14ELi8ELb1ELi0ELb0E", r"14mul_mid_kernelILi14ELb1ELb0ELb[01]E", r"20mulrelin_head_kernelILi14ELi8ELi0ELb1ELb0E",
-       r"13ks_mid_kernelILi14ELb0ELi16E", r"20mulrelin_tail_kernelILi14ELi8ELi0ELb1ELb0E", r"14ks_head_kernelILi14ELb0ELb0E", r"14ks_tail_kernelILi14ELb0ELb0E")
+       r"13ks_mid_kernelILi14ELb0ELi16E", r"20mulrelin_tail_kernelILi14ELi8ELi0ELb1ELb0E", r"14ks_head_kernelILi14ELb0ELb0E", r"14ks_tail_kernelILi14ELb0ELb0E",
+       # r06: n = 16384 packs the multiply's rows PER ROW by default (the rows whose prime is below 2^48): head / tail <.., PACK = 2, ..> and the
+       # packed middle instantiation beside the 8-byte one (its squaring form was the spilling kernel that kept this opt-in through r05)
+       r"15mul_head_kernelILi14ELi8ELb1ELi2ELb0E", r"14mul_mid_kernelILi14ELb1ELb1ELb[01]E", r"20mulrelin_head_kernelILi14ELi8ELi2ELb1ELb0E",
+       r"20mulrelin_tail_kernelILi14ELi8ELi2ELb1ELb0E")
 
 
 @pytest.mark.parametrize("pattern", HOT)
@@ -63,13 +67,12 @@ def test_hot_kernels_use_no_scratch_and_no_flat_memory_instructions(kernels, pat
 
 
 def test_the_known_spilling_instantiations_are_the_ones_no_default_set_launches(kernels):
-    """Which split kernels DO use scratch, so that a new one is noticed: the packed squaring middle kernel of n = 16384 (why per-row
-    packing stays opt-in: HISTORY.md R5), the packed 16-element key-switch middle kernel of n = 16384 (no default set has packed key
-    rows there) the integer middle kernel of n = 4096, and the integer key-switch middle kernel of n = 32768."""
+    """Which split kernels DO use scratch, so that a new one is noticed: the packed 16-element key-switch middle kernel of n = 16384 (no
+    default set has packed key rows there) the integer middle kernel of n = 4096, and the integer key-switch middle kernel of n = 32768."""
     spilling = sorted(k for k, ins in kernels.items() if re.search(r"mul_|ks_|mulrelin", k) and any(i.startswith("scratch_") for i in ins))
     # r06: + the integer key-switch middle kernel of n = 32768 (one 1024-thread workgroup per CU: 128 registers per lane; measured
     # against three variants that spill less or not at all -- all slower, kernels_split.hip KS_MID_INT_EPT15)
-    allowed = (r"13ks_mid_kernelILi14ELb1ELi16E", r"14mul_mid_kernelILi12ELb0ELb0ELb0E", r"14mul_mid_kernelILi14ELb1ELb1ELb1E", r"17ks_mid_int_kernelILi15ELi8E")
+    allowed = (r"13ks_mid_kernelILi14ELb1ELi16E", r"14mul_mid_kernelILi12ELb0ELb0ELb0E", r"17ks_mid_int_kernelILi15ELi8E")
     for k in spilling:
         assert any(re.search(a, k) for a in allowed), k
 
