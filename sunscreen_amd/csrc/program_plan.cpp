@@ -720,7 +720,21 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
   std::vector<int> block_of(P.nslots, -1);
   std::vector<char> direct_written(num_outputs_given, 0);
   std::vector<void*> temps;  // staging buffers released when the run ends (stream-ordered)
+  struct SideProduct {
+    const u64* base = nullptr;      // the product's output block (rows x batch ciphertexts)
+    size_t rows = 0;
+    std::vector<size_t> row_end;    // chunk c covers rows [row_end[c - 1], row_end[c])
+    std::vector<hipEvent_t> done;   // recorded on the side stream behind chunk c
+    bool noted = false;
+  } side;
   auto cleanup = [&](int code, const char* m) {
+    // (nothing of the side stream may still run when the run's buffers go back to the pool)
+    for (hipEvent_t e : side.done) {
+      (void)hipEventSynchronize(e);
+      (void)hipEventDestroy(e);
+    }
+    side.done.clear();
+    side.base = nullptr;
     for (Block& b : blocks)
       if (b.owned && b.refs > 0) pool.release(b.ptr, s);
     for (void* t : temps) pool.release(t, s);
@@ -927,10 +941,59 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
     return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
   };
   static const char* step_names[] = {"sum", "plain_matrix", "mul_relin", "multiply", "relinearize", "rotate", "plain_op", "output"};
+  // ---- r06: the plaintext-matrix product on a side stream (examples/pir) ----
+  // The product of a LinComb step streams the database at 6+ TB/s and hardly uses the vector units; the merged multiply +
+  // relinearize that consumes its rows is bound by them.  When that is the very next step, the product runs on a SIDE stream in
+  // row chunks and the main stream takes each chunk's rows through the multiply as soon as its event has passed: chunk c + 1 of
+  // the product streams while chunk c is multiplied (measured with the batch primitives in r05: +2...4 %, same bits --
+  // tools/pir_overlap_probe.py).  Anything else that follows waits for every chunk first (`side_flush`).
+  // OPT-IN (HIPBFV_PIR_OVERLAP=1, read per run): measured inside this executor it LOSES -- examples/pir, 512 x 256 entries at
+  // n = 16384, interleaved on one box (profiles/r06_s11_ab_pir_overlap*.txt): serial 3.93 M entries/s, 2 chunks 3.84 M, 4 chunks
+  // 3.75 M, 8 chunks 3.48 M.  The probe's +2...4 % was against a CHUNKED serial schedule; the executor's serial schedule is one
+  // 512-row product and one 512-member multiply, and next to a concurrent multiply the product stream slows down by more (22.2 ->
+  // 24.6 ms) than the multiply hides.  Kept exercised by tests/test_gpu_program.py.
+  const bool side_enabled = [] {
+    const char* e = std::getenv("HIPBFV_PIR_OVERLAP");
+    return e && e[0] == '1';
+  }();
+  auto side_stream = [&]() -> hipStream_t {
+    thread_local hipStream_t streams[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipStream_t& ss = streams[dev & 15];
+    if (!ss && hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) != hipSuccess) ss = nullptr;
+    return ss;
+  };
+  auto side_drop = [&]() {
+    for (hipEvent_t e : side.done) (void)hipEventDestroy(e);
+    side = SideProduct{};
+  };
+  // the main stream waits for every outstanding chunk (a consumer other than the pipelined multiply, or the end of the run)
+  auto side_flush = [&]() -> int {
+    if (!side.base) return kOk;
+    int rc2 = kOk;
+    for (hipEvent_t e : side.done)
+      if (hipStreamWaitEvent(s, e, 0) != hipSuccess) rc2 = kHipError;
+    if (!rc2 && !side.noted) rc2 = ev.note_result(side.base, 2, (u32)K, side.rows * batch, s);
+    side_drop();
+    return rc2;
+  };
   for (size_t si = 0; si < P.steps.size(); si++) {
     const Plan::Step& st = P.steps[si];
     const size_t members = st.node.size();
     int rc = kOk;
+    // the one consumer that takes the side product chunk by chunk: a merged multiply + relinearize right behind it (below)
+    bool side_consumer = side.base && st.kind == kStepMulRelin && small && members > 1 && members == side.rows && !st.square;
+    if (side_consumer) {  // member m's left (or right) operand is row m of the product, in place
+      bool as_a = true, as_b = true;
+      for (size_t m = 0; m < members; m++) {
+        as_a = as_a && sp[st.a[m]] == side.base + m * batch * 2 * poly;
+        as_b = as_b && sp[st.b[m]] == side.base + m * batch * 2 * poly;
+      }
+      side_consumer = as_a || as_b;
+    }
+    if (side.base && !side_consumer)
+      if ((rc = side_flush())) return cleanup(rc, "operation failed");
     const double t_begin = trace ? now_us() : 0.0;
     struct TraceEnd {
       bool on;
@@ -1045,6 +1108,23 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
           u64* out = (u64*)blocks[blk].ptr;
           for (size_t m = 0; m < members; m++) bind(st.out[m], blk, out + m * out_words);
           const size_t count = members * batch;
+          if (side_consumer && is_mul) {
+            // rows of the side-stream product, chunk by chunk: the main stream waits for chunk c's event only, so the product's
+            // later chunks stream while this one is multiplied
+            size_t r0 = 0;
+            for (size_t c = 0; c < side.done.size() && !rc; c++) {
+              const size_t r1 = side.row_end[c];
+              if (hipStreamWaitEvent(s, side.done[c], 0) != hipSuccess) rc = kHipError;
+              KeySel sub = relin_key;
+              sub.first = relin_key.first + r0 * batch;
+              if (!rc) rc = ev.multiply_relin(A + r0 * batch * 2 * poly, B2 + r0 * batch * 2 * poly, sub, out + r0 * batch * 2 * poly, (r1 - r0) * batch, s);
+              r0 = r1;
+            }
+            if (!rc) rc = ev.note_result(side.base, 2, (u32)K, side.rows * batch, s);
+            side.noted = true;
+            side_drop();
+            break;
+          }
           rc = is_mul ? ev.multiply_relin(A, st.square ? A : B2, relin_key, out, count, s)
              : is_rot ? ev.apply_galois(A, elt, gkey, out, count, s)
                       : ev.relinearize(A, relin_key, out, count, s);
@@ -1177,6 +1257,45 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
         if (blk < 0) return cleanup(kOutOfMemory, "out of device memory");
         u64* out = (u64*)blocks[blk].ptr;
         for (size_t m = 0; m < rows; m++) bind(st.out[m], blk, out + m * ct_words);
+        {
+          // on the side stream, in row chunks, when the next step is the merged multiply + relinearize of these rows
+          bool pipelined = false;
+          if (side_enabled && small && rows >= 64 && si + 1 < P.steps.size()) {
+            const Plan::Step& nx = P.steps[si + 1];
+            bool consumes = nx.kind == kStepMulRelin && nx.node.size() == rows && !nx.square;
+            if (consumes) {  // member m of the multiply takes row m of this product, as its left or its right operand, rows in order
+              bool as_a = true, as_b = true;
+              for (size_t m = 0; m < rows; m++) as_a = as_a && nx.a[m] == st.out[m], as_b = as_b && nx.b[m] == st.out[m];
+              consumes = as_a || as_b;
+            }
+            hipStream_t ss = consumes ? side_stream() : nullptr;
+            if (ss) {
+              const size_t kChunks = [] { const char* e = std::getenv("HIPBFV_PIR_CHUNKS"); const long v = e ? atol(e) : 2; return (size_t)(v >= 1 && v <= 64 ? v : 2); }();
+              hipEvent_t ready = nullptr;
+              bool ok = hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess && hipEventRecord(ready, s) == hipSuccess &&
+                        hipStreamWaitEvent(ss, ready, 0) == hipSuccess;  // the staged ciphertexts and the table were enqueued on `s`
+              if (ready) (void)hipEventDestroy(ready);
+              if (ok) {
+                side.base = out;
+                side.rows = rows;
+                for (size_t c = 0; c < kChunks && ok; c++) {
+                  const size_t r0 = rows * c / kChunks, r1 = rows * (c + 1) / kChunks;
+                  if ((rc = ev.dot_plain_tab(staged, (u32)cols, dtab + r0 * cols, (u32)(r1 - r0), (u32)batch, out + r0 * ct_words, ss))) break;
+                  hipEvent_t e = nullptr;
+                  ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess && hipEventRecord(e, ss) == hipSuccess;
+                  if (e) side.done.push_back(e);
+                  side.row_end.push_back(r1);
+                }
+                if (rc || !ok) {  // launched chunks finish on the side stream; wait for them here and fail the run
+                  (void)hipStreamSynchronize(ss);
+                  return cleanup(rc ? rc : (int)kHipError, "operation failed");
+                }
+                pipelined = true;
+              }
+            }
+          }
+          if (pipelined) break;
+        }
         if ((rc = ev.dot_plain_tab(staged, (u32)cols, dtab, (u32)rows, (u32)batch, out, s))) return cleanup(rc, "operation failed");
         rc = ev.note_result(out, 2, (u32)K, rows * batch, s);
         break;
@@ -1193,6 +1312,7 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
     if (rc) return cleanup(rc, st.kind == kStepMulRelin ? "multiply+relinearize failed" : "operation failed");
     for (int sl : st.release) unbind(sl);
   }
+  if (int rc2 = side_flush()) return cleanup(rc2, "operation failed");
   for (Block& b : blocks)
     if (b.owned && b.refs > 0) pool.release(b.ptr, s);
   for (void* t : temps) pool.release(t, s);

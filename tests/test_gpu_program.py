@@ -351,6 +351,40 @@ def test_whole_pir_lookup_graph_through_the_scheduled_executor():
     assert (to_host(out3)[0] == ref).all()
 
 
+def test_pir_lookup_with_the_product_on_a_side_stream(monkeypatch):
+    """HIPBFV_PIR_OVERLAP=1 (opt-in: measured slower inside the executor, program_plan.cpp): the plaintext-matrix product of a
+    lookup with >= 64 rows runs on a side stream in row chunks and the merged multiply + relinearize takes each chunk behind its
+    event.  Same bits as the serial schedule and as the oracle's node-by-node evaluation; one input set, 3 and 4
+    chunks (64 rows: 21 + 21 + 22 and 4 x 16)."""
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.program import FheProgram, TransformedPlaintext
+    from sunscreen_amd.workloads import pir_lookup_graph
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_4096_16")
+    rows, cols = 64, 3
+    prog = FheProgram.from_json(pir_lookup_graph(rows, cols).to_json())
+    rng = np.random.default_rng(64)
+    vals = rng.integers(1, 1000, (rows, cols))
+    db = np.stack([np.stack([_scalar(o, int(vals[i, j])) for j in range(cols)]) for i in range(rows)])
+    sel_r, sel_c = 41, 2
+    cq = np.stack([o.encrypt(pk, _scalar(o, 1 if j == sel_c else 0)) for j in range(cols)])
+    rq = np.stack([o.encrypt(pk, _scalar(o, 1 if i == sel_r else 0)) for i in range(rows)])
+    host_args = [cq[j] for j in range(cols)] + [rq[i] for i in range(rows)] + [db[i, j] for i in range(rows) for j in range(cols)]
+    (ref,) = run_program(o, prog.nodes, prog.edges, host_args, rk)
+    assert int(o.decrypt(ref, sk)[0]) == int(vals[sel_r, sel_c])
+    dcq, drq = to_device(cq), to_device(rq)
+    dbn = ev.plain_to_ntt(to_device(db))
+    args = [dcq[j : j + 1] for j in range(cols)] + [drq[i : i + 1] for i in range(rows)] + [TransformedPlaintext(dbn[i, j]) for i in range(rows) for j in range(cols)]
+    (serial,) = prog.run(ev, args, rkd)
+    assert (to_host(serial)[0] == ref).all()
+    monkeypatch.setenv("HIPBFV_PIR_OVERLAP", "1")
+    for chunks in ("3", "4"):
+        monkeypatch.setenv("HIPBFV_PIR_CHUNKS", chunks)
+        for _ in range(2):
+            (out,) = prog.run(ev, args, rkd)
+            assert (to_host(out)[0] == ref).all(), chunks
+
+
 def test_zero_plaintext_inside_a_transform_domain_sum_fails_like_multiply_plain():
     """sunscreen/tests/features.rs:8-34: a * 0 is an error.  Inside a sum of products that stays in the transform domain the single
     product never exists, so the zero plaintext itself must raise the failure -- and name the input set."""
