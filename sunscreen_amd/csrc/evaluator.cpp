@@ -1,5 +1,6 @@
 // sunscreen_amd/csrc/evaluator.cpp -- see evaluator.hpp.
 #include "evaluator.hpp"
+#include "nttshape.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -486,8 +487,13 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64*
   const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
   // Fused pipeline (all-FP64 contexts: every SEAL default set up to N = 16384): six launches; the product's c0 and c1 are
   // formed inside the last one (mulrelin_tail_kernel) and only c2 -- the key-switch target -- is written by mul_tail.
-  const bool fused = fuse_mulrelin_ && split_mul_ && split_ks_ && h.aux_f64 && h.ks_split_ok && h.ks_ni == 0 && kneed <= 8 && h.logn >= 12 && h.logn <= 14 &&
-                     !few_for_fused(count);
+  const bool fused_d = fuse_mulrelin_ && split_mul_ && split_ks_ && h.aux_f64 && h.ks_split_ok && h.ks_ni == 0 && kneed <= 8 && h.logn >= 12 && h.logn <= 14 &&
+                       !few_for_fused(count);
+  // r06: the same five launches for MIXED contexts (integer-policy data / key primes beside the library's FP64 auxiliary base: the
+  // 3 x 54-bit set): mulrelin_head_mixed / mulrelin_tail_mixed, 8-byte rows, one or two middle launches per policy
+  const bool fused_m = !fused_d && fuse_mulrelin_ && fuse_head_ && split_mul_ && split_ks_ && !h.aux_f64 && h.aux_mixed && h.ks_split_ok && kneed <= 4 &&
+                       h.logn >= 12 && h.logn <= 14 && !lane_split((int)h.logn) && !few_for_fused(count);
+  const bool fused = fused_d || fused_m;
   const bool square = fused && a == b;  // x * x: the head extends and the middle kernel transforms x once
   if (fused) {
     const size_t ext_words = (size_t)4 * R * n, d_words = (size_t)3 * R * n, t_words = (size_t)KK * K * n, acc_words = (size_t)2 * KK * n, c2_words = (size_t)K * n;
@@ -507,6 +513,14 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64*
     u64* C2 = ACC + cc * acc_words;
     for (size_t off = 0; off < count; off += chunk) {
       const size_t c = std::min(chunk, count - off);
+      if (fused_m) {
+        HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, false, 1, kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u));
+        HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_dp, h.mid_ndp, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
+        HB_LAUNCH(kKernKsHead, c, launch_mulrelin_head_mixed(ctx_->dev(), h.tw_inv, h.tw_fwd, h.logn, D, T, c, s));
+        HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, false, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, rk.key, ACC, c, s, kl.at(off)));
+        HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail_mixed(ctx_->dev(), h.tw_inv, h.logn, D, ACC, addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s));
+        continue;
+      }
       HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, (int)h.pack_mul | (h.conv_grid == 1 ? 4 : 0), kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u));
       HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_dp, h.mid_ndp, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
       if (fuse_head_) {

@@ -73,6 +73,10 @@ hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp
                                 const u64* D, u64* T, size_t ops, hipStream_t s);
 hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
                                 const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s);
+// the same two kernels for MIXED contexts (integer-policy data / key primes + the FP64 auxiliary base, K <= 4)
+hipError_t launch_mulrelin_head_mixed(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, const u64* D, u64* T, size_t ops, hipStream_t s);
+hipError_t launch_mulrelin_tail_mixed(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* D, const u64* ACC, const u64* extra, u64* out2, size_t ops,
+                                      hipStream_t s);
 hipError_t launch_ks_moddown(const DevCtx* ctx, u32 n, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out,
                              size_t ops, hipStream_t s);
 hipError_t launch_mod_switch(const DevCtx* ctx, u32 n, const u64* in, u64* out, size_t polys, hipStream_t s);

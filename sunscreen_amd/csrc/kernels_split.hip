@@ -2055,6 +2055,66 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
       res);
 }
 
+// The MIXED tail (integer-policy data primes, the library's FP64 auxiliary base: the 3 x 54-bit set) for the 4 coefficients
+// {t + k*N/4} of ONE output polynomial, results in registers: res[k][i] = canonical residue i of coefficient slot k.  What
+// mul_tail_kernel's mixed instantiation stores, and what the fused mixed kernels below compute on [r06].
+template <int L, int KMAX>
+__device__ __forceinline__ void mul_tail_compute_mixed(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base, const u64* __restrict__ d, u32 t,
+                                                       u64 (&res)[4][KMAX]) {
+  constexpr u32 N = 1u << L;
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK;
+  u64 y[4][KMAX], xb[4][KMAX + 2];
+  const u32 last_row = K + S - 1;
+  const BufRsrc rd = buf_rsrc(d);  // buffer addressing: see BufRow
+  u64 cur[4], nxt[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) cur[k] = ld_tail_in<L>(buf_row(rd, 0), t, k);
+#pragma unroll
+  for (int i = 0; i < KMAX; i++) {
+    {
+      const u32 nr = (u32)i + 1 < K ? (u32)i + 1 : K;  // after the last data row: the first auxiliary row
+      const BufRow next_row = buf_row(rd, (size_t)(nr < last_row ? nr : last_row) * N);
+#pragma unroll
+      for (int k = 0; k < 4; k++) nxt[k] = ld_tail_in<L>(next_row, t, k);
+    }
+    if ((u32)i < K) {
+      const DevMod& dm = ctx->mod[i];
+      u64 r4[4];
+      if (residue_is_f64(dm)) {
+        const ArithD ar(dm);
+        tail_inv4_scale_raw<ArithD, L>(ar, cur, t, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, r4);
+      } else {
+        const ArithI ar(dm);
+        tail_inv4_scale_raw<ArithI, L>(ar, cur, t, twi_base + (size_t)i * N, ctx->intt_scale_q[i], 0u, r4);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) y[k][i] = r4[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) cur[k] = nxt[k];  // (rows i >= K keep `cur`: it already holds the first auxiliary row)
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KMAX + 2; j++) {
+    {
+      const u32 nr = K + (u32)j + 1;
+      const BufRow next_row = buf_row(rd, (size_t)(nr < last_row ? nr : last_row) * N);
+#pragma unroll
+      for (int k = 0; k < 4; k++) nxt[k] = ld_tail_in<L>(next_row, t, k);
+    }
+    if ((u32)j < S) {
+      const DevMod& dm = ctx->mod[KK + j];
+      u64 r4[4];
+      const ArithD ar(dm);  // the auxiliary rows come back from the FP64 middle kernel as doubles
+      tail_inv4_scale_raw<ArithD, L>(ar, cur, t, reinterpret_cast<const double*>(twi_base + (size_t)(KK + j) * N), ctx->intt_scale_bsk_d[j], dm.split_inv_mask, r4);
+#pragma unroll
+      for (int k = 0; k < 4; k++) xb[k][j] = r4[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+  }
+  behz_floor_sk_coeff_mixed<KMAX, 4>(ctx, y, xb, res);
+}
+
 template <int L, int KMAX, bool AUXD, int PACK, bool GRID>
 // poly0 / out_polys: the launch covers product polynomials poly0 .. poly0 + gridDim.y - 1 and writes them to
 // out[op][out_polys][K][N] (3 polynomials from 0 for a stand-alone multiply; only c2, compactly, in the fused
@@ -2081,6 +2141,17 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
     return;
   }
   constexpr bool mixed = !AUXD && PACK;  // the MIXED instantiation: integer data primes, FP64 auxiliary primes, Bsk-side sums in exact FP64
+  if constexpr (mixed && TAIL_MIXED_NC == 4) {
+    u64 res[4][KMAX];
+    mul_tail_compute_mixed<L, KMAX>(ctx, twi_base, d, t, res);
+    const BufRsrc rres = buf_rsrc(o);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int i = 0; i < KMAX; i++)
+        if ((u32)i < K) st_tail_out<L>(buf_row(rres, (size_t)i * N), t, k, res[k][i]);
+    return;
+  }
   u64 y[4][KMAX], xb[4][KMAX + 2];
   // The K + S rows of D are visited in order; the four words of the NEXT row are requested (branch-free: beyond the last row the
   // last row is re-read) before the current row is transformed (r04: each row used to load, wait and compute in its own block).
@@ -2317,6 +2388,154 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_head_kernel(const DevCtx* __restrict_
       }
       nat_store_head<L, PACKK, NtSites<L>::ks_head_st>(buf_row(rout, ((size_t)I * K + J) * N), t, v);
     }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// multiply + relinearize for MIXED contexts (integer-policy data / key primes, FP64 auxiliary base: the north star's
+// 3 x 54-bit set) [r06]: the two fused kernels above with the mixed tail (mul_tail_compute_mixed) and the MIXED arms of
+// ks_head_kernel / ks_tail_kernel -- c0, c1, c2 of the product stay in registers here too (1.5 MB of HBM traffic per op at N = 8192).
+// grid: head (N/NC/256, 1, ops), tail (N/4/256, 2, ops); 8-byte rows throughout.
+// -------------------------------------------------------------------------------------------------
+#ifndef MRH_MIXED_WAVES
+#define MRH_MIXED_WAVES 2
+#endif
+template <int L, int KMAX>
+__global__ __launch_bounds__(kHeadThreads, MRH_MIXED_WAVES) void mulrelin_head_mixed_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+                                                                           const MulOp* __restrict__ twf_base, const u64* __restrict__ D,
+                                                                           double* __restrict__ T) {
+  using G = EdgeGeom<L>;
+  constexpr int NC = G::HEAD_NC;
+  static_assert(!G::SPLIT, "lane-split degrees have no mixed instantiation");
+  constexpr int GROUPS = NC / 4;
+  constexpr u32 N = 1u << L;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 op = blockIdx.z;
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
+  const BufRsrc rout = buf_rsrc(T + (size_t)op * KK * K * N);
+  u64 x[KMAX][NC];  // c2's residues = the key-switch digits (canonical)
+  auto group = [&](auto h_tag) {  // (a compile-time group index: a rolled loop would index x dynamically -- scratch)
+    constexpr int h = decltype(h_tag)::value;
+    const u32 tt = t + (u32)h * (N / NC);
+    u64 res[4][KMAX];
+    mul_tail_compute_mixed<L, KMAX>(ctx, twi_base, D + ((size_t)op * 3 + 2) * R * N, tt, res);
+#pragma unroll
+    for (int J = 0; J < KMAX; J++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[J][GROUPS * k + h] = res[k][J];
+  };
+  group(std::integral_constant<int, 0>{});
+  if constexpr (GROUPS > 1) group(std::integral_constant<int, 1>{});
+  static_assert(GROUPS <= 2, "a head thread owns 4 or 8 coefficients");
+#pragma unroll
+  for (int J = 0; J < KMAX; J++) {
+    if ((u32)J >= K) break;
+    const u64 qJ = ctx->mod[J].q;
+    for (u32 I = 0; I < KK; I++) {  // exactly ks_head_kernel<L, false, true>
+      const DevMod& dm = ctx->mod[I];
+      if (!residue_is_f64(dm)) {
+        const ArithI ai(dm);
+        const bool shrink = qJ > dm.q;
+        u64 w[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) w[k] = shrink ? reduce64(x[J][k], dm) : x[J][k];
+        head_fwd_owned<ArithI, L>(ai, w, twf_base + (size_t)I * N, t);
+#pragma unroll
+        for (int k = 0; k < NC; k++) st_head_out<L>(buf_row(rout, ((size_t)I * K + J) * N), t, k, w[k]);
+        continue;
+      }
+      const ArithD ar(dm);
+      const bool need_reduce = qJ > dm.q;
+      double v[NC];
+#pragma unroll
+      for (int k = 0; k < NC; k++) v[k] = ar.from_u64(need_reduce ? reduce64(x[J][k], dm) : x[J][k]);
+      head_fwd_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(twf_base + (size_t)I * N), t);
+      nat_store_head<L, false, NtSites<L>::ks_head_st>(buf_row(rout, ((size_t)I * K + J) * N), t, v);
+    }
+  }
+}
+
+template <int L, int KMAX>
+__global__ __launch_bounds__(kHeadThreads) void mulrelin_tail_mixed_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
+                                                                           const u64* __restrict__ D, const double* __restrict__ ACC,
+                                                                           const u64* __restrict__ extra, u64* __restrict__ out) {
+  constexpr u32 N = 1u << L;
+  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
+  const u32 c = blockIdx.y, op = blockIdx.z;
+  const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
+  u64 basev[4][KMAX];  // c0 / c1 of the product, canonical
+  mul_tail_compute_mixed<L, KMAX>(ctx, twi_base, D + ((size_t)op * 3 + c) * R * N, t, basev);
+  const double* acc = ACC + ((size_t)op * 2 + c) * KK * N;
+  const BufRsrc racc = buf_rsrc(acc), rout = buf_rsrc(out + ((size_t)op * 2 + c) * K * N);
+  const BufRsrc rex = buf_rsrc_opt(extra + ((size_t)op * 2 + c) * K * N, extra != nullptr);
+  // from here: the MIXED arm of ks_tail_kernel with the base ciphertext in registers
+  u64 tl[4];
+  {
+    const DevMod& sp = ctx->mod[KK - 1];
+    if (!residue_is_f64(sp)) {
+      const ArithI ai(sp);
+      u64 w[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) w[k] = ld_tail_in<L>(buf_row(racc, (size_t)(KK - 1) * N), t, k);
+      tail_inv_owned<ArithI, L>(ai, w, twi_base + (size_t)(KK - 1) * N, 0u, t);
+#pragma unroll
+      for (int k = 0; k < 4; k++) tl[k] = add_mod(ai.scale_canonical(w[k], sp.ninv), ctx->qsp_half, sp.q);
+    } else {
+      const ArithD ar(sp);
+      double v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = __longlong_as_double((long long)ld_tail_in<L>(buf_row(racc, (size_t)(KK - 1) * N), t, k));
+      tail_inv_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(twi_base + (size_t)(KK - 1) * N), sp.split_inv_mask, t);
+#pragma unroll
+      for (int k = 0; k < 4; k++) tl[k] = add_mod(ar.scale_canonical(v[k], sp.ninv_d), ctx->qsp_half, sp.q);
+    }
+  }
+  const u64 qsp = ctx->mod[KK - 1].q;
+  u64 cur[4], nxt[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) cur[k] = ld_tail_in<L>(buf_row(racc, 0), t, k);
+#pragma unroll
+  for (int J = 0; J < KMAX; J++) {
+    if (J + 1 < KMAX) {
+      const BufRow next_row = buf_row(racc, (size_t)((u32)(J + 1) < K ? (u32)(J + 1) : K - 1) * N);
+#pragma unroll
+      for (int k = 0; k < 4; k++) nxt[k] = ld_tail_in<L>(next_row, t, k);
+    }
+    if ((u32)J < K) {
+      const DevMod& mj = ctx->mod[J];
+      u64 ex[4];  // (an absent addend: a descriptor of zero records, the loads return 0)
+#pragma unroll
+      for (int k = 0; k < 4; k++) ex[k] = ld_tail_out<L>(buf_row(rex, (size_t)J * N), t, k);
+      u64 av[4];
+      if (!residue_is_f64(mj)) {
+        const ArithI ai(mj);
+        u64 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = cur[k];
+        tail_inv_owned<ArithI, L>(ai, w, twi_base + (size_t)J * N, 0u, t);
+#pragma unroll
+        for (int k = 0; k < 4; k++) av[k] = ai.scale_canonical(w[k], mj.ninv);
+      } else {
+        const ArithD ar(mj);
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = __longlong_as_double((long long)cur[k]);
+        tail_inv_owned<ArithD, L>(ar, v, reinterpret_cast<const double*>(twi_base + (size_t)J * N), mj.split_inv_mask, t);
+#pragma unroll
+        for (int k = 0; k < 4; k++) av[k] = ar.scale_canonical(v[k], mj.ninv_d);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        u64 tk = qsp > mj.q ? reduce64(tl[k], mj) : tl[k];
+        tk = sub_mod(tk, ctx->qsp_half_mod_q[J], mj.q);
+        u64 dd = sub_mod(av[k], tk, mj.q);
+        dd = mul_shoup(dd, ctx->inv_qsp_mod_q[J], mj.q);
+        const u64 bv = add_mod(basev[k][J], ex[k], mj.q);  // the product's c0 / c1 + a fused Add node's (absent: 0)
+        st_tail_out<L>(buf_row(rout, (size_t)J * N), t, k, add_mod(bv, dd, mj.q));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = nxt[k];
   }
 }
 
@@ -2725,6 +2944,35 @@ hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp
 }
 
 // the last kernel of the fused multiply + relinearize of all-FP64 contexts (DevCtx::aux_f64, every key prime FP64-policy)
+template <int L>
+static hipError_t mulrelin_head_mixed_t(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, const u64* D, u64* T, size_t ops, hipStream_t s) {
+  if constexpr (EdgeGeom<L>::SPLIT) {
+    return hipErrorInvalidValue;
+  } else {
+    const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, 1, (unsigned)ops);
+    mulrelin_head_mixed_kernel<L, 4><<<grid, kHeadThreads, 0, s>>>(ctx, twi, twf, D, reinterpret_cast<double*>(T));
+    return hipGetLastError();
+  }
+}
+template <int L>
+static hipError_t mulrelin_tail_mixed_t(const DevCtx* ctx, const MulOp* twi, const u64* D, const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s) {
+  if constexpr (EdgeGeom<L>::SPLIT) {
+    return hipErrorInvalidValue;
+  } else {
+    const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
+    mulrelin_tail_mixed_kernel<L, 4><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, reinterpret_cast<const double*>(ACC), extra, out2);
+    return hipGetLastError();
+  }
+}
+// the mixed forms (DevCtx::aux_mixed, K <= 4 data primes): 8-byte rows of either policy in D, T and ACC
+hipError_t launch_mulrelin_head_mixed(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, const u64* D, u64* T, size_t ops, hipStream_t s) {
+  SPLIT_DISPATCH(mulrelin_head_mixed_t, ctx, twi, twf, D, T, ops, s)
+}
+hipError_t launch_mulrelin_tail_mixed(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* D, const u64* ACC, const u64* extra, u64* out2, size_t ops,
+                                      hipStream_t s) {
+  SPLIT_DISPATCH(mulrelin_tail_mixed_t, ctx, twi, D, ACC, extra, out2, ops, s)
+}
+
 hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
                                 const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s) {
   SPLIT_DISPATCH(mulrelin_tail_t, ctx, twi, pack_mul, conv_grid, pack_ks, kneed, D, ACC, extra, out2, ops, s)
