@@ -908,6 +908,7 @@ def measure(args, env: Env, secondary: bool = False):
         "kernel_units_per_launch": {k: v["units"] / v["launches"] for k, v in prof.items()},
         "cpu_baseline": cpu,
         "parity": parity,
+        "kernel_source_hash": kernel_source_hash(),  # the sources this line (and the PMC file it may quote) was measured on
     }
     if power:
         line["power"] = power

@@ -2018,28 +2018,56 @@ __device__ __forceinline__ void mul_tail_compute_d(const DevCtx* __restrict__ ct
       for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
   } else {
+    // per-row packing (r06: the default at N = 16384): the same look-ahead as above -- row i + 1 requested before row i is
+    // transformed -- on a raw form that serves both representations: two dwords per value, the packed row's (u32, biased u16)
+    // or the 8-byte row's (low, high) halves; which one a row is, is wave-uniform (DevCtx::mul_row_mask).  r05 had no
+    // look-ahead in this arm: every row loaded, waited and computed in turn, and the packed tail ran 8 % slower than the 8-byte one.
+    struct RawU {
+      u32 lo, hi;
+    };
+    const u32 rmask = ctx->mul_row_mask;
+    auto fetch_u = [&](u32 row, RawU(&r)[4]) {
+      const BufRow br = buf_row(rd, (size_t)row * N);
+      if ((rmask >> row) & 1u) {
 #pragma unroll
-  for (int i = 0; i < KMAX; i++) {
-    if ((u32)i < K) {
-      const DevMod& dm = ctx->mod[i];
-      const ArithD ar(dm);
-      const BufRow row = buf_row(rd, (size_t)i * N);
-      double r4[4];
-      if (((ctx->mul_row_mask >> i) & 1u) != 0) {  // wave-uniform
-        NatRaw<true> raw[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) raw[k] = nat_fetch_tail<L, true, NtSites<L>::tail_ld>(row, t, k);
-        tail_inv4_scale_d<L, true>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+        for (int k = 0; k < 4; k++) {
+          const NatRaw<true> x = nat_fetch_tail<L, true, NtSites<L>::tail_ld>(br, t, k);
+          r[k].lo = x.lo, r[k].hi = x.hi;
+        }
       } else {
-        NatRaw<false> raw[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) raw[k] = nat_fetch_tail<L, false, NtSites<L>::tail_ld>(row, t, k);
-        tail_inv4_scale_d<L, false>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+        for (int k = 0; k < 4; k++) {
+          const NatRaw<false> x = nat_fetch_tail<L, false, NtSites<L>::tail_ld>(br, t, k);
+          r[k].lo = (u32)__double2loint(x.d), r[k].hi = (u32)__double2hiint(x.d);
+        }
+      }
+    };
+    RawU cur[4], nxt[4];
+    fetch_u(0u, cur);
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+      if (i + 1 < KMAX) fetch_u((u32)(i + 1) < K ? (u32)(i + 1) : K - 1, nxt);
+      if ((u32)i < K) {
+        const DevMod& dm = ctx->mod[i];
+        const ArithD ar(dm);
+        double r4[4];
+        if (((rmask >> i) & 1u) != 0) {  // wave-uniform
+          NatRaw<true> raw[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) raw[k].lo = cur[k].lo, raw[k].hi = cur[k].hi;
+          tail_inv4_scale_d<L, true>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+        } else {
+          NatRaw<false> raw[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) raw[k].d = __hiloint2double((int)cur[k].hi, (int)cur[k].lo);
+          tail_inv4_scale_d<L, false>(ar, raw, reinterpret_cast<const double*>(twi_base + (size_t)i * N), ctx->intt_scale_q_d[i], dm.split_inv_mask, t, r4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: |r4| < q
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) yc[i][k] = r4[k] < 0.0 ? r4[k] + ar.q : r4[k];  // canonical: |r4| < q
+      for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
-  }
   }
   behz_floor_sk_multi_d<KMAX, 4, GRID, NatRaw<PA>>(
       ctx, yc,
