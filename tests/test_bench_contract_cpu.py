@@ -153,3 +153,36 @@ def test_default_line_is_compact_and_ends_in_the_summary_of_every_metric_quantit
     # a failed or skipped secondary job is visible in the summary and never passes for a measurement
     assert bench.summary_entry({"error": "OutOfMemoryError: ..."}) == {"error": "OutOfMemoryError: ...", "parity_ok": False}
     assert bench.summary_entry({"skipped": "needs 140 GiB"})["parity_ok"] is False
+
+
+# summary key of the default line -> workload key of its evidence (kernel trace + three PMC passes); keys64 shares the kernels and the
+# command shape of keys4096 (one PMC set covers the per-key path), the 128-set chi_sq run is the 1024-set workload at another batch
+SUMMARY_EVIDENCE = {
+    "mulrelin_n8192": "mulrelin_n8192", "mulrelin_n16384": "mulrelin_n16384", "ntt_n8192": "ntt_n8192", "3x54": "mulrelin_n8192_bits54-54-54-56",
+    "keys64": "mulrelin_n8192_keys4096", "keys4096": "mulrelin_n8192_keys4096", "n16384_keys1024": "mulrelin_n16384_keys1024",
+    "chi_sq_1024": "chi_sq_n16384", "chi_sq_128": "chi_sq_n16384", "dot_prod": "dot_prod_n16384", "pir_2p17": "pir_n16384",
+}
+
+
+def test_every_summary_workload_has_its_kernel_trace_and_pmc_passes_for_the_tree_sources():
+    """every quantity the newest default line's `summary` claims has, under profiles/, the rocprofv3 kernel trace and
+    the three PMC passes of its workload, merged into pmc_traffic.json under the kernel-source hash of THIS tree (bench.py refuses
+    stale PMC figures at run time; this refuses a stale evidence set at commit time)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    newest = _newest("r*_final_bench_default.json")
+    tag = os.path.basename(newest)[: -len("_bench_default.json")]
+    line = json.load(open(newest))
+    doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    tree = bench.kernel_source_hash()
+    assert set(line["summary"]) == set(SUMMARY_EVIDENCE), sorted(set(line["summary"]) ^ set(SUMMARY_EVIDENCE))
+    for skey, wkey in SUMMARY_EVIDENCE.items():
+        assert line["summary"][skey]["parity_ok"] is True, skey
+        for part in ("kernel_stats", "pmc_fetch", "pmc_write", "pmc_inst"):
+            f = os.path.join(ROOT, "profiles", f"{tag}_{wkey}_{part}.txt")
+            assert os.path.exists(f) and os.path.getsize(f) > 200, f
+        assert wkey in doc["workloads"] and doc["workloads"][wkey]["kernels"], wkey
+        assert doc["source_hash"].get(wkey) == tree, (wkey, doc["source_hash"].get(wkey), tree)
+    if "kernel_source_hash" in line:
+        assert line["kernel_source_hash"] == tree

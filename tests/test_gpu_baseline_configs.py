@@ -107,6 +107,21 @@ def test_north_star_literal_3x54bit_primes_mul_relin_and_rotate():
         assert (relin[i] == orl[i]).all(), i
         assert (fused[i] == orl[i]).all(), i
         assert (_signed(t, o.batch_decode(o.decrypt(fused[i], sk))) == va[i] * vb[i]).all()
+    # r06: the fused pair of this prime set (mulrelin_head_mixed / mulrelin_tail_mixed) with ONE operand twice (the squaring head
+    # and middle kernels) and with an Add folded into the key switch's last kernel (examples/chi_sq through the graph executor)
+    sq = to_host(ev.multiply_relin(da, da, rkd))
+    for i in range(3):
+        assert (sq[i] == o.relinearize(o.multiply(a[i], a[i]), rk)).all(), i
+    from oracle.program_interp import run_program
+    from sunscreen_amd.workloads import chi_sq_optimized
+
+    prog = chi_sq_optimized()
+    small = [_encrypt_slots(o, pk, rng.integers(0, 7, (2, n))) for _ in range(3)]
+    outs = [to_host(x) for x in prog.run(ev, [to_device(c) for c in small], rkd)]
+    for i in range(2):
+        ref = run_program(o, prog.nodes, prog.edges, [c[i] for c in small], rk)
+        for k in range(4):
+            assert (outs[k][i] == ref[k]).all(), (i, k)
     # key switching under the same primes: rotations (a3)
     r1 = to_host(ev.rotate_rows(da, 1, gkd))
     r3 = to_host(ev.rotate_rows(da, -3, gkd))
