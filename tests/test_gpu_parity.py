@@ -510,7 +510,8 @@ def test_plan_flags_on_primes_that_keep_their_store_side_reductions(n, bits):
         flags |= (out[4] | out[5]) & (1 << 30)
     assert flags, "no prime of this set keeps a store-side reduction: the test would not test what it says"
     ctx = Context.from_raw(n, primes, t)
-    assert ctx.aux_fp64 and ctx.packed_mul
+    # (under the HIPBFV_NO_PACK switch suite the rows are 8-byte doubles and the store-side flags are moot: the bits are still checked)
+    assert ctx.aux_fp64 and (ctx.packed_mul or os.environ.get("HIPBFV_NO_PACK"))
     ev = BatchEvaluator(ctx)
     ev.set_transparent_check(False)
     rkd = RelinearizationKeys.from_array(ctx, rk)

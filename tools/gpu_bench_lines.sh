@@ -10,7 +10,10 @@ run mulrelin_n8192 --steps 10 --warmup 2
 run mulrelin_n16384 --n 16384 --batch 1024 --steps 5 --warmup 1
 run ntt_n8192 --workload ntt --steps 10 --warmup 2
 run mulrelin_n8192_bits54-54-54-56 --coeff-bits 54,54,54,56 --steps 5 --warmup 2
+run mulrelin_n8192_keys4096 --keys 4096 --steps 5 --warmup 2
+run mulrelin_n16384_keys1024 --n 16384 --batch 1024 --keys 1024 --steps 5 --warmup 1
 if [ "$2" = all ]; then
+run mulrelin_n8192_keys64 --keys 64 --steps 5 --warmup 2
 run mulrelin_n4096 --n 4096 --batch 8192 --steps 5 --warmup 2
 run mulrelin_n32768 --n 32768 --batch 256 --steps 2 --warmup 1
 run ntt_n16384 --workload ntt --n 16384 --batch 2048 --steps 10 --warmup 2

@@ -14,4 +14,4 @@ PY
 bash tools/gpu_bench_lines.sh $T all
 timeout 300 python tools/program_latency.py > $O/program_latency_n16384.json 2> $O/program_latency.err
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-timeout 300 python tools/pir_overlap_probe.py 128 256 4 > $O/pir_overlap_probe.txt 2>&1; tail -2 $O/pir_overlap_probe.txt
+VARIANTS="HIPBFV_NO_PACK=1" bash tools/gpu_variant_suites.sh > $O/variant_suite_no_pack_rerun.txt 2>&1; cat $O/variant_suite_no_pack_rerun.txt
