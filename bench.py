@@ -215,7 +215,13 @@ def plan_bytes(args, rank, world, K):
     if args.workload == "ntt":
         return {"items": B, "resident_bytes": 2 * B * 3 * n * 8}
     nin, nout = {"mulrelin": (2, 1), "e2e": (2, 1), "chi_sq": (3, 4), "dot_prod": (2, 1)}[args.workload]
-    return {"items": B, "resident_bytes": B * ct * (nin + nout)}
+    plan = {"items": B, "resident_bytes": B * ct * (nin + nout)}
+    if args.workload == "mulrelin" and getattr(args, "keys", 1) > 1:  # one relinearisation key (+ public key) per client of this rank
+        nk = min(args.keys, B)
+        plan["key_sets"] = nk
+        plan["key_bytes"] = nk * (16 * K * (K + 1) * n + 2 * (K + 1) * n * 8)
+        plan["resident_bytes"] += plan["key_bytes"]
+    return plan
 
 
 def dry_run(args) -> int:
