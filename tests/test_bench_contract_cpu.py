@@ -169,6 +169,10 @@ def test_every_summary_workload_has_its_kernel_trace_and_pmc_passes_for_the_tree
     """every quantity the newest default line's `summary` claims has, under profiles/, the rocprofv3 kernel trace and
     the three PMC passes of its workload, merged into pmc_traffic.json under the kernel-source hash of THIS tree (bench.py refuses
     stale PMC figures at run time; this refuses a stale evidence set at commit time)."""
+    import pytest
+
+    if os.environ.get("HIPBFV_LIB"):
+        pytest.skip("a variant library is loaded (its build flags are part of the source hash): the evidence belongs to the default build")
     sys.path.insert(0, ROOT)
     import bench
 
