@@ -803,6 +803,9 @@ def measure(args, env: Env, secondary: bool = False):
             # per-row packing (N = 16384 default set: 13 of 18 rows travel as 6 bytes): the average bytes per value over the K + S rows
             rows_ = list(primes[:K]) + list(ctx.aux_primes)
             bm = sum(6 if p < (1 << 48) else 8 for p in rows_) / len(rows_)
+        ba = bk  # the accumulator rows
+        if getattr(ctx, "packed_ks_rows", False):  # the rows of T per key prime (3 of 9 at N = 16384), the accumulator rows as doubles
+            bk, ba = sum(6 if p < (1 << 48) else 8 for p in primes[:KK]) / KK, 8
         per_unit = {
             # whole-polynomial path (kernels.hip)
             "ntt_fwd": 16 * n, "ntt_inv": 16 * n,                    # per residue polynomial: read + write
@@ -813,8 +816,8 @@ def measure(args, env: Env, secondary: bool = False):
             # split path (kernels_split.hip); units: polynomials for mul_head / mul_tail, ops otherwise
             # (intermediates travel as 6 bytes per value when the context packs them, 8 otherwise: bm / bk)
             "mul_head": n * (8 * K + bm * R_), "mul_mid": bm * n * 7 * R_, "mul_tail": n * (bm * R_ + 8 * K),
-            "ks_head": n * (8 * K + bk * KK * K), "ks_mid": n * bk * (KK * K + 2 * KK),
-            "ks_tail": n * (bk * 2 * KK + 32 * K),
+            "ks_head": n * (8 * K + bk * KK * K), "ks_mid": n * (bk * KK * K + ba * 2 * KK),
+            "ks_tail": n * (ba * 2 * KK + 32 * K),
             "galois": 16 * n * K, "eltwise": 24 * n,                 # per polynomial / per residue polynomial (2 reads + 1 write)
             "plain": 8 * K * n,                                      # dot_plain_ntt, per database entry: its K transform-domain residues
         }.get(name, 16 * n)

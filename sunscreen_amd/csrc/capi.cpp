@@ -905,7 +905,7 @@ long hipbfv_Context_AuxBase(void* h, uint64_t* count, uint64_t* primes, uint64_t
   if (!c || !count) return HIPBFV_E_POINTER;
   const hipbfv::DevCtx& d = c->ctx->host();
   *count = d.S;
-  if (fp64_base) *fp64_base = (d.aux_f64 ? 1 : 0) | (d.pack_mul ? 2 : 0) | (d.pack_ks ? 4 : 0) | (d.conv_grid ? 8 : 0) | (d.aux_mixed ? 16 : 0) | (d.pack_mul == 2 ? 32 : 0);
+  if (fp64_base) *fp64_base = (d.aux_f64 ? 1 : 0) | (d.pack_mul ? 2 : 0) | (d.pack_ks ? 4 : 0) | (d.conv_grid ? 8 : 0) | (d.aux_mixed ? 16 : 0) | (d.pack_mul == 2 ? 32 : 0) | (d.pack_ks == 2 ? 64 : 0);
   if (primes) {
     if (capacity < d.S) return fail(HIPBFV_E_INVALIDARG, "capacity too small");
     for (uint32_t j = 0; j < d.S; j++) primes[j] = d.mod[d.KK + j].q;
@@ -2198,7 +2198,7 @@ long hipbfv_debug_aux_base(uint64_t poly_modulus_degree, const uint64_t* coeff_p
   if (!c) return fail(HIPBFV_E_INVALIDARG, err.c_str());
   const hipbfv::DevCtx& d = c->host();
   *count = d.S;
-  if (flags) *flags = (d.aux_f64 ? 1 : 0) | (d.pack_mul ? 2 : 0) | (d.pack_ks ? 4 : 0) | (d.conv_grid ? 8 : 0) | (d.aux_mixed ? 16 : 0) | (d.pack_mul == 2 ? 32 : 0);
+  if (flags) *flags = (d.aux_f64 ? 1 : 0) | (d.pack_mul ? 2 : 0) | (d.pack_ks ? 4 : 0) | (d.conv_grid ? 8 : 0) | (d.aux_mixed ? 16 : 0) | (d.pack_mul == 2 ? 32 : 0) | (d.pack_ks == 2 ? 64 : 0);
   if (primes) {
     if (capacity < d.S) return fail(HIPBFV_E_INVALIDARG, "capacity too small");
     for (uint32_t j = 0; j < d.S; j++) primes[j] = d.mod[d.KK + j].q;

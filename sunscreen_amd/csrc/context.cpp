@@ -701,16 +701,9 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
 
   // key switching: a key prime takes the FP64 policy when its split range plan exists, the integer policy when its
   // twiddle tables are Shoup pairs (use_f64 == 0); an FP64-table prime WITHOUT a split plan has neither form
-  h.ks_nd = h.ks_ni = 0;
   h.ks_split_ok = 1;
-  for (u32 i = 0; i < KK; i++) {
-    if (h.mod[i].use_f64 && h.mod[i].split_ok)
-      h.ks_res_d[h.ks_nd++] = (unsigned char)i;
-    else if (!h.mod[i].use_f64)
-      h.ks_res_i[h.ks_ni++] = (unsigned char)i;
-    else
-      h.ks_split_ok = 0;
-  }
+  for (u32 i = 0; i < KK; i++)
+    if (h.mod[i].use_f64 && !h.mod[i].split_ok) h.ks_split_ok = 0;
 
   {
     // N = 4096: the multiply's middle kernel loses more on the doubled load count than its head gains (measured -1.4 %)
@@ -747,6 +740,34 @@ Context* Context::create(u32 n, const std::vector<u64>& key_primes, u64 t, int d
     if (part && !(rows_env && rows_env[0] == '0')) h.pack_mul = 2;  // (the auxiliary rows alone are S of the K + S rows)
   }
   if (h.pack_mul == 2 && K + h.S > 32) return fail("internal: per-row packing covers at most 32 rows (DevCtx::mul_row_mask)");
+  // r06, the same per row for the key switch's intermediates: every key prime FP64-policy, some below 2^48 (N = 16384 default set:
+  // the rows of 3 of the 9 key primes).  Instantiated beside the per-row multiply only (the 8-prime fused kernels), so it follows
+  // pack_mul == 2; HIPBFV_NO_PACK=ks / HIPBFV_PACK_ROWS=0 leave the 8-byte rows.
+  if (!h.pack_ks && h.pack_mul == 2) {
+    bool all = true, some = false;
+    for (u32 i = 0; i < KK; i++) {
+      all = all && h.mod[i].use_f64 && h.mod[i].split_ok;
+      some = some || h.mod[i].q < (1ull << 48);
+    }
+    const char* env = std::getenv("HIPBFV_NO_PACK");
+    if (all && some && !(env && env[0] == 'k')) h.pack_ks = 2;
+  }
+  // key switching: a key prime takes the FP64 policy when its split range plan exists (8-byte rows of T: ks_res_d, packed rows: ks_res_dp),
+  // the integer policy when its twiddle tables are Shoup pairs (use_f64 == 0)
+  h.ks_nd = h.ks_ndp = h.ks_ni = 0;
+  h.ks_row_mask = 0;
+  for (u32 i = 0; i < KK; i++) {
+    if (h.mod[i].use_f64 && h.mod[i].split_ok) {
+      if (h.pack_ks == 1 || (h.pack_ks == 2 && h.mod[i].q < (1ull << 48))) {
+        h.ks_res_dp[h.ks_ndp++] = (unsigned char)i;
+        h.ks_row_mask |= 1u << i;
+      } else {
+        h.ks_res_d[h.ks_nd++] = (unsigned char)i;
+      }
+    } else if (!h.mod[i].use_f64) {
+      h.ks_res_i[h.ks_ni++] = (unsigned char)i;
+    }
+  }
   h.mid_nd = h.mid_ndp = h.mid_ni = 0;
   h.mul_row_mask = 0;
   for (u32 r = 0; r < K + h.S; r++) {

@@ -138,9 +138,13 @@ struct DevCtx {
   u32 mul_row_mask;  // bit r = mul_row_packed[r], r < 32 (the head / tail kernels test it: a scalar load, not a byte load)
   // split key switch: key-prime indices (0..KK-1) handled by the FP64 / integer middle kernel; ks_split_ok: every key prime
   // has a policy the split kernels implement (FP64 with a split range plan, or integer with Shoup twiddle tables)
+  // pack_ks == 2 (r06): PER ROW, like pack_mul == 2 -- every key prime FP64-policy and some below 2^48: the rows T[.][I][.] of those
+  // primes travel as 6 bytes (ks_res_dp / ks_row_mask bit I), the others (ks_res_d) and every accumulator row as doubles
   unsigned char ks_res_d[kMaxKey + 3];
+  unsigned char ks_res_dp[kMaxKey + 3];
   unsigned char ks_res_i[kMaxKey + 3];
-  u32 ks_nd, ks_ni, ks_split_ok, pad5;
+  u32 ks_nd, ks_ndp, ks_ni, ks_split_ok;
+  u32 ks_row_mask, pad5;  // bit I: the rows of key prime I are 48-bit packed (pack_ks == 1: every bit set)
 
   // ---- key switching (special prime = mod[KK-1]) ----
   u64 qsp_half;                        // q_sp >> 1
@@ -176,7 +180,7 @@ struct DevCtx {
 
 // the residue lists are read through aligned 32-bit scalar loads (kernels_split.hip residue_of)
 static_assert(offsetof(DevCtx, mid_res_d) % 4 == 0 && offsetof(DevCtx, mid_res_dp) % 4 == 0 && offsetof(DevCtx, mid_res_i) % 4 == 0 &&
-                  offsetof(DevCtx, ks_res_d) % 4 == 0 && offsetof(DevCtx, ks_res_i) % 4 == 0,
+                  offsetof(DevCtx, ks_res_d) % 4 == 0 && offsetof(DevCtx, ks_res_dp) % 4 == 0 && offsetof(DevCtx, ks_res_i) % 4 == 0,
               "residue lists must start at 4-byte-aligned offsets");
 
 }  // namespace hipbfv

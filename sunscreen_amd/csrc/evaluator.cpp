@@ -426,7 +426,7 @@ int Evaluator::stage_keymap(const KeySel& sel, size_t count, size_t chunk, hipSt
 bool Evaluator::ks_split_for(size_t count) const {
   const DevCtx& h = ctx_->host();
   // (N = 32768 [r06]: integer-policy key primes only -- kernels_split.hip KS_DISPATCH; the multiply keeps the whole-polynomial kernels there)
-  return split_ks_ && h.logn >= 12 && (h.logn <= 14 || (h.logn == 15 && h.ks_nd == 0)) && h.ks_split_ok && !few_for_split_ks(count);
+  return split_ks_ && h.logn >= 12 && (h.logn <= 14 || (h.logn == 15 && h.ks_nd + h.ks_ndp == 0)) && h.ks_split_ok && !few_for_split_ks(count);
 }
 
 // out2[op] = base[op] (masked) + modDown( sum_J NTT(target_J) (.) key[J] ); scratch >= count * ks_scratch_words()
@@ -444,9 +444,9 @@ int Evaluator::key_switch(const u64* target, size_t tstride, const u64* key, con
     // head / middle / tail split transforms (kernels_split.hip): 3 launches (4 when FP64- and integer-policy key primes are
     // mixed: one middle kernel per policy), no whole-polynomial NTT round trips
     const bool mixed = h.ks_ni != 0;
-    HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, mixed, K, target, tstride, T, count, s, ginv));
-    HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, key, ACC, count, s, km));
-    HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, h.pack_ks != 0, mixed, ACC, base, bstride, base_mask, extra, out2, count, s, ginv));
+    HB_LAUNCH(kKernKsHead, count, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, (int)h.pack_ks, mixed, K, target, tstride, T, count, s, ginv));
+    HB_LAUNCH(kKernKsMid, count, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h, T, key, ACC, count, s, km));
+    HB_LAUNCH(kKernKsTail, count, launch_ks_tail(ctx_->dev(), h.tw_inv, h.logn, (int)h.pack_ks, mixed, ACC, base, bstride, base_mask, extra, out2, count, s, ginv));
     return kOk;
   }
   HB_LAUNCH(kKernKsDecompose, count, launch_ks_decompose(ctx_->dev(), n, K, target, tstride, T, count, s));
@@ -517,20 +517,20 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64*
         HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, false, 1, kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u));
         HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_dp, h.mid_ndp, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
         HB_LAUNCH(kKernKsHead, c, launch_mulrelin_head_mixed(ctx_->dev(), h.tw_inv, h.tw_fwd, h.logn, D, T, c, s));
-        HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, false, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, rk.key, ACC, c, s, kl.at(off)));
+        HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h, T, rk.key, ACC, c, s, kl.at(off)));
         HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail_mixed(ctx_->dev(), h.tw_inv, h.logn, D, ACC, addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s));
         continue;
       }
       HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, (int)h.pack_mul | (h.conv_grid == 1 ? 4 : 0), kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u));
       HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_dp, h.mid_ndp, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
       if (fuse_head_) {
-        HB_LAUNCH(kKernKsHead, c, launch_mulrelin_head(ctx_->dev(), h.tw_inv, h.tw_fwd, h.logn, (int)h.pack_mul, h.conv_grid != 0, h.pack_ks != 0, kneed, D, T, c, s));
+        HB_LAUNCH(kKernKsHead, c, launch_mulrelin_head(ctx_->dev(), h.tw_inv, h.tw_fwd, h.logn, (int)h.pack_mul, h.conv_grid != 0, (int)h.pack_ks, kneed, D, T, c, s));
       } else {
         HB_LAUNCH(kKernMulTail, c, launch_mul_tail(ctx_->dev(), h.tw_inv, h.logn, true, (int)h.pack_mul, h.conv_grid != 0, kneed, D, C2, c, s, 2, 1));
-        HB_LAUNCH(kKernKsHead, c, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, h.pack_ks != 0, false, K, C2, c2_words, T, c, s));
+        HB_LAUNCH(kKernKsHead, c, launch_ks_head(ctx_->dev(), h.tw_fwd, h.logn, (int)h.pack_ks, false, K, C2, c2_words, T, c, s));
       }
-      HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h.pack_ks != 0, ctx_->dev()->ks_res_d, h.ks_nd, ctx_->dev()->ks_res_i, h.ks_ni, T, rk.key, ACC, c, s, kl.at(off)));
-      HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail(ctx_->dev(), h.tw_inv, h.logn, (int)h.pack_mul, h.conv_grid != 0, h.pack_ks != 0, kneed, D, ACC,
+      HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h, T, rk.key, ACC, c, s, kl.at(off)));
+      HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail(ctx_->dev(), h.tw_inv, h.logn, (int)h.pack_mul, h.conv_grid != 0, (int)h.pack_ks, kneed, D, ACC,
                                                     addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s));
     }
     return note_result(out2, 2, K, count, s);

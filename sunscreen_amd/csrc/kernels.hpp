@@ -56,11 +56,12 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
 // 4-byte aligned and readable up to the next word boundary (the DevCtx members are; the launchers refuse anything else)
 // ginv != 0 (launch_ks_head, launch_ks_tail): a rotation's key switch -- the target / the base polynomials are sigma_g(.) for g = ginv^-1 mod 2N,
 // read through the automorphism instead of from a rotated copy (base and out2 must not alias then)
-hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
+hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, int pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
                           u32 ginv = 0);
-hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd, const unsigned char* res_i, u32 ni,
-                         const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km = KeyMap{});
-hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
+// h: the host copy of *ctx (its residue lists' counts: ks_nd 8-byte FP64 rows, ks_ndp packed FP64 rows, ks_ni integer rows)
+hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, const DevCtx& h, const u64* T, const u64* key, u64* ACC, size_t ops,
+                         hipStream_t s, KeyMap km = KeyMap{});
+hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
                           size_t ops, hipStream_t s, u32 ginv = 0);
 // split BEHZ multiply (2 x 2 -> 3), K <= 4
 hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, int pack, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
@@ -69,9 +70,9 @@ hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi,
                           const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s, bool square = false);
 hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, int pack, bool conv_grid, u32 kneed, const u64* D, u64* out,
                            size_t ops, hipStream_t s, u32 poly0 = 0, u32 npolys = 3);
-hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed,
+hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, int pack_mul, bool conv_grid, int pack_ks, u32 kneed,
                                 const u64* D, u64* T, size_t ops, hipStream_t s);
-hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
+hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, int pack_ks, u32 kneed, const u64* D,
                                 const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s);
 // the same two kernels for MIXED contexts (integer-policy data / key primes + the FP64 auxiliary base, K <= 4)
 hipError_t launch_mulrelin_head_mixed(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, const u64* D, u64* T, size_t ops, hipStream_t s);

@@ -879,6 +879,27 @@ __device__ __forceinline__ bool residue_is_f64(const DevMod& dm) { return dm.use
 template <class A, int NC>
 __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], const typename A::Tw* __restrict__ tw);
 
+// one row of T out of a key-switch head: 8 bytes per value, or -- the rows of key prime I are packed (wave-uniform) -- 6, reduced
+// first when the head's outputs exceed the packed range (context.cpp plan_f64_split)
+template <int L, int PACK>
+__device__ __forceinline__ void ks_head_store(const DevCtx* __restrict__ ctx, const DevMod& dm, const ArithD& ar, const BufRow& row, u32 I, u32 t,
+                                              double (&v)[EdgeGeom<L>::HEAD_NC]) {
+  constexpr int NC = EdgeGeom<L>::HEAD_NC;
+  if constexpr (PACK == 0) {
+    nat_store_head<L, false, NtSites<L>::ks_head_st>(row, t, v);
+  } else {
+    if (PACK == 1 || ((ctx->ks_row_mask >> I) & 1u) != 0) {
+      if (dm.split_fwd_mask & kPlanStoreReduce) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
+      }
+      nat_store_head<L, true, NtSites<L>::ks_head_st>(row, t, v);
+    } else {
+      nat_store_head<L, false, NtSites<L>::ks_head_st>(row, t, v);
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // key switch, head: T[op][I][J] = first three forward stages over q_I of (target_J mod q_I)
 // grid: (N/8/256, K, ops)
@@ -886,7 +907,8 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 // their rows of T hold lazy u64 values in [0, 4q) instead of doubles; the policy is a property of the residue I, so the
 // branch is wave-uniform.  MIXED = false is the all-FP64 kernel (every SEAL default parameter set).
 // -------------------------------------------------------------------------------------------------
-template <int L, bool PACK, bool MIXED>
+// PACK: DevCtx::pack_ks (0: 8-byte rows, 1: every row 48-bit packed, 2: per key prime, DevCtx::ks_row_mask)
+template <int L, int PACK, bool MIXED>
 __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                const u64* __restrict__ target, size_t tstride, double* __restrict__ T, u32 ginv) {
   using G = EdgeGeom<L>;
@@ -940,13 +962,7 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
       }
     }
     head_fwd_owned<ArithD, L>(ar, v, tw, t);
-    if constexpr (PACK) {
-      if (dm.split_fwd_mask & kPlanStoreReduce) {
-#pragma unroll
-        for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
-      }
-    }
-    nat_store_head<L, PACK, NtSites<L>::ks_head_st>(buf_row(rout, ((size_t)I * K + J) * N), t, v);
+    ks_head_store<L, PACK>(ctx, dm, ar, buf_row(rout, ((size_t)I * K + J) * N), I, t, v);
   }
 }
 
@@ -972,7 +988,12 @@ typedef unsigned long long key2_t __attribute__((ext_vector_type(2)));  // two k
 // SEAL default sets; the integer-policy ones go through ks_mid_int_kernel below)
 // EPT (KS_EPT(L), experiment hook): elements per thread; 16 = two radix-8 groups per thread and half the threads per workgroup
 // (N = 16384: 256-thread workgroups, of which two fit a CU's registers without the 128-VGPR ceiling of two 512-thread ones)
-template <int L, bool PACK, int EPT = KS_EPT(L)>
+// PACK: the rows of T this launch reads are 48-bit packed; PACK_ACC: so are the accumulator rows it writes.  Per-row contexts
+// (DevCtx::pack_ks == 2) pack T only, and launch this kernel once per kind of residue (ks_res_dp / ks_res_d):
+//  - the tails read every accumulator row as doubles -- a per-row fetch cost them more than 6 of 18 shorter rows saved
+//    (profiles/r06_s22_ab_ksrows_v1_*.txt);
+//  - ONE launch that tests the row's kind per workgroup spilt 27 registers into the digit loop and ran 27 % slower (..._v3_*.txt).
+template <int L, bool PACK, int EPT = KS_EPT(L), bool PACK_ACC = PACK>
 __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks_mid_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                        const MulOp* __restrict__ twi_base, const double* __restrict__ T,
                                                                        const u64* __restrict__ key, double* __restrict__ ACC, u32 ops,
@@ -1081,7 +1102,7 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
     __syncthreads();
     mid_inverse_multi<A, L, 1, EPT, KS_TW_PIPE(L)>(ar, *reinterpret_cast<One*>(&acc[1]), smem, tid, blk, twi, dm.split_inv_mask);
   }
-  if constexpr (PACK) {
+  if constexpr (PACK_ACC) {
     if (dm.split_inv_mask & kPlanStoreReduce) {  // primes whose last pass leaves more than a packed row holds (context.cpp plan_f64_split)
       reduce_all<A, EPT>(ar, acc[0]);
       reduce_all<A, EPT>(ar, acc[1]);
@@ -1093,7 +1114,7 @@ __global__ __launch_bounds__((SplitShape<L, EPT>::TPB), KS_MID_WAVES(L)) void ks
 #pragma unroll
     for (int g = 0; g < Out::G; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << RI); k++) nat_store<PACK, NtSites<L>::ks_mid_st>(dst, Sh::N, Out::elem(tid, blk, g, k), acc[c][g * (1 << RI) + k]);
+      for (int k = 0; k < (1 << RI); k++) nat_store<PACK_ACC, NtSites<L>::ks_mid_st>(dst, Sh::N, Out::elem(tid, blk, g, k), acc[c][g * (1 << RI) + k]);
   }
 }
 
@@ -2370,7 +2391,7 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
 // into x[J][k]; then, per digit J and key prime I, the conversion and the first forward stages exactly as ks_head_kernel.
 // All-FP64 contexts only.  grid: (N/NC/256, 1, ops)
 // -------------------------------------------------------------------------------------------------
-template <int L, int KMAX, int PACKM, bool GRID, bool PACKK>
+template <int L, int KMAX, int PACKM, bool GRID, int PACKK>
 __global__ EDGE_BOUNDS(KMAX) void mulrelin_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                      const MulOp* __restrict__ twf_base, const u64* __restrict__ D,
                                                                      double* __restrict__ T) {
@@ -2408,13 +2429,7 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_head_kernel(const DevCtx* __restrict_
 #pragma unroll
       for (int k = 0; k < NC; k++) v[k] = need_reduce ? ar.reduce(x[J][k]) : x[J][k];
       head_fwd_owned<ArithD, L>(ar, v, tw, t);
-      if constexpr (PACKK) {
-        if (dm.split_fwd_mask & kPlanStoreReduce) {
-#pragma unroll
-          for (int k = 0; k < NC; k++) v[k] = ar.reduce(v[k]);
-        }
-      }
-      nat_store_head<L, PACKK, NtSites<L>::ks_head_st>(buf_row(rout, ((size_t)I * K + J) * N), t, v);
+      ks_head_store<L, PACKK>(ctx, dm, ar, buf_row(rout, ((size_t)I * K + J) * N), I, t, v);
     }
   }
 }
@@ -2761,43 +2776,54 @@ hipError_t launch_ntt_split(const DevCtx* ctx, const MulOp* tw, u32 logn, u64* d
   }
 
 template <int L>
-static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
+static hipError_t ks_head_t(const DevCtx* ctx, const MulOp* twf, int pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
                             u32 ginv) {
   const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, K, (unsigned)ops);
   if constexpr (L == 15) {
     if (!mixed) return hipErrorInvalidValue;
-    ks_head_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
+    ks_head_kernel<L, 0, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
     return hipGetLastError();
   } else if (mixed)
-    ks_head_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
-  else if (pack)
-    ks_head_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
+    ks_head_kernel<L, 0, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
+  else if (pack == 2) {
+    if constexpr (L >= 13) ks_head_kernel<L, 2, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
+    else return hipErrorInvalidValue;  // (context.cpp: beside pack_mul == 2 only)
+  } else if (pack)
+    ks_head_kernel<L, 1, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
   else
-    ks_head_kernel<L, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
+    ks_head_kernel<L, 0, false><<<grid, kHeadThreads, 0, s>>>(ctx, twf, target, tstride, reinterpret_cast<double*>(T), ginv);
   return hipGetLastError();
 }
 // pack: DevCtx::pack_ks of the context behind `ctx` (48-bit packed intermediates, see nat_load); mixed: DevCtx::ks_ni != 0
 // ginv != 0: the target is sigma_g(target) for the Galois element g = ginv^-1 mod 2N, read through the automorphism
-hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
+hipError_t launch_ks_head(const DevCtx* ctx, const MulOp* twf, u32 logn, int pack, bool mixed, u32 K, const u64* target, size_t tstride, u64* T, size_t ops, hipStream_t s,
                           u32 ginv) {
   KS_DISPATCH(ks_head_t, ctx, twf, pack, mixed, K, target, tstride, T, ops, s, ginv)
 }
 
-// res_d / nd, res_i / ni: device lists (inside the DevCtx) of the key primes that take the FP64 / the integer policy
+// res_d / nd, res_dp / ndp, res_i / ni: device lists (inside the DevCtx) of the key primes that take the FP64 policy with 8-byte rows,
+// the FP64 policy with 48-bit packed rows and the integer policy
 template <int L>
-static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack, const unsigned char* res_d, u32 nd,
-                           const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km) {
+static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, bool pack_acc, const unsigned char* res_d, u32 nd, const unsigned char* res_dp,
+                           u32 ndp, const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km) {
   using Sh = SplitShape<L>;
-  if (((reinterpret_cast<uintptr_t>(res_d) | reinterpret_cast<uintptr_t>(res_i)) & 3u) != 0) return hipErrorInvalidValue;  // residue_of reads words
+  if (((reinterpret_cast<uintptr_t>(res_d) | reinterpret_cast<uintptr_t>(res_dp) | reinterpret_cast<uintptr_t>(res_i)) & 3u) != 0)
+    return hipErrorInvalidValue;  // residue_of reads words
   const size_t ops8 = (ops + 7) / 8 * 8;
   if constexpr (L == 15) {
-    if (nd) return hipErrorInvalidValue;  // integer-policy key primes only at this degree (context.cpp: ks_split_ok)
-  } else if (nd) {
-    const dim3 grid((unsigned)(ops8 * nd * Sh::NBLK));
-    if (pack)
-      ks_mid_kernel<L, true><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd, km);
-    else
+    if (nd || ndp) return hipErrorInvalidValue;  // integer-policy key primes only at this degree (context.cpp: ks_split_ok)
+  } else {
+    if (ndp) {
+      const dim3 grid((unsigned)(ops8 * ndp * Sh::NBLK));
+      if (pack_acc)
+        ks_mid_kernel<L, true><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_dp, ndp, km);
+      else
+        ks_mid_kernel<L, true, KS_EPT(L), false><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_dp, ndp, km);
+    }
+    if (nd) {
+      const dim3 grid((unsigned)(ops8 * nd * Sh::NBLK));
       ks_mid_kernel<L, false><<<grid, SplitShape<L, KS_EPT(L)>::TPB, 0, s>>>(ctx, twf, twi, reinterpret_cast<const double*>(T), key, reinterpret_cast<double*>(ACC), (u32)ops, res_d, nd, km);
+    }
   }
   if (ni) {
     const dim3 grid((unsigned)(ops8 * ni * Sh::NBLK));
@@ -2805,13 +2831,15 @@ static hipError_t ks_mid_t(const DevCtx* ctx, const MulOp* twf, const MulOp* twi
   }
   return hipGetLastError();
 }
-hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, bool pack, const unsigned char* res_d, u32 nd,
-                         const unsigned char* res_i, u32 ni, const u64* T, const u64* key, u64* ACC, size_t ops, hipStream_t s, KeyMap km) {
-  KS_DISPATCH(ks_mid_t, ctx, twf, twi, pack, res_d, nd, res_i, ni, T, key, ACC, ops, s, km)
+// the residue lists of the context behind `ctx` (DevCtx::ks_res_d / ks_res_dp / ks_res_i and their counts, read on the host); the
+// accumulator rows are packed when EVERY key prime's are (pack_ks == 1)
+hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, const DevCtx& h, const u64* T, const u64* key, u64* ACC, size_t ops,
+                         hipStream_t s, KeyMap km) {
+  KS_DISPATCH(ks_mid_t, ctx, twf, twi, h.pack_ks == 1, ctx->ks_res_d, h.ks_nd, ctx->ks_res_dp, h.ks_ndp, ctx->ks_res_i, h.ks_ni, T, key, ACC, ops, s, km)
 }
 
 template <int L>
-static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
+static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, int pack_ks, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
                             const u64* extra, u64* out2, size_t ops, hipStream_t s, u32 ginv) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
   if constexpr (L == 15) {
@@ -2820,16 +2848,16 @@ static hipError_t ks_tail_t(const DevCtx* ctx, const MulOp* twi, bool pack, bool
     return hipGetLastError();
   } else if (mixed)
     ks_tail_kernel<L, false, true><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2, ginv);
-  else if (pack)
+  else if (pack_ks == 1)  // (2 = per key prime: the rows of T only, the accumulator rows are doubles)
     ks_tail_kernel<L, true, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2, ginv);
   else
     ks_tail_kernel<L, false, false><<<grid, kHeadThreads, 0, s>>>(ctx, twi, reinterpret_cast<const double*>(ACC), base, bstride, base_mask, extra, out2, ginv);
   return hipGetLastError();
 }
 // extra: optional ciphertexts u64[ops][2][K][N] added to the result; ginv != 0: the base polynomials are read through sigma_g (launch_ks_head)
-hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
+hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_ks, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask,
                           const u64* extra, u64* out2, size_t ops, hipStream_t s, u32 ginv) {
-  KS_DISPATCH(ks_tail_t, ctx, twi, pack, mixed, ACC, base, bstride, base_mask, extra, out2, ops, s, ginv)
+  KS_DISPATCH(ks_tail_t, ctx, twi, pack_ks, mixed, ACC, base, bstride, base_mask, extra, out2, ops, s, ginv)
 }
 
 template <int L>
@@ -2928,12 +2956,13 @@ hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool a
 }
 
 template <int L>
-static hipError_t mulrelin_tail_t(const DevCtx* ctx, const MulOp* twi, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D, const u64* ACC,
+static hipError_t mulrelin_tail_t(const DevCtx* ctx, const MulOp* twi, int pack_mul, bool conv_grid, int pack_ks, u32 kneed, const u64* D, const u64* ACC,
                                   const u64* extra, u64* out2, size_t ops, hipStream_t s) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
   const double* acc = reinterpret_cast<const double*>(ACC);
 #define MRT(KM, PM, GR, PK) mulrelin_tail_kernel<L, KM, PM, GR, PK><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, acc, extra, out2)
-#define MRT_K(KM, PM, GR) do { if (pack_ks) MRT(KM, PM, GR, true); else MRT(KM, PM, GR, false); } while (0)
+// (pack_ks == 2, per key prime: the rows of T only -- the accumulator rows are doubles)
+#define MRT_K(KM, PM, GR) do { if (pack_ks == 1) MRT(KM, PM, GR, true); else MRT(KM, PM, GR, false); } while (0)
   if (kneed > 4) {
     if (pack_mul == 2) { if (conv_grid) MRT_K(8, 2, true); else MRT_K(8, 2, false); }
     else if (pack_mul) { if (conv_grid) MRT_K(8, 1, true); else MRT_K(8, 1, false); }
@@ -2947,26 +2976,29 @@ static hipError_t mulrelin_tail_t(const DevCtx* ctx, const MulOp* twi, int pack_
   return hipGetLastError();
 }
 template <int L>
-static hipError_t mulrelin_head_t(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
+static hipError_t mulrelin_head_t(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, int pack_mul, bool conv_grid, int pack_ks, u32 kneed, const u64* D,
                                   u64* T, size_t ops, hipStream_t s) {
   const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, 1, (unsigned)ops);
   double* t = reinterpret_cast<double*>(T);
 #define MRH(KM, PM, GR, PK) mulrelin_head_kernel<L, KM, PM, GR, PK><<<grid, kHeadThreads, 0, s>>>(ctx, twi, twf, D, t)
-#define MRH_K(KM, PM, GR) do { if (pack_ks) MRH(KM, PM, GR, true); else MRH(KM, PM, GR, false); } while (0)
+#define MRH_K(KM, PM, GR) do { if (pack_ks == 2) return hipErrorInvalidValue; if (pack_ks) MRH(KM, PM, GR, 1); else MRH(KM, PM, GR, 0); } while (0)
+// (per-row key-switch rows come with the per-row multiply only: context.cpp)
+#define MRH_K2(GR) do { if (pack_ks == 2) MRH(8, 2, GR, 2); else if (pack_ks) MRH(8, 2, GR, 1); else MRH(8, 2, GR, 0); } while (0)
   if (kneed > 4) {
-    if (pack_mul == 2) { if (conv_grid) MRH_K(8, 2, true); else MRH_K(8, 2, false); }
+    if (pack_mul == 2) { if (conv_grid) MRH_K2(true); else MRH_K2(false); }
     else if (pack_mul) { if (conv_grid) MRH_K(8, 1, true); else MRH_K(8, 1, false); }
     else { if (conv_grid) MRH_K(8, 0, true); else MRH_K(8, 0, false); }
   } else {
     if (pack_mul == 2) return hipErrorInvalidValue;
     if (pack_mul) MRH_K(4, 1, false); else MRH_K(4, 0, false);
   }
+#undef MRH_K2
 #undef MRH_K
 #undef MRH
   return hipGetLastError();
 }
 // multiply tail of c2 + key-switch head in one kernel (all-FP64 contexts)
-hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed,
+hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, int pack_mul, bool conv_grid, int pack_ks, u32 kneed,
                                 const u64* D, u64* T, size_t ops, hipStream_t s) {
   SPLIT_DISPATCH(mulrelin_head_t, ctx, twi, twf, pack_mul, conv_grid, pack_ks, kneed, D, T, ops, s)
 }
@@ -3001,7 +3033,7 @@ hipError_t launch_mulrelin_tail_mixed(const DevCtx* ctx, const MulOp* twi, u32 l
   SPLIT_DISPATCH(mulrelin_tail_mixed_t, ctx, twi, D, ACC, extra, out2, ops, s)
 }
 
-hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, bool pack_ks, u32 kneed, const u64* D,
+hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, int pack_ks, u32 kneed, const u64* D,
                                 const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s) {
   SPLIT_DISPATCH(mulrelin_tail_t, ctx, twi, pack_mul, conv_grid, pack_ks, kneed, D, ACC, extra, out2, ops, s)
 }

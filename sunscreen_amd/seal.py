@@ -252,6 +252,7 @@ class Context:
         self.packed_mul = bool(own.value & 2)  # 48-bit packed intermediates in the split multiply / key switch
         self.packed_ks = bool(own.value & 4)
         self.packed_mul_rows = bool(own.value & 32)  # ... per row: only the rows whose prime is below 2^48 (r04)
+        self.packed_ks_rows = bool(own.value & 64)  # the key switch's rows per key prime (r06; packed_ks is set too)
         self.conv_grid = bool(own.value & 8)  # base-conversion sums formed exactly and reduced once (griddot.hpp)
 
     def get_handle(self):

@@ -322,7 +322,7 @@ def test_per_row_packing_of_the_multiply_intermediates(n, bits, monkeypatch):
     default context (8-byte rows throughout) gives the same bits."""
     import torch
 
-    from sunscreen_amd import Context, RelinearizationKeys
+    from sunscreen_amd import Context, GaloisKeys, RelinearizationKeys
     from sunscreen_amd.batch import BatchEvaluator
 
     if any(os.environ.get(k) == "1" for k in ("HIPBFV_SEAL_AUX", "HIPBFV_NO_F64")):
@@ -332,7 +332,7 @@ def test_per_row_packing_of_the_multiply_intermediates(n, bits, monkeypatch):
     o = O.Oracle(n, primes, t)
     o.throw_on_transparent = False  # _extreme_rows has an all-zero operand: the (transparent) product's bits are compared
     O.seed(31)
-    sk, pk, rk, _ = o.keygen()
+    sk, pk, rk, gk = o.keygen(galois_elts=[3, 2 * n - 1])
     K = len(primes) - 1
     rng = np.random.default_rng(n + sum(bits))
     a = np.stack([rng.integers(0, q, (3, 2, n), dtype=np.uint64) for q in primes[:K]], axis=2).astype(np.int64)
@@ -351,11 +351,22 @@ def test_per_row_packing_of_the_multiply_intermediates(n, bits, monkeypatch):
         ev = BatchEvaluator(ctx)
         ev.set_transparent_check(False)
         assert ctx.aux_fp64 and ctx.packed_mul_rows == (env is None) and (ctx.packed_mul == (env is None)), (tag, ctx.packed_mul, ctx.packed_mul_rows)
-        rkd = RelinearizationKeys.from_array(ctx, rk)
-        got[tag] = [x.cpu().numpy().astype(np.uint64) for x in (ev.multiply(da, db), ev.multiply_relin(da, db, rkd), ev.multiply(da, da), ev.multiply_relin(db, db, rkd))]
+        # r06: the key switch's rows T / ACC per KEY prime too (DevCtx::pack_ks == 2) when some key primes are below 2^48 -- the second
+        # set has the SPECIAL prime among them (its accumulator row packed), the third none
+        some_below = any(p < (1 << 48) for p in primes)
+        assert ctx.packed_ks_rows == (env is None and some_below) and ctx.packed_ks == ctx.packed_ks_rows, (tag, ctx.packed_ks, ctx.packed_ks_rows)
+        rkd, gkd = RelinearizationKeys.from_array(ctx, rk), GaloisKeys.from_arrays(ctx, gk)
+        prod = ev.multiply(da, db)
+        # (the stand-alone relinearize and the rotations run ks_head / ks_tail, the fused forms mulrelin_head / mulrelin_tail)
+        got[tag] = [x.cpu().numpy().astype(np.uint64) for x in (prod, ev.multiply_relin(da, db, rkd), ev.multiply(da, da), ev.multiply_relin(db, db, rkd),
+                                                                ev.relinearize(prod, rkd), ev.rotate_rows(da, 1, gkd), ev.rotate_columns(db, gkd))]
     for x, y in zip(got["rows"], got["bytes8"]):
         assert (x == y).all()
-    m, r, sq, sqr = got["rows"]
+    m, r, sq, sqr, rl, rr, rc = got["rows"]
+    assert (rl == r).all()
+    for i in (0, len(a) - 1):
+        assert (rr[i] == o.rotate_rows(a[i].astype(np.uint64), 1, gk)).all(), i
+        assert (rc[i] == o.rotate_columns(b[i].astype(np.uint64), gk)).all(), i
     for i in list(range(2)) + list(range(3, len(a))):  # two random items and every edge row
         ua, ub = a[i].astype(np.uint64), b[i].astype(np.uint64)
         om = o.multiply(ua, ub)

@@ -48,27 +48,35 @@ def _pick(kernels, pattern):
     return hit
 
 
-# the instantiations the BASELINE configurations launch: n = 8192 (every FP64 row 48-bit packed) and n = 16384 (8-byte rows)
-HOT = (r"15mul_head_kernelILi13ELi4ELb1ELi1ELb[01]E", r"14mul_mid_kernelILi13ELb1ELb1ELb[01]E", r"20mulrelin_head_kernelILi13ELi4ELi1ELb0ELb1E",
-       r"13ks_mid_kernelILi13ELb1ELi8E", r"20mulrelin_tail_kernelILi13ELi4ELi1ELb0ELb1E", r"14ks_head_kernelILi13ELb1ELb0E", r"14ks_tail_kernelILi13ELb1ELb0E",
-       r"15mul_head_kernelILi14ELi8ELb1ELi0ELb0E", r"14mul_mid_kernelILi14ELb1ELb0ELb[01]E", r"20mulrelin_head_kernelILi14ELi8ELi0ELb1ELb0E",
-       r"13ks_mid_kernelILi14ELb0ELi16E", r"20mulrelin_tail_kernelILi14ELi8ELi0ELb1ELb0E", r"14ks_head_kernelILi14ELb0ELb0E", r"14ks_tail_kernelILi14ELb0ELb0E",
+# the instantiations the BASELINE configurations launch: n = 8192 (every FP64 row 48-bit packed) and n = 16384 (8-byte rows; per row since r06)
+HOT = (r"15mul_head_kernelILi13ELi4ELb1ELi1ELb[01]E", r"14mul_mid_kernelILi13ELb1ELb1ELb[01]E", r"20mulrelin_head_kernelILi13ELi4ELi1ELb0ELi1E",
+       r"13ks_mid_kernelILi13ELb1ELi8E", r"20mulrelin_tail_kernelILi13ELi4ELi1ELb0ELb1E", r"14ks_head_kernelILi13ELi1ELb0E", r"14ks_tail_kernelILi13ELb1ELb0E",
+       r"15mul_head_kernelILi14ELi8ELb1ELi0ELb0E", r"14mul_mid_kernelILi14ELb1ELb0ELb[01]E", r"20mulrelin_head_kernelILi14ELi8ELi0ELb1ELi0E",
+       r"13ks_mid_kernelILi14ELb0ELi16E", r"20mulrelin_tail_kernelILi14ELi8ELi0ELb1ELb0E", r"14ks_head_kernelILi14ELi0ELb0E", r"14ks_tail_kernelILi14ELb0ELb0E",
        # r06: n = 16384 packs the multiply's rows PER ROW by default (the rows whose prime is below 2^48): head / tail <.., PACK = 2, ..> and the
        # packed middle instantiation beside the 8-byte one (its squaring form was the spilling kernel that kept this opt-in through r05)
-       r"15mul_head_kernelILi14ELi8ELb1ELi2ELb0E", r"14mul_mid_kernelILi14ELb1ELb1ELb[01]E", r"20mulrelin_head_kernelILi14ELi8ELi2ELb1ELb0E",
-       r"20mulrelin_tail_kernelILi14ELi8ELi2ELb1ELb0E")
+       r"15mul_head_kernelILi14ELi8ELb1ELi2ELb0E", r"14mul_mid_kernelILi14ELb1ELb1ELb[01]E", r"20mulrelin_head_kernelILi14ELi8ELi2ELb1ELi[02]E",
+       r"20mulrelin_tail_kernelILi14ELi8ELi2ELb1ELb0E", r"14ks_head_kernelILi14ELi2ELb0E", r"13ks_mid_kernelILi14ELb1ELi16ELb0E")
+
+
+# The one tolerated exception: the packed 16-element key-switch middle kernel of n = 16384 (launched since r06's per-row packing of the
+# key-switch rows) parks four loop-invariant dwords in scratch AROUND its digit loop: 4 stores before it, 5 loads after it, none inside
+# (9 of ~9300 instructions; measured with the rest of the per-row change, HISTORY.md R6 s22).  More than that is a regression.
+PARKED = {r"13ks_mid_kernelILi14ELb1ELi16ELb0E": 10}
 
 
 @pytest.mark.parametrize("pattern", HOT)
 def test_hot_kernels_use_no_scratch_and_no_flat_memory_instructions(kernels, pattern):
     for name, ins in _pick(kernels, pattern).items():
-        bad = sorted({i for i in ins if i.startswith(("scratch_", "flat_"))})
-        assert not bad, (name, bad)
+        flat = sorted({i for i in ins if i.startswith("flat_")})
+        assert not flat, (name, flat)
+        scratch = [i for i in ins if i.startswith("scratch_")]
+        assert len(scratch) <= PARKED.get(pattern, 0), (name, len(scratch), sorted(set(scratch)))
 
 
-def test_the_known_spilling_instantiations_are_the_ones_no_default_set_launches(kernels):
-    """Which split kernels DO use scratch, so that a new one is noticed: the packed 16-element key-switch middle kernel of n = 16384 (no
-    default set has packed key rows there) the integer middle kernel of n = 4096, and the integer key-switch middle kernel of n = 32768."""
+def test_the_known_spilling_instantiations_are_pinned(kernels):
+    """Which split kernels DO use scratch, so that a new one is noticed: the packed 16-element key-switch middle kernel of n = 16384 (four
+    dwords parked around its loop: PARKED above), the integer middle kernel of n = 4096, and the integer key-switch middle kernel of n = 32768."""
     spilling = sorted(k for k, ins in kernels.items() if re.search(r"mul_|ks_|mulrelin", k) and any(i.startswith("scratch_") for i in ins))
     # r06: + the integer key-switch middle kernel of n = 32768 (one 1024-thread workgroup per CU: 128 registers per lane; measured
     # against three variants that spill less or not at all -- all slower, kernels_split.hip KS_MID_INT_EPT15)
