@@ -254,7 +254,8 @@ long hipbfv_Context_NextLevel(void *context, void **next);
  * bit 1 / bit 2 = the split multiply / key-switch pipelines store their intermediates 48-bit packed; bit 3 = the
  * multiply forms its q -> Bsk base-conversion sums exactly and reduces each once; bit 4 = mixed base: the data primes are too
  * wide for the FP64 pipe (the 3 x 54-bit set) but the auxiliary primes are the library's own FP64-pipe ones; bit 5 = the multiply packs
- * its intermediates PER ROW: only the rows whose prime is below 2^48 (the SEAL default set of n = 16384: 13 of 18 rows) (diagnostics).
+ * its intermediates PER ROW: only the rows whose prime is below 2^48 (the SEAL default set of n = 16384: 13 of 18 rows); bit 6 = the key
+ * switch packs its digit rows per KEY PRIME (bit 2 is set too; n = 16384: the rows of 3 of the 9 key primes) (diagnostics).
  * primes may be NULL; otherwise capacity >= *count words, B first, m_sk last. */
 long hipbfv_Context_AuxBase(void *context, uint64_t *count, uint64_t *primes, uint64_t capacity, int *fp64_base);
 
