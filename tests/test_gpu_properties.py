@@ -376,6 +376,59 @@ def test_per_row_packing_of_the_multiply_intermediates(n, bits, monkeypatch):
         assert (sqr[i] == o.relinearize(o.multiply(ub, ub), rk)).all(), i
 
 
+def test_per_row_packing_down_the_modulus_chain_at_n16384():
+    """The level contexts of n = 16384 (sunscreen_runtime never switches levels itself -- seal_fhe::Evaluator::mod_switch_to_next
+    is the caller's, seal_fhe/src/evaluator_base.rs -- but a program that does lands here): K = 8 -> 7 -> 6 -> 5 keep the per-row
+    packed pipelines (three 48-bit primes beside 49-bit ones, their own row masks and residue lists), K = 4 leaves them (four-prime
+    instantiations, 8-byte rows).  Batches of six (above the small-batch cut-over), every level against the oracle of that level:
+    the fused multiply + relinearize, the stand-alone relinearize and a rotation."""
+    import torch
+
+    from sunscreen_amd import Context, GaloisKeys, RelinearizationKeys
+    from sunscreen_amd.batch import BatchEvaluator
+
+    if any(os.environ.get(k) == "1" for k in ("HIPBFV_SEAL_AUX", "HIPBFV_NO_F64")):
+        pytest.skip("packed rows exist on the FP64 pipe with the library's own auxiliary base only")
+    n = 16384
+    primes, t = O.bfv_default(n), O.plain_batching(n, 17)
+    o = O.Oracle(n, primes, t)
+    O.seed(77)
+    sk, pk, rk, gk = o.keygen(galois_elts=[3])
+    ctx = Context.from_raw(n, primes, t)
+    rng = np.random.default_rng(5)
+    vals = rng.integers(0, 30, (2, n)).astype(np.uint64)
+    ra, rb = (o.encrypt(pk, o.batch_encode(v)) for v in vals)
+    per_row = not (os.environ.get("HIPBFV_NO_PACK") or os.environ.get("HIPBFV_PACK_ROWS") == "0")
+    for level in range(5):  # K = 8, 7, 6, 5, 4
+        ev = BatchEvaluator(ctx)
+        if per_row:
+            assert ctx.packed_mul_rows == (o.K > 4) and ctx.packed_ks_rows == (o.K > 4), (level, o.K)
+        rkd, gkd = RelinearizationKeys.from_array(ctx, rk), GaloisKeys.from_arrays(ctx, gk)
+        da = torch.from_numpy(np.stack([ra, rb, ra, rb, ra, rb]).astype(np.int64)).cuda()
+        db = torch.from_numpy(np.stack([rb, rb, ra, ra, rb, ra]).astype(np.int64)).cuda()
+        prod = o.multiply(ra, rb)
+        exp = o.relinearize(prod, rk)
+        got = ev.multiply_relin(da, db, rkd).cpu().numpy().astype(np.uint64)
+        assert (got[0] == exp).all() and (got[4] == exp).all(), level
+        assert (got[1] == o.relinearize(o.multiply(rb, rb), rk)).all(), level
+        rel = ev.relinearize(ev.multiply(da, db), rkd).cpu().numpy().astype(np.uint64)
+        assert (rel == got).all(), level
+        rot = ev.rotate_rows(da, 1, gkd).cpu().numpy().astype(np.uint64)
+        assert (rot[0] == o.rotate_rows(ra, 1, gk)).all() and (rot[1] == o.rotate_rows(rb, 1, gk)).all(), level
+        if level == 4:
+            break
+        # the next level: the oracle's view drops the last data prime everywhere (keys keep the special prime's row)
+        sw = ev.mod_switch(torch.from_numpy(np.stack([ra, rb]).astype(np.int64)).cuda()).cpu().numpy().astype(np.uint64)
+        ra, rb = o.mod_switch_to_next(ra), o.mod_switch_to_next(rb)
+        assert (sw[0] == ra).all() and (sw[1] == rb).all(), level
+        o2 = o.next_level()
+        rows = list(range(o2.K)) + [o.KK - 1]
+        rk = np.ascontiguousarray(rk[: o2.K][:, :, rows, :])
+        gk = {e: np.ascontiguousarray(g[: o2.K][:, :, rows, :]) for e, g in gk.items()}
+        o, ctx = o2, ctx.next_level()
+        assert ctx.K == o.K
+
+
 def test_concurrent_host_threads_on_one_evaluator():
     """sunscreen_runtime/src/run.rs:415-469 calls one evaluator from a rayon pool: handle-level calls must be
     thread-safe (one non-blocking HIP stream per host thread, no shared mutable scratch)."""

@@ -14,4 +14,7 @@ PY
 bash tools/gpu_bench_lines.sh $T all
 timeout 300 python tools/program_latency.py > $O/program_latency_n16384.json 2> $O/program_latency.err
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-VARIANTS="HIPBFV_NO_PACK=1" bash tools/gpu_variant_suites.sh > $O/variant_suite_no_pack_rerun.txt 2>&1; cat $O/variant_suite_no_pack_rerun.txt
+# the tests added after step 1's suite (the per-row pipelines down the modulus chain), under the default and the two packing switches
+for e in HIPBFV_X=0 HIPBFV_NO_PACK=ks HIPBFV_PACK_ROWS=0; do
+  echo "$e: $(env $e timeout 600 python -m pytest tests/test_gpu_properties.py -m gpu -q -p no:cacheprovider -k 'per_row' 2>&1 | tail -1)"
+done > $O/pytest_per_row_chain.txt 2>&1; cat $O/pytest_per_row_chain.txt
