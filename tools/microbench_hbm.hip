@@ -68,6 +68,43 @@ __global__ void k_chunk(const u64* __restrict__ in, u64* __restrict__ out, int r
   for (int e = 0; e < EPT; e++) st<NT>(dst + (size_t)e * blockDim.x + threadIdx.x, v[e]);
 }
 
+// the stand-alone INVERSE transform's shape: every thread loads runs of 2^RF consecutive elements with 16-byte loads (a wavefront's load
+// instruction covers 64 x 16 bytes at a stride of 8 << RF), and stores 8-byte words, lanes contiguous
+template <int EPT, int RF>
+__global__ void k_chunk_runs(const u64* __restrict__ in, u64* __restrict__ out) {
+  const size_t chunk = (size_t)blockDim.x * EPT;
+  const u64* src = in + (size_t)blockIdx.x * chunk;
+  u64* dst = out + (size_t)blockIdx.x * chunk;
+  u64 v[EPT];
+#pragma unroll
+  for (int g = 0; g < (EPT >> RF); g++) {
+    const u64x2* p = reinterpret_cast<const u64x2*>(src + ((size_t)(threadIdx.x + g * blockDim.x) << RF));
+#pragma unroll
+    for (int k = 0; k < (1 << RF); k += 2) {
+      const u64x2 w = p[k >> 1];
+      v[g * (1 << RF) + k] = w.x, v[g * (1 << RF) + k + 1] = w.y;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; e++) dst[(size_t)e * blockDim.x + threadIdx.x] = v[e];
+}
+// ... and the mirror image: 8-byte loads, lanes contiguous; runs of 2^RF stored with 16-byte stores
+template <int EPT, int RF>
+__global__ void k_chunk_run_stores(const u64* __restrict__ in, u64* __restrict__ out) {
+  const size_t chunk = (size_t)blockDim.x * EPT;
+  const u64* src = in + (size_t)blockIdx.x * chunk;
+  u64* dst = out + (size_t)blockIdx.x * chunk;
+  u64 v[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; e++) v[e] = src[(size_t)e * blockDim.x + threadIdx.x];
+#pragma unroll
+  for (int g = 0; g < (EPT >> RF); g++) {
+    u64x2* p = reinterpret_cast<u64x2*>(dst + ((size_t)(threadIdx.x + g * blockDim.x) << RF));
+#pragma unroll
+    for (int k = 0; k < (1 << RF); k += 2) p[k >> 1] = u64x2{v[g * (1 << RF) + k], v[g * (1 << RF) + k + 1]};
+  }
+}
+
 template <typename F>
 static float time_ms(F f, int reps = 10) {
   hipEvent_t a, b;
@@ -125,6 +162,20 @@ int main() {
       printf("chunk 64KB copy nt   rounds %2d: %7.3f ms  %5.2f TB/s (read + write)\n", rounds, ms, tb(2.0 * bytes, ms));
       ms = time_ms([&] { k_chunk<16, false><<<chunks, 512>>>((const u64*)dst, (u64*)dst, rounds); });
       printf("chunk 64KB in place  rounds %2d: %7.3f ms  %5.2f TB/s (read + write)\n", rounds, ms, tb(2.0 * bytes, ms));
+    }
+    {
+      float ms = time_ms([&] { k_chunk_runs<16, 1><<<chunks, 512>>>((const u64*)src, (u64*)dst); });
+      printf("chunk 64KB, loads in runs of 2 : %7.3f ms  %5.2f TB/s (read + write)\n", ms, tb(2.0 * bytes, ms));
+      ms = time_ms([&] { k_chunk_runs<16, 2><<<chunks, 512>>>((const u64*)src, (u64*)dst); });
+      printf("chunk 64KB, loads in runs of 4 : %7.3f ms  %5.2f TB/s (read + write)\n", ms, tb(2.0 * bytes, ms));
+      ms = time_ms([&] { k_chunk_runs<16, 3><<<chunks, 512>>>((const u64*)src, (u64*)dst); });
+      printf("chunk 64KB, loads in runs of 8 : %7.3f ms  %5.2f TB/s (read + write)\n", ms, tb(2.0 * bytes, ms));
+      ms = time_ms([&] { k_chunk_runs<16, 4><<<chunks, 512>>>((const u64*)src, (u64*)dst); });
+      printf("chunk 64KB, loads in runs of 16: %7.3f ms  %5.2f TB/s (read + write)\n", ms, tb(2.0 * bytes, ms));
+      ms = time_ms([&] { k_chunk_run_stores<16, 2><<<chunks, 512>>>((const u64*)src, (u64*)dst); });
+      printf("chunk 64KB, stores in runs of 4: %7.3f ms  %5.2f TB/s (read + write)\n", ms, tb(2.0 * bytes, ms));
+      ms = time_ms([&] { k_chunk_run_stores<16, 4><<<chunks, 512>>>((const u64*)src, (u64*)dst); });
+      printf("chunk 64KB, stores in runs of 16: %7.3f ms  %5.2f TB/s (read + write)\n", ms, tb(2.0 * bytes, ms));
     }
     // 32 KB chunks at 256 threads (the edge kernels' workgroup size)
     const int chunks2 = (int)(bytes / (256 * 16 * 8));
