@@ -479,16 +479,24 @@ int Evaluator::relinearize(const u64* ct3, const KeySel& rk, u64* out2, size_t c
   return watch ? note_result(out2, 2, K, count, s) : (int)kOk;
 }
 
-int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend) {
+// the all-FP64 fused multiply + relinearize (every SEAL default set up to N = 16384) would run for a batch of `count`
+bool Evaluator::member_tail_ok(size_t count) const {
+  const DevCtx& h = ctx_->host();
+  const u32 kneed = std::max(h.K, h.S > 2 ? h.S - 2 : 0u);
+  return fuse_mulrelin_ && split_mul_ && split_ks_ && h.aux_f64 && h.ks_split_ok && h.ks_ni == 0 && kneed <= 8 && h.logn >= 12 && h.logn <= 14 && !few_for_fused(count);
+}
+
+int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend, const MemberTail* members,
+                              u32 per) {
   const DevCtx& h = ctx_->host();
   if (h.KK < 2 || !rk.present()) return kNoKey;
+  if (members && (!member_tail_ok(count) || !per || addend)) return kInvalidArg;
   const u32 n = h.n, K = h.K, KK = h.KK, S = h.S, R = K + S;
   const size_t cs = (size_t)3 * K * n, c2 = (size_t)2 * K * n;
   const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
   // Fused pipeline (all-FP64 contexts: every SEAL default set up to N = 16384): six launches; the product's c0 and c1 are
   // formed inside the last one (mulrelin_tail_kernel) and only c2 -- the key-switch target -- is written by mul_tail.
-  const bool fused_d = fuse_mulrelin_ && split_mul_ && split_ks_ && h.aux_f64 && h.ks_split_ok && h.ks_ni == 0 && kneed <= 8 && h.logn >= 12 && h.logn <= 14 &&
-                       !few_for_fused(count);
+  const bool fused_d = member_tail_ok(count);
   // r06: the same five launches for MIXED contexts (integer-policy data / key primes beside the library's FP64 auxiliary base: the
   // 3 x 54-bit set): mulrelin_head_mixed / mulrelin_tail_mixed, 8-byte rows, one or two middle launches per policy
   const bool fused_m = !fused_d && fuse_mulrelin_ && fuse_head_ && split_mul_ && split_ks_ && !h.aux_f64 && h.aux_mixed && h.ks_split_ok && kneed <= 4 &&
@@ -531,9 +539,9 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64*
       }
       HB_LAUNCH(kKernKsMid, c, launch_ks_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, h, T, rk.key, ACC, c, s, kl.at(off)));
       HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail(ctx_->dev(), h.tw_inv, h.logn, (int)h.pack_mul, h.conv_grid != 0, (int)h.pack_ks, kneed, D, ACC,
-                                                    addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s));
+                                                    addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s, members, (u32)off, per));
     }
-    return note_result(out2, 2, K, count, s);
+    return members ? (int)kOk : note_result(out2, 2, K, count, s);
   }
   const size_t chunk = chunk_ops_;
   ScratchGuard sg(pool_, std::min(chunk, count) * cs * sizeof(u64), s);

@@ -178,7 +178,12 @@ class Evaluator {
   // addend (optional, the three key-switching operations): ciphertexts u64[count][2][K][N] added to the results inside the last kernel
   // rk / key: one key for the whole batch (a device pointer converts) or a per-item selection (KeySel above)
   int relinearize(const u64* ct3, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr, bool watch = true);
-  int multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
+  // members / per (program executor, merged launches): a DEVICE table of per-member epilogues (kernels.hpp MemberTail) -- item i belongs to
+  // member i / per and is written to that member's own buffer as mult * product + sign * extra; out2 and addend are unused then, and
+  // the caller notes the results itself.  Only where member_tail_ok(count) says so (the all-FP64 fused path).
+  int multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr,
+                     const MemberTail* members = nullptr, u32 per = 0);
+  bool member_tail_ok(size_t count) const;
   // out2 = (sigma_g(c0), 0) + switch_key(sigma_g(c1), key)
   int apply_galois(const u64* ct2, u32 galois_elt, const KeySel& key, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);
   int mod_switch_next(const u64* ct, u32 size, u64* out, size_t count, hipStream_t s);  // out has K-1 residues per polynomial

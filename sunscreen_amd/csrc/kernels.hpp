@@ -72,8 +72,18 @@ hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool a
                            size_t ops, hipStream_t s, u32 poly0 = 0, u32 npolys = 3);
 hipError_t launch_mulrelin_head(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, int pack_mul, bool conv_grid, int pack_ks, u32 kneed,
                                 const u64* D, u64* T, size_t ops, hipStream_t s);
+// Per-member epilogue of a MERGED multiply + relinearize launch (the graph executor's members x batch items): item i of the launch is
+// item (first + i) % per of member (first + i) / per, and the last kernel writes  mult * product + sign * extra  (mod q, canonical)
+// into that member's own buffer -- the Add / Sub chain around a product (examples/chi_sq: 2 x^2, 4 n0 n2 - n1^2) without a pass of
+// its own, and program outputs written where the caller wants them.  A device table; all-FP64 fused path only (mulrelin_tail_kernel).
+struct MemberTail {
+  u64* out;          // u64[per][2][K][N]
+  const u64* extra;  // u64[per][2][K][N]; nullptr with sign == 0
+  u32 mult;          // 1 ... 4
+  int sign;          // -1, 0, +1
+};
 hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, int pack_ks, u32 kneed, const u64* D,
-                                const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s);
+                                const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s, const MemberTail* members = nullptr, u32 first = 0, u32 per = 0);
 // the same two kernels for MIXED contexts (integer-policy data / key primes + the FP64 auxiliary base, K <= 4)
 hipError_t launch_mulrelin_head_mixed(const DevCtx* ctx, const MulOp* twi, const MulOp* twf, u32 logn, const u64* D, u64* T, size_t ops, hipStream_t s);
 hipError_t launch_mulrelin_tail_mixed(const DevCtx* ctx, const MulOp* twi, u32 logn, const u64* D, const u64* ACC, const u64* extra, u64* out2, size_t ops,

@@ -2315,7 +2315,8 @@ __global__ EDGE_BOUNDS(KMAX) void mul_tail_kernel(const DevCtx* __restrict__ ctx
 template <int L, int KMAX, int PACKM, bool GRID, bool PACKK>
 __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twi_base,
                                                                      const u64* __restrict__ D, const double* __restrict__ ACC,
-                                                                     const u64* __restrict__ extra, u64* __restrict__ out) {
+                                                                     const u64* __restrict__ extra, u64* __restrict__ out,
+                                                                     const MemberTail* __restrict__ members, u32 mfirst, u32 mper) {
   using G = EdgeGeom<L>;
   constexpr u32 N = 1u << L;
   const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
@@ -2324,9 +2325,25 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
   double basev[KMAX][4];  // c0 / c1 of the product: canonical integers, as doubles (the mod-down adds them in FP64)
   mul_tail_compute_d<L, KMAX, PACKM, GRID>(ctx, twi_base, D + ((size_t)op * 3 + c) * R * N, t, basev);
   const double* acc = ACC + ((size_t)op * 2 + c) * KK * N;
+  // a member table (kernels.hpp MemberTail; the graph executor's merged launches): this item's own output buffer, multiplier and signed
+  // addend -- wave-uniform, scalar loads
+  const u64* ex_base = extra + ((size_t)op * 2 + c) * K * N;
+  u64* out_base = out + ((size_t)op * 2 + c) * K * N;
+  bool has_ex = extra != nullptr;
+  double mmult = 1.0, msign = 1.0;
+  if (members) {
+    const u32 it = mfirst + op, mem = it / mper;
+    const size_t at = ((size_t)(it - mem * mper) * 2 + c) * K * N;
+    const MemberTail mt = members[mem];
+    out_base = mt.out + at;
+    ex_base = mt.extra + at;
+    has_ex = mt.sign != 0;
+    mmult = (double)mt.mult;
+    msign = (double)mt.sign;
+  }
   // buffer addressing (BufRow): the accumulator rows, the optional addend and the output
-  const BufRsrc racc = buf_rsrc(acc), rout = buf_rsrc(out + ((size_t)op * 2 + c) * K * N);
-  const BufRsrc rex = buf_rsrc_opt(extra + ((size_t)op * 2 + c) * K * N, extra != nullptr);
+  const BufRsrc racc = buf_rsrc(acc), rout = buf_rsrc(out_base);
+  const BufRsrc rex = buf_rsrc_opt(ex_base, has_ex);
   double tld[4];
   {
     const DevMod& sp = ctx->mod[KK - 1];
@@ -2372,11 +2389,22 @@ __global__ EDGE_BOUNDS(KMAX) void mulrelin_tail_kernel(const DevCtx* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; k++) s[k] = ar.reduce(s[k]);
       }
+      if (members) {
+        // mult * (c_J of the relinearised product) + sign * addend: |.| <= 4q + q < 2^53, an exact integer, reduced once more
+        HIPBFV_KEEP_BRANCH();
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const double bd = basev[J][k] + ArithD::from_u64(ex[k]);  // (an absent addend reads as 0)
-        const double r = mod_down_d(ar.q, ar.qinv, iw.w, iw.wq, hf, p_above_q, s[k], tld[k], bd);  // moddown_d.hpp
-        st_tail_out<L>(buf_row(rout, (size_t)J * N), t, k, ArithD::to_bits(r));
+        for (int k = 0; k < 4; k++) {
+          const double r0 = mod_down_d(ar.q, ar.qinv, iw.w, iw.wq, hf, p_above_q, s[k], tld[k], basev[J][k]);
+          const double r1 = ar.reduce(fma(mmult, r0, msign * ArithD::from_u64(ex[k])));
+          st_tail_out<L>(buf_row(rout, (size_t)J * N), t, k, ArithD::to_bits(r1 < 0.0 ? r1 + ar.q : r1));
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const double bd = basev[J][k] + ArithD::from_u64(ex[k]);  // (an absent addend reads as 0)
+          const double r = mod_down_d(ar.q, ar.qinv, iw.w, iw.wq, hf, p_above_q, s[k], tld[k], bd);  // moddown_d.hpp
+          st_tail_out<L>(buf_row(rout, (size_t)J * N), t, k, ArithD::to_bits(r));
+        }
       }
     }
 #pragma unroll
@@ -2957,10 +2985,10 @@ hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool a
 
 template <int L>
 static hipError_t mulrelin_tail_t(const DevCtx* ctx, const MulOp* twi, int pack_mul, bool conv_grid, int pack_ks, u32 kneed, const u64* D, const u64* ACC,
-                                  const u64* extra, u64* out2, size_t ops, hipStream_t s) {
+                                  const u64* extra, u64* out2, size_t ops, hipStream_t s, const MemberTail* members, u32 mfirst, u32 mper) {
   const dim3 grid((1u << L) / 4 / kHeadThreads, 2, (unsigned)ops);
   const double* acc = reinterpret_cast<const double*>(ACC);
-#define MRT(KM, PM, GR, PK) mulrelin_tail_kernel<L, KM, PM, GR, PK><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, acc, extra, out2)
+#define MRT(KM, PM, GR, PK) mulrelin_tail_kernel<L, KM, PM, GR, PK><<<grid, kHeadThreads, 0, s>>>(ctx, twi, D, acc, extra, out2, members, mfirst, mper)
 // (pack_ks == 2, per key prime: the rows of T only -- the accumulator rows are doubles)
 #define MRT_K(KM, PM, GR) do { if (pack_ks == 1) MRT(KM, PM, GR, true); else MRT(KM, PM, GR, false); } while (0)
   if (kneed > 4) {
@@ -3034,8 +3062,9 @@ hipError_t launch_mulrelin_tail_mixed(const DevCtx* ctx, const MulOp* twi, u32 l
 }
 
 hipError_t launch_mulrelin_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack_mul, bool conv_grid, int pack_ks, u32 kneed, const u64* D,
-                                const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s) {
-  SPLIT_DISPATCH(mulrelin_tail_t, ctx, twi, pack_mul, conv_grid, pack_ks, kneed, D, ACC, extra, out2, ops, s)
+                                const u64* ACC, const u64* extra, u64* out2, size_t ops, hipStream_t s, const MemberTail* members, u32 first, u32 per) {
+  if (members && (!per || extra)) return hipErrorInvalidValue;
+  SPLIT_DISPATCH(mulrelin_tail_t, ctx, twi, pack_mul, conv_grid, pack_ks, kneed, D, ACC, extra, out2, ops, s, members, first, per)
 }
 
 }  // namespace hipbfv

@@ -34,6 +34,7 @@
 #include <functional>
 #include <iterator>
 #include <map>
+#include <set>
 #include <unordered_map>
 
 #include "program.hpp"
@@ -64,12 +65,20 @@ struct Program::Plan {
   struct Fold {  // an Add that can ride in this key-switching member's last kernel when the member runs unmerged
     int nary_step = -1, nary_member = -1, other_slot = -1;
   };
+  // r06: a whole Add / Sub chain around a fused product -- the sum U = mult * product + sign * other, the product used by nothing else --
+  // that the product's last kernel can write in the product's place (kernels.hpp MemberTail): examples/chi_sq's 2 x^2, 2 y^2 and
+  // 4 n0 n2 - n1^2.  Decided at run time like Fold (the evaluator must run the all-FP64 fused path); the sum's own step skips it then.
+  struct LinFold {
+    int mult = 0, sign = 0, other_slot = -1;
+    int nary_step = -1, nary_member = -1;
+  };
   struct Step {
     int kind = 0;
     std::vector<int> node;   // member -> graph node (diagnostics, literal lookup)
     std::vector<int> out;    // member -> output slot
     std::vector<int> a, b;   // member -> operand slots (b: second factor; -1 when unused)
     std::vector<Fold> fold;  // key-switching kinds: per member
+    std::vector<LinFold> lin;  // kStepMulRelin: per member (mult == 0: none)
     // kStepNary
     std::vector<u32> first;  // member -> offset into terms (size = members + 1)
     std::vector<Term> terms;
@@ -128,6 +137,10 @@ std::shared_ptr<const Program::Plan> Program::plan() const {
         uses[src]++;
         user0[src] = i;
       }
+  std::vector<std::vector<int>> users(nn);  // every user, once per operand slot
+  for (int i = 0; i < nn; i++)
+    for (int src : {nodes_[i].left, nodes_[i].right})
+      if (src >= 0) users[src].push_back(i);
   auto is_linear = [&](int i) { return nodes_[i].op == kOpAdd || nodes_[i].op == kOpSub || nodes_[i].op == kOpNegate; };
   for (int id : order) {
     const Node& nd = nodes_[id];
@@ -275,10 +288,23 @@ std::shared_ptr<const Program::Plan> Program::plan() const {
     const TailMap* m = tail_of(node);
     return !m || m->empty();
   };
+  std::vector<int> absorbed_into(nn, -1);  // linear node -> the linear node that took its terms
   for (int id : order) {
     if (!is_linear(id)) continue;
     const Node& nd = nodes_[id];
     Lin& me = lin[id];
+    // r06: x + x for a linear x that nothing else uses (chi_sq: t = p + p, then t + t): both operand slots of this Add are the node's
+    // only two uses -- its terms are taken twice (the executor lists repeated terms one by one; modular addition: same bits)
+    if (nd.op == kOpAdd && nd.left == nd.right && is_linear(nd.left) && uses[nd.left] == 2 && !virt[nd.left] && !cancels(nd.left, lin[nd.left])) {
+      Lin& o = lin[nd.left];
+      for (int rep = 0; rep < 2; rep++)
+        for (auto& p : o.t) me.t.push_back(p);
+      me.sum += 2 * o.sum;
+      std::vector<std::pair<int, int>>().swap(o.t);
+      virt[nd.left] = 1;
+      absorbed_into[nd.left] = id;
+      continue;
+    }
     auto take = [&](int src, int sign) {
       // absorb a linear operand whose only user is this node and whose tail does not vanish identically
       if (is_linear(src) && uses[src] == 1 && !virt[src] && !cancels(src, lin[src])) {
@@ -287,6 +313,7 @@ std::shared_ptr<const Program::Plan> Program::plan() const {
         me.sum += o.sum * sign;
         std::vector<std::pair<int, int>>().swap(o.t);
         virt[src] = 1;
+        absorbed_into[src] = id;
       } else {
         me.t.push_back({src, sign});
         me.sum += sign;
@@ -529,6 +556,88 @@ std::shared_ptr<const Program::Plan> Program::plan() const {
         return fail(kInvalidArg, "unsupported operation");
       }
     }
+    // ---- r06: linear folds of fused products (Plan::LinFold) ----
+    // U = the one sum root every use of the product ends in; U's terms = mult copies of the product (all +1, mult <= 4) and at most
+    // one other ciphertext (sign +-1, size 2) that exists when the product's launch runs: made in an earlier round, or by another
+    // group of THIS round -- the groups are then ordered producer first.  Two products never share a U.
+    {
+      const size_t ng = groups.size();
+      std::vector<int> group_of(nn, -1);
+      for (size_t gi = 0; gi < ng; gi++)
+        for (int id : groups[gi].node) group_of[id] = (int)gi;
+      std::vector<std::vector<int>> before(ng);  // before[g]: groups whose results g's folds read
+      std::set<int> claimed;
+      for (size_t gi = 0; gi < ng; gi++) {
+        Plan::Step& g = groups[gi];
+        if (g.kind != kStepMulRelin) continue;
+        g.lin.assign(g.node.size(), Plan::LinFold());
+        for (size_t m = 0; m < g.node.size(); m++) {
+          const int id = g.node[m];
+          int U = -1;
+          bool ok = !users[id].empty();
+          for (int u : users[id]) {
+            if (!is_linear(u)) {
+              ok = false;
+              break;
+            }
+            int r = u;
+            while (absorbed_into[r] >= 0) r = absorbed_into[r];
+            if (U >= 0 && r != U) ok = false;
+            U = r;
+          }
+          if (!ok || U < 0 || virt[U] || lincomb[U] || size[U] != 2 || claimed.count(U)) continue;
+          int mult = 0, other = -1, osign = 0;
+          for (auto& p : lin[U].t) {
+            if (p.first == id) {
+              if (p.second != 1) ok = false;
+              mult++;
+            } else if (other < 0) {
+              other = p.first, osign = p.second;
+            } else {
+              ok = false;
+            }
+          }
+          if (!ok || mult < 1 || mult > 4 || (mult == 1 && other < 0)) continue;
+          if (other >= 0) {
+            if (size[other] != 2 || ty[other] != kTyCt) continue;
+            if (!done[other]) {
+              const int og = group_of[other];
+              if (og < 0 || og == (int)gi) continue;  // not made yet, or made by this very launch
+              before[gi].push_back(og);
+            }
+          }
+          claimed.insert(U);
+          g.lin[m].mult = mult;
+          g.lin[m].sign = other >= 0 ? osign : 0;
+          g.lin[m].other_slot = other >= 0 ? slot[other] : -1;
+          g.lin[m].nary_member = U;  // node id for now; resolved to (step, member) after the sum is scheduled
+        }
+      }
+      // producer-first order (stable); a cycle drops the folds that caused it
+      std::vector<size_t> ord;
+      std::vector<char> placed(ng, 0);
+      while (ord.size() < ng) {
+        bool any = false;
+        for (size_t gi = 0; gi < ng; gi++) {
+          if (placed[gi]) continue;
+          bool free = true;
+          for (int b : before[gi]) free = free && placed[b];
+          if (!free) continue;
+          placed[gi] = 1, ord.push_back(gi), any = true;
+        }
+        if (!any) {
+          for (size_t gi = 0; gi < ng; gi++)
+            if (!placed[gi]) {
+              for (auto& lf : groups[gi].lin)
+                if (lf.other_slot >= 0) lf = Plan::LinFold();
+              before[gi].clear();
+            }
+        }
+      }
+      std::vector<Plan::Step> sorted;
+      for (size_t gi : ord) sorted.push_back(std::move(groups[gi]));
+      groups.swap(sorted);
+    }
     for (auto& g : groups) {
       const int sidx = (int)P->steps.size();
       if (g.kind == kStepMulRelin || g.kind == kStepRelin || g.kind == kStepGalois) {
@@ -562,6 +671,14 @@ std::shared_ptr<const Program::Plan> Program::plan() const {
         f.nary_step = nary_step_of[u];
         f.nary_member = nary_member_of[u];
         if (f.nary_step < 0) f = Plan::Fold();
+      }
+  for (auto& st : P->steps)
+    for (auto& f : st.lin)
+      if (f.mult) {
+        const int u = f.nary_member;
+        f.nary_step = nary_step_of[u];
+        f.nary_member = nary_member_of[u];
+        if (f.nary_step < 0) f = Plan::LinFold();
       }
 
   // ---- release lists: the last step that reads each slot ----
@@ -606,6 +723,9 @@ int Program::describe(std::string* out) const {
     size_t folds = 0;
     for (auto& f : st.fold) folds += f.other_slot >= 0;
     if (folds) t += " add_foldable=" + std::to_string(folds);
+    size_t lins = 0;
+    for (auto& f : st.lin) lins += f.mult != 0;
+    if (lins) t += " lin_foldable=" + std::to_string(lins);
     size_t direct = 0;
     for (int sl : st.out) direct += sl >= 0 && P.slot_direct[sl] >= 0;
     if (direct && st.kind != kStepOutput) t += " direct_outputs=" + std::to_string(direct);
@@ -956,6 +1076,10 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
     const char* e = std::getenv("HIPBFV_PIR_OVERLAP");
     return e && e[0] == '1';
   }();
+  const bool member_tails = [] {  // HIPBFV_NO_MEMBER_TAILS=1: the sums around fused products as launches of their own (the cross-check arm)
+    const char* e = std::getenv("HIPBFV_NO_MEMBER_TAILS");
+    return !(e && e[0] == '1');
+  }();
   auto side_stream = [&]() -> hipStream_t {
     thread_local hipStream_t streams[16] = {};
     int dev = 0;
@@ -1098,6 +1222,49 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
         const u32 in_size = st.kind == kStepRelin ? st.out_size : 2;
         const size_t in_words = batch * in_size * poly, out_words = batch * 2 * poly;
         const bool direct_ks = is_mul || (st.kind == kStepRelin && in_size == 3) || (is_rot && gkey.present());
+        // r06: products with a linear fold (Plan::LinFold) or a caller's buffer to write take each member's destination, multiplier and
+        // signed addend from a table in their last kernel (kernels.hpp MemberTail): the sums around the products and the copies into the
+        // outputs cost no pass of their own (examples/chi_sq: 2 x^2, 2 y^2, 4 n0 n2 - n1^2, x y).  Members [m0, m1) in one launch.
+        auto has_lin = [&](size_t m) { return !st.lin.empty() && st.lin[m].mult != 0; };
+        auto tail_launch = [&](size_t m0, size_t m1) -> int {
+          const size_t cnt = m1 - m0;
+          const std::vector<int> sa(st.a.begin() + m0, st.a.begin() + m1), sb(st.b.begin() + m0, st.b.begin() + m1);
+          const u64 *A = nullptr, *B2 = nullptr;
+          if (int r = as_array(sa, in_words, &A)) return r;
+          if (!st.square)
+            if (int r = as_array(sb, in_words, &B2)) return r;
+          std::vector<MemberTail> tab(cnt);
+          for (size_t m = m0; m < m1; m++) {
+            const Plan::LinFold* lf = has_lin(m) ? &st.lin[m] : nullptr;
+            const int target = lf ? P.steps[lf->nary_step].out[lf->nary_member] : st.out[m];
+            u64* o = alloc_member(target);  // the caller's buffer when the value is a program output
+            if (!o) return (int)kOutOfMemory;
+            if (lf) {
+              bind(st.out[m], block_of[target], o);  // (nothing reads the bare product: every use of it is inside the sum)
+              auto& v = folded_into[lf->nary_step];
+              if (v.empty()) v.assign(P.steps[lf->nary_step].node.size(), -1);
+              v[lf->nary_member] = st.out[m];
+            }
+            const bool has_other = lf && lf->other_slot >= 0;
+            tab[m - m0] = MemberTail{o, has_other ? sp[lf->other_slot] : nullptr, lf ? (u32)lf->mult : 1u, has_other ? lf->sign : 0};
+          }
+          const MemberTail* dtab = (const MemberTail*)stage_table(tab.data(), tab.size() * sizeof(MemberTail));
+          if (!dtab) return (int)kOutOfMemory;
+          KeySel sub = relin_key;  // (member-major item numbering: member m0's items start at m0 * batch)
+          sub.first = relin_key.first + m0 * batch;
+          int r = ev.multiply_relin(A, st.square ? A : B2, sub, nullptr, cnt * batch, s, nullptr, dtab, (u32)batch);
+          for (size_t m = 0; m < cnt && !r; m++) r = ev.note_result(tab[m].out, 2, (u32)K, batch, s);
+          return r;
+        };
+        const bool tails_on = is_mul && !side_consumer && member_tails;
+        if (tails_on && small && members > 1 && members <= 8 && ev.member_tail_ok(members * batch)) {
+          bool wanted = false;
+          for (size_t m = 0; m < members; m++) wanted = wanted || has_lin(m) || P.slot_direct[st.out[m]] >= 0;
+          if (wanted) {
+            rc = tail_launch(0, members);
+            break;
+          }
+        }
         if (small && members > 1 && direct_ks) {
           // ONE launch sequence over members x batch ciphertexts
           const u64 *A = nullptr, *B2 = nullptr;
@@ -1131,6 +1298,10 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
           break;
         }
         for (size_t m = 0; m < members && !rc; m++) {
+          if (tails_on && has_lin(m) && !(small && members > 1) && ev.member_tail_ok(batch)) {  // (a merged launch has no tables: whole or not at all)
+            rc = tail_launch(m, m + 1);
+            continue;
+          }
           const u64* addend = direct_ks ? try_fold(st, m) : nullptr;
           u64* out = addend ? alloc_for_fold(st, m) : alloc_member(st.out[m]);
           if (!out) return cleanup(kOutOfMemory, "out of device memory");

@@ -562,3 +562,66 @@ def test_one_program_object_run_from_several_threads():
     [x.start() for x in ths]
     [x.join() for x in ths]
     assert not errors, errors
+
+
+@pytest.mark.parametrize("name", ["default_4096_16", "default_16384_17"])
+def test_sums_around_products_ride_in_the_products_last_kernel(name, monkeypatch):
+    """r06, Plan::LinFold / kernels.hpp MemberTail: mult * (x * y) +- z written by the fused multiply + relinearize's last kernel --
+    the reference adds node by node (sunscreen_runtime/src/run.rs:130-176: Add / Sub each a SEAL call), modular sums give the same
+    bits in any grouping.  Every fold shape (multipliers 2 ... 4, a subtracted addend, an addend made by ANOTHER launch of the same
+    round, a product that is itself a program output beside a folded one, no addend) and the shapes that must NOT fold (five copies,
+    a negated product), at a merged batch (2: members x batch items in one launch, per-member destinations) and at an unmerged one
+    (40) -- against the oracle interpreter, the node-by-node executor and the scheduled one with the folds switched off."""
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.program import FheProgram
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx(name)
+
+    def mul(p, a, b):
+        return p.append_relinearize(p.append_multiply(a, b))
+
+    p = FheProgram()
+    x, y, z = (p.append_input_ciphertext(i) for i in range(3))
+    xy = mul(p, x, y)
+    o1 = p.append_sub(p.append_add(p.append_add(xy, xy), xy), z)            # 3 x y - z
+    zz = mul(p, z, z)
+    o2 = p.append_add(zz, zz)                                              # 2 z^2 (a square; no addend)
+    yz = mul(p, y, z)
+    t = p.append_add(yz, yz)
+    xx = mul(p, x, x)
+    o3 = p.append_sub(p.append_add(t, t), xx)                              # 4 y z - x^2: the addend is made by the squares' launch
+    o4 = mul(p, x, z)                                                      # a plain product beside the folded ones (merged: its own buffer)
+    xz2 = mul(p, z, x)
+    t2 = p.append_add(xz2, xz2)
+    o5 = p.append_add(p.append_add(t2, t2), xz2)                           # five copies: an ordinary sum
+    o6 = p.append_sub(x, mul(p, y, y))                                     # x - y^2: the product is negated -- no fold
+    o7 = p.append_add(mul(p, y, x), x)                                     # x y + x (the old two-term fold's shape)
+    for node in (o1, o2, o3, o4, o5, o6, o7, xx):
+        p.append_output_ciphertext(node)
+    desc = p.describe()
+    assert sum(int(l.split("lin_foldable=")[1].split()[0]) for l in desc if "lin_foldable" in l) == 4, desc
+    rng = np.random.default_rng(9)
+    for batch in (2, 40):
+        vals = rng.integers(0, 5, (3, batch, o.n)).astype(np.uint64)
+        cts = [np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vals[a]]) for a in range(3)]
+        if batch > 2:  # every residue of one operand at its maximum / at zero: the epilogue's range (mult * (q - 1) + (q - 1))
+            cts[2][1, :, :, :] = (np.array(o.primes[: o.K], dtype=np.uint64) - 1)[None, :, None]
+        dev = [to_device(c) for c in cts]
+        monkeypatch.delenv("HIPBFV_PROGRAM_SERIAL", raising=False)
+        monkeypatch.delenv("HIPBFV_NO_MEMBER_TAILS", raising=False)
+        got = [to_host(t_) for t_ in p.run(ev, dev, rkd, gkd)]
+        monkeypatch.setenv("HIPBFV_NO_MEMBER_TAILS", "1")
+        plain = [to_host(t_) for t_ in p.run(ev, dev, rkd, gkd)]
+        monkeypatch.delenv("HIPBFV_NO_MEMBER_TAILS", raising=False)
+        monkeypatch.setenv("HIPBFV_PROGRAM_SERIAL", "1")
+        serial = [to_host(t_) for t_ in p.run(ev, dev, rkd, gkd)]
+        monkeypatch.delenv("HIPBFV_PROGRAM_SERIAL", raising=False)
+        for k in range(len(got)):
+            assert (got[k] == plain[k]).all() and (got[k] == serial[k]).all(), (name, batch, k)
+        for i in (0, 1):
+            ref = run_program(o, p.nodes, p.edges, [c[i] for c in cts], rk, gk)
+            for k in range(len(got)):
+                assert (got[k][i] == ref[k]).all(), (name, batch, i, k)
+        a, b, c = (vals[j][0].astype(np.int64) for j in range(3))
+        assert (o.batch_decode(o.decrypt(got[0][0], sk)) == (3 * a * b - c) % o.t).all()
+        assert (o.batch_decode(o.decrypt(got[2][0], sk)) == (4 * b * c - a * a) % o.t).all()

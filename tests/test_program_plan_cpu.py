@@ -16,17 +16,62 @@ def test_chi_sq_levels_six_products_in_three_launch_groups():
     five products are ready at once: squares {n1^2, x^2, y^2} and general {n0 n2, x y}; alpha^2 follows.  Node by node that
     is six launch sequences, scheduled it is three."""
     lines = chi_sq_optimized().describe()
-    mr = [l.replace(" direct_outputs=1", "") for l in lines if l.startswith("mul_relin")]
-    assert mr == ["mul_relin members=3 square", "mul_relin members=2", "mul_relin members=1 square"], lines
+    mr = [l for l in lines if l.startswith("mul_relin")]
+    # r06: the sums AROUND the products ride in the products' last kernels (Plan::LinFold): 2 x^2 and 2 y^2 (program outputs), and
+    # 4 n0 n2 - n1^2 -- whose addend n1^2 is made by the squares' launch, so that group runs first
+    assert mr == ["mul_relin members=3 square lin_foldable=2", "mul_relin members=2 lin_foldable=1 direct_outputs=1",
+                  "mul_relin members=1 square direct_outputs=1"], lines
     # the Add / Sub chains are n-ary sums: x = n0 + n0 + n1 and y = n2 + n2 + n1 in one launch before any product ...
     sums = [l for l in lines if l.startswith("sum")]
     assert lines[0] == "sum members=2 terms=6", lines
-    # ... 2 n0n2, 2 x^2, 2 y^2 in one launch after the five products (the doubled n0n2 has two users, so it is a result of its
-    # own), then alpha's operand (2 n0n2) + (2 n0n2) - n1^2 as one three-term sum
-    assert sums[1].startswith("sum members=3 terms=6") and sums[2].startswith("sum members=1 terms=3"), lines
-    # program outputs are written by their producers where those run on their own (no copy)
-    assert sum("direct_outputs" in l for l in lines) >= 3, lines
+    # ... and ONE launch after the five products for whatever was not folded at run time: 2 x^2, 2 y^2 and p + p + p + p - n1^2 (the
+    # doubled n0 n2 is used twice by one Add only: its terms are taken twice instead of materialising it)
+    assert sums[1:] == ["sum members=3 terms=9 direct_outputs=2"], lines
     assert _kinds(lines).count("output") == 4
+
+
+def test_linear_folds_of_products():
+    """Plan::LinFold: mult copies (<= 4) of a fused product plus at most one other ciphertext, the product used by nothing else."""
+    def prog(build):
+        p = FheProgram()
+        x, y, z = (p.append_input_ciphertext(i) for i in range(3))
+        p.append_output_ciphertext(build(p, x, y, z))
+        return p.describe()
+
+    def mul(p, a, b):
+        return p.append_relinearize(p.append_multiply(a, b))
+
+    # 3 x y - z: foldable (the addend is a program input)
+    lines = prog(lambda p, x, y, z: p.append_sub(p.append_add(p.append_add(mul(p, x, y), mul(p, x, y)), mul(p, x, y)), z))
+    assert any("lin_foldable" in l for l in lines) is False, lines  # three DIFFERENT product nodes: three members, one sum
+    def tripled(p, x, y, z):
+        m = mul(p, x, y)
+        return p.append_sub(p.append_add(p.append_add(m, m), m), z)
+    lines = prog(tripled)
+    assert lines[0] == "mul_relin members=1 lin_foldable=1", lines
+    # five copies: beyond the kernel's multiplier range -- an ordinary sum
+    def five(p, x, y, z):
+        m = mul(p, x, y)
+        t = p.append_add(m, m)
+        return p.append_add(p.append_add(t, t), m)
+    assert not any("lin_foldable" in l for l in prog(five))
+    # the product has another user: it must exist on its own
+    def shared(p, x, y, z):
+        m = mul(p, x, y)
+        p.append_output_ciphertext(m)
+        return p.append_add(m, m)
+    assert not any("lin_foldable" in l for l in prog(shared))
+    # a negated product, or two other terms: not this pattern
+    assert not any("lin_foldable" in l for l in prog(lambda p, x, y, z: p.append_sub(z, mul(p, x, y))))
+    assert not any("lin_foldable" in l for l in prog(lambda p, x, y, z: p.append_add(p.append_add(mul(p, x, y), z), x)))
+    # two products into one sum, a square and a general one (two launch groups): one folds, reading the other -- which runs first
+    def two(p, x, y, z):
+        return p.append_add(mul(p, x, y), mul(p, z, z))
+    lines = prog(two)
+    assert [l for l in lines if l.startswith("mul_relin")] == ["mul_relin members=1 square", "mul_relin members=1 lin_foldable=1"], lines
+    # ... both in ONE group: the addend would be made by the same launch
+    lines = prog(lambda p, x, y, z: p.append_add(mul(p, x, y), mul(p, x, z)))
+    assert not any("lin_foldable" in l for l in lines), lines
 
 
 def test_dot_product_rotations_keep_their_foldable_adds():

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6 evidence, step 1 (GPU): on the FINAL sources -- the whole suite, the eight switch suites, PMC passes + kernel traces of the seven
+# round 6 evidence, step 1 (GPU): on the FINAL sources -- the whole suite, the nine switch suites, PMC passes + kernel traces of the seven
 # PMC workloads (chi_sq and dot_prod included: VERDICT r04 #5), the stall / LDS passes of the three metric workloads, and the kernel
 # trace of the driver's default command.  Step 2 (container): tools/pmc_merge.sh r06_final <key> per key -> profiles/pmc_traffic.json.
 # Step 3 (GPU): tools/gpu_r06_final2.sh.

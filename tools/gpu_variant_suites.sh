@@ -10,7 +10,7 @@ run() {
   env $kv timeout 1500 python -m pytest ${TESTS:-tests} -m gpu -q -p no:cacheprovider > $OUT/pytest_$kv.log 2>&1
   echo "$kv: $(tail -1 $OUT/pytest_$kv.log)"
 }
-VARIANTS=${VARIANTS:-"HIPBFV_NO_F64=1 HIPBFV_SEAL_AUX=1 HIPBFV_NO_PACK=1 HIPBFV_NO_PACK=ks HIPBFV_PACK_ROWS=0 HIPBFV_NO_FUSED_TAIL=1 HIPBFV_NO_SMALL_BATCH=0 HIPBFV_NO_FUSED_GALOIS=1"}
+VARIANTS=${VARIANTS:-"HIPBFV_NO_F64=1 HIPBFV_SEAL_AUX=1 HIPBFV_NO_PACK=1 HIPBFV_NO_PACK=ks HIPBFV_PACK_ROWS=0 HIPBFV_NO_FUSED_TAIL=1 HIPBFV_NO_SMALL_BATCH=0 HIPBFV_NO_FUSED_GALOIS=1 HIPBFV_NO_MEMBER_TAILS=1"}
 n=0
 for v in $VARIANTS; do
   run $v &
