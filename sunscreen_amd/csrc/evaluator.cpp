@@ -487,10 +487,11 @@ bool Evaluator::member_tail_ok(size_t count) const {
 }
 
 int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend, const MemberTail* members,
-                              u32 per) {
+                              u32 per, const MemberHead* heads, bool heads_square) {
   const DevCtx& h = ctx_->host();
   if (h.KK < 2 || !rk.present()) return kNoKey;
   if (members && (!member_tail_ok(count) || !per || addend)) return kInvalidArg;
+  if (heads && !members) return kInvalidArg;
   const u32 n = h.n, K = h.K, KK = h.KK, S = h.S, R = K + S;
   const size_t cs = (size_t)3 * K * n, c2 = (size_t)2 * K * n;
   const u32 kneed = std::max(K, S > 2 ? S - 2 : 0u);
@@ -502,7 +503,7 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64*
   const bool fused_m = !fused_d && fuse_mulrelin_ && fuse_head_ && split_mul_ && split_ks_ && !h.aux_f64 && h.aux_mixed && h.ks_split_ok && kneed <= 4 &&
                        h.logn >= 12 && h.logn <= 14 && !lane_split((int)h.logn) && !few_for_fused(count);
   const bool fused = fused_d || fused_m;
-  const bool square = fused && a == b;  // x * x: the head extends and the middle kernel transforms x once
+  const bool square = fused && (heads ? heads_square : a == b);  // x * x: the head extends and the middle kernel transforms x once
   if (fused) {
     const size_t ext_words = (size_t)4 * R * n, d_words = (size_t)3 * R * n, t_words = (size_t)KK * K * n, acc_words = (size_t)2 * KK * n, c2_words = (size_t)K * n;
     const size_t per_op = ext_words + d_words + t_words + acc_words + c2_words;
@@ -529,7 +530,7 @@ int Evaluator::multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64*
         HB_LAUNCH(kKernKsTail, c, launch_mulrelin_tail_mixed(ctx_->dev(), h.tw_inv, h.logn, D, ACC, addend ? addend + off * c2 : nullptr, out2 + off * c2, c, s));
         continue;
       }
-      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, (int)h.pack_mul | (h.conv_grid == 1 ? 4 : 0), kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u));
+      HB_LAUNCH(kKernMulHead, c * (square ? 2 : 4), launch_mul_head(ctx_->dev(), h.tw_fwd, h.logn, true, (int)h.pack_mul | (h.conv_grid == 1 ? 4 : 0), kneed, a + off * c2, b + off * c2, ext, c, s, square ? 2u : 4u, heads, (u32)off, per));
       HB_LAUNCH(kKernMulMid, c, launch_mul_mid(ctx_->dev(), h.tw_fwd, h.tw_inv, h.logn, ctx_->dev()->mid_res_dp, h.mid_ndp, ctx_->dev()->mid_res_d, h.mid_nd, ctx_->dev()->mid_res_i, h.mid_ni, ext, D, c, s, square));
       if (fuse_head_) {
         HB_LAUNCH(kKernKsHead, c, launch_mulrelin_head(ctx_->dev(), h.tw_inv, h.tw_fwd, h.logn, (int)h.pack_mul, h.conv_grid != 0, (int)h.pack_ks, kneed, D, T, c, s));

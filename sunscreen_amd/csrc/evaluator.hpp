@@ -181,8 +181,10 @@ class Evaluator {
   // members / per (program executor, merged launches): a DEVICE table of per-member epilogues (kernels.hpp MemberTail) -- item i belongs to
   // member i / per and is written to that member's own buffer as mult * product + sign * extra; out2 and addend are unused then, and
   // the caller notes the results itself.  Only where member_tail_ok(count) says so (the all-FP64 fused path).
+  // heads (with members): the members' operands where they are (kernels.hpp MemberHead) -- a and b are unused then, `square` says whether every
+  // member multiplies a ciphertext by itself
   int multiply_relin(const u64* a, const u64* b, const KeySel& rk, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr,
-                     const MemberTail* members = nullptr, u32 per = 0);
+                     const MemberTail* members = nullptr, u32 per = 0, const MemberHead* heads = nullptr, bool heads_square = false);
   bool member_tail_ok(size_t count) const;
   // out2 = (sigma_g(c0), 0) + switch_key(sigma_g(c1), key)
   int apply_galois(const u64* ct2, u32 galois_elt, const KeySel& key, u64* out2, size_t count, hipStream_t s, const u64* addend = nullptr);

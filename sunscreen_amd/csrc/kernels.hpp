@@ -64,8 +64,14 @@ hipError_t launch_ks_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, 
 hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pack, bool mixed, const u64* ACC, const u64* base, size_t bstride, u32 base_mask, const u64* extra, u64* out2,
                           size_t ops, hipStream_t s, u32 ginv = 0);
 // split BEHZ multiply (2 x 2 -> 3), K <= 4
+// Per-member operands of a MERGED multiply launch (graph executor): item i of the launch is item (first + i) % per of member
+// (first + i) / per, whose two factors are read where they are (u64[per][2][K][N] each; b == a for a squaring launch) -- no gather
+struct MemberHead {
+  const u64* a;
+  const u64* b;
+};
 hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, int pack, u32 kneed, const u64* a, const u64* b, u64* ext, size_t ops,
-                           hipStream_t s, u32 npolys = 4);
+                           hipStream_t s, u32 npolys = 4, const MemberHead* members = nullptr, u32 first = 0, u32 per = 0);
 hipError_t launch_mul_mid(const DevCtx* ctx, const MulOp* twf, const MulOp* twi, u32 logn, const unsigned char* res_dp, u32 ndp, const unsigned char* res_d, u32 nd,
                           const unsigned char* res_i, u32 ni, const u64* ext, u64* D, size_t ops, hipStream_t s, bool square = false);
 hipError_t launch_mul_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, bool aux_f64, int pack, bool conv_grid, u32 kneed, const u64* D, u64* out,

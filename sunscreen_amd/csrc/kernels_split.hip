@@ -1497,7 +1497,7 @@ __device__ __forceinline__ void head_fwd(const A& ar, typename A::V (&v)[NC], co
 template <int L, int KMAX, bool AUXD, int PACK, bool HGRID = false>
 __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1)) void mul_head_kernel(const DevCtx* __restrict__ ctx, const MulOp* __restrict__ twf_base,
                                                                 const u64* __restrict__ in0, const u64* __restrict__ in1,
-                                                                u64* __restrict__ ext) {
+                                                                u64* __restrict__ ext, const MemberHead* __restrict__ members, u32 mfirst, u32 mper) {
   using G = EdgeGeom<L>;
   constexpr int NC = G::HEAD_NC;
   constexpr u32 N = 1u << L;
@@ -1506,6 +1506,11 @@ __global__ __launch_bounds__(kHeadThreads, (!AUXD && PACK ? HEAD_MIXED_WAVES : 1
   const u32 K = ctx->K, S = ctx->S, KK = ctx->KK, R = K + S;
   // src / dst: the polynomial's rows; owned coefficients sit at G::head_in(t, k) (inputs) / G::head_out(t, k) (outputs)
   const u64* src = (poly < 2 ? in0 + ((size_t)op * 2 + poly) * K * N : in1 + ((size_t)op * 2 + (poly - 2)) * K * N);
+  if (members) {  // a merged launch of the graph executor: every member's operands where they are (kernels.hpp MemberHead; wave-uniform)
+    const u32 it = mfirst + op, mem = it / mper;
+    const MemberHead mh = members[mem];
+    src = (poly < 2 ? mh.a : mh.b) + ((size_t)(it - mem * mper) * 2 + (poly & 1u)) * K * N;
+  }
   u64* dst = ext + ((size_t)op * 4 + poly) * R * N;
   const BufRsrc rin = buf_rsrc(src), rout = buf_rsrc(dst);  // buffer addressing: see BufRow
   if constexpr (AUXD) {
@@ -2890,32 +2895,32 @@ hipError_t launch_ks_tail(const DevCtx* ctx, const MulOp* twi, u32 logn, int pac
 
 template <int L>
 static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, int pack, u32 kneed, const u64* a, const u64* b, u64* ext,
-                             size_t ops, u32 npolys, hipStream_t s) {
+                             size_t ops, u32 npolys, hipStream_t s, const MemberHead* members, u32 mfirst, u32 mper) {
   const dim3 grid(EdgeGeom<L>::HEAD_THREADS / kHeadThreads, npolys, (unsigned)ops);
   const bool head_grid = (pack & 4) != 0;  // bit 2 of `pack`: DevCtx::conv_grid == 1 (evaluator.cpp), the exact-sum extension
   pack &= 3;
   if (kneed > 4) {  // only the all-FP64 instantiation exists for 5..8 data primes (evaluator.cpp checks)
     if (pack == 2)
-      mul_head_kernel<L, 8, true, 2><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 8, true, 2><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext, members, mfirst, mper);
     else if (pack)
-      mul_head_kernel<L, 8, true, 1><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 8, true, 1><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext, members, mfirst, mper);
     else
-      mul_head_kernel<L, 8, true, 0><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 8, true, 0><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext, members, mfirst, mper);
   } else if (aux_f64) {
     if (pack == 2) return hipErrorInvalidValue;  // per-row packing exists in the 8-prime instantiations (context.cpp)
     if (head_grid) {
       if (pack)
-        mul_head_kernel<L, 4, true, 1, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+        mul_head_kernel<L, 4, true, 1, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext, members, mfirst, mper);
       else
-        mul_head_kernel<L, 4, true, 0, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+        mul_head_kernel<L, 4, true, 0, true><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext, members, mfirst, mper);
     } else if (pack)
-      mul_head_kernel<L, 4, true, 1><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 4, true, 1><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext, members, mfirst, mper);
     else
-      mul_head_kernel<L, 4, true, 0><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+      mul_head_kernel<L, 4, true, 0><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext, members, mfirst, mper);
   } else if (pack) {  // mixed base: integer data primes, FP64 auxiliary primes (DevCtx::aux_mixed)
-    mul_head_kernel<L, 4, false, 1><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+    mul_head_kernel<L, 4, false, 1><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext, members, mfirst, mper);
   } else {
-    mul_head_kernel<L, 4, false, 0><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext);
+    mul_head_kernel<L, 4, false, 0><<<grid, kHeadThreads, 0, s>>>(ctx, twf, a, b, ext, members, mfirst, mper);
   }
   return hipGetLastError();
 }
@@ -2925,8 +2930,9 @@ static hipError_t mul_head_t(const DevCtx* ctx, const MulOp* twf, bool aux_f64, 
 //       WITHOUT aux_f64, non-zero selects the mixed-base instantiation (DevCtx::aux_mixed)
 // npolys: 4 = (a0, a1, b0, b1); 2 = the first operand only (squaring: ext polys 2, 3 stay unwritten and unread)
 hipError_t launch_mul_head(const DevCtx* ctx, const MulOp* twf, u32 logn, bool aux_f64, int pack, u32 kneed, const u64* a, const u64* b, u64* ext,
-                           size_t ops, hipStream_t s, u32 npolys) {
-  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack, kneed, a, b, ext, ops, npolys, s)
+                           size_t ops, hipStream_t s, u32 npolys, const MemberHead* members, u32 first, u32 per) {
+  if (members && !per) return hipErrorInvalidValue;
+  SPLIT_DISPATCH(mul_head_t, ctx, twf, aux_f64, pack, kneed, a, b, ext, ops, npolys, s, members, first, per)
 }
 
 template <int L>

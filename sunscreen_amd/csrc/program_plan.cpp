@@ -1080,6 +1080,10 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
     const char* e = std::getenv("HIPBFV_NO_MEMBER_TAILS");
     return !(e && e[0] == '1');
   }();
+  const bool merge_products = [] {  // HIPBFV_NO_MERGED_PRODUCTS=1: merged product launches below merge_max_batch() only (r03 ... r06 s26)
+    const char* e = std::getenv("HIPBFV_NO_MERGED_PRODUCTS");
+    return !(e && e[0] == '1');
+  }() || small;
   auto side_stream = [&]() -> hipStream_t {
     thread_local hipStream_t streams[16] = {};
     int dev = 0;
@@ -1228,11 +1232,8 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
         auto has_lin = [&](size_t m) { return !st.lin.empty() && st.lin[m].mult != 0; };
         auto tail_launch = [&](size_t m0, size_t m1) -> int {
           const size_t cnt = m1 - m0;
-          const std::vector<int> sa(st.a.begin() + m0, st.a.begin() + m1), sb(st.b.begin() + m0, st.b.begin() + m1);
-          const u64 *A = nullptr, *B2 = nullptr;
-          if (int r = as_array(sa, in_words, &A)) return r;
-          if (!st.square)
-            if (int r = as_array(sb, in_words, &B2)) return r;
+          std::vector<MemberHead> heads(cnt);  // the operands where they are (no gather into one array)
+          for (size_t m = m0; m < m1; m++) heads[m - m0] = MemberHead{sp[st.a[m]], sp[st.square ? st.a[m] : st.b[m]]};
           std::vector<MemberTail> tab(cnt);
           for (size_t m = m0; m < m1; m++) {
             const Plan::LinFold* lf = has_lin(m) ? &st.lin[m] : nullptr;
@@ -1249,21 +1250,21 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
             tab[m - m0] = MemberTail{o, has_other ? sp[lf->other_slot] : nullptr, lf ? (u32)lf->mult : 1u, has_other ? lf->sign : 0};
           }
           const MemberTail* dtab = (const MemberTail*)stage_table(tab.data(), tab.size() * sizeof(MemberTail));
-          if (!dtab) return (int)kOutOfMemory;
+          const MemberHead* dheads = (const MemberHead*)stage_table(heads.data(), heads.size() * sizeof(MemberHead));
+          if (!dtab || !dheads) return (int)kOutOfMemory;
           KeySel sub = relin_key;  // (member-major item numbering: member m0's items start at m0 * batch)
           sub.first = relin_key.first + m0 * batch;
-          int r = ev.multiply_relin(A, st.square ? A : B2, sub, nullptr, cnt * batch, s, nullptr, dtab, (u32)batch);
+          int r = ev.multiply_relin(nullptr, nullptr, sub, nullptr, cnt * batch, s, nullptr, dtab, (u32)batch, dheads, st.square);
           for (size_t m = 0; m < cnt && !r; m++) r = ev.note_result(tab[m].out, 2, (u32)K, batch, s);
           return r;
         };
         const bool tails_on = is_mul && !side_consumer && member_tails;
-        if (tails_on && small && members > 1 && members <= 8 && ev.member_tail_ok(members * batch)) {
-          bool wanted = false;
-          for (size_t m = 0; m < members; m++) wanted = wanted || has_lin(m) || P.slot_direct[st.out[m]] >= 0;
-          if (wanted) {
-            rc = tail_launch(0, members);
-            break;
-          }
+        // With both tables a merged launch costs nothing to set up (operands and results stay where they are), so the ready products
+        // of a round run as ONE launch sequence at every batch size, not only below merge_max_batch(): examples/chi_sq at one GPU's
+        // share of 128 sets runs 384 + 256 + 128 items instead of six launches of 128.
+        if (tails_on && members > 1 && members <= 8 && merge_products && ev.member_tail_ok(members * batch)) {
+          rc = tail_launch(0, members);
+          break;
         }
         if (small && members > 1 && direct_ks) {
           // ONE launch sequence over members x batch ciphertexts

@@ -570,8 +570,9 @@ def test_sums_around_products_ride_in_the_products_last_kernel(name, monkeypatch
     the reference adds node by node (sunscreen_runtime/src/run.rs:130-176: Add / Sub each a SEAL call), modular sums give the same
     bits in any grouping.  Every fold shape (multipliers 2 ... 4, a subtracted addend, an addend made by ANOTHER launch of the same
     round, a product that is itself a program output beside a folded one, no addend) and the shapes that must NOT fold (five copies,
-    a negated product), at a merged batch (2: members x batch items in one launch, per-member destinations) and at an unmerged one
-    (40) -- against the oracle interpreter, the node-by-node executor and the scheduled one with the folds switched off."""
+    a negated product), at batch 2 and batch 40 -- the ready products of a round are ONE launch over members x batch items, operands read
+    and results written where they are (MemberHead / MemberTail tables) -- against the oracle interpreter, the node-by-node executor, the
+    scheduled one with the folds switched off, and the one with a launch per product (HIPBFV_NO_MERGED_PRODUCTS=1)."""
     from sunscreen_amd.batch import to_device, to_host
     from sunscreen_amd.program import FheProgram
 
@@ -613,6 +614,11 @@ def test_sums_around_products_ride_in_the_products_last_kernel(name, monkeypatch
         monkeypatch.setenv("HIPBFV_NO_MEMBER_TAILS", "1")
         plain = [to_host(t_) for t_ in p.run(ev, dev, rkd, gkd)]
         monkeypatch.delenv("HIPBFV_NO_MEMBER_TAILS", raising=False)
+        monkeypatch.setenv("HIPBFV_NO_MERGED_PRODUCTS", "1")  # batch 40: every product a launch of its own, its sum in its last kernel
+        apart = [to_host(t_) for t_ in p.run(ev, dev, rkd, gkd)]
+        monkeypatch.delenv("HIPBFV_NO_MERGED_PRODUCTS", raising=False)
+        for k in range(len(got)):
+            assert (got[k] == apart[k]).all(), (name, batch, k)
         monkeypatch.setenv("HIPBFV_PROGRAM_SERIAL", "1")
         serial = [to_host(t_) for t_ in p.run(ev, dev, rkd, gkd)]
         monkeypatch.delenv("HIPBFV_PROGRAM_SERIAL", raising=False)
