@@ -202,15 +202,15 @@ def test_program_run_with_one_key_set_per_input_set():
             dot = int((va[i].astype(np.int64) * vb[i].astype(np.int64)).sum()) % o.t
             assert (o.batch_decode(o.decrypt(out[i], ten[int(k)]["sk"])) == dot).all()
     # chi_sq (examples/chi_sq/src/main.rs:59-88): several multiply+relinearize members per round -> merged launches
+    # (r06 s27: merged at every batch size -- 40 input sets: 3 x 40 and 2 x 40 items per launch, the key of item m * 40 + j is input set j's)
     prog = chi_sq_optimized()
-    batch = 5
-    key_index = np.array([4, 7, 0, 4, 2], dtype=np.uint32)
-    cts = [_enc(o, ten, key_index, rng, hi=7)[1] for _ in range(3)]
-    outs = [to_host(t) for t in prog.run(ev, [to_device(c) for c in cts], rks, None, key_index=key_index)]
-    for i, k in enumerate(key_index):
-        ref = run_program(o, prog.nodes, prog.edges, [c[i] for c in cts], ten[int(k)]["rk"])
-        for j in range(4):
-            assert (outs[j][i] == ref[j]).all(), (i, j)
+    for key_index in (np.array([4, 7, 0, 4, 2], dtype=np.uint32), rng.integers(0, 8, 40).astype(np.uint32)):
+        cts = [_enc(o, ten, key_index, rng, hi=7)[1] for _ in range(3)]
+        outs = [to_host(t) for t in prog.run(ev, [to_device(c) for c in cts], rks, None, key_index=key_index)]
+        for i, k in enumerate(key_index):  # every input set against the oracle under ITS client's keys
+            ref = run_program(o, prog.nodes, prog.edges, [c[i] for c in cts], ten[int(k)]["rk"])
+            for j in range(4):
+                assert (outs[j][i] == ref[j]).all(), (len(key_index), i, j)
 
 
 def test_per_key_argument_errors():
