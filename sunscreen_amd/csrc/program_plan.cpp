@@ -1262,7 +1262,7 @@ int Program::run_plan(Evaluator& ev, size_t batch, const ProgramInput* inputs, s
         // With both tables a merged launch costs nothing to set up (operands and results stay where they are), so the ready products
         // of a round run as ONE launch sequence at every batch size, not only below merge_max_batch(): examples/chi_sq at one GPU's
         // share of 128 sets runs 384 + 256 + 128 items instead of six launches of 128.
-        if (tails_on && members > 1 && members <= 8 && merge_products && ev.member_tail_ok(members * batch)) {
+        if (tails_on && members > 1 && members <= 64 && merge_products && ev.member_tail_ok(members * batch)) {
           rc = tail_launch(0, members);
           break;
         }

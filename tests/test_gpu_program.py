@@ -631,3 +631,42 @@ def test_sums_around_products_ride_in_the_products_last_kernel(name, monkeypatch
         a, b, c = (vals[j][0].astype(np.int64) for j in range(3))
         assert (o.batch_decode(o.decrypt(got[0][0], sk)) == (3 * a * b - c) % o.t).all()
         assert (o.batch_decode(o.decrypt(got[2][0], sk)) == (4 * b * c - a * a) % o.t).all()
+
+
+def test_a_dozen_ready_products_in_one_launch_sequence(monkeypatch):
+    """A round of twelve products (a dot product written out term by term, the shape a compiler emits without SIMD packing): one launch
+    sequence over 12 x batch items through the operand / destination tables, the pairwise sums behind them folded where the pattern
+    allows (x_i y_i + x_j y_j: one product folds, reading the other's result from ANOTHER group only -- here all are in one group, so
+    none folds and the sum runs as one n-ary launch).  Against the oracle interpreter and the launch-per-product executor."""
+    from sunscreen_amd.batch import to_device, to_host
+    from sunscreen_amd.program import FheProgram
+
+    o, sk, pk, rk, gk, ev, rkd, gkd = _ctx("default_4096_16")
+    p = FheProgram()
+    xs = [p.append_input_ciphertext(i) for i in range(12)]
+    ys = [p.append_input_ciphertext(12 + i) for i in range(12)]
+    prods = [p.append_relinearize(p.append_multiply(a, b)) for a, b in zip(xs, ys)]
+    acc = prods[0]
+    for t in prods[1:]:
+        acc = p.append_add(acc, t)
+    p.append_output_ciphertext(acc)
+    p.append_output_ciphertext(p.append_add(prods[3], prods[3]))  # (prods[3] has two users: it exists on its own)
+    desc = p.describe()
+    assert desc[0] == "mul_relin members=12", desc
+    rng = np.random.default_rng(12)
+    for batch in (3, 40):
+        vals = rng.integers(0, 9, (24, batch, o.n)).astype(np.uint64)
+        cts = [np.stack([o.encrypt(pk, o.batch_encode(v)) for v in vals[a]]) for a in range(24)]
+        dev = [to_device(c) for c in cts]
+        monkeypatch.delenv("HIPBFV_NO_MERGED_PRODUCTS", raising=False)
+        got = [to_host(t) for t in p.run(ev, dev, rkd, gkd)]
+        monkeypatch.setenv("HIPBFV_NO_MERGED_PRODUCTS", "1")
+        apart = [to_host(t) for t in p.run(ev, dev, rkd, gkd)]
+        monkeypatch.delenv("HIPBFV_NO_MERGED_PRODUCTS", raising=False)
+        for k in range(2):
+            assert (got[k] == apart[k]).all(), (batch, k)
+        ref = run_program(o, p.nodes, p.edges, [c[0] for c in cts], rk, gk)
+        for k in range(2):
+            assert (got[k][0] == ref[k]).all(), (batch, k)
+        dot = (vals[:12, 0].astype(np.int64) * vals[12:, 0].astype(np.int64)).sum(axis=0)
+        assert (o.batch_decode(o.decrypt(got[0][0], sk)) == dot % o.t).all()
