@@ -11,7 +11,7 @@ reference's example programs.  The default run times all of them in one process:
 `secondary` object carries the n=16384 mul+relin (batch/4 pairs, SEAL default K=8+1), the configs[1] transform workload
 (forward+inverse NTT, n=8192, 3 primes), the north star's literal prime set (n=8192, 3 x 54-bit + special prime), and -- on one
 GPU -- examples/chi_sq at n=16384 (the 1024-input batch of configs[3] and one GPU's 128-set share of it), examples/dot_prod
-(256 sets) and examples/pir over 2^17 entries (512 x 256, 128 GiB in transform form), each with its own value, ms_per_step,
+(256 sets) and examples/pir over 2^17 entries (128 rows x 1024 columns: one GPU's rows of the 1024 x 1024 database, 128 GiB in transform form), each with its own value, ms_per_step,
 repeats, roofline, cpu_baseline and parity gate (64 items / 8 input sets against the oracle), measured with the same --steps /
 --warmup / --repeats (`--no-secondary` drops them; the NTT workload times at least 100 of its 0.7 ms steps per region; the whole
 default run takes 2-3 minutes).  `--workload ntt|chi_sq|dot_prod|pir|e2e` run one workload alone (same JSON contract).
@@ -972,7 +972,10 @@ def main():
                 ("chi_sq_n16384", dict(workload="chi_sq", n=16384, batch=q4)),                       # configs[3]: the 1024-input batch
                 ("chi_sq_n16384_share128", dict(workload="chi_sq", n=16384, batch=max(q4 // 8, 1), no_cpu=True)),  # ... one GPU's share of it on 8
                 ("dot_prod_n16384", dict(workload="dot_prod", n=16384, batch=max(q4 // 4, 1))),
-                ("pir_n16384_2p17", dict(workload="pir", n=16384, batch=max(q4 // 4, 1), pir_rows=max(q4 // 2, 1))),  # 512 x 256 = 2^17 entries, 128 GiB
+                # configs[4]: DB = 2^20 entries = a 1024 x 1024 database (the example's database is square) sharded by row over 8 GPUs: ONE GPU's
+                # share is 128 rows x 1024 columns = 2^17 entries, 128 GiB -- exactly what `--workload pir --n 16384 --batch 1024 --gpus 8` gives rank r
+                # (r01 ... r06 s30 ran 512 x 256 here: the same entries, four times the row-side multiplies a shard of the real database has)
+                ("pir_n16384_2p17", dict(workload="pir", n=16384, batch=q4, pir_rows=max(q4 // 8, 1))),
             ]
         failed = False
         for key, over in jobs:
@@ -984,7 +987,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             if sub.workload == "pir":
-                # the database alone is rows x cols x K x n words in transform form (128 GiB for 512 x 256 at n = 16384): on a device
+                # the database alone is rows x cols x K x n words in transform form (128 GiB for 128 x 1024 at n = 16384): on a device
                 # that does not have that much free, say so instead of running out of memory with the headline unprinted
                 from oracle import bfv_oracle as O_
 

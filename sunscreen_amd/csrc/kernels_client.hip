@@ -441,10 +441,28 @@ __device__ __forceinline__ void pir_dot_body(const DevMod& dm, u32 cols, const Q
 // at about the same time, and each XCD's L2 serves them after the first.  With the coefficient ranges on x (the r01-r03 order) the
 // resident workgroups cover all coefficients of 8 row blocks, and every row block re-reads the whole transformed query: at
 // n = 16384 that is 512 MiB per 4 rows -- 64 GiB beside the 128 GiB database, and more than the 256 MB Infinity Cache holds.
-struct PirGrid {  // row blocks on x
-  static __device__ __forceinline__ u32 rowblock() { return blockIdx.x; }
-  static __device__ __forceinline__ u32 xblock() { return blockIdx.y; }
-  static __device__ __forceinline__ u32 residue() { return blockIdx.z; }
+// r06 s31: ... and all row blocks of ONE slice on ONE XCD.  Workgroups go to the 8 XCDs round robin in dispatch order, so with the row
+// blocks merely x-fastest a slice's row blocks were spread over all eight L2s: every XCD fetched the slice's query words from HBM, and
+// with few row blocks (one GPU's share of a 1024 x 1024 database is 128 rows: 32 row blocks, four per XCD) the few that shared an L2
+// drifted apart -- the 128 x 1024 product ran at 5.2 TB/s against 6.0 for 512 x 256.  Now dispatch index d = 8 q + xcd is mapped to
+// row block q % RB of slice (q / RB) * 8 + xcd: an XCD walks its own slices, each slice's row blocks back to back on that XCD.
+#ifndef PIR_XCD_SLICES
+#define PIR_XCD_SLICES 1  // (experiment hook: 0 = the x-fastest order of r04 ... r06 s30)
+#endif
+struct PirGrid {
+  u32 rb, xb, res;
+  __device__ __forceinline__ PirGrid() {
+    const u32 RB = gridDim.x, XB = gridDim.y, S = XB * gridDim.z;
+    rb = blockIdx.x, xb = blockIdx.y, res = blockIdx.z;
+    if (PIR_XCD_SLICES && (S & 7u) == 0u) {  // (wave-uniform; otherwise the plain x-fastest order)
+      const u32 d = blockIdx.x + RB * (blockIdx.y + XB * blockIdx.z);
+      const u32 q = d >> 3, sl = (q / RB) * 8u + (d & 7u);
+      rb = q % RB, xb = sl % XB, res = sl / XB;
+    }
+  }
+  __device__ __forceinline__ u32 rowblock() const { return rb; }
+  __device__ __forceinline__ u32 xblock() const { return xb; }
+  __device__ __forceinline__ u32 residue() const { return res; }
   static dim3 grid(u32 xblocks, u32 K, u32 rowblocks) { return dim3(rowblocks, xblocks, K); }
 };
 
@@ -452,8 +470,9 @@ template <int RT>
 __global__ __launch_bounds__(kClientThreads) void dot_plain2_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 cols,
                                                                     const u64* __restrict__ pntt, u32 rows, u64* __restrict__ acc) {
   const u32 n = ctx->n, K = ctx->K;
-  const u32 x = 2 * (PirGrid::xblock() * kClientThreads + threadIdx.x);
-  const u32 i = PirGrid::residue(), r0 = PirGrid::rowblock() * RT;
+  const PirGrid pg;
+  const u32 x = 2 * (pg.xblock() * kClientThreads + threadIdx.x);
+  const u32 i = pg.residue(), r0 = pg.rowblock() * RT;
   if (x >= n) return;
   const DevMod& dm = ctx->mod[i];
   const size_t in_row = (size_t)i * n + x;
@@ -492,8 +511,9 @@ template <int RT>
 __global__ __launch_bounds__(kClientThreads) void dot_plain_tab_kernel(const DevCtx* __restrict__ ctx, const u64* __restrict__ ctn, u32 cols,
                                                                        const PlainNttRef* __restrict__ tab, u32 rows, u32 batch, u64* __restrict__ acc) {
   const u32 n = ctx->n, K = ctx->K;
-  const u32 x = 2 * (PirGrid::xblock() * kClientThreads + threadIdx.x);
-  const u32 i = PirGrid::residue(), r0 = (PirGrid::rowblock() / batch) * RT, b = PirGrid::rowblock() % batch;
+  const PirGrid pg;
+  const u32 x = 2 * (pg.xblock() * kClientThreads + threadIdx.x);
+  const u32 i = pg.residue(), r0 = (pg.rowblock() / batch) * RT, b = pg.rowblock() % batch;
   if (x >= n) return;
   const DevMod& dm = ctx->mod[i];
   const size_t in_row = (size_t)i * n + x;

@@ -22,6 +22,6 @@ run chi_sq_n16384 --workload chi_sq --n 16384 --batch 256 --steps 3 --warmup 1
 run dot_prod_n16384 --workload dot_prod --n 16384 --batch 256 --steps 3 --warmup 1
 run e2e_n8192 --workload e2e --batch 2048 --steps 5 --warmup 2
 run pir_n8192 --workload pir --batch 256 --steps 5 --warmup 1
-run pir_n16384 --workload pir --n 16384 --batch 256 --steps 3 --warmup 1
+run pir_n16384 --workload pir --n 16384 --batch 1024 --pir-rows 128 --steps 3 --warmup 1
 timeout 300 python tools/latency.py > $OUT/latency_n8192.json 2>$OUT/latency.err
 fi

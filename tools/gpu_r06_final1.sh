@@ -14,7 +14,7 @@ bash tools/gpu_pmc_report.sh $T ntt_n8192 --workload ntt > /dev/null 2>&1
 bash tools/gpu_pmc_report.sh $T mulrelin_n8192_bits54-54-54-56 --coeff-bits 54,54,54,56 > /dev/null 2>&1
 bash tools/gpu_pmc_report.sh $T chi_sq_n16384 --workload chi_sq --n 16384 --batch 256 --steps 3 --warmup 1 > /dev/null 2>&1
 bash tools/gpu_pmc_report.sh $T dot_prod_n16384 --workload dot_prod --n 16384 --batch 256 --steps 3 --warmup 1 > /dev/null 2>&1
-bash tools/gpu_pmc_report.sh $T pir_n16384 --workload pir --n 16384 --batch 256 --pir-rows 512 --steps 3 --warmup 1 > /dev/null 2>&1
+bash tools/gpu_pmc_report.sh $T pir_n16384 --workload pir --n 16384 --batch 1024 --pir-rows 128 --steps 3 --warmup 1 > /dev/null 2>&1
 bash tools/gpu_pmc_report.sh $T mulrelin_n8192_keys4096 --keys 4096 > /dev/null 2>&1
 bash tools/gpu_pmc_report.sh $T mulrelin_n16384_keys1024 --n 16384 --batch 1024 --keys 1024 > /dev/null 2>&1
 bash tools/gpu_pmc_stall.sh $T mulrelin_n8192 > /dev/null 2>&1
