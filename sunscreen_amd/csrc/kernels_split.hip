@@ -866,6 +866,9 @@ __device__ __forceinline__ void st_tail_out(const BufRow& row, u32 t, int k, u64
   buf_st64<false>(row.r, X::tail_out_lane(t, k) * 8u, row.soff + X::tail_uni(k) * 8u, v);
 }
 
+#ifndef KS_XCD_ROWS
+#define KS_XCD_ROWS 1  // (experiment hook: 0 = the x-fastest order of the rotation head / tail, r06 s3 ... s31)
+#endif
 // coefficient j of sigma_g(p) mod q, p a canonical residue row at byte offset soff of the descriptor: +- p[j * g^-1 mod 2N]
 template <int L>
 __device__ __forceinline__ u64 galois_gather(BufRsrc r, u32 soff, u32 j, u32 ginv, u64 q) {
@@ -914,8 +917,20 @@ __global__ __launch_bounds__(kHeadThreads) void ks_head_kernel(const DevCtx* __r
   using G = EdgeGeom<L>;
   constexpr int NC = G::HEAD_NC;
   constexpr u32 N = 1u << L;
-  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
-  const u32 J = blockIdx.y, op = blockIdx.z;
+  u32 bx = blockIdx.x, J = blockIdx.y, op = blockIdx.z;
+  if (KS_XCD_ROWS && ginv) {
+    // r06 s32: a rotation's head GATHERS its digit row through the automorphism -- every workgroup of a row touches lines all over the
+    // row.  Workgroups go to the 8 XCDs round robin in dispatch order (x fastest), so the TB workgroups of one row landed on TB different
+    // XCDs and every one of their L2s fetched the row from HBM: 4.9 MB read per item at N = 16384 where 1.05 MB is compulsory
+    // (profiles/r06_final_dot_prod_n16384_pmc_fetch.txt).  Dispatch index 8q + xcd -> workgroup q mod TB of row 8 (q / TB) + xcd: a row's
+    // workgroups run back to back on ONE XCD.  (Wave-uniform; rows not a multiple of 8: the plain order.)
+    const u32 TB = gridDim.x, R = gridDim.y * gridDim.z;
+    if ((R & 7u) == 0u) {
+      const u32 d = blockIdx.x + TB * (blockIdx.y + gridDim.y * blockIdx.z), q = d >> 3, row = (q / TB) * 8u + (d & 7u);
+      bx = q % TB, J = row % gridDim.y, op = row / gridDim.y;
+    }
+  }
+  const u32 t = bx * kHeadThreads + threadIdx.x;
   const u32 K = ctx->K, KK = ctx->KK;
   const u64* src = target + (size_t)op * tstride + (size_t)J * N;
   const BufRsrc rout = buf_rsrc(T + (size_t)op * KK * K * N);  // buffer addressing: see BufRow
@@ -1305,8 +1320,15 @@ __global__ __launch_bounds__(kHeadThreads) void ks_tail_kernel(const DevCtx* __r
                                                                u32 base_mask, const u64* __restrict__ extra, u64* __restrict__ out, u32 ginv) {
   using G = EdgeGeom<L>;
   constexpr u32 N = 1u << L;
-  const u32 t = blockIdx.x * kHeadThreads + threadIdx.x;
-  const u32 c = blockIdx.y, op = blockIdx.z;
+  u32 bx = blockIdx.x, c = blockIdx.y, op = blockIdx.z;
+  if (KS_XCD_ROWS && ginv) {  // a rotation's tail gathers sigma_g(c0): the workgroups of one (polynomial, item) on one XCD (ks_head_kernel)
+    const u32 TB = gridDim.x, R = gridDim.y * gridDim.z;
+    if ((R & 7u) == 0u) {
+      const u32 d = blockIdx.x + TB * (blockIdx.y + gridDim.y * blockIdx.z), q = d >> 3, row = (q / TB) * 8u + (d & 7u);
+      bx = q % TB, c = row % gridDim.y, op = row / gridDim.y;
+    }
+  }
+  const u32 t = bx * kHeadThreads + threadIdx.x;
   const u32 K = ctx->K, KK = ctx->KK;
   const double* acc = ACC + ((size_t)op * 2 + c) * KK * N;
   // special prime first
