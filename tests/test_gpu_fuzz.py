@@ -100,7 +100,13 @@ def test_every_operation_on_random_parameter_sets(n, bits, tbits):
             assert (enc[i] == o.batch_encode(vals[i])).all()
 
 
-@pytest.mark.parametrize("seed", range(16))
+def _graph_seeds():
+    # HIPBFV_FUZZ_GRAPH_SEEDS="lo:hi": extended campaigns of random graphs (profiles/r06_s36_*); the default is the suite's own 16
+    lo, hi = (int(x) for x in os.environ.get("HIPBFV_FUZZ_GRAPH_SEEDS", "0:16").split(":"))
+    return range(lo, hi)
+
+
+@pytest.mark.parametrize("seed", _graph_seeds())
 def test_random_program_graphs(seed, monkeypatch):
     """Random FheProgram DAGs (every ciphertext node kind the compiler emits, run.rs:160-341) through the batch graph
     executor vs the oracle interpreter, bit for bit: exercises operand lifetime / buffer recycling, the fused
