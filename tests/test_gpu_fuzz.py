@@ -119,11 +119,12 @@ def test_random_program_graphs(seed, monkeypatch):
     from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
     from sunscreen_amd.program import FheProgram
 
-    n = 4096
-    primes, t = O.bfv_default(n), O.plain_batching(n, 16)
+    n = int(os.environ.get("HIPBFV_FUZZ_GRAPH_N", "4096"))  # campaigns at the larger split geometries: 8192, 16384 (per-row packed rows)
+    primes, t = O.bfv_default(n), O.plain_batching(n, 16 if n == 4096 else 20)
     o = O.Oracle(n, primes, t)
     O.seed(1000 + seed)
-    elts = sorted({o.galois_elt_from_step(1 << i) for i in range(11)} | {o.galois_elt_from_step(-(1 << i)) for i in range(11)} | {2 * n - 1})
+    nb = (n // 2).bit_length() - 1  # steps below n/2 from power-of-two keys: 11 at n = 4096
+    elts = sorted({o.galois_elt_from_step(1 << i) for i in range(nb)} | {o.galois_elt_from_step(-(1 << i)) for i in range(nb)} | {2 * n - 1})
     sk, pk, rk, gk = o.keygen(galois_elts=elts)
     ctx = Context.from_raw(n, primes, t)
     ev = BatchEvaluator(ctx)
