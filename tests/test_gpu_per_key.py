@@ -5,6 +5,8 @@ runtime.rs:310-327), so a server that batches the calls of many clients holds on
 calls libhipbfv.so through the C ABI (hipbfv_batch_*_keys, hipbfv_Program_RunKeys) with SEVERAL key sets in one call
 and checks every item bit for bit against the CPU oracle run with that item's own keys.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -114,6 +116,58 @@ def test_per_key_call_with_one_key_equals_the_single_key_call():
     assert torch.equal(single, perkey)
     odd = torch.arange(count, device=mixed.device) % 2 == 1
     assert torch.equal(mixed[odd], single[odd]) and torch.equal(mixed[~odd], single1[~odd])
+
+
+def _shape_trials():
+    # HIPBFV_FUZZ_PERKEY_TRIALS="lo:hi": extended campaigns (profiles/r06_s38_*); the suite's own are 0:6
+    lo, hi = (int(x) for x in os.environ.get("HIPBFV_FUZZ_PERKEY_TRIALS", "0:6").split(":"))
+    return range(lo, hi)
+
+
+@pytest.mark.parametrize("trial", _shape_trials())
+def test_per_key_random_shapes(trial):
+    """Random tenant counts, batch sizes, chunk sizes and key assignments (runs of one key, every eighth item, unused key sets,
+    counts that are no multiple of 8: the per-XCD walk of the key-switch kernels): every item of the per-key calls equals the
+    single-key call with that item's key word for word, and two items per trial equal the oracle."""
+    import torch
+    from sunscreen_amd.batch import to_device, to_host
+
+    rng = np.random.default_rng(9000 + trial)
+    name = ("default_4096_16", "default_8192_17", "default_4096_16", "default_16384_17")[trial % 4]
+    ntenants = int(rng.integers(1, 4 if "16384" in name else 10))
+    count = int(rng.integers(1, 24 if "16384" in name else 90))
+    o, ctx, ev, ten = _tenants(name, ntenants, seed=300 + trial)
+    chunk = int(rng.choice([0, 0, 3, 8, 17]))
+    if chunk:
+        ev.set_chunk_ops(chunk)
+    kind = trial % 3
+    if kind == 0:
+        key_index = rng.integers(0, ntenants, count)
+    elif kind == 1:
+        key_index = np.sort(rng.integers(0, ntenants, count))  # runs of one key
+    else:
+        key_index = np.arange(count) % ntenants  # neighbours never share a key
+    key_index = key_index.astype(np.uint32)
+    n, primes = o.n, params(name)[1]
+    K = o.K
+    a = np.stack([rng.integers(0, pr, (count, 2, n), dtype=np.uint64) for pr in primes[:K]], axis=2)
+    b = np.stack([rng.integers(0, pr, (count, 2, n), dtype=np.uint64) for pr in primes[:K]], axis=2)
+    da, db = to_device(a), to_device(b)
+    sets = [x["rkd"] for x in ten]
+    fused = ev.multiply_relin_keys(da, db, sets, key_index)
+    relin = ev.relinearize_keys(ev.multiply(da, db), sets, key_index)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, relin), (trial, name, ntenants, count, chunk)
+    ki = torch.from_numpy(key_index.astype(np.int64)).to(fused.device)
+    for k in range(ntenants):
+        sel = ki == k
+        if not bool(sel.any()):
+            continue
+        single = ev.multiply_relin(da[sel].contiguous(), db[sel].contiguous(), sets[k])
+        assert torch.equal(fused[sel], single), (trial, name, ntenants, count, chunk, k)
+    got = to_host(fused)
+    for i in {0, count - 1}:
+        assert (got[i] == o.relinearize(o.multiply(a[i], b[i]), ten[int(key_index[i])]["rk"])).all(), (trial, name, i)
 
 
 def test_per_key_small_batches_take_the_whole_polynomial_pipeline():
