@@ -193,3 +193,46 @@ def test_random_program_graphs(seed, monkeypatch):
     serial = [to_host(g) for g in q.run(ev, [to_device(x) for x in ins] + [to_device(shared), to_device(per_item)], rkd, gkd)]
     for k in range(len(got)):
         assert (serial[k] == got[k]).all(), (seed, k, q.describe())
+
+
+def _rotation_trials():
+    # HIPBFV_FUZZ_ROT_TRIALS="lo:hi": extended campaigns (profiles/r06_s40_*); the suite's own are 0:6
+    lo, hi = (int(x) for x in os.environ.get("HIPBFV_FUZZ_ROT_TRIALS", "0:6").split(":"))
+    return range(lo, hi)
+
+
+@pytest.mark.parametrize("trial", _rotation_trials())
+def test_rotations_at_random_batch_sizes(trial):
+    """The rotation head / tail order their workgroups row by row per XCD when the row count is a multiple of 8 and in the plain
+    order otherwise (kernels_split.hip: KS_XCD_ROWS): batches of random size -- each item of the batched rotate_rows / rotate_columns
+    equals the same call on that item alone (one item: the plain order) word for word, and two items equal the oracle."""
+    import torch
+    from sunscreen_amd import Context, GaloisKeys
+    from sunscreen_amd.batch import BatchEvaluator, to_device, to_host
+
+    rng = np.random.default_rng(40000 + trial)
+    n = (4096, 8192, 16384)[trial % 3]
+    primes, t = O.bfv_default(n), O.plain_batching(n, 20)
+    o = O.Oracle(n, primes, t)
+    O.seed(700 + trial)
+    step_pow2 = (1 << int(rng.integers(0, (n // 2).bit_length() - 1)))
+    elts = sorted({o.galois_elt_from_step(step_pow2), 2 * n - 1})
+    sk, pk, rk, gk = o.keygen(galois_elts=elts)
+    ctx = Context.from_raw(n, primes, t)
+    ev = BatchEvaluator(ctx)
+    gkd = GaloisKeys.from_arrays(ctx, gk)
+    count = int(rng.integers(1, 30 if n == 16384 else 70))
+    K = o.K
+    a = np.stack([rng.integers(0, pr, (count, 2, n), dtype=np.uint64) for pr in primes[:K]], axis=2)
+    da = to_device(a)
+    rows = ev.rotate_rows(da, step_pow2, gkd)
+    cols = ev.rotate_columns(da, gkd)
+    torch.cuda.synchronize()
+    for i in sorted({0, count - 1, int(rng.integers(0, count)), int(rng.integers(0, count))}):
+        one = da[i:i + 1].contiguous()
+        assert torch.equal(ev.rotate_rows(one, step_pow2, gkd)[0], rows[i]), (trial, n, count, i)
+        assert torch.equal(ev.rotate_columns(one, gkd)[0], cols[i]), (trial, n, count, i)
+    hr, hc = to_host(rows), to_host(cols)
+    for i in {0, count - 1}:
+        assert (hr[i] == o.rotate_rows(a[i], step_pow2, gk)).all(), (trial, n, count, i)
+        assert (hc[i] == o.rotate_columns(a[i], gk)).all(), (trial, n, count, i)
